@@ -1,0 +1,126 @@
+"""ctypes binding of the C ABI declared in ``include/pplie.h`` (lib/libpplie.so).
+
+The library is pure HIP behind ``extern "C"`` entry points: plain pointers, row counts and a
+``hipStream_t``; it never allocates, frees or synchronises.  PyTorch is used here only as the
+owner of device memory and streams (``tensor.data_ptr()``, ``current_stream().cuda_stream``).
+
+There is **no CPU fallback**: if the shared library is missing, or a tensor is not on a HIP
+device, the call raises.  (Tests that exercise host-side logic without a GPU install their own
+backend through :func:`set_backend_for_testing`; the product never does.)
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from pathlib import Path
+
+import torch
+
+_LIB_PATH = Path(__file__).resolve().parent / "lib" / "libpplie.so"
+
+_ERRORS = {-1: "bad argument (negative row count or null pointer)", -2: "kernel launch failed (hipGetLastError)"}
+
+_ROW_SIG = [ctypes.c_void_p] * 5 + [ctypes.c_int64, ctypes.c_void_p]
+
+
+class HipLibrary:
+    """Lazy handle on libpplie.so."""
+
+    def __init__(self, path: Path = _LIB_PATH):
+        self.path = Path(path)
+        self._cdll = None
+        self._fns = {}
+
+    @property
+    def cdll(self):
+        if self._cdll is None:
+            if not self.path.exists():
+                raise ImportError(
+                    f"pypose_amd: HIP library {self.path} not found. Build it with "
+                    f"`python -m pypose_amd.build` (needs hipcc, gfx950 cross-compiles without a GPU). "
+                    f"There is no CPU fallback.")
+            # torch must already be imported so that libamdhip64.so.7 resolves to the runtime
+            # PyTorch itself uses (one HIP runtime per process: streams/pointers are shared).
+            self._cdll = ctypes.CDLL(str(self.path), mode=os.RTLD_NOW | os.RTLD_LOCAL)
+        return self._cdll
+
+    def symbol(self, name: str, argtypes=None):
+        fn = self._fns.get(name)
+        if fn is None:
+            try:
+                fn = getattr(self.cdll, name)
+            except AttributeError as e:
+                raise AttributeError(f"pypose_amd: symbol {name} missing from {self.path}") from e
+            fn.argtypes = _ROW_SIG if argtypes is None else argtypes
+            fn.restype = ctypes.c_int
+            self._fns[name] = fn
+        return fn
+
+    def has(self, name: str) -> bool:
+        try:
+            getattr(self.cdll, name)
+            return True
+        except AttributeError:
+            return False
+
+
+_lib = HipLibrary()
+_SUFFIX = {torch.float32: "_f32", torch.float64: "_f64"}
+_test_backend = None
+
+
+def library() -> HipLibrary:
+    return _lib
+
+
+def set_backend_for_testing(backend):
+    """Install a stand-in for the HIP row-op launcher (tests only; ``None`` restores HIP).
+
+    ``backend(name, ins, out_widths) -> tuple[Tensor, ...]`` with ``name`` like ``"se3_exp_fwd"``.
+    """
+    global _test_backend
+    _test_backend = backend
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def check(code: int, what: str):
+    if code != 0:
+        raise RuntimeError(f"pypose_amd: {what} failed: {_ERRORS.get(code, code)}")
+
+
+def stream_ptr(device) -> ctypes.c_void_p:
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def row_op(name: str, ins, out_widths):
+    """Launch ``pplie_<name>_{f32,f64}`` on contiguous ``[N, W]`` inputs.
+
+    ins: 1-3 tensors, same dtype/device, same N, contiguous. out_widths: 1-2 ints.
+    Returns a tuple of freshly allocated ``[N, W_out]`` tensors.
+    """
+    if _test_backend is not None:
+        return _test_backend(name, ins, out_widths)
+    x0 = ins[0]
+    if not x0.is_cuda:
+        raise RuntimeError(
+            f"pypose_amd: op {name} needs tensors on a HIP device (got {x0.device}); there is no CPU path.")
+    suffix = _SUFFIX.get(x0.dtype)
+    if suffix is None:
+        raise TypeError(f"pypose_amd: op {name} supports float32/float64, got {x0.dtype}")
+    n = x0.shape[0]
+    for t in ins:
+        if t.dtype != x0.dtype or t.device != x0.device or t.shape[0] != n or t.dim() != 2 or not t.is_contiguous():
+            raise ValueError(f"pypose_amd: op {name}: inputs must be contiguous [N,W], same N/dtype/device")
+    outs = tuple(torch.empty((n, w), dtype=x0.dtype, device=x0.device) for w in out_widths)
+    if n == 0:
+        return outs
+    fn = _lib.symbol("pplie_" + name + suffix)
+    pi = [_ptr(t) for t in ins] + [ctypes.c_void_p(0)] * (3 - len(ins))
+    po = [_ptr(t) for t in outs] + [ctypes.c_void_p(0)] * (2 - len(outs))
+    with torch.cuda.device(x0.device):
+        code = fn(*pi, *po, ctypes.c_int64(n), stream_ptr(x0.device))
+    check(code, "pplie_" + name + suffix)
+    return outs

@@ -1,0 +1,84 @@
+"""Build the HIP library (gfx950) in-tree: pypose_amd/lib/libpplie.so.
+
+hipcc cross-compiles without a GPU, so this runs in the build container; the resulting .so
+travels to the GPU box with the repo snapshot (it is git-ignored, not gpurun-ignored).
+
+    python -m pypose_amd.build [--force] [-j N]
+"""
+from __future__ import annotations
+
+import argparse
+import hashlib
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+from pathlib import Path
+
+PKG = Path(__file__).resolve().parent
+CSRC = PKG / "csrc"
+LIBDIR = PKG / "lib"
+OBJDIR = PKG / "build"
+LIBNAME = "libpplie.so"
+ARCH = "gfx950"
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+CFLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc",
+          f"-I{CSRC}", f"-I{PKG.parent / 'include'}"]
+
+
+def _sources():
+    return sorted(CSRC.glob("*.hip"))
+
+
+def _digest(src: Path) -> str:
+    h = hashlib.sha1()
+    h.update(" ".join(CFLAGS).encode())
+    for p in [src, *sorted(CSRC.glob("*.h")), *sorted((PKG.parent / "include").glob("*.h"))]:
+        h.update(p.read_bytes())
+    return h.hexdigest()
+
+
+def _compile(src: Path, force: bool) -> Path:
+    obj = OBJDIR / (src.stem + ".o")
+    stamp = OBJDIR / (src.stem + ".sha1")
+    dig = _digest(src)
+    if not force and obj.exists() and stamp.exists() and stamp.read_text() == dig:
+        return obj
+    cmd = [HIPCC, *CFLAGS, "-c", str(src), "-o", str(obj)]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc failed on {src.name}:\n{r.stdout}\n{r.stderr}")
+    stamp.write_text(dig)
+    return obj
+
+
+def build(force: bool = False, jobs: int | None = None, verbose: bool = True) -> Path:
+    """Compile every csrc/*.hip for gfx950 and link lib/libpplie.so. Returns the .so path."""
+    OBJDIR.mkdir(exist_ok=True)
+    LIBDIR.mkdir(exist_ok=True)
+    srcs = _sources()
+    jobs = jobs or min(len(srcs), os.cpu_count() or 4)
+    with ThreadPoolExecutor(max_workers=jobs) as ex:
+        objs = list(ex.map(lambda s: _compile(s, force), srcs))
+    out = LIBDIR / LIBNAME
+    newest = max(o.stat().st_mtime for o in objs)
+    if force or not out.exists() or out.stat().st_mtime < newest:
+        cmd = [HIPCC, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", str(out), *map(str, objs)]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    if verbose:
+        print(f"[pypose_amd.build] {out} ({out.stat().st_size >> 10} KiB, {len(objs)} objects)")
+    return out
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--force", action="store_true")
+    ap.add_argument("-j", type=int, default=None)
+    a = ap.parse_args()
+    try:
+        build(force=a.force, jobs=a.j)
+    except RuntimeError as e:
+        print(e, file=sys.stderr)
+        sys.exit(1)

@@ -1,0 +1,862 @@
+// lie_math.h -- per-row Lie-group arithmetic shared by every HIP kernel in this library.
+//
+// Everything here is a register-resident, matrix-free restatement of what the reference
+// builds out of [B,3,3]/[B,6,6]/[B,7,7] temporaries (pypose/lietensor/operation.py).  One
+// call = one row (one group element); the kernels in rowmap.h are thin load/transpose/store
+// shells around these functions.  The functions are templated on the scalar type S so that
+// the same code serves fp32 kernels, fp64 kernels and the forward-mode Dual<T> used for the
+// Jinvp backward.  They compile with hipcc (device) and with g++ (tests/hostmath builds this
+// header for the CPU-only arithmetic check -- that build is test infrastructure, never a
+// product fallback).
+//
+// Conventions (reference: pypose/lietensor/lietensor.py:196-198,303-305,354-356,447-449,
+// 494-496,590-592,638-640,731-733): quaternion [x,y,z,w]; SE3 [t(3),q(4)]; Sim3 [t,q,s];
+// RxSO3 [q,s]; tangents se3 [tau,phi], sim3 [tau,phi,sigma], rxso3 [phi,sigma].
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <cfloat>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define PP_HD __host__ __device__ __forceinline__
+#else
+#define PP_HD inline
+#endif
+
+namespace pplie {
+
+// ---------------------------------------------------------------------------------------
+// numeric traits
+// ---------------------------------------------------------------------------------------
+template <class T> struct Num;
+template <> struct Num<float> {
+  typedef float base;
+  static PP_HD float eps() { return 1.1920928955078125e-07f; }   // torch.finfo(float32).eps
+  static PP_HD float max() { return FLT_MAX; }
+  // below theta^2 < series2 the rotation coefficient functions use their power series
+  // (the closed forms cancel catastrophically in fp32: SURVEY.md section 7 "hard parts")
+  static PP_HD float series2() { return 2.25f; }
+};
+template <> struct Num<double> {
+  typedef double base;
+  static PP_HD double eps() { return 2.220446049250313e-16; }     // torch.finfo(float64).eps
+  static PP_HD double max() { return DBL_MAX; }
+  static PP_HD double series2() { return 0.0625; }
+};
+
+PP_HD float pp_sin(float x) { return ::sinf(x); }
+PP_HD double pp_sin(double x) { return ::sin(x); }
+PP_HD float pp_cos(float x) { return ::cosf(x); }
+PP_HD double pp_cos(double x) { return ::cos(x); }
+PP_HD float pp_sqrt(float x) { return ::sqrtf(x); }
+PP_HD double pp_sqrt(double x) { return ::sqrt(x); }
+PP_HD float pp_atan(float x) { return ::atanf(x); }
+PP_HD double pp_atan(double x) { return ::atan(x); }
+PP_HD float pp_exp(float x) { return ::expf(x); }
+PP_HD double pp_exp(double x) { return ::exp(x); }
+PP_HD float pp_expm1(float x) { return ::expm1f(x); }
+PP_HD double pp_expm1(double x) { return ::expm1(x); }
+PP_HD float pp_log(float x) { return ::logf(x); }
+PP_HD double pp_log(double x) { return ::log(x); }
+PP_HD float pp_abs(float x) { return ::fabsf(x); }
+PP_HD double pp_abs(double x) { return ::fabs(x); }
+PP_HD float pp_val(float x) { return x; }
+PP_HD double pp_val(double x) { return x; }
+PP_HD bool pp_isnan(float x) { return x != x; }
+PP_HD bool pp_isnan(double x) { return x != x; }
+
+// torch.nan_to_num default semantics: nan -> 0, +inf -> max, -inf -> lowest
+template <class S> PP_HD S pp_nan_to_num(S x) {
+  typedef typename Num<S>::base B;
+  B v = pp_val(x);
+  if (v != v) return S(B(0));
+  if (v > Num<B>::max()) return S(Num<B>::max());
+  if (v < -Num<B>::max()) return S(-Num<B>::max());
+  return x;
+}
+
+// pypose.basics.pm: sign(sign(x)*2+1) -> +1 at 0 (reference basics/ops.py:24)
+template <class S> PP_HD S pp_pm(S x) {
+  typedef typename Num<S>::base B;
+  B v = pp_val(x);
+  if (v != v) return x;
+  return v < B(0) ? S(B(-1)) : S(B(1));
+}
+
+// ---------------------------------------------------------------------------------------
+// tiny 3-vector
+// ---------------------------------------------------------------------------------------
+template <class S> struct V3 {
+  S x, y, z;
+};
+template <class S> PP_HD V3<S> v3(S x, S y, S z) {
+  V3<S> r;
+  r.x = x; r.y = y; r.z = z;
+  return r;
+}
+template <class S> PP_HD V3<S> v3(const S* p) { return v3(p[0], p[1], p[2]); }
+template <class S> PP_HD void put(const V3<S>& a, S* p) { p[0] = a.x; p[1] = a.y; p[2] = a.z; }
+template <class S> PP_HD V3<S> operator+(const V3<S>& a, const V3<S>& b) { return v3<S>(a.x + b.x, a.y + b.y, a.z + b.z); }
+template <class S> PP_HD V3<S> operator-(const V3<S>& a, const V3<S>& b) { return v3<S>(a.x - b.x, a.y - b.y, a.z - b.z); }
+template <class S> PP_HD V3<S> operator-(const V3<S>& a) { return v3<S>(-a.x, -a.y, -a.z); }
+template <class S> PP_HD V3<S> operator*(S s, const V3<S>& a) { return v3<S>(s * a.x, s * a.y, s * a.z); }
+template <class S> PP_HD V3<S> cross(const V3<S>& a, const V3<S>& b) {
+  return v3<S>(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+template <class S> PP_HD S dot(const V3<S>& a, const V3<S>& b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+template <class S> PP_HD S norm2(const V3<S>& a) { return dot(a, a); }
+
+// ---------------------------------------------------------------------------------------
+// rotation coefficient functions of theta = |phi|
+//   B = (1-cos t)/t^2, C = (t - sin t)/t^3                      so3_Jl   (operation.py:7-20)
+//   D = (t^2 + 2cos t - 2)/(2 t^4), E = (2t - 3 sin t + t cos t)/(2 t^5)   calcQ (:37-58)
+//   F = (1 - t cos(t/2) / (2 sin(t/2)))/t^2                      so3_Jl_inv (:23-32)
+// The reference evaluates the closed forms for every theta > eps and a 2-term Taylor below;
+// here the power series is used for theta^2 < Num::series2 (it contains the reference's
+// Taylor branch as its leading terms) and cancellation-free closed forms above.
+// ---------------------------------------------------------------------------------------
+template <class S> struct RotCoef {
+  S B, C, D, E;
+};
+
+template <class S> PP_HD S poly8(S t, S c0, S c1, S c2, S c3, S c4, S c5, S c6, S c7) {
+  return c0 + t * (c1 + t * (c2 + t * (c3 + t * (c4 + t * (c5 + t * (c6 + t * c7))))));
+}
+
+// B and C only (forward paths)
+template <class S> PP_HD void rot_coef_BC(S th2, S& B, S& C) {
+  typedef typename Num<S>::base T;
+  if (pp_val(th2) < Num<T>::series2()) {
+    B = poly8<S>(th2, S(T(1.0 / 2)), S(T(-1.0 / 24)), S(T(1.0 / 720)), S(T(-1.0 / 40320)), S(T(1.0 / 3628800)),
+                 S(T(-1.0 / 479001600)), S(T(1.0 / 87178291200.0)), S(T(-1.0 / 20922789888000.0)));
+    C = poly8<S>(th2, S(T(1.0 / 6)), S(T(-1.0 / 120)), S(T(1.0 / 5040)), S(T(-1.0 / 362880)), S(T(1.0 / 39916800)),
+                 S(T(-1.0 / 6227020800.0)), S(T(1.0 / 1307674368000.0)), S(T(-1.0 / 355687428096000.0)));
+  } else {
+    S th = pp_sqrt(th2);
+    S sh = pp_sin(S(T(0.5)) * th);
+    S s = pp_sin(th);
+    B = S(T(2)) * sh * sh / th2;          // 2 sin^2(t/2) / t^2: no cancellation
+    C = (th - s) / (th2 * th);
+  }
+}
+
+template <class S> PP_HD RotCoef<S> rot_coef(S th2) {
+  typedef typename Num<S>::base T;
+  RotCoef<S> k;
+  if (pp_val(th2) < Num<T>::series2()) {
+    k.B = poly8<S>(th2, S(T(1.0 / 2)), S(T(-1.0 / 24)), S(T(1.0 / 720)), S(T(-1.0 / 40320)), S(T(1.0 / 3628800)),
+                   S(T(-1.0 / 479001600)), S(T(1.0 / 87178291200.0)), S(T(-1.0 / 20922789888000.0)));
+    k.C = poly8<S>(th2, S(T(1.0 / 6)), S(T(-1.0 / 120)), S(T(1.0 / 5040)), S(T(-1.0 / 362880)), S(T(1.0 / 39916800)),
+                   S(T(-1.0 / 6227020800.0)), S(T(1.0 / 1307674368000.0)), S(T(-1.0 / 355687428096000.0)));
+    // D = sum (-1)^j t^j / (2j+4)!
+    k.D = poly8<S>(th2, S(T(1.0 / 24)), S(T(-1.0 / 720)), S(T(1.0 / 40320)), S(T(-1.0 / 3628800)), S(T(1.0 / 479001600)),
+                   S(T(-1.0 / 87178291200.0)), S(T(1.0 / 20922789888000.0)), S(T(-1.0 / 6402373705728000.0)));
+    // E = sum (-1)^j (j+1) t^j / (2j+5)!
+    k.E = poly8<S>(th2, S(T(1.0 / 120)), S(T(-2.0 / 5040)), S(T(3.0 / 362880)), S(T(-4.0 / 39916800)),
+                   S(T(5.0 / 6227020800.0)), S(T(-6.0 / 1307674368000.0)), S(T(7.0 / 355687428096000.0)),
+                   S(T(-8.0 / 121645100408832000.0)));
+  } else {
+    S th = pp_sqrt(th2);
+    S sh = pp_sin(S(T(0.5)) * th);
+    S s = pp_sin(th);
+    k.B = S(T(2)) * sh * sh / th2;
+    k.C = (th - s) / (th2 * th);
+    k.D = (S(T(0.5)) - k.B) / th2;                       // == (t^2 + 2cos t - 2)/(2 t^4)
+    k.E = (S(T(3)) * k.C - k.B) / (S(T(2)) * th2);       // == (2t - 3 sin t + t cos t)/(2 t^5)
+  }
+  return k;
+}
+
+// F of so3_Jl_inv
+template <class S> PP_HD S rot_coef_F(S th2) {
+  typedef typename Num<S>::base T;
+  if (pp_val(th2) < Num<T>::series2()) {
+    // (t/2)cot(t/2) = 1 - t^2/12 - t^4/720 - t^6/30240 - ... (Bernoulli numbers)
+    return poly8<S>(th2, S(T(1.0 / 12)), S(T(1.0 / 720)), S(T(1.0 / 30240)), S(T(1.0 / 1209600)), S(T(1.0 / 47900160)),
+                    S(T(691.0 / 1307674368000.0)), S(T(1.0 / 74724249600.0)), S(T(3617.0 / 10670622842880000.0)));
+  }
+  S th = pp_sqrt(th2);
+  S h = S(T(0.5)) * th;
+  return pp_nan_to_num((S(T(1)) - th * pp_cos(h) / (S(T(2)) * pp_sin(h))) / th2);
+}
+
+// Jl(phi) v = v + B phi x v + C phi x (phi x v)            (operation.py:7-20)
+template <class S> PP_HD V3<S> jl_apply(S B, S C, const V3<S>& phi, const V3<S>& v) {
+  V3<S> a = cross(phi, v);
+  return v + B * a + C * cross(phi, a);
+}
+// Jl_inv(phi) v = v - 1/2 phi x v + F phi x (phi x v)      (operation.py:23-32)
+template <class S> PP_HD V3<S> jlinv_apply(S F, const V3<S>& phi, const V3<S>& v) {
+  typedef typename Num<S>::base T;
+  V3<S> a = cross(phi, v);
+  return v - S(T(0.5)) * a + F * cross(phi, a);
+}
+
+// Q(tau,phi) v with the four calcQ coefficient groups (operation.py:56-57); every
+// Phi..Tau..Phi factor is a nested cross product.
+template <class S> PP_HD V3<S> q_apply(const RotCoef<S>& k, const V3<S>& tau, const V3<S>& phi, const V3<S>& v) {
+  typedef typename Num<S>::base T;
+  V3<S> pv = cross(phi, v);       // Phi v
+  V3<S> tv = cross(tau, v);       // Tau v
+  V3<S> ppv = cross(phi, pv);     // Phi^2 v
+  V3<S> tpv = cross(tau, pv);     // Tau Phi v
+  V3<S> ptv = cross(phi, tv);     // Phi Tau v
+  V3<S> ptpv = cross(phi, tpv);   // Phi Tau Phi v
+  V3<S> pptv = cross(phi, ptv);   // Phi^2 Tau v
+  V3<S> tppv = cross(tau, ppv);   // Tau Phi^2 v
+  V3<S> ptppv = cross(phi, tppv); // Phi Tau Phi^2 v
+  V3<S> pptpv = cross(phi, ptpv); // Phi^2 Tau Phi v
+  return S(T(0.5)) * tv + k.C * (ptv + tpv + ptpv) + k.D * (pptv + tppv - S(T(3)) * ptpv) + k.E * (ptppv + pptpv);
+}
+
+// ---------------------------------------------------------------------------------------
+// quaternion helpers  (SO3_Act operation.py:519-525, SO3_Mul :832-837)
+// ---------------------------------------------------------------------------------------
+template <class S> PP_HD V3<S> quat_rotate(const V3<S>& qv, S qw, const V3<S>& p) {
+  V3<S> uv = cross(qv, p);
+  uv = uv + uv;
+  return p + qw * uv + cross(qv, uv);
+}
+// R^T p = rotation by the conjugate
+template <class S> PP_HD V3<S> quat_rotate_inv(const V3<S>& qv, S qw, const V3<S>& p) { return quat_rotate(-qv, qw, p); }
+
+template <class S> PP_HD void quat_mul(const S* X, const S* Y, S* Z) {
+  V3<S> xv = v3(X), yv = v3(Y);
+  S xw = X[3], yw = Y[3];
+  V3<S> zv = xw * yv + yw * xv + cross(xv, yv);   // Xw*Yv + Xv*Yw + Xv x Yv
+  put(zv, Z);
+  Z[3] = xw * yw - dot(xv, yv);
+}
+
+// ---------------------------------------------------------------------------------------
+// SO3
+// ---------------------------------------------------------------------------------------
+// so3_Exp.forward (operation.py:343-357)
+template <class S> PP_HD void so3_exp(const S* x, S* q) {
+  typedef typename Num<S>::base T;
+  V3<S> phi = v3(x);
+  S th2 = norm2(phi);
+  S th = pp_sqrt(th2);
+  S imag, real;
+  if (pp_val(th) > Num<T>::eps()) {
+    S h = S(T(0.5)) * th;
+    imag = pp_sin(h) / th;
+    real = pp_cos(h);
+  } else {
+    S th4 = th2 * th2;
+    imag = S(T(0.5)) - S(T(1.0 / 48.0)) * th2 + S(T(1.0 / 3840.0)) * th4;
+    real = S(T(1.0)) - S(T(1.0 / 8.0)) * th2 + S(T(1.0 / 384.0)) * th4;
+  }
+  put(imag * phi, q);
+  q[3] = real;
+}
+
+// SO3_Log.forward (operation.py:307-324): three-way branch, atan (not atan2), no
+// canonicalisation of the quaternion sign.
+template <class S> PP_HD void so3_log(const S* q, S* x) {
+  typedef typename Num<S>::base T;
+  V3<S> v = v3(q);
+  S w = q[3];
+  S vn = pp_sqrt(norm2(v));
+  bool vbig = pp_val(vn) > Num<T>::eps();
+  bool wbig = pp_val(pp_abs(w)) > Num<T>::eps();
+  S f;
+  if (vbig && wbig)
+    f = pp_nan_to_num(S(T(2)) * pp_atan(vn / w) / vn);
+  else if (vbig)
+    f = pp_nan_to_num(pp_pm(w) * S(T(3.14159265358979323846)) / vn);
+  else
+    f = pp_nan_to_num(S(T(2)) * (S(T(1)) / w - vn * vn / (S(T(3)) * w * w * w)));
+  put(f * v, x);
+}
+
+// so3_Exp.backward: g[:3] @ so3_Jl(x) == Jl(-x) g   (operation.py:366-370)
+template <class S> PP_HD void so3_exp_bwd(const S* x, const S* g, S* gx) {
+  V3<S> phi = v3(x);
+  S B, C;
+  rot_coef_BC(norm2(phi), B, C);
+  put(jl_apply(B, C, -phi, v3(g)), gx);
+}
+// SO3_Log.backward: [g @ so3_Jl_inv(y), 0]             (operation.py:332-337)
+template <class S> PP_HD void so3_log_bwd(const S* y, const S* g, S* gX) {
+  typedef typename Num<S>::base T;
+  V3<S> phi = v3(y);
+  S F = rot_coef_F(norm2(phi));
+  put(jlinv_apply(F, -phi, v3(g)), gX);
+  gX[3] = S(T(0));
+}
+
+// SO3_Act (operation.py:519-525) and its backward (:535-542):
+//   X_grad = [g @ skew(-out), 0] = [out x g, 0]; p_grad = g @ R = R^T g
+template <class S> PP_HD void so3_act(const S* X, const S* p, S* out) { put(quat_rotate(v3(X), X[3], v3(p)), out); }
+template <class S> PP_HD void so3_act_bwd(const S* X, const S* out, const S* g, S* gX, S* gp) {
+  typedef typename Num<S>::base T;
+  put(cross(v3(out), v3(g)), gX);
+  gX[3] = S(T(0));
+  put(quat_rotate_inv(v3(X), X[3], v3(g)), gp);
+}
+// SO3_Act4 (:626-645): rotate xyz, carry w; X_grad from the 3 leading comps of out/g
+template <class S> PP_HD void so3_act4(const S* X, const S* p, S* out) {
+  put(quat_rotate(v3(X), X[3], v3(p)), out);
+  out[3] = p[3];
+}
+template <class S> PP_HD void so3_act4_bwd(const S* X, const S* out, const S* g, S* gX, S* gp) {
+  typedef typename Num<S>::base T;
+  put(cross(v3(out), v3(g)), gX);
+  gX[3] = S(T(0));
+  put(quat_rotate_inv(v3(X), X[3], v3(g)), gp);
+  gp[3] = g[3];
+}
+
+// SO3_Mul (:832-852)
+template <class S> PP_HD void so3_mul(const S* X, const S* Y, S* Z) { quat_mul(X, Y, Z); }
+template <class S> PP_HD void so3_mul_bwd(const S* X, const S* g, S* gX, S* gY) {
+  typedef typename Num<S>::base T;
+  gX[0] = g[0]; gX[1] = g[1]; gX[2] = g[2]; gX[3] = S(T(0));
+  put(quat_rotate_inv(v3(X), X[3], v3(g)), gY);   // g @ Adj(X) = R^T g
+  gY[3] = S(T(0));
+}
+// SO3_Inv (:933-949)
+template <class S> PP_HD void so3_inv(const S* X, S* Y) {
+  Y[0] = -X[0]; Y[1] = -X[1]; Y[2] = -X[2]; Y[3] = X[3];
+}
+template <class S> PP_HD void so3_inv_bwd(const S* Y, const S* g, S* gX) {
+  typedef typename Num<S>::base T;
+  put(-quat_rotate_inv(v3(Y), Y[3], v3(g)), gX);
+  gX[3] = S(T(0));
+}
+// SO3_AdjXa (:728-748): out = R a; X_grad = [-g @ skew(out), 0] = [out x g ... sign below]
+//   (-g^T K(out))^T = -K(out)^T g = K(out) g = out x g ; a_grad = R^T g
+template <class S> PP_HD void so3_adj(const S* X, const S* a, S* out) { put(quat_rotate(v3(X), X[3], v3(a)), out); }
+template <class S> PP_HD void so3_adj_bwd(const S* X, const S* out, const S* g, S* gX, S* ga) {
+  typedef typename Num<S>::base T;
+  put(cross(v3(out), v3(g)), gX);
+  gX[3] = S(T(0));
+  put(quat_rotate_inv(v3(X), X[3], v3(g)), ga);
+}
+// SO3_AdjTXa (:1027-1044): out = R^T a; a_grad = R g; X_grad = [-a @ skew(a_grad),0] = [a_grad x a, 0]
+template <class S> PP_HD void so3_adjt(const S* X, const S* a, S* out) { put(quat_rotate_inv(v3(X), X[3], v3(a)), out); }
+template <class S> PP_HD void so3_adjt_bwd(const S* X, const S* a, const S* g, S* gX, S* ga) {
+  typedef typename Num<S>::base T;
+  V3<S> ag = quat_rotate(v3(X), X[3], v3(g));
+  put(ag, ga);
+  put(cross(ag, v3(a)), gX);
+  gX[3] = S(T(0));
+}
+// SO3 Jinvp (lietensor.py:257-264): so3_Jl_inv(Log X) p
+template <class S> PP_HD void so3_jinvp(const S* X, const S* p, S* out) {
+  S x[3];
+  so3_log(X, x);
+  V3<S> phi = v3(x);
+  put(jlinv_apply(rot_coef_F(norm2(phi)), phi, v3(p)), out);
+}
+// so3.Jr (lietensor.py:343-351): I - c1 K + c2 K^2 where theta > eps else I; row-major 3x3
+template <class S> PP_HD void so3_jr(const S* x, S* J) {
+  typedef typename Num<S>::base T;
+  V3<S> phi = v3(x);
+  S th2 = norm2(phi);
+  S B = S(T(0)), C = S(T(0));
+  if (pp_val(pp_sqrt(th2)) > Num<T>::eps()) rot_coef_BC(th2, B, C);
+  // Jr = I - B K + C K^2, K = skew(phi), K^2 = phi phi^T - th2 I
+  S px = phi.x, py = phi.y, pz = phi.z;
+  J[0] = S(T(1)) + C * (px * px - th2);
+  J[1] = B * pz + C * px * py;
+  J[2] = -B * py + C * px * pz;
+  J[3] = -B * pz + C * px * py;
+  J[4] = S(T(1)) + C * (py * py - th2);
+  J[5] = B * px + C * py * pz;
+  J[6] = B * py + C * px * pz;
+  J[7] = -B * px + C * py * pz;
+  J[8] = S(T(1)) + C * (pz * pz - th2);
+}
+
+// ---------------------------------------------------------------------------------------
+// SE3
+// ---------------------------------------------------------------------------------------
+// se3_Exp.forward (operation.py:401-405): t = Jl(phi) tau, q = Exp(phi)
+template <class S> PP_HD void se3_exp(const S* x, S* X) {
+  V3<S> tau = v3(x), phi = v3(x + 3);
+  S B, C;
+  rot_coef_BC(norm2(phi), B, C);
+  put(jl_apply(B, C, phi, tau), X);
+  so3_exp(x + 3, X + 3);
+}
+// SE3_Log.forward (:376-382): phi = Log(q), tau = Jl_inv(phi) t
+template <class S> PP_HD void se3_log(const S* X, S* x) {
+  so3_log(X + 3, x + 3);
+  V3<S> phi = v3(x + 3);
+  put(jlinv_apply(rot_coef_F(norm2(phi)), phi, v3(X)), x);
+}
+// se3_Exp.backward (:413-418): g[:6] @ se3_Jl(x);  se3_Jl = [[J,Q],[0,J]]  (:61-65)
+//   out_tau = J^T g_tau ; out_phi = Q^T g_tau + J^T g_phi ; J^T = J(-phi), Q^T = Q(-tau,-phi)
+template <class S> PP_HD void se3_exp_bwd(const S* x, const S* g, S* gx) {
+  V3<S> tau = v3(x), phi = v3(x + 3);
+  V3<S> gt = v3(g), gp = v3(g + 3);
+  RotCoef<S> k = rot_coef(norm2(phi));
+  V3<S> nphi = -phi;
+  put(jl_apply(k.B, k.C, nphi, gt), gx);
+  put(q_apply(k, -tau, nphi, gt) + jl_apply(k.B, k.C, nphi, gp), gx + 3);
+}
+// SE3_Log.backward (:389-395): [g @ se3_Jl_inv(y), 0];
+//   se3_Jl_inv = [[Ji, -Ji Q Ji],[0, Ji]] (:68-75)
+//   out_tau = Ji^T g_tau ; out_phi = -Ji^T Q^T Ji^T g_tau + Ji^T g_phi
+template <class S> PP_HD void se3_log_bwd(const S* y, const S* g, S* gX) {
+  typedef typename Num<S>::base T;
+  V3<S> tau = v3(y), phi = v3(y + 3);
+  V3<S> gt = v3(g), gp = v3(g + 3);
+  S th2 = norm2(phi);
+  RotCoef<S> k = rot_coef(th2);
+  S F = rot_coef_F(th2);
+  V3<S> nphi = -phi;
+  V3<S> a = jlinv_apply(F, nphi, gt);
+  put(a, gX);
+  V3<S> b = q_apply(k, -tau, nphi, a);
+  put(jlinv_apply(F, nphi, gp - b), gX + 3);
+  gX[6] = S(T(0));
+}
+// SE3_Act (:548-568)
+template <class S> PP_HD void se3_act(const S* X, const S* p, S* out) {
+  put(v3(X) + quat_rotate(v3(X + 3), X[6], v3(p)), out);
+}
+//   X_grad = [g @ [I | skew(-out)], 0] = [g, out x g, 0]; p_grad = R^T g
+template <class S> PP_HD void se3_act_bwd(const S* X, const S* out, const S* g, S* gX, S* gp) {
+  typedef typename Num<S>::base T;
+  gX[0] = g[0]; gX[1] = g[1]; gX[2] = g[2];
+  put(cross(v3(out), v3(g)), gX + 3);
+  gX[6] = S(T(0));
+  put(quat_rotate_inv(v3(X + 3), X[6], v3(g)), gp);
+}
+// SE3_Act4 (:651-671): t = R p3 + t*p4, out4 = p4
+//   X_grad = g @ SE3_Act4_Jacobian(out) (:229-234): J[:3,:3] = I*out4, J[:3,3:] = skew(-out3); row 4 zero
+//   p_grad = g @ SE3_Matrix4x4(X) = [R^T g3, t.g3 + g4]
+template <class S> PP_HD void se3_act4(const S* X, const S* p, S* out) {
+  put(quat_rotate(v3(X + 3), X[6], v3(p)) + p[3] * v3(X), out);
+  out[3] = p[3];
+}
+template <class S> PP_HD void se3_act4_bwd(const S* X, const S* out, const S* g, S* gX, S* gp) {
+  typedef typename Num<S>::base T;
+  V3<S> g3 = v3(g);
+  put(out[3] * g3, gX);
+  put(cross(v3(out), g3), gX + 3);
+  gX[6] = S(T(0));
+  put(quat_rotate_inv(v3(X + 3), X[6], g3), gp);
+  gp[3] = dot(v3(X), g3) + g[3];
+}
+// SE3_Mul (:858-877)
+template <class S> PP_HD void se3_mul(const S* X, const S* Y, S* Z) {
+  put(v3(X) + quat_rotate(v3(X + 3), X[6], v3(Y)), Z);
+  quat_mul(X + 3, Y + 3, Z + 3);
+}
+// SE3 Adj(X) = [[R, tx R],[0,R]] (:202-210).  Adj [u;w] = [R u + t x (R w), R w]
+//   row-vector product g @ Adj = Adj^T g = [R^T g_t, R^T(g_t x t) ... ] derived:
+//   Adj^T = [[R^T, 0],[(tx R)^T, R^T]] ; (tx R)^T g_t = R^T tx^T g_t = -R^T (t x g_t) = R^T (g_t x t)
+template <class S> PP_HD void se3_adjT_apply(const S* X, const V3<S>& gt, const V3<S>& gp, V3<S>& ot, V3<S>& op) {
+  V3<S> qv = v3(X + 3);
+  S qw = X[6];
+  ot = quat_rotate_inv(qv, qw, gt);
+  op = quat_rotate_inv(qv, qw, cross(gt, v3(X)) + gp);
+}
+template <class S> PP_HD void se3_adj_apply(const S* X, const V3<S>& u, const V3<S>& w, V3<S>& ot, V3<S>& op) {
+  V3<S> qv = v3(X + 3);
+  S qw = X[6];
+  op = quat_rotate(qv, qw, w);
+  ot = quat_rotate(qv, qw, u) + cross(v3(X), op);
+}
+template <class S> PP_HD void se3_mul_bwd(const S* X, const S* g, S* gX, S* gY) {
+  typedef typename Num<S>::base T;
+  for (int i = 0; i < 6; ++i) gX[i] = g[i];
+  gX[6] = S(T(0));
+  V3<S> ot, op;
+  se3_adjT_apply(X, v3(g), v3(g + 3), ot, op);
+  put(ot, gY);
+  put(op, gY + 3);
+  gY[6] = S(T(0));
+}
+// SE3_Inv (:955-973)
+template <class S> PP_HD void se3_inv(const S* X, S* Y) {
+  so3_inv(X + 3, Y + 3);
+  put(-quat_rotate(v3(Y + 3), Y[6], v3(X)), Y);
+}
+template <class S> PP_HD void se3_inv_bwd(const S* Y, const S* g, S* gX) {
+  typedef typename Num<S>::base T;
+  V3<S> ot, op;
+  se3_adjT_apply(Y, v3(g), v3(g + 3), ot, op);
+  put(-ot, gX);
+  put(-op, gX + 3);
+  gX[6] = S(T(0));
+}
+// se3_adj(x) = [[Phi, Tau],[0, Phi]] (:77-83); row-vector g @ adj = [g_t x phi, g_t x tau + g_p x phi]
+//   since (g^T K(a))^T = K(a)^T g = -a x g = g x a
+template <class S> PP_HD void se3_rowvec_adj(const V3<S>& gt, const V3<S>& gp, const V3<S>& tau, const V3<S>& phi, V3<S>& ot, V3<S>& op) {
+  ot = cross(gt, phi);
+  op = cross(gt, tau) + cross(gp, phi);
+}
+// SE3_AdjXa (:754-774)
+template <class S> PP_HD void se3_adj(const S* X, const S* a, S* out) {
+  V3<S> ot, op;
+  se3_adj_apply(X, v3(a), v3(a + 3), ot, op);
+  put(ot, out);
+  put(op, out + 3);
+}
+template <class S> PP_HD void se3_adj_bwd(const S* X, const S* out, const S* g, S* gX, S* ga) {
+  typedef typename Num<S>::base T;
+  V3<S> ot, op;
+  se3_rowvec_adj(v3(g), v3(g + 3), v3(out), v3(out + 3), ot, op);
+  put(-ot, gX);
+  put(-op, gX + 3);
+  gX[6] = S(T(0));
+  se3_adjT_apply(X, v3(g), v3(g + 3), ot, op);
+  put(ot, ga);
+  put(op, ga + 3);
+}
+// SE3_AdjTXa (:1050-1067): out = Adj(X^-1) a; a_grad = Adj(X) g; X_grad = [-a @ adj(a_grad), 0]
+template <class S> PP_HD void se3_adjt(const S* X, const S* a, S* out) {
+  S Y[7];
+  se3_inv(X, Y);
+  se3_adj(Y, a, out);
+}
+template <class S> PP_HD void se3_adjt_bwd(const S* X, const S* a, const S* g, S* gX, S* ga) {
+  typedef typename Num<S>::base T;
+  V3<S> at, ap, ot, op;
+  se3_adj_apply(X, v3(g), v3(g + 3), at, ap);
+  put(at, ga);
+  put(ap, ga + 3);
+  se3_rowvec_adj(v3(a), v3(a + 3), at, ap, ot, op);
+  put(-ot, gX);
+  put(-op, gX + 3);
+  gX[6] = S(T(0));
+}
+// SE3 Jinvp (lietensor.py:422-429): se3_Jl_inv(Log X) p = [Ji p_t - Ji Q Ji p_p, Ji p_p]
+template <class S> PP_HD void se3_jinvp(const S* X, const S* p, S* out) {
+  S x[6];
+  se3_log(X, x);
+  V3<S> tau = v3(x), phi = v3(x + 3);
+  S th2 = norm2(phi);
+  RotCoef<S> k = rot_coef(th2);
+  S F = rot_coef_F(th2);
+  V3<S> b = jlinv_apply(F, phi, v3(p + 3));
+  put(b, out + 3);
+  put(jlinv_apply(F, phi, v3(p) - q_apply(k, tau, phi, b)), out);
+}
+
+// ---------------------------------------------------------------------------------------
+// RxSO3  [q(4), s]  /  rxso3 [phi(3), sigma]
+// ---------------------------------------------------------------------------------------
+template <class S> PP_HD void rxso3_exp(const S* x, S* X) {   // :447-451
+  so3_exp(x, X);
+  X[4] = pp_exp(x[3]);
+}
+template <class S> PP_HD void rxso3_log(const S* X, S* x) {   // :424-428
+  so3_log(X, x);
+  x[3] = pp_log(X[4]);
+}
+// rxso3_Jl = blockdiag(so3_Jl, 1) (:132-135)
+template <class S> PP_HD void rxso3_exp_bwd(const S* x, const S* g, S* gx) {
+  so3_exp_bwd(x, g, gx);
+  gx[3] = g[3];
+}
+template <class S> PP_HD void rxso3_log_bwd(const S* y, const S* g, S* gX) {   // :436-441
+  typedef typename Num<S>::base T;
+  V3<S> phi = v3(y);
+  put(jlinv_apply(rot_coef_F(norm2(phi)), -phi, v3(g)), gX);
+  gX[3] = g[3];
+  gX[4] = S(T(0));
+}
+template <class S> PP_HD void rxso3_act(const S* X, const S* p, S* out) {     // :574-577
+  put(X[4] * quat_rotate(v3(X), X[3], v3(p)), out);
+}
+// RxSO3_Act.backward (:587-594): X_grad = g @ [skew(-out) | out] ; p_grad = g @ (s R) = s R^T g
+template <class S> PP_HD void rxso3_act_bwd(const S* X, const S* out, const S* g, S* gX, S* gp) {
+  typedef typename Num<S>::base T;
+  put(cross(v3(out), v3(g)), gX);
+  gX[3] = dot(v3(g), v3(out));
+  gX[4] = S(T(0));
+  put(X[4] * quat_rotate_inv(v3(X), X[3], v3(g)), gp);
+}
+template <class S> PP_HD void rxso3_act4(const S* X, const S* p, S* out) {    // :677-680
+  rxso3_act(X, p, out);
+  out[3] = p[3];
+}
+// RxSO3_Act4.backward (:690-696): J (:261-265) rows 0..2 = [skew(-out3) | out3], row 3 zero;
+//   p_grad = g @ Matrix4x4 (:255-258) = [s R^T g3, g4]
+template <class S> PP_HD void rxso3_act4_bwd(const S* X, const S* out, const S* g, S* gX, S* gp) {
+  rxso3_act_bwd(X, out, g, gX, gp);
+  gp[3] = g[3];
+}
+template <class S> PP_HD void rxso3_mul(const S* X, const S* Y, S* Z) {       // :883-887
+  quat_mul(X, Y, Z);
+  Z[4] = X[4] * Y[4];
+}
+// RxSO3_Adj = blockdiag(R, 1) (:237-240)
+template <class S> PP_HD void rxso3_mul_bwd(const S* X, const S* g, S* gX, S* gY) {
+  typedef typename Num<S>::base T;
+  for (int i = 0; i < 4; ++i) gX[i] = g[i];
+  gX[4] = S(T(0));
+  put(quat_rotate_inv(v3(X), X[3], v3(g)), gY);
+  gY[3] = g[3];
+  gY[4] = S(T(0));
+}
+template <class S> PP_HD void rxso3_inv(const S* X, S* Y) {                   // :979-984
+  typedef typename Num<S>::base T;
+  so3_inv(X, Y);
+  Y[4] = S(T(1)) / X[4];
+}
+template <class S> PP_HD void rxso3_inv_bwd(const S* Y, const S* g, S* gX) {  // :992-997
+  typedef typename Num<S>::base T;
+  put(-quat_rotate_inv(v3(Y), Y[3], v3(g)), gX);
+  gX[3] = -g[3];
+  gX[4] = S(T(0));
+}
+template <class S> PP_HD void rxso3_adj(const S* X, const S* a, S* out) {     // :780-783
+  put(quat_rotate(v3(X), X[3], v3(a)), out);
+  out[3] = a[3];
+}
+// RxSO3_AdjXa.backward (:795-800): X_grad = -g @ rxso3_adj(out) (4x4 with skew(out3) top-left, :142-145)
+template <class S> PP_HD void rxso3_adj_bwd(const S* X, const S* out, const S* g, S* gX, S* ga) {
+  typedef typename Num<S>::base T;
+  put(cross(v3(out), v3(g)), gX);
+  gX[3] = S(T(0));
+  gX[4] = S(T(0));
+  put(quat_rotate_inv(v3(X), X[3], v3(g)), ga);
+  ga[3] = g[3];
+}
+template <class S> PP_HD void rxso3_adjt(const S* X, const S* a, S* out) {    // :1073-1076
+  put(quat_rotate_inv(v3(X), X[3], v3(a)), out);
+  out[3] = a[3];
+}
+template <class S> PP_HD void rxso3_adjt_bwd(const S* X, const S* a, const S* g, S* gX, S* ga) {  // :1084-1090
+  typedef typename Num<S>::base T;
+  V3<S> ag = quat_rotate(v3(X), X[3], v3(g));
+  put(ag, ga);
+  ga[3] = g[3];
+  put(cross(ag, v3(a)), gX);
+  gX[3] = S(T(0));
+  gX[4] = S(T(0));
+}
+template <class S> PP_HD void rxso3_jinvp(const S* X, const S* p, S* out) {   // lietensor.py:700-707
+  S x[4];
+  rxso3_log(X, x);
+  V3<S> phi = v3(x);
+  put(jlinv_apply(rot_coef_F(norm2(phi)), phi, v3(p)), out);
+  out[3] = p[3];
+}
+
+// ---------------------------------------------------------------------------------------
+// Sim3  [t(3), q(4), s]  /  sim3 [tau(3), phi(3), sigma]
+// ---------------------------------------------------------------------------------------
+// rxso3_Ws coefficients (operation.py:85-129): W = A K + B K^2 + C I with the reference's
+// four-way (sigma, theta) branch -- including its condition-3 B formula exactly as written.
+template <class S> PP_HD void ws_coef(const V3<S>& phi, S sigma, S& A, S& B, S& C) {
+  typedef typename Num<S>::base T;
+  S th2 = norm2(phi);
+  S th = pp_sqrt(th2);
+  bool sl = pp_val(pp_abs(sigma)) > Num<T>::eps();
+  bool tl = pp_val(th) > Num<T>::eps();
+  S scale = pp_exp(sigma);
+  S s2 = sigma * sigma;
+  if (!sl && !tl) {
+    C = S(T(1)); A = S(T(0.5)); B = S(T(1.0 / 6));
+  } else if (!sl && tl) {
+    C = S(T(1));
+    rot_coef_BC(th2, A, B);   // (1-cos t)/t^2, (t - sin t)/t^3, cancellation-free
+  } else if (sl && !tl) {
+    C = pp_expm1(sigma) / sigma;                       // (e^s - 1)/s without the fp32 cancellation
+    A = (S(T(1)) + (sigma - S(T(1))) * scale) / s2;
+    B = (S(T(0.5)) * s2 * scale + scale - S(T(1)) - s2 * scale) / (s2 * sigma);   // sic: reference :115
+  } else {
+    C = pp_expm1(sigma) / sigma;
+    S a = scale * pp_sin(th), b = scale * pp_cos(th), c = th2 + s2;
+    A = (a * sigma + (S(T(1)) - b) * th) / (th * c);
+    B = (C - ((b - S(T(1))) * sigma + a * th) / c) * (S(T(1)) / th2);
+  }
+}
+// W v = A phi x v + B phi x (phi x v) + C v
+template <class S> PP_HD V3<S> ws_apply(S A, S B, S C, const V3<S>& phi, const V3<S>& v) {
+  V3<S> a = cross(phi, v);
+  return A * a + B * cross(phi, a) + C * v;
+}
+// W^-1 v in closed form (the reference calls torch .inverse() on the 3x3, operation.py:473).
+// W = C I + A K + B K^2 acts as C on the phi axis and as (alpha I + A K) on the plane normal
+// to phi, alpha = C - B theta^2; hence W^-1 = a I + b K + c K^2 with
+//   a = 1/C, b = -A/(alpha^2 + A^2 theta^2), c = (1/C - alpha/(alpha^2 + A^2 theta^2))/theta^2.
+template <class S> PP_HD V3<S> ws_inv_apply(S A, S B, S C, const V3<S>& phi, const V3<S>& v) {
+  typedef typename Num<S>::base T;
+  S th2 = norm2(phi);
+  S alpha = C - B * th2;
+  S den = alpha * alpha + A * A * th2;
+  S a = S(T(1)) / C;
+  S b = -A / den;
+  V3<S> kv = cross(phi, v);
+  V3<S> r = a * v + b * kv;
+  if (pp_val(th2) > T(0)) {
+    S c = (a - alpha / den) / th2;
+    r = r + c * cross(phi, kv);
+  }
+  return r;
+}
+template <class S> PP_HD void sim3_exp(const S* x, S* X) {    // :495-500
+  V3<S> tau = v3(x), phi = v3(x + 3);
+  S A, B, C;
+  ws_coef(phi, x[6], A, B, C);
+  put(ws_apply(A, B, C, phi, tau), X);
+  rxso3_exp(x + 3, X + 3);
+}
+template <class S> PP_HD void sim3_log(const S* X, S* x) {    // :470-476
+  rxso3_log(X + 3, x + 3);
+  V3<S> phi = v3(x + 3);
+  S A, B, C;
+  ws_coef(phi, x[6], A, B, C);
+  put(ws_inv_apply(A, B, C, phi, v3(X)), x);
+}
+// sim3_adj (:147-156): Xi = [[Phi + sigma I, Tau, -tau],[0, Phi, 0],[0,0,0]];
+// row-vector product g @ Xi (7 comps): [g_t x phi + sigma g_t, g_t x tau + g_p x phi, -g_t . tau]
+template <class S> PP_HD void sim3_rowvec_adj(const S* g, const V3<S>& tau, const V3<S>& phi, S sigma, S* o) {
+  V3<S> gt = v3(g), gp = v3(g + 3);
+  put(cross(gt, phi) + sigma * gt, o);
+  put(cross(gt, tau) + cross(gp, phi), o + 3);
+  o[6] = -dot(gt, tau);
+}
+// sim3_Exp.backward (:509-513): g[:7] @ sim3_Jl, sim3_Jl = sum_{k<=5} Xi^k/(k+1)! (:159-164)
+template <class S> PP_HD void sim3_exp_bwd(const S* x, const S* g, S* gx) {
+  typedef typename Num<S>::base T;
+  V3<S> tau = v3(x), phi = v3(x + 3);
+  S sigma = x[6];
+  const T cf[5] = {T(1.0 / 2), T(1.0 / 6), T(1.0 / 24), T(1.0 / 120), T(1.0 / 720)};
+  S p[7], q[7];
+  for (int i = 0; i < 7; ++i) { p[i] = g[i]; gx[i] = g[i]; }
+  for (int k = 0; k < 5; ++k) {
+    sim3_rowvec_adj(p, tau, phi, sigma, q);
+    for (int i = 0; i < 7; ++i) { p[i] = q[i]; gx[i] = gx[i] + S(cf[k]) * q[i]; }
+  }
+}
+// Sim3_Log.backward (:484-489): [g @ sim3_Jl_inv(y), 0], Jl_inv = I - Xi/2 + Xi^2/12 - Xi^4/720 (:167-172)
+template <class S> PP_HD void sim3_log_bwd(const S* y, const S* g, S* gX) {
+  typedef typename Num<S>::base T;
+  V3<S> tau = v3(y), phi = v3(y + 3);
+  S sigma = y[6];
+  S p1[7], p2[7], p3[7], p4[7];
+  sim3_rowvec_adj(g, tau, phi, sigma, p1);
+  sim3_rowvec_adj(p1, tau, phi, sigma, p2);
+  sim3_rowvec_adj(p2, tau, phi, sigma, p3);
+  sim3_rowvec_adj(p3, tau, phi, sigma, p4);
+  for (int i = 0; i < 7; ++i)
+    gX[i] = g[i] - S(T(0.5)) * p1[i] + S(T(1.0 / 12)) * p2[i] - S(T(1.0 / 720)) * p4[i];
+  gX[7] = S(T(0));
+}
+template <class S> PP_HD void sim3_act(const S* X, const S* p, S* out) {      // :600-603
+  put(v3(X) + X[7] * quat_rotate(v3(X + 3), X[6], v3(p)), out);
+}
+// Sim3_Act.backward (:613-620): J = [I | skew(-out) | out]; p_grad = s R^T g
+template <class S> PP_HD void sim3_act_bwd(const S* X, const S* out, const S* g, S* gX, S* gp) {
+  typedef typename Num<S>::base T;
+  gX[0] = g[0]; gX[1] = g[1]; gX[2] = g[2];
+  put(cross(v3(out), v3(g)), gX + 3);
+  gX[6] = dot(v3(g), v3(out));
+  gX[7] = S(T(0));
+  put(X[7] * quat_rotate_inv(v3(X + 3), X[6], v3(g)), gp);
+}
+template <class S> PP_HD void sim3_act4(const S* X, const S* p, S* out) {     // :702-706
+  put(X[7] * quat_rotate(v3(X + 3), X[6], v3(p)) + p[3] * v3(X), out);
+  out[3] = p[3];
+}
+// Sim3_Act4.backward (:716-722): J (:297-301) = [SE3_Act4_Jacobian | out3]; p_grad = g @ Sim3_Matrix4x4
+template <class S> PP_HD void sim3_act4_bwd(const S* X, const S* out, const S* g, S* gX, S* gp) {
+  typedef typename Num<S>::base T;
+  V3<S> g3 = v3(g);
+  put(out[3] * g3, gX);
+  put(cross(v3(out), g3), gX + 3);
+  gX[6] = dot(g3, v3(out));
+  gX[7] = S(T(0));
+  put(X[7] * quat_rotate_inv(v3(X + 3), X[6], g3), gp);
+  gp[3] = dot(v3(X), g3) + g[3];
+}
+template <class S> PP_HD void sim3_mul(const S* X, const S* Y, S* Z) {        // :908-912
+  put(v3(X) + X[7] * quat_rotate(v3(X + 3), X[6], v3(Y)), Z);
+  quat_mul(X + 3, Y + 3, Z + 3);
+  Z[7] = X[7] * Y[7];
+}
+// Sim3_Adj (:268-276) = [[sR, tx R, -t],[0, R, 0],[0,0,1]]
+//   Adj [u;w;c] = [s R u + t x (R w) - c t, R w, c]
+//   g @ Adj = [s R^T g_t, R^T (g_t x t) + R^T g_p, -g_t.t + g_s]
+template <class S> PP_HD void sim3_adj_apply(const S* X, const S* a, S* o) {
+  V3<S> qv = v3(X + 3);
+  S qw = X[6];
+  V3<S> t = v3(X);
+  V3<S> rw = quat_rotate(qv, qw, v3(a + 3));
+  put(X[7] * quat_rotate(qv, qw, v3(a)) + cross(t, rw) - a[6] * t, o);
+  put(rw, o + 3);
+  o[6] = a[6];
+}
+template <class S> PP_HD void sim3_adjT_apply(const S* X, const S* g, S* o) {
+  V3<S> qv = v3(X + 3);
+  S qw = X[6];
+  V3<S> t = v3(X), gt = v3(g);
+  put(X[7] * quat_rotate_inv(qv, qw, gt), o);
+  put(quat_rotate_inv(qv, qw, cross(gt, t) + v3(g + 3)), o + 3);
+  o[6] = g[6] - dot(gt, t);
+}
+template <class S> PP_HD void sim3_mul_bwd(const S* X, const S* g, S* gX, S* gY) {   // :921-927
+  typedef typename Num<S>::base T;
+  for (int i = 0; i < 7; ++i) gX[i] = g[i];
+  gX[7] = S(T(0));
+  sim3_adjT_apply(X, g, gY);
+  gY[7] = S(T(0));
+}
+template <class S> PP_HD void sim3_inv(const S* X, S* Y) {                     // :1003-1008
+  rxso3_inv(X + 3, Y + 3);
+  put(-(Y[7] * quat_rotate(v3(Y + 3), Y[6], v3(X))), Y);
+}
+template <class S> PP_HD void sim3_inv_bwd(const S* Y, const S* g, S* gX) {    // :1016-1021
+  typedef typename Num<S>::base T;
+  S o[7];
+  sim3_adjT_apply(Y, g, o);
+  for (int i = 0; i < 7; ++i) gX[i] = -o[i];
+  gX[7] = S(T(0));
+}
+template <class S> PP_HD void sim3_adj(const S* X, const S* a, S* out) { sim3_adj_apply(X, a, out); }   // :806-810
+template <class S> PP_HD void sim3_adj_bwd(const S* X, const S* out, const S* g, S* gX, S* ga) {      // :820-826
+  typedef typename Num<S>::base T;
+  S o[7];
+  sim3_rowvec_adj(g, v3(out), v3(out + 3), out[6], o);
+  for (int i = 0; i < 7; ++i) gX[i] = -o[i];
+  gX[7] = S(T(0));
+  sim3_adjT_apply(X, g, ga);
+}
+template <class S> PP_HD void sim3_adjt(const S* X, const S* a, S* out) {      // :1096-1099
+  S Y[8];
+  sim3_inv(X, Y);
+  sim3_adj_apply(Y, a, out);
+}
+template <class S> PP_HD void sim3_adjt_bwd(const S* X, const S* a, const S* g, S* gX, S* ga) {   // :1107-1113
+  typedef typename Num<S>::base T;
+  sim3_adj_apply(X, g, ga);
+  S o[7];
+  sim3_rowvec_adj(a, v3(ga), v3(ga + 3), ga[6], o);
+  for (int i = 0; i < 7; ++i) gX[i] = -o[i];
+  gX[7] = S(T(0));
+}
+// Xi v (column product) for Jinvp: [phi x u + sigma u + tau x w - c tau, phi x w, 0]
+template <class S> PP_HD void sim3_adj_colvec(const S* v, const V3<S>& tau, const V3<S>& phi, S sigma, S* o) {
+  typedef typename Num<S>::base T;
+  V3<S> u = v3(v), w = v3(v + 3);
+  put(cross(phi, u) + sigma * u + cross(tau, w) - v[6] * tau, o);
+  put(cross(phi, w), o + 3);
+  o[6] = S(T(0));
+}
+template <class S> PP_HD void sim3_jinvp(const S* X, const S* p, S* out) {     // lietensor.py:556-563
+  typedef typename Num<S>::base T;
+  S x[7];
+  sim3_log(X, x);
+  V3<S> tau = v3(x), phi = v3(x + 3);
+  S sigma = x[6];
+  S p1[7], p2[7], p3[7], p4[7];
+  sim3_adj_colvec(p, tau, phi, sigma, p1);
+  sim3_adj_colvec(p1, tau, phi, sigma, p2);
+  sim3_adj_colvec(p2, tau, phi, sigma, p3);
+  sim3_adj_colvec(p3, tau, phi, sigma, p4);
+  for (int i = 0; i < 7; ++i)
+    out[i] = p[i] - S(T(0.5)) * p1[i] + S(T(1.0 / 12)) * p2[i] - S(T(1.0 / 720)) * p4[i];
+}
+
+}  // namespace pplie

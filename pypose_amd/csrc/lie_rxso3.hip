@@ -1,0 +1,3 @@
+// lie_rxso3.hip -- C-ABI entry points of the rxso3 / RXSO3 op set (include/pplie.h).
+#include "lie_ops.h"
+PPLIE_DEFINE_GROUP(rxso3, 4, 5)

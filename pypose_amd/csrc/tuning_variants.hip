@@ -1,0 +1,39 @@
+// tuning_variants.hip -- launch-shape variants of the SE3 Exp/Log kernels and a plain
+// dwordx4 copy, exported for tools/tune_rowmap.py (A/B measurements on the GPU box).
+// Not part of the product API (not declared in include/pplie.h; symbols are pplie_var_*).
+#include "lie_ops.h"
+
+namespace pplie {
+PPLIE_OP_1_1(Var_se3_exp, se3_exp, 6, 7)
+PPLIE_OP_1_1(Var_se3_log, se3_log, 7, 6)
+
+template <class Op>
+int var_dispatch(int path, int rpt, int grid_cap, const void* x, void* y, int64_t n, void* stream) {
+  if (path == 1) return launch_rowmap_direct<float, Op>(x, nullptr, nullptr, y, nullptr, n, stream, grid_cap);
+  switch (rpt) {
+    case 1: return launch_rowmap<float, Op, 1, 256>(x, nullptr, nullptr, y, nullptr, n, stream, grid_cap);
+    case 2: return launch_rowmap<float, Op, 2, 256>(x, nullptr, nullptr, y, nullptr, n, stream, grid_cap);
+    case 4: return launch_rowmap<float, Op, 4, 256>(x, nullptr, nullptr, y, nullptr, n, stream, grid_cap);
+    case 8: return launch_rowmap<float, Op, 8, 256>(x, nullptr, nullptr, y, nullptr, n, stream, grid_cap);
+  }
+  return PPLIE_EBADARG;
+}
+
+__global__ void __launch_bounds__(256) copy16_kernel(const raw16* __restrict__ src, raw16* __restrict__ dst, int64_t nvec) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256)
+    __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
+}
+}  // namespace pplie
+
+extern "C" int pplie_var_se3_exp_f32(int path, int rpt, int grid_cap, const void* x, void* y, int64_t n, void* stream) {
+  return pplie::var_dispatch<pplie::Var_se3_exp<float>>(path, rpt, grid_cap, x, y, n, stream);
+}
+extern "C" int pplie_var_se3_log_f32(int path, int rpt, int grid_cap, const void* x, void* y, int64_t n, void* stream) {
+  return pplie::var_dispatch<pplie::Var_se3_log<float>>(path, rpt, grid_cap, x, y, n, stream);
+}
+// device-copy ceiling: nbytes must be a multiple of 16
+extern "C" int pplie_var_copy(const void* src, void* dst, int64_t nbytes, int grid, void* stream) {
+  hipLaunchKernelGGL(pplie::copy16_kernel, dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     static_cast<const pplie::raw16*>(src), static_cast<pplie::raw16*>(dst), nbytes / 16);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
