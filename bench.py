@@ -1,0 +1,164 @@
+"""bench.py -- BASELINE.json's metric on its configs[1] workload.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload ("se3_explog_b10m"): batched SE3 Exp -> Log forward, B = 10,000,000 rows of fp32 per GPU
+(BASELINE.json configs[1]; inputs `pp.randn_se3(B)`, seed = rank), through the public API
+(``x.Exp()`` then ``X.Log()``: two HIP kernels per step, the group element X is materialised in
+HBM as in the reference).  One step = one Exp+Log pass over the whole batch; value = SE3
+Exp+Log pairs per second summed over all ranks (weak scaling: rows are independent, each rank
+owns its own B rows, no data-path collective).
+
+Printed JSON line (rank 0): the driver contract + "roofline" (dominant kernel, HIP-event timed
+inside the timed region) + "cpu_baseline" (the oracle -- a numpy port of the reference's
+algorithm -- timed on this box's host cores on a bounded sample of the same workload).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+BYTES_PER_ROW = {"se3_exp_fwd": 24 + 28, "se3_log_fwd": 28 + 24}    # 52 B/row each
+
+
+def _cpu_worker(args):
+    import numpy as np
+    from oracle import lie_np
+    seed, n = args
+    rng = np.random.default_rng(seed)
+    d = rng.standard_normal((n, 3))
+    d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    x = np.concatenate([rng.standard_normal((n, 3)), d * rng.standard_normal((n, 1))], -1).astype(np.float32)
+    t0 = time.perf_counter()
+    X = lie_np.se3_exp_fwd(x)[0]
+    y = lie_np.se3_log_fwd(X)[0]
+    return time.perf_counter() - t0, float(y[0, 0])
+
+
+def cpu_baseline(budget_s: float = 12.0):
+    """Oracle (numpy port of operation.py's se3_Exp / SE3_Log) on all host cores, bounded sample."""
+    import multiprocessing as mp
+    cores = os.cpu_count() or 1
+    chunk = 250_000
+    ctx = mp.get_context("spawn")
+    rows = 0
+    with ctx.Pool(cores) as pool:
+        pool.map(_cpu_worker, [(i, 1000) for i in range(cores)])       # warm the workers
+        t0 = time.perf_counter()
+        rnd = 0
+        while time.perf_counter() - t0 < budget_s and rows < 10_000_000:
+            pool.map(_cpu_worker, [(1000 + rnd * cores + i, chunk) for i in range(cores)])
+            rows += chunk * cores
+            rnd += 1
+        wall = time.perf_counter() - t0
+    return {"value": rows / wall, "unit": "SE3 Exp+Log pairs/s", "cores": cores, "kind": "port",
+            "sample": f"{rows} rows of the same fp32 workload (oracle/lie_np.py se3_exp_fwd+se3_log_fwd, "
+                      f"{cores} processes x {chunk}-row chunks, {wall:.1f} s wall)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--rows", type=int, default=10_000_000, help="rows per GPU (BASELINE configs[1]: 10M)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    import pypose_amd as pp
+    from pypose_amd import _C
+    assert _C._test_backend is None
+
+    B = a.rows
+    torch.manual_seed(rank)
+    x = pp.randn_se3(B, device=dev)          # [B,6] fp32, resident in HBM before timing starts
+
+    def step():
+        X = x.Exp()
+        return X.Log()
+
+    for _ in range(a.warmup):
+        y = step()
+    torch.cuda.synchronize()
+
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(a.steps)]
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(a.steps):
+        ev[k][0].record()
+        X = x.Exp()
+        ev[k][1].record()
+        y = X.Log()
+        ev[k][2].record()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        import torch.distributed as dist
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = t.item()
+
+    if rank == 0:
+        ms_exp = sum(e[0].elapsed_time(e[1]) for e in ev) / a.steps
+        ms_log = sum(e[1].elapsed_time(e[2]) for e in ev) / a.steps
+        dom, ms_dom = ("se3_log_fwd", ms_log) if ms_log >= ms_exp else ("se3_exp_fwd", ms_exp)
+        achieved = B * BYTES_PER_ROW[dom] / (ms_dom * 1e-3) / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            traffic = json.load(open(pmc)).get(dom)
+        out = {
+            "metric": "batched SE3 Exp+Log ops/sec", "value": world * B * a.steps / elapsed,
+            "unit": "SE3 Exp+Log pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "se3_explog_b10m (BASELINE configs[1]: batched SE3 Exp then Log, fp32, forward)",
+                       "rows_per_gpu": B, "parallelism": f"rows sharded x{world}, no collective"},
+            "roofline": {"bound": "hbm", "kernel": f"rowmap_lds_kernel<{dom}> (pplie_{dom}_f32)",
+                         "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                         "traffic": traffic, "algorithmic_bytes_per_launch": B * BYTES_PER_ROW[dom],
+                         "avg_launch_ms": ms_dom, "other_kernel_ms": {"se3_exp_fwd": ms_exp, "se3_log_fwd": ms_log}},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -105,8 +105,15 @@ def row_op(name: str, ins, out_widths):
         return _test_backend(name, ins, out_widths)
     x0 = ins[0]
     if not x0.is_cuda:
-        raise RuntimeError(
-            f"pypose_amd: op {name} needs tensors on a HIP device (got {x0.device}); there is no CPU path.")
+        # Host tensors are staged through the GPU (the arithmetic still runs in the HIP kernel);
+        # with no GPU present this raises -- there is no CPU implementation to fall back to.
+        if not torch.cuda.is_available():
+            raise RuntimeError(
+                f"pypose_amd: op {name} needs a HIP device (got {x0.device} tensors and no GPU is visible); "
+                f"there is no CPU compute path.")
+        dev = torch.device("cuda", torch.cuda.current_device())
+        outs = row_op(name, [t.to(dev) for t in ins], out_widths)
+        return tuple(o.to(x0.device) for o in outs)
     suffix = _SUFFIX.get(x0.dtype)
     if suffix is None:
         raise TypeError(f"pypose_amd: op {name} supports float32/float64, got {x0.dtype}")

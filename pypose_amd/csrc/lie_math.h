@@ -66,6 +66,36 @@ PP_HD double pp_val(double x) { return x; }
 PP_HD bool pp_isnan(float x) { return x != x; }
 PP_HD bool pp_isnan(double x) { return x != x; }
 
+// sin and cos of one fp32 angle in ~30 instructions: 3-constant Cody-Waite reduction by pi/2
+// (exact enough for |x| < 2^15; every angle on the hot path is a rotation angle or half of one)
+// + the classic degree-9 / degree-8 minimax polynomials on [-pi/4, pi/4] (<= 1 ulp).  Larger or
+// non-finite arguments take the libm path.  The library's sinf+cosf pair costs ~4x as much
+// because each call carries its own Payne-Hanek reduction.
+PP_HD void pp_sincos(float x, float& s, float& c) {
+  if (!(::fabsf(x) < 32768.0f)) {
+    s = ::sinf(x);
+    c = ::cosf(x);
+    return;
+  }
+  float kf = ::rintf(x * 0.63661977236758134f);
+  int k = (int)kf;
+  float r = ::fmaf(kf, -1.57079625129699707031e+00f, x);
+  r = ::fmaf(kf, -7.54978941586159635335e-08f, r);
+  r = ::fmaf(kf, -5.39030252995776476554e-15f, r);
+  float z = r * r;
+  float ps = ::fmaf(::fmaf(::fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f), z * r, r);
+  float pc = ::fmaf(::fmaf(::fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f), z * z,
+                    ::fmaf(-0.5f, z, 1.0f));
+  float ss = (k & 1) ? pc : ps;
+  float cc = (k & 1) ? ps : pc;
+  s = (k & 2) ? -ss : ss;
+  c = ((k + 1) & 2) ? -cc : cc;
+}
+PP_HD void pp_sincos(double x, double& s, double& c) {
+  s = ::sin(x);
+  c = ::cos(x);
+}
+
 // torch.nan_to_num default semantics: nan -> 0, +inf -> max, -inf -> lowest
 template <class S> PP_HD S pp_nan_to_num(S x) {
   typedef typename Num<S>::base B;
@@ -134,10 +164,10 @@ template <class S> PP_HD void rot_coef_BC(S th2, S& B, S& C) {
                  S(T(-1.0 / 6227020800.0)), S(T(1.0 / 1307674368000.0)), S(T(-1.0 / 355687428096000.0)));
   } else {
     S th = pp_sqrt(th2);
-    S sh = pp_sin(S(T(0.5)) * th);
-    S s = pp_sin(th);
-    B = S(T(2)) * sh * sh / th2;          // 2 sin^2(t/2) / t^2: no cancellation
-    C = (th - s) / (th2 * th);
+    S sh, ch;
+    pp_sincos(S(T(0.5)) * th, sh, ch);
+    B = S(T(2)) * sh * sh / th2;                        // 2 sin^2(t/2) / t^2: no cancellation
+    C = (th - S(T(2)) * sh * ch) / (th2 * th);          // sin t = 2 sin(t/2) cos(t/2)
   }
 }
 
@@ -158,10 +188,10 @@ template <class S> PP_HD RotCoef<S> rot_coef(S th2) {
                    S(T(-8.0 / 121645100408832000.0)));
   } else {
     S th = pp_sqrt(th2);
-    S sh = pp_sin(S(T(0.5)) * th);
-    S s = pp_sin(th);
+    S sh, ch;
+    pp_sincos(S(T(0.5)) * th, sh, ch);
     k.B = S(T(2)) * sh * sh / th2;
-    k.C = (th - s) / (th2 * th);
+    k.C = (th - S(T(2)) * sh * ch) / (th2 * th);
     k.D = (S(T(0.5)) - k.B) / th2;                       // == (t^2 + 2cos t - 2)/(2 t^4)
     k.E = (S(T(3)) * k.C - k.B) / (S(T(2)) * th2);       // == (2t - 3 sin t + t cos t)/(2 t^5)
   }
@@ -177,8 +207,9 @@ template <class S> PP_HD S rot_coef_F(S th2) {
                     S(T(691.0 / 1307674368000.0)), S(T(1.0 / 74724249600.0)), S(T(3617.0 / 10670622842880000.0)));
   }
   S th = pp_sqrt(th2);
-  S h = S(T(0.5)) * th;
-  return pp_nan_to_num((S(T(1)) - th * pp_cos(h) / (S(T(2)) * pp_sin(h))) / th2);
+  S sh, ch;
+  pp_sincos(S(T(0.5)) * th, sh, ch);
+  return pp_nan_to_num((S(T(1)) - th * ch / (S(T(2)) * sh)) / th2);
 }
 
 // Jl(phi) v = v + B phi x v + C phi x (phi x v)            (operation.py:7-20)
@@ -221,6 +252,16 @@ template <class S> PP_HD V3<S> quat_rotate(const V3<S>& qv, S qw, const V3<S>& p
 // R^T p = rotation by the conjugate
 template <class S> PP_HD V3<S> quat_rotate_inv(const V3<S>& qv, S qw, const V3<S>& p) { return quat_rotate(-qv, qw, p); }
 
+// R v with R = SO3_Adj(q) = 2w(wI + K(v)) - I + 2 v v^T (operation.py:175-179; SO3_Matrix is the
+// same matrix, :182-183).  It equals the SO3_Act rotation only for unit quaternions; the
+// reference multiplies by this matrix in every Adj / Matrix / backward product and by the
+// cross-product form in every forward Act, so non-normalised inputs must take the same routes.
+template <class S> PP_HD V3<S> adj_rotate(const V3<S>& qv, S qw, const V3<S>& p) {
+  typedef typename Num<S>::base T;
+  return (S(T(2)) * qw * qw - S(T(1))) * p + (S(T(2)) * qw) * cross(qv, p) + (S(T(2)) * dot(qv, p)) * qv;
+}
+template <class S> PP_HD V3<S> adj_rotate_T(const V3<S>& qv, S qw, const V3<S>& p) { return adj_rotate(-qv, qw, p); }
+
 template <class S> PP_HD void quat_mul(const S* X, const S* Y, S* Z) {
   V3<S> xv = v3(X), yv = v3(Y);
   S xw = X[3], yw = Y[3];
@@ -240,9 +281,9 @@ template <class S> PP_HD void so3_exp(const S* x, S* q) {
   S th = pp_sqrt(th2);
   S imag, real;
   if (pp_val(th) > Num<T>::eps()) {
-    S h = S(T(0.5)) * th;
-    imag = pp_sin(h) / th;
-    real = pp_cos(h);
+    S sh;
+    pp_sincos(S(T(0.5)) * th, sh, real);
+    imag = sh / th;
   } else {
     S th4 = th2 * th2;
     imag = S(T(0.5)) - S(T(1.0 / 48.0)) * th2 + S(T(1.0 / 3840.0)) * th4;
@@ -294,7 +335,7 @@ template <class S> PP_HD void so3_act_bwd(const S* X, const S* out, const S* g, 
   typedef typename Num<S>::base T;
   put(cross(v3(out), v3(g)), gX);
   gX[3] = S(T(0));
-  put(quat_rotate_inv(v3(X), X[3], v3(g)), gp);
+  put(adj_rotate_T(v3(X), X[3], v3(g)), gp);
 }
 // SO3_Act4 (:626-645): rotate xyz, carry w; X_grad from the 3 leading comps of out/g
 template <class S> PP_HD void so3_act4(const S* X, const S* p, S* out) {
@@ -305,7 +346,7 @@ template <class S> PP_HD void so3_act4_bwd(const S* X, const S* out, const S* g,
   typedef typename Num<S>::base T;
   put(cross(v3(out), v3(g)), gX);
   gX[3] = S(T(0));
-  put(quat_rotate_inv(v3(X), X[3], v3(g)), gp);
+  put(adj_rotate_T(v3(X), X[3], v3(g)), gp);
   gp[3] = g[3];
 }
 
@@ -314,7 +355,7 @@ template <class S> PP_HD void so3_mul(const S* X, const S* Y, S* Z) { quat_mul(X
 template <class S> PP_HD void so3_mul_bwd(const S* X, const S* g, S* gX, S* gY) {
   typedef typename Num<S>::base T;
   gX[0] = g[0]; gX[1] = g[1]; gX[2] = g[2]; gX[3] = S(T(0));
-  put(quat_rotate_inv(v3(X), X[3], v3(g)), gY);   // g @ Adj(X) = R^T g
+  put(adj_rotate_T(v3(X), X[3], v3(g)), gY);   // g @ Adj(X) = R^T g
   gY[3] = S(T(0));
 }
 // SO3_Inv (:933-949)
@@ -323,23 +364,23 @@ template <class S> PP_HD void so3_inv(const S* X, S* Y) {
 }
 template <class S> PP_HD void so3_inv_bwd(const S* Y, const S* g, S* gX) {
   typedef typename Num<S>::base T;
-  put(-quat_rotate_inv(v3(Y), Y[3], v3(g)), gX);
+  put(-adj_rotate_T(v3(Y), Y[3], v3(g)), gX);
   gX[3] = S(T(0));
 }
 // SO3_AdjXa (:728-748): out = R a; X_grad = [-g @ skew(out), 0] = [out x g ... sign below]
 //   (-g^T K(out))^T = -K(out)^T g = K(out) g = out x g ; a_grad = R^T g
-template <class S> PP_HD void so3_adj(const S* X, const S* a, S* out) { put(quat_rotate(v3(X), X[3], v3(a)), out); }
+template <class S> PP_HD void so3_adj(const S* X, const S* a, S* out) { put(adj_rotate(v3(X), X[3], v3(a)), out); }
 template <class S> PP_HD void so3_adj_bwd(const S* X, const S* out, const S* g, S* gX, S* ga) {
   typedef typename Num<S>::base T;
   put(cross(v3(out), v3(g)), gX);
   gX[3] = S(T(0));
-  put(quat_rotate_inv(v3(X), X[3], v3(g)), ga);
+  put(adj_rotate_T(v3(X), X[3], v3(g)), ga);
 }
 // SO3_AdjTXa (:1027-1044): out = R^T a; a_grad = R g; X_grad = [-a @ skew(a_grad),0] = [a_grad x a, 0]
-template <class S> PP_HD void so3_adjt(const S* X, const S* a, S* out) { put(quat_rotate_inv(v3(X), X[3], v3(a)), out); }
+template <class S> PP_HD void so3_adjt(const S* X, const S* a, S* out) { put(adj_rotate_T(v3(X), X[3], v3(a)), out); }
 template <class S> PP_HD void so3_adjt_bwd(const S* X, const S* a, const S* g, S* gX, S* ga) {
   typedef typename Num<S>::base T;
-  V3<S> ag = quat_rotate(v3(X), X[3], v3(g));
+  V3<S> ag = adj_rotate(v3(X), X[3], v3(g));
   put(ag, ga);
   put(cross(ag, v3(a)), gX);
   gX[3] = S(T(0));
@@ -374,19 +415,57 @@ template <class S> PP_HD void so3_jr(const S* x, S* J) {
 // ---------------------------------------------------------------------------------------
 // SE3
 // ---------------------------------------------------------------------------------------
-// se3_Exp.forward (operation.py:401-405): t = Jl(phi) tau, q = Exp(phi)
+// se3_Exp.forward (operation.py:401-405): t = Jl(phi) tau, q = Exp(phi).  One sincos of the
+// half angle feeds the quaternion and both Jl coefficients (sin t = 2 sin(t/2) cos(t/2)).
 template <class S> PP_HD void se3_exp(const S* x, S* X) {
+  typedef typename Num<S>::base T;
   V3<S> tau = v3(x), phi = v3(x + 3);
-  S B, C;
-  rot_coef_BC(norm2(phi), B, C);
+  S th2 = norm2(phi);
+  S th = pp_sqrt(th2);
+  S sh = S(T(0)), ch = S(T(1)), imag, B, C;
+  bool big = pp_val(th) > Num<T>::eps();
+  if (big) {
+    pp_sincos(S(T(0.5)) * th, sh, ch);
+    imag = sh / th;
+  } else {   // so3_Exp Taylor branch (operation.py:354-355)
+    S th4 = th2 * th2;
+    imag = S(T(0.5)) - S(T(1.0 / 48.0)) * th2 + S(T(1.0 / 3840.0)) * th4;
+    ch = S(T(1.0)) - S(T(1.0 / 8.0)) * th2 + S(T(1.0 / 384.0)) * th4;
+  }
+  if (pp_val(th2) < Num<T>::series2()) {
+    rot_coef_BC(th2, B, C);
+  } else {
+    B = S(T(2)) * sh * sh / th2;
+    C = (th - S(T(2)) * sh * ch) / (th2 * th);
+  }
   put(jl_apply(B, C, phi, tau), X);
-  so3_exp(x + 3, X + 3);
+  put(imag * phi, X + 3);
+  X[6] = ch;
 }
-// SE3_Log.forward (:376-382): phi = Log(q), tau = Jl_inv(phi) t
+// SE3_Log.forward (:376-382): phi = Log(q), tau = Jl_inv(phi) t.  In the regular branch of
+// SO3_Log (|v| > eps, |w| > eps) the half angle is atan(|v|/w), so the cot(theta/2) that
+// so3_Jl_inv needs (operation.py:29-30) is exactly |w|/|v| -- no trigonometric call at all.
 template <class S> PP_HD void se3_log(const S* X, S* x) {
-  so3_log(X + 3, x + 3);
-  V3<S> phi = v3(x + 3);
-  put(jlinv_apply(rot_coef_F(norm2(phi)), phi, v3(X)), x);
+  typedef typename Num<S>::base T;
+  V3<S> v = v3(X + 3);
+  S w = X[6];
+  S vn = pp_sqrt(norm2(v));
+  if (pp_val(vn) > Num<T>::eps() && pp_val(pp_abs(w)) > Num<T>::eps()) {
+    S half = pp_atan(vn / w);
+    V3<S> phi = pp_nan_to_num(S(T(2)) * half / vn) * v;
+    put(phi, x + 3);
+    S th2 = norm2(phi);
+    S F;
+    if (pp_val(th2) < Num<T>::series2())
+      F = rot_coef_F(th2);
+    else
+      F = pp_nan_to_num((S(T(1)) - pp_abs(half) * pp_abs(w) / vn) / th2);
+    put(jlinv_apply(F, phi, v3(X)), x);
+  } else {
+    so3_log(X + 3, x + 3);
+    V3<S> phi = v3(x + 3);
+    put(jlinv_apply(rot_coef_F(norm2(phi)), phi, v3(X)), x);
+  }
 }
 // se3_Exp.backward (:413-418): g[:6] @ se3_Jl(x);  se3_Jl = [[J,Q],[0,J]]  (:61-65)
 //   out_tau = J^T g_tau ; out_phi = Q^T g_tau + J^T g_phi ; J^T = J(-phi), Q^T = Q(-tau,-phi)
@@ -425,7 +504,7 @@ template <class S> PP_HD void se3_act_bwd(const S* X, const S* out, const S* g, 
   gX[0] = g[0]; gX[1] = g[1]; gX[2] = g[2];
   put(cross(v3(out), v3(g)), gX + 3);
   gX[6] = S(T(0));
-  put(quat_rotate_inv(v3(X + 3), X[6], v3(g)), gp);
+  put(adj_rotate_T(v3(X + 3), X[6], v3(g)), gp);
 }
 // SE3_Act4 (:651-671): t = R p3 + t*p4, out4 = p4
 //   X_grad = g @ SE3_Act4_Jacobian(out) (:229-234): J[:3,:3] = I*out4, J[:3,3:] = skew(-out3); row 4 zero
@@ -440,7 +519,7 @@ template <class S> PP_HD void se3_act4_bwd(const S* X, const S* out, const S* g,
   put(out[3] * g3, gX);
   put(cross(v3(out), g3), gX + 3);
   gX[6] = S(T(0));
-  put(quat_rotate_inv(v3(X + 3), X[6], g3), gp);
+  put(adj_rotate_T(v3(X + 3), X[6], g3), gp);
   gp[3] = dot(v3(X), g3) + g[3];
 }
 // SE3_Mul (:858-877)
@@ -454,14 +533,14 @@ template <class S> PP_HD void se3_mul(const S* X, const S* Y, S* Z) {
 template <class S> PP_HD void se3_adjT_apply(const S* X, const V3<S>& gt, const V3<S>& gp, V3<S>& ot, V3<S>& op) {
   V3<S> qv = v3(X + 3);
   S qw = X[6];
-  ot = quat_rotate_inv(qv, qw, gt);
-  op = quat_rotate_inv(qv, qw, cross(gt, v3(X)) + gp);
+  ot = adj_rotate_T(qv, qw, gt);
+  op = adj_rotate_T(qv, qw, cross(gt, v3(X)) + gp);
 }
 template <class S> PP_HD void se3_adj_apply(const S* X, const V3<S>& u, const V3<S>& w, V3<S>& ot, V3<S>& op) {
   V3<S> qv = v3(X + 3);
   S qw = X[6];
-  op = quat_rotate(qv, qw, w);
-  ot = quat_rotate(qv, qw, u) + cross(v3(X), op);
+  op = adj_rotate(qv, qw, w);
+  ot = adj_rotate(qv, qw, u) + cross(v3(X), op);
 }
 template <class S> PP_HD void se3_mul_bwd(const S* X, const S* g, S* gX, S* gY) {
   typedef typename Num<S>::base T;
@@ -572,7 +651,7 @@ template <class S> PP_HD void rxso3_act_bwd(const S* X, const S* out, const S* g
   put(cross(v3(out), v3(g)), gX);
   gX[3] = dot(v3(g), v3(out));
   gX[4] = S(T(0));
-  put(X[4] * quat_rotate_inv(v3(X), X[3], v3(g)), gp);
+  put(X[4] * adj_rotate_T(v3(X), X[3], v3(g)), gp);
 }
 template <class S> PP_HD void rxso3_act4(const S* X, const S* p, S* out) {    // :677-680
   rxso3_act(X, p, out);
@@ -593,7 +672,7 @@ template <class S> PP_HD void rxso3_mul_bwd(const S* X, const S* g, S* gX, S* gY
   typedef typename Num<S>::base T;
   for (int i = 0; i < 4; ++i) gX[i] = g[i];
   gX[4] = S(T(0));
-  put(quat_rotate_inv(v3(X), X[3], v3(g)), gY);
+  put(adj_rotate_T(v3(X), X[3], v3(g)), gY);
   gY[3] = g[3];
   gY[4] = S(T(0));
 }
@@ -604,12 +683,12 @@ template <class S> PP_HD void rxso3_inv(const S* X, S* Y) {                   //
 }
 template <class S> PP_HD void rxso3_inv_bwd(const S* Y, const S* g, S* gX) {  // :992-997
   typedef typename Num<S>::base T;
-  put(-quat_rotate_inv(v3(Y), Y[3], v3(g)), gX);
+  put(-adj_rotate_T(v3(Y), Y[3], v3(g)), gX);
   gX[3] = -g[3];
   gX[4] = S(T(0));
 }
 template <class S> PP_HD void rxso3_adj(const S* X, const S* a, S* out) {     // :780-783
-  put(quat_rotate(v3(X), X[3], v3(a)), out);
+  put(adj_rotate(v3(X), X[3], v3(a)), out);
   out[3] = a[3];
 }
 // RxSO3_AdjXa.backward (:795-800): X_grad = -g @ rxso3_adj(out) (4x4 with skew(out3) top-left, :142-145)
@@ -618,16 +697,16 @@ template <class S> PP_HD void rxso3_adj_bwd(const S* X, const S* out, const S* g
   put(cross(v3(out), v3(g)), gX);
   gX[3] = S(T(0));
   gX[4] = S(T(0));
-  put(quat_rotate_inv(v3(X), X[3], v3(g)), ga);
+  put(adj_rotate_T(v3(X), X[3], v3(g)), ga);
   ga[3] = g[3];
 }
 template <class S> PP_HD void rxso3_adjt(const S* X, const S* a, S* out) {    // :1073-1076
-  put(quat_rotate_inv(v3(X), X[3], v3(a)), out);
+  put(adj_rotate_T(v3(X), X[3], v3(a)), out);
   out[3] = a[3];
 }
 template <class S> PP_HD void rxso3_adjt_bwd(const S* X, const S* a, const S* g, S* gX, S* ga) {  // :1084-1090
   typedef typename Num<S>::base T;
-  V3<S> ag = quat_rotate(v3(X), X[3], v3(g));
+  V3<S> ag = adj_rotate(v3(X), X[3], v3(g));
   put(ag, ga);
   ga[3] = g[3];
   put(cross(ag, v3(a)), gX);
@@ -754,7 +833,7 @@ template <class S> PP_HD void sim3_act_bwd(const S* X, const S* out, const S* g,
   put(cross(v3(out), v3(g)), gX + 3);
   gX[6] = dot(v3(g), v3(out));
   gX[7] = S(T(0));
-  put(X[7] * quat_rotate_inv(v3(X + 3), X[6], v3(g)), gp);
+  put(X[7] * adj_rotate_T(v3(X + 3), X[6], v3(g)), gp);
 }
 template <class S> PP_HD void sim3_act4(const S* X, const S* p, S* out) {     // :702-706
   put(X[7] * quat_rotate(v3(X + 3), X[6], v3(p)) + p[3] * v3(X), out);
@@ -768,7 +847,7 @@ template <class S> PP_HD void sim3_act4_bwd(const S* X, const S* out, const S* g
   put(cross(v3(out), g3), gX + 3);
   gX[6] = dot(g3, v3(out));
   gX[7] = S(T(0));
-  put(X[7] * quat_rotate_inv(v3(X + 3), X[6], g3), gp);
+  put(X[7] * adj_rotate_T(v3(X + 3), X[6], g3), gp);
   gp[3] = dot(v3(X), g3) + g[3];
 }
 template <class S> PP_HD void sim3_mul(const S* X, const S* Y, S* Z) {        // :908-912
@@ -783,8 +862,8 @@ template <class S> PP_HD void sim3_adj_apply(const S* X, const S* a, S* o) {
   V3<S> qv = v3(X + 3);
   S qw = X[6];
   V3<S> t = v3(X);
-  V3<S> rw = quat_rotate(qv, qw, v3(a + 3));
-  put(X[7] * quat_rotate(qv, qw, v3(a)) + cross(t, rw) - a[6] * t, o);
+  V3<S> rw = adj_rotate(qv, qw, v3(a + 3));
+  put(X[7] * adj_rotate(qv, qw, v3(a)) + cross(t, rw) - a[6] * t, o);
   put(rw, o + 3);
   o[6] = a[6];
 }
@@ -792,8 +871,8 @@ template <class S> PP_HD void sim3_adjT_apply(const S* X, const S* g, S* o) {
   V3<S> qv = v3(X + 3);
   S qw = X[6];
   V3<S> t = v3(X), gt = v3(g);
-  put(X[7] * quat_rotate_inv(qv, qw, gt), o);
-  put(quat_rotate_inv(qv, qw, cross(gt, t) + v3(g + 3)), o + 3);
+  put(X[7] * adj_rotate_T(qv, qw, gt), o);
+  put(adj_rotate_T(qv, qw, cross(gt, t) + v3(g + 3)), o + 3);
   o[6] = g[6] - dot(gt, t);
 }
 template <class S> PP_HD void sim3_mul_bwd(const S* X, const S* g, S* gX, S* gY) {   // :921-927

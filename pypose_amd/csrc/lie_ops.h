@@ -4,7 +4,7 @@
 #include "rowmap.h"
 
 // Defines functors Op_<g>_<op> for a group with algebra width DA and group width DG.
-#define PPLIE_DEFINE_GROUP(g, DA, DG)                                            \
+#define PPLIE_DEFINE_GROUP(g, DA, DG, RPT_LOG)                                          \
   namespace pplie {                                                              \
   PPLIE_OP_1_1(Op_##g##_exp_fwd, g##_exp, DA, DG)                                \
   PPLIE_OP_2_1(Op_##g##_exp_bwd, g##_exp_bwd, DA, DG, DA)                        \
@@ -26,7 +26,7 @@
   }                                                                              \
   PPLIE_EXPORT(pplie_##g##_exp_fwd, pplie::Op_##g##_exp_fwd)                     \
   PPLIE_EXPORT(pplie_##g##_exp_bwd, pplie::Op_##g##_exp_bwd)                     \
-  PPLIE_EXPORT(pplie_##g##_log_fwd, pplie::Op_##g##_log_fwd)                     \
+  PPLIE_EXPORT_RPT(pplie_##g##_log_fwd, pplie::Op_##g##_log_fwd, RPT_LOG, 1)     \
   PPLIE_EXPORT(pplie_##g##_log_bwd, pplie::Op_##g##_log_bwd)                     \
   PPLIE_EXPORT(pplie_##g##_inv_fwd, pplie::Op_##g##_inv_fwd)                     \
   PPLIE_EXPORT(pplie_##g##_inv_bwd, pplie::Op_##g##_inv_bwd)                     \

@@ -10,9 +10,10 @@
 //
 //   HBM --dwordx4--> LDS(in slabs) --row/lane--> VGPR --Op::apply--> LDS(out slabs) --dwordx4--> HBM
 //
-// Grid: min(#tiles, cap) blocks, grid-stride over tiles (a launch fills all 256 CUs / 8 XCDs
-// many times over at the sizes this library targets; there is no inter-tile reuse, so no
-// XCD-specific tile mapping is needed -- each tile is touched by exactly one workgroup).
+// Grid: one workgroup per tile (a launch fills all 256 CUs / 8 XCDs many times over at the
+// sizes this library targets; there is no inter-tile reuse, so no XCD-specific tile mapping is
+// needed -- each tile is touched by exactly one workgroup, consecutive tiles land on
+// consecutive XCDs and stream disjoint HBM pages).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -186,8 +187,10 @@ rowmap_direct_kernel(const T* __restrict__ i0, const T* __restrict__ i1, const T
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
-// grid cap: 256 CUs x 8 resident 256-thread blocks is the most the chip holds at once
-constexpr int kGridCap = 256 * 8;
+// One tile per workgroup (no grid-stride cap) measured fastest on MI355X at 10M rows
+// (profiles/r01/tune_rowmap_first.json: 6.3 TB/s uncapped vs 5.3-5.7 TB/s capped at 2048/4096);
+// the grid-stride loop only engages beyond 2^30 tiles.
+constexpr int kGridCap = 1 << 30;
 
 template <class T, class Op, int RPT = 2, int BLOCK = 256>
 int launch_rowmap(const void* i0, const void* i1, const void* i2, void* o0, void* o1, int64_t n, void* stream,
@@ -248,15 +251,18 @@ int launch_rowmap_direct(const void* i0, const void* i1, const void* i2, void* o
     static PP_HD void apply(const T* a, const T* b, const T* c, T* o, T* p) { FN<T>(a, b, c, o, p); } \
   };
 
-// C-ABI export of one op in both precisions (uniform signature, see include/pplie.h)
-#define PPLIE_EXPORT(SYM, OP)                                                                                    \
+// C-ABI export of one op in both precisions (uniform signature, see include/pplie.h).
+// RPT = rows per lane per tile (tile = RPT * 256 rows): 2 by default; ops whose slab sizes are
+// not a whole number of 256 x 16 B chunks at RPT=2 (odd widths) may measure faster at 4.
+#define PPLIE_EXPORT_RPT(SYM, OP, RPT32, RPT64)                                                                  \
   extern "C" int SYM##_f32(const void* i0, const void* i1, const void* i2, void* o0, void* o1, int64_t n,        \
                            void* stream) {                                                                       \
-    return pplie::launch_rowmap<float, OP<float>>(i0, i1, i2, o0, o1, n, stream);                                \
+    return pplie::launch_rowmap<float, OP<float>, RPT32>(i0, i1, i2, o0, o1, n, stream);                         \
   }                                                                                                              \
   extern "C" int SYM##_f64(const void* i0, const void* i1, const void* i2, void* o0, void* o1, int64_t n,        \
                            void* stream) {                                                                       \
-    return pplie::launch_rowmap<double, OP<double>>(i0, i1, i2, o0, o1, n, stream);                              \
+    return pplie::launch_rowmap<double, OP<double>, RPT64>(i0, i1, i2, o0, o1, n, stream);                       \
   }
+#define PPLIE_EXPORT(SYM, OP) PPLIE_EXPORT_RPT(SYM, OP, 2, 1)
 
 }  // namespace pplie

@@ -1,0 +1,239 @@
+"""The 32 Lie-group ``torch.autograd.Function`` classes, backed by the HIP library.
+
+Host-side mirror of ``pypose/lietensor/operation.py:304-1113`` (same class names, same argument
+meaning, same gradient convention: gradients w.r.t. a *group* element live in the left tangent
+space, zero-padded to the embedding width).  Where the reference composes 20-150 eager aten
+ops and materialises [B,3,3]..[B,7,7] temporaries per call, every forward and every backward
+here is ONE kernel launch through the C ABI (``include/pplie.h``), reading/writing exactly the
+algorithmic bytes.
+
+Each class is generated from a small table (op kind x group); each has
+
+* ``forward(*inputs)``      -> ``pplie_<g>_<op>_fwd``,
+* ``setup_context``         saving what the backward kernel reads,
+* ``backward``              -> a hidden, non-differentiable ``*_Bwd`` Function wrapping
+                              ``pplie_<g>_<op>_bwd`` (so that the backward itself is vmappable),
+* ``vmap``                  row-wise ops: the vmapped dim is folded into the row dimension,
+                              which is what ``jacobian(vectorize=True)`` (optim/functional.py)
+                              and ``torch.func.jacrev`` need (the reference relies on
+                              ``generate_vmap_rule = True``).
+
+There is no CPU implementation: tensors must live on a HIP device (see ``_C.row_op``).
+"""
+from __future__ import annotations
+
+import torch
+
+from .. import _C
+
+# (algebra width, group width)
+_GROUPS = {"so3": (3, 4), "se3": (6, 7), "sim3": (7, 8), "rxso3": (4, 5)}
+_CAP = {"so3": "SO3", "se3": "SE3", "sim3": "Sim3", "rxso3": "RxSO3"}
+
+
+def _rows(t: torch.Tensor, width: int) -> torch.Tensor:
+    if t.shape[-1] != width:
+        raise ValueError(f"expected last dimension {width}, got shape {tuple(t.shape)}")
+    return t.reshape(-1, width).contiguous()
+
+
+_is_legacy_batched = torch._C._functorch.is_legacy_batchedtensor
+
+
+def _legacy_level():
+    lvl = torch._C._vmapmode_increment_nesting() - 1
+    torch._C._vmapmode_decrement_nesting()
+    return lvl
+
+
+def _launch(name, ins, in_widths, out_widths):
+    """Broadcast leading dims, flatten to rows, launch, un-flatten."""
+    if any(_is_legacy_batched(t) for t in ins):
+        # torch.autograd.grad(is_grads_batched=True) -- what jacobian(vectorize=True) uses -- runs
+        # the backward under the *legacy* vmap, which does not consult Function.vmap: peel the
+        # batch dim off by hand (row-wise op: it simply joins the leading dims) and put it back.
+        lvl = _legacy_level()
+        phys = [torch._remove_batch_dim(t, lvl, 1, 0) if _is_legacy_batched(t) else None for t in ins]
+        bsz = next(p.shape[0] for p in phys if p is not None)
+        phys = [p if p is not None else t.unsqueeze(0).expand((bsz,) + tuple(t.shape)) for p, t in zip(phys, ins)]
+        outs = _launch(name, phys, in_widths, out_widths)
+        return tuple(torch._add_batch_dim(o, 0, lvl) for o in outs)
+    lead = torch.broadcast_shapes(*[t.shape[:-1] for t in ins])
+    flat = []
+    for t, w in zip(ins, in_widths):
+        if t.shape[:-1] != lead:
+            t = t.expand(lead + (t.shape[-1],))
+        flat.append(_rows(t, w))
+    outs = _C.row_op(name, flat, out_widths)
+    return tuple(o.view(lead + (w,)) for o, w in zip(outs, out_widths))
+
+
+def _fold_vmap(in_dims, args):
+    """Move every vmapped dim to the front; expand un-batched args to the batch size."""
+    bsz = next(a.shape[d] for a, d in zip(args, in_dims) if d is not None)
+    out = []
+    for a, d in zip(args, in_dims):
+        if d is None:
+            out.append(a.unsqueeze(0).expand((bsz,) + tuple(a.shape)))
+        else:
+            out.append(a.movedim(d, 0))
+    return out
+
+
+def _make_bwd(qualname, kernel, in_widths, out_widths):
+    """Hidden Function running one backward kernel (non-differentiable, vmappable)."""
+    single = len(out_widths) == 1
+
+    class _Bwd(torch.autograd.Function):
+        @staticmethod
+        def forward(*ins):
+            outs = _launch(kernel, ins, in_widths, out_widths)
+            return outs[0] if single else outs
+
+        @staticmethod
+        def setup_context(ctx, inputs, output):
+            return
+
+        @staticmethod
+        def backward(ctx, *grads):
+            raise NotImplementedError(f"{qualname}: double backward is not supported")
+
+        @staticmethod
+        def vmap(info, in_dims, *ins):
+            res = _Bwd.apply(*_fold_vmap(in_dims, ins))
+            return (res, 0) if single else (res, (0,) * len(out_widths))
+
+    _Bwd.__name__ = _Bwd.__qualname__ = qualname
+    return _Bwd
+
+
+def _make_fwd(clsname, g, kind, doc):
+    da, dg = _GROUPS[g]
+    # kind -> (fwd input widths, fwd output width, bwd input widths, bwd output widths, what bwd reads)
+    table = {
+        "exp": ((da,), dg, (da, dg), (da,), "in0"),
+        "log": ((dg,), da, (da, da), (dg,), "out"),
+        "inv": ((dg,), dg, (dg, dg), (dg,), "out"),
+        "mul": ((dg, dg), dg, (dg, dg), (dg, dg), "in0"),
+        "act": ((dg, 3), 3, (dg, 3, 3), (dg, 3), "in0,out"),
+        "act4": ((dg, 4), 4, (dg, 4, 4), (dg, 4), "in0,out"),
+        "adj": ((dg, da), da, (dg, da, da), (dg, da), "in0,out"),
+        "adjt": ((dg, da), da, (dg, da, da), (dg, da), "in0,in1"),
+    }
+    fin, fout, bin_, bout, reads = table[kind]
+    fwd_kernel, bwd_kernel = f"{g}_{kind}_fwd", f"{g}_{kind}_bwd"
+    Bwd = _make_bwd(clsname + "_Bwd", bwd_kernel, bin_, bout)
+
+    class _Fn(torch.autograd.Function):
+        __doc__ = doc
+
+        @staticmethod
+        def forward(*ins):
+            return _launch(fwd_kernel, ins, fin, (fout,))[0]
+
+        @staticmethod
+        def setup_context(ctx, inputs, output):
+            saved = []
+            for key in reads.split(","):
+                saved.append(output if key == "out" else inputs[int(key[2:])])
+            ctx.save_for_backward(*saved)
+
+        @staticmethod
+        def backward(ctx, grad_output):
+            res = Bwd.apply(*ctx.saved_tensors, grad_output)
+            return res if isinstance(res, tuple) else res
+
+        @staticmethod
+        def vmap(info, in_dims, *ins):
+            return _Fn.apply(*_fold_vmap(in_dims, ins)), 0
+
+    _Fn.__name__ = _Fn.__qualname__ = clsname
+    _Fn._bwd = Bwd
+    return _Fn
+
+
+_DOC = {
+    "exp": "{g}_Exp (reference operation.py: so3 :340, se3 :398, rxso3 :444, sim3 :492)",
+    "log": "{G}_Log (reference operation.py: SO3 :304, SE3 :373, RxSO3 :421, Sim3 :467)",
+    "inv": "{G}_Inv (reference operation.py:930-1021)",
+    "mul": "{G}_Mul (reference operation.py:829-927)",
+    "act": "{G}_Act (reference operation.py:516-620)",
+    "act4": "{G}_Act4 (reference operation.py:623-722)",
+    "adj": "{G}_AdjXa (reference operation.py:725-826)",
+    "adjt": "{G}_AdjTXa (reference operation.py:1024-1113)",
+}
+_SUFFIX = {"log": "_Log", "inv": "_Inv", "mul": "_Mul", "act": "_Act", "act4": "_Act4", "adj": "_AdjXa", "adjt": "_AdjTXa"}
+
+__all__ = []
+for _g in _GROUPS:
+    for _kind in _DOC:
+        _name = f"{_g}_Exp" if _kind == "exp" else _CAP[_g] + _SUFFIX[_kind]
+        globals()[_name] = _make_fwd(_name, _g, _kind, _DOC[_kind].format(g=_g, G=_CAP[_g]))
+        __all__.append(_name)
+
+
+# ---------------------------------------------------------------------------------------
+# Jinvp: reference differentiates through so3_Jl_inv/calcQ with plain autograd
+# (lietensor.py:257-264, 422-429, 556-563, 700-707).  Forward is one fused kernel.
+# ---------------------------------------------------------------------------------------
+def _make_jinvp(g):
+    da, dg = _GROUPS[g]
+    kernel = f"{g}_jinvp_fwd"
+
+    class _Jinvp(torch.autograd.Function):
+        @staticmethod
+        def forward(X, p):
+            return _launch(kernel, (X, p), (dg, da), (da,))[0]
+
+        @staticmethod
+        def setup_context(ctx, inputs, output):
+            ctx.save_for_backward(*inputs)
+
+        @staticmethod
+        def backward(ctx, grad_output):
+            X, p = ctx.saved_tensors
+            if _C.library().has(f"pplie_{g}_jinvp_bwd_f32"):
+                gX, gp = _launch(f"{g}_jinvp_bwd", (X, p, grad_output), (dg, da, da), (dg, da))
+                return gX, gp
+            raise NotImplementedError(f"{_CAP[g]} Jinvp backward kernel is not built")
+
+        @staticmethod
+        def vmap(info, in_dims, *ins):
+            return _Jinvp.apply(*_fold_vmap(in_dims, ins)), 0
+
+    _Jinvp.__name__ = _Jinvp.__qualname__ = _CAP[g] + "_Jinvp"
+    return _Jinvp
+
+
+SO3_Jinvp, SE3_Jinvp, Sim3_Jinvp, RxSO3_Jinvp = (_make_jinvp(g) for g in ("so3", "se3", "sim3", "rxso3"))
+
+
+class so3_Jr(torch.autograd.Function):
+    """Right Jacobian of so3 (reference lietensor.py:343-351): [...,3] -> [...,3,3]."""
+
+    @staticmethod
+    def forward(x):
+        return _launch("so3_jr_fwd", (x,), (3,), (9,))[0].unflatten(-1, (3, 3))
+
+    @staticmethod
+    def setup_context(ctx, inputs, output):
+        return
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        raise NotImplementedError("so3.Jr: backward is not provided by the HIP path")
+
+    @staticmethod
+    def vmap(info, in_dims, x):
+        return so3_Jr.apply(*_fold_vmap(in_dims, (x,))), 0
+
+
+def broadcast_inputs(x, y):
+    """Reference operation.py:1116-1125: broadcast leading dims and flatten to rows."""
+    if y is None:
+        return (x.reshape(-1, x.shape[-1]).contiguous(),), tuple(x.shape[:-1])
+    out_shape = torch.broadcast_shapes(x.shape[:-1], y.shape[:-1])
+    shape = out_shape if out_shape != torch.Size([]) else (1,)
+    x = x.expand(tuple(shape) + (x.shape[-1],)).reshape(-1, x.shape[-1]).contiguous()
+    y = y.expand(tuple(shape) + (y.shape[-1],)).reshape(-1, y.shape[-1]).contiguous()
+    return (x, y), tuple(out_shape)

@@ -1,0 +1,48 @@
+"""Access to tests/golden/lie_golden.npz (outputs of the real reference, see make_golden.py)."""
+import os
+
+import numpy as np
+
+from oracle import lie_np
+
+_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lie_golden.npz")
+
+
+def load_golden():
+    return dict(np.load(_PATH))
+
+
+def golden_case(G, dname, name):
+    """-> (inputs tuple, expected outputs tuple) for ABI op ``name`` ('se3_exp_bwd', ...)."""
+    if name == "so3_jr_fwd":
+        return (G[f"{dname}/so3/in/x"],), (G[f"{dname}/so3_jr_fwd/out0"],)
+    g, o = name.split("_", 1)
+    I = lambda k: G[f"{dname}/{g}/in/{k}"]
+    F = lambda op: G[f"{dname}/{g}_{op}_fwd/out0"]
+    ins = {
+        "exp_fwd": lambda: (I("x"),), "exp_bwd": lambda: (I("x"), I("g_grp")),
+        "log_fwd": lambda: (I("X"),), "log_bwd": lambda: (F("log"), I("g_alg")),
+        "inv_fwd": lambda: (I("X"),), "inv_bwd": lambda: (F("inv"), I("g_grp")),
+        "mul_fwd": lambda: (I("X"), I("Y")), "mul_bwd": lambda: (I("X"), I("g_grp")),
+        "act_fwd": lambda: (I("X"), I("p3")), "act_bwd": lambda: (I("X"), F("act"), I("g3")),
+        "act4_fwd": lambda: (I("X"), I("p4")), "act4_bwd": lambda: (I("X"), F("act4"), I("g4")),
+        "adj_fwd": lambda: (I("X"), I("a")), "adj_bwd": lambda: (I("X"), F("adj"), I("g_alg")),
+        "adjt_fwd": lambda: (I("X"), I("a")), "adjt_bwd": lambda: (I("X"), I("a"), I("g_alg")),
+        "jinvp_fwd": lambda: (I("X"), I("a")),
+    }[o]()
+    nout = len(lie_np.op_signature(name)[1])
+    outs = tuple(G[f"{dname}/{name}/out{i}"] for i in range(nout))
+    return ins, outs
+
+
+def row_rel_err(got, ref):
+    """max over rows of |got-ref|_2 / max(|ref|_2, tiny), ignoring rows where ref is not finite / huge."""
+    got = np.asarray(got, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    ok = np.isfinite(ref).all(-1) & (np.abs(ref).max(-1) < 1e30)
+    num = np.linalg.norm(got[ok] - ref[ok], axis=-1)
+    den = np.maximum(np.linalg.norm(ref[ok], axis=-1), 1e-300)
+    den = np.where(den < 1e-30, 1.0, den)   # rows whose reference is ~0: absolute error
+    e = num / den
+    e = np.where(np.isnan(e), np.inf, e)
+    return e, ok

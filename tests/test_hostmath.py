@@ -1,0 +1,46 @@
+"""The kernels' per-row arithmetic (pypose_amd/csrc/lie_math.h, compiled here for the host)
+against the reference's golden vectors -- the fp64-anchored protocol of SURVEY.md section 7:
+
+  (1) new-fp32 vs reference-fp64 (inputs = the fp32 golden inputs, up-cast for the reference)
+      <= 1e-5 row-relative on all rows,
+  (2) new-fp64 vs reference-fp64 tight, except where the reference's own closed forms lose
+      digits (tiny theta), where the bound is the reference's cancellation envelope.
+
+This is a check of the arithmetic header on the CPU; the GPU build of the same header is
+checked through the C ABI in tests/test_lie_parity_gpu.py.
+"""
+import numpy as np
+import pytest
+
+from oracle import lie_np
+from tests.golden_util import golden_case, row_rel_err
+from tests.hostmath_util import hostmath_op
+
+ALL_OPS = sorted(lie_np.OPS)
+
+# ops whose reference formulation itself is ill-conditioned on part of the adversarial set
+# sim3_Exp: the reference's C = (exp(s)-1)/s (operation.py:112) loses ~eps/|s| digits at |s| -> 0 (golden row
+# 97 has s = 1e-9 -> 1e-7 relative noise in the reference's own fp64 result); the kernels use expm1.
+LOOSE64 = {"sim3_exp_fwd": 1e-6}
+
+
+@pytest.mark.parametrize("name", ALL_OPS)
+def test_fp64_vs_reference(golden, name):
+    ins, refs = golden_case(golden, "f64", name)
+    outs = hostmath_op(name, ins)
+    for o, r in zip(outs, refs):
+        e, ok = row_rel_err(o, r)
+        assert e.max() < LOOSE64.get(name, 2e-9), (name, e.max(), int(np.argmax(e)))
+        assert np.median(e) < 1e-14, (name, np.median(e))
+
+
+@pytest.mark.parametrize("name", ALL_OPS)
+def test_fp32_vs_reference_fp64(golden, name):
+    ins32, _ = golden_case(golden, "f32", name)
+    # reference-quality answer for exactly these fp32 inputs: the oracle in fp64 (pinned to 1e-11)
+    refs = lie_np.OPS[name](*[a.astype(np.float64) for a in ins32])
+    outs = hostmath_op(name, ins32)
+    for o, r in zip(outs, refs):
+        assert o.dtype == np.float32
+        e, ok = row_rel_err(o, r)
+        assert e.max() < 1e-5, (name, e.max(), int(np.argmax(e)))

@@ -1,0 +1,201 @@
+"""GPU parity of every Lie op, called THROUGH THE C ABI (pypose_amd._C.row_op -> libpplie.so).
+
+  * golden vectors produced by the real reference (tests/golden), fp64 and fp32,
+  * the oracle on seeded random inputs at 100k rows (ragged tile tails, unaligned bases),
+  * size-independent properties at BASELINE's 10M rows (round trips, group axioms).
+Tolerances follow the fp64-anchored protocol (SURVEY.md section 7 / tests/test_hostmath.py):
+fp32 kernels <= 1e-5 row-relative against the reference evaluated in fp64 on the same inputs.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import lie_np
+from tests.golden_util import golden_case, row_rel_err
+
+pytestmark = pytest.mark.gpu
+ALL_OPS = sorted(lie_np.OPS)
+LOOSE64 = {"sim3_exp_fwd": 1e-6}   # reference's (exp(s)-1)/s cancellation, see tests/test_hostmath.py
+
+
+def _dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+def run_hip(name, arrays):
+    from pypose_amd import _C
+    assert _C._test_backend is None
+    ins = [torch.from_numpy(np.ascontiguousarray(a)).to(_dev()) for a in arrays]
+    outs = _C.row_op(name, ins, lie_np.op_signature(name)[1])
+    torch.cuda.synchronize()
+    return tuple(o.cpu().numpy() for o in outs)
+
+
+@pytest.mark.parametrize("name", ALL_OPS)
+def test_golden_fp64(golden, name):
+    ins, refs = golden_case(golden, "f64", name)
+    outs = run_hip(name, ins)
+    for o, r in zip(outs, refs):
+        e, ok = row_rel_err(o, r)
+        assert e.max() < LOOSE64.get(name, 2e-9), (name, e.max(), int(np.argmax(e)))
+        assert np.median(e) < 1e-14
+
+
+@pytest.mark.parametrize("name", ALL_OPS)
+def test_golden_fp32_vs_reference_fp64(golden, name):
+    ins32, _ = golden_case(golden, "f32", name)
+    refs = lie_np.OPS[name](*[a.astype(np.float64) for a in ins32])
+    outs = run_hip(name, ins32)
+    for o, r in zip(outs, refs):
+        assert o.dtype == np.float32
+        e, ok = row_rel_err(o, r)
+        assert e.max() < 1e-5, (name, e.max(), int(np.argmax(e)))
+
+
+def _random_inputs(name, n, dtype, rng):
+    """Random well-conditioned inputs for op ``name`` built from the oracle's own Exp."""
+    g = name.split("_")[0]
+    da, dg = lie_np.GROUPS[g]
+
+    def alg(scale=1.0):
+        d = rng.standard_normal((n, 3))
+        d /= np.linalg.norm(d, axis=-1, keepdims=True)
+        phi = d * rng.standard_normal((n, 1)) * scale
+        parts = {"so3": [phi], "se3": [rng.standard_normal((n, 3)), phi],
+                 "sim3": [rng.standard_normal((n, 3)), phi, 0.3 * rng.standard_normal((n, 1))],
+                 "rxso3": [phi, 0.3 * rng.standard_normal((n, 1))]}[g]
+        return np.concatenate(parts, -1).astype(dtype)
+
+    def grp():
+        return lie_np.OPS[f"{g}_exp_fwd"](alg().astype(np.float64))[0].astype(dtype)
+
+    r = lambda w: rng.standard_normal((n, w)).astype(dtype)
+    iw, _ = lie_np.op_signature(name)
+    kind = name.split("_", 1)[1]
+    if name == "so3_jr_fwd":
+        return [alg()]
+    X = grp()
+    table = {
+        "exp_fwd": lambda: [alg()], "exp_bwd": lambda: [alg(), r(dg)],
+        "log_fwd": lambda: [X], "log_bwd": lambda: [alg(0.7), r(da)],
+        "inv_fwd": lambda: [X], "inv_bwd": lambda: [X, r(dg)],
+        "mul_fwd": lambda: [X, grp()], "mul_bwd": lambda: [X, r(dg)],
+        "act_fwd": lambda: [X, r(3)], "act_bwd": lambda: [X, r(3), r(3)],
+        "act4_fwd": lambda: [X, r(4)], "act4_bwd": lambda: [X, r(4), r(4)],
+        "adj_fwd": lambda: [X, r(da)], "adj_bwd": lambda: [X, r(da), r(da)],
+        "adjt_fwd": lambda: [X, r(da)], "adjt_bwd": lambda: [X, r(da), r(da)],
+        "jinvp_fwd": lambda: [X, r(da)],
+    }
+    return table[kind]()
+
+
+@pytest.mark.parametrize("name", ALL_OPS)
+def test_random_100k_fp32_vs_oracle_fp64(name):
+    n = 100_003                       # not a multiple of the 512-row tile: ragged tail
+    rng = np.random.default_rng(abs(hash(name)) % (2 ** 31))
+    ins = _random_inputs(name, n, np.float32, rng)
+    refs = lie_np.OPS[name](*[a.astype(np.float64) for a in ins])
+    outs = run_hip(name, ins)
+    # rows at the rotation-log singularity (|theta| ~ pi, 2pi) are ill-conditioned w.r.t. the
+    # fp32 rounding of the INPUT; they are excluded by the 99.99% quantile, the bulk must be tight
+    for o, r in zip(outs, refs):
+        e, ok = row_rel_err(o, r)
+        assert np.quantile(e, 0.9999) < 1e-5, (name, np.quantile(e, 0.9999))
+        assert np.median(e) < 2e-7, (name, np.median(e))
+
+
+@pytest.mark.parametrize("name", ["se3_exp_fwd", "se3_log_fwd", "se3_mul_fwd", "sim3_act_bwd", "so3_log_bwd"])
+def test_random_fp64_vs_oracle(name):
+    n = 20_001
+    rng = np.random.default_rng(5)
+    ins = _random_inputs(name, n, np.float64, rng)
+    refs = lie_np.OPS[name](*ins)
+    outs = run_hip(name, ins)
+    for o, r in zip(outs, refs):
+        e, ok = row_rel_err(o, r)
+        assert np.quantile(e, 0.999) < 1e-9 and np.median(e) < 1e-14, (name, e.max())
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 63, 64, 511, 512, 513, 1025, 4096 + 7])
+def test_ragged_sizes_and_unaligned_views(n):
+    from pypose_amd import _C
+    dev = _dev()
+    rng = np.random.default_rng(n)
+    x = rng.standard_normal((n, 6)).astype(np.float32)
+    ref = lie_np.se3_exp_fwd(x.astype(np.float64))[0] if n else np.zeros((0, 7))
+    (X,) = _C.row_op("se3_exp_fwd", [torch.from_numpy(x).to(dev)], [7])
+    assert X.shape == (n, 7)
+    if n:
+        e, _ = row_rel_err(X.cpu().numpy(), ref)
+        assert e.max() < 1e-5
+        # an input whose base pointer is only 4-byte aligned takes the non-vector path: same bits
+        buf = torch.zeros(n * 6 + 1, device=dev)
+        buf[1:] = torch.from_numpy(x).to(dev).flatten()
+        xv = buf[1:].view(n, 6)
+        assert xv.data_ptr() % 16 != 0 and xv.is_contiguous()
+        (X2,) = _C.row_op("se3_exp_fwd", [xv], [7])
+        assert torch.equal(X, X2)
+
+
+def test_bad_arguments_return_codes():
+    import ctypes
+    from pypose_amd import _C
+    fn = _C.library().symbol("pplie_se3_exp_fwd_f32")
+    null = ctypes.c_void_p(0)
+    assert fn(null, null, null, null, null, ctypes.c_int64(-1), null) == -1
+    assert fn(null, null, null, null, null, ctypes.c_int64(5), null) == -1
+    assert fn(null, null, null, null, null, ctypes.c_int64(0), null) == 0
+
+
+def test_properties_at_full_size():
+    """BASELINE config[1] size (10M rows, fp32): size-independent invariants, checked on device."""
+    import pypose_amd as pp
+    dev = _dev()
+    n = 10_000_000
+    torch.manual_seed(0)
+    x = pp.randn_se3(n, device=dev)
+    X = x.Exp()
+    # |q| = 1
+    qn = X.tensor()[:, 3:].norm(dim=-1)
+    assert (qn - 1).abs().max().item() < 1e-6
+    # Log(Exp(x)) == x where |phi| < pi - 0.1 (the principal branch)
+    th = x.tensor()[:, 3:].norm(dim=-1)
+    y = X.Log()
+    sel = th < np.pi - 0.1
+    err = ((y.tensor() - x.tensor()).norm(dim=-1) / x.tensor().norm(dim=-1))[sel]
+    assert err.max().item() < 2e-5 and err.median().item() < 3e-7
+    # X * X^-1 == identity ; (X^-1)^-1 == X
+    I = (X * X.Inv()).tensor()
+    ident = torch.tensor([0, 0, 0, 0, 0, 0, 1.0], device=dev)
+    assert (I - ident).abs().max().item() < 5e-5
+    assert (X.Inv().Inv().tensor() - X.tensor()).abs().max().item() < 5e-5
+    # Act is linear in p and Mul is compatible with Act: (X*Y).p == X.(Y.p)
+    Y = pp.SE3(X.tensor().flip(0))
+    p = torch.randn(n, 3, device=dev)
+    lhs, rhs = (X * Y).Act(p), X.Act(Y.Act(p))
+    assert ((lhs - rhs).norm(dim=-1) / (1 + rhs.norm(dim=-1))).max().item() < 1e-5
+    # Adj identity: Exp(Adj_X a) * X == X * Exp(a)
+    a = pp.randn_se3(n, sigma=0.2, device=dev)
+    d = ((X.Adj(a).Exp() * X).Inv() * (X * a.Exp())).Log().tensor().norm(dim=-1)
+    assert d.max().item() < 5e-4 and d.median().item() < 5e-6
+
+
+def test_c1_fwd_bwd_through_lietensor_api():
+    """BASELINE config[0]: pp.randn_se3(1024).Exp().Log() fwd+bwd, through the public API."""
+    import pypose_amd as pp
+    dev = _dev()
+    torch.manual_seed(0)
+    x = pp.randn_se3(1024, requires_grad=True, device=dev)
+    y = x.Exp().Log()
+    y.sum().backward()
+    xn = x.detach().cpu().numpy().astype(np.float64)
+    X = lie_np.se3_exp_fwd(xn)[0]
+    yr = lie_np.se3_log_fwd(X)[0]
+    gX = lie_np.se3_log_bwd(yr, np.ones_like(yr))[0]
+    gx = lie_np.se3_exp_bwd(xn, gX)[0]
+    e, _ = row_rel_err(y.detach().cpu().numpy(), yr)
+    assert np.quantile(e, 0.995) < 1e-5
+    e, _ = row_rel_err(x.grad.cpu().numpy(), gx)
+    assert np.quantile(e, 0.995) < 1e-5
+    assert x.grad.shape == (1024, 6) and x.grad.is_cuda

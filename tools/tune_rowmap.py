@@ -29,14 +29,16 @@ def ref_exp(x):
     a = torch.linalg.cross(phi, tau); t = tau + B * a + C * torch.linalg.cross(phi, a)
     return torch.cat([t, phi * (th / 2).sin() / th, (th / 2).cos()], -1)
 
-def timeit(f, reps=20):
-    for _ in range(3): f()
+def timeit(f, reps=40):
+    """median of per-launch HIP-event durations (ms)"""
+    for _ in range(5): f()
     torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps): f()
-    e1.record(); torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / reps
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for a, b in ev:
+        a.record(); f(); b.record()
+    torch.cuda.synchronize()
+    ts = sorted(a.elapsed_time(b) for a, b in ev)
+    return ts[len(ts) // 2]
 
 res = {"N": N, "device": torch.cuda.get_device_name(0), "variants": []}
 # correctness of the production entry points
@@ -62,7 +64,7 @@ for nbytes, label in ((N * 24, "24B/row"), (N * 28, "28B/row")):
 
 for op, fn, src, dst in (("exp", fexp, x, X), ("log", flog, Xp, y)):
     for path, rpt in ((0, 1), (0, 2), (0, 4), (0, 8), (1, 0)):
-        for cap in (1024, 2048, 4096, 1 << 30):
+        for cap in (4096, 1 << 30):
             code = fn(path, rpt, cap, src.data_ptr(), dst.data_ptr(), N, st)
             assert code == 0, code
             ms = timeit(lambda: fn(path, rpt, cap, src.data_ptr(), dst.data_ptr(), N, st))
