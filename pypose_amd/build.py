@@ -25,7 +25,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # fp32 a/b and sqrt lower to v_rcp/v_sqrt (<= 2.5 ulp) instead of the ~10-instruction correctly
 # rounded sequences: the kernels sit close enough to the VALU roof for that to matter.
 CFLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc",
-          "-fno-hip-fp32-correctly-rounded-divide-sqrt",
+          "-fno-hip-fp32-correctly-rounded-divide-sqrt", "-munsafe-fp-atomics",
           f"-I{CSRC}", f"-I{PKG.parent / 'include'}"]
 
 

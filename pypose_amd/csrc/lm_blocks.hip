@@ -1,0 +1,148 @@
+// lm_blocks.hip -- per-problem normal equations and damped Cholesky solves for the
+// block-structured Levenberg-Marquardt / Gauss-Newton paths (include/pplie.h, "LM blocks").
+//
+// Reference: pypose/optim/optimizer.py:655-668 builds ONE dense A = J^T W J of size
+// [sum N_param]^2 and factorises it with LAPACK (solver.py:213-216).  When the Jacobian is
+// block diagonal (B independent problems: J_b is d_res x d_par with d_* <= 8) that is B tiny
+// SPD systems; here each lane owns one problem, forms A_b and g_b in registers and solves it
+// with a fully unrolled Cholesky.  Same row-map shell as the Lie ops: slabs of J / r / W are
+// streamed HBM -> LDS -> registers with dwordx4 accesses.
+#include "rowmap.h"
+
+namespace pplie {
+
+// A = J^T W J (DPxDP, row-major), g = J^T W r   (W optional, not assumed symmetric:
+// the reference computes J_T = J.T @ weight, A = J_T @ J, b = -J_T @ R; optimizer.py:655-668)
+template <class T, int DR, int DP, bool HAS_W> struct Op_normal_eq {
+  enum { IW0 = DR * DP, IW1 = DR, IW2 = HAS_W ? DR * DR : 0, OW0 = DP * DP, OW1 = DP };
+  static PP_HD void apply(const T* J, const T* r, const T* W, T* A, T* g) {
+    T JtW[DP * DR];   // (J^T W)[p][k] = sum_i J[i][p] W[i][k]
+#pragma unroll
+    for (int p = 0; p < DP; ++p)
+#pragma unroll
+      for (int k = 0; k < DR; ++k) {
+        if (HAS_W) {
+          T acc = T(0);
+#pragma unroll
+          for (int i = 0; i < DR; ++i) acc += J[i * DP + p] * W[i * DR + k];
+          JtW[p * DR + k] = acc;
+        } else {
+          JtW[p * DR + k] = J[k * DP + p];
+        }
+      }
+#pragma unroll
+    for (int p = 0; p < DP; ++p) {
+#pragma unroll
+      for (int q = 0; q < DP; ++q) {
+        T acc = T(0);
+#pragma unroll
+        for (int k = 0; k < DR; ++k) acc += JtW[p * DR + k] * J[k * DP + q];
+        A[p * DP + q] = acc;
+      }
+      T acc = T(0);
+#pragma unroll
+      for (int k = 0; k < DR; ++k) acc += JtW[p * DR + k] * r[k];
+      g[p] = acc;
+    }
+  }
+};
+
+// x = A^-1 (-g) by Cholesky A = L L^T (lower).  A non-positive pivot yields NaNs in x, which
+// the host turns into the reference's "Cholesky decomposition failed" error (solver.py:214).
+template <class T, int DP> struct Op_chol_solve {
+  enum { IW0 = DP * DP, IW1 = DP, IW2 = 0, OW0 = DP, OW1 = 0 };
+  static PP_HD void apply(const T* A, const T* g, const T*, T* x, T*) {
+    T L[DP * DP];
+#pragma unroll
+    for (int j = 0; j < DP; ++j) {
+      T d = A[j * DP + j];
+#pragma unroll
+      for (int k = 0; k < j; ++k) d -= L[j * DP + k] * L[j * DP + k];
+      T ljj = pp_sqrt(d);          // d <= 0 -> NaN (or 0 -> inf below), propagates to x
+      L[j * DP + j] = ljj;
+      T inv = T(1) / ljj;
+#pragma unroll
+      for (int i = j + 1; i < DP; ++i) {
+        T s = A[i * DP + j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) s -= L[i * DP + k] * L[j * DP + k];
+        L[i * DP + j] = s * inv;
+      }
+    }
+    T y[DP];
+#pragma unroll
+    for (int i = 0; i < DP; ++i) {   // L y = -g
+      T s = -g[i];
+#pragma unroll
+      for (int k = 0; k < i; ++k) s -= L[i * DP + k] * y[k];
+      y[i] = s / L[i * DP + i];
+    }
+#pragma unroll
+    for (int i = DP - 1; i >= 0; --i) {   // L^T x = y
+      T s = y[i];
+#pragma unroll
+      for (int k = i + 1; k < DP; ++k) s -= L[k * DP + i] * x[k];
+      x[i] = s / L[i * DP + i];
+    }
+  }
+};
+
+// 64-lane workgroups: the per-problem slabs are wide (up to 8x8 + 8x8 + 8 + 64 scalars)
+template <class T, int DR, int DP> int normal_eq_launch(const void* J, const void* r, const void* W, void* A, void* g,
+                                                        int64_t n, void* stream) {
+  if (W) return launch_rowmap<T, Op_normal_eq<T, DR, DP, true>, 1, 64>(J, r, W, A, g, n, stream);
+  return launch_rowmap<T, Op_normal_eq<T, DR, DP, false>, 1, 64>(J, r, nullptr, A, g, n, stream);
+}
+
+template <class T, int DR> int normal_eq_dp(int dp, const void* J, const void* r, const void* W, void* A, void* g,
+                                            int64_t n, void* stream) {
+  switch (dp) {
+    case 3: return normal_eq_launch<T, DR, 3>(J, r, W, A, g, n, stream);
+    case 4: return normal_eq_launch<T, DR, 4>(J, r, W, A, g, n, stream);
+    case 5: return normal_eq_launch<T, DR, 5>(J, r, W, A, g, n, stream);
+    case 6: return normal_eq_launch<T, DR, 6>(J, r, W, A, g, n, stream);
+    case 7: return normal_eq_launch<T, DR, 7>(J, r, W, A, g, n, stream);
+    case 8: return normal_eq_launch<T, DR, 8>(J, r, W, A, g, n, stream);
+  }
+  return PPLIE_EBADARG;
+}
+
+template <class T> int normal_eq_dispatch(int dr, int dp, const void* J, const void* r, const void* W, void* A, void* g,
+                                          int64_t n, void* stream) {
+  switch (dr) {
+    case 3: return normal_eq_dp<T, 3>(dp, J, r, W, A, g, n, stream);
+    case 4: return normal_eq_dp<T, 4>(dp, J, r, W, A, g, n, stream);
+    case 6: return normal_eq_dp<T, 6>(dp, J, r, W, A, g, n, stream);
+    case 7: return normal_eq_dp<T, 7>(dp, J, r, W, A, g, n, stream);
+  }
+  return PPLIE_EBADARG;
+}
+
+template <class T> int chol_dispatch(int dp, const void* A, const void* g, void* x, int64_t n, void* stream) {
+  switch (dp) {
+    case 3: return launch_rowmap<T, Op_chol_solve<T, 3>, 1, 64>(A, g, nullptr, x, nullptr, n, stream);
+    case 4: return launch_rowmap<T, Op_chol_solve<T, 4>, 1, 64>(A, g, nullptr, x, nullptr, n, stream);
+    case 5: return launch_rowmap<T, Op_chol_solve<T, 5>, 1, 64>(A, g, nullptr, x, nullptr, n, stream);
+    case 6: return launch_rowmap<T, Op_chol_solve<T, 6>, 1, 64>(A, g, nullptr, x, nullptr, n, stream);
+    case 7: return launch_rowmap<T, Op_chol_solve<T, 7>, 1, 64>(A, g, nullptr, x, nullptr, n, stream);
+    case 8: return launch_rowmap<T, Op_chol_solve<T, 8>, 1, 64>(A, g, nullptr, x, nullptr, n, stream);
+  }
+  return PPLIE_EBADARG;
+}
+
+}  // namespace pplie
+
+extern "C" int pplie_block_normal_eq_f32(const void* J, const void* r, const void* W, void* A, void* g, int64_t n, int dr,
+                                         int dp, void* stream) {
+  return pplie::normal_eq_dispatch<float>(dr, dp, J, r, W, A, g, n, stream);
+}
+extern "C" int pplie_block_normal_eq_f64(const void* J, const void* r, const void* W, void* A, void* g, int64_t n, int dr,
+                                         int dp, void* stream) {
+  return pplie::normal_eq_dispatch<double>(dr, dp, J, r, W, A, g, n, stream);
+}
+extern "C" int pplie_block_chol_solve_f32(const void* A, const void* g, void* x, int64_t n, int dp, void* stream) {
+  return pplie::chol_dispatch<float>(dp, A, g, x, n, stream);
+}
+extern "C" int pplie_block_chol_solve_f64(const void* A, const void* g, void* x, int64_t n, int dp, void* stream) {
+  return pplie::chol_dispatch<double>(dp, A, g, x, n, stream);
+}

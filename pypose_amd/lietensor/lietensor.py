@@ -36,6 +36,9 @@ index_copy_ select select_scatter index_put index_put_ copy_
 """.split())
 
 
+_gather_recorders = []      # active optim.posegraph.GatherRecorder instances
+
+
 def _raw(t):
     return t.tensor() if isinstance(t, LieTensor) else t
 
@@ -373,7 +376,11 @@ class LieTensor(Tensor):
         kwargs = {} if kwargs is None else kwargs
         plain = tuple(Tensor if issubclass(t, LieTensor) else t for t in types)
         data = Tensor.__torch_function__(func, plain, args, kwargs)
-        if data is None or getattr(func, '__name__', None) not in HANDLED_FUNCTIONS:
+        name = getattr(func, '__name__', None)
+        if _gather_recorders and name == '__getitem__' and len(args) == 2:
+            for rec in _gather_recorders:        # optim/posegraph.py: which rows feed which residual
+                rec.note(args[0], args[1], data)
+        if data is None or name not in HANDLED_FUNCTIONS:
             return data
         flat, _ = tree_flatten(args)
         ltype = next(a.ltype for a in flat if isinstance(a, LieTensor))

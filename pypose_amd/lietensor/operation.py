@@ -40,10 +40,14 @@ def _rows(t: torch.Tensor, width: int) -> torch.Tensor:
 _is_legacy_batched = torch._C._functorch.is_legacy_batchedtensor
 
 
-def _legacy_level():
-    lvl = torch._C._vmapmode_increment_nesting() - 1
-    torch._C._vmapmode_decrement_nesting()
-    return lvl
+def _legacy_level(t):
+    """vmap level of a legacy-batched tensor.  The backward of a GPU graph runs on the autograd
+    engine's device thread, where the (thread-local) vmap nesting counter is not visible, so the
+    level is found by trial: removing the right level leaves a plain tensor."""
+    for lvl in range(1, 9):
+        if not _is_legacy_batched(torch._remove_batch_dim(t, lvl, 1, 0)):
+            return lvl
+    raise RuntimeError("pypose_amd: nested legacy vmap over a Lie op is not supported")
 
 
 def _launch(name, ins, in_widths, out_widths):
@@ -52,7 +56,7 @@ def _launch(name, ins, in_widths, out_widths):
         # torch.autograd.grad(is_grads_batched=True) -- what jacobian(vectorize=True) uses -- runs
         # the backward under the *legacy* vmap, which does not consult Function.vmap: peel the
         # batch dim off by hand (row-wise op: it simply joins the leading dims) and put it back.
-        lvl = _legacy_level()
+        lvl = _legacy_level(next(t for t in ins if _is_legacy_batched(t)))
         phys = [torch._remove_batch_dim(t, lvl, 1, 0) if _is_legacy_batched(t) else None for t in ins]
         bsz = next(p.shape[0] for p in phys if p is not None)
         phys = [p if p is not None else t.unsqueeze(0).expand((bsz,) + tuple(t.shape)) for p, t in zip(phys, ins)]

@@ -1,0 +1,336 @@
+"""Gauss-Newton and Levenberg-Marquardt (host-side mirror of pypose/optim/optimizer.py).
+
+Same constructor and ``step(input, target=None, weight=None)`` contract as the reference
+(GN :239-328, LM :459-679), same global semantics -- ONE scalar loss, ONE damping, ONE
+accept/reject decision per trial step, damping applied multiplicatively to the clamped diagonal
+and compounding over rejected retries, rejected steps undone by ``update_parameter(-D)``.
+
+What differs is how a step is linearised.  Three linearisations share one driver loop:
+
+``DenseLinearization``   the reference's algorithm: dense ``J`` from ``modjac``, ``A = J^T W J``,
+                         any ``solver(A=, b=)``.  Used whenever no structure is found.
+``BlockLinearization``   residual row n depends on parameter row n only (B independent problems):
+                         per-row blocks from ``d_res`` batched backward sweeps, per-problem normal
+                         equations and damped Cholesky in HIP kernels (optim/blocks.py).  Detected
+                         automatically and verified by a random vector-Jacobian probe.
+``GraphLinearization``   residual row e depends on gathered parameter rows idx_k[e] (pose graphs):
+                         see optim/posegraph.py.
+
+The block and graph paths produce the same iterates as the dense path up to rounding (the dense
+``A`` is exactly their block / block-sparse matrix), which tests/test_optim_* check against
+trajectories recorded from the reference.
+"""
+from __future__ import annotations
+
+import torch
+from torch import nn
+from torch.optim import Optimizer
+
+from . import blocks as _blocks
+from .corrector import FastTriggs
+from .functional import modjac
+from .solver import PINV, Cholesky
+from .strategy import TrustRegion
+
+
+class Trivial(nn.Module):
+    """Identity-like module: returns its (single) argument, or all of them as a tuple
+    (reference optimizer.py:51-61)."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__()
+
+    def forward(self, *args, **kwargs):
+        out = *args, *kwargs.values()
+        return out[0] if len(out) == 1 else out
+
+
+class RobustModel(nn.Module):
+    """Standardises a model into residual(s) and a robust loss (reference optimizer.py:64-125)."""
+
+    def __init__(self, model, kernel=None, auto=False):
+        super().__init__()
+        self.model = model
+        self.kernel = [Trivial()] if kernel is None else kernel
+
+    def flatten_row_jacobian(self, J, params_values):
+        if isinstance(J, (tuple, list)):
+            J = torch.cat([j.reshape(-1, p.numel()) for j, p in zip(J, params_values)], 1)
+        return J
+
+    @staticmethod
+    def _weight_blocks(w, r):
+        """per-row weight matrices [k, d, d] and the tiling factor covering all rows of r"""
+        ni = r.numel() * w.shape[-1] / w.numel()
+        w = w.view(*w.shape, 1, 1) if r.shape[-1] == 1 else w
+        return w.reshape(-1, w.shape[-2], w.shape[-1]), int(ni)
+
+    def normalize_RWJ(self, R, weight, J):
+        weight_diag = None
+        if weight is not None:
+            weight = weight if isinstance(weight, (tuple, list)) else [weight]
+            assert len(R) == len(weight)
+            mats = []
+            for w, r in zip(weight, R):
+                ws, ni = self._weight_blocks(w, r)
+                mats += list(ws.unbind(0)) * ni
+            weight_diag = torch.block_diag(*mats)
+        R = [r.reshape(-1) for r in R]
+        J = torch.cat(J) if isinstance(J, (tuple, list)) else J
+        return torch.cat(R), weight_diag, J
+
+    def forward(self, input, target=None):
+        return self.residuals(self.model_forward(input), target)
+
+    def model_forward(self, input):
+        if isinstance(input, dict):
+            return self.model(**input)
+        if isinstance(input, (tuple, list)):
+            return self.model(*input)
+        return self.model(input)
+
+    def residual(self, output, target):
+        return output if target is None else output - target
+
+    def residuals(self, outputs, targets):
+        if isinstance(outputs, (tuple, list)):
+            targets = [None] * len(outputs) if targets is None else targets
+            return tuple(self.residual(out, targets[i]) for i, out in enumerate(outputs))
+        return (self.residual(outputs, targets),)
+
+    def loss(self, input, target):
+        residuals = self.residuals(self.model_forward(input), target)
+        kernels = self.kernel if len(self.kernel) > 1 else [self.kernel[0]] * len(residuals)
+        return sum(k(r.square().sum(-1)).sum() for k, r in zip(kernels, residuals))
+
+
+# ---------------------------------------------------------------------------------------------
+# linearisations
+# ---------------------------------------------------------------------------------------------
+class DenseLinearization:
+    """The reference's dense pipeline (optimizer.py:644-657 for LM, :310-324 for GN)."""
+
+    kind = "dense"
+
+    def __init__(self, opt, pg, input, target, weight):
+        model = opt.model
+        R = list(model(input, target))
+        J = modjac(model, input=(input, target), flatten=False, **opt.jackwargs)
+        values = tuple(dict(model.named_parameters()).values())
+        J = [model.flatten_row_jacobian(Jr, values) for Jr in J]
+        for i in range(len(R)):
+            c = opt.corrector[0] if len(opt.corrector) == 1 else opt.corrector[i]
+            R[i], J[i] = c(R=R[i], J=J[i])
+        self.R, self.W, self.J = model.normalize_RWJ(R, weight, J)
+
+    # LM
+    def build_normal_equations(self, dmin, dmax):
+        self.J_T = self.J.T @ self.W if self.W is not None else self.J.T
+        self.A = self.J_T @ self.J
+        self.A.diagonal().clamp_(dmin, dmax)
+
+    def damp(self, damping):
+        self.A.diagonal().add_(self.A.diagonal() * damping)
+
+    def solve(self, solver):
+        return solver(A=self.A, b=-self.J_T @ self.R.view(-1, 1))
+
+    # GN
+    def solve_gauss_newton(self, solver):
+        A, b = (self.J, -self.R) if self.W is None else (self.W @ self.J, -self.W @ self.R)
+        return solver(A=A, b=b.view(-1, 1))
+
+    def strategy_args(self):
+        return self.J, self.R.view(-1, 1)
+
+
+class BlockLinearization:
+    """B independent problems: blocks [n, dr, dp] (see optim/blocks.py)."""
+
+    kind = "block"
+
+    def __init__(self, opt, pg, input, target, weight, R, params, Jb):
+        model = opt.model
+        n = Jb.shape[0]
+        dims = [r.shape[-1] for r in R]
+        # correctors act per residual row; split the stacked blocks back per residual
+        Rs, Js, off = [], [], 0
+        for i, r in enumerate(R):
+            c = opt.corrector[0] if len(opt.corrector) == 1 else opt.corrector[i]
+            ri, ji = c(R=r.detach().reshape(n, dims[i]), J=Jb[:, off:off + dims[i], :])
+            Rs.append(ri)
+            Js.append(ji)
+            off += dims[i]
+        self.Rb = torch.cat(Rs, dim=-1)
+        self.Jb = torch.cat(Js, dim=-2) if len(Js) > 1 else Js[0]
+        self.Wb = None
+        if weight is not None:
+            weight = weight if isinstance(weight, (tuple, list)) else [weight]
+            assert len(R) == len(weight)
+            dr = sum(dims)
+            self.Wb = torch.zeros((n, dr, dr), dtype=Jb.dtype, device=Jb.device)
+            off = 0
+            for w, r, d in zip(weight, R, dims):
+                ws, ni = model._weight_blocks(w, r)
+                self.Wb[:, off:off + d, off:off + d] = ws.repeat(ni, 1, 1)
+                off += d
+        self.op = _blocks.BlockJacobian(self.Jb, [p.shape[-1] for p in params])
+
+    def build_normal_equations(self, dmin, dmax):
+        self.A, self.g = _blocks.normal_equations(self.Jb, self.Rb, self.Wb)
+        self.A.diagonal(dim1=-2, dim2=-1).clamp_(dmin, dmax)
+
+    def damp(self, damping):
+        d = self.A.diagonal(dim1=-2, dim2=-1)
+        d.add_(d * damping)
+
+    def solve(self, solver):
+        if isinstance(solver, Cholesky) and not solver.upper:
+            Db = _blocks.chol_solve(self.A, self.g)
+            assert not torch.any(torch.isnan(Db)), \
+                'Cholesky decomposition failed. Check your matrix (may not be positive-definite)'
+        else:   # any other solver object: batched call, block by block
+            Db = solver(A=self.A, b=-self.g.unsqueeze(-1)).squeeze(-1)
+        return self.op.blocks_to_step(Db)
+
+    def solve_gauss_newton(self, solver):
+        if self.Wb is None:
+            A, b = self.Jb, -self.Rb.unsqueeze(-1)
+        else:
+            A, b = self.Wb @ self.Jb, -(self.Wb @ self.Rb.unsqueeze(-1))
+        return self.op.blocks_to_step(solver(A=A, b=b).squeeze(-1))
+
+    def strategy_args(self):
+        return self.op, self.Rb.reshape(-1, 1)
+
+
+def _row_count(t):
+    return t.numel() // t.shape[-1] if t.dim() >= 1 and t.shape[-1] > 0 else -1
+
+
+def _linearize(opt, pg, input, target, weight):
+    """Pick the cheapest valid linearisation for this model (cached per shape signature)."""
+    params = [p for p in pg['params'] if p.requires_grad]
+    cache = opt.__dict__.setdefault('_structure_cache', {})
+    if getattr(opt, 'structured', True) and params:
+        from . import posegraph as _pg
+        with torch.enable_grad():
+            with _pg.GatherRecorder(params) as rec:
+                R = list(opt.model(input, target))
+            sig = (tuple(tuple(r.shape) for r in R), tuple(tuple(p.shape) for p in params), len(rec.events))
+            n = _row_count(R[0])
+            same_rows = n > 1 and all(r.dim() >= 2 and _row_count(r) == n for r in R)
+            if same_rows and not rec.events and all(p.dim() >= 2 and _row_count(p) == n for p in params):
+                verdict = cache.get(sig)
+                if verdict is not False:
+                    Jb = _blocks.jacobian_blocks(R, params)
+                    if verdict is None:
+                        verdict = cache[sig] = _blocks.probe_block_structure(R, params, Jb)
+                    if verdict:
+                        return BlockLinearization(opt, pg, input, target, weight, R, params, Jb)
+            elif same_rows and rec.events and cache.get(sig) is not False:
+                lin = _pg.try_graph_linearization(opt, pg, input, target, weight, R, params, rec, cache, sig)
+                if lin is not None:
+                    return lin
+    return DenseLinearization(opt, pg, input, target, weight)
+
+
+class _Optimizer(Optimizer):
+    """Base class of the second-order optimizers (reference optimizer.py:128-140)."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+
+    def update_parameter(self, params, step):
+        """``p.add_(d)`` parameter by parameter; for LieTensor parameters ``add_`` is the left
+        retraction ``Exp(d[..., :dof]) * p`` (lietensor.py add_)."""
+        steps = step.split([p.numel() for p in params if p.requires_grad])
+        [p.add_(d.view(p.shape)) for p, d in zip(params, steps) if p.requires_grad]
+
+    def _setup_correctors(self, kernel, corrector):
+        if kernel is not None:
+            kernel = [kernel] if not isinstance(kernel, (tuple, list)) else kernel
+            kernel = [k if k is not None else Trivial() for k in kernel]
+            self.corrector = [FastTriggs(k) for k in kernel] if corrector is None else corrector
+        else:
+            self.corrector = [Trivial()] if corrector is None else corrector
+        self.corrector = [self.corrector] if not isinstance(self.corrector, (tuple, list)) else self.corrector
+        self.corrector = [c if c is not None else Trivial() for c in self.corrector]
+        return kernel
+
+
+class GaussNewton(_Optimizer):
+    """Gauss-Newton: solve ``W J d = -W R`` and update (reference optimizer.py:143-328)."""
+
+    def __init__(self, model, solver=None, kernel=None, corrector=None, weight=None, vectorize=True):
+        super().__init__(model.parameters(), defaults={})
+        self.jackwargs = {'vectorize': vectorize}
+        self.solver = PINV() if solver is None else solver
+        self.weight = weight
+        kernel = self._setup_correctors(kernel, corrector)
+        self.model = RobustModel(model, kernel)
+
+    @torch.no_grad()
+    def step(self, input, target=None, weight=None):
+        for pg in self.param_groups:
+            weight = self.weight if weight is None else weight
+            lin = _linearize(self, pg, input, target, weight)
+            D = lin.solve_gauss_newton(self.solver)
+            self.last = self.loss if hasattr(self, 'loss') else self.model.loss(input, target)
+            self.update_parameter(params=pg['params'], step=D)
+            self.loss = self.model.loss(input, target)
+        return self.loss
+
+
+class LevenbergMarquardt(_Optimizer):
+    """Levenberg-Marquardt (reference optimizer.py:331-679).
+
+    ``sparse=True`` selects the reference's optional ``bae`` plugin, which this library does not
+    provide; structured problems are handled by the automatic block / graph paths instead.
+    """
+
+    def __init__(self, model, solver=None, strategy=None, kernel=None, corrector=None,
+                 weight=None, reject=16, min=1e-6, max=1e32, vectorize=True, sparse=False):
+        assert min > 0, ValueError("min value has to be positive: {}".format(min))
+        assert max > 0, ValueError("max value has to be positive: {}".format(max))
+        self.strategy = TrustRegion() if strategy is None else strategy
+        defaults = {**{'min': min, 'max': max}, **self.strategy.defaults}
+        super().__init__(model.parameters(), defaults=defaults)
+        if sparse:
+            raise ImportError("pypose_amd: LM(sparse=True) needs the reference's optional sparse backend "
+                              "(bae>=0.2.1,<0.3); it is not part of this library. Leave sparse=False: "
+                              "block-diagonal and pose-graph structure is detected automatically.")
+        self.sparse = False
+        self.jackwargs = {'vectorize': vectorize}
+        self.solver = Cholesky() if solver is None else solver
+        self.reject, self.reject_count = reject, 0
+        self.weight = weight
+        kernel = self._setup_correctors(kernel, corrector)
+        self.model = RobustModel(model, kernel)
+
+    @torch.no_grad()
+    def step(self, input, target=None, weight=None):
+        for pg in self.param_groups:
+            weight = self.weight if weight is None else weight
+            lin = _linearize(self, pg, input, target, weight)
+            lin.build_normal_equations(pg['min'], pg['max'])
+            self.linearization = lin.kind
+            self.last = self.loss = self.loss if hasattr(self, 'loss') else self.model.loss(input, target)
+            self.reject_count = 0
+            J, R = lin.strategy_args()
+            while self.last <= self.loss:
+                lin.damp(pg['damping'])
+                try:
+                    D = lin.solve(self.solver)
+                except Exception as e:
+                    print(e, "\nLinear solver failed. Breaking optimization step...")
+                    break
+                self.update_parameter(pg['params'], D)
+                self.loss = self.model.loss(input, target)
+                self.strategy.update(pg, last=self.last, loss=self.loss, J=J, D=D, R=R)
+                if self.last < self.loss and self.reject_count < self.reject:     # reject the step
+                    self.update_parameter(params=pg['params'], step=-D)
+                    self.loss, self.reject_count = self.last, self.reject_count + 1
+                else:
+                    break
+        return self.loss

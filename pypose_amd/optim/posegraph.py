@@ -1,0 +1,283 @@
+"""Gather-structured (pose-graph) linearisation for Levenberg-Marquardt.
+
+The reference's pose-graph model (examples/module/pgo/pgo.py:15-25) is an ordinary nn.Module:
+
+    node1, node2 = self.nodes[edges[..., 0]], self.nodes[edges[..., 1]]
+    return (poses.Inv() @ node1.Inv() @ node2).Log().tensor()
+
+Its dense LM path needs a [6E, 7N] Jacobian and cannot run beyond a few hundred nodes
+(examples/module/pgo/readme.md:47-49); its scalable path is the un-vendored ``bae`` plugin.
+This module gives the SAME unmodified model a scalable path on the GPU:
+
+1. :class:`GatherRecorder` notes every integer-tensor ``__getitem__`` on an optimised
+   ``pp.Parameter`` during the forward pass (index tensor + the gathered rows, which are nodes
+   of the autograd graph).
+2. Per-edge Jacobian blocks w.r.t. the *gathered rows* come from ``d_res`` batched backward
+   sweeps (blocks.jacobian_blocks) -- block-diagonal by construction if each residual row only
+   depends on its own gathered rows.  A random vector-Jacobian probe against the real model
+   verifies that; otherwise the optimizer falls back to the dense path.
+3. The normal equations stay block sparse and matrix-free (csrc/graph.hip): block diagonal +
+   gradient by scatter-add, ``H p`` one lane per edge, block-Jacobi PCG; small graphs can instead
+   be assembled densely and handed to the user's ``solver`` (bit-for-bit the reference's
+   algebra, used by the parity tests).
+4. With ``group=`` (torch.distributed) edges are sharded over ranks, nodes replicated: the
+   block diagonal, the gradient, every ``H p`` and the loss are all-reduced (RCCL on GPUs).
+"""
+from __future__ import annotations
+
+import ctypes
+import warnings
+
+import torch
+from torch import nn
+
+from .. import _C
+from ..lietensor import lietensor as _lt
+from . import blocks as _blocks
+
+_SPMV_SIG = [ctypes.c_void_p] * 5 + [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+_ASM_SIG = [ctypes.c_void_p] * 6 + [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+_HIP_SHAPES = {(6, 6, 2), (7, 7, 2), (3, 3, 2), (6, 6, 1), (3, 3, 1)}
+DENSE_LIMIT = 4096          # assemble a dense A for the user's solver up to this many unknowns
+
+
+class GatherRecorder:
+    """Context manager recording ``param[index_tensor]`` gathers on the tracked parameters."""
+
+    def __init__(self, params):
+        self.ids = {id(p): p for p in params}
+        self.events = []      # (param, index LongTensor [E], gathered rows [E, w])
+
+    def __enter__(self):
+        _lt._gather_recorders.append(self)
+        return self
+
+    def __exit__(self, *exc):
+        _lt._gather_recorders.remove(self)
+
+    def note(self, source, index, out):
+        if id(source) in self.ids and isinstance(index, torch.Tensor) and index.dtype == torch.int64 \
+                and index.dim() >= 1 and isinstance(out, torch.Tensor) and out.requires_grad:
+            self.events.append((source, index, out))
+
+
+class PCG(nn.Module):
+    """Preconditioned conjugate gradient with a block-Jacobi preconditioner for the matrix-free
+    pose-graph normal equations (the name the reference exposes for its plugin solver,
+    pypose/optim/solver.py:343-364).  Stops when ||r|| <= tol * ||b|| or after ``maxiter``."""
+
+    def __init__(self, maxiter=None, tol=1e-5, check_every=8):
+        super().__init__()
+        self.maxiter, self.tol, self.check_every = maxiter, tol, check_every
+
+    def solve(self, matvec, b, precond):
+        x = torch.zeros_like(b)
+        r = b.clone()
+        bn = torch.linalg.norm(b)
+        if bn == 0:
+            return x
+        maxiter = b.numel() * 10 if self.maxiter is None else self.maxiter
+        z = precond(r)
+        p = z.clone()
+        rho = (r * z).sum()
+        for it in range(maxiter):
+            q = matvec(p)
+            alpha = rho / (p * q).sum()
+            x.add_(alpha * p)
+            r.sub_(alpha * q)
+            if (it + 1) % self.check_every == 0 and torch.linalg.norm(r) <= self.tol * bn:
+                break
+            z = precond(r)
+            rho_new = (r * z).sum()
+            p.mul_(rho_new / rho).add_(z)
+            rho = rho_new
+        self.iterations = it + 1
+        return x
+
+    def forward(self, A, b, x=None, M=None):
+        """Dense call shape ``solver(A=, b=)`` (Jacobi preconditioner) for API compatibility."""
+        d = A.diagonal().clamp_min(torch.finfo(A.dtype).tiny).unsqueeze(-1)
+        return self.solve(lambda v: A @ v, b, lambda v: v / d)
+
+
+def _all_reduce(t, group):
+    if group is not None:
+        import torch.distributed as dist
+        dist.all_reduce(t, group=group)
+    return t
+
+
+class GraphOperator:
+    """``J`` handed to ``strategy.update`` for the graph path: ``J @ D`` with D the flat step."""
+
+    def __init__(self, lin):
+        self.lin = lin
+
+    def __matmul__(self, D):
+        lin = self.lin
+        Dn = lin.step_to_nodes(D)                                  # [N, m]
+        JD = torch.zeros((lin.E, lin.dr), dtype=Dn.dtype, device=Dn.device)
+        for k in range(lin.K):
+            JD += torch.einsum('edm,em->ed', lin.J[:, k], Dn[lin.idx[:, k]])
+        return JD.reshape(-1, 1)
+
+
+class GraphLinearization:
+    kind = "graph"
+
+    def __init__(self, opt, weight, R, param, idx, J, wfull, m):
+        """R [E,dr] (corrected), J [E,K,dr,m], idx [E,K], param the node Parameter [N,wfull]."""
+        self.opt, self.param = opt, param
+        self.R, self.J, self.idx = R.contiguous(), J.contiguous(), idx.contiguous()
+        self.E, self.K, self.dr, self.m = J.shape
+        self.N, self.wfull = param.shape[0], wfull
+        self.W = weight
+        self.group = getattr(opt, 'group', None)
+        self.s = 1.0            # compounded damping factor prod(1 + lambda_i)
+
+    # -- index helpers -------------------------------------------------------------------------
+    def step_to_nodes(self, D):
+        return D.reshape(self.N, self.wfull)[:, :self.m]
+
+    def nodes_to_step(self, Dn):
+        if self.m < self.wfull:
+            Dn = torch.cat([Dn, torch.zeros((self.N, self.wfull - self.m), dtype=Dn.dtype, device=Dn.device)], -1)
+        return Dn.reshape(-1, 1)
+
+    # -- kernels ---------------------------------------------------------------------------------
+    def _hip(self):
+        return (_C._test_backend is None and self.J.is_cuda and (self.dr, self.m, self.K) in _HIP_SHAPES
+                and self.J.dtype in (torch.float32, torch.float64))
+
+    def _assemble(self):
+        N, m = self.N, self.m
+        B = torch.zeros((N, m, m), dtype=self.J.dtype, device=self.J.device)
+        g = torch.zeros((N, m), dtype=self.J.dtype, device=self.J.device)
+        if self._hip():
+            sfx = "_f32" if self.J.dtype == torch.float32 else "_f64"
+            fn = _C.library().symbol("pplie_graph_assemble" + sfx, _ASM_SIG)
+            with torch.cuda.device(self.J.device):
+                code = fn(self.J.data_ptr(), self.W.data_ptr() if self.W is not None else None, self.R.data_ptr(),
+                          self.idx.data_ptr(), B.data_ptr(), g.data_ptr(), self.E, self.dr, self.m, self.K,
+                          _C.stream_ptr(self.J.device))
+            _C.check(code, "pplie_graph_assemble")
+        else:
+            for k in range(self.K):
+                Jk = self.J[:, k]
+                JtW = Jk.mT if self.W is None else Jk.mT @ self.W
+                B.index_add_(0, self.idx[:, k], JtW @ Jk)
+                g.index_add_(0, self.idx[:, k], (JtW @ self.R.unsqueeze(-1)).squeeze(-1))
+        return _all_reduce(B, self.group), _all_reduce(g, self.group)
+
+    def _Hp(self, p):
+        """(J^T W J) p for a node vector p [N, m] (all-reduced over edge shards)."""
+        y = torch.zeros_like(p)
+        if self._hip():
+            sfx = "_f32" if p.dtype == torch.float32 else "_f64"
+            fn = _C.library().symbol("pplie_graph_spmv" + sfx, _SPMV_SIG)
+            with torch.cuda.device(p.device):
+                code = fn(self.J.data_ptr(), self.W.data_ptr() if self.W is not None else None, self.idx.data_ptr(),
+                          p.data_ptr(), y.data_ptr(), self.E, self.dr, self.m, self.K, _C.stream_ptr(p.device))
+            _C.check(code, "pplie_graph_spmv")
+        else:
+            q = torch.zeros((self.E, self.dr), dtype=p.dtype, device=p.device)
+            for k in range(self.K):
+                q += torch.einsum('edm,em->ed', self.J[:, k], p[self.idx[:, k]])
+            if self.W is not None:
+                q = (self.W @ q.unsqueeze(-1)).squeeze(-1)
+            for k in range(self.K):
+                y.index_add_(0, self.idx[:, k], torch.einsum('edm,ed->em', self.J[:, k], q))
+        return _all_reduce(y, self.group)
+
+    # -- LM interface ------------------------------------------------------------------------------
+    def build_normal_equations(self, dmin, dmax):
+        self.B, self.g = self._assemble()
+        self.diag_raw = self.B.diagonal(dim1=-2, dim2=-1).clone()
+        self.diag_clamped = self.diag_raw.clamp(dmin, dmax)
+        # the parameter components outside the tangent space (7th of SE3, ...) have a structurally
+        # zero Jacobian column: the reference clamps their diagonal to ``min`` and solves d = 0.
+        self.s = 1.0
+
+    def damp(self, damping):
+        self.s = self.s * (1.0 + damping)
+
+    def solve(self, solver):
+        N, m = self.N, self.m
+        shift = self.s * self.diag_clamped - self.diag_raw          # A = H + diag(shift)
+        b = -self.g
+        if not isinstance(solver, PCG) and N * m <= DENSE_LIMIT and self.group is None:
+            A = self.dense_matrix()
+            A.diagonal().add_(shift.reshape(-1))
+            Dn = solver(A=A, b=b.reshape(-1, 1)).reshape(N, m)
+        else:
+            if not isinstance(solver, PCG):
+                if not getattr(self.opt, '_warned_pcg', False):
+                    warnings.warn(f"{type(solver).__name__} cannot factor a {N * m}-unknown pose graph densely; "
+                                  f"using the matrix-free block-Jacobi PCG (tol 1e-10) instead.")
+                    self.opt._warned_pcg = True
+                solver = PCG(tol=1e-10, maxiter=max(1000, 2 * N))
+            Bd = self.B.clone()
+            Bd.diagonal(dim1=-2, dim2=-1).copy_(self.s * self.diag_clamped)
+            Binv = torch.linalg.inv(Bd)                              # block-Jacobi preconditioner
+            Dn = solver.solve(lambda p: self._Hp(p) + shift * p, b,
+                              lambda r: torch.einsum('nij,nj->ni', Binv, r))
+        assert not torch.any(torch.isnan(Dn)), 'Linear solve produced NaN (matrix may not be positive-definite)'
+        return self.nodes_to_step(Dn)
+
+    def dense_matrix(self):
+        """H = J^T W J as a dense [N m, N m] matrix (small graphs / parity tests)."""
+        N, m = self.N, self.m
+        A = torch.zeros((N * N, m, m), dtype=self.J.dtype, device=self.J.device)
+        for k in range(self.K):
+            JtW = self.J[:, k].mT if self.W is None else self.J[:, k].mT @ self.W
+            for l in range(self.K):
+                A.index_add_(0, self.idx[:, k] * N + self.idx[:, l], JtW @ self.J[:, l])
+        return A.view(N, N, m, m).permute(0, 2, 1, 3).reshape(N * m, N * m).contiguous()
+
+    def solve_gauss_newton(self, solver):
+        raise NotImplementedError
+
+    def strategy_args(self):
+        return GraphOperator(self), self.R.reshape(-1, 1)
+
+
+def try_graph_linearization(opt, pg, input, target, weight, R, params, rec, cache, sig):
+    """Build a GraphLinearization if the recorded gathers explain the whole Jacobian."""
+    if len(params) != 1 or len(R) != 1 or params[0].dim() != 2:
+        cache[sig] = False
+        return None
+    param, r = params[0], R[0]
+    E = r.numel() // r.shape[-1]
+    events = [(src, ix, out) for src, ix, out in rec.events if ix.numel() == E and out.numel() == E * param.shape[-1]]
+    if not events or len(events) != len(rec.events):
+        cache[sig] = False
+        return None
+    outs = [out for _, _, out in events]
+    K, wfull, dr = len(events), param.shape[-1], r.shape[-1]
+    with torch.enable_grad():
+        Jcat = _blocks.jacobian_blocks([r], outs)                    # [E, dr, K*wfull]
+        if cache.get(sig) is None:
+            # probe: u^T dR/dnodes by one real backward == scatter-add of the per-edge blocks
+            u = torch.randn_like(r)
+            true = torch.autograd.grad([r], [param], [u], retain_graph=True)[0]
+            got = torch.zeros_like(true)
+            contrib = torch.einsum('ed,edw->ew', u.reshape(E, dr), Jcat)
+            for k, (_, ix, _) in enumerate(events):
+                got.index_add_(0, ix.reshape(-1), contrib[:, k * wfull:(k + 1) * wfull])
+            scale = true.abs().max().clamp_min(torch.finfo(true.dtype).tiny)
+            cache[sig] = bool((got - true).abs().max() <= 1e-3 * scale)
+    if not cache[sig]:
+        return None
+    # tangent width: gradients of LieTensor group parameters are zero-padded to the embedding
+    m = int(param.ltype.manifold[0]) if isinstance(param, _lt.LieTensor) and not param.ltype.on_manifold else wfull
+    J = Jcat.reshape(E, dr, K, wfull)[..., :m].permute(0, 2, 1, 3)    # [E, K, dr, m]
+    idx = torch.stack([ix.reshape(-1) for _, ix, _ in events], dim=-1)
+    c = opt.corrector[0]                                              # row-local: acts on [E, dr, K*m]
+    Rc, Jc = c(R=r.detach().reshape(E, dr), J=J.permute(0, 2, 1, 3).reshape(E, dr, K * m))
+    Jc = Jc.reshape(E, dr, K, m).permute(0, 2, 1, 3)
+    Wb = None
+    if weight is not None:
+        w = weight[0] if isinstance(weight, (tuple, list)) else weight
+        ws, ni = opt.model._weight_blocks(w, r)
+        Wb = ws.repeat(ni, 1, 1).contiguous()
+    return GraphLinearization(opt, Wb, Rc, param, idx, Jc, wfull, m)

@@ -1,0 +1,84 @@
+"""The reference's example models, re-stated against pypose_amd (tests only)."""
+import numpy as np
+import torch
+from torch import nn
+
+import pypose_amd as pp
+
+
+class InvNet(nn.Module):                       # reference README.md:120-129
+    def __init__(self, init):
+        super().__init__()
+        self.pose = pp.Parameter(init)
+
+    def forward(self, input):
+        return (self.pose @ input).Log().tensor()
+
+
+class PoseGraph(nn.Module):                    # reference examples/module/pgo/pgo.py:15-25
+    def __init__(self, nodes):
+        super().__init__()
+        self.nodes = pp.Parameter(nodes)
+
+    def forward(self, edges, poses):
+        node1 = self.nodes[edges[..., 0]]
+        node2 = self.nodes[edges[..., 1]]
+        error = poses.Inv() @ node1.Inv() @ node2
+        return error.Log().tensor()
+
+
+def load_lm_golden():
+    import os
+    return dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lm_golden.npz")))
+
+
+def T(a, device="cpu"):
+    return torch.from_numpy(np.array(a, copy=True)).to(device)
+
+
+def run_steps(opt, args, kwargs, nsteps):
+    rec = {"loss": [], "damping": [], "reject": [], "kind": []}
+    for _ in range(nsteps):
+        loss = opt.step(*args, **kwargs)
+        rec["loss"].append(float(loss))
+        rec["damping"].append(float(opt.param_groups[0].get("damping", 0.0)))
+        rec["reject"].append(int(getattr(opt, "reject_count", 0)))
+        rec["kind"].append(getattr(opt, "linearization", "?"))
+    return rec
+
+
+def invnet_cases(G, device="cpu"):
+    """name -> (make optimizer+model, step args, kwargs, n steps) for every recorded InvNet run."""
+    S = pp.optim.strategy
+    inp = pp.SE3(T(G["invnet/input"], device))
+    init = lambda key="invnet/init": pp.SE3(T(G[key], device))
+    W = T(G["invnet/weight"], device)
+    tgt = T(G["invnet/target"], device)
+    return {
+        "constant": (lambda net: pp.optim.LM(net, strategy=S.Constant(damping=1e-4)), init(), (inp,), {}, 6),
+        "adaptive": (lambda net: pp.optim.LM(net, strategy=S.Adaptive(damping=1e-6)), init(), (inp,), {}, 6),
+        "trustregion": (lambda net: pp.optim.LM(net, strategy=S.TrustRegion()), init(), (inp,), {}, 6),
+        "huber_weight": (lambda net: pp.optim.LM(net, strategy=S.Adaptive(damping=1e-6), kernel=pp.optim.kernel.Huber(delta=0.5)),
+                         init(), (inp,), {"weight": W}, 6),
+        "cauchy_target": (lambda net: pp.optim.LM(net, strategy=S.TrustRegion(radius=1e4), kernel=pp.optim.kernel.Cauchy()),
+                          init(), (inp, tgt), {}, 6),
+        "gn": (lambda net: pp.optim.GN(net), init(), (inp,), {}, 4),
+        "far": (lambda net: pp.optim.LM(net, strategy=S.TrustRegion(radius=1e8), min=1e-12), init("invnet/far_init"), (inp,), {}, 8),
+    }
+
+
+def compare_trajectory(rec, G, prefix, floor=1e-16, rtol=1e-6):
+    """Loss sequence equal to the reference's while above the fp64 noise floor; same damping /
+    reject sequence over that range."""
+    ref = G[prefix + "/loss"]
+    for k, (a, b) in enumerate(zip(rec["loss"], ref)):
+        if b > floor:
+            assert abs(a - b) <= rtol * b, (prefix, k, a, b)
+            # accept/reject and the damping update are decided by the sign / size of (last - loss):
+            # only meaningful while the step still changes the loss beyond rounding
+            prev = ref[k - 1] if k else None
+            if prev is None or abs(prev - b) > 1e-7 * b:
+                assert np.isclose(rec["damping"][k], G[prefix + "/damping"][k], rtol=1e-12), (prefix, k)
+                assert rec["reject"][k] == G[prefix + "/reject"][k], (prefix, k)
+        else:
+            assert a <= max(floor, 100 * b), (prefix, k, a, b)

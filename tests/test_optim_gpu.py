@@ -1,0 +1,154 @@
+"""LM / GN on the MI355X through the HIP kernels: reference trajectories (fp64), kernel-level
+parity of the block / graph linear algebra, and the BASELINE-size runs (configs[2], configs[3])."""
+import numpy as np
+import pytest
+import torch
+
+import pypose_amd as pp
+from tests.optim_models import InvNet, PoseGraph, T, compare_trajectory, invnet_cases, load_lm_golden, run_steps
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def G():
+    return load_lm_golden()
+
+
+@pytest.mark.parametrize("structured", [False, True])
+@pytest.mark.parametrize("case", ["constant", "adaptive", "trustregion", "huber_weight", "cauchy_target", "gn", "far"])
+def test_invnet_trajectory_matches_reference(G, case, structured):
+    from pypose_amd import _C
+    assert _C._test_backend is None
+    mk, init, args, kwargs, n = invnet_cases(G, DEV)[case]
+    net = InvNet(init)
+    opt = mk(net)
+    opt.structured = structured
+    rec = run_steps(opt, args, kwargs, n)
+    assert set(rec["kind"]) <= ({"block", "?"} if structured else {"dense", "?"}), rec["kind"]
+    compare_trajectory(rec, G, "invnet/" + case)
+
+
+@pytest.mark.parametrize("structured", [False, True])
+@pytest.mark.parametrize("tag,wname", [("pgo12", "noweight"), ("pgo40", "infos")])
+def test_posegraph_trajectory_matches_reference(G, tag, wname, structured):
+    edges, poses = T(G[f"{tag}/edges"], DEV), pp.SE3(T(G[f"{tag}/poses"], DEV))
+    graph = PoseGraph(pp.SE3(T(G[f"{tag}/init"], DEV)))
+    opt = pp.optim.LM(graph, solver=pp.optim.solver.Cholesky(), strategy=pp.optim.strategy.TrustRegion(radius=1e4), min=1e-6)
+    opt.structured = structured
+    w = T(G[f"{tag}/infos"], DEV) if wname == "infos" else None
+    rec = run_steps(opt, ((edges, poses),), {"weight": w}, 5)
+    assert set(rec["kind"]) == ({"graph"} if structured else {"dense"}), rec["kind"]
+    compare_trajectory(rec, G, f"{tag}/{wname}", floor=1e-12, rtol=1e-8)
+    torch.testing.assert_close(graph.nodes.detach().tensor().cpu(), T(G[f"{tag}/{wname}/final"]), rtol=0, atol=1e-8)
+
+
+def test_posegraph_pcg_matrix_free_on_gpu(G):
+    edges, poses = T(G["pgo40/edges"], DEV), pp.SE3(T(G["pgo40/poses"], DEV))
+    graph = PoseGraph(pp.SE3(T(G["pgo40/init"], DEV)))
+    opt = pp.optim.LM(graph, solver=pp.optim.solver.PCG(tol=1e-13, maxiter=2000, check_every=1),
+                      strategy=pp.optim.strategy.TrustRegion(radius=1e4), min=1e-6)
+    rec = run_steps(opt, ((edges, poses),), {"weight": T(G["pgo40/infos"], DEV)}, 5)
+    assert set(rec["kind"]) == {"graph"}
+    compare_trajectory(rec, G, "pgo40/infos", floor=1e-12, rtol=1e-7)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-12), (torch.float32, 2e-5)])
+@pytest.mark.parametrize("dr,dp,has_w", [(6, 7, False), (6, 7, True), (3, 4, False), (7, 8, True), (4, 5, False), (6, 6, True)])
+def test_block_kernels_vs_oracle(dtype, tol, dr, dp, has_w):
+    from oracle import optim_np
+    from pypose_amd.optim import blocks
+    n = 20_011
+    g = torch.Generator().manual_seed(dr * 10 + dp)
+    J = torch.randn(n, dr, dp, generator=g, dtype=dtype)
+    R = torch.randn(n, dr, generator=g, dtype=dtype)
+    W = None
+    if has_w:
+        W = torch.randn(n, dr, dr, generator=g, dtype=dtype) * 0.3
+        W = W @ W.mT + torch.eye(dr, dtype=dtype)
+    A, gr = blocks.normal_equations(J.to(DEV), R.to(DEV), W.to(DEV) if has_w else None)
+    Ar, gr_ref = optim_np.block_normal_eq(J.double().numpy(), R.double().numpy(), W.double().numpy() if has_w else None)
+    assert np.abs(A.cpu().double().numpy() - Ar).max() <= tol * np.abs(Ar).max()
+    assert np.abs(gr.cpu().double().numpy() - gr_ref).max() <= tol * np.abs(gr_ref).max()
+    # SPD system: damp the diagonal like LM does, then solve
+    A.diagonal(dim1=-2, dim2=-1).add_(1.0)
+    x = blocks.chol_solve(A, gr)
+    xr = np.linalg.solve(A.cpu().double().numpy(), -gr.cpu().double().numpy()[..., None])[..., 0]
+    assert np.abs(x.cpu().double().numpy() - xr).max() <= 50 * tol * max(1.0, np.abs(xr).max())
+    # an indefinite block yields NaNs (-> the reference's "Cholesky decomposition failed")
+    bad = A.clone()
+    bad[0] = -bad[0]
+    assert torch.isnan(blocks.chol_solve(bad, gr)[0]).any()
+
+
+def _synthetic_graph(N, E, dtype, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    torch.manual_seed(seed)
+    steps = pp.randn_SE3(N, sigma=0.3, dtype=dtype, device=DEV)
+    gt = pp.cumprod(steps, dim=0, left=False)
+    chain = torch.stack([torch.arange(N - 1), torch.arange(1, N)], -1)
+    extra = torch.randint(0, N, (E - (N - 1), 2), generator=g)
+    extra[:, 1] = torch.where(extra[:, 0] == extra[:, 1], (extra[:, 1] + 1) % N, extra[:, 1])
+    edges = torch.cat([chain, extra], 0).to(DEV)
+    rel = gt[edges[:, 0]].Inv() @ gt[edges[:, 1]] @ pp.randn_SE3(E, sigma=0.01, dtype=dtype, device=DEV)
+    init = gt @ pp.randn_SE3(N, sigma=0.05, dtype=dtype, device=DEV)
+    return edges, rel, init
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-11), (torch.float32, 5e-4)])
+def test_graph_kernels_vs_torch_reference(dtype, tol):
+    """pplie_graph_assemble / pplie_graph_spmv against plain torch index_add_ formulations."""
+    from pypose_amd.optim import posegraph
+    N, E = 3000, 12_001
+    g = torch.Generator().manual_seed(1)
+    J = torch.randn(E, 2, 6, 6, generator=g, dtype=dtype).to(DEV)
+    R = torch.randn(E, 6, generator=g, dtype=dtype).to(DEV)
+    W = torch.randn(E, 6, 6, generator=g, dtype=dtype)
+    W = (W @ W.mT + torch.eye(6, dtype=dtype)).to(DEV)
+    idx = torch.randint(0, N, (E, 2), generator=g).to(DEV)
+    p = torch.randn(N, 6, generator=g, dtype=dtype).to(DEV)
+    for Wm in (None, W):
+        class Opt:
+            pass
+        lin = posegraph.GraphLinearization(Opt(), Wm, R, torch.zeros(N, 7, dtype=dtype, device=DEV), idx, J, 7, 6)
+        assert lin._hip()
+        B, gr = lin._assemble()
+        y = lin._Hp(p)
+        lin._hip = lambda: False               # torch formulation on the same device
+        B2, gr2 = lin._assemble()
+        y2 = lin._Hp(p)
+        for a, b in ((B, B2), (gr, gr2), (y, y2)):
+            assert (a - b).abs().max().item() <= tol * b.abs().max().item()
+
+
+def test_c3_invnet_one_million_problems():
+    """BASELINE configs[2]: LM on InvNet SE3, B = 1M independent problems, fp32."""
+    torch.manual_seed(0)
+    B = 1_000_000
+    net = InvNet(pp.randn_SE3(B, device=DEV))
+    torch.manual_seed(1)
+    inp = pp.randn_SE3(B, device=DEV)
+    opt = pp.optim.LM(net, strategy=pp.optim.strategy.Constant(damping=1e-4))
+    l0 = float(net.forward(inp).square().sum())
+    losses = [float(opt.step(inp)) for _ in range(3)]
+    assert opt.linearization == "block"
+    assert losses[0] < 1e-3 * l0 and losses[-1] < 1e-6 * l0, (l0, losses)
+    # the optimum is pose = input^-1: pose * input == identity
+    I = (pp.SE3(net.pose.detach().tensor()) * inp).Log().tensor()
+    assert I.abs().max().item() < 1e-3
+
+
+def test_c4_pose_graph_10k_and_100k():
+    """BASELINE metric + configs[3] sizes on one GPU: the unmodified PoseGraph model takes the graph path,
+    the loss decreases monotonically and the solution approaches the generating trajectory."""
+    for N, E in ((10_000, 40_000), (100_000, 400_000)):
+        edges, rel, init = _synthetic_graph(N, E, torch.float32)
+        graph = PoseGraph(init)
+        opt = pp.optim.LM(graph, solver=pp.optim.solver.PCG(tol=1e-4, maxiter=250),
+                          strategy=pp.optim.strategy.TrustRegion(radius=1e4))
+        l_init = float(graph(edges, rel).square().sum())
+        losses = [float(opt.step((edges, rel))) for _ in range(4)]
+        assert opt.linearization == "graph"
+        assert all(b <= a * (1 + 1e-6) for a, b in zip([l_init] + losses, losses)), (l_init, losses)
+        assert losses[-1] < 0.2 * l_init, (N, l_init, losses)
