@@ -290,7 +290,7 @@ class LevenbergMarquardt(_Optimizer):
     """
 
     def __init__(self, model, solver=None, strategy=None, kernel=None, corrector=None,
-                 weight=None, reject=16, min=1e-6, max=1e32, vectorize=True, sparse=False):
+                 weight=None, reject=16, min=1e-6, max=1e32, vectorize=True, sparse=False, *, group=None):
         assert min > 0, ValueError("min value has to be positive: {}".format(min))
         assert max > 0, ValueError("max value has to be positive: {}".format(max))
         self.strategy = TrustRegion() if strategy is None else strategy
@@ -301,6 +301,10 @@ class LevenbergMarquardt(_Optimizer):
                               "(bae>=0.2.1,<0.3); it is not part of this library. Leave sparse=False: "
                               "block-diagonal and pose-graph structure is detected automatically.")
         self.sparse = False
+        # torch.distributed process group: independent problems / graph edges are sharded over its
+        # ranks (one process per GPU, RCCL); the loss, the gain ratio and -- for pose graphs -- the
+        # normal-equation pieces are all-reduced so that every rank takes the same decisions.
+        self.group = group
         self.jackwargs = {'vectorize': vectorize}
         self.solver = Cholesky() if solver is None else solver
         self.reject, self.reject_count = reject, 0
@@ -308,14 +312,38 @@ class LevenbergMarquardt(_Optimizer):
         kernel = self._setup_correctors(kernel, corrector)
         self.model = RobustModel(model, kernel)
 
+    def _loss(self, input, target):
+        loss = self.model.loss(input, target)
+        if self.group is not None:
+            import torch.distributed as dist
+            loss = loss.clone()
+            dist.all_reduce(loss, group=self.group)
+        return loss
+
+    def _strategy_update(self, pg, J, D, R):
+        if self.group is None:
+            return self.strategy.update(pg, last=self.last, loss=self.loss, J=J, D=D, R=R)
+        # the gain ratio needs the GLOBAL (J D)^T (2 R + J D): all-reduce its two dot products and
+        # hand the strategy an equivalent 1x1 problem x (2 r + x) with x^2 = a, x r = b
+        import torch.distributed as dist
+        JD = J @ D
+        ab = torch.stack([(JD * JD).sum(), (JD * R).sum()])
+        dist.all_reduce(ab, group=self.group)
+        x = ab[0].sqrt().clamp_min(torch.finfo(ab.dtype).tiny)
+        one = torch.ones((1, 1), dtype=ab.dtype, device=ab.device)
+        return self.strategy.update(pg, last=self.last, loss=self.loss, J=one, D=x * one, R=(ab[1] / x) * one)
+
     @torch.no_grad()
     def step(self, input, target=None, weight=None):
         for pg in self.param_groups:
             weight = self.weight if weight is None else weight
             lin = _linearize(self, pg, input, target, weight)
+            if self.group is not None and lin.kind == "dense":
+                raise RuntimeError("LM(group=...) needs a block or pose-graph structured model; the dense "
+                                   "linearisation is not sharded")
             lin.build_normal_equations(pg['min'], pg['max'])
             self.linearization = lin.kind
-            self.last = self.loss = self.loss if hasattr(self, 'loss') else self.model.loss(input, target)
+            self.last = self.loss = self.loss if hasattr(self, 'loss') else self._loss(input, target)
             self.reject_count = 0
             J, R = lin.strategy_args()
             while self.last <= self.loss:
@@ -326,8 +354,8 @@ class LevenbergMarquardt(_Optimizer):
                     print(e, "\nLinear solver failed. Breaking optimization step...")
                     break
                 self.update_parameter(pg['params'], D)
-                self.loss = self.model.loss(input, target)
-                self.strategy.update(pg, last=self.last, loss=self.loss, J=J, D=D, R=R)
+                self.loss = self._loss(input, target)
+                self._strategy_update(pg, J, D, R)
                 if self.last < self.loss and self.reject_count < self.reject:     # reject the step
                     self.update_parameter(params=pg['params'], step=-D)
                     self.loss, self.reject_count = self.last, self.reject_count + 1

@@ -1,0 +1,86 @@
+"""world_size-2 gloo runs of the sharded LM paths on the CPU (oracle stand-in backend):
+independent problems sharded by rows, pose-graph edges sharded with replicated nodes.
+Both must reproduce the single-process trajectory (same loss / damping sequence)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import pypose_amd as pp
+from tests.optim_models import InvNet, PoseGraph, T, load_lm_golden, run_steps
+from tests.oracle_backend import oracle_backend
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, kind, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    G = load_lm_golden()
+    with oracle_backend():
+        if kind == "block":
+            torch.manual_seed(3)
+            B = 8
+            init, inp = pp.randn_SE3(B, dtype=torch.float64), pp.randn_SE3(B, dtype=torch.float64)
+            lo, hi = rank * B // world, (rank + 1) * B // world
+            net = InvNet(pp.SE3(init.tensor()[lo:hi].clone()))
+            opt = pp.optim.LM(net, strategy=pp.optim.strategy.Adaptive(damping=1e-2), group=dist.group.WORLD)
+            rec = run_steps(opt, (pp.SE3(inp.tensor()[lo:hi].clone()),), {}, 3)
+        else:
+            edges, poses, infos = T(G["pgo40/edges"]), T(G["pgo40/poses"]), T(G["pgo40/infos"])
+            sel = torch.arange(rank, edges.shape[0], world)              # interleaved edge shard
+            graph = PoseGraph(pp.SE3(T(G["pgo40/init"])))                 # nodes replicated
+            opt = pp.optim.LM(graph, solver=pp.optim.solver.PCG(tol=1e-13, maxiter=2000, check_every=1),
+                              strategy=pp.optim.strategy.TrustRegion(radius=1e4), min=1e-6, group=dist.group.WORLD)
+            rec = run_steps(opt, ((edges[sel], pp.SE3(poses[sel])),), {"weight": infos[sel]}, 4)
+            rec["nodes"] = graph.nodes.detach().tensor().numpy()
+    q.put((rank, rec))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run(kind):
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, kind, q)) for r in range(2)]
+    [p.start() for p in procs]
+    out = dict(q.get() for _ in range(2))
+    [p.join(60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    return out
+
+
+@pytest.mark.timeout(300)
+def test_sharded_independent_problems_match_single_process():
+    out = _run("block")
+    with oracle_backend():
+        torch.manual_seed(3)
+        init, inp = pp.randn_SE3(8, dtype=torch.float64), pp.randn_SE3(8, dtype=torch.float64)
+        net = InvNet(init)
+        opt = pp.optim.LM(net, strategy=pp.optim.strategy.Adaptive(damping=1e-2))
+        ref = run_steps(opt, (inp,), {}, 3)
+    for r in (0, 1):
+        assert out[r]["kind"] == ["block"] * 3
+        np.testing.assert_allclose(out[r]["loss"][:2], ref["loss"][:2], rtol=1e-9)
+        np.testing.assert_allclose(out[r]["damping"], ref["damping"], rtol=1e-12)
+
+
+@pytest.mark.timeout(300)
+def test_sharded_pose_graph_matches_reference_trajectory():
+    out = _run("graph")
+    G = load_lm_golden()
+    for r in (0, 1):
+        assert out[r]["kind"] == ["graph"] * 4
+        np.testing.assert_allclose(out[r]["loss"][:3], G["pgo40/infos/loss"][:3], rtol=1e-7)
+        np.testing.assert_allclose(out[r]["damping"][:3], G["pgo40/infos/damping"][:3], rtol=1e-12)
+    np.testing.assert_allclose(out[0]["nodes"], out[1]["nodes"], rtol=0, atol=1e-12)   # replicas stay in lock-step

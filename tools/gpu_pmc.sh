@@ -1,0 +1,28 @@
+#!/bin/bash
+# HBM traffic counters for the dominant kernels (separate --pmc passes, kernel-trace only).
+set -u
+cd "$(dirname "$0")/.."
+R=$GRAFT_REPO_ROOT
+mkdir -p gpurun_out/pmc
+cd /tmp && export TMPDIR=/tmp
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/gpurun_out/pmc/$c -o pmc -- python $R/tools/pmc_probe.py > $R/gpurun_out/pmc/$c.log 2>&1
+  tail -2 $R/gpurun_out/pmc/$c.log
+done
+cd $R
+python - <<'PY'
+import csv, glob, json, collections
+res = collections.defaultdict(dict)
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    for f in glob.glob(f"gpurun_out/pmc/{c}/**/*counter_collection.csv", recursive=True):
+        acc = collections.defaultdict(list)
+        for row in csv.DictReader(open(f)):
+            if row.get("Counter_Name") == c:
+                acc[row["Kernel_Name"]].append(float(row["Counter_Value"]))
+        for k, v in acc.items():
+            short = "copy16" if "copy16" in k else ("se3_exp_fwd" if "se3_exp_fwd" in k else ("se3_log_fwd" if "se3_log_fwd" in k else None))
+            if short:
+                res[short][c] = sum(v) / len(v)
+print(json.dumps(res, indent=1))
+json.dump(res, open("gpurun_out/pmc/pmc_raw.json", "w"), indent=1)
+PY

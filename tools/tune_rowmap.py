@@ -4,7 +4,7 @@ Run on the GPU box: python tools/tune_rowmap.py [N]  -> gpurun_out/tune_rowmap.j
 """
 import ctypes, json, sys, time
 import torch
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pypose_amd import _C
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
