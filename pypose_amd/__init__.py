@@ -18,3 +18,4 @@ from .lietensor import tensor, translation, rotation, scale, matrix, euler, vec2
 from .lietensor.lietensor import retain_ltype
 from .basics import pm, cumops, cummul, cumprod, cumops_, cummul_, cumprod_
 from . import optim
+from . import module

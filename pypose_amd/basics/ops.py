@@ -31,6 +31,10 @@ def cumops_(input, dim, ops):
 
 
 def cummul_(input, dim, left=True):
+    from .scan import try_scan_
+    done = try_scan_(input, dim, left)      # on group LieTensors ``*`` is the group product
+    if done is not None:
+        return done
     return cumops_(input, dim, (lambda a, b: b * a) if left else (lambda a, b: a * b))
 
 

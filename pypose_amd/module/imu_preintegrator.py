@@ -1,0 +1,225 @@
+"""IMU pre-integration (host-side mirror of pypose/module/imu_preintegrator.py:8-465).
+
+Same constructor, buffers, ``forward(dt, gyro, acc, rot=None, gyro_cov=None, acc_cov=None,
+init_state=None)`` contract and returned dictionary (``rot``, ``vel``, ``pos``, ``cov``, ``Rij``).
+
+Two execution routes:
+
+* fused (no gradient required, tensors on the GPU): two HIP kernels -- ``pplie_imu_integrate``
+  (Exp of the gyro increments, the SO3 product scan, the velocity / position / time prefix sums
+  and the state prediction in one pass, one wavefront per sequence) and ``pplie_imu_cov``
+  (the 9x9 covariance by its backward recurrence, never materialising [B,F+1,9,9]);
+* composed (gradients flow, or host tensors): the same algebra written with LieTensor ops, each
+  of which is a HIP kernel with a custom backward.
+
+The covariance follows the reference's CODE (a sum over suffix products, :438-464), not the
+textbook recursion in its docstring -- see SURVEY.md Appendix C.
+"""
+import ctypes
+
+import torch
+from torch import nn
+
+from .. import _C
+from ..basics import cumprod
+from ..lietensor import LieTensor, SO3, identity_SO3, so3, vec2skew
+
+_INT_SIG = [ctypes.c_void_p] * 8 + [ctypes.POINTER(ctypes.c_double)] + [ctypes.c_void_p] * 6 + \
+           [ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p]
+_COV_SIG = [ctypes.c_void_p] * 6 + [ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
+                                    ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p]
+
+
+def _sfx(t):
+    return "_f32" if t.dtype == torch.float32 else "_f64"
+
+
+class IMUPreintegrator(nn.Module):
+    def __init__(self, pos=torch.zeros(3), rot=None, vel=torch.zeros(3), gravity=9.81007,
+                 gyro_cov=(3.2e-3) ** 2, acc_cov=(8e-2) ** 2, prop_cov=True, reset=False):
+        super().__init__()
+        if not reset and not prop_cov:
+            raise RuntimeError('"prop_cov" and "reset" cannot be False simultaneously.')
+        self.reset, self.prop_cov = reset, prop_cov
+        rot = identity_SO3() if rot is None else rot
+        if isinstance(acc_cov, float):
+            acc_cov = torch.tensor([[acc_cov, acc_cov, acc_cov]])
+        if isinstance(gyro_cov, float):
+            gyro_cov = torch.tensor([[gyro_cov, gyro_cov, gyro_cov]])
+        self.register_buffer('gravity', torch.tensor([0, 0, gravity]), persistent=False)
+        self.register_buffer('pos', self._check(pos).clone(), persistent=False)
+        self.register_buffer('rot', self._check(rot).clone(), persistent=False)
+        self.register_buffer('vel', self._check(vel).clone(), persistent=False)
+        self.register_buffer('cov', torch.zeros(1, 9, 9), persistent=False)
+        self.register_buffer('gyro_cov', gyro_cov, persistent=False)
+        self.register_buffer('acc_cov', acc_cov, persistent=False)
+        self.Rij = None      # rotation corresponding to the "zero-state" covariance
+
+    def _check(self, obj):
+        if obj is not None:
+            if len(obj.shape) == 2:
+                obj = obj[None, ...]
+            elif len(obj.shape) == 1:
+                obj = obj[None, None, ...]
+        return obj
+
+    # ------------------------------------------------------------------------------------------
+    def forward(self, dt, gyro, acc, rot: SO3 = None, gyro_cov=None, acc_cov=None, init_state=None):
+        assert (0 < len(acc.shape) == len(dt.shape) == len(gyro.shape) <= 3)
+        acc, gyro, dt, rot = self._check(acc), self._check(gyro), self._check(dt), self._check(rot)
+        B = dt.shape[0]
+        if init_state is None:
+            init_state = {'pos': self.pos, 'rot': self.rot, 'vel': self.vel}
+        if self.prop_cov:
+            gyro_cov = self.gyro_cov.repeat([B, 1, 1]) if gyro_cov is None else gyro_cov
+            acc_cov = self.acc_cov.repeat([B, 1, 1]) if acc_cov is None else acc_cov
+            if 'cov' not in init_state or init_state['cov'] is None:
+                init_cov = self.cov.expand(B, 9, 9)
+            else:
+                init_cov = init_state['cov']
+            Rij0 = init_state['Rij'] if 'Rij' in init_state else self.Rij
+
+        fused = self._fused_ok(dt, gyro, acc, rot, init_state)
+        if fused:
+            predict, aux = self._fused_integrate(dt, gyro, acc, rot, init_state, Rij0 if self.prop_cov else None)
+            if self.prop_cov:
+                Rij = LieTensor(aux['Rij'], ltype=init_state['rot'].ltype) if isinstance(init_state['rot'], LieTensor) \
+                    else SO3(aux['Rij'])
+                cov = {'cov': self._fused_cov(dt, aux, init_cov, gyro_cov, acc_cov), 'Rij': Rij[..., -1:, :]}
+            else:
+                cov = {'cov': None}
+        else:
+            inte_state = self.integrate(dt, gyro, acc, rot=rot, init_rot=init_state['rot'])
+            predict = self.predict(init_state, inte_state)
+            if self.prop_cov:
+                Rij = Rij0 * inte_state['Dr'] if Rij0 is not None else inte_state['Dr']
+                cov_input_state = {'Rij': Rij.detach(), 'Rk': inte_state['w'].detach(),
+                                   'Ha': vec2skew(inte_state['a'].detach()), 'dt': dt.detach()}
+                cov = self.propagate_cov(cov_input=cov_input_state, init_cov=init_cov, gyro_cov=gyro_cov, acc_cov=acc_cov)
+            else:
+                cov = {'cov': None}
+
+        if not self.reset:
+            self.pos = predict['pos'][..., -1:, :]
+            self.rot = predict['rot'][..., -1:, :]
+            self.vel = predict['vel'][..., -1:, :]
+            self.cov = cov['cov']
+            self.Rij = Rij[..., -1:, :]
+        return {**predict, **cov}
+
+    # ---- fused route ---------------------------------------------------------------------------
+    def _fused_ok(self, dt, gyro, acc, rot, init_state):
+        ts = [dt, gyro, acc, init_state['pos'], init_state['rot'], init_state['vel']] + ([rot] if rot is not None else [])
+        if _C._test_backend is not None or not all(t.is_cuda for t in ts):
+            return False
+        if torch.is_grad_enabled() and any(t.requires_grad for t in ts):
+            return False
+        return dt.dtype in (torch.float32, torch.float64) and all(t.dtype == dt.dtype for t in ts)
+
+    def _fused_integrate(self, dt, gyro, acc, rot, init_state, Rij0):
+        B, F = dt.shape[:2]
+        dev, dty = dt.device, dt.dtype
+        c = lambda t: t.contiguous()
+        r0 = c(torch.Tensor.as_subclass(init_state['rot'], torch.Tensor).expand(B, 1, 4).reshape(B, 4))
+        v0 = c(init_state['vel'].expand(B, 1, 3).reshape(B, 3))
+        p0 = c(init_state['pos'].expand(B, 1, 3).reshape(B, 3))
+        dtc, gy, ac = c(dt), c(gyro), c(acc)
+        rk = c(torch.Tensor.as_subclass(rot, torch.Tensor).expand(B, F, 4)) if rot is not None else None
+        q0 = c(torch.Tensor.as_subclass(Rij0, torch.Tensor).expand(B, 1, 4).reshape(B, 4)) if Rij0 is not None else None
+        orot = torch.empty((B, F, 4), dtype=dty, device=dev)
+        ovel = torch.empty((B, F, 3), dtype=dty, device=dev)
+        opos = torch.empty((B, F, 3), dtype=dty, device=dev)
+        aux = {}
+        if self.prop_cov:
+            aux = {'Rk': torch.empty((B, F, 4), dtype=dty, device=dev), 'Rij': torch.empty((B, F, 4), dtype=dty, device=dev),
+                   'a': torch.empty((B, F, 3), dtype=dty, device=dev)}
+        g = (ctypes.c_double * 3)(*[float(x) for x in self.gravity.tolist()])
+        P = lambda t: t.data_ptr() if t is not None else None
+        fn = _C.library().symbol("pplie_imu_integrate" + _sfx(dt), _INT_SIG)
+        with torch.cuda.device(dev):
+            code = fn(P(dtc), P(gy), P(ac), P(rk), P(r0), P(v0), P(p0), P(q0), g, P(orot), P(ovel), P(opos),
+                      P(aux.get('Rk')), P(aux.get('Rij')), P(aux.get('a')), B, F, _C.stream_ptr(dev))
+        _C.check(code, "pplie_imu_integrate")
+        rot_out = LieTensor(orot, ltype=init_state['rot'].ltype) if isinstance(init_state['rot'], LieTensor) else SO3(orot)
+        return {'rot': rot_out, 'vel': ovel, 'pos': opos}, aux
+
+    def _fused_cov(self, dt, aux, init_cov, gyro_cov, acc_cov):
+        B, F = dt.shape[:2]
+        cov = torch.empty((B, 9, 9), dtype=dt.dtype, device=dt.device)
+
+        def strided(cv):            # [B or 1, F or 1, 3] -> element strides over (b, f)
+            cv = cv.to(dt.dtype)
+            cv = cv if cv.dim() == 3 else cv.reshape(-1, 1, 3)
+            cv = cv.contiguous()
+            sb = cv.stride(0) if cv.shape[0] > 1 else 0
+            sf = cv.stride(1) if cv.shape[1] > 1 else 0
+            return cv, sb, sf
+        gc, gsb, gsf = strided(gyro_cov)
+        ac, asb, asf = strided(acc_cov)
+        ic = init_cov.to(dt.dtype).expand(B, 9, 9).contiguous()
+        fn = _C.library().symbol("pplie_imu_cov" + _sfx(dt), _COV_SIG)
+        with torch.cuda.device(dt.device):
+            code = fn(dt.contiguous().data_ptr(), aux['Rk'].data_ptr(), aux['Rij'].data_ptr(), aux['a'].data_ptr(),
+                      ic.data_ptr(), gc.data_ptr(), gsb, gsf, ac.data_ptr(), asb, asf, cov.data_ptr(), B, F,
+                      _C.stream_ptr(dt.device))
+        _C.check(code, "pplie_imu_cov")
+        return cov
+
+    # ---- composed (differentiable) route: reference :314-465 --------------------------------------
+    def integrate(self, dt, gyro, acc, rot: SO3 = None, init_rot: SO3 = None):
+        B, F = dt.shape[:2]
+        dr = so3(gyro * dt).Exp()
+        w = torch.cat([identity_SO3(B, 1, dtype=dt.dtype, device=dt.device), dr], dim=1)
+        incre_r = cumprod(w, dim=1, left=False)
+        if isinstance(rot, LieTensor):
+            a = acc - rot.Inv() @ self.gravity
+        else:
+            if init_rot is None:
+                init_rot = identity_SO3(B, 1, dtype=dt.dtype, device=dt.device)
+            a = acc - (init_rot * incre_r)[:, 1:, :].Inv() @ self.gravity
+        Ra = incre_r[:, :F, :] @ a
+        zeros = torch.zeros(B, 1, 3, dtype=dt.dtype, device=dt.device)
+        incre_v = torch.cumsum(torch.cat([zeros, Ra * dt], dim=1), dim=1)
+        incre_p = torch.cumsum(torch.cat([zeros, incre_v[:, :F, :] * dt + Ra * 0.5 * dt ** 2], dim=1), dim=1)
+        incre_t = torch.cat([torch.zeros(B, 1, 1, dtype=dt.dtype, device=dt.device), torch.cumsum(dt, dim=1)], dim=1)
+        return {'a': a, 'Dp': incre_p[:, 1:, :], 'Dv': incre_v[..., 1:, :], 'Dr': incre_r[:, 1:, :],
+                'Dt': incre_t[..., 1:, :], 'w': w[:, 1:, :]}
+
+    @classmethod
+    def predict(cls, init_state, integrate):
+        return {
+            'rot': init_state['rot'] * integrate['Dr'],
+            'vel': init_state['vel'] + init_state['rot'] * integrate['Dv'],
+            'pos': init_state['pos'] + init_state['rot'] * integrate['Dp'] + init_state['vel'] * integrate['Dt'],
+        }
+
+    @classmethod
+    def propagate_cov(cls, cov_input, init_cov, gyro_cov, acc_cov):
+        """cov = sum_k P_k Bc_k P_k^T with P_k = A_k ... A_{F-1}, Bc_0 = init_cov (reference :428-465),
+        evaluated by one backward pass P <- A_k P, cov += P Bc_k P^T (no [B,F+1,9,9] scan)."""
+        dt = cov_input['dt']
+        B, F = dt.shape[:2]
+        dev, dty = dt.device, dt.dtype
+        Cg, Ca = torch.diag_embed(gyro_cov).to(dty), torch.diag_embed(acc_cov).to(dty)
+        Rk, Rij, Ha = cov_input['Rk'].matrix(), cov_input['Rij'].matrix(), cov_input['Ha']
+        h = dt.unsqueeze(-1)                                       # [B,F,1,1]
+        A = torch.eye(9, device=dev, dtype=dty).repeat([B, F, 1, 1])
+        A[..., 0:3, 0:3] = Rk.mT
+        A[..., 3:6, 0:3] = -(Rij @ Ha) * h
+        A[..., 6:9, 0:3] = -0.5 * (Rij @ Ha) * h ** 2
+        A[..., 6:9, 3:6] = torch.eye(3, device=dev, dtype=dty) * h
+        Bg = torch.zeros(B, F, 9, 3, device=dev, dtype=dty)
+        Ba = torch.zeros(B, F, 9, 3, device=dev, dtype=dty)
+        Bg[..., 0:3, 0:3] = cov_input['Rk'].Jr() * h
+        Ba[..., 3:6, 0:3] = Rij * h
+        Ba[..., 6:9, 0:3] = 0.5 * Rij * h ** 2
+        Bc = (Bg @ Cg @ Bg.mT + Ba @ Ca @ Ba.mT) / h              # Bc[:, k] is the reference's B_cov[k+1]
+        P = torch.eye(9, device=dev, dtype=dty).repeat([B, 1, 1])
+        cov = torch.zeros(B, 9, 9, device=dev, dtype=dty)
+        for k in range(F, 0, -1):
+            if k < F:
+                P = A[:, k] @ P
+            cov = cov + P @ Bc[:, k - 1] @ P.mT
+        P = A[:, 0] @ P
+        cov = cov + P @ init_cov @ P.mT
+        return {'cov': cov, 'Rij': cov_input['Rij'][..., -1:, :]}
