@@ -3,8 +3,9 @@
 #pragma once
 #include "rowmap.h"
 
-// Defines functors Op_<g>_<op> for a group with algebra width DA and group width DG.
-#define PPLIE_DEFINE_GROUP(g, DA, DG, RPT_LOG)                                          \
+// PPLIE_DEFINE_GROUP_OPS defines functors Op_<g>_<op> for a group with algebra width DA and group
+// width DG; PPLIE_EXPORT_GROUP exports them (TileOf specialisations go in between).
+#define PPLIE_DEFINE_GROUP_OPS(g, DA, DG)                                               \
   namespace pplie {                                                              \
   PPLIE_OP_1_1(Op_##g##_exp_fwd, g##_exp, DA, DG)                                \
   PPLIE_OP_2_1(Op_##g##_exp_bwd, g##_exp_bwd, DA, DG, DA)                        \
@@ -23,10 +24,12 @@
   PPLIE_OP_2_1(Op_##g##_adjt_fwd, g##_adjt, DG, DA, DA)                          \
   PPLIE_OP_3_2(Op_##g##_adjt_bwd, g##_adjt_bwd, DG, DA, DA, DG, DA)              \
   PPLIE_OP_2_1(Op_##g##_jinvp_fwd, g##_jinvp, DG, DA, DA)                        \
-  }                                                                              \
+  }
+
+#define PPLIE_EXPORT_GROUP(g)                                                    \
   PPLIE_EXPORT(pplie_##g##_exp_fwd, pplie::Op_##g##_exp_fwd)                     \
   PPLIE_EXPORT(pplie_##g##_exp_bwd, pplie::Op_##g##_exp_bwd)                     \
-  PPLIE_EXPORT_RPT(pplie_##g##_log_fwd, pplie::Op_##g##_log_fwd, RPT_LOG, 1)     \
+  PPLIE_EXPORT(pplie_##g##_log_fwd, pplie::Op_##g##_log_fwd)                     \
   PPLIE_EXPORT(pplie_##g##_log_bwd, pplie::Op_##g##_log_bwd)                     \
   PPLIE_EXPORT(pplie_##g##_inv_fwd, pplie::Op_##g##_inv_fwd)                     \
   PPLIE_EXPORT(pplie_##g##_inv_bwd, pplie::Op_##g##_inv_bwd)                     \

@@ -1,4 +1,4 @@
 // lie_rxso3.hip -- C-ABI entry points of the rxso3 / RXSO3 op set (include/pplie.h).
 #include "lie_ops.h"
-// last argument: rows per lane of the fp32 log_fwd tile (tuned on MI355X, profiles/r01)
-PPLIE_DEFINE_GROUP(rxso3, 4, 5, 2)
+PPLIE_DEFINE_GROUP_OPS(rxso3, 4, 5)
+PPLIE_EXPORT_GROUP(rxso3)

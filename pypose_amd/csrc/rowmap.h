@@ -251,18 +251,27 @@ int launch_rowmap_direct(const void* i0, const void* i1, const void* i2, void* o
     static PP_HD void apply(const T* a, const T* b, const T* c, T* o, T* p) { FN<T>(a, b, c, o, p); } \
   };
 
+// Tile shape of an op: rows per lane per tile (tile = RPT x 256 rows).  Default: 2 rows per lane
+// while the LDS slabs stay <= 28 KB per workgroup, else 1 (multi-slab backward kernels would drop
+// to 2 workgroups per CU); fp64 always 1.  Ops measured faster at another shape on MI355X
+// (profiles/r01/tune_*.json) specialise TileOf.
+template <class Op> struct TileOf {
+  static constexpr int sumw = Op::IW0 + Op::IW1 + Op::IW2 + Op::OW0 + Op::OW1;
+  static constexpr int rpt32 = sumw <= 14 ? 2 : 1;
+  static constexpr int rpt64 = 1;
+};
+#define PPLIE_TILE(OP, RPT32) \
+  template <> struct TileOf<OP<float>> { static constexpr int rpt32 = RPT32; static constexpr int rpt64 = 1; };
+
 // C-ABI export of one op in both precisions (uniform signature, see include/pplie.h).
-// RPT = rows per lane per tile (tile = RPT * 256 rows): 2 by default; ops whose slab sizes are
-// not a whole number of 256 x 16 B chunks at RPT=2 (odd widths) may measure faster at 4.
-#define PPLIE_EXPORT_RPT(SYM, OP, RPT32, RPT64)                                                                  \
+#define PPLIE_EXPORT(SYM, OP)                                                                                    \
   extern "C" int SYM##_f32(const void* i0, const void* i1, const void* i2, void* o0, void* o1, int64_t n,        \
                            void* stream) {                                                                       \
-    return pplie::launch_rowmap<float, OP<float>, RPT32>(i0, i1, i2, o0, o1, n, stream);                         \
+    return pplie::launch_rowmap<float, OP<float>, pplie::TileOf<OP<float>>::rpt32>(i0, i1, i2, o0, o1, n, stream); \
   }                                                                                                              \
   extern "C" int SYM##_f64(const void* i0, const void* i1, const void* i2, void* o0, void* o1, int64_t n,        \
                            void* stream) {                                                                       \
-    return pplie::launch_rowmap<double, OP<double>, RPT64>(i0, i1, i2, o0, o1, n, stream);                       \
+    return pplie::launch_rowmap<double, OP<double>, 1>(i0, i1, i2, o0, o1, n, stream);                           \
   }
-#define PPLIE_EXPORT(SYM, OP) PPLIE_EXPORT_RPT(SYM, OP, 2, 1)
 
 }  // namespace pplie

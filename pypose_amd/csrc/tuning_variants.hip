@@ -31,6 +31,39 @@ extern "C" int pplie_var_se3_exp_f32(int path, int rpt, int grid_cap, const void
 extern "C" int pplie_var_se3_log_f32(int path, int rpt, int grid_cap, const void* x, void* y, int64_t n, void* stream) {
   return pplie::var_dispatch<pplie::Var_se3_log<float>>(path, rpt, grid_cap, x, y, n, stream);
 }
+
+// general (multi-slab) variants: rpt in {1,2,4} x block in {128,256}
+namespace pplie {
+PPLIE_OP_2_1(Var_se3_exp_bwd, se3_exp_bwd, 6, 7, 6)
+PPLIE_OP_2_1(Var_se3_log_bwd, se3_log_bwd, 6, 6, 7)
+PPLIE_OP_2_1(Var_se3_mul_fwd, se3_mul, 7, 7, 7)
+PPLIE_OP_2_2(Var_se3_mul_bwd, se3_mul_bwd, 7, 7, 7, 7)
+PPLIE_OP_3_2(Var_se3_act_bwd, se3_act_bwd, 7, 3, 3, 7, 3)
+template <class Op>
+int var_general(int rpt, int block, const void* a, const void* b, const void* c, void* o, void* p, int64_t n, void* st) {
+  if (block == 256) {
+    if (rpt == 1) return launch_rowmap<float, Op, 1, 256>(a, b, c, o, p, n, st);
+    if (rpt == 2) return launch_rowmap<float, Op, 2, 256>(a, b, c, o, p, n, st);
+    if (rpt == 4) return launch_rowmap<float, Op, 4, 256>(a, b, c, o, p, n, st);
+  } else if (block == 128) {
+    if (rpt == 1) return launch_rowmap<float, Op, 1, 128>(a, b, c, o, p, n, st);
+    if (rpt == 2) return launch_rowmap<float, Op, 2, 128>(a, b, c, o, p, n, st);
+    if (rpt == 4) return launch_rowmap<float, Op, 4, 128>(a, b, c, o, p, n, st);
+  }
+  return PPLIE_EBADARG;
+}
+}  // namespace pplie
+#define PPLIE_VAR_GENERAL(NAME)                                                                                      \
+  extern "C" int pplie_var_##NAME##_f32(int rpt, int block, const void* a, const void* b, const void* c, void* o,    \
+                                        void* p, int64_t n, void* st) {                                              \
+    return pplie::var_general<pplie::Var_##NAME<float>>(rpt, block, a, b, c, o, p, n, st);                           \
+  }
+PPLIE_VAR_GENERAL(se3_exp_bwd)
+PPLIE_VAR_GENERAL(se3_log_bwd)
+PPLIE_VAR_GENERAL(se3_mul_fwd)
+PPLIE_VAR_GENERAL(se3_mul_bwd)
+PPLIE_VAR_GENERAL(se3_act_bwd)
+
 // device-copy ceiling: nbytes must be a multiple of 16
 extern "C" int pplie_var_copy(const void* src, void* dst, int64_t nbytes, int grid, void* stream) {
   hipLaunchKernelGGL(pplie::copy16_kernel, dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
