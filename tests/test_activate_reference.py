@@ -1,0 +1,84 @@
+"""The activation shim (pypose_amd.activate) on top of the REAL reference, when it is present
+(build container only: /root/reference does not exist on the GPU box).  With the oracle stand-in
+backend and force=True every Lie op of ``pypose`` runs through pypose_amd's Functions; results
+and gradients must coincide with the reference's own, and the reference's LM must walk the same
+trajectory."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+REF = "/root/reference"
+pytestmark = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "pypose")), reason="reference not present")
+
+
+@pytest.fixture(scope="module")
+def ref_pp():
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, REF)
+    try:
+        import pypose
+        yield pypose
+    finally:
+        sys.path.remove(REF)
+
+
+def test_activated_reference_matches_itself(ref_pp):
+    from pypose_amd import activate
+    from tests.oracle_backend import oracle_backend
+    pp = ref_pp
+    torch.manual_seed(0)
+    D = torch.float64
+
+    def workload():
+        torch.manual_seed(1)
+        x = pp.randn_se3(5, dtype=D, requires_grad=True)
+        X = pp.randn_SE3(5, dtype=D)
+        p = torch.randn(5, 3, dtype=D, requires_grad=True)
+        a = pp.randn_se3(5, dtype=D)
+        Y = x.Exp() * X
+        out = (Y.Inv() @ X).Log().tensor().sum() + Y.Act(p).sum() + Y.Adj(a).tensor().sum() + Y.AdjT(a).tensor().sum()
+        out.backward()
+        S = pp.randn_Sim3(4, dtype=D)
+        return [out.detach(), x.grad.clone(), p.grad.clone(), S.Log().Exp().tensor(), (S * S.Inv()).tensor()]
+
+    want = workload()
+    with oracle_backend():
+        activate.activate(pp, force=True)
+        try:
+            got = workload()
+            assert type(pp.lietensor.lietensor.SE3_Log).__name__ == "_Dispatch"
+        finally:
+            activate.deactivate()
+    assert pp.lietensor.lietensor.SE3_Log.__name__ == "SE3_Log"
+    for g, w in zip(got, want):
+        torch.testing.assert_close(g, w, rtol=1e-9, atol=1e-11)
+
+
+def test_reference_lm_runs_on_activated_ops(ref_pp):
+    from pypose_amd import activate
+    from tests.optim_models import load_lm_golden
+    from tests.oracle_backend import oracle_backend
+    pp = ref_pp
+    G = load_lm_golden()
+
+    class InvNet(torch.nn.Module):
+        def __init__(self, init):
+            super().__init__()
+            self.pose = pp.Parameter(init)
+
+        def forward(self, input):
+            return (self.pose @ input).Log().tensor()
+
+    with oracle_backend():
+        activate.activate(pp, force=True)
+        try:
+            net = InvNet(pp.SE3(torch.from_numpy(G["invnet/init"].copy())))
+            opt = pp.optim.LM(net, strategy=pp.optim.strategy.Constant(damping=1e-4))     # the reference's own LM
+            inp = pp.SE3(torch.from_numpy(G["invnet/input"].copy()))
+            losses = [float(opt.step(inp)) for _ in range(2)]
+        finally:
+            activate.deactivate()
+    np.testing.assert_allclose(losses, G["invnet/constant/loss"][:2], rtol=1e-6)
