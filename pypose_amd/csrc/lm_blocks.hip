@@ -87,6 +87,23 @@ template <class T, int DP> struct Op_chol_solve {
   }
 };
 
+// Ainv = A^-1 for SPD blocks (block-Jacobi preconditioner of the pose-graph PCG): Cholesky, then
+// the columns of the identity are solved one by one.
+template <class T, int DP> struct Op_spd_inverse {
+  enum { IW0 = DP * DP, IW1 = 0, IW2 = 0, OW0 = DP * DP, OW1 = 0 };
+  static PP_HD void apply(const T* A, const T*, const T*, T* X, T*) {
+#pragma unroll
+    for (int c = 0; c < DP; ++c) {
+      T g[DP], x[DP];
+#pragma unroll
+      for (int i = 0; i < DP; ++i) g[i] = (i == c) ? T(-1) : T(0);
+      Op_chol_solve<T, DP>::apply(A, g, nullptr, x, nullptr);
+#pragma unroll
+      for (int i = 0; i < DP; ++i) X[i * DP + c] = x[i];
+    }
+  }
+};
+
 // 64-lane workgroups: the per-problem slabs are wide (up to 8x8 + 8x8 + 8 + 64 scalars)
 template <class T, int DR, int DP> int normal_eq_launch(const void* J, const void* r, const void* W, void* A, void* g,
                                                         int64_t n, void* stream) {
@@ -130,8 +147,22 @@ template <class T> int chol_dispatch(int dp, const void* A, const void* g, void*
   return PPLIE_EBADARG;
 }
 
+template <class T> int spd_inverse_dispatch(int dp, const void* A, void* X, int64_t n, void* stream) {
+  switch (dp) {
+    case 3: return launch_rowmap<T, Op_spd_inverse<T, 3>, 1, 64>(A, nullptr, nullptr, X, nullptr, n, stream);
+    case 6: return launch_rowmap<T, Op_spd_inverse<T, 6>, 1, 64>(A, nullptr, nullptr, X, nullptr, n, stream);
+    case 7: return launch_rowmap<T, Op_spd_inverse<T, 7>, 1, 64>(A, nullptr, nullptr, X, nullptr, n, stream);
+  }
+  return PPLIE_EBADARG;
+}
 }  // namespace pplie
 
+extern "C" int pplie_block_spd_inverse_f32(const void* A, void* X, int64_t n, int dp, void* stream) {
+  return pplie::spd_inverse_dispatch<float>(dp, A, X, n, stream);
+}
+extern "C" int pplie_block_spd_inverse_f64(const void* A, void* X, int64_t n, int dp, void* stream) {
+  return pplie::spd_inverse_dispatch<double>(dp, A, X, n, stream);
+}
 extern "C" int pplie_block_normal_eq_f32(const void* J, const void* r, const void* W, void* A, void* g, int64_t n, int dr,
                                          int dp, void* stream) {
   return pplie::normal_eq_dispatch<float>(dr, dp, J, r, W, A, g, n, stream);

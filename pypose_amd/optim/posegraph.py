@@ -36,7 +36,9 @@ from ..lietensor import lietensor as _lt
 from . import blocks as _blocks
 
 _SPMV_SIG = [ctypes.c_void_p] * 5 + [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
-_ASM_SIG = [ctypes.c_void_p] * 6 + [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+_ASM_SIG = [ctypes.c_void_p] * 7 + [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+_BSR_SIG = [ctypes.c_void_p] * 8 + [ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]
+_INV_SIG = [ctypes.c_void_p] * 2 + [ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]
 _HIP_SHAPES = {(6, 6, 2), (7, 7, 2), (3, 3, 2), (6, 6, 1), (3, 3, 1)}
 DENSE_LIMIT = 4096          # assemble a dense A for the user's solver up to this many unknowns
 
@@ -107,6 +109,123 @@ def _all_reduce(t, group):
     return t
 
 
+_PCG_SIG = [ctypes.c_int] + [ctypes.c_void_p] * 10 + [ctypes.c_int, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]
+
+
+class FusedPCG:
+    """Device-resident block-Jacobi PCG for one graph shape (csrc/graph.hip).
+
+    Five small launches per iteration (memset, ``pplie_graph_spmv``, and the fused vector stages of
+    ``pplie_pcg_stage``) with every scalar kept on the device; ``check_every`` iterations are captured
+    into one hipGraph and replayed, so the loop costs neither Python dispatch nor a host sync per
+    iteration.  Buffers (and the graph) are cached per shape and reused across LM steps.
+    """
+
+    def __init__(self, E, K, dr, m, N, dtype, device, has_w, check_every):
+        z = lambda *s: torch.zeros(s, dtype=dtype, device=device)
+        self.key = (E, K, dr, m, N, dtype, device, has_w, check_every)
+        self.E, self.K, self.dr, self.m, self.N, self.check_every = E, K, dr, m, N, check_every
+        self.J, self.W = z(E, K, dr, m), (z(E, dr, dr) if has_w else None)
+        self.idx = torch.zeros((E, K), dtype=torch.int64, device=device)
+        self.Binv, self.shift = z(N, m, m), z(N, m)
+        self.x, self.r, self.p, self.q, self.z = (z(N, m) for _ in range(5))
+        self.scal = z(4)
+        self.cap = 1 << 16
+        self.rr_hist = z(self.cap)
+        self.it = torch.zeros(1, dtype=torch.int32, device=device)
+        self.sfx = "_f32" if dtype == torch.float32 else "_f64"
+        self.graph = None
+
+    def _csr(self, idx):
+        """incidence lists sorted by node (rebuilt only when the edge list changes)"""
+        if getattr(self, '_csr_idx', None) is not None and self._csr_idx.shape == idx.shape and torch.equal(self._csr_idx, idx):
+            return
+        E, N = self.E, self.N
+        flat = idx.t().reshape(-1)                                 # [side0 entries | side1 entries]
+        order = torch.argsort(flat, stable=True)
+        self.ptr = torch.zeros(N + 1, dtype=torch.int32, device=idx.device)
+        self.ptr[1:] = torch.cumsum(torch.bincount(flat, minlength=N), 0).to(torch.int32)
+        e, side = order % E, order // E
+        self.blk = (2 * e + side).to(torch.int32)
+        self.other = idx[e, 1 - side].to(torch.int32)
+        self._csr_idx = idx.clone()
+        self.graph = None                                           # captured pointers are stale
+
+    def _iteration(self, group):
+        lib = _C.library()
+        st = _C.stream_ptr(self.J.device)
+        stage = lib.symbol("pplie_pcg_stage" + self.sfx, _PCG_SIG)
+        if self.bsr:
+            code = lib.symbol("pplie_graph_bsr_spmv" + self.sfx, _BSR_SIG)(
+                self.ptr.data_ptr(), self.blk.data_ptr(), self.other.data_ptr(), self.HB.data_ptr(), self.D.data_ptr(),
+                self.p.data_ptr(), self.q.data_ptr(), self.scal.data_ptr(), self.N, self.m, st)
+            _C.check(code, "pplie_graph_bsr_spmv")
+            first = 1                                               # q = A p and p.q are already done
+        else:
+            self.q.zero_()
+            code = lib.symbol("pplie_graph_spmv" + self.sfx, _SPMV_SIG)(
+                self.J.data_ptr(), self.W.data_ptr() if self.W is not None else None, self.idx.data_ptr(), self.p.data_ptr(),
+                self.q.data_ptr(), self.E, self.dr, self.m, self.K, st)
+            _C.check(code, "pplie_graph_spmv")
+            _all_reduce(self.q, group)
+            first = 0
+        for s in range(first, 4):
+            code = stage(s, self.x.data_ptr(), self.r.data_ptr(), self.p.data_ptr(), self.q.data_ptr(), self.z.data_ptr(),
+                         self.Binv.data_ptr(), self.shift.data_ptr(), self.scal.data_ptr(), self.rr_hist.data_ptr(),
+                         self.it.data_ptr(), self.cap, self.N, self.m, st)
+            _C.check(code, "pplie_pcg_stage")
+
+    def solve(self, lin, b, shift, Binv, Bd, tol, maxiter, group):
+        bsr = lin.H12 is not None and group is None and self.m in (3, 6, 7)
+        if bsr != getattr(self, 'bsr', None):
+            self.graph = None                                       # the captured iteration differs
+        self.bsr = bsr
+        if bsr:
+            self._csr(lin.idx)
+            if getattr(self, 'HB', None) is None:
+                self.HB = torch.empty((self.E, 2, self.m, self.m), dtype=self.J.dtype, device=self.J.device)
+                self.D = torch.empty((self.N, self.m, self.m), dtype=self.J.dtype, device=self.J.device)
+            self.HB[:, 0].copy_(lin.H12)
+            self.HB[:, 1].copy_(lin.H12.mT)
+            self.D.copy_(Bd)                                        # diagonal blocks incl. clamp + damping
+        else:
+            self.J.copy_(lin.J)
+            self.idx.copy_(lin.idx)
+            if self.W is not None:
+                self.W.copy_(lin.W)
+        self.Binv.copy_(Binv)
+        self.shift.copy_(shift)
+        self.x.zero_()
+        self.r.copy_(b)
+        self.z.copy_((self.Binv * self.r.unsqueeze(-2)).sum(-1))
+        self.p.copy_(self.z)
+        self.scal.zero_()
+        self.scal[0] = (self.r * self.z).sum()
+        self.it.zero_()
+        bn2 = float((b * b).sum())
+        if bn2 == 0.0:
+            return self.x.clone(), 0
+        maxiter = min(maxiter, self.cap - self.check_every)
+        done = 0
+        with torch.cuda.device(self.J.device):
+            while done < maxiter:
+                if group is None and self.graph is None and done > 0:
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):
+                        for _ in range(self.check_every):
+                            self._iteration(None)
+                    self.graph = g
+                if self.graph is not None and group is None:
+                    self.graph.replay()
+                else:
+                    for _ in range(self.check_every):
+                        self._iteration(group)
+                done += self.check_every
+                if float(self.rr_hist[done - 1]) <= tol * tol * bn2:
+                    break
+        return self.x.clone(), done
+
+
 class GraphOperator:
     """``J`` handed to ``strategy.update`` for the graph path: ``J @ D`` with D the flat step."""
 
@@ -118,7 +237,7 @@ class GraphOperator:
         Dn = lin.step_to_nodes(D)                                  # [N, m]
         JD = torch.zeros((lin.E, lin.dr), dtype=Dn.dtype, device=Dn.device)
         for k in range(lin.K):
-            JD += torch.einsum('edm,em->ed', lin.J[:, k], Dn[lin.idx[:, k]])
+            JD += (lin.J[:, k] * Dn[lin.idx[:, k]].unsqueeze(-2)).sum(-1)     # (tiny batched GEMMs are slow)
         return JD.reshape(-1, 1)
 
 
@@ -134,6 +253,7 @@ class GraphLinearization:
         self.W = weight
         self.group = getattr(opt, 'group', None)
         self.s = 1.0            # compounded damping factor prod(1 + lambda_i)
+        self.H12 = None
 
     # -- index helpers -------------------------------------------------------------------------
     def step_to_nodes(self, D):
@@ -156,9 +276,13 @@ class GraphLinearization:
         if self._hip():
             sfx = "_f32" if self.J.dtype == torch.float32 else "_f64"
             fn = _C.library().symbol("pplie_graph_assemble" + sfx, _ASM_SIG)
+            # off-diagonal blocks H12[e] = J_0^T W J_1 feed the node-parallel (atomic-free) SpMV
+            self.H12 = torch.empty((self.E, m, m), dtype=self.J.dtype, device=self.J.device) \
+                if (self.K == 2 and self.group is None and self.E < (1 << 30)) else None
             with torch.cuda.device(self.J.device):
                 code = fn(self.J.data_ptr(), self.W.data_ptr() if self.W is not None else None, self.R.data_ptr(),
-                          self.idx.data_ptr(), B.data_ptr(), g.data_ptr(), self.E, self.dr, self.m, self.K,
+                          self.idx.data_ptr(), B.data_ptr(), g.data_ptr(),
+                          self.H12.data_ptr() if self.H12 is not None else None, self.E, self.dr, self.m, self.K,
                           _C.stream_ptr(self.J.device))
             _C.check(code, "pplie_graph_assemble")
         else:
@@ -182,11 +306,11 @@ class GraphLinearization:
         else:
             q = torch.zeros((self.E, self.dr), dtype=p.dtype, device=p.device)
             for k in range(self.K):
-                q += torch.einsum('edm,em->ed', self.J[:, k], p[self.idx[:, k]])
+                q += (self.J[:, k] * p[self.idx[:, k]].unsqueeze(-2)).sum(-1)
             if self.W is not None:
                 q = (self.W @ q.unsqueeze(-1)).squeeze(-1)
             for k in range(self.K):
-                y.index_add_(0, self.idx[:, k], torch.einsum('edm,ed->em', self.J[:, k], q))
+                y.index_add_(0, self.idx[:, k], (self.J[:, k] * q.unsqueeze(-1)).sum(-2))
         return _all_reduce(y, self.group)
 
     # -- LM interface ------------------------------------------------------------------------------
@@ -218,9 +342,23 @@ class GraphLinearization:
                 solver = PCG(tol=1e-10, maxiter=max(1000, 2 * N))
             Bd = self.B.clone()
             Bd.diagonal(dim1=-2, dim2=-1).copy_(self.s * self.diag_clamped)
-            Binv = torch.linalg.inv(Bd)                              # block-Jacobi preconditioner
-            Dn = solver.solve(lambda p: self._Hp(p) + shift * p, b,
-                              lambda r: torch.einsum('nij,nj->ni', Binv, r))
+            if self._hip() and getattr(solver, 'fused', True):
+                Binv = torch.empty_like(Bd)                          # block-Jacobi preconditioner
+                fn = _C.library().symbol("pplie_block_spd_inverse" + ("_f32" if Bd.dtype == torch.float32 else "_f64"), _INV_SIG)
+                with torch.cuda.device(Bd.device):
+                    _C.check(fn(Bd.data_ptr(), Binv.data_ptr(), N, m, _C.stream_ptr(Bd.device)), "pplie_block_spd_inverse")
+                cache = self.opt.__dict__.setdefault('_pcg_workspaces', {})
+                key = (self.E, self.K, self.dr, self.m, self.N, self.J.dtype, self.J.device, self.W is not None,
+                       solver.check_every)
+                wsp = cache.get(key)
+                if wsp is None:
+                    wsp = cache[key] = FusedPCG(*key)
+                maxiter = b.numel() * 10 if solver.maxiter is None else solver.maxiter
+                Dn, solver.iterations = wsp.solve(self, b, shift, Binv, Bd, solver.tol, maxiter, self.group)
+            else:
+                Binv = torch.linalg.inv(Bd)
+                Dn = solver.solve(lambda p: self._Hp(p) + shift * p, b,
+                                  lambda r: (Binv * r.unsqueeze(-2)).sum(-1))
         assert not torch.any(torch.isnan(Dn)), 'Linear solve produced NaN (matrix may not be positive-definite)'
         return self.nodes_to_step(Dn)
 

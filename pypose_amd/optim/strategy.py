@@ -12,7 +12,9 @@ import torch
 def _gain_ratio(last, loss, J, D, R):
     """(actual decrease) / (decrease predicted by the linear model), reference strategy.py:144/261."""
     JD = J @ D
-    return (last - loss) / -(JD.mT @ (2 * R + JD)).squeeze()
+    # (JD)^T (2R + JD) as a dot product: the reference's [1,n] @ [n,1] matmul is the same number but
+    # lands on a GEMM kernel that takes milliseconds at n ~ 10^6
+    return (last - loss) / -(JD * (2 * R + JD)).sum()
 
 
 def _clip(x, lo, hi):
