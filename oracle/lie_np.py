@@ -711,18 +711,59 @@ def sim3_jinvp_fwd(X, p):
     return (_mv(sim3_Jl_inv(sim3_log_fwd(X)[0]), p),)
 
 
+# --------------------------------------------------------------------------- Jinvp / Jr backward
+def _central_diff(f, x, g, h):
+    """sum_i g_i d f_i / d x_k by central differences (oracle only: O(h^2) accurate)."""
+    out = np.zeros_like(x)
+    for k in range(x.shape[1]):
+        e = np.zeros_like(x)
+        e[:, k] = h
+        out[:, k] = ((f(x + e) - f(x - e)) * g).sum(-1) / (2 * h)
+    return out
+
+
+def _make_jinvp_bwd(g):
+    Jl_inv = {"so3": so3_Jl_inv, "se3": se3_Jl_inv, "sim3": sim3_Jl_inv, "rxso3": rxso3_Jl_inv}[g]
+    log_fwd, log_bwd = globals()[f"{g}_log_fwd"], globals()[f"{g}_log_bwd"]
+
+    def bwd(X, p, gr):
+        """Jinvp backward as autograd sees it (lietensor.py:257-264 etc.): through Jl_inv(x) p by
+        (here) central differences in float64, then through <Group>_Log.backward."""
+        x = log_fwd(X.astype(np.float64))[0]
+        p64, g64 = p.astype(np.float64), gr.astype(np.float64)
+        h = _central_diff(lambda xx: _mv(Jl_inv(xx), p64), x, g64, 1e-6)
+        gX = log_bwd(x, h)[0]
+        gp = _vm(g64, Jl_inv(x))
+        return gX.astype(X.dtype), gp.astype(X.dtype)
+    bwd.__name__ = f"{g}_jinvp_bwd"
+    return bwd
+
+
+so3_jinvp_bwd, se3_jinvp_bwd, sim3_jinvp_bwd, rxso3_jinvp_bwd = (_make_jinvp_bwd(g) for g in ("so3", "se3", "sim3", "rxso3"))
+
+
+def so3_jr_bwd(x, G):
+    """so3.Jr backward (autograd through lietensor.py:343-351), by central differences in float64."""
+    x64 = x.astype(np.float64)
+    return (_central_diff(lambda xx: so3_jr_fwd(xx)[0], x64, G.astype(np.float64), 1e-6).astype(x.dtype),)
+
+
 # --------------------------------------------------------------------------- registry
 GROUPS = {"so3": (3, 4), "se3": (6, 7), "sim3": (7, 8), "rxso3": (4, 5)}   # (algebra, group) widths
 _OPNAMES = ["exp_fwd", "exp_bwd", "log_fwd", "log_bwd", "inv_fwd", "inv_bwd", "mul_fwd", "mul_bwd",
-            "act_fwd", "act_bwd", "act4_fwd", "act4_bwd", "adj_fwd", "adj_bwd", "adjt_fwd", "adjt_bwd", "jinvp_fwd"]
+            "act_fwd", "act_bwd", "act4_fwd", "act4_bwd", "adj_fwd", "adj_bwd", "adjt_fwd", "adjt_bwd", "jinvp_fwd",
+            "jinvp_bwd"]
 OPS = {f"{g}_{o}": globals()[f"{g}_{o}"] for g in GROUPS for o in _OPNAMES}
 OPS["so3_jr_fwd"] = so3_jr_fwd
+OPS["so3_jr_bwd"] = so3_jr_bwd
 
 
 def op_signature(name):
     """(input widths, output widths) of op ``name`` -- the shapes the C ABI uses."""
     if name == "so3_jr_fwd":
         return (3,), (9,)
+    if name == "so3_jr_bwd":
+        return (3, 9), (3,)
     g, o = name.split("_", 1)
     da, dg = GROUPS[g]
     return {
@@ -734,5 +775,5 @@ def op_signature(name):
         "act4_fwd": ((dg, 4), (4,)), "act4_bwd": ((dg, 4, 4), (dg, 4)),
         "adj_fwd": ((dg, da), (da,)), "adj_bwd": ((dg, da, da), (dg, da)),
         "adjt_fwd": ((dg, da), (da,)), "adjt_bwd": ((dg, da, da), (dg, da)),
-        "jinvp_fwd": ((dg, da), (da,)),
+        "jinvp_fwd": ((dg, da), (da,)), "jinvp_bwd": ((dg, da, da), (dg, da)),
     }[o]

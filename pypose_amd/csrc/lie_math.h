@@ -96,6 +96,46 @@ PP_HD void pp_sincos(double x, double& s, double& c) {
   c = ::cos(x);
 }
 
+// ---------------------------------------------------------------------------------------
+// Forward-mode dual numbers: value + one directional derivative.  Every row function below is
+// templated on its scalar type, so instantiating it with Dual<T> differentiates exactly the
+// branch the value takes -- this is how the Jinvp / Jr backwards are obtained (the reference
+// lets autograd differentiate through so3_Jl_inv / calcQ: lietensor.py:257-264, 343-351).
+// ---------------------------------------------------------------------------------------
+template <class T> struct Dual {
+  T v, d;
+  PP_HD Dual() : v(T(0)), d(T(0)) {}
+  PP_HD explicit Dual(T a) : v(a), d(T(0)) {}
+  PP_HD Dual(T a, T b) : v(a), d(b) {}
+};
+template <class T> struct Num<Dual<T>> { typedef T base; };
+template <class T> PP_HD Dual<T> operator+(Dual<T> a, Dual<T> b) { return Dual<T>(a.v + b.v, a.d + b.d); }
+template <class T> PP_HD Dual<T> operator-(Dual<T> a, Dual<T> b) { return Dual<T>(a.v - b.v, a.d - b.d); }
+template <class T> PP_HD Dual<T> operator-(Dual<T> a) { return Dual<T>(-a.v, -a.d); }
+template <class T> PP_HD Dual<T> operator*(Dual<T> a, Dual<T> b) { return Dual<T>(a.v * b.v, a.d * b.v + a.v * b.d); }
+template <class T> PP_HD Dual<T> operator/(Dual<T> a, Dual<T> b) {
+  T q = a.v / b.v;
+  return Dual<T>(q, (a.d - q * b.d) / b.v);
+}
+template <class T> PP_HD T pp_val(Dual<T> a) { return a.v; }
+template <class T> PP_HD Dual<T> pp_sqrt(Dual<T> a) {
+  T r = pp_sqrt(a.v);
+  return Dual<T>(r, a.d == T(0) ? T(0) : a.d / (T(2) * r));
+}
+template <class T> PP_HD Dual<T> pp_sin(Dual<T> a) { return Dual<T>(pp_sin(a.v), pp_cos(a.v) * a.d); }
+template <class T> PP_HD Dual<T> pp_cos(Dual<T> a) { return Dual<T>(pp_cos(a.v), -pp_sin(a.v) * a.d); }
+template <class T> PP_HD void pp_sincos(Dual<T> a, Dual<T>& s, Dual<T>& c) {
+  T sv, cv;
+  pp_sincos(a.v, sv, cv);
+  s = Dual<T>(sv, cv * a.d);
+  c = Dual<T>(cv, -sv * a.d);
+}
+template <class T> PP_HD Dual<T> pp_atan(Dual<T> a) { return Dual<T>(pp_atan(a.v), a.d / (T(1) + a.v * a.v)); }
+template <class T> PP_HD Dual<T> pp_exp(Dual<T> a) { T e = pp_exp(a.v); return Dual<T>(e, e * a.d); }
+template <class T> PP_HD Dual<T> pp_expm1(Dual<T> a) { T e = pp_expm1(a.v); return Dual<T>(e, (e + T(1)) * a.d); }
+template <class T> PP_HD Dual<T> pp_log(Dual<T> a) { return Dual<T>(pp_log(a.v), a.d / a.v); }
+template <class T> PP_HD Dual<T> pp_abs(Dual<T> a) { return a.v < T(0) ? -a : a; }
+
 // torch.nan_to_num default semantics: nan -> 0, +inf -> max, -inf -> lowest
 template <class S> PP_HD S pp_nan_to_num(S x) {
   typedef typename Num<S>::base B;
@@ -103,7 +143,7 @@ template <class S> PP_HD S pp_nan_to_num(S x) {
   if (v != v) return S(B(0));
   if (v > Num<B>::max()) return S(Num<B>::max());
   if (v < -Num<B>::max()) return S(-Num<B>::max());
-  return x;
+  return x;   // (for Dual: a replaced value drops its derivative, as autograd through nan_to_num does)
 }
 
 // pypose.basics.pm: sign(sign(x)*2+1) -> +1 at 0 (reference basics/ops.py:24)
@@ -270,6 +310,13 @@ template <class S> PP_HD void quat_mul(const S* X, const S* Y, S* Z) {
   Z[3] = xw * yw - dot(xv, yv);
 }
 
+
+// Jl_inv(x) p for each algebra (defined with the Jinvp backward at the end of this header)
+template <class S> PP_HD void so3_jlinv_p(const S* x, const S* p, S* out);
+template <class S> PP_HD void se3_jlinv_p(const S* x, const S* p, S* out);
+template <class S> PP_HD void rxso3_jlinv_p(const S* x, const S* p, S* out);
+template <class S> PP_HD void sim3_jlinv_p(const S* x, const S* p, S* out);
+
 // ---------------------------------------------------------------------------------------
 // SO3
 // ---------------------------------------------------------------------------------------
@@ -389,8 +436,7 @@ template <class S> PP_HD void so3_adjt_bwd(const S* X, const S* a, const S* g, S
 template <class S> PP_HD void so3_jinvp(const S* X, const S* p, S* out) {
   S x[3];
   so3_log(X, x);
-  V3<S> phi = v3(x);
-  put(jlinv_apply(rot_coef_F(norm2(phi)), phi, v3(p)), out);
+  so3_jlinv_p(x, p, out);
 }
 // so3.Jr (lietensor.py:343-351): I - c1 K + c2 K^2 where theta > eps else I; row-major 3x3
 template <class S> PP_HD void so3_jr(const S* x, S* J) {
@@ -610,13 +656,7 @@ template <class S> PP_HD void se3_adjt_bwd(const S* X, const S* a, const S* g, S
 template <class S> PP_HD void se3_jinvp(const S* X, const S* p, S* out) {
   S x[6];
   se3_log(X, x);
-  V3<S> tau = v3(x), phi = v3(x + 3);
-  S th2 = norm2(phi);
-  RotCoef<S> k = rot_coef(th2);
-  S F = rot_coef_F(th2);
-  V3<S> b = jlinv_apply(F, phi, v3(p + 3));
-  put(b, out + 3);
-  put(jlinv_apply(F, phi, v3(p) - q_apply(k, tau, phi, b)), out);
+  se3_jlinv_p(x, p, out);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -716,9 +756,7 @@ template <class S> PP_HD void rxso3_adjt_bwd(const S* X, const S* a, const S* g,
 template <class S> PP_HD void rxso3_jinvp(const S* X, const S* p, S* out) {   // lietensor.py:700-707
   S x[4];
   rxso3_log(X, x);
-  V3<S> phi = v3(x);
-  put(jlinv_apply(rot_coef_F(norm2(phi)), phi, v3(p)), out);
-  out[3] = p[3];
+  rxso3_jlinv_p(x, p, out);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -924,9 +962,39 @@ template <class S> PP_HD void sim3_adj_colvec(const S* v, const V3<S>& tau, cons
   o[6] = S(T(0));
 }
 template <class S> PP_HD void sim3_jinvp(const S* X, const S* p, S* out) {     // lietensor.py:556-563
-  typedef typename Num<S>::base T;
   S x[7];
   sim3_log(X, x);
+  sim3_jlinv_p(x, p, out);
+}
+
+// ---------------------------------------------------------------------------------------
+// Jinvp backward (the reference differentiates Jl_inv(Log X) p with plain autograd through
+// so3_Jl_inv / calcQ and through <Group>_Log's custom backward; lietensor.py:257-264, 422-429,
+// 556-563, 700-707):
+//   x = Log X ;  f(x, p) = Jl_inv(x) p
+//   gp = Jl_inv(x)^T g                      (= the tangent part of <Group>_Log.backward(x, g))
+//   h  = d(g . f)/dx   by dx forward-mode sweeps (Dual<T>)
+//   gX = <Group>_Log.backward(x, h) = [h @ Jl_inv(x), 0]
+// ---------------------------------------------------------------------------------------
+template <class S> PP_HD void so3_jlinv_p(const S* x, const S* p, S* out) {
+  V3<S> phi = v3(x);
+  put(jlinv_apply(rot_coef_F(norm2(phi)), phi, v3(p)), out);
+}
+template <class S> PP_HD void se3_jlinv_p(const S* x, const S* p, S* out) {
+  V3<S> tau = v3(x), phi = v3(x + 3);
+  S th2 = norm2(phi);
+  RotCoef<S> k = rot_coef(th2);
+  S F = rot_coef_F(th2);
+  V3<S> b = jlinv_apply(F, phi, v3(p + 3));
+  put(b, out + 3);
+  put(jlinv_apply(F, phi, v3(p) - q_apply(k, tau, phi, b)), out);
+}
+template <class S> PP_HD void rxso3_jlinv_p(const S* x, const S* p, S* out) {
+  so3_jlinv_p(x, p, out);
+  out[3] = p[3];
+}
+template <class S> PP_HD void sim3_jlinv_p(const S* x, const S* p, S* out) {
+  typedef typename Num<S>::base T;
   V3<S> tau = v3(x), phi = v3(x + 3);
   S sigma = x[6];
   S p1[7], p2[7], p3[7], p4[7];
@@ -936,6 +1004,43 @@ template <class S> PP_HD void sim3_jinvp(const S* X, const S* p, S* out) {     /
   sim3_adj_colvec(p3, tau, phi, sigma, p4);
   for (int i = 0; i < 7; ++i)
     out[i] = p[i] - S(T(0.5)) * p1[i] + S(T(1.0 / 12)) * p2[i] - S(T(1.0 / 720)) * p4[i];
+}
+
+#define PPLIE_JINVP_BWD(g, DA, DG)                                                                  \
+  template <class T> PP_HD void g##_jinvp_bwd(const T* X, const T* p, const T* gr, T* gX, T* gp) { \
+    T x[DA], h[DA];                                                                                 \
+    g##_log<T>(X, x);                                                                               \
+    for (int k = 0; k < DA; ++k) {                                                                  \
+      Dual<T> xd[DA], pd[DA], od[DA];                                                               \
+      for (int i = 0; i < DA; ++i) {                                                                \
+        xd[i] = Dual<T>(x[i], i == k ? T(1) : T(0));                                                \
+        pd[i] = Dual<T>(p[i]);                                                                      \
+      }                                                                                             \
+      g##_jlinv_p<Dual<T>>(xd, pd, od);                                                             \
+      T acc = T(0);                                                                                 \
+      for (int i = 0; i < DA; ++i) acc += gr[i] * od[i].d;                                          \
+      h[k] = acc;                                                                                   \
+    }                                                                                               \
+    g##_log_bwd<T>(x, h, gX);                                                                       \
+    T tmp[DG];                                                                                      \
+    g##_log_bwd<T>(x, gr, tmp);                                                                     \
+    for (int i = 0; i < DA; ++i) gp[i] = tmp[i];                                                    \
+  }
+PPLIE_JINVP_BWD(so3, 3, 4)
+PPLIE_JINVP_BWD(se3, 6, 7)
+PPLIE_JINVP_BWD(sim3, 7, 8)
+PPLIE_JINVP_BWD(rxso3, 4, 5)
+
+// so3.Jr backward: gx_k = sum_ij G_ij dJr_ij/dx_k (the reference: autograd through lietensor.py:343-351)
+template <class T> PP_HD void so3_jr_bwd(const T* x, const T* G, T* gx) {
+  for (int k = 0; k < 3; ++k) {
+    Dual<T> xd[3], J[9];
+    for (int i = 0; i < 3; ++i) xd[i] = Dual<T>(x[i], i == k ? T(1) : T(0));
+    so3_jr<Dual<T>>(xd, J);
+    T acc = T(0);
+    for (int i = 0; i < 9; ++i) acc += G[i] * J[i].d;
+    gx[k] = acc;
+  }
 }
 
 }  // namespace pplie

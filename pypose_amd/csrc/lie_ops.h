@@ -24,6 +24,7 @@
   PPLIE_OP_2_1(Op_##g##_adjt_fwd, g##_adjt, DG, DA, DA)                          \
   PPLIE_OP_3_2(Op_##g##_adjt_bwd, g##_adjt_bwd, DG, DA, DA, DG, DA)              \
   PPLIE_OP_2_1(Op_##g##_jinvp_fwd, g##_jinvp, DG, DA, DA)                        \
+  PPLIE_OP_3_2(Op_##g##_jinvp_bwd, g##_jinvp_bwd, DG, DA, DA, DG, DA)            \
   }
 
 #define PPLIE_EXPORT_GROUP(g)                                                    \
@@ -43,4 +44,5 @@
   PPLIE_EXPORT(pplie_##g##_adj_bwd, pplie::Op_##g##_adj_bwd)                     \
   PPLIE_EXPORT(pplie_##g##_adjt_fwd, pplie::Op_##g##_adjt_fwd)                   \
   PPLIE_EXPORT(pplie_##g##_adjt_bwd, pplie::Op_##g##_adjt_bwd)                   \
-  PPLIE_EXPORT(pplie_##g##_jinvp_fwd, pplie::Op_##g##_jinvp_fwd)
+  PPLIE_EXPORT(pplie_##g##_jinvp_fwd, pplie::Op_##g##_jinvp_fwd)                 \
+  PPLIE_EXPORT(pplie_##g##_jinvp_bwd, pplie::Op_##g##_jinvp_bwd)

@@ -5,3 +5,5 @@ PPLIE_EXPORT_GROUP(so3)
 // so3.Jr (reference lietensor.py:343-351): [N,3] -> [N,9] row-major right Jacobians
 namespace pplie { PPLIE_OP_1_1(Op_so3_jr_fwd, so3_jr, 3, 9) }
 PPLIE_EXPORT(pplie_so3_jr_fwd, pplie::Op_so3_jr_fwd)
+namespace pplie { PPLIE_OP_2_1(Op_so3_jr_bwd, so3_jr_bwd, 3, 9, 3) }
+PPLIE_EXPORT(pplie_so3_jr_bwd, pplie::Op_so3_jr_bwd)

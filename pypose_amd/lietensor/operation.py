@@ -183,6 +183,8 @@ for _g in _GROUPS:
 def _make_jinvp(g):
     da, dg = _GROUPS[g]
     kernel = f"{g}_jinvp_fwd"
+    # one kernel: forward-mode sweeps through Jl_inv(Log X) p, then <Group>_Log's backward (lie_math.h)
+    Bwd = _make_bwd(_CAP[g] + "_Jinvp_Bwd", f"{g}_jinvp_bwd", (dg, da, da), (dg, da))
 
     class _Jinvp(torch.autograd.Function):
         @staticmethod
@@ -195,11 +197,7 @@ def _make_jinvp(g):
 
         @staticmethod
         def backward(ctx, grad_output):
-            X, p = ctx.saved_tensors
-            if _C.library().has(f"pplie_{g}_jinvp_bwd_f32"):
-                gX, gp = _launch(f"{g}_jinvp_bwd", (X, p, grad_output), (dg, da, da), (dg, da))
-                return gX, gp
-            raise NotImplementedError(f"{_CAP[g]} Jinvp backward kernel is not built")
+            return Bwd.apply(*ctx.saved_tensors, grad_output)
 
         @staticmethod
         def vmap(info, in_dims, *ins):
@@ -212,8 +210,12 @@ def _make_jinvp(g):
 SO3_Jinvp, SE3_Jinvp, Sim3_Jinvp, RxSO3_Jinvp = (_make_jinvp(g) for g in ("so3", "se3", "sim3", "rxso3"))
 
 
+_so3_Jr_Bwd = _make_bwd("so3_Jr_Bwd", "so3_jr_bwd", (3, 9), (3,))
+
+
 class so3_Jr(torch.autograd.Function):
-    """Right Jacobian of so3 (reference lietensor.py:343-351): [...,3] -> [...,3,3]."""
+    """Right Jacobian of so3 (reference lietensor.py:343-351): [...,3] -> [...,3,3]; the reference
+    differentiates it with plain autograd, here the backward is one kernel (forward-mode sweeps)."""
 
     @staticmethod
     def forward(x):
@@ -221,11 +223,12 @@ class so3_Jr(torch.autograd.Function):
 
     @staticmethod
     def setup_context(ctx, inputs, output):
-        return
+        ctx.save_for_backward(inputs[0])
 
     @staticmethod
     def backward(ctx, grad_output):
-        raise NotImplementedError("so3.Jr: backward is not provided by the HIP path")
+        (x,) = ctx.saved_tensors
+        return _so3_Jr_Bwd.apply(x, grad_output.flatten(-2))
 
     @staticmethod
     def vmap(info, in_dims, x):

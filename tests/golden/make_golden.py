@@ -114,8 +114,20 @@ def main():
             # Jinvp forward (lietensor.py:257-264 etc.)
             XL = pp.LieTensor(I["X"], ltype=getattr(pp, {"so3": "SO3", "se3": "SE3", "sim3": "Sim3", "rxso3": "RxSO3"}[g] + "_type"))
             store[f"{dname}/{g}_jinvp_fwd/out0"] = XL.Jinvp(I["a"]).tensor().numpy()
+            # Jinvp backward: plain autograd through so3_Jl_inv / calcQ and <Group>_Log (no custom Function)
+            Xr = pp.LieTensor(I["X"].clone().requires_grad_(True), ltype=XL.ltype)
+            pr = I["a"].clone().requires_grad_(True)
+            out = Xr.Jinvp(pp.LieTensor(pr, ltype=XL.ltype)).tensor() if False else Xr.Jinvp(pr).tensor()
+            gX, gp = torch.autograd.grad(out, [Xr, pr], I["g_alg"], allow_unused=True)
+            store[f"{dname}/{g}_jinvp_bwd/out0"] = torch.nan_to_num(gX.detach(), nan=float("nan")).numpy()
+            store[f"{dname}/{g}_jinvp_bwd/out1"] = gp.detach().numpy()
             if g == "so3":
                 store[f"{dname}/so3_jr_fwd/out0"] = pp.so3(I["x"]).Jr().reshape(-1, 9).numpy()
+                xr = I["x"].clone().requires_grad_(True)
+                Gm = torch.randn(len(xr), 9, dtype=dtype, generator=gen)
+                store[f"{dname}/so3/in/g9"] = Gm.numpy()
+                (gx,) = torch.autograd.grad(pp.so3(xr).Jr().reshape(-1, 9), xr, Gm)
+                store[f"{dname}/so3_jr_bwd/out0"] = gx.detach().numpy()
     np.savez_compressed(OUT, **store)
     print(f"wrote {OUT}: {len(store)} arrays, {os.path.getsize(OUT) / 1e6:.2f} MB, pypose {pp.__version__}, torch {torch.__version__}")
 

@@ -50,6 +50,7 @@ using namespace pplie;
   HM_2_1(k_##g##_adjt_fwd, g##_adjt, DG, DA, DA)                   \
   HM_3_2(k_##g##_adjt_bwd, g##_adjt_bwd, DG, DA, DA, DG, DA)       \
   HM_2_1(k_##g##_jinvp_fwd, g##_jinvp, DG, DA, DA)                 \
+  HM_3_2(k_##g##_jinvp_bwd, g##_jinvp_bwd, DG, DA, DA, DG, DA)     \
   HM_EXPORT(g##_exp_fwd, k_##g##_exp_fwd) HM_EXPORT(g##_exp_bwd, k_##g##_exp_bwd)       \
   HM_EXPORT(g##_log_fwd, k_##g##_log_fwd) HM_EXPORT(g##_log_bwd, k_##g##_log_bwd)       \
   HM_EXPORT(g##_inv_fwd, k_##g##_inv_fwd) HM_EXPORT(g##_inv_bwd, k_##g##_inv_bwd)       \
@@ -58,7 +59,7 @@ using namespace pplie;
   HM_EXPORT(g##_act4_fwd, k_##g##_act4_fwd) HM_EXPORT(g##_act4_bwd, k_##g##_act4_bwd)   \
   HM_EXPORT(g##_adj_fwd, k_##g##_adj_fwd) HM_EXPORT(g##_adj_bwd, k_##g##_adj_bwd)       \
   HM_EXPORT(g##_adjt_fwd, k_##g##_adjt_fwd) HM_EXPORT(g##_adjt_bwd, k_##g##_adjt_bwd)   \
-  HM_EXPORT(g##_jinvp_fwd, k_##g##_jinvp_fwd)
+  HM_EXPORT(g##_jinvp_fwd, k_##g##_jinvp_fwd) HM_EXPORT(g##_jinvp_bwd, k_##g##_jinvp_bwd)
 
 HM_GROUP(so3, 3, 4)
 HM_GROUP(se3, 6, 7)
@@ -66,3 +67,5 @@ HM_GROUP(sim3, 7, 8)
 HM_GROUP(rxso3, 4, 5)
 HM_1_1(k_so3_jr_fwd, so3_jr, 3, 9)
 HM_EXPORT(so3_jr_fwd, k_so3_jr_fwd)
+HM_2_1(k_so3_jr_bwd, so3_jr_bwd, 3, 9, 3)
+HM_EXPORT(so3_jr_bwd, k_so3_jr_bwd)

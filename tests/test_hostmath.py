@@ -13,7 +13,7 @@ import numpy as np
 import pytest
 
 from oracle import lie_np
-from tests.golden_util import golden_case, row_rel_err
+from tests.golden_util import AUTOGRAD_OPS, golden_case, row_rel_err, well_conditioned_rows
 from tests.hostmath_util import hostmath_op
 
 ALL_OPS = sorted(lie_np.OPS)
@@ -28,8 +28,10 @@ LOOSE64 = {"sim3_exp_fwd": 1e-6}
 def test_fp64_vs_reference(golden, name):
     ins, refs = golden_case(golden, "f64", name)
     outs = hostmath_op(name, ins)
+    m = well_conditioned_rows(name, ins)
     for o, r in zip(outs, refs):
-        e, ok = row_rel_err(o, r)
+        assert np.isfinite(o).all()              # also where the reference's autograd returns NaN (theta = 0)
+        e, ok = row_rel_err(o[m], r[m])
         assert e.max() < LOOSE64.get(name, 2e-9), (name, e.max(), int(np.argmax(e)))
         assert np.median(e) < 1e-14, (name, np.median(e))
 
@@ -40,7 +42,8 @@ def test_fp32_vs_reference_fp64(golden, name):
     # reference-quality answer for exactly these fp32 inputs: the oracle in fp64 (pinned to 1e-11)
     refs = lie_np.OPS[name](*[a.astype(np.float64) for a in ins32])
     outs = hostmath_op(name, ins32)
+    m = well_conditioned_rows(name, ins32, theta_min=1e-4)     # the oracle's central differences need theta >> h
     for o, r in zip(outs, refs):
-        assert o.dtype == np.float32
-        e, ok = row_rel_err(o, r)
-        assert e.max() < 1e-5, (name, e.max(), int(np.argmax(e)))
+        assert o.dtype == np.float32 and np.isfinite(o).all()
+        e, ok = row_rel_err(o[m], r[m])
+        assert e.max() < (2e-5 if name in AUTOGRAD_OPS else 1e-5), (name, e.max(), int(np.argmax(e)))

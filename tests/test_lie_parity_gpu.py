@@ -11,7 +11,7 @@ import pytest
 import torch
 
 from oracle import lie_np
-from tests.golden_util import golden_case, row_rel_err
+from tests.golden_util import AUTOGRAD_OPS, golden_case, row_rel_err, well_conditioned_rows
 
 pytestmark = pytest.mark.gpu
 ALL_OPS = sorted(lie_np.OPS)
@@ -36,8 +36,10 @@ def run_hip(name, arrays):
 def test_golden_fp64(golden, name):
     ins, refs = golden_case(golden, "f64", name)
     outs = run_hip(name, ins)
+    m = well_conditioned_rows(name, ins)
     for o, r in zip(outs, refs):
-        e, ok = row_rel_err(o, r)
+        assert np.isfinite(o).all()
+        e, ok = row_rel_err(o[m], r[m])
         assert e.max() < LOOSE64.get(name, 2e-9), (name, e.max(), int(np.argmax(e)))
         assert np.median(e) < 1e-14
 
@@ -47,10 +49,11 @@ def test_golden_fp32_vs_reference_fp64(golden, name):
     ins32, _ = golden_case(golden, "f32", name)
     refs = lie_np.OPS[name](*[a.astype(np.float64) for a in ins32])
     outs = run_hip(name, ins32)
+    m = well_conditioned_rows(name, ins32, theta_min=1e-4)
     for o, r in zip(outs, refs):
-        assert o.dtype == np.float32
-        e, ok = row_rel_err(o, r)
-        assert e.max() < 1e-5, (name, e.max(), int(np.argmax(e)))
+        assert o.dtype == np.float32 and np.isfinite(o).all()
+        e, ok = row_rel_err(o[m], r[m])
+        assert e.max() < (2e-5 if name in AUTOGRAD_OPS else 1e-5), (name, e.max(), int(np.argmax(e)))
 
 
 def _random_inputs(name, n, dtype, rng):
@@ -75,6 +78,8 @@ def _random_inputs(name, n, dtype, rng):
     kind = name.split("_", 1)[1]
     if name == "so3_jr_fwd":
         return [alg()]
+    if name == "so3_jr_bwd":
+        return [alg(), r(9)]
     X = grp()
     table = {
         "exp_fwd": lambda: [alg()], "exp_bwd": lambda: [alg(), r(dg)],
@@ -85,7 +90,7 @@ def _random_inputs(name, n, dtype, rng):
         "act4_fwd": lambda: [X, r(4)], "act4_bwd": lambda: [X, r(4), r(4)],
         "adj_fwd": lambda: [X, r(da)], "adj_bwd": lambda: [X, r(da), r(da)],
         "adjt_fwd": lambda: [X, r(da)], "adjt_bwd": lambda: [X, r(da), r(da)],
-        "jinvp_fwd": lambda: [X, r(da)],
+        "jinvp_fwd": lambda: [X, r(da)], "jinvp_bwd": lambda: [X, r(da), r(da)],
     }
     return table[kind]()
 
@@ -96,12 +101,15 @@ def test_random_100k_fp32_vs_oracle_fp64(name):
     rng = np.random.default_rng(abs(hash(name)) % (2 ** 31))
     ins = _random_inputs(name, n, np.float32, rng)
     refs = lie_np.OPS[name](*[a.astype(np.float64) for a in ins])
+    if name in AUTOGRAD_OPS:       # the oracle differentiates numerically: needs theta >> its step
+        keep = well_conditioned_rows(name, ins, theta_min=1e-3)
+        ins, refs = [a[keep] for a in ins], [r[keep] for r in refs]
     outs = run_hip(name, ins)
     # rows at the rotation-log singularity (|theta| ~ pi, 2pi) are ill-conditioned w.r.t. the
     # fp32 rounding of the INPUT; they are excluded by the 99.99% quantile, the bulk must be tight
     for o, r in zip(outs, refs):
         e, ok = row_rel_err(o, r)
-        assert np.quantile(e, 0.9999) < 1e-5, (name, np.quantile(e, 0.9999))
+        assert np.quantile(e, 0.9999) < (1e-4 if name in AUTOGRAD_OPS else 1e-5), (name, np.quantile(e, 0.9999))
         assert np.median(e) < 2e-7, (name, np.median(e))
 
 
