@@ -68,20 +68,28 @@ PP_HD bool pp_isnan(double x) { return x != x; }
 
 // sin and cos of one fp32 angle in ~30 instructions: 3-constant Cody-Waite reduction by pi/2
 // (exact enough for |x| < 2^15; every angle on the hot path is a rotation angle or half of one)
-// + the classic degree-9 / degree-8 minimax polynomials on [-pi/4, pi/4] (<= 1 ulp).  Larger or
-// non-finite arguments take the libm path.  The library's sinf+cosf pair costs ~4x as much
-// because each call carries its own Payne-Hanek reduction.
+// + the classic degree-9 / degree-8 minimax polynomials on [-pi/4, pi/4] (<= 1 ulp).  Larger
+// arguments are reduced in double.  The library's sinf+cosf pair costs ~4x as much because each
+// call carries its own Payne-Hanek reduction.
 PP_HD void pp_sincos(float x, float& s, float& c) {
-  if (!(::fabsf(x) < 32768.0f)) {
-    s = ::sinf(x);
-    c = ::cosf(x);
-    return;
+  float kf, r;
+  int k;
+  if (::fabsf(x) < 32768.0f) {
+    kf = ::rintf(x * 0.63661977236758134f);
+    k = (int)kf;
+    r = ::fmaf(kf, -1.57079625129699707031e+00f, x);
+    r = ::fmaf(kf, -7.54978941586159635335e-08f, r);
+    r = ::fmaf(kf, -5.39030252995776476554e-15f, r);
+  } else {
+    // rare (an angle beyond 5000 turns): reduce in double instead of dragging libm's Payne-Hanek
+    // tables and its register footprint into every kernel; inf / nan fall through as nan
+    double xd = (double)x;
+    double kd = ::rint(xd * 0.63661977236758134308);
+    double rd = ::fma(kd, -1.57079632679489655800e+00, xd);
+    rd = ::fma(kd, -6.12323399573676603587e-17, rd);
+    k = (int)(((long long)kd) & 3);
+    r = (float)rd;
   }
-  float kf = ::rintf(x * 0.63661977236758134f);
-  int k = (int)kf;
-  float r = ::fmaf(kf, -1.57079625129699707031e+00f, x);
-  r = ::fmaf(kf, -7.54978941586159635335e-08f, r);
-  r = ::fmaf(kf, -5.39030252995776476554e-15f, r);
   float z = r * r;
   float ps = ::fmaf(::fmaf(::fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f), z * r, r);
   float pc = ::fmaf(::fmaf(::fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f), z * z,

@@ -107,7 +107,7 @@ template <int W> struct AtLeast1 { enum { v = W > 0 ? W : 1 }; };
 
 // Op concept: enum {IW0,IW1,IW2,OW0,OW1} (0 = unused) and
 //   static __device__ void apply(const T* a, const T* b, const T* c, T* o, T* p)
-template <class T, class Op, int RPT, int BLOCK, bool VEC>
+template <class T, class Op, int RPT, int BLOCK, bool VEC, bool ROLL = false>
 __global__ void __launch_bounds__(BLOCK)
 rowmap_lds_kernel(const T* __restrict__ i0, const T* __restrict__ i1, const T* __restrict__ i2,
                   T* __restrict__ o0, T* __restrict__ o1, int64_t n) {
@@ -134,8 +134,7 @@ rowmap_lds_kernel(const T* __restrict__ i0, const T* __restrict__ i1, const T* _
     if constexpr (IW2 > 0) slab_g2s<T, BLOCK, TILE * IW2, VEC>(i2 + row0 * IW2, s_i2, rows * IW2, full);
     __syncthreads();
 
-#pragma unroll
-    for (int r = 0; r < RPT; ++r) {
+    auto do_row = [&](int r) {
       const int row = threadIdx.x + r * BLOCK;
       if (row < rows) {
         T a[AtLeast1<IW0>::v], b[AtLeast1<IW1>::v], c[AtLeast1<IW2>::v], p[AtLeast1<OW0>::v], q[AtLeast1<OW1>::v];
@@ -146,6 +145,13 @@ rowmap_lds_kernel(const T* __restrict__ i0, const T* __restrict__ i1, const T* _
         row_st<OW0>(s_o0 + row * OW0, p);
         if constexpr (OW1 > 0) row_st<OW1>(s_o1 + row * OW1, q);
       }
+    };
+    if constexpr (ROLL) {      // rows one after the other: register footprint of a single row
+#pragma unroll 1
+      for (int r = 0; r < RPT; ++r) do_row(r);
+    } else {
+#pragma unroll
+      for (int r = 0; r < RPT; ++r) do_row(r);
     }
     __syncthreads();
 
@@ -192,7 +198,7 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 // the grid-stride loop only engages beyond 2^30 tiles.
 constexpr int kGridCap = 1 << 30;
 
-template <class T, class Op, int RPT = 2, int BLOCK = 256>
+template <class T, class Op, int RPT = 2, int BLOCK = 256, bool ROLL = false>
 int launch_rowmap(const void* i0, const void* i1, const void* i2, void* o0, void* o1, int64_t n, void* stream,
                   int grid_cap = kGridCap) {
   if (n < 0) return PPLIE_EBADARG;
@@ -210,9 +216,9 @@ int launch_rowmap(const void* i0, const void* i1, const void* i2, void* o0, void
   T* p = static_cast<T*>(o0);
   T* q = static_cast<T*>(o1);
   if (vec)
-    hipLaunchKernelGGL((rowmap_lds_kernel<T, Op, RPT, BLOCK, true>), dim3(grid), dim3(BLOCK), 0, st, a, b, c, p, q, n);
+    hipLaunchKernelGGL((rowmap_lds_kernel<T, Op, RPT, BLOCK, true, ROLL>), dim3(grid), dim3(BLOCK), 0, st, a, b, c, p, q, n);
   else
-    hipLaunchKernelGGL((rowmap_lds_kernel<T, Op, RPT, BLOCK, false>), dim3(grid), dim3(BLOCK), 0, st, a, b, c, p, q, n);
+    hipLaunchKernelGGL((rowmap_lds_kernel<T, Op, RPT, BLOCK, false, ROLL>), dim3(grid), dim3(BLOCK), 0, st, a, b, c, p, q, n);
   return hipGetLastError() == hipSuccess ? PPLIE_OK : PPLIE_ELAUNCH;
 }
 

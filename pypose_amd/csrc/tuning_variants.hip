@@ -41,6 +41,7 @@ PPLIE_OP_2_2(Var_se3_mul_bwd, se3_mul_bwd, 7, 7, 7, 7)
 PPLIE_OP_3_2(Var_se3_act_bwd, se3_act_bwd, 7, 3, 3, 7, 3)
 template <class Op>
 int var_general(int rpt, int block, const void* a, const void* b, const void* c, void* o, void* p, int64_t n, void* st) {
+  // block: 256 / 128 = unrolled rows ; 1256 / 1128 = rolled rows (one row's registers at a time)
   if (block == 256) {
     if (rpt == 1) return launch_rowmap<float, Op, 1, 256>(a, b, c, o, p, n, st);
     if (rpt == 2) return launch_rowmap<float, Op, 2, 256>(a, b, c, o, p, n, st);
@@ -49,6 +50,12 @@ int var_general(int rpt, int block, const void* a, const void* b, const void* c,
     if (rpt == 1) return launch_rowmap<float, Op, 1, 128>(a, b, c, o, p, n, st);
     if (rpt == 2) return launch_rowmap<float, Op, 2, 128>(a, b, c, o, p, n, st);
     if (rpt == 4) return launch_rowmap<float, Op, 4, 128>(a, b, c, o, p, n, st);
+  } else if (block == 1256) {
+    if (rpt == 2) return launch_rowmap<float, Op, 2, 256, true>(a, b, c, o, p, n, st);
+    if (rpt == 4) return launch_rowmap<float, Op, 4, 256, true>(a, b, c, o, p, n, st);
+  } else if (block == 1128) {
+    if (rpt == 2) return launch_rowmap<float, Op, 2, 128, true>(a, b, c, o, p, n, st);
+    if (rpt == 4) return launch_rowmap<float, Op, 4, 128, true>(a, b, c, o, p, n, st);
   }
   return PPLIE_EBADARG;
 }

@@ -11,19 +11,23 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
 torch.manual_seed(0)
 
 
-def med_ms(f, reps=30):
+def med_ms(f, reps=20, inner=8):
+    """median over `reps` of (HIP-event time of `inner` back-to-back launches) / inner: the queue never
+    drains between the events, so host launch latency is not billed to the kernel"""
     for _ in range(5): f()
     torch.cuda.synchronize()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
     for a, b in ev:
-        a.record(); f(); b.record()
+        f(); a.record()
+        for _ in range(inner): f()
+        b.record()
     torch.cuda.synchronize()
-    ts = sorted(a.elapsed_time(b) for a, b in ev)
+    ts = sorted(a.elapsed_time(b) / inner for a, b in ev)
     return ts[len(ts) // 2]
 
 rows = []
 ops = ["se3_exp_fwd", "se3_log_fwd", "se3_exp_bwd", "se3_log_bwd", "se3_adj_fwd", "se3_adjt_fwd", "se3_mul_fwd", "se3_mul_bwd",
-       "se3_inv_fwd", "se3_inv_bwd", "se3_act_fwd", "se3_act_bwd", "se3_jinvp_fwd", "so3_exp_fwd", "so3_log_fwd", "so3_mul_fwd",
+       "se3_inv_fwd", "se3_inv_bwd", "se3_act_fwd", "se3_act_bwd", "se3_jinvp_fwd", "se3_jinvp_bwd", "so3_exp_fwd", "so3_log_fwd", "so3_mul_fwd",
        "sim3_exp_fwd", "sim3_log_fwd", "sim3_exp_bwd", "sim3_log_bwd", "rxso3_exp_fwd", "rxso3_log_fwd"]
 gens = {"so3": (pp.randn_so3, pp.randn_SO3), "se3": (pp.randn_se3, pp.randn_SE3), "sim3": (pp.randn_sim3, pp.randn_Sim3),
         "rxso3": (pp.randn_rxso3, pp.randn_RxSO3)}
@@ -57,12 +61,12 @@ gyro = 0.1 * torch.randn(B, F, 3, device=dev)
 acc = torch.randn(B, F, 3, device=dev) + torch.tensor([0, 0, 9.81], device=dev)
 for cov in (True, False):
     m = pp.module.IMUPreintegrator(reset=True, prop_cov=cov).to(dev)
-    ms = med_ms(lambda: m(dt, gyro, acc), reps=10)
+    ms = med_ms(lambda: m(dt, gyro, acc), reps=6, inner=3)
     out[f"c5_imu_cov{int(cov)}"] = {"ms": ms, "steps_per_s": B * F / ms * 1e3, "GBps_68B_per_step": B * F * 68 / ms / 1e6}
     print("c5", cov, out[f"c5_imu_cov{int(cov)}"], flush=True)
 # scan alone: SO3 [4096, 1025, 4]
 X = pp.randn_SO3(B, F + 1, device=dev)
-ms = med_ms(lambda: pp.cumprod_(X, dim=1, left=False), reps=10)
+ms = med_ms(lambda: pp.cumprod_(X, dim=1, left=False), reps=10, inner=4)
 out["scan_so3_4096x1025"] = {"ms": ms, "GBps": B * (F + 1) * 32 / ms / 1e6}
 print("scan", out["scan_so3_4096x1025"], flush=True)
 json.dump(out, open("gpurun_out/bench_ops.json", "w"), indent=1)

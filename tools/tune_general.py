@@ -24,11 +24,14 @@ def med_ms(f, reps=30):
 res = []
 for name, (iw, ow) in ops.items():
     fn = lib.symbol(f"pplie_var_{name}_f32", SIG)
-    ins = [torch.randn(N, w, device=dev) * 0.5 for w in iw]
+    import pypose_amd as pp
+    ins = [torch.randn(N, w, device=dev) for w in iw]
+    if name in ("se3_exp_bwd", "se3_log_bwd"):
+        ins[0] = pp.randn_se3(N, device=dev).tensor().contiguous()      # realistic angle distribution (both coefficient branches)
     outs = [torch.empty(N, w, device=dev) for w in ow]
     P = lambda l, k: l[k].data_ptr() if k < len(l) else None
-    for block in (128, 256):
-        for rpt in (1, 2, 4):
+    for block in (128, 256, 1128, 1256):
+        for rpt in ((1, 2, 4) if block < 1000 else (2, 4)):
             call = lambda: fn(rpt, block, P(ins, 0), P(ins, 1), P(ins, 2), P(outs, 0), P(outs, 1), N, st)
             assert call() == 0
             ms = med_ms(call)
