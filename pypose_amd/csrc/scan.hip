@@ -223,159 +223,145 @@ template <class T> __device__ __forceinline__ void quat_to_matrix(const T* q, T*
   M[6] = c0.z; M[7] = c1.z; M[8] = c2.z;
 }
 
-// cov += X diag(d) X^T for a 9x3 X
-template <class T> __device__ __forceinline__ void rank3_update(T* cov, const T* X, const T* d) {
-#pragma unroll
-  for (int r = 0; r < 9; ++r)
-#pragma unroll
-    for (int c = 0; c < 9; ++c) {
-      T s = T(0);
-#pragma unroll
-      for (int l = 0; l < 3; ++l) s += X[r * 3 + l] * d[l] * X[c * 3 + l];
-      cov[r * 9 + c] += s;
-    }
-}
-
+// Nine lanes cooperate on one sequence (seven sequences per wavefront): lane r owns row r of P and
+// row r of cov.  P <- A_k P needs rows 0..2 of P (27 broadcast shuffles inside the group) and, for
+// rows 6..8, the lane three below; the rank-3 updates need every lane's V / U row (54 shuffles).
+// The recurrence over the F steps is inherently sequential, so the parallelism is 9 x B lanes.
 template <class T>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(256)
 imu_cov_kernel(const T* __restrict__ dt, const T* __restrict__ rk, const T* __restrict__ rij, const T* __restrict__ a,
                const T* __restrict__ init_cov,                 // [B,9,9]
                const T* __restrict__ gyro_cov, int64_t gc_sb, int64_t gc_sf,   // [.,.,3] with strides (elements)
                const T* __restrict__ acc_cov, int64_t ac_sb, int64_t ac_sf,
                T* __restrict__ cov, int64_t B, int64_t F) {
-  const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
-  if (b >= B) return;
-  T C[81], P[81];
+  const int lane = threadIdx.x & 63;
+  const int sub = lane / 9, r = lane - sub * 9;
+  const int64_t wave = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+  int64_t b = wave * 7 + sub;
+  const bool live = (sub < 7) && (b < B);
+  if (!live) b = 0;                       // idle lanes shadow sequence 0 (they must execute the shuffles)
+  const int g0 = (sub < 7 ? sub : 0) * 9; // first lane of this group
+  const int blk = r / 3, ri = r - blk * 3;  // row block (0: rotation, 1: velocity, 2: position) and row inside it
+
+  T C[9], P[9];
 #pragma unroll
-  for (int i = 0; i < 81; ++i) { C[i] = T(0); P[i] = (i % 10 == 0) ? T(1) : T(0); }
-  // term k (k = F .. 1) uses Bc_k built from step k-1 and P_k; P_k = A_k P_{k+1} uses step k.
-  for (int64_t k = F; k >= 1; --k) {
-    if (k < F) {   // P <- A_k P
-      const int64_t row = b * F + k;
-      const T h = dt[row];
-      T q[4] = {rk[row * 4], rk[row * 4 + 1], rk[row * 4 + 2], rk[row * 4 + 3]};
-      T qij[4] = {rij[row * 4], rij[row * 4 + 1], rij[row * 4 + 2], rij[row * 4 + 3]};
-      T Rk[9], Rj[9], M1[9];      // M1 = -Rij Ha dt ; M2 = M1 * dt/2
-      quat_to_matrix<T>(q, Rk);
-      quat_to_matrix<T>(qij, Rj);
-      const T ax = a[row * 3], ay = a[row * 3 + 1], az = a[row * 3 + 2];
-      const T Ha[9] = {T(0), -az, ay, az, T(0), -ax, -ay, ax, T(0)};
+  for (int c = 0; c < 9; ++c) { C[c] = T(0); P[c] = (c == r) ? T(1) : T(0); }
+
+  // Per-step quantities.  With ~0.5 wavefront per SIMD nothing else hides memory latency, so the raw
+  // inputs of step k-2 are fetched while steps k and k-1 are being consumed (software pipeline), and
+  // what is derived from a step (its matrices) is computed once and used twice: in Bc_{k} and in A_{k-1}.
+  struct Raw { T h, q[4], qij[4], a[3], cg[3], ca[3]; };
+  struct Step { T h, coef[3], V_J[9], U_R[9], cg[3], ca[3]; };   // coef: this lane's weights on old rows 0..2
+  auto fetch = [&](int64_t k, Raw& w) {
+    const int64_t row = b * F + k;
+    w.h = dt[row];
 #pragma unroll
-      for (int i = 0; i < 3; ++i)
+    for (int i = 0; i < 4; ++i) { w.q[i] = rk[row * 4 + i]; w.qij[i] = rij[row * 4 + i]; }
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-          T s = T(0);
-#pragma unroll
-          for (int l = 0; l < 3; ++l) s += Rj[i * 3 + l] * Ha[l * 3 + j];
-          M1[i * 3 + j] = -s * h;
-        }
-#pragma unroll
-      for (int c = 0; c < 9; ++c) {
-        T p0[3] = {P[c], P[9 + c], P[18 + c]};
-        T p1[3] = {P[27 + c], P[36 + c], P[45 + c]};
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-          T t0 = T(0), t1 = T(0);
-#pragma unroll
-          for (int l = 0; l < 3; ++l) { t0 += Rk[l * 3 + i] * p0[l]; t1 += M1[i * 3 + l] * p0[l]; }
-          P[i * 9 + c] = t0;
-          P[(3 + i) * 9 + c] = p1[i] + t1;
-          P[(6 + i) * 9 + c] += T(0.5) * h * t1 + h * p1[i];
-        }
-      }
+    for (int i = 0; i < 3; ++i) {
+      w.a[i] = a[row * 3 + i];
+      w.cg[i] = gyro_cov[b * gc_sb + k * gc_sf + i];
+      w.ca[i] = acc_cov[b * ac_sb + k * ac_sf + i];
     }
-    // cov += P Bc_k P^T, Bc_k from step k-1
-    const int64_t row = b * F + (k - 1);
-    const T h = dt[row];
-    T q[4] = {rk[row * 4], rk[row * 4 + 1], rk[row * 4 + 2], rk[row * 4 + 3]};
-    T qij[4] = {rij[row * 4], rij[row * 4 + 1], rij[row * 4 + 2], rij[row * 4 + 3]};
-    T Rj[9], phi[3], Jr[9];
-    quat_to_matrix<T>(qij, Rj);
-    so3_log<T>(q, phi);
-    so3_jr<T>(phi, Jr);
-    T dg[3], da[3];
+  };
+  auto derive = [&](const Raw& w, Step& st) {
+    T Rk[9], Rj[9], phi[3];
+    quat_to_matrix<T>(w.q, Rk);
+    quat_to_matrix<T>(w.qij, Rj);
+    so3_log<T>(w.q, phi);
+    so3_jr<T>(phi, st.V_J);                 // V = P[:,0:3] Jr
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      dg[j] = h * gyro_cov[b * gc_sb + (k - 1) * gc_sf + j];
-      da[j] = h * acc_cov[b * ac_sb + (k - 1) * ac_sf + j];
+    for (int i = 0; i < 9; ++i) st.U_R[i] = Rj[i];   // U = (P[:,3:6] + h/2 P[:,6:9]) Rij
+    st.h = w.h;
+    const T Ha[9] = {T(0), -w.a[2], w.a[1], w.a[2], T(0), -w.a[0], -w.a[1], w.a[0], T(0)};
+#pragma unroll
+    for (int l = 0; l < 3; ++l) {
+      T m1 = T(0);
+#pragma unroll
+      for (int jj = 0; jj < 3; ++jj) m1 += Rj[ri * 3 + jj] * Ha[jj * 3 + l];
+      m1 = -m1 * w.h;
+      st.coef[l] = blk == 0 ? Rk[l * 3 + ri] : (blk == 1 ? m1 : T(0.5) * w.h * m1);
     }
-    T X[27];
 #pragma unroll
-    for (int r = 0; r < 9; ++r)
-#pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        T s = T(0);
-#pragma unroll
-        for (int l = 0; l < 3; ++l) s += P[r * 9 + l] * Jr[l * 3 + j];
-        X[r * 3 + j] = s;
-      }
-    rank3_update<T>(C, X, dg);
-#pragma unroll
-    for (int r = 0; r < 9; ++r)
-#pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        T s = T(0);
-#pragma unroll
-        for (int l = 0; l < 3; ++l) s += (P[r * 9 + 3 + l] + T(0.5) * h * P[r * 9 + 6 + l]) * Rj[l * 3 + j];
-        X[r * 3 + j] = s;
-      }
-    rank3_update<T>(C, X, da);
-  }
-  // k = 0: P_0 = A_0 P_1, Bc_0 = init_cov
-  {
-    const int64_t row = b * F;
-    const T h = dt[row];
-    T q[4] = {rk[row * 4], rk[row * 4 + 1], rk[row * 4 + 2], rk[row * 4 + 3]};
-    T qij[4] = {rij[row * 4], rij[row * 4 + 1], rij[row * 4 + 2], rij[row * 4 + 3]};
-    T Rk[9], Rj[9], M1[9];
-    quat_to_matrix<T>(q, Rk);
-    quat_to_matrix<T>(qij, Rj);
-    const T ax = a[row * 3], ay = a[row * 3 + 1], az = a[row * 3 + 2];
-    const T Ha[9] = {T(0), -az, ay, az, T(0), -ax, -ay, ax, T(0)};
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        T s = T(0);
-#pragma unroll
-        for (int l = 0; l < 3; ++l) s += Rj[i * 3 + l] * Ha[l * 3 + j];
-        M1[i * 3 + j] = -s * h;
-      }
+    for (int i = 0; i < 3; ++i) { st.cg[i] = w.h * w.cg[i]; st.ca[i] = w.h * w.ca[i]; }
+  };
+  const T mine = blk == 0 ? T(0) : T(1);    // rows 3..8 keep their own old row
+  auto advance = [&](const Step& st) {      // P <- A_k P
+    const T below = blk == 2 ? st.h : T(0); // rows 6..8 add dt * (old row three above)
+    T Pn[9];
 #pragma unroll
     for (int c = 0; c < 9; ++c) {
-      T p0[3] = {P[c], P[9 + c], P[18 + c]};
-      T p1[3] = {P[27 + c], P[36 + c], P[45 + c]};
+      const T p0 = __shfl(P[c], g0 + 0, 64), p1 = __shfl(P[c], g0 + 1, 64), p2 = __shfl(P[c], g0 + 2, 64);
+      const T up = __shfl(P[c], g0 + (r >= 3 ? r - 3 : r), 64);
+      Pn[c] = mine * P[c] + below * up + st.coef[0] * p0 + st.coef[1] * p1 + st.coef[2] * p2;
+    }
 #pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        T t0 = T(0), t1 = T(0);
+    for (int c = 0; c < 9; ++c) P[c] = Pn[c];
+  };
+  auto accumulate = [&](const Step& st) {   // cov += P Bc P^T with Bc built from this step
+    T V[3], U[3], Vr[3], Ur[3];
 #pragma unroll
-        for (int l = 0; l < 3; ++l) { t0 += Rk[l * 3 + i] * p0[l]; t1 += M1[i * 3 + l] * p0[l]; }
-        P[i * 9 + c] = t0;
-        P[(3 + i) * 9 + c] = p1[i] + t1;
-        P[(6 + i) * 9 + c] += T(0.5) * h * t1 + h * p1[i];
+    for (int jj = 0; jj < 3; ++jj) {
+      T v = T(0), u = T(0);
+#pragma unroll
+      for (int l = 0; l < 3; ++l) {
+        v += P[l] * st.V_J[l * 3 + jj];
+        u += (P[3 + l] + T(0.5) * st.h * P[6 + l]) * st.U_R[l * 3 + jj];
+      }
+      Vr[jj] = v; Ur[jj] = u;
+      V[jj] = v * st.cg[jj];
+      U[jj] = u * st.ca[jj];
+    }
+#pragma unroll
+    for (int c = 0; c < 9; ++c) {
+      T sacc = T(0);
+#pragma unroll
+      for (int jj = 0; jj < 3; ++jj) {
+        sacc += V[jj] * __shfl(Vr[jj], g0 + c, 64);
+        sacc += U[jj] * __shfl(Ur[jj], g0 + c, 64);
+      }
+      C[c] += sacc;
+    }
+  };
+
+  if (F > 0) {
+    Raw nxt;
+    Step prev, cur;                          // prev: step k-1 (for Bc_k), cur: step k (for A_k)
+    fetch(F - 1, nxt);
+    derive(nxt, prev);
+    if (F > 1) fetch(F - 2, nxt);
+    for (int64_t k = F; k >= 1; --k) {
+      if (k < F) advance(cur);
+      accumulate(prev);
+      cur = prev;
+      if (k >= 2) {
+        derive(nxt, prev);                   // step k-2, fetched one iteration ago
+        if (k >= 3) fetch(k - 3, nxt);
       }
     }
-    // cov += P init_cov P^T
-    for (int r = 0; r < 9; ++r) {
-      T t[9];
+    advance(cur);                            // P_0 = A_0 P_1
+  }
+  {                                          // Bc_0 = init_cov
+    T t[9];
 #pragma unroll
-      for (int c = 0; c < 9; ++c) {
-        T s = T(0);
+    for (int c = 0; c < 9; ++c) {
+      T sacc = T(0);
 #pragma unroll
-        for (int l = 0; l < 9; ++l) s += P[r * 9 + l] * init_cov[b * 81 + l * 9 + c];
-        t[c] = s;
-      }
+      for (int l = 0; l < 9; ++l) sacc += P[l] * init_cov[b * 81 + l * 9 + c];
+      t[c] = sacc;
+    }
 #pragma unroll
-      for (int c = 0; c < 9; ++c) {
-        T s = T(0);
+    for (int c = 0; c < 9; ++c) {
+      T sacc = T(0);
 #pragma unroll
-        for (int l = 0; l < 9; ++l) s += t[l] * P[c * 9 + l];
-        C[r * 9 + c] += s;
-      }
+      for (int l = 0; l < 9; ++l) sacc += t[l] * __shfl(P[l], g0 + c, 64);
+      C[c] += sacc;
     }
   }
+  if (live) {
 #pragma unroll
-  for (int i = 0; i < 81; ++i) cov[b * 81 + i] = C[i];
+    for (int c = 0; c < 9; ++c) cov[b * 81 + r * 9 + c] = C[c];
+  }
 }
 
 template <class T>
@@ -402,8 +388,9 @@ int imu_cov_launch(const void* dt, const void* rk, const void* rij, const void* 
   if (B < 0 || F < 0) return SC_EBADARG;
   if (B == 0) return SC_OK;
   if (!dt || !rk || !rij || !a || !init_cov || !gc || !ac || !cov) return SC_EBADARG;
-  int64_t blocks = (B + 63) / 64;
-  hipLaunchKernelGGL((imu_cov_kernel<T>), dim3((unsigned)blocks), dim3(64), 0, reinterpret_cast<hipStream_t>(stream),
+  int64_t waves = (B + 6) / 7;              // seven sequences per wavefront, nine lanes each
+  int64_t blocks = (waves + 3) / 4;
+  hipLaunchKernelGGL((imu_cov_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                      (const T*)dt, (const T*)rk, (const T*)rij, (const T*)a, (const T*)init_cov, (const T*)gc, gc_sb, gc_sf,
                      (const T*)ac, ac_sb, ac_sf, (T*)cov, B, F);
   return hipGetLastError() == hipSuccess ? SC_OK : SC_ELAUNCH;
