@@ -22,8 +22,8 @@ import os
 import sys
 import time
 
-import torch
-
+# torch is imported inside main(): the cpu_baseline leg spawns one worker per host core and every
+# worker re-imports this file, which must stay light (numpy only).
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
@@ -67,6 +67,45 @@ def cpu_baseline(budget_s: float = 12.0):
                       f"{cores} processes x {chunk}-row chunks, {wall:.1f} s wall)"}
 
 
+def pgo_lm_rate(dev, nodes=10_000, edges=40_000, steps=6):
+    """Second half of BASELINE.json's metric: LM iterations/s on a synthetic pose graph
+    (SURVEY.md section 8d C4 generator: chain + random loop closures, sigma 0.01 edge noise, sigma 0.05
+    initial error; the reference's own PoseGraph model, examples/module/pgo/pgo.py:15-25; PCG tol 1e-4 /
+    maxiter 250 as examples/module/ba, TrustRegion(radius=1e4) as pgo.py:67).  Not part of `value`."""
+    import torch
+    import pypose_amd as pp
+
+    class PoseGraph(torch.nn.Module):
+        def __init__(self, init):
+            super().__init__()
+            self.nodes = pp.Parameter(init)
+
+        def forward(self, e, poses):
+            n1, n2 = self.nodes[e[..., 0]], self.nodes[e[..., 1]]
+            return (poses.Inv() @ n1.Inv() @ n2).Log().tensor()
+
+    g = torch.Generator().manual_seed(0)
+    torch.manual_seed(0)
+    gt = pp.cumprod(pp.randn_SE3(nodes, sigma=0.3, device=dev), dim=0, left=False)
+    chain = torch.stack([torch.arange(nodes - 1), torch.arange(1, nodes)], -1)
+    extra = torch.randint(0, nodes, (edges - (nodes - 1), 2), generator=g)
+    extra[:, 1] = torch.where(extra[:, 0] == extra[:, 1], (extra[:, 1] + 1) % nodes, extra[:, 1])
+    e = torch.cat([chain, extra], 0).to(dev)
+    rel = gt[e[:, 0]].Inv() @ gt[e[:, 1]] @ pp.randn_SE3(edges, sigma=0.01, device=dev)
+    graph = PoseGraph(gt @ pp.randn_SE3(nodes, sigma=0.05, device=dev))
+    solver = pp.optim.solver.PCG(tol=1e-4, maxiter=250)
+    opt = pp.optim.LM(graph, solver=solver, strategy=pp.optim.strategy.TrustRegion(radius=1e4))
+    l0 = float(graph(e, rel).detach().square().sum())
+    opt.step((e, rel))                                   # structure probe + graph capture, untimed
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    losses = [float(opt.step((e, rel))) for _ in range(steps)]
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    return {"metric": "LM iters/sec (PGO 10k poses)", "value": 1.0 / dt, "unit": "LM steps/s", "nodes": nodes, "edges": edges,
+            "path": opt.linearization, "initial_loss": l0, "final_loss": losses[-1], "pcg_iterations_last": solver.iterations}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -75,6 +114,7 @@ def main():
     ap.add_argument("--rows", type=int, default=10_000_000, help="rows per GPU (BASELINE configs[1]: 10M)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
+    import torch
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -141,7 +181,8 @@ def main():
         if os.path.exists(pmc):
             traffic = json.load(open(pmc)).get(dom)
         out = {
-            "metric": "batched SE3 Exp+Log ops/sec", "value": world * B * a.steps / elapsed,
+            "metric": "batched SE3 Exp+Log ops/sec (BASELINE metric, first half; second half under lm_pgo)",
+            "value": world * B * a.steps / elapsed,
             "unit": "SE3 Exp+Log pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -152,6 +193,11 @@ def main():
                          "traffic": traffic, "algorithmic_bytes_per_launch": B * BYTES_PER_ROW[dom],
                          "avg_launch_ms": ms_dom, "other_kernel_ms": {"se3_exp_fwd": ms_exp, "se3_log_fwd": ms_log}},
         }
+        if world == 1:
+            try:
+                out["lm_pgo"] = pgo_lm_rate(dev)
+            except Exception as e:        # never lose the headline line over the secondary figure
+                out["lm_pgo"] = {"error": repr(e)}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

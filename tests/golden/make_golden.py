@@ -117,9 +117,9 @@ def main():
             # Jinvp backward: plain autograd through so3_Jl_inv / calcQ and <Group>_Log (no custom Function)
             Xr = pp.LieTensor(I["X"].clone().requires_grad_(True), ltype=XL.ltype)
             pr = I["a"].clone().requires_grad_(True)
-            out = Xr.Jinvp(pp.LieTensor(pr, ltype=XL.ltype)).tensor() if False else Xr.Jinvp(pr).tensor()
+            out = Xr.Jinvp(pr).tensor()
             gX, gp = torch.autograd.grad(out, [Xr, pr], I["g_alg"], allow_unused=True)
-            store[f"{dname}/{g}_jinvp_bwd/out0"] = torch.nan_to_num(gX.detach(), nan=float("nan")).numpy()
+            store[f"{dname}/{g}_jinvp_bwd/out0"] = gX.detach().numpy()
             store[f"{dname}/{g}_jinvp_bwd/out1"] = gp.detach().numpy()
             if g == "so3":
                 store[f"{dname}/so3_jr_fwd/out0"] = pp.so3(I["x"]).Jr().reshape(-1, 9).numpy()
