@@ -276,7 +276,7 @@ template <class T> __global__ void __launch_bounds__(256) pcg_dot_shift_kernel(T
 // node's other r/q elements and Binv row i are 4m-byte contiguous reads shared within the node's lanes.
 template <class T> __global__ void __launch_bounds__(256)
 pcg_update_kernel(T* x, T* r, const T* p, const T* q, T* z, const T* Binv, T* scal, int64_t N, int m) {
-  const T alpha = scal[0] / scal[1];
+  const T alpha = scal[1] != T(0) ? scal[0] / scal[1] : T(0);   // p.q = 0 only once r = 0: stay put, no NaN
   T a1 = T(0), a2 = T(0);
   const int64_t total = N * m;
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
@@ -301,13 +301,13 @@ pcg_update_kernel(T* x, T* r, const T* p, const T* q, T* z, const T* Binv, T* sc
 }
 // second half of the update: r -= alpha q (kept separate so every lane of stage 1 sees the old r)
 template <class T> __global__ void __launch_bounds__(256) pcg_residual_kernel(T* r, const T* q, const T* scal_prev, int64_t n) {
-  const T alpha = scal_prev[0] / scal_prev[1];
+  const T alpha = scal_prev[1] != T(0) ? scal_prev[0] / scal_prev[1] : T(0);
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) r[i] -= alpha * q[i];
 }
 
 // p = z + (rho_new / rho) p
 template <class T> __global__ void __launch_bounds__(256) pcg_direction_kernel(T* p, const T* z, const T* scal, int64_t n) {
-  const T beta = scal[2] / scal[0];
+  const T beta = scal[0] != T(0) ? scal[2] / scal[0] : T(0);
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) p[i] = z[i] + beta * p[i];
 }
 

@@ -38,6 +38,7 @@ def _rows(t: torch.Tensor, width: int) -> torch.Tensor:
 
 
 _is_legacy_batched = torch._C._functorch.is_legacy_batchedtensor
+_transforms_active = torch._C._are_functorch_transforms_active
 
 
 def _legacy_level(t):
@@ -130,6 +131,15 @@ def _make_fwd(clsname, g, kind, doc):
 
     class _Fn(torch.autograd.Function):
         __doc__ = doc
+
+        @classmethod
+        def apply(cls, *ins):
+            # nothing to record (no_grad, or no input requires grad) and no functorch transform:
+            # launch directly -- Function.apply costs ~40 us of Python per call (signature binding,
+            # context set-up), which is the whole budget of a small kernel inside LM.step
+            if not _transforms_active() and not (torch.is_grad_enabled() and any(t.requires_grad for t in ins)):
+                return _launch(fwd_kernel, ins, fin, (fout,))[0]
+            return super().apply(*ins)
 
         @staticmethod
         def forward(*ins):
