@@ -204,13 +204,9 @@ imu_integrate_kernel(const T* __restrict__ dt, const T* __restrict__ gyro, const
 // Covariance (imu_preintegrator.py:428-465).  The reference's code evaluates
 //   cov = sum_{k=0..F} P_k Bc_k P_k^T,   P_k = A_k A_{k+1} ... A_{F-1} (P_F = I),   Bc_0 = init_cov
 // through a cumprod of flipped 9x9 matrices (:462-464).  Note this is NOT the textbook recursion of
-// its docstring (the products share their RIGHT factors).  One backward pass per sequence:
-//   P <- A_k P  (k = F-1 .. 0),  cov += P Bc_k P^T
+// its docstring (the products share their RIGHT factors).
 // A_k = I9 with [0:3,0:3] = Rk^T, [3:6,0:3] = -Rij Ha dt, [6:9,0:3] = -Rij Ha dt^2/2, [6:9,3:6] = dt I (:442-448)
 // Bc_{k+1} = (Bg Cg Bg^T + Ba Ca Ba^T)/dt, Bg[0:3] = Jr(Rk) dt, Ba[3:6] = Rij dt, Ba[6:9] = Rij dt^2/2 (:451-460)
-//          = V (dt Cg) V^T + U (dt Ca) U^T  with  V = [I;0;0] Jr,  U = [0;I;dt/2 I] Rij,
-// so  P Bc P^T = (P0 Jr)(dt Cg)(P0 Jr)^T + ((P1 + dt/2 P2) Rij)(dt Ca)(...)^T  (P = [P0 P1 P2] column blocks):
-// two rank-3 updates instead of two 9x9x9 products.  One lane per sequence, P and cov in registers.
 // ---------------------------------------------------------------------------------------------
 template <class T> __device__ __forceinline__ void quat_to_matrix(const T* q, T* M) {
   // columns = images of the basis vectors under SO3_Act (matrix(): lietensor.py:281-285)
@@ -223,144 +219,182 @@ template <class T> __device__ __forceinline__ void quat_to_matrix(const T* q, T*
   M[6] = c0.z; M[7] = c1.z; M[8] = c2.z;
 }
 
-// Nine lanes cooperate on one sequence (seven sequences per wavefront): lane r owns row r of P and
-// row r of cov.  P <- A_k P needs rows 0..2 of P (27 broadcast shuffles inside the group) and, for
-// rows 6..8, the lane three below; the rank-3 updates need every lane's V / U row (54 shuffles).
-// The recurrence over the F steps is inherently sequential, so the parallelism is 9 x B lanes.
-template <class T>
-__global__ void __launch_bounds__(256)
-imu_cov_kernel(const T* __restrict__ dt, const T* __restrict__ rk, const T* __restrict__ rij, const T* __restrict__ a,
-               const T* __restrict__ init_cov,                 // [B,9,9]
-               const T* __restrict__ gyro_cov, int64_t gc_sb, int64_t gc_sf,   // [.,.,3] with strides (elements)
-               const T* __restrict__ acc_cov, int64_t ac_sb, int64_t ac_sf,
-               T* __restrict__ cov, int64_t B, int64_t F) {
+// ---------------------------------------------------------------------------------------------
+// Covariance as scans + a reduction.
+// The transition matrices are block lower-triangular with identity blocks,
+//   A_k = [[Rk^T, 0, 0], [M1_k, I, 0], [h_k/2 M1_k, h_k I, I]],   M1_k = -h_k Rij_k skew(a_k),
+// and so is every product of them:  P_k = A_k ... A_{F-1} = [[S_k, 0, 0], [X_k, I, 0], [Y_k, t_k I, I]] with
+//   S_k = Rk_k^T S_{k+1}                       (a suffix product of the inverse gyro increments: one SO3 scan)
+//   X_k = M1_k S_{k+1} + X_{k+1}               (suffix sum of G_k := M1_k S_{k+1})
+//   Y_k = h_k/2 G_k + h_k X_{k+1} + Y_{k+1}    (suffix sum)
+//   t_k = h_k + t_{k+1}                        (suffix sum)
+// so all P_k come from wave-level suffix scans, and  cov = P_0 C_0 P_0^T + sum_{j=0}^{F-1} P_{j+1} Bc(j) P_{j+1}^T,
+//   P Bc P^T = V (h Cg) V^T + U (h Ca) U^T,  V = [S; X; Y] Jr_j,  U = [0; Rij_j; (t + h_j/2) Rij_j],
+// is a sum over steps that each lane accumulates privately (45 symmetric entries) and the wave reduces
+// once.  One wavefront per sequence walks it backwards in 64-step chunks; no step depends on another
+// except through the scans' carried values.
+// ---------------------------------------------------------------------------------------------
+template <class T> __device__ __forceinline__ T suffix_sum(T v, T carry, int lane) {
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    T u = __shfl_down(v, off, 64);
+    if (lane + off < 64) v += u;
+  }
+  return v + carry;
+}
+template <class T> __device__ __forceinline__ void mat3_mul(const T* A, const T* B, T* C) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) C[i * 3 + j] = A[i * 3] * B[j] + A[i * 3 + 1] * B[3 + j] + A[i * 3 + 2] * B[6 + j];
+}
+
+template <class T, int WAVES>
+__global__ void __launch_bounds__(WAVES * 64)
+imu_cov_scan_kernel(const T* __restrict__ dt, const T* __restrict__ rk, const T* __restrict__ rij, const T* __restrict__ a,
+                    const T* __restrict__ init_cov, const T* __restrict__ gyro_cov, int64_t gc_sb, int64_t gc_sf,
+                    const T* __restrict__ acc_cov, int64_t ac_sb, int64_t ac_sf, T* __restrict__ cov, int64_t B, int64_t F) {
   const int lane = threadIdx.x & 63;
-  const int sub = lane / 9, r = lane - sub * 9;
-  const int64_t wave = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
-  int64_t b = wave * 7 + sub;
-  const bool live = (sub < 7) && (b < B);
-  if (!live) b = 0;                       // idle lanes shadow sequence 0 (they must execute the shuffles)
-  const int g0 = (sub < 7 ? sub : 0) * 9; // first lane of this group
-  const int blk = r / 3, ri = r - blk * 3;  // row block (0: rotation, 1: velocity, 2: position) and row inside it
+  const int64_t b = (int64_t)blockIdx.x * WAVES + (threadIdx.x >> 6);
+  if (b >= B) return;
+  // carried suffix values at the first step after the current chunk (P_F = I)
+  T cS[4] = {T(0), T(0), T(0), T(1)}, cX[9], cY[9], ct = T(0);
+#pragma unroll
+  for (int i = 0; i < 9; ++i) { cX[i] = T(0); cY[i] = T(0); }
+  T acc[45];                                   // upper triangle of this lane's share of cov
+#pragma unroll
+  for (int i = 0; i < 45; ++i) acc[i] = T(0);
 
-  T C[9], P[9];
+  const int64_t nchunks = (F + 63) / 64;
+  for (int64_t ch = nchunks - 1; ch >= 0; --ch) {
+    const int64_t j = ch * 64 + lane;
+    const bool valid = j < F;
+    const int64_t row = b * F + (valid ? j : 0);
+    const T h = valid ? dt[row] : T(0);
+    T q[4], qij[4], av[3];
 #pragma unroll
-  for (int c = 0; c < 9; ++c) { C[c] = T(0); P[c] = (c == r) ? T(1) : T(0); }
-
-  // Per-step quantities.  With ~0.5 wavefront per SIMD nothing else hides memory latency, so the raw
-  // inputs of step k-2 are fetched while steps k and k-1 are being consumed (software pipeline), and
-  // what is derived from a step (its matrices) is computed once and used twice: in Bc_{k} and in A_{k-1}.
-  struct Raw { T h, q[4], qij[4], a[3], cg[3], ca[3]; };
-  struct Step { T h, coef[3], V_J[9], U_R[9], cg[3], ca[3]; };   // coef: this lane's weights on old rows 0..2
-  auto fetch = [&](int64_t k, Raw& w) {
-    const int64_t row = b * F + k;
-    w.h = dt[row];
+    for (int i = 0; i < 4; ++i) { q[i] = valid ? rk[row * 4 + i] : (i == 3 ? T(1) : T(0)); qij[i] = valid ? rij[row * 4 + i] : (i == 3 ? T(1) : T(0)); }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { w.q[i] = rk[row * 4 + i]; w.qij[i] = rij[row * 4 + i]; }
+    for (int i = 0; i < 3; ++i) av[i] = valid ? a[row * 3 + i] : T(0);
+    // ---- S: suffix product of inverse increments, s_j = dr_j^-1 * s_{j+1}
+    T sv[4] = {-q[0], -q[1], -q[2], q[3]};
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      w.a[i] = a[row * 3 + i];
-      w.cg[i] = gyro_cov[b * gc_sb + k * gc_sf + i];
-      w.ca[i] = acc_cov[b * ac_sb + k * ac_sf + i];
+    for (int off = 1; off < 64; off <<= 1) {
+      T u[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) u[i] = __shfl_down(sv[i], off, 64);
+      if (lane + off < 64) { T t4[4]; so3_mul<T>(sv, u, t4); sv[0] = t4[0]; sv[1] = t4[1]; sv[2] = t4[2]; sv[3] = t4[3]; }
     }
-  };
-  auto derive = [&](const Raw& w, Step& st) {
-    T Rk[9], Rj[9], phi[3];
-    quat_to_matrix<T>(w.q, Rk);
-    quat_to_matrix<T>(w.qij, Rj);
-    so3_log<T>(w.q, phi);
-    so3_jr<T>(phi, st.V_J);                 // V = P[:,0:3] Jr
+    { T t4[4]; so3_mul<T>(sv, cS, t4); sv[0] = t4[0]; sv[1] = t4[1]; sv[2] = t4[2]; sv[3] = t4[3]; }   // inclusive S_j
+    T sx[4];                                   // exclusive S_{j+1}
 #pragma unroll
-    for (int i = 0; i < 9; ++i) st.U_R[i] = Rj[i];   // U = (P[:,3:6] + h/2 P[:,6:9]) Rij
-    st.h = w.h;
-    const T Ha[9] = {T(0), -w.a[2], w.a[1], w.a[2], T(0), -w.a[0], -w.a[1], w.a[0], T(0)};
+    for (int i = 0; i < 4; ++i) { T d = __shfl_down(sv[i], 1, 64); sx[i] = lane == 63 ? cS[i] : d; }
+    // ---- G_j = M1_j S_{j+1},  M1_j = -h Rij skew(a)
+    T Rj[9], Sx[9], M1[9], G[9];
+    quat_to_matrix<T>(qij, Rj);
+    quat_to_matrix<T>(sx, Sx);
+    {
+      const T Ha[9] = {T(0), -av[2], av[1], av[2], T(0), -av[0], -av[1], av[0], T(0)};
+      mat3_mul<T>(Rj, Ha, M1);
 #pragma unroll
-    for (int l = 0; l < 3; ++l) {
-      T m1 = T(0);
-#pragma unroll
-      for (int jj = 0; jj < 3; ++jj) m1 += Rj[ri * 3 + jj] * Ha[jj * 3 + l];
-      m1 = -m1 * w.h;
-      st.coef[l] = blk == 0 ? Rk[l * 3 + ri] : (blk == 1 ? m1 : T(0.5) * w.h * m1);
+      for (int i = 0; i < 9; ++i) M1[i] = -h * M1[i];
     }
+    mat3_mul<T>(M1, Sx, G);
+    // ---- X (inclusive) and its exclusive shift; Z_j = h/2 G_j + h X_{j+1}; Y ; t
+    T X[9], Xx[9], Y[9], Yx[9];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) { st.cg[i] = w.h * w.cg[i]; st.ca[i] = w.h * w.ca[i]; }
-  };
-  const T mine = blk == 0 ? T(0) : T(1);    // rows 3..8 keep their own old row
-  auto advance = [&](const Step& st) {      // P <- A_k P
-    const T below = blk == 2 ? st.h : T(0); // rows 6..8 add dt * (old row three above)
-    T Pn[9];
-#pragma unroll
-    for (int c = 0; c < 9; ++c) {
-      const T p0 = __shfl(P[c], g0 + 0, 64), p1 = __shfl(P[c], g0 + 1, 64), p2 = __shfl(P[c], g0 + 2, 64);
-      const T up = __shfl(P[c], g0 + (r >= 3 ? r - 3 : r), 64);
-      Pn[c] = mine * P[c] + below * up + st.coef[0] * p0 + st.coef[1] * p1 + st.coef[2] * p2;
+    for (int i = 0; i < 9; ++i) {
+      X[i] = suffix_sum(G[i], cX[i], lane);
+      T d = __shfl_down(X[i], 1, 64);
+      Xx[i] = lane == 63 ? cX[i] : d;
     }
 #pragma unroll
-    for (int c = 0; c < 9; ++c) P[c] = Pn[c];
-  };
-  auto accumulate = [&](const Step& st) {   // cov += P Bc P^T with Bc built from this step
-    T V[3], U[3], Vr[3], Ur[3];
-#pragma unroll
-    for (int jj = 0; jj < 3; ++jj) {
-      T v = T(0), u = T(0);
-#pragma unroll
-      for (int l = 0; l < 3; ++l) {
-        v += P[l] * st.V_J[l * 3 + jj];
-        u += (P[3 + l] + T(0.5) * st.h * P[6 + l]) * st.U_R[l * 3 + jj];
-      }
-      Vr[jj] = v; Ur[jj] = u;
-      V[jj] = v * st.cg[jj];
-      U[jj] = u * st.ca[jj];
+    for (int i = 0; i < 9; ++i) {
+      Y[i] = suffix_sum(T(0.5) * h * G[i] + h * Xx[i], cY[i], lane);
+      T d = __shfl_down(Y[i], 1, 64);
+      Yx[i] = lane == 63 ? cY[i] : d;
     }
+    const T tin = suffix_sum(h, ct, lane);
+    const T tdn = __shfl_down(tin, 1, 64);     // (shuffles stay outside any lane-dependent expression:
+    const T tx = lane == 63 ? ct : tdn;        //  an inactive source lane reads as garbage)
+    // ---- this step's term  P_{j+1} Bc(j) P_{j+1}^T
+    if (valid) {
+      T phi[3], Jr[9], V[27];
+      so3_log<T>(q, phi);
+      so3_jr<T>(phi, Jr);
+      mat3_mul<T>(Sx, Jr, V);                  // rows 0..2
+      mat3_mul<T>(Xx, Jr, V + 9);              // rows 3..5
+      mat3_mul<T>(Yx, Jr, V + 18);             // rows 6..8
+      T dg[3], da[3];
 #pragma unroll
-    for (int c = 0; c < 9; ++c) {
-      T sacc = T(0);
+      for (int i = 0; i < 3; ++i) { dg[i] = h * gyro_cov[b * gc_sb + j * gc_sf + i]; da[i] = h * acc_cov[b * ac_sb + j * ac_sf + i]; }
+      const T tu = tx + T(0.5) * h;            // U = [0; Rj; tu Rj]
+      int e = 0;
+#pragma unroll
+      for (int r = 0; r < 9; ++r)
+#pragma unroll
+        for (int c = r; c < 9; ++c, ++e) {
+          T sacc = V[r * 3] * dg[0] * V[c * 3] + V[r * 3 + 1] * dg[1] * V[c * 3 + 1] + V[r * 3 + 2] * dg[2] * V[c * 3 + 2];
+          if (r >= 3) {                        // U rows 0..2 are zero
+            const T fr = r < 6 ? T(1) : tu, fc = c < 6 ? T(1) : tu;
+            const int rr = r % 3, cc = c % 3;
+            sacc += fr * fc * (Rj[rr * 3] * da[0] * Rj[cc * 3] + Rj[rr * 3 + 1] * da[1] * Rj[cc * 3 + 1] + Rj[rr * 3 + 2] * da[2] * Rj[cc * 3 + 2]);
+          }
+          acc[e] += sacc;
+        }
+    }
+    // ---- carries for the next (earlier) chunk: the inclusive values of lane 0
+#pragma unroll
+    for (int i = 0; i < 4; ++i) cS[i] = __shfl(sv[i], 0, 64);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { cX[i] = __shfl(X[i], 0, 64); cY[i] = __shfl(Y[i], 0, 64); }
+    ct = __shfl(tin, 0, 64);
+  }
+  // wave reduction of the per-lane partial sums
+#pragma unroll
+  for (int e = 0; e < 45; ++e) {
+    T v = acc[e];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    acc[e] = v;
+  }
+  if (lane == 0) {
+    // P_0 = [[S_0,0,0],[X_0,I,0],[Y_0,t_0 I,I]] (the carries) ; cov = P_0 init_cov P_0^T + sum
+    T P[81], S0[9];
+#pragma unroll
+    for (int i = 0; i < 81; ++i) P[i] = T(0);
+    quat_to_matrix<T>(cS, S0);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
 #pragma unroll
       for (int jj = 0; jj < 3; ++jj) {
-        sacc += V[jj] * __shfl(Vr[jj], g0 + c, 64);
-        sacc += U[jj] * __shfl(Ur[jj], g0 + c, 64);
+        P[i * 9 + jj] = S0[i * 3 + jj];
+        P[(3 + i) * 9 + jj] = cX[i * 3 + jj];
+        P[(6 + i) * 9 + jj] = cY[i * 3 + jj];
       }
-      C[c] += sacc;
-    }
-  };
-
-  if (F > 0) {
-    Raw nxt;
-    Step prev, cur;                          // prev: step k-1 (for Bc_k), cur: step k (for A_k)
-    fetch(F - 1, nxt);
-    derive(nxt, prev);
-    if (F > 1) fetch(F - 2, nxt);
-    for (int64_t k = F; k >= 1; --k) {
-      if (k < F) advance(cur);
-      accumulate(prev);
-      cur = prev;
-      if (k >= 2) {
-        derive(nxt, prev);                   // step k-2, fetched one iteration ago
-        if (k >= 3) fetch(k - 3, nxt);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { P[(3 + i) * 9 + 3 + i] = T(1); P[(6 + i) * 9 + 3 + i] = ct; P[(6 + i) * 9 + 6 + i] = T(1); }
+    // the accumulated step terms are symmetric by construction; P_0 init_cov P_0^T is formed in full
+    // (the reference does not symmetrise a caller-supplied init_cov)
+    int e = 0;
+    for (int r = 0; r < 9; ++r)
+      for (int c = r; c < 9; ++c, ++e) {
+        cov[b * 81 + r * 9 + c] = acc[e];
+        cov[b * 81 + c * 9 + r] = acc[e];
+      }
+    for (int r = 0; r < 9; ++r) {
+      T tl[9];
+      for (int l = 0; l < 9; ++l) {
+        T s0 = T(0);
+        for (int m = 0; m < 9; ++m) s0 += P[r * 9 + m] * init_cov[b * 81 + m * 9 + l];
+        tl[l] = s0;
+      }
+      for (int c = 0; c < 9; ++c) {
+        T s1 = T(0);
+        for (int l = 0; l < 9; ++l) s1 += tl[l] * P[c * 9 + l];
+        cov[b * 81 + r * 9 + c] += s1;
       }
     }
-    advance(cur);                            // P_0 = A_0 P_1
-  }
-  {                                          // Bc_0 = init_cov
-    T t[9];
-#pragma unroll
-    for (int c = 0; c < 9; ++c) {
-      T sacc = T(0);
-#pragma unroll
-      for (int l = 0; l < 9; ++l) sacc += P[l] * init_cov[b * 81 + l * 9 + c];
-      t[c] = sacc;
-    }
-#pragma unroll
-    for (int c = 0; c < 9; ++c) {
-      T sacc = T(0);
-#pragma unroll
-      for (int l = 0; l < 9; ++l) sacc += t[l] * __shfl(P[l], g0 + c, 64);
-      C[c] += sacc;
-    }
-  }
-  if (live) {
-#pragma unroll
-    for (int c = 0; c < 9; ++c) cov[b * 81 + r * 9 + c] = C[c];
   }
 }
 
@@ -388,11 +422,15 @@ int imu_cov_launch(const void* dt, const void* rk, const void* rij, const void* 
   if (B < 0 || F < 0) return SC_EBADARG;
   if (B == 0) return SC_OK;
   if (!dt || !rk || !rij || !a || !init_cov || !gc || !ac || !cov) return SC_EBADARG;
-  int64_t waves = (B + 6) / 7;              // seven sequences per wavefront, nine lanes each
-  int64_t blocks = (waves + 3) / 4;
-  hipLaunchKernelGGL((imu_cov_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                     (const T*)dt, (const T*)rk, (const T*)rij, (const T*)a, (const T*)init_cov, (const T*)gc, gc_sb, gc_sf,
-                     (const T*)ac, ac_sb, ac_sf, (T*)cov, B, F);
+  if (F == 0) {                               // no steps: cov = init_cov
+    hipMemcpyAsync(cov, init_cov, (size_t)B * 81 * sizeof(T), hipMemcpyDeviceToDevice, reinterpret_cast<hipStream_t>(stream));
+    return hipGetLastError() == hipSuccess ? SC_OK : SC_ELAUNCH;
+  }
+  constexpr int WAVES = 2;
+  int64_t blocks = (B + WAVES - 1) / WAVES;
+  hipLaunchKernelGGL((imu_cov_scan_kernel<T, WAVES>), dim3((unsigned)blocks), dim3(WAVES * 64), 0,
+                     reinterpret_cast<hipStream_t>(stream), (const T*)dt, (const T*)rk, (const T*)rij, (const T*)a,
+                     (const T*)init_cov, (const T*)gc, gc_sb, gc_sf, (const T*)ac, ac_sb, ac_sf, (T*)cov, B, F);
   return hipGetLastError() == hipSuccess ? SC_OK : SC_ELAUNCH;
 }
 }  // namespace pplie
