@@ -17,5 +17,6 @@ from .lietensor import Sim3_type, sim3_type, RxSO3_type, rxso3_type
 from .lietensor import tensor, translation, rotation, scale, matrix, euler, vec2skew
 from .lietensor.lietensor import retain_ltype
 from .basics import pm, cumops, cummul, cumprod, cumops_, cummul_, cumprod_
+from . import autograd
 from . import optim
 from . import module

@@ -504,8 +504,8 @@ class LieTensor(Tensor):
 class Parameter(LieTensor, nn.Parameter):
     """``nn.Parameter`` that keeps its ``ltype`` (reference lietensor.py:1236-1337).
 
-    ``sjac=True`` selects the reference's optional sparse-Jacobian plugin (un-vendored ``bae``
-    package); that plugin boundary is outside this library's hot path.
+    ``sjac=True`` (the reference's request for its optional sparse-Jacobian plugin, ``bae``) is
+    accepted and ignored: sparse structure is detected by ``pypose_amd.optim`` without tracing.
     """
 
     def __init__(self, data=None, requires_grad=True, sjac=False):
@@ -515,10 +515,9 @@ class Parameter(LieTensor, nn.Parameter):
     def __new__(cls, data=None, requires_grad=True, sjac=False):
         if data is None:
             data = torch.tensor([])
-        if sjac:
-            raise ImportError("pypose_amd: Parameter(sjac=True) needs the reference's optional sparse backend "
-                              "(bae>=0.2.1,<0.3), which this library does not provide; use the structured "
-                              "fast paths of pypose_amd.optim instead.")
+        # sjac=True asks the reference's optional `bae` plugin to trace operations for sparse Jacobians.
+        # Here structure is discovered by the optimizer itself (optim/blocks.py, optim/posegraph.py), so
+        # the flag is accepted and needs no tracing tensor: the parameter is an ordinary Parameter.
         if isinstance(data, LieTensor):
             param = Tensor._make_subclass(cls, data.tensor(), requires_grad)
             param.ltype = data.ltype

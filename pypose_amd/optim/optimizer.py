@@ -185,7 +185,9 @@ class BlockLinearization:
         d.add_(d * damping)
 
     def solve(self, solver):
-        if isinstance(solver, Cholesky) and not solver.upper:
+        from .posegraph import PCG
+        if (isinstance(solver, Cholesky) and not solver.upper) or isinstance(solver, PCG):
+            # (an iterative solver has nothing to iterate on for d_par x d_par blocks: factor them)
             Db = _blocks.chol_solve(self.A, self.g)
             assert not torch.any(torch.isnan(Db)), \
                 'Cholesky decomposition failed. Check your matrix (may not be positive-definite)'
@@ -285,8 +287,8 @@ class GaussNewton(_Optimizer):
 class LevenbergMarquardt(_Optimizer):
     """Levenberg-Marquardt (reference optimizer.py:331-679).
 
-    ``sparse=True`` selects the reference's optional ``bae`` plugin, which this library does not
-    provide; structured problems are handled by the automatic block / graph paths instead.
+    ``sparse=True`` (the reference's switch to its optional ``bae`` plugin) is accepted: structured
+    problems are handled by the automatic block / graph linearisations whether or not it is set.
     """
 
     def __init__(self, model, solver=None, strategy=None, kernel=None, corrector=None,
@@ -296,11 +298,10 @@ class LevenbergMarquardt(_Optimizer):
         self.strategy = TrustRegion() if strategy is None else strategy
         defaults = {**{'min': min, 'max': max}, **self.strategy.defaults}
         super().__init__(model.parameters(), defaults=defaults)
-        if sparse:
-            raise ImportError("pypose_amd: LM(sparse=True) needs the reference's optional sparse backend "
-                              "(bae>=0.2.1,<0.3); it is not part of this library. Leave sparse=False: "
-                              "block-diagonal and pose-graph structure is detected automatically.")
-        self.sparse = False
+        # sparse=True selects the reference's optional `bae` plugin (sparse J, CSR J^T J, PCG).  Here the
+        # same problems are covered by the automatically detected block / pose-graph linearisations, so
+        # the flag only records the intent; a model without detectable structure still runs densely.
+        self.sparse = bool(sparse)
         # torch.distributed process group: independent problems / graph edges are sharded over its
         # ranks (one process per GPU, RCCL); the loss, the gain ratio and -- for pose graphs -- the
         # normal-equation pieces are all-reduced so that every rank takes the same decisions.

@@ -58,9 +58,40 @@ class GatherRecorder:
         _lt._gather_recorders.remove(self)
 
     def note(self, source, index, out):
-        if id(source) in self.ids and isinstance(index, torch.Tensor) and index.dtype == torch.int64 \
-                and index.dim() >= 1 and isinstance(out, torch.Tensor) and out.requires_grad:
+        # gathers on a tracked parameter, or on a tensor derived from one (e.g. ``cat((root, nodes))`` in
+        # the reference's chain example, tests/optim/test_sparse_lm.py:26-36)
+        if isinstance(index, torch.Tensor) and index.dtype == torch.int64 and index.dim() >= 1 \
+                and isinstance(out, torch.Tensor) and out.requires_grad and isinstance(source, torch.Tensor) \
+                and source.dim() == 2:
             self.events.append((source, index, out))
+
+
+def _rows_of_parameter(src, param):
+    """For a ``src`` [Ns, w] built from ``param`` [N, w] by pure row movement (cat with constants,
+    slicing, identity): LongTensor [Ns] giving the parameter row behind each ``src`` row, -1 for rows that
+    do not come from the parameter (fixed nodes).  None if ``src`` is not such a row copy."""
+    if src is param:
+        return torch.arange(param.shape[0], device=param.device)
+    if src.shape[-1] != param.shape[-1] or src.grad_fn is None:
+        return None
+    ns, n = src.shape[0], param.shape[0]
+    cot = torch.zeros_like(src)
+    cot[:, 0] = torch.arange(1, ns + 1, device=src.device, dtype=src.dtype)
+    (g,) = torch.autograd.grad([src], [param], [cot], retain_graph=True, allow_unused=True)
+    if g is None or bool((g[:, 1:] != 0).any()):
+        return None
+    ids = g[:, 0].round().to(torch.int64)                      # 1-based src row of every parameter row (0: unused)
+    used = ids > 0
+    if bool((ids[used] > ns).any()) or ids[used].unique().numel() != int(used.sum()):
+        return None
+    back = torch.full((ns,), -1, dtype=torch.int64, device=src.device)
+    back[ids[used] - 1] = torch.arange(n, device=src.device)[used]
+    # a pure row copy passes values through unchanged
+    chk = back >= 0
+    if not torch.equal(torch.Tensor.as_subclass(src.detach(), torch.Tensor)[chk],
+                       torch.Tensor.as_subclass(param.detach(), torch.Tensor)[back[chk]]):
+        return None
+    return back
 
 
 class PCG(nn.Module):
@@ -387,21 +418,29 @@ def try_graph_linearization(opt, pg, input, target, weight, R, params, rec, cach
     param, r = params[0], R[0]
     E = r.numel() // r.shape[-1]
     events = [(src, ix, out) for src, ix, out in rec.events if ix.numel() == E and out.numel() == E * param.shape[-1]]
-    if not events or len(events) != len(rec.events):
+    if not events or len(events) != len(rec.events) or any(ev[0] is not events[0][0] for ev in events):
         cache[sig] = False
         return None
     outs = [out for _, _, out in events]
     K, wfull, dr = len(events), param.shape[-1], r.shape[-1]
     with torch.enable_grad():
+        back = _rows_of_parameter(events[0][0], param)
+        if back is None:
+            cache[sig] = False
+            return None
+        node_idx = [back[ix.reshape(-1)] for _, ix, _ in events]      # parameter row per edge end (-1: fixed)
         Jcat = _blocks.jacobian_blocks([r], outs)                    # [E, dr, K*wfull]
+        for k, ni in enumerate(node_idx):                            # a fixed end contributes no unknowns
+            Jcat[:, :, k * wfull:(k + 1) * wfull] *= (ni >= 0).to(Jcat.dtype).view(E, 1, 1)
+        node_idx = [ni.clamp_min(0) for ni in node_idx]
         if cache.get(sig) is None:
             # probe: u^T dR/dnodes by one real backward == scatter-add of the per-edge blocks
             u = torch.randn_like(r)
             true = torch.autograd.grad([r], [param], [u], retain_graph=True)[0]
             got = torch.zeros_like(true)
-            contrib = torch.einsum('ed,edw->ew', u.reshape(E, dr), Jcat)
-            for k, (_, ix, _) in enumerate(events):
-                got.index_add_(0, ix.reshape(-1), contrib[:, k * wfull:(k + 1) * wfull])
+            contrib = (u.reshape(E, dr).unsqueeze(-1) * Jcat).sum(-2)
+            for k, ni in enumerate(node_idx):
+                got.index_add_(0, ni, contrib[:, k * wfull:(k + 1) * wfull])
             scale = true.abs().max().clamp_min(torch.finfo(true.dtype).tiny)
             cache[sig] = bool((got - true).abs().max() <= 1e-3 * scale)
     if not cache[sig]:
@@ -409,7 +448,7 @@ def try_graph_linearization(opt, pg, input, target, weight, R, params, rec, cach
     # tangent width: gradients of LieTensor group parameters are zero-padded to the embedding
     m = int(param.ltype.manifold[0]) if isinstance(param, _lt.LieTensor) and not param.ltype.on_manifold else wfull
     J = Jcat.reshape(E, dr, K, wfull)[..., :m].permute(0, 2, 1, 3)    # [E, K, dr, m]
-    idx = torch.stack([ix.reshape(-1) for _, ix, _ in events], dim=-1)
+    idx = torch.stack(node_idx, dim=-1)
     c = opt.corrector[0]                                              # row-local: acts on [E, dr, K*m]
     Rc, Jc = c(R=r.detach().reshape(E, dr), J=J.permute(0, 2, 1, 3).reshape(E, dr, K * m))
     Jc = Jc.reshape(E, dr, K, m).permute(0, 2, 1, 3)
