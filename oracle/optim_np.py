@@ -19,3 +19,23 @@ def block_chol_solve(A, g):
         y = np.linalg.solve(L, -g[i])
         x[i] = np.linalg.solve(L.T, y)
     return (x,)
+
+
+def lm_se3inv_trial(R, P, X, scale, dmin, dmax):
+    """One LM trial step of B independent problems r = Log(P X) (reference README.md:120-129 run through
+    optimizer.py:644-679): J = [se3_Jl_inv(r) | 0] (operation.py:385-395 SE3_Log backward, :905-908 SE3_Mul
+    backward), A = J^T J with the diagonal clamped to [dmin, dmax] and scaled by ``scale`` = prod(1 + damping),
+    d = -A^-1 J^T r (Cholesky), P' = Exp(d) P.  Returns P', d (zero-padded to 7), and the four sums
+    [ |Log(P' X)|^2, |r|^2, (J d).(J d), (J d).r ]."""
+    from oracle import lie_np
+    J = lie_np.se3_Jl_inv(R)                                     # [n,6,6]
+    A = np.swapaxes(J, -1, -2) @ J
+    g = (np.swapaxes(J, -1, -2) @ R[..., None])[..., 0]
+    idx = np.arange(6)
+    A[:, idx, idx] = np.clip(A[:, idx, idx], dmin, dmax) * scale
+    (d,) = block_chol_solve(A, g)
+    Pn = lie_np.se3_mul_fwd(lie_np.se3_exp_fwd(d)[0], P)[0]
+    rn = lie_np.se3_log_fwd(lie_np.se3_mul_fwd(Pn, X)[0])[0]
+    Jd = (J @ d[..., None])[..., 0]
+    sums = np.array([(rn * rn).sum(), (R * R).sum(), (Jd * Jd).sum(), (Jd * R).sum()])
+    return Pn, np.concatenate([d, np.zeros_like(d[:, :1])], -1), sums

@@ -246,19 +246,6 @@ extern "C" int pplie_graph_assemble_f64(const void* J, const void* W, const void
 // ---------------------------------------------------------------------------------------------
 namespace pplie {
 
-template <class T> __device__ __forceinline__ T block_sum(T v) {
-  __shared__ T part[4];
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  if (lane == 0) part[w] = v;
-  __syncthreads();
-  T s = T(0);
-  if (threadIdx.x == 0) s = part[0] + part[1] + part[2] + part[3];
-  __syncthreads();
-  return s;   // valid in thread 0
-}
-
 // q += shift * p (elementwise) ; scal[1] += p . q
 template <class T> __global__ void __launch_bounds__(256) pcg_dot_shift_kernel(T* q, const T* p, const T* shift, T* scal, int64_t n) {
   T acc = T(0);

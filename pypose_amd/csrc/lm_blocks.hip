@@ -47,46 +47,9 @@ template <class T, int DR, int DP, bool HAS_W> struct Op_normal_eq {
   }
 };
 
-// x = A^-1 (-g) by Cholesky A = L L^T (lower).  A non-positive pivot yields NaNs in x, which
-// the host turns into the reference's "Cholesky decomposition failed" error (solver.py:214).
-template <class T, int DP> struct Op_chol_solve {
-  enum { IW0 = DP * DP, IW1 = DP, IW2 = 0, OW0 = DP, OW1 = 0 };
-  static PP_HD void apply(const T* A, const T* g, const T*, T* x, T*) {
-    T L[DP * DP];
-#pragma unroll
-    for (int j = 0; j < DP; ++j) {
-      T d = A[j * DP + j];
-#pragma unroll
-      for (int k = 0; k < j; ++k) d -= L[j * DP + k] * L[j * DP + k];
-      T ljj = pp_sqrt(d);          // d <= 0 -> NaN (or 0 -> inf below), propagates to x
-      L[j * DP + j] = ljj;
-      T inv = T(1) / ljj;
-#pragma unroll
-      for (int i = j + 1; i < DP; ++i) {
-        T s = A[i * DP + j];
-#pragma unroll
-        for (int k = 0; k < j; ++k) s -= L[i * DP + k] * L[j * DP + k];
-        L[i * DP + j] = s * inv;
-      }
-    }
-    T y[DP];
-#pragma unroll
-    for (int i = 0; i < DP; ++i) {   // L y = -g
-      T s = -g[i];
-#pragma unroll
-      for (int k = 0; k < i; ++k) s -= L[i * DP + k] * y[k];
-      y[i] = s / L[i * DP + i];
-    }
-#pragma unroll
-    for (int i = DP - 1; i >= 0; --i) {   // L^T x = y
-      T s = y[i];
-#pragma unroll
-      for (int k = i + 1; k < DP; ++k) s -= L[k * DP + i] * x[k];
-      x[i] = s / L[i * DP + i];
-    }
-  }
-};
-
+}  // namespace pplie
+#include "chol.h"
+namespace pplie {
 // Ainv = A^-1 for SPD blocks (block-Jacobi preconditioner of the pose-graph PCG): Cholesky, then
 // the columns of the identity are solved one by one.
 template <class T, int DP> struct Op_spd_inverse {

@@ -103,6 +103,20 @@ __device__ __forceinline__ void slab_s2g(const T* __restrict__ s, T* __restrict_
   }
 }
 
+// sum over a 256-thread workgroup (valid in thread 0); every thread must call it
+template <class T> __device__ __forceinline__ T block_sum(T v) {
+  __shared__ T part[4];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) part[w] = v;
+  __syncthreads();
+  T s = T(0);
+  if (threadIdx.x == 0) s = part[0] + part[1] + part[2] + part[3];
+  __syncthreads();
+  return s;   // valid in thread 0
+}
+
 template <int W> struct AtLeast1 { enum { v = W > 0 ? W : 1 }; };
 
 // Op concept: enum {IW0,IW1,IW2,OW0,OW1} (0 = unused) and

@@ -51,6 +51,10 @@ def _legacy_level(t):
     raise RuntimeError("pypose_amd: nested legacy vmap over a Lie op is not supported")
 
 
+# optim/fused.py registers tracers here to recognise whole residual programs (kernel name, inputs, outputs)
+_op_tracers = []
+
+
 def _launch(name, ins, in_widths, out_widths):
     """Broadcast leading dims, flatten to rows, launch, un-flatten."""
     if any(_is_legacy_batched(t) for t in ins):
@@ -63,14 +67,19 @@ def _launch(name, ins, in_widths, out_widths):
         phys = [p if p is not None else t.unsqueeze(0).expand((bsz,) + tuple(t.shape)) for p, t in zip(phys, ins)]
         outs = _launch(name, phys, in_widths, out_widths)
         return tuple(torch._add_batch_dim(o, 0, lvl) for o in outs)
-    lead = torch.broadcast_shapes(*[t.shape[:-1] for t in ins])
+    lead = ins[0].shape[:-1]
+    if any(t.shape[:-1] != lead for t in ins[1:]):
+        lead = torch.broadcast_shapes(*[t.shape[:-1] for t in ins])
     flat = []
     for t, w in zip(ins, in_widths):
         if t.shape[:-1] != lead:
             t = t.expand(lead + (t.shape[-1],))
         flat.append(_rows(t, w))
     outs = _C.row_op(name, flat, out_widths)
-    return tuple(o.view(lead + (w,)) for o, w in zip(outs, out_widths))
+    outs = tuple(o.view(lead + (w,)) for o, w in zip(outs, out_widths))
+    for tr in _op_tracers:
+        tr.note(name, ins, outs)
+    return outs
 
 
 def _fold_vmap(in_dims, args):
@@ -249,7 +258,8 @@ def broadcast_inputs(x, y):
     """Reference operation.py:1116-1125: broadcast leading dims and flatten to rows."""
     if y is None:
         return (x.reshape(-1, x.shape[-1]).contiguous(),), tuple(x.shape[:-1])
-    out_shape = torch.broadcast_shapes(x.shape[:-1], y.shape[:-1])
+    # (equal shapes are the common case; torch.broadcast_shapes costs ~10 us of Python)
+    out_shape = x.shape[:-1] if x.shape[:-1] == y.shape[:-1] else torch.broadcast_shapes(x.shape[:-1], y.shape[:-1])
     shape = out_shape if out_shape != torch.Size([]) else (1,)
     x = x.expand(tuple(shape) + (x.shape[-1],)).reshape(-1, x.shape[-1]).contiguous()
     y = y.expand(tuple(shape) + (y.shape[-1],)).reshape(-1, y.shape[-1]).contiguous()

@@ -1,0 +1,174 @@
+"""Whole-step fused Levenberg-Marquardt for recognised residual programs.
+
+The block path (optim/blocks.py) differentiates ANY row-independent model with ``d_res`` batched
+backward sweeps and then runs per-problem kernels; every intermediate (J blocks, A, g, D) makes a
+round trip through HBM.  For a model whose forward pass is exactly a known chain of Lie kernels the
+whole trial step -- Jacobian, normal equations, damped Cholesky, retraction and the new loss -- fits in
+registers, one problem per lane (csrc/lm_fused.hip).
+
+Recognition is by *execution trace*, not by model class: :class:`OpTracer` records the HIP kernels the
+model's forward launches (name, input tensors, output tensors); a program matches only if the trace is
+exactly the expected chain and its last output IS the residual the optimizer sees.  The first fused
+step of a given signature is cross-checked against the generic block linearisation.
+
+Programs:
+
+``se3inv``   r = Log(P * X), P an SE3 ``pp.Parameter`` [n,7], X a constant SE3 batch -- the reference's
+             README InvNet (README.md:120-129; BASELINE configs[2]), J = [Jl_inv(r) | 0].
+"""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+
+from .. import _C
+from ..lietensor import lietensor as _lt
+from ..lietensor import operation as _op
+from . import blocks as _blocks
+
+_PARTIALS = 4096          # PPLIE_LM_TRIAL_PARTIALS: rows of per-workgroup partial sums the kernel may write
+_TRIAL_SIG = [ctypes.c_void_p] * 6 + [ctypes.c_double] * 3 + [ctypes.c_int64, ctypes.c_void_p]
+
+
+class OpTracer:
+    """Context manager recording every row kernel launched by the Lie Functions."""
+
+    def __init__(self):
+        self.events = []        # (kernel name, inputs, outputs); holds the tensors alive -> stable data_ptrs
+
+    def __enter__(self):
+        _op._op_tracers.append(self)
+        return self
+
+    def __exit__(self, *exc):
+        _op._op_tracers.remove(self)
+
+    def note(self, name, ins, outs):
+        self.events.append((name, tuple(ins), tuple(outs)))
+
+
+def _same(a, b):
+    # (the Lie methods flatten leading dims to rows before launching: same storage, same element count)
+    return a.data_ptr() == b.data_ptr() and a.numel() == b.numel() and a.dtype == b.dtype and a.is_contiguous() and b.is_contiguous()
+
+
+def match_se3inv(trace, R, params):
+    """(P, X, r) if the traced forward is exactly  r = se3_log(se3_mul(P, X))  with P the only parameter."""
+    if len(trace.events) != 2 or len(R) != 1 or len(params) != 1:
+        return None
+    (n0, i0, o0), (n1, i1, o1) = trace.events
+    P = params[0]
+    if n0 != "se3_mul_fwd" or n1 != "se3_log_fwd" or getattr(P, "ltype", None) is not _lt.SE3_type:
+        return None
+    A, X = i0
+    if not _same(A, P) or X.requires_grad or X.numel() != P.numel() or P.dim() < 2 or not _same(i1[0], o0[0]):
+        return None
+    if not _same(o1[0], R[0]) or R[0].shape[-1] != 6:
+        return None
+    return P, X, o1[0]
+
+
+class Se3InvLinearization:
+    """LM trial steps of ``r = Log(P X)`` in one kernel each (pplie_lm_se3inv_trial)."""
+
+    kind = "fused:se3inv"
+
+    def __init__(self, opt, P, X, r):
+        self.opt, self.P = opt, P
+        self.n = P.numel() // 7
+        self.X = X.detach().reshape(self.n, 7).contiguous()
+        self.R = r.detach().reshape(self.n, 6).contiguous()
+        self.scale = 1.0
+        self.sums = None
+
+    def build_normal_equations(self, dmin, dmax):
+        self.dmin, self.dmax = float(dmin), float(dmax)
+
+    def damp(self, damping):
+        self.scale *= 1.0 + float(damping)          # A.diag += A.diag * damping, compounding (optimizer.py:666)
+
+    def _trial(self, out, scale):
+        pt = self.P.detach().reshape(self.n, 7)
+        assert pt.is_contiguous()
+        out = pt if out is None else out
+        D = torch.empty((self.n, 7), dtype=pt.dtype, device=pt.device)
+        part = torch.zeros((_PARTIALS, 4), dtype=pt.dtype, device=pt.device)
+        fn = _C.library().symbol("pplie_lm_se3inv_trial" + _blocks._suffix(pt), _TRIAL_SIG)
+        with torch.cuda.device(pt.device):
+            code = fn(self.R.data_ptr(), pt.data_ptr(), self.X.data_ptr(), out.data_ptr(), D.data_ptr(), part.data_ptr(),
+                      scale, self.dmin, self.dmax, self.n, _C.stream_ptr(pt.device))
+        _C.check(code, "pplie_lm_se3inv_trial")
+        return D, part.sum(0)
+
+    def verify(self, ref, dmin, dmax, rtol=1e-3):
+        """Undamped trial into a scratch buffer vs the generic block linearisation ``ref`` of the same model."""
+        from .solver import Cholesky
+        self.build_normal_equations(dmin, dmax)
+        D, sums = self._trial(torch.empty_like(self.P.detach().reshape(self.n, 7)), 1.0)
+        ref.build_normal_equations(dmin, dmax)
+        Dr = ref.solve(Cholesky()).view(self.n, 7)
+        Rr = ref.Rb
+        ok = bool((D - Dr).abs().max() <= rtol * Dr.abs().max().clamp_min(1e-30))
+        return ok and bool((sums[1] - Rr.square().sum()).abs() <= rtol * Rr.square().sum().clamp_min(1e-30))
+
+    def run_trials(self, opt, pg):
+        """The trial loop of LM.step (reference optimizer.py:662-678) with every decision taken on host
+        scalars: one kernel and one 4-float read-back per trial."""
+        strategy, P = opt.strategy, self.P
+        have = hasattr(opt, 'loss')
+        cached = opt.__dict__.get('_host_loss', (None, None))
+        last = loss = (cached[1] if cached[0] is opt.loss else float(opt.loss)) if have else None
+        opt.reject_count = 0
+        if have:
+            opt.last = opt.loss
+        while True:
+            self.damp(pg['damping'])
+            # P_new is written in place: this IS update_parameter (p.add_(d) = Exp(d) * p, lietensor.py:442)
+            D, sums = self._trial(None, self.scale)
+            if opt.group is not None:
+                import torch.distributed as dist
+                dist.all_reduce(sums, group=opt.group)
+            new, old, jdjd, jdr = sums.tolist()
+            assert new == new, 'Cholesky decomposition failed. Check your matrix (may not be positive-definite)'
+            if last is None:                          # first step ever: |R|^2 is the loss before the update
+                last = old
+                opt.last = sums[1]
+            loss, opt.loss = new, sums[0]
+            # gain ratio from the two reduced dot products: an equivalent 1x1 problem on the host
+            x = max(jdjd, 1e-300) ** 0.5
+            one = torch.ones((1, 1), dtype=torch.float64)
+            strategy.update(pg, last=last, loss=loss, J=one, D=x * one, R=(jdr / x) * one)
+            if last < loss and opt.reject_count < opt.reject:          # reject the step
+                opt.update_parameter(params=pg['params'], step=-D.view(-1, 1))
+                loss, opt.loss, opt.reject_count = last, opt.last, opt.reject_count + 1
+            else:
+                break
+            if not last <= loss:
+                break
+        opt._host_loss = (opt.loss, loss)
+        return opt.loss
+
+
+def try_fused(opt, pg, input, target, weight, cache):
+    """A fused linearisation if the model's forward is a recognised program, else None."""
+    from .optimizer import Trivial
+    from .solver import Cholesky
+    from .posegraph import PCG
+    params = [p for p in pg['params'] if p.requires_grad]
+    if cache.get("fused") is False or len(params) != 1 or _C._test_backend is not None:
+        return None
+    P = params[0]
+    if not (P.is_cuda and _blocks._suffix(P) and target is None and weight is None and len(opt.param_groups) == 1):
+        return None
+    if not all(isinstance(c, Trivial) for c in opt.corrector) or not all(isinstance(k, Trivial) for k in opt.model.kernel):
+        return None
+    if not ((isinstance(opt.solver, Cholesky) and not opt.solver.upper) or isinstance(opt.solver, PCG)):
+        return None
+    with torch.no_grad(), OpTracer() as tr:
+        R = list(opt.model(input, target))
+    m = match_se3inv(tr, R, params)
+    if m is None:
+        cache["fused"] = False
+        return None
+    return Se3InvLinearization(opt, *m)

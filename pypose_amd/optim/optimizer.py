@@ -216,6 +216,16 @@ def _linearize(opt, pg, input, target, weight):
     cache = opt.__dict__.setdefault('_structure_cache', {})
     if getattr(opt, 'structured', True) and params:
         from . import posegraph as _pg
+        if getattr(opt, 'fused', False):
+            from . import fused as _fused
+            lin = _fused.try_fused(opt, pg, input, target, weight, cache)
+            if lin is not None:
+                if cache.get("fused") is None:       # first use: cross-check against the generic block path
+                    cache["fused"] = False
+                    ref = _linearize(opt, pg, input, target, weight)
+                    cache["fused"] = ref.kind == "block" and lin.verify(ref, pg['min'], pg['max'])
+                if cache["fused"]:
+                    return lin
         with torch.enable_grad():
             with _pg.GatherRecorder(params) as rec:
                 R = list(opt.model(input, target))
@@ -302,6 +312,7 @@ class LevenbergMarquardt(_Optimizer):
         # same problems are covered by the automatically detected block / pose-graph linearisations, so
         # the flag only records the intent; a model without detectable structure still runs densely.
         self.sparse = bool(sparse)
+        self.fused = True          # whole-step kernels for recognised residual programs (optim/fused.py)
         # torch.distributed process group: independent problems / graph edges are sharded over its
         # ranks (one process per GPU, RCCL); the loss, the gain ratio and -- for pose graphs -- the
         # normal-equation pieces are all-reduced so that every rank takes the same decisions.
@@ -344,6 +355,9 @@ class LevenbergMarquardt(_Optimizer):
                                    "linearisation is not sharded")
             lin.build_normal_equations(pg['min'], pg['max'])
             self.linearization = lin.kind
+            if hasattr(lin, 'run_trials'):              # whole-step fused kernels (optim/fused.py)
+                lin.run_trials(self, pg)
+                continue
             self.last = self.loss = self.loss if hasattr(self, 'loss') else self._loss(input, target)
             self.reject_count = 0
             J, R = lin.strategy_args()

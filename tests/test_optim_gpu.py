@@ -16,18 +16,79 @@ def G():
     return load_lm_golden()
 
 
-@pytest.mark.parametrize("structured", [False, True])
+FUSABLE = {"constant", "adaptive", "trustregion", "far"}     # Trivial kernel, no weight, no target: optim/fused.py
+
+
+@pytest.mark.parametrize("mode", ["dense", "block", "fused"])
 @pytest.mark.parametrize("case", ["constant", "adaptive", "trustregion", "huber_weight", "cauchy_target", "gn", "far"])
-def test_invnet_trajectory_matches_reference(G, case, structured):
+def test_invnet_trajectory_matches_reference(G, case, mode):
     from pypose_amd import _C
     assert _C._test_backend is None
     mk, init, args, kwargs, n = invnet_cases(G, DEV)[case]
     net = InvNet(init)
     opt = mk(net)
-    opt.structured = structured
+    opt.structured, opt.fused = mode != "dense", mode == "fused"
     rec = run_steps(opt, args, kwargs, n)
-    assert set(rec["kind"]) <= ({"block", "?"} if structured else {"dense", "?"}), rec["kind"]
+    want = {"dense": "dense", "block": "block", "fused": "fused:se3inv" if case in FUSABLE else "block"}[mode]
+    assert set(rec["kind"]) <= {want, "?"}, rec["kind"]
     compare_trajectory(rec, G, "invnet/" + case)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-11), (torch.float32, 3e-5)])
+@pytest.mark.parametrize("n", [1, 255, 256, 70_001])
+def test_fused_se3inv_trial_kernel_vs_oracle(dtype, tol, n):
+    """pplie_lm_se3inv_trial through the C ABI against oracle/optim_np.lm_se3inv_trial (fp64 anchor)."""
+    from oracle import optim_np
+    from pypose_amd.optim import fused
+    torch.manual_seed(n)
+    P = pp.Parameter(pp.randn_SE3(n, dtype=dtype, device=DEV))
+    X = pp.randn_SE3(n, dtype=dtype, device=DEV)
+    r = (P @ X).Log().tensor().detach()
+
+    class Opt:
+        group = None
+    lin = fused.Se3InvLinearization(Opt(), P, X, r)
+    lin.build_normal_equations(1e-6, 1e32)
+    out = torch.empty((n, 7), dtype=dtype, device=DEV)
+    D, sums = lin._trial(out, 1.37)
+    f64 = lambda t: t.detach().double().cpu().numpy()
+    Pn, d, s = optim_np.lm_se3inv_trial(f64(r), f64(P.tensor()), f64(X.tensor()), 1.37, 1e-6, 1e32)
+    assert np.abs(f64(D) - d).max() <= tol * max(1.0, np.abs(d).max())
+    assert np.abs(f64(out) - Pn).max() <= tol * max(1.0, np.abs(Pn).max())
+    got = f64(sums)
+    assert np.all(np.abs(got[1:] - s[1:]) <= 20 * tol * np.abs(s[1:]).max()), (got, s)
+    # the new loss is a squared distance to the optimum: compare on the scale of the old one
+    assert abs(got[0] - s[0]) <= tol * s[1]
+    # in place: P_new written over P_cur gives the same result
+    D2, sums2 = lin._trial(None, 1.37)
+    assert torch.equal(P.detach().tensor(), out) and torch.equal(D2, D) and torch.equal(sums2, sums)
+
+
+def test_fused_program_is_recognised_only_when_exact(G):
+    """Anything but  Log(P @ X)  with a Trivial kernel / no weight / no target stays on the generic paths."""
+    torch.manual_seed(0)
+    inp = pp.randn_SE3(64, device=DEV)
+
+    class Scaled(InvNet):
+        def forward(self, input):
+            return 2 * super().forward(input)
+
+    class Swapped(InvNet):
+        def forward(self, input):
+            return (input @ self.pose).Log().tensor()
+
+    for cls, kw, want in ((InvNet, {}, "fused:se3inv"), (Scaled, {}, "block"), (Swapped, {}, "block"),
+                          (InvNet, {"kernel": pp.optim.kernel.Huber()}, "block"),
+                          (InvNet, {"solver": pp.optim.solver.PINV()}, "block")):
+        net = cls(pp.randn_SE3(64, device=DEV))
+        opt = pp.optim.LM(net, strategy=pp.optim.strategy.Constant(1e-6), **kw)
+        l0 = float(net(inp).detach().square().sum())
+        assert float(opt.step(inp)) < l0
+        assert opt.linearization == want, (cls.__name__, kw, opt.linearization)
+    net = InvNet(pp.randn_SE3(64, device=DEV))
+    opt = pp.optim.LM(net, strategy=pp.optim.strategy.Constant(1e-6))
+    opt.step(inp, target=torch.zeros(64, 6, device=DEV))
+    assert opt.linearization == "block"
 
 
 @pytest.mark.parametrize("structured", [False, True])
@@ -132,7 +193,7 @@ def test_c3_invnet_one_million_problems():
     opt = pp.optim.LM(net, strategy=pp.optim.strategy.Constant(damping=1e-4))
     l0 = float(net.forward(inp).square().sum())
     losses = [float(opt.step(inp)) for _ in range(3)]
-    assert opt.linearization == "block"
+    assert opt.linearization == "fused:se3inv"
     assert losses[0] < 1e-3 * l0 and losses[-1] < 1e-6 * l0, (l0, losses)
     # the optimum is pose = input^-1: pose * input == identity
     I = (pp.SE3(net.pose.detach().tensor()) * inp).Log().tensor()
