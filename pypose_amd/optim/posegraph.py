@@ -37,7 +37,9 @@ from . import blocks as _blocks
 
 _SPMV_SIG = [ctypes.c_void_p] * 5 + [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
 _ASM_SIG = [ctypes.c_void_p] * 7 + [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+_ASMC_SIG = [ctypes.c_void_p] * 8 + [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
 _BSR_SIG = [ctypes.c_void_p] * 8 + [ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]
+_PCG_SCAL_ELEMS = 2 * 4 * 32 * 32          # PPLIE_PCG_SCAL_ELEMS: two sets of slot-spread scalars (csrc/graph.hip)
 _INV_SIG = [ctypes.c_void_p] * 2 + [ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]
 _HIP_SHAPES = {(6, 6, 2), (7, 7, 2), (3, 3, 2), (6, 6, 1), (3, 3, 1)}
 DENSE_LIMIT = 4096          # assemble a dense A for the user's solver up to this many unknowns
@@ -146,7 +148,7 @@ _PCG_SIG = [ctypes.c_int] + [ctypes.c_void_p] * 10 + [ctypes.c_int, ctypes.c_int
 class FusedPCG:
     """Device-resident block-Jacobi PCG for one graph shape (csrc/graph.hip).
 
-    Five small launches per iteration (memset, ``pplie_graph_spmv``, and the fused vector stages of
+    Three launches per iteration (``pplie_graph_bsr_spmv`` fused with p.q, then stages 1 and 2 of
     ``pplie_pcg_stage``) with every scalar kept on the device; ``check_every`` iterations are captured
     into one hipGraph and replayed, so the loop costs neither Python dispatch nor a host sync per
     iteration.  Buffers (and the graph) are cached per shape and reused across LM steps.
@@ -160,27 +162,19 @@ class FusedPCG:
         self.idx = torch.zeros((E, K), dtype=torch.int64, device=device)
         self.Binv, self.shift = z(N, m, m), z(N, m)
         self.x, self.r, self.p, self.q, self.z = (z(N, m) for _ in range(5))
-        self.scal = z(4)
+        self.scal = z(_PCG_SCAL_ELEMS)
         self.cap = 1 << 16
         self.rr_hist = z(self.cap)
-        self.it = torch.zeros(1, dtype=torch.int32, device=device)
+        self.it = torch.zeros(2, dtype=torch.int32, device=device)
         self.sfx = "_f32" if dtype == torch.float32 else "_f64"
         self.graph = None
 
-    def _csr(self, idx):
-        """incidence lists sorted by node (rebuilt only when the edge list changes)"""
-        if getattr(self, '_csr_idx', None) is not None and self._csr_idx.shape == idx.shape and torch.equal(self._csr_idx, idx):
-            return
-        E, N = self.E, self.N
-        flat = idx.t().reshape(-1)                                 # [side0 entries | side1 entries]
-        order = torch.argsort(flat, stable=True)
-        self.ptr = torch.zeros(N + 1, dtype=torch.int32, device=idx.device)
-        self.ptr[1:] = torch.cumsum(torch.bincount(flat, minlength=N), 0).to(torch.int32)
-        e, side = order % E, order // E
-        self.blk = (2 * e + side).to(torch.int32)
-        self.other = idx[e, 1 - side].to(torch.int32)
-        self._csr_idx = idx.clone()
-        self.graph = None                                           # captured pointers are stale
+    def _csr(self, lin):
+        """incidence lists sorted by node (shared with the assembly kernel, rebuilt only when the edge list changes)"""
+        csr = lin.csr()
+        if getattr(self, '_csr_obj', None) is not csr:
+            self._csr_obj, (self.ptr, self.blk, self.other) = csr, csr
+            self.graph = None                                       # captured pointers are stale
 
     def _iteration(self, group):
         lib = _C.library()
@@ -188,8 +182,8 @@ class FusedPCG:
         stage = lib.symbol("pplie_pcg_stage" + self.sfx, _PCG_SIG)
         if self.bsr:
             code = lib.symbol("pplie_graph_bsr_spmv" + self.sfx, _BSR_SIG)(
-                self.ptr.data_ptr(), self.blk.data_ptr(), self.other.data_ptr(), self.HB.data_ptr(), self.D.data_ptr(),
-                self.p.data_ptr(), self.q.data_ptr(), self.scal.data_ptr(), self.N, self.m, st)
+                self.ptr.data_ptr(), self.other.data_ptr(), self.HB.data_ptr(), self.D.data_ptr(),
+                self.p.data_ptr(), self.q.data_ptr(), self.scal.data_ptr(), self.it.data_ptr(), self.N, self.m, st)
             _C.check(code, "pplie_graph_bsr_spmv")
             first = 1                                               # q = A p and p.q are already done
         else:
@@ -200,24 +194,23 @@ class FusedPCG:
             _C.check(code, "pplie_graph_spmv")
             _all_reduce(self.q, group)
             first = 0
-        for s in range(first, 4):
+        for s in range(first, 3):
             code = stage(s, self.x.data_ptr(), self.r.data_ptr(), self.p.data_ptr(), self.q.data_ptr(), self.z.data_ptr(),
                          self.Binv.data_ptr(), self.shift.data_ptr(), self.scal.data_ptr(), self.rr_hist.data_ptr(),
                          self.it.data_ptr(), self.cap, self.N, self.m, st)
             _C.check(code, "pplie_pcg_stage")
 
     def solve(self, lin, b, shift, Binv, Bd, tol, maxiter, group):
-        bsr = lin.H12 is not None and group is None and self.m in (3, 6, 7)
+        bsr = lin.HB is not None and group is None and self.m in (3, 6, 7)
         if bsr != getattr(self, 'bsr', None):
             self.graph = None                                       # the captured iteration differs
         self.bsr = bsr
         if bsr:
-            self._csr(lin.idx)
+            self._csr(lin)
             if getattr(self, 'HB', None) is None:
-                self.HB = torch.empty((self.E, 2, self.m, self.m), dtype=self.J.dtype, device=self.J.device)
+                self.HB = torch.empty_like(lin.HB)
                 self.D = torch.empty((self.N, self.m, self.m), dtype=self.J.dtype, device=self.J.device)
-            self.HB[:, 0].copy_(lin.H12)
-            self.HB[:, 1].copy_(lin.H12.mT)
+            self.HB.copy_(lin.HB)                                   # off-diagonal blocks in incidence order
             self.D.copy_(Bd)                                        # diagonal blocks incl. clamp + damping
         else:
             self.J.copy_(lin.J)
@@ -284,7 +277,7 @@ class GraphLinearization:
         self.W = weight
         self.group = getattr(opt, 'group', None)
         self.s = 1.0            # compounded damping factor prod(1 + lambda_i)
-        self.H12 = None
+        self.HB = None
 
     # -- index helpers -------------------------------------------------------------------------
     def step_to_nodes(self, D):
@@ -295,6 +288,26 @@ class GraphLinearization:
             Dn = torch.cat([Dn, torch.zeros((self.N, self.wfull - self.m), dtype=Dn.dtype, device=Dn.device)], -1)
         return Dn.reshape(-1, 1)
 
+    def csr(self):
+        """(ptr [N+1], blk [K E] = K*edge + side, other [K E]) int32: the incidences of every node, sorted by
+        node.  Cached on the optimizer; rebuilt only when the edge list changes."""
+        cache = self.opt.__dict__.setdefault('_graph_csr', {})
+        key = (self.E, self.K, self.N, self.idx.device)
+        hit = cache.get(key)
+        if hit is not None and torch.equal(hit[0], self.idx):
+            return hit[1]
+        E, N, K, idx = self.E, self.N, self.K, self.idx
+        flat = idx.t().reshape(-1)                                 # [side 0 entries | side 1 entries | ...]
+        order = torch.argsort(flat, stable=True)
+        ptr = torch.zeros(N + 1, dtype=torch.int32, device=idx.device)
+        ptr[1:] = torch.cumsum(torch.bincount(flat, minlength=N), 0).to(torch.int32)
+        e, side = order % E, order // E
+        blk = (K * e + side).to(torch.int32)
+        other = idx[e, 1 - side].to(torch.int32) if K == 2 else torch.zeros_like(blk)
+        csr = (ptr, blk, other)
+        cache[key] = (idx.clone(), csr)
+        return csr
+
     # -- kernels ---------------------------------------------------------------------------------
     def _hip(self):
         return (_C._test_backend is None and self.J.is_cuda and (self.dr, self.m, self.K) in _HIP_SHAPES
@@ -302,21 +315,33 @@ class GraphLinearization:
 
     def _assemble(self):
         N, m = self.N, self.m
-        B = torch.zeros((N, m, m), dtype=self.J.dtype, device=self.J.device)
-        g = torch.zeros((N, m), dtype=self.J.dtype, device=self.J.device)
+        dt, dev = self.J.dtype, self.J.device
         if self._hip():
-            sfx = "_f32" if self.J.dtype == torch.float32 else "_f64"
-            fn = _C.library().symbol("pplie_graph_assemble" + sfx, _ASM_SIG)
-            # off-diagonal blocks H12[e] = J_0^T W J_1 feed the node-parallel (atomic-free) SpMV
-            self.H12 = torch.empty((self.E, m, m), dtype=self.J.dtype, device=self.J.device) \
-                if (self.K == 2 and self.group is None and self.E < (1 << 30)) else None
-            with torch.cuda.device(self.J.device):
-                code = fn(self.J.data_ptr(), self.W.data_ptr() if self.W is not None else None, self.R.data_ptr(),
-                          self.idx.data_ptr(), B.data_ptr(), g.data_ptr(),
-                          self.H12.data_ptr() if self.H12 is not None else None, self.E, self.dr, self.m, self.K,
-                          _C.stream_ptr(self.J.device))
-            _C.check(code, "pplie_graph_assemble")
+            sfx = "_f32" if dt == torch.float32 else "_f64"
+            lib, st = _C.library(), _C.stream_ptr(dev)
+            wptr = self.W.data_ptr() if self.W is not None else None
+            csr_ok = self.group is None and self.E * self.K < (1 << 31)
+            with torch.cuda.device(dev):
+                if csr_ok:      # node-parallel: every block / gradient row written once, no atomics, no zero-fill
+                    B = torch.empty((N, m, m), dtype=dt, device=dev)
+                    g = torch.empty((N, m), dtype=dt, device=dev)
+                    ptr, blk, _ = self.csr()
+                    # off-diagonal blocks in incidence order feed the streaming node-parallel SpMV of the PCG
+                    self.HB = torch.empty((self.E * 2, m, m), dtype=dt, device=dev) if self.K == 2 else None
+                    code = lib.symbol("pplie_graph_assemble_csr" + sfx, _ASMC_SIG)(
+                        ptr.data_ptr(), blk.data_ptr(), self.J.data_ptr(), wptr, self.R.data_ptr(), B.data_ptr(),
+                        g.data_ptr(), self.HB.data_ptr() if self.HB is not None else None, N, self.dr, self.m, self.K, st)
+                    _C.check(code, "pplie_graph_assemble_csr")
+                else:           # edge shards (group=): scatter-add, then all-reduce
+                    B = torch.zeros((N, m, m), dtype=dt, device=dev)
+                    g = torch.zeros((N, m), dtype=dt, device=dev)
+                    code = lib.symbol("pplie_graph_assemble" + sfx, _ASM_SIG)(
+                        self.J.data_ptr(), wptr, self.R.data_ptr(), self.idx.data_ptr(), B.data_ptr(), g.data_ptr(),
+                        None, self.E, self.dr, self.m, self.K, st)
+                    _C.check(code, "pplie_graph_assemble")
         else:
+            B = torch.zeros((N, m, m), dtype=dt, device=dev)
+            g = torch.zeros((N, m), dtype=dt, device=dev)
             for k in range(self.K):
                 Jk = self.J[:, k]
                 JtW = Jk.mT if self.W is None else Jk.mT @ self.W

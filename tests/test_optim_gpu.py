@@ -174,12 +174,26 @@ def test_graph_kernels_vs_torch_reference(dtype, tol):
             pass
         lin = posegraph.GraphLinearization(Opt(), Wm, R, torch.zeros(N, 7, dtype=dtype, device=DEV), idx, J, 7, 6)
         assert lin._hip()
-        B, gr = lin._assemble()
+        B, gr = lin._assemble()                 # node-parallel (CSR) kernel + H12
         y = lin._Hp(p)
+        # the edge-parallel scatter-add kernel (used when edges are sharded over ranks), through the C ABI
+        from pypose_amd import _C
+        Ba, ga = torch.zeros_like(B), torch.zeros_like(gr)
+        fn = _C.library().symbol("pplie_graph_assemble" + ("_f32" if dtype == torch.float32 else "_f64"), posegraph._ASM_SIG)
+        _C.check(fn(J.data_ptr(), Wm.data_ptr() if Wm is not None else None, R.data_ptr(), idx.data_ptr(), Ba.data_ptr(),
+                    ga.data_ptr(), None, E, 6, 6, 2, _C.stream_ptr(J.device)), "pplie_graph_assemble")
+        assert (Ba - B).abs().max().item() <= tol * B.abs().max().item()
+        assert (ga - gr).abs().max().item() <= tol * gr.abs().max().item()
+        HB, (ptr, blk, other) = lin.HB, lin.csr()
         lin._hip = lambda: False               # torch formulation on the same device
         B2, gr2 = lin._assemble()
         y2 = lin._Hp(p)
-        for a, b in ((B, B2), (gr, gr2), (y, y2)):
+        # off-diagonal blocks in incidence order: HB[c] = J[e, side]^T W J[e, 1 - side] with blk[c] = 2 e + side
+        e, side = (blk // 2).long(), (blk % 2).long()
+        Jn, Jf = J[e, side], J[e, 1 - side]
+        want = (Jn.mT if Wm is None else Jn.mT @ Wm[e]) @ Jf
+        assert torch.equal(other.long(), idx[e, 1 - side])
+        for a, b in ((B, B2), (gr, gr2), (y, y2), (HB, want)):
             assert (a - b).abs().max().item() <= tol * b.abs().max().item()
 
 
