@@ -39,3 +39,21 @@ def lm_se3inv_trial(R, P, X, scale, dmin, dmax):
     Jd = (J @ d[..., None])[..., 0]
     sums = np.array([(rn * rn).sum(), (R * R).sum(), (Jd * Jd).sum(), (Jd * R).sum()])
     return Pn, np.concatenate([d, np.zeros_like(d[:, :1])], -1), sums
+
+
+def pgo_linearize(nodes, idx, Z):
+    """Per-edge residuals and Jacobian blocks of the reference's PoseGraph model (examples/module/pgo/pgo.py:15-25),
+    r = Log(Z^-1 n_i^-1 n_j), by the chain of backward rules the reference's autograd applies:
+    SE3_Log.backward g @ se3_Jl_inv(r) (operation.py:385-395), SE3_Mul.backward Y_grad = g @ Adj(X) (:905-908),
+    SE3_Inv.backward X_grad = -g @ Adj(Y) (:992-998).  Returns R [E,6], J [E,2,6,6] (left tangents)."""
+    from oracle import lie_np
+    n1, n2 = nodes[idx[:, 0]], nodes[idx[:, 1]]
+    a = lie_np.se3_inv_fwd(Z)[0]
+    b = lie_np.se3_inv_fwd(n1)[0]
+    c = lie_np.se3_mul_fwd(a, b)[0]
+    u = lie_np.se3_mul_fwd(c, n2)[0]
+    R = lie_np.se3_log_fwd(u)[0]
+    Ji = lie_np.se3_Jl_inv(R)                                  # d r / d u
+    J2 = Ji @ lie_np.SE3_Adj(c)                                # through u = c * n2 to n2
+    J1 = -(Ji @ lie_np.SE3_Adj(a)) @ lie_np.SE3_Adj(b)         # through c = a * b to b, through b = n1^-1 to n1
+    return R, np.stack([J1, J2], axis=1)

@@ -1,0 +1,162 @@
+// pgo_fused.hip -- the pose-graph residual program of the reference (examples/module/pgo/pgo.py:15-25)
+//
+//     node1, node2 = nodes[edges[..., 0]], nodes[edges[..., 1]]
+//     r_e = Log(Z_e^-1 * node1^-1 * node2)                         Z = the measured relative poses
+//
+// linearised per edge in one kernel.  Chaining the reference's backward rules (operation.py:385-395 SE3_Log,
+// :905-908 SE3_Mul: Y_grad = g @ Adj(X), :992-998 SE3_Inv: X_grad = -g @ Adj(Y)) gives, with T = Z^-1 node1^-1,
+//     d r / d node2 = Jl_inv(r) Adj(T)            d r / d node1 = -Jl_inv(r) Adj(T)
+// (left tangents).  With Jl_inv(r) = [[Ji, Mq], [0, Ji]] (operation.py:68-75) and Adj(T) = [[R, tx R], [0, R]]
+// (:202-210) the product is [[Ji R, Ji tx R + Mq R], [0, Ji R]]: three 3x3 products per edge.
+// Algorithmic bytes per edge: 16 idx + 28 Z + 2 * 28 gathered nodes read,
+// 24 residual + 2 * 144 Jacobian written = 412 B; the autograd route makes 6 backward sweeps through five ops.
+#include "rowmap.h"
+
+namespace pplie {
+
+// r = Log(Z^-1 n1^-1 n2);  T = Z^-1 n1^-1
+template <class T> __device__ __forceinline__ void pgo_residual(const T* z, const T* n1, const T* n2, T* Tm, T* r) {
+  T zi[7], n1i[7], u[7];
+  se3_inv<T>(z, zi);
+  se3_inv<T>(n1, n1i);
+  se3_mul<T>(zi, n1i, Tm);
+  se3_mul<T>(Tm, n2, u);
+  se3_log<T>(u, r);
+}
+
+template <class T, int BLOCK>
+__global__ void __launch_bounds__(BLOCK)
+pgo_linearize_kernel(const T* __restrict__ nodes, const int64_t* __restrict__ idx, const T* __restrict__ Z,
+                     T* __restrict__ R, T* __restrict__ J, int64_t E) {
+  __shared__ __attribute__((aligned(16))) T lds[BLOCK * 72];
+  const int64_t ntiles = (E + BLOCK - 1) / BLOCK;
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t e0 = tile * BLOCK;
+    const int64_t left = E - e0;
+    const bool full = left >= BLOCK;
+    const int rows = full ? BLOCK : (int)left;
+    slab_g2s<T, BLOCK, BLOCK * 7, true>(Z + e0 * 7, lds, rows * 7, full);
+    __syncthreads();
+    const int t = threadIdx.x;
+    T r[6], Jm[36];
+    if (t < rows) {
+      const int64_t e = e0 + t;
+      const int64_t i0 = idx[e * 2], i1 = idx[e * 2 + 1];
+      T z[7], n1[7], n2[7], Tm[7];
+      row_ld<7>(lds + t * 7, z);
+#pragma unroll
+      for (int k = 0; k < 7; ++k) { n1[k] = nodes[i0 * 7 + k]; n2[k] = nodes[i1 * 7 + k]; }
+      pgo_residual<T>(z, n1, n2, Tm, r);
+      V3<T> tau = v3(r), phi = v3(r + 3);
+      const T th2 = norm2(phi);
+      const RotCoef<T> kc = rot_coef(th2);
+      const T F = rot_coef_F(th2);
+      const V3<T> tt = v3(Tm), qv = v3(Tm + 3);
+      const T qw = Tm[6];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        V3<T> e3 = v3<T>(c == 0 ? T(1) : T(0), c == 1 ? T(1) : T(0), c == 2 ? T(1) : T(0));
+        V3<T> rc = adj_rotate(qv, qw, e3);                        // column c of R
+        V3<T> a = jlinv_apply(F, phi, rc);                        // column c of Ji R
+        V3<T> txr = cross(tt, rc);                                // column c of tx R
+        V3<T> b = jlinv_apply(F, phi, txr - q_apply(kc, tau, phi, a));   // Ji tx R + Mq R, Mq = -Ji Q Ji
+        Jm[0 * 6 + c] = a.x; Jm[1 * 6 + c] = a.y; Jm[2 * 6 + c] = a.z;
+        Jm[3 * 6 + c] = T(0); Jm[4 * 6 + c] = T(0); Jm[5 * 6 + c] = T(0);
+        Jm[0 * 6 + 3 + c] = b.x; Jm[1 * 6 + 3 + c] = b.y; Jm[2 * 6 + 3 + c] = b.z;
+        Jm[3 * 6 + 3 + c] = a.x; Jm[4 * 6 + 3 + c] = a.y; Jm[5 * 6 + 3 + c] = a.z;
+      }
+    }
+    __syncthreads();                                              // every lane has read its Z row
+    if (t < rows) row_st<6>(lds + t * 6, r);
+    __syncthreads();
+    slab_s2g<T, BLOCK, BLOCK * 6, true>(lds, R + e0 * 6, rows * 6, full);
+    __syncthreads();
+    if (t < rows) {
+#pragma unroll
+      for (int k = 0; k < 36; ++k) { lds[t * 72 + k] = -Jm[k]; lds[t * 72 + 36 + k] = Jm[k]; }
+    }
+    __syncthreads();
+    slab_s2g<T, BLOCK, BLOCK * 72, true>(lds, J + e0 * 72, rows * 72, full);
+    __syncthreads();
+  }
+}
+
+// residuals only + per-workgroup partial sums of |r|^2 (the Trivial-kernel loss, optimizer.py:118-125)
+template <class T, int BLOCK>
+__global__ void __launch_bounds__(BLOCK)
+pgo_residual_kernel(const T* __restrict__ nodes, const int64_t* __restrict__ idx, const T* __restrict__ Z,
+                    T* __restrict__ R /* or null */, T* __restrict__ partial /* [gridDim.x] */, int64_t E) {
+  __shared__ __attribute__((aligned(16))) T lds[BLOCK * 7];
+  T acc = T(0);
+  const int64_t ntiles = (E + BLOCK - 1) / BLOCK;
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t e0 = tile * BLOCK;
+    const int64_t left = E - e0;
+    const bool full = left >= BLOCK;
+    const int rows = full ? BLOCK : (int)left;
+    slab_g2s<T, BLOCK, BLOCK * 7, true>(Z + e0 * 7, lds, rows * 7, full);
+    __syncthreads();
+    const int t = threadIdx.x;
+    T r[6];
+    if (t < rows) {
+      const int64_t e = e0 + t;
+      const int64_t i0 = idx[e * 2], i1 = idx[e * 2 + 1];
+      T z[7], n1[7], n2[7], Tm[7];
+      row_ld<7>(lds + t * 7, z);
+#pragma unroll
+      for (int k = 0; k < 7; ++k) { n1[k] = nodes[i0 * 7 + k]; n2[k] = nodes[i1 * 7 + k]; }
+      pgo_residual<T>(z, n1, n2, Tm, r);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) acc += r[k] * r[k];
+    }
+    __syncthreads();
+    if (R) {
+      if (t < rows) row_st<6>(lds + t * 6, r);
+      __syncthreads();
+      slab_s2g<T, BLOCK, BLOCK * 6, true>(lds, R + e0 * 6, rows * 6, full);
+      __syncthreads();
+    }
+  }
+  T s = block_sum(acc);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
+constexpr int kPgoPartials = 1024;     // = PPLIE_PGO_PARTIALS in include/pplie.h
+
+template <class T>
+int pgo_linearize(const void* nodes, const void* idx, const void* Z, void* R, void* J, int64_t E, void* stream) {
+  if (E < 0) return PPLIE_EBADARG;
+  if (E == 0) return PPLIE_OK;
+  if (!nodes || !idx || !Z || !R || !J || !aligned16(Z) || !aligned16(R) || !aligned16(J)) return PPLIE_EBADARG;
+  constexpr int BLOCK = 64;
+  int64_t nt = (E + BLOCK - 1) / BLOCK;
+  int grid = (int)(nt < (1 << 20) ? nt : (1 << 20));
+  hipLaunchKernelGGL((pgo_linearize_kernel<T, BLOCK>), dim3(grid), dim3(BLOCK), 0, reinterpret_cast<hipStream_t>(stream),
+                     (const T*)nodes, (const int64_t*)idx, (const T*)Z, (T*)R, (T*)J, E);
+  return hipGetLastError() == hipSuccess ? PPLIE_OK : PPLIE_ELAUNCH;
+}
+template <class T>
+int pgo_residual_launch(const void* nodes, const void* idx, const void* Z, void* R, void* partial, int64_t E, void* stream) {
+  if (E <= 0) return E == 0 ? PPLIE_OK : PPLIE_EBADARG;
+  if (!nodes || !idx || !Z || !partial || !aligned16(Z) || (R && !aligned16(R))) return PPLIE_EBADARG;
+  constexpr int BLOCK = 256;
+  int64_t nt = (E + BLOCK - 1) / BLOCK;
+  int grid = (int)(nt < kPgoPartials ? nt : kPgoPartials);
+  hipLaunchKernelGGL((pgo_residual_kernel<T, BLOCK>), dim3(grid), dim3(BLOCK), 0, reinterpret_cast<hipStream_t>(stream),
+                     (const T*)nodes, (const int64_t*)idx, (const T*)Z, (T*)R, (T*)partial, E);
+  return hipGetLastError() == hipSuccess ? PPLIE_OK : PPLIE_ELAUNCH;
+}
+}  // namespace pplie
+
+extern "C" int pplie_pgo_linearize_f32(const void* nodes, const void* idx, const void* Z, void* R, void* J, int64_t E, void* stream) {
+  return pplie::pgo_linearize<float>(nodes, idx, Z, R, J, E, stream);
+}
+extern "C" int pplie_pgo_linearize_f64(const void* nodes, const void* idx, const void* Z, void* R, void* J, int64_t E, void* stream) {
+  return pplie::pgo_linearize<double>(nodes, idx, Z, R, J, E, stream);
+}
+extern "C" int pplie_pgo_residual_f32(const void* nodes, const void* idx, const void* Z, void* R, void* partial, int64_t E, void* stream) {
+  return pplie::pgo_residual_launch<float>(nodes, idx, Z, R, partial, E, stream);
+}
+extern "C" int pplie_pgo_residual_f64(const void* nodes, const void* idx, const void* Z, void* R, void* partial, int64_t E, void* stream) {
+  return pplie::pgo_residual_launch<double>(nodes, idx, Z, R, partial, E, stream);
+}

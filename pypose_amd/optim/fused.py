@@ -15,6 +15,10 @@ Programs:
 
 ``se3inv``   r = Log(P * X), P an SE3 ``pp.Parameter`` [n,7], X a constant SE3 batch -- the reference's
              README InvNet (README.md:120-129; BASELINE configs[2]), J = [Jl_inv(r) | 0].
+``pgo``      r = Log(Z^-1 * nodes[i]^-1 * nodes[j]) -- the reference's PoseGraph (examples/module/pgo/pgo.py:15-25;
+             BASELINE metric / configs[3]): residuals and both Jacobian blocks per edge from ONE kernel
+             (csrc/pgo_fused.hip) instead of six batched backward sweeps; everything downstream (correctors,
+             weights, assembly, PCG, sharding) is the ordinary pose-graph linearisation (optim/posegraph.py).
 """
 from __future__ import annotations
 
@@ -73,6 +77,7 @@ class Se3InvLinearization:
     """LM trial steps of ``r = Log(P X)`` in one kernel each (pplie_lm_se3inv_trial)."""
 
     kind = "fused:se3inv"
+    reference_kind = "block"
 
     def __init__(self, opt, P, X, r):
         self.opt, self.P = opt, P
@@ -150,25 +155,121 @@ class Se3InvLinearization:
         return opt.loss
 
 
+_PGO_SIG = [ctypes.c_void_p] * 5 + [ctypes.c_int64, ctypes.c_void_p]
+_PGO_PARTIALS = 1024      # PPLIE_PGO_PARTIALS
+
+
+def match_pgo(trace, gathers, R, params):
+    """(param, idx0, idx1, Z) if the traced forward is exactly  Log(Inv(Z) * Inv(param[idx0]) * param[idx1])."""
+    if len(trace.events) != 5 or len(gathers) != 2 or len(R) != 1 or len(params) != 1:
+        return None
+    P = params[0]
+    if getattr(P, "ltype", None) is not _lt.SE3_type or P.dim() != 2 or any(src is not P for src, _, _ in gathers):
+        return None
+    by_out = {o[0].data_ptr(): (n, i) for n, i, o in trace.events}
+    gat = {out.data_ptr(): ix for _, ix, out in gathers}
+    if len(by_out) != 5 or len(gat) != 2:
+        return None
+    log = [(n, i, o) for n, i, o in trace.events if n == "se3_log_fwd"]
+    if len(log) != 1 or not _same(log[0][2][0], R[0]):
+        return None
+    m2 = by_out.get(log[0][1][0].data_ptr())
+    if m2 is None or m2[0] != "se3_mul_fwd" or m2[1][1].data_ptr() not in gat:
+        return None
+    idx1 = gat[m2[1][1].data_ptr()]
+    m1 = by_out.get(m2[1][0].data_ptr())
+    if m1 is None or m1[0] != "se3_mul_fwd":
+        return None
+    ia, ib = by_out.get(m1[1][0].data_ptr()), by_out.get(m1[1][1].data_ptr())
+    if ia is None or ib is None or ia[0] != "se3_inv_fwd" or ib[0] != "se3_inv_fwd" or ib[1][0].data_ptr() not in gat:
+        return None
+    idx0, Z = gat[ib[1][0].data_ptr()], ia[1][0]
+    if ib[1][0].data_ptr() == m2[1][1].data_ptr() or Z.requires_grad or Z.data_ptr() in gat or Z.data_ptr() in by_out:
+        return None
+    E = R[0].numel() // 6
+    if idx0.numel() != E or idx1.numel() != E or Z.numel() != E * 7 or Z.dtype != P.dtype:
+        return None
+    return P, idx0.reshape(-1), idx1.reshape(-1), Z
+
+
+class PgoProgram:
+    """Fused evaluation of the recognised pose-graph residual program (csrc/pgo_fused.hip)."""
+
+    def __init__(self, P, idx0, idx1, Z):
+        self.P = P
+        self.idx = torch.stack([idx0, idx1], dim=-1).contiguous()
+        self.Z = Z.detach().reshape(-1, 7).contiguous()
+        self.E = self.idx.shape[0]
+
+    def linearize(self):
+        nodes = self.P.detach()
+        assert nodes.is_contiguous()
+        R = torch.empty((self.E, 6), dtype=nodes.dtype, device=nodes.device)
+        J = torch.empty((self.E, 2, 6, 6), dtype=nodes.dtype, device=nodes.device)
+        fn = _C.library().symbol("pplie_pgo_linearize" + _blocks._suffix(nodes), _PGO_SIG)
+        with torch.cuda.device(nodes.device):
+            code = fn(nodes.data_ptr(), self.idx.data_ptr(), self.Z.data_ptr(), R.data_ptr(), J.data_ptr(), self.E,
+                      _C.stream_ptr(nodes.device))
+        _C.check(code, "pplie_pgo_linearize")
+        return R, J
+
+    def loss(self, group=None):
+        """sum |r|^2 at the current parameter values (the Trivial-kernel loss of optimizer.py:118-125)."""
+        nodes = self.P.detach()
+        part = torch.zeros(_PGO_PARTIALS, dtype=nodes.dtype, device=nodes.device)
+        fn = _C.library().symbol("pplie_pgo_residual" + _blocks._suffix(nodes), _PGO_SIG)
+        with torch.cuda.device(nodes.device):
+            code = fn(nodes.data_ptr(), self.idx.data_ptr(), self.Z.data_ptr(), None, part.data_ptr(), self.E,
+                      _C.stream_ptr(nodes.device))
+        _C.check(code, "pplie_pgo_residual")
+        loss = part.sum()
+        if group is not None:
+            import torch.distributed as dist
+            dist.all_reduce(loss, group=group)
+        return loss
+
+
 def try_fused(opt, pg, input, target, weight, cache):
     """A fused linearisation if the model's forward is a recognised program, else None."""
     from .optimizer import Trivial
     from .solver import Cholesky
-    from .posegraph import PCG
+    from . import posegraph as _pg
     params = [p for p in pg['params'] if p.requires_grad]
     if cache.get("fused") is False or len(params) != 1 or _C._test_backend is not None:
         return None
     P = params[0]
-    if not (P.is_cuda and _blocks._suffix(P) and target is None and weight is None and len(opt.param_groups) == 1):
+    if not (P.is_cuda and _blocks._suffix(P) and target is None and len(opt.param_groups) == 1):
         return None
-    if not all(isinstance(c, Trivial) for c in opt.corrector) or not all(isinstance(k, Trivial) for k in opt.model.kernel):
-        return None
-    if not ((isinstance(opt.solver, Cholesky) and not opt.solver.upper) or isinstance(opt.solver, PCG)):
-        return None
-    with torch.no_grad(), OpTracer() as tr:
+    trivial = all(isinstance(c, Trivial) for c in opt.corrector) and all(isinstance(k, Trivial) for k in opt.model.kernel)
+    with torch.no_grad(), OpTracer() as tr, _pg.GatherRecorder(params) as rec:
         R = list(opt.model(input, target))
-    m = match_se3inv(tr, R, params)
-    if m is None:
-        cache["fused"] = False
-        return None
-    return Se3InvLinearization(opt, *m)
+    m = match_se3inv(tr, R, params) if not rec.events else None
+    if m is not None and weight is None and trivial and \
+            ((isinstance(opt.solver, Cholesky) and not opt.solver.upper) or isinstance(opt.solver, _pg.PCG)):
+        return Se3InvLinearization(opt, *m)
+    m = match_pgo(tr, rec.events, R, params)
+    if m is not None and len(opt.corrector) == 1:
+        prog = PgoProgram(*m)
+        r, J = prog.linearize()
+        lin = _pg.build_graph_linearization(opt, weight, r, J, prog.idx, P, 7, 6)
+        lin.kind = "fused:pgo"
+        def verify(ref, dmin, dmax, rtol=1e-3):
+            """residuals and blocks against the autograd-derived pose-graph linearisation (whose edge ends are in
+            gather order, ours in (inverted node, other node) order)"""
+            if ref.J.shape != lin.J.shape:
+                return False
+            if torch.equal(ref.idx, lin.idx):
+                Jr = ref.J
+            elif torch.equal(ref.idx, lin.idx.flip(-1)):
+                Jr = ref.J.flip(1)
+            else:
+                return False
+            return bool((ref.R - lin.R).abs().max() <= rtol * ref.R.abs().max().clamp_min(1e-30)) \
+                and bool((Jr - lin.J).abs().max() <= rtol * Jr.abs().max().clamp_min(1e-30))
+        lin.verify = verify
+        lin.reference_kind = "graph"
+        if trivial:
+            lin.fast_loss = lambda: prog.loss(opt.group)
+        return lin
+    cache["fused"] = False
+    return None

@@ -223,7 +223,7 @@ def _linearize(opt, pg, input, target, weight):
                 if cache.get("fused") is None:       # first use: cross-check against the generic block path
                     cache["fused"] = False
                     ref = _linearize(opt, pg, input, target, weight)
-                    cache["fused"] = ref.kind == "block" and lin.verify(ref, pg['min'], pg['max'])
+                    cache["fused"] = ref.kind == lin.reference_kind and lin.verify(ref, pg['min'], pg['max'])
                 if cache["fused"]:
                     return lin
         with torch.enable_grad():
@@ -369,7 +369,7 @@ class LevenbergMarquardt(_Optimizer):
                     print(e, "\nLinear solver failed. Breaking optimization step...")
                     break
                 self.update_parameter(pg['params'], D)
-                self.loss = self._loss(input, target)
+                self.loss = lin.fast_loss() if hasattr(lin, 'fast_loss') else self._loss(input, target)
                 self._strategy_update(pg, J, D, R)
                 if self.last < self.loss and self.reject_count < self.reject:     # reject the step
                     self.update_parameter(params=pg['params'], step=-D)

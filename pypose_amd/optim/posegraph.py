@@ -63,8 +63,8 @@ class GatherRecorder:
         # gathers on a tracked parameter, or on a tensor derived from one (e.g. ``cat((root, nodes))`` in
         # the reference's chain example, tests/optim/test_sparse_lm.py:26-36)
         if isinstance(index, torch.Tensor) and index.dtype == torch.int64 and index.dim() >= 1 \
-                and isinstance(out, torch.Tensor) and out.requires_grad and isinstance(source, torch.Tensor) \
-                and source.dim() == 2:
+                and isinstance(out, torch.Tensor) and (out.requires_grad or id(source) in self.ids) \
+                and isinstance(source, torch.Tensor) and source.dim() == 2:
             self.events.append((source, index, out))
 
 
@@ -473,9 +473,14 @@ def try_graph_linearization(opt, pg, input, target, weight, R, params, rec, cach
     # tangent width: gradients of LieTensor group parameters are zero-padded to the embedding
     m = int(param.ltype.manifold[0]) if isinstance(param, _lt.LieTensor) and not param.ltype.on_manifold else wfull
     J = Jcat.reshape(E, dr, K, wfull)[..., :m].permute(0, 2, 1, 3)    # [E, K, dr, m]
-    idx = torch.stack(node_idx, dim=-1)
+    return build_graph_linearization(opt, weight, r.detach().reshape(E, dr), J, torch.stack(node_idx, dim=-1), param, wfull, m)
+
+
+def build_graph_linearization(opt, weight, r, J, idx, param, wfull, m):
+    """Corrector and weights applied to per-edge residuals r [E,dr] and blocks J [E,K,dr,m] -> GraphLinearization."""
+    E, K, dr, _ = J.shape
     c = opt.corrector[0]                                              # row-local: acts on [E, dr, K*m]
-    Rc, Jc = c(R=r.detach().reshape(E, dr), J=J.permute(0, 2, 1, 3).reshape(E, dr, K * m))
+    Rc, Jc = c(R=r, J=J.permute(0, 2, 1, 3).reshape(E, dr, K * m))
     Jc = Jc.reshape(E, dr, K, m).permute(0, 2, 1, 3)
     Wb = None
     if weight is not None:
