@@ -67,7 +67,7 @@ def cpu_baseline(budget_s: float = 12.0):
                       f"{cores} processes x {chunk}-row chunks, {wall:.1f} s wall)"}
 
 
-def pgo_lm_rate(dev, nodes=10_000, edges=40_000, steps=6):
+def pgo_lm_rate(dev, nodes=10_000, edges=40_000, steps=3, reps=5):
     """Second half of BASELINE.json's metric: LM iterations/s on a synthetic pose graph
     (SURVEY.md section 8d C4 generator: chain + random loop closures, sigma 0.01 edge noise, sigma 0.05
     initial error; the reference's own PoseGraph model, examples/module/pgo/pgo.py:15-25; PCG tol 1e-4 /
@@ -92,18 +92,72 @@ def pgo_lm_rate(dev, nodes=10_000, edges=40_000, steps=6):
     extra[:, 1] = torch.where(extra[:, 0] == extra[:, 1], (extra[:, 1] + 1) % nodes, extra[:, 1])
     e = torch.cat([chain, extra], 0).to(dev)
     rel = gt[e[:, 0]].Inv() @ gt[e[:, 1]] @ pp.randn_SE3(edges, sigma=0.01, device=dev)
-    graph = PoseGraph(gt @ pp.randn_SE3(nodes, sigma=0.05, device=dev))
+    init = gt @ pp.randn_SE3(nodes, sigma=0.05, device=dev)
+    graph = PoseGraph(init.clone())
     solver = pp.optim.solver.PCG(tol=1e-4, maxiter=250)
     opt = pp.optim.LM(graph, solver=solver, strategy=pp.optim.strategy.TrustRegion(radius=1e4))
     l0 = float(graph(e, rel).detach().square().sum())
-    opt.step((e, rel))                                   # structure probe + graph capture, untimed
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    losses = [float(opt.step((e, rel))) for _ in range(steps)]
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / steps
+    # every repetition restarts from the same initial estimate and takes the `steps` LM steps that do the
+    # actual descent (this problem reaches its noise floor in 3-4); repetition 0 (structure probe, kernel
+    # verification, hipGraph capture) is untimed; the rate is the median repetition
+    times, losses, its = [], [], []
+    for rep in range(reps + 1):
+        graph.nodes.data.copy_(init.tensor())
+        if hasattr(opt, "loss"):
+            del opt.loss
+        opt.param_groups[0].update(opt.strategy.defaults)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        losses, its = [], []
+        for _ in range(steps):
+            losses.append(opt.step((e, rel)))
+            its.append(solver.iterations)
+        torch.cuda.synchronize()
+        if rep:
+            times.append((time.perf_counter() - t0) / steps)
+    dt = sorted(times)[len(times) // 2]
     return {"metric": "LM iters/sec (PGO 10k poses)", "value": 1.0 / dt, "unit": "LM steps/s", "nodes": nodes, "edges": edges,
-            "path": opt.linearization, "initial_loss": l0, "final_loss": losses[-1], "pcg_iterations_last": solver.iterations}
+            "path": opt.linearization, "initial_loss": l0, "losses": [float(l) for l in losses], "pcg_iterations": its,
+            "steps_per_repetition": steps, "repetitions_ms_per_step": [round(t * 1e3, 3) for t in times]}
+
+
+def invnet_lm_rate(dev, B=1_000_000, steps=3, reps=5):
+    """BASELINE configs[2]: LM on the reference's README InvNet, B independent SE3 problems, fp32
+    (SURVEY.md section 8d C3).  Each repetition restarts from the same random initial poses and takes `steps`
+    LM steps (the problem converges in 2-3); LM steps/s over the best repetition.  Not part of `value`."""
+    import torch
+    import pypose_amd as pp
+
+    class InvNet(torch.nn.Module):
+        def __init__(self, init):
+            super().__init__()
+            self.pose = pp.Parameter(init)
+
+        def forward(self, input):
+            return (self.pose @ input).Log().tensor()
+
+    torch.manual_seed(0)
+    init = pp.randn_SE3(B, device=dev)
+    inp = pp.randn_SE3(B, device=dev)
+    net = InvNet(init.clone())
+    opt = pp.optim.LM(net, strategy=pp.optim.strategy.Constant(damping=1e-4))
+    l0 = float(net(inp).detach().square().sum())
+    best, loss = float("inf"), None
+    for rep in range(reps + 1):                               # repetition 0 = structure probe / verification, untimed
+        net.pose.data.copy_(init.tensor())
+        if hasattr(opt, "loss"):
+            del opt.loss
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = opt.step(inp)
+        torch.cuda.synchronize()
+        if rep:
+            best = min(best, (time.perf_counter() - t0) / steps)
+    return {"metric": "LM iters/sec (InvNet SE3, 1M independent problems)", "value": 1.0 / best, "unit": "LM steps/s",
+            "problems": B, "problem_steps_per_s": B / best, "path": opt.linearization, "initial_loss": l0,
+            "final_loss": float(loss), "algorithmic_bytes_per_problem_step": 84,
+            "hbm_fraction_of_8TBps": 84.0 * B / best / 8e12}
 
 
 def main():
@@ -194,10 +248,14 @@ def main():
                          "avg_launch_ms": ms_dom, "other_kernel_ms": {"se3_exp_fwd": ms_exp, "se3_log_fwd": ms_log}},
         }
         if world == 1:
-            try:
-                out["lm_pgo"] = pgo_lm_rate(dev)
-            except Exception as e:        # never lose the headline line over the secondary figure
-                out["lm_pgo"] = {"error": repr(e)}
+            import gc
+            gc.collect()
+            gc.freeze()                   # (a gen-2 collection with torch loaded is a 40-70 ms pause)
+            for key, fn in (("lm_pgo", pgo_lm_rate), ("lm_invnet", invnet_lm_rate)):
+                try:
+                    out[key] = fn(dev)
+                except Exception as e:    # never lose the headline line over a secondary figure
+                    out[key] = {"error": repr(e)}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

@@ -7,7 +7,7 @@ import pypose_amd as pp
 from tests.optim_models import PoseGraph
 from tests.test_optim_gpu import _synthetic_graph
 cases = [(int(sys.argv[1]), int(sys.argv[2]))] if len(sys.argv) > 2 else [(10_000, 40_000), (100_000, 400_000)]
-steps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
+steps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 for N, E in cases:
     edges, rel, init = _synthetic_graph(N, E, torch.float32)
     for fused in (True, False):
