@@ -131,3 +131,34 @@ def row_op(name: str, ins, out_widths):
         code = fn(*pi, *po, ctypes.c_int64(n), stream_ptr(x0.device))
     check(code, "pplie_" + name + suffix)
     return outs
+
+
+def param_op(name: str, ins, out_width: int, prm: float):
+    """Row ops with one launch-wide scalar parameter (``pplie_mat2so3_*``, ``pplie_so3_euler_*``):
+    ``fn(in0[, in1], out, prm, n, stream)``.  Same staging / error rules as :func:`row_op`."""
+    if _test_backend is not None:
+        return _test_backend(name, ins, (out_width,), prm)[0]
+    x0 = ins[0]
+    if not x0.is_cuda:
+        if not torch.cuda.is_available():
+            raise RuntimeError(
+                f"pypose_amd: op {name} needs a HIP device (got {x0.device} tensors and no GPU is visible); "
+                f"there is no CPU compute path.")
+        dev = torch.device("cuda", torch.cuda.current_device())
+        return param_op(name, [t.to(dev) for t in ins], out_width, prm).to(x0.device)
+    suffix = _SUFFIX.get(x0.dtype)
+    if suffix is None:
+        raise TypeError(f"pypose_amd: op {name} supports float32/float64, got {x0.dtype}")
+    n = x0.shape[0]
+    for t in ins:
+        if t.dtype != x0.dtype or t.device != x0.device or t.shape[0] != n or t.dim() != 2 or not t.is_contiguous():
+            raise ValueError(f"pypose_amd: op {name}: inputs must be contiguous [N,W], same N/dtype/device")
+    out = torch.empty((n, out_width), dtype=x0.dtype, device=x0.device)
+    if n == 0:
+        return out
+    sig = [ctypes.c_void_p] * (len(ins) + 1) + [ctypes.c_double, ctypes.c_int64, ctypes.c_void_p]
+    fn = _lib.symbol("pplie_" + name + suffix, sig)
+    with torch.cuda.device(x0.device):
+        code = fn(*[_ptr(t) for t in ins], _ptr(out), float(prm), n, stream_ptr(x0.device))
+    check(code, "pplie_" + name + suffix)
+    return out

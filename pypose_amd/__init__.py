@@ -16,7 +16,9 @@ from .lietensor import SO3_type, so3_type, SE3_type, se3_type
 from .lietensor import Sim3_type, sim3_type, RxSO3_type, rxso3_type
 from .lietensor import tensor, translation, rotation, scale, matrix, euler, vec2skew
 from .lietensor.lietensor import retain_ltype
+from .lietensor import mat2SO3, mat2SE3, mat2Sim3, mat2RxSO3, from_matrix, euler2SO3, quat2unit
 from .basics import pm, cumops, cummul, cumprod, cumops_, cummul_, cumprod_
 from . import autograd
 from . import optim
 from . import module
+from . import io

@@ -59,6 +59,10 @@ PP_HD float pp_expm1(float x) { return ::expm1f(x); }
 PP_HD double pp_expm1(double x) { return ::expm1(x); }
 PP_HD float pp_log(float x) { return ::logf(x); }
 PP_HD double pp_log(double x) { return ::log(x); }
+PP_HD float pp_atan2(float y, float x) { return ::atan2f(y, x); }
+PP_HD double pp_atan2(double y, double x) { return ::atan2(y, x); }
+PP_HD float pp_asin(float x) { return ::asinf(x); }
+PP_HD double pp_asin(double x) { return ::asin(x); }
 PP_HD float pp_abs(float x) { return ::fabsf(x); }
 PP_HD double pp_abs(double x) { return ::fabs(x); }
 PP_HD float pp_val(float x) { return x; }
@@ -143,6 +147,10 @@ template <class T> PP_HD Dual<T> pp_exp(Dual<T> a) { T e = pp_exp(a.v); return D
 template <class T> PP_HD Dual<T> pp_expm1(Dual<T> a) { T e = pp_expm1(a.v); return Dual<T>(e, (e + T(1)) * a.d); }
 template <class T> PP_HD Dual<T> pp_log(Dual<T> a) { return Dual<T>(pp_log(a.v), a.d / a.v); }
 template <class T> PP_HD Dual<T> pp_abs(Dual<T> a) { return a.v < T(0) ? -a : a; }
+template <class T> PP_HD Dual<T> pp_atan2(Dual<T> y, Dual<T> x) {
+  return Dual<T>(pp_atan2(y.v, x.v), (x.v * y.d - y.v * x.d) / (x.v * x.v + y.v * y.v));
+}
+template <class T> PP_HD Dual<T> pp_asin(Dual<T> a) { return Dual<T>(pp_asin(a.v), a.d / pp_sqrt(T(1) - a.v * a.v)); }
 
 // torch.nan_to_num default semantics: nan -> 0, +inf -> max, -inf -> lowest
 template <class S> PP_HD S pp_nan_to_num(S x) {

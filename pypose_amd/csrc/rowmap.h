@@ -121,10 +121,16 @@ template <int W> struct AtLeast1 { enum { v = W > 0 ? W : 1 }; };
 
 // Op concept: enum {IW0,IW1,IW2,OW0,OW1} (0 = unused) and
 //   static __device__ void apply(const T* a, const T* b, const T* c, T* o, T* p)
-template <class T, class Op, int RPT, int BLOCK, bool VEC, bool ROLL = false>
+// or, for ops with a launch-wide scalar parameter (Prm != NoParam),
+//   static __device__ void apply(const T* a, const T* b, const T* c, T* o, T* p, Prm prm)
+struct NoParam {};
+template <class A, class B> struct SameType { static constexpr bool v = false; };
+template <class A> struct SameType<A, A> { static constexpr bool v = true; };
+
+template <class T, class Op, int RPT, int BLOCK, bool VEC, bool ROLL = false, class Prm = NoParam>
 __global__ void __launch_bounds__(BLOCK)
 rowmap_lds_kernel(const T* __restrict__ i0, const T* __restrict__ i1, const T* __restrict__ i2,
-                  T* __restrict__ o0, T* __restrict__ o1, int64_t n) {
+                  T* __restrict__ o0, T* __restrict__ o1, int64_t n, Prm prm = Prm()) {
   constexpr int TILE = RPT * BLOCK;
   constexpr int IW0 = Op::IW0, IW1 = Op::IW1, IW2 = Op::IW2, OW0 = Op::OW0, OW1 = Op::OW1;
   constexpr int OFF_I1 = TILE * IW0, OFF_I2 = OFF_I1 + TILE * IW1, OFF_O0 = OFF_I2 + TILE * IW2,
@@ -155,7 +161,8 @@ rowmap_lds_kernel(const T* __restrict__ i0, const T* __restrict__ i1, const T* _
         row_ld<IW0>(s_i0 + row * IW0, a);
         if constexpr (IW1 > 0) row_ld<IW1>(s_i1 + row * IW1, b);
         if constexpr (IW2 > 0) row_ld<IW2>(s_i2 + row * IW2, c);
-        Op::apply(a, b, c, p, q);
+        if constexpr (SameType<Prm, NoParam>::v) Op::apply(a, b, c, p, q);
+        else Op::apply(a, b, c, p, q, prm);
         row_st<OW0>(s_o0 + row * OW0, p);
         if constexpr (OW1 > 0) row_st<OW1>(s_o1 + row * OW1, q);
       }
@@ -212,9 +219,9 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 // the grid-stride loop only engages beyond 2^30 tiles.
 constexpr int kGridCap = 1 << 30;
 
-template <class T, class Op, int RPT = 2, int BLOCK = 256, bool ROLL = false>
+template <class T, class Op, int RPT = 2, int BLOCK = 256, bool ROLL = false, class Prm = NoParam>
 int launch_rowmap(const void* i0, const void* i1, const void* i2, void* o0, void* o1, int64_t n, void* stream,
-                  int grid_cap = kGridCap) {
+                  int grid_cap = kGridCap, Prm prm = Prm()) {
   if (n < 0) return PPLIE_EBADARG;
   if (n == 0) return PPLIE_OK;
   if (!i0 || !o0 || (Op::IW1 > 0 && !i1) || (Op::IW2 > 0 && !i2) || (Op::OW1 > 0 && !o1)) return PPLIE_EBADARG;
@@ -230,9 +237,9 @@ int launch_rowmap(const void* i0, const void* i1, const void* i2, void* o0, void
   T* p = static_cast<T*>(o0);
   T* q = static_cast<T*>(o1);
   if (vec)
-    hipLaunchKernelGGL((rowmap_lds_kernel<T, Op, RPT, BLOCK, true, ROLL>), dim3(grid), dim3(BLOCK), 0, st, a, b, c, p, q, n);
+    hipLaunchKernelGGL((rowmap_lds_kernel<T, Op, RPT, BLOCK, true, ROLL, Prm>), dim3(grid), dim3(BLOCK), 0, st, a, b, c, p, q, n, prm);
   else
-    hipLaunchKernelGGL((rowmap_lds_kernel<T, Op, RPT, BLOCK, false, ROLL>), dim3(grid), dim3(BLOCK), 0, st, a, b, c, p, q, n);
+    hipLaunchKernelGGL((rowmap_lds_kernel<T, Op, RPT, BLOCK, false, ROLL, Prm>), dim3(grid), dim3(BLOCK), 0, st, a, b, c, p, q, n, prm);
   return hipGetLastError() == hipSuccess ? PPLIE_OK : PPLIE_ELAUNCH;
 }
 

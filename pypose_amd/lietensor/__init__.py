@@ -6,3 +6,4 @@ from .utils import (randn_like, randn_SE3, randn_SO3, randn_so3, randn_se3, rand
                     Exp, Log, Inv, Mul, Retr, Act, Adj, AdjT, Jinvp, Jr, tensor, translation, rotation, scale, matrix,
                     euler)
 from .basics import vec2skew, add, add_, mul
+from .convert import mat2SO3, mat2SE3, mat2Sim3, mat2RxSO3, from_matrix, euler2SO3, quat2unit

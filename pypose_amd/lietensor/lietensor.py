@@ -467,17 +467,9 @@ class LieTensor(Tensor):
         return self.ltype.scale(self)
 
     def euler(self, eps=2e-4):
-        """roll/pitch/yaw of the rotation part (reference lietensor.py:1147-1173)."""
-        from ..basics import pm
-        q = self.rotation().tensor()
-        x, y, z, w = q[..., 0], q[..., 1], q[..., 2], q[..., 3]
-        xx, yy, zz, ww = x * x, y * y, z * z, w * w
-        t2 = 2 * (w * y - z * x) / (xx + yy + zz + ww)
-        regular = t2.abs() < 1. - eps
-        roll = torch.where(regular, torch.atan2(2 * (w * x + y * z), (ww + zz) - (xx + yy)), torch.zeros_like(t2))
-        yaw = torch.where(regular, torch.atan2(2 * (w * z + x * y), (ww + xx) - (yy + zz)),
-                          -2 * pm(t2) * torch.atan2(x, w))
-        return torch.stack([roll, torch.asin(t2.clamp(-1, 1)), yaw], dim=-1)
+        """roll/pitch/yaw of the rotation part (reference lietensor.py:1147-1173; kernel pplie_so3_euler)."""
+        from .convert import so3_euler
+        return so3_euler(self.rotation().tensor(), eps)
 
     def identity_(self):
         return self.ltype.identity_(self)

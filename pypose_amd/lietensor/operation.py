@@ -55,8 +55,9 @@ def _legacy_level(t):
 _op_tracers = []
 
 
-def _launch(name, ins, in_widths, out_widths):
-    """Broadcast leading dims, flatten to rows, launch, un-flatten."""
+def _launch(name, ins, in_widths, out_widths, prm=None):
+    """Broadcast leading dims, flatten to rows, launch, un-flatten (``prm``: launch-wide scalar of the
+    conversion kernels, csrc/convert.hip)."""
     if any(_is_legacy_batched(t) for t in ins):
         # torch.autograd.grad(is_grads_batched=True) -- what jacobian(vectorize=True) uses -- runs
         # the backward under the *legacy* vmap, which does not consult Function.vmap: peel the
@@ -65,7 +66,7 @@ def _launch(name, ins, in_widths, out_widths):
         phys = [torch._remove_batch_dim(t, lvl, 1, 0) if _is_legacy_batched(t) else None for t in ins]
         bsz = next(p.shape[0] for p in phys if p is not None)
         phys = [p if p is not None else t.unsqueeze(0).expand((bsz,) + tuple(t.shape)) for p, t in zip(phys, ins)]
-        outs = _launch(name, phys, in_widths, out_widths)
+        outs = _launch(name, phys, in_widths, out_widths, prm)
         return tuple(torch._add_batch_dim(o, 0, lvl) for o in outs)
     lead = ins[0].shape[:-1]
     if any(t.shape[:-1] != lead for t in ins[1:]):
@@ -75,7 +76,7 @@ def _launch(name, ins, in_widths, out_widths):
         if t.shape[:-1] != lead:
             t = t.expand(lead + (t.shape[-1],))
         flat.append(_rows(t, w))
-    outs = _C.row_op(name, flat, out_widths)
+    outs = _C.row_op(name, flat, out_widths) if prm is None else (_C.param_op(name, flat, out_widths[0], prm),)
     outs = tuple(o.view(lead + (w,)) for o, w in zip(outs, out_widths))
     for tr in _op_tracers:
         tr.note(name, ins, outs)

@@ -14,7 +14,14 @@ from oracle import lie_np
 from pypose_amd import _C
 
 
-def oracle_row_op(name, ins, out_widths):
+def oracle_row_op(name, ins, out_widths, prm=None):
+    from oracle import convert_np
+    if name in convert_np.OPS:
+        arrs = [t.detach().cpu().numpy() for t in ins]
+        if arrs[0].shape[0] == 0:
+            return tuple(torch.empty((0, w), dtype=ins[0].dtype) for w in out_widths)
+        outs = convert_np.OPS[name](*arrs) if prm is None else convert_np.OPS[name](*arrs, prm)
+        return tuple(torch.from_numpy(np.ascontiguousarray(o)).to(ins[0].dtype) for o in outs)
     if name.startswith("block_"):
         from oracle import optim_np
         outs = getattr(optim_np, name)(*[t.detach().cpu().numpy() for t in ins])
