@@ -22,3 +22,5 @@ from . import autograd
 from . import optim
 from . import module
 from . import io
+from . import function
+from .function import cart2homo, homo2cart, point2pixel, pixel2point, reprojerr

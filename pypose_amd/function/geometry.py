@@ -1,0 +1,68 @@
+"""Camera geometry either side of the bundle-adjustment path.
+
+Host-side mirror of the five pinhole helpers of pypose/function/geometry.py (cart2homo :8, homo2cart :37,
+point2pixel :60, pixel2point :115, reprojerr :171): same names, argument meaning, broadcasting and assertion
+messages.  The rigid transform inside ``point2pixel`` is the HIP ``SE3_Act`` kernel (autograd included); the
+pinhole algebra around it is plain tensor arithmetic on whatever device the inputs live on.
+"""
+import torch
+
+from ..lietensor import LieTensor
+
+
+def _need(cond, msg):
+    assert cond, msg
+
+
+def _is_k(intrinsics):
+    return intrinsics.shape[-2:] == (3, 3)
+
+
+def cart2homo(coordinates):
+    """``(*, D) -> (*, D + 1)``: append a one."""
+    return torch.cat([coordinates, coordinates.new_ones(coordinates.shape[:-1] + (1,))], dim=-1)
+
+
+def homo2cart(coordinates):
+    """``(*, D + 1) -> (*, D)``: divide by the last component; a zero (of either sign) is replaced by the
+    smallest normal number with the sign convention ``pm(0) = +1`` of the reference."""
+    w = coordinates[..., -1:]
+    tiny = torch.finfo(coordinates.dtype).tiny
+    sign = torch.where(w < 0, -torch.ones_like(w), torch.ones_like(w))
+    return coordinates[..., :-1] / (sign * w.abs().clamp(min=tiny))
+
+
+def point2pixel(points, intrinsics, extrinsics=None):
+    """Pixels ``(*, N, 2)`` of ``points (*, N, 3)`` seen through ``intrinsics (*, 3, 3)``; with ``extrinsics``
+    (SE3 ``(*, 7)``, world -> camera) the points are transformed first."""
+    _need(points.size(-1) == 3, "Points shape incorrect")
+    _need(_is_k(intrinsics), "Intrinsics shape incorrect.")
+    lead = [points.shape[:-2], intrinsics.shape[:-2]]
+    if extrinsics is not None:
+        _need(isinstance(extrinsics, LieTensor) and extrinsics.shape[-1] == 7, "Type incorrect.")
+        lead.append(extrinsics.shape[:-1])
+    torch.broadcast_shapes(*lead)                                      # raises on incompatible batch dims
+    cam = points if extrinsics is None else extrinsics.unsqueeze(-2).Act(points)
+    return homo2cart(cam @ intrinsics.mT)
+
+
+def pixel2point(pixels, depth, intrinsics):
+    """Camera-frame points ``(*, N, 3)`` of ``pixels (*, N, 2)`` at ``depth (*, N)``."""
+    _need(pixels.size(-1) == 2, "Pixels shape incorrect")
+    _need(depth.size(-1) == pixels.size(-2), "Depth shape does not match pixels")
+    _need(_is_k(intrinsics), "Intrinsics shape incorrect.")
+    focal = torch.stack([intrinsics[..., 0, 0], intrinsics[..., 1, 1]], dim=-1)
+    centre = torch.stack([intrinsics[..., 0, 2], intrinsics[..., 1, 2]], dim=-1)
+    _need(not torch.any(focal[..., 0] == 0), "fx Cannot contain zero")
+    _need(not torch.any(focal[..., 1] == 0), "fy Cannot contain zero")
+    xy = (pixels - centre.unsqueeze(-2)) * depth.unsqueeze(-1) / focal.unsqueeze(-2)
+    return torch.cat([xy, depth.unsqueeze(-1)], dim=-1)
+
+
+def reprojerr(points, pixels, intrinsics, extrinsics=None, reduction='none'):
+    """Projected minus observed pixels: ``'none'`` -> ``(*, N, 2)``; ``'norm'`` / ``'sum'`` reduce the last dim."""
+    torch.broadcast_shapes(points.shape[:-2], pixels.shape[:-2], intrinsics.shape[:-2])
+    _need(points.size(-1) == 3 and pixels.size(-1) == 2 and _is_k(intrinsics), "Shape not compatible.")
+    _need(reduction in {'norm', 'sum', 'none'}, "Reduction method can only be 'norm'|'sum'|'none'.")
+    err = point2pixel(points, intrinsics, extrinsics) - pixels
+    return {'none': lambda e: e, 'norm': lambda e: e.norm(dim=-1), 'sum': lambda e: e.sum(dim=-1)}[reduction](err)

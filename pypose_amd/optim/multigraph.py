@@ -1,0 +1,238 @@
+"""Gather-structured linearisation over SEVERAL parameters of different widths (bundle adjustment).
+
+The reference's BA model (examples/module/ba/bundle_adjustment.py:16-43) optimises intrinsics ``K [Nc,3]``, camera
+poses ``C [Nc,7]`` (SE3) and points ``P [Np,3]``; residual row ``e`` (one observation) reads ``K[cidx[e]]``,
+``C[cidx[e]]`` and ``P[pidx[e]]``.  Its dense LM path needs a ``[2E, 3Nc + 7Nc + 3Np]`` Jacobian; its scalable
+path is the un-vendored ``bae`` plugin.  Here the SAME unmodified model is linearised per observation:
+
+* every ``param[index]`` gather on an optimised parameter is a *slot* ``(parameter, index [E], block width)``;
+  the per-observation blocks ``J_s [E, d_res, m_s]`` come from ``d_res`` batched backward sweeps w.r.t. the gathered
+  rows (blocks.jacobian_blocks) and a random vector-Jacobian probe against the real model verifies the structure;
+* the normal equations are never formed: block diagonals + gradient by scatter-add, ``H p`` matrix-free, block-Jacobi
+  PCG on the concatenated unknowns (small problems are assembled densely for the user's ``solver``: bit-for-bit
+  the reference's algebra, used by the parity tests).
+
+This is the device-agnostic formulation (gathers, broadcast-multiply-sums and ``index_add_`` on whatever device
+the model lives on; the Lie arithmetic inside the model is the HIP kernels).  Single-parameter SE3 / Sim3 / SO3
+graphs take the HIP kernels of optim/posegraph.py instead.
+"""
+from __future__ import annotations
+
+import warnings
+
+import torch
+
+from ..lietensor import lietensor as _lt
+from . import blocks as _blocks
+from .posegraph import DENSE_LIMIT, PCG, _all_reduce
+
+
+def _tangent_width(p):
+    return int(p.ltype.manifold[0]) if isinstance(p, _lt.LieTensor) and not p.ltype.on_manifold else p.shape[-1]
+
+
+class MultiGraphOperator:
+    """``J`` handed to ``strategy.update``: ``J @ D`` with D the flat step in optimizer parameter order."""
+
+    def __init__(self, lin):
+        self.lin = lin
+
+    def __matmul__(self, D):
+        return self.lin._J_times(self.lin.step_to_nodes(D)).reshape(-1, 1)
+
+
+class MultiGraphLinearization:
+    kind = "multigraph"
+
+    def __init__(self, opt, W, R, params, slots):
+        """R [E,dr] (corrected), W [E,dr,dr] | None, params: the optimised parameters in optimizer order,
+        slots: list of (parameter position, idx [E] int64, J [E,dr,m])."""
+        self.opt, self.params, self.slots = opt, list(params), slots
+        self.R, self.W = R.contiguous(), W
+        self.E, self.dr = R.shape
+        self.m = [_tangent_width(p) for p in self.params]
+        self.N = [p.shape[0] for p in self.params]
+        self.group = getattr(opt, 'group', None)
+        self.s = 1.0
+
+    # -- layouts ------------------------------------------------------------------------------------
+    def step_to_nodes(self, D):
+        """flat [sum N_p w_p, 1] -> per-parameter tangent rows [N_p, m_p]"""
+        out, off = [], 0
+        flat = D.reshape(-1)
+        for p, m in zip(self.params, self.m):
+            n = p.numel()
+            out.append(flat[off:off + n].view(p.shape[0], p.shape[-1])[:, :m])
+            off += n
+        return out
+
+    def nodes_to_step(self, Dn):
+        cols = []
+        for p, m, d in zip(self.params, self.m, Dn):
+            w = p.shape[-1]
+            if m < w:
+                d = torch.cat([d, torch.zeros((d.shape[0], w - m), dtype=d.dtype, device=d.device)], -1)
+            cols.append(d.reshape(-1))
+        return torch.cat(cols).view(-1, 1)
+
+    def _split(self, x):
+        out, off = [], 0
+        for n, m in zip(self.N, self.m):
+            out.append(x[off:off + n * m].view(n, m))
+            off += n * m
+        return out
+
+    @staticmethod
+    def _cat(xs):
+        return torch.cat([x.reshape(-1) for x in xs])
+
+    # -- products -----------------------------------------------------------------------------------
+    def _WJ(self, J):
+        return J if self.W is None else (self.W.unsqueeze(-1) * J.unsqueeze(-3)).sum(-2)     # [E,dr,dr] x [E,dr,m]
+
+    def _J_times(self, nodes):
+        q = torch.zeros((self.E, self.dr), dtype=self.R.dtype, device=self.R.device)
+        for pi, idx, J in self.slots:
+            q += (J * nodes[pi][idx].unsqueeze(-2)).sum(-1)           # (tiny batched GEMMs are slow: multiply-sum)
+        return q
+
+    def _Hp(self, nodes):
+        q = self._J_times(nodes)
+        if self.W is not None:
+            q = (self.W * q.unsqueeze(-2)).sum(-1)
+        ys = [torch.zeros_like(n) for n in nodes]
+        for pi, idx, J in self.slots:
+            ys[pi].index_add_(0, idx, (J * q.unsqueeze(-1)).sum(-2))
+        return [_all_reduce(y, self.group) for y in ys]
+
+    def _assemble(self):
+        dt, dev = self.R.dtype, self.R.device
+        B = [torch.zeros((n, m, m), dtype=dt, device=dev) for n, m in zip(self.N, self.m)]
+        g = [torch.zeros((n, m), dtype=dt, device=dev) for n, m in zip(self.N, self.m)]
+        Wr = self.R if self.W is None else (self.W * self.R.unsqueeze(-2)).sum(-1)
+        for pi, idx, J in self.slots:
+            WJ = self._WJ(J)
+            B[pi].index_add_(0, idx, (J.unsqueeze(-1) * WJ.unsqueeze(-2)).sum(-3))           # J^T W J  [E,m,m]
+            g[pi].index_add_(0, idx, (J * Wr.unsqueeze(-1)).sum(-2))
+        # two slots of the SAME parameter meeting in the same row (a self loop) put their cross term on the
+        # diagonal block as well
+        for a, (pa, ia, Ja) in enumerate(self.slots):
+            for pb, ib, Jb in self.slots[a + 1:]:
+                if pa == pb:
+                    same = ia == ib
+                    if bool(same.any()):
+                        blk = (Ja[same].unsqueeze(-1) * self._WJ(Jb)[same].unsqueeze(-2)).sum(-3)
+                        B[pa].index_add_(0, ia[same], blk + blk.mT)
+        return [_all_reduce(b, self.group) for b in B], [_all_reduce(x, self.group) for x in g]
+
+    # -- LM interface ---------------------------------------------------------------------------------
+    def build_normal_equations(self, dmin, dmax):
+        self.B, self.g = self._assemble()
+        self.diag_raw = [b.diagonal(dim1=-2, dim2=-1).clone() for b in self.B]
+        self.diag_clamped = [d.clamp(dmin, dmax) for d in self.diag_raw]
+        self.s = 1.0
+
+    def damp(self, damping):
+        self.s = self.s * (1.0 + damping)
+
+    def dense_matrix(self):
+        """H = J^T W J as a dense matrix over the concatenated tangent unknowns (small problems / parity)."""
+        offs, tot = [], 0
+        for n, m in zip(self.N, self.m):
+            offs.append(tot)
+            tot += n * m
+        A = torch.zeros((tot, tot), dtype=self.R.dtype, device=self.R.device)
+        for pa, ia, Ja in self.slots:
+            WJa = self._WJ(Ja)
+            ra = offs[pa] + ia.unsqueeze(-1) * self.m[pa] + torch.arange(self.m[pa], device=ia.device)       # [E, ma]
+            for pb, ib, Jb in self.slots:
+                rb = offs[pb] + ib.unsqueeze(-1) * self.m[pb] + torch.arange(self.m[pb], device=ib.device)   # [E, mb]
+                blk = (WJa.unsqueeze(-1) * Jb.unsqueeze(-2)).sum(-3)                                         # [E, ma, mb]
+                A.index_put_((ra.unsqueeze(-1).expand_as(blk), rb.unsqueeze(-2).expand_as(blk)), blk, accumulate=True)
+        return A
+
+    def solve(self, solver):
+        shift = [self.s * c - r for c, r in zip(self.diag_clamped, self.diag_raw)]               # A = H + diag(shift)
+        b = [-x for x in self.g]
+        tot = sum(n * m for n, m in zip(self.N, self.m))
+        if not isinstance(solver, PCG) and tot <= DENSE_LIMIT and self.group is None:
+            A = self.dense_matrix()
+            A.diagonal().add_(self._cat(shift))
+            Dn = self._split(solver(A=A, b=self._cat(b).view(-1, 1)).reshape(-1))
+        else:
+            if not isinstance(solver, PCG):
+                if not getattr(self.opt, '_warned_pcg', False):
+                    warnings.warn(f"{type(solver).__name__} cannot factor a {tot}-unknown problem densely; "
+                                  f"using the matrix-free block-Jacobi PCG (tol 1e-10) instead.")
+                    self.opt._warned_pcg = True
+                solver = PCG(tol=1e-10, maxiter=max(1000, 2 * tot))
+            Binv = []
+            for B, c in zip(self.B, self.diag_clamped):
+                Bd = B.clone()
+                Bd.diagonal(dim1=-2, dim2=-1).copy_(self.s * c)
+                Binv.append(torch.linalg.inv(Bd))
+            matvec = lambda v: self._cat([y + sh * x for y, sh, x in zip(self._Hp(self._split(v)), shift, self._split(v))])
+            precond = lambda v: self._cat([(Bi * x.unsqueeze(-2)).sum(-1) for Bi, x in zip(Binv, self._split(v))])
+            Dn = self._split(solver.solve(matvec, self._cat(b), precond))
+        assert not any(bool(torch.isnan(d).any()) for d in Dn), 'Linear solve produced NaN (matrix may not be positive-definite)'
+        return self.nodes_to_step(Dn)
+
+    def solve_gauss_newton(self, solver):
+        raise NotImplementedError
+
+    def strategy_args(self):
+        return MultiGraphOperator(self), self.R.reshape(-1, 1)
+
+
+def try_multigraph_linearization(opt, pg, input, target, weight, R, params, rec, cache, sig):
+    """A MultiGraphLinearization if every optimised parameter enters the residual only through recorded gathers."""
+    key = (sig, "multi")
+    if cache.get(key) is False or len(R) != 1 or len(opt.corrector) != 1:
+        return None
+    r = R[0]
+    dr = r.shape[-1]
+    E = r.numel() // dr
+    pos = {id(p): k for k, p in enumerate(params)}
+    events = [(src, ix, out) for src, ix, out in rec.events if id(src) in pos and ix.numel() == E
+              and out.numel() == E * src.shape[-1] and src.dim() == 2]
+    if not events or len(events) != len(rec.events) or {id(s) for s, _, _ in events} != set(pos):
+        cache[key] = False
+        return None
+    outs = [out for _, _, out in events]
+    widths = [src.shape[-1] for src, _, _ in events]
+    with torch.enable_grad():
+        Jcat = _blocks.jacobian_blocks([r], outs)                              # [E, dr, sum widths]
+        if cache.get(key) is None:
+            # probe: u^T dR/dparams by one real backward == scatter-add of the per-observation blocks
+            u = torch.randn_like(r)
+            true = torch.autograd.grad([r], params, [u], retain_graph=True, allow_unused=True)
+            contrib = (u.reshape(E, dr).unsqueeze(-1) * Jcat).sum(-2)
+            got = [torch.zeros_like(p) for p in params]
+            off = 0
+            for (src, ix, _), w in zip(events, widths):
+                got[pos[id(src)]].index_add_(0, ix.reshape(-1), contrib[:, off:off + w])
+                off += w
+            ok = True
+            for t, gt in zip(true, got):
+                t = torch.zeros_like(gt) if t is None else t
+                ok = ok and bool((gt - t).abs().max() <= 1e-3 * t.abs().max().clamp_min(torch.finfo(t.dtype).tiny))
+            cache[key] = ok
+    if not cache[key]:
+        return None
+    ms = [_tangent_width(src) for src, _, _ in events]
+    # corrector: row-local on the concatenated tangent blocks
+    cols, off = [], 0
+    for w, m in zip(widths, ms):
+        cols.append(Jcat[:, :, off:off + m])
+        off += w
+    Rc, Jc = opt.corrector[0](R=r.detach().reshape(E, dr), J=torch.cat(cols, -1))
+    slots, off = [], 0
+    for (src, ix, _), m in zip(events, ms):
+        slots.append((pos[id(src)], ix.reshape(-1), Jc[:, :, off:off + m].contiguous()))
+        off += m
+    Wb = None
+    if weight is not None:
+        w = weight[0] if isinstance(weight, (tuple, list)) else weight
+        ws, ni = opt.model._weight_blocks(w, r)
+        Wb = ws.repeat(ni, 1, 1).contiguous()
+    return MultiGraphLinearization(opt, Wb, Rc, params, slots)

@@ -240,8 +240,13 @@ def _linearize(opt, pg, input, target, weight):
                         verdict = cache[sig] = _blocks.probe_block_structure(R, params, Jb)
                     if verdict:
                         return BlockLinearization(opt, pg, input, target, weight, R, params, Jb)
-            elif same_rows and rec.events and cache.get(sig) is not False:
-                lin = _pg.try_graph_linearization(opt, pg, input, target, weight, R, params, rec, cache, sig)
+            elif rec.events:
+                lin = None
+                if same_rows and cache.get(sig) is not False:
+                    lin = _pg.try_graph_linearization(opt, pg, input, target, weight, R, params, rec, cache, sig)
+                if lin is None and all(p.dim() == 2 for p in params) and R[0].dim() >= 2:
+                    from . import multigraph as _mg       # several parameters / widths (bundle adjustment)
+                    lin = _mg.try_multigraph_linearization(opt, pg, input, target, weight, R, params, rec, cache, sig)
                 if lin is not None:
                     return lin
     return DenseLinearization(opt, pg, input, target, weight)

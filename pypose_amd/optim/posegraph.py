@@ -54,9 +54,16 @@ class GatherRecorder:
 
     def __enter__(self):
         _lt._gather_recorders.append(self)
+        # plain nn.Parameters (e.g. intrinsics / 3-D points of a bundle-adjustment model) do not pass through
+        # LieTensor.__torch_function__: a TorchFunctionMode sees their ``param[index]`` too
+        self._mode = _PlainGatherMode(self) if any(not isinstance(p, _lt.LieTensor) for p in self.ids.values()) else None
+        if self._mode is not None:
+            self._mode.__enter__()
         return self
 
     def __exit__(self, *exc):
+        if self._mode is not None:
+            self._mode.__exit__(*exc)
         _lt._gather_recorders.remove(self)
 
     def note(self, source, index, out):
@@ -66,6 +73,19 @@ class GatherRecorder:
                 and isinstance(out, torch.Tensor) and (out.requires_grad or id(source) in self.ids) \
                 and isinstance(source, torch.Tensor) and source.dim() == 2:
             self.events.append((source, index, out))
+
+
+class _PlainGatherMode(torch.overrides.TorchFunctionMode):
+    def __init__(self, rec):
+        super().__init__()
+        self.rec = rec
+
+    def __torch_function__(self, func, types, args=(), kwargs=None):
+        out = func(*args, **(kwargs or {}))
+        if func is torch.Tensor.__getitem__ and len(args) == 2 and not isinstance(args[0], _lt.LieTensor) \
+                and id(args[0]) in self.rec.ids:
+            self.rec.note(args[0], args[1], out)
+        return out
 
 
 def _rows_of_parameter(src, param):

@@ -1,4 +1,5 @@
 """The reference's example models, re-stated against pypose_amd (tests only)."""
+import os
 import numpy as np
 import torch
 from torch import nn
@@ -82,3 +83,36 @@ def compare_trajectory(rec, G, prefix, floor=1e-16, rtol=1e-6):
                 assert rec["reject"][k] == G[prefix + "/reject"][k], (prefix, k)
         else:
             assert a <= max(floor, 100 * b), (prefix, k, a, b)
+
+
+class Reproj(nn.Module):                       # reference examples/module/ba/bundle_adjustment.py:16-43, verbatim structure
+    def __init__(self, K, C, P):
+        super().__init__()
+        self.K = pp.Parameter(K, sjac=True)
+        self.C = pp.Parameter(C, sjac=True)
+        self.P = pp.Parameter(P, sjac=True)
+
+    def forward(self, observe, cidx, pidx):
+        return Reproj.project(self.K[cidx], self.C[cidx], self.P[pidx]) - observe
+
+    @pp.autograd.function.psjac
+    def project(K, C, P):
+        cp = C.Act(P)
+        n = - cp[..., :2] / cp[..., [2]]
+        radius = n.square().sum(dim=-1, keepdim=True)
+        focal, k1, k2 = K[..., :1], K[..., 1:2], K[..., 2:3]
+        distortion = 1 + k1 * radius + k2 * radius.square()
+        return focal * distortion * n
+
+
+def load_ba_golden():
+    return dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ba_golden.npz")))
+
+
+def ba_case(G, tag, device="cpu"):
+    model = Reproj(T(G[f"{tag}/K0"], device), pp.SE3(T(G[f"{tag}/C0"], device)), T(G[f"{tag}/P0"], device))
+    args = (T(G[f"{tag}/obs"], device), T(G[f"{tag}/cidx"], device), T(G[f"{tag}/pidx"], device))
+    kernel = pp.optim.kernel.Huber(delta=1.0) if tag == "ba_huber" else None
+    opt = pp.optim.LM(model, solver=pp.optim.solver.Cholesky(), strategy=pp.optim.strategy.TrustRegion(radius=1e4),
+                      kernel=kernel, min=1e-6)
+    return model, opt, args

@@ -1,0 +1,63 @@
+"""Bundle adjustment on the MI355X: reference trajectories through the HIP Lie kernels, and a BAL-scale synthetic
+problem (257 cameras, 65 k points, 225 k observations -- the size of the reference example's default
+`problem-257-65132-pre`) through the matrix-free multi-parameter path."""
+import numpy as np
+import pytest
+import torch
+
+import pypose_amd as pp
+from tests.optim_models import Reproj, ba_case, compare_trajectory, load_ba_golden, run_steps
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def G():
+    return load_ba_golden()
+
+
+@pytest.mark.parametrize("structured", [False, True])
+@pytest.mark.parametrize("tag", ["ba_small", "ba_huber"])
+def test_ba_trajectory_matches_reference(G, tag, structured):
+    from pypose_amd import _C
+    assert _C._test_backend is None
+    model, opt, args = ba_case(G, tag, DEV)
+    opt.structured = structured
+    rec = run_steps(opt, (args,), {}, 6)
+    assert set(rec["kind"]) == ({"multigraph"} if structured else {"dense"}), rec["kind"]
+    compare_trajectory(rec, G, tag, floor=1e-12, rtol=1e-7)
+    np.testing.assert_allclose(model.P.detach().cpu().numpy(), G[f"{tag}/P"], atol=1e-6)
+    np.testing.assert_allclose(model.C.detach().tensor().cpu().numpy(), G[f"{tag}/C"], atol=1e-6)
+
+
+def synthetic_ba(Nc, Np, per_point, dtype, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    torch.manual_seed(seed)
+    P = (torch.randn(Np, 3, generator=g, dtype=dtype) * 0.5).to(DEV)
+    base = torch.cat([torch.tensor([[0., 0., -4.]], dtype=dtype).repeat(Nc, 1), pp.identity_SO3(Nc, dtype=dtype).tensor()], -1).to(DEV)
+    C = pp.randn_SE3(Nc, sigma=0.15, dtype=dtype, device=DEV) @ pp.SE3(base)
+    K = torch.stack([torch.full((Nc,), 500.), torch.full((Nc,), -0.05), torch.full((Nc,), 0.01)], -1).to(dtype).to(DEV)
+    cidx = torch.randint(0, Nc, (Np * per_point,), generator=g).to(DEV)
+    pidx = torch.arange(Np).repeat_interleave(per_point).to(DEV)
+    with torch.no_grad():
+        obs = Reproj.project(K[cidx], C[cidx], P[pidx]) + 0.2 * torch.randn(len(cidx), 2, generator=g, dtype=dtype).to(DEV)
+    K0 = K * (1 + 0.002 * torch.randn(Nc, 3, generator=g, dtype=dtype).to(DEV))
+    C0 = pp.randn_SE3(Nc, sigma=0.005, dtype=dtype, device=DEV) @ C
+    P0 = P + 0.02 * torch.randn(Np, 3, generator=g, dtype=dtype).to(DEV)
+    return (obs, cidx, pidx), (K0, C0, P0)
+
+
+def test_ba_bal_scale():
+    Nc, Np = 257, 65_132
+    args, (K0, C0, P0) = synthetic_ba(Nc, Np, 4, torch.float64)          # ~260 k observations
+    model = Reproj(K0, C0, P0)
+    opt = pp.optim.LM(model, solver=pp.optim.solver.PCG(tol=1e-4, maxiter=250), strategy=pp.optim.strategy.TrustRegion(radius=1e4),
+                      reject=30)
+    l0 = float(opt.model.loss(args, None).detach())
+    losses = [float(opt.step(args)) for _ in range(4)]
+    assert opt.linearization == "multigraph"
+    assert all(b <= a for a, b in zip([l0] + losses, losses)), (l0, losses)
+    # noise floor: 0.2 px per coordinate -> sum of squares ~ 0.04 * 2 E; the start is far above it
+    E = args[0].shape[0]
+    assert losses[-1] < 0.2 * l0 and losses[-1] < 4 * 0.04 * 2 * E, (l0, losses)

@@ -1,0 +1,82 @@
+"""Bundle adjustment (several parameters of different widths gathered per observation) on the CPU through the
+oracle backend: the reference example's model takes the multi-parameter graph path and reproduces the
+trajectories recorded from the reference's dense LM."""
+import numpy as np
+import pytest
+import torch
+
+import pypose_amd as pp
+from tests.optim_models import ba_case, compare_trajectory, load_ba_golden, run_steps
+from tests.oracle_backend import oracle_backend
+
+
+@pytest.fixture(scope="module")
+def G():
+    return load_ba_golden()
+
+
+@pytest.mark.parametrize("structured", [False, True])
+@pytest.mark.parametrize("tag", ["ba_small", "ba_huber"])
+def test_ba_trajectory_matches_reference(G, tag, structured):
+    with oracle_backend():
+        model, opt, args = ba_case(G, tag)
+        opt.structured = structured
+        rec = run_steps(opt, (args,), {}, 6)
+        assert set(rec["kind"]) == ({"multigraph"} if structured else {"dense"}), rec["kind"]
+        compare_trajectory(rec, G, tag, floor=1e-12, rtol=1e-7)
+        np.testing.assert_allclose(model.P.detach().numpy(), G[f"{tag}/P"], atol=1e-6)
+        np.testing.assert_allclose(model.C.detach().tensor().numpy(), G[f"{tag}/C"], atol=1e-6)
+        np.testing.assert_allclose(model.K.detach().numpy(), G[f"{tag}/K"], rtol=1e-6, atol=1e-6)
+
+
+def test_ba_matrix_free_pcg_and_operator(G):
+    """PCG on the matrix-free operator == the dense solve; J @ D of the strategy operator == dense J @ D."""
+    from pypose_amd.optim import multigraph
+    from pypose_amd.optim.optimizer import _linearize, DenseLinearization
+    with oracle_backend():
+        model, opt, args = ba_case(G, "ba_small")
+        pg = opt.param_groups[0]
+        with torch.no_grad():
+            lin = _linearize(opt, pg, args, None, None)
+            assert isinstance(lin, multigraph.MultiGraphLinearization)
+            lin.build_normal_equations(pg['min'], pg['max'])
+            lin.damp(1e-3)
+            D1 = lin.solve(pp.optim.solver.Cholesky())
+            D2 = lin.solve(pp.optim.solver.PCG(tol=1e-14, maxiter=5000, check_every=1))
+            torch.testing.assert_close(D1, D2, rtol=1e-7, atol=1e-9)
+            dense = DenseLinearization(opt, pg, args, None, None)
+            dense.build_normal_equations(pg['min'], pg['max'])
+            dense.damp(1e-3)
+            D3 = dense.solve(pp.optim.solver.Cholesky())
+            torch.testing.assert_close(D1, D3, rtol=1e-7, atol=1e-9)
+            J, R = lin.strategy_args()
+            torch.testing.assert_close(J @ D1, dense.J @ D3, rtol=1e-7, atol=1e-9)
+            torch.testing.assert_close(R, dense.R.view(-1, 1))
+
+
+def test_self_loop_slots_keep_the_exact_diagonal():
+    """Two gathers of the same parameter hitting the same row: the cross term lands on the diagonal block."""
+    class Pair(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.x = pp.Parameter(torch.randn(5, 2, dtype=torch.float64))
+            self.y = pp.Parameter(torch.randn(3, 2, dtype=torch.float64))
+
+        def forward(self, i, j, k):
+            return self.x[i] * 2 + self.x[j] ** 2 + self.y[k]
+
+    torch.manual_seed(0)
+    i = torch.tensor([0, 1, 2, 3, 4, 1]); j = torch.tensor([1, 1, 3, 0, 4, 2]); k = torch.tensor([0, 1, 2, 0, 1, 2])
+    from pypose_amd.optim.optimizer import _linearize, DenseLinearization
+    net = Pair()
+    opt = pp.optim.LM(net, solver=pp.optim.solver.Cholesky())
+    pg = opt.param_groups[0]
+    with torch.no_grad():
+        lin = _linearize(opt, pg, (i, j, k), None, None)
+        assert lin.kind == "multigraph"
+        lin.build_normal_equations(1e-6, 1e32)
+        dense = DenseLinearization(opt, pg, (i, j, k), None, None)
+        dense.build_normal_equations(1e-6, 1e32)
+        torch.testing.assert_close(torch.cat([d.reshape(-1) for d in lin.diag_clamped]), dense.A.diagonal())
+        lin.damp(0.5), dense.damp(0.5)              # (x[i]*2 + x[j]^2 + y[k] is rank deficient without damping)
+        torch.testing.assert_close(lin.solve(pp.optim.solver.Cholesky()), dense.solve(pp.optim.solver.Cholesky()))
