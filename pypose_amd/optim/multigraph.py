@@ -18,13 +18,51 @@ graphs take the HIP kernels of optim/posegraph.py instead.
 """
 from __future__ import annotations
 
+import ctypes
 import warnings
 
 import torch
 
+from .. import _C
+
 from ..lietensor import lietensor as _lt
 from . import blocks as _blocks
 from .posegraph import DENSE_LIMIT, PCG, _all_reduce
+
+
+_SEG_SIG = [ctypes.c_void_p] * 4 + [ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]
+
+
+class _Scatter:
+    """``out.index_add_(0, idx, vals)`` into N rows for a FIXED index vector: on a HIP device a segmented sum over
+    the incidence lists (``pplie_segment_sum``: deterministic, no atomics -- a camera row of a BA problem receives
+    ~10^3 contributions); elsewhere ``index_add_``."""
+
+    def __init__(self, idx, N):
+        self.idx, self.N = idx, N
+        self.hip = idx.is_cuda and _C._test_backend is None and idx.numel() < (1 << 31)
+        if self.hip:
+            order = torch.argsort(idx, stable=True)
+            self.perm = order.to(torch.int32)
+            self.ptr = torch.zeros(N + 1, dtype=torch.int32, device=idx.device)
+            self.ptr[1:] = torch.cumsum(torch.bincount(idx, minlength=N), 0).to(torch.int32)
+
+    def __call__(self, vals):
+        """vals [E, ...] -> [N, ...] (trailing dims flattened for the kernel, at most 64 values per row)"""
+        tail = vals.shape[1:]
+        w = 1
+        for t in tail:
+            w *= t
+        if self.hip and w <= 64 and vals.dtype in (torch.float32, torch.float64):
+            vals = vals.reshape(vals.shape[0], w).contiguous()
+            out = torch.empty((self.N, w), dtype=vals.dtype, device=vals.device)
+            fn = _C.library().symbol("pplie_segment_sum" + ("_f32" if vals.dtype == torch.float32 else "_f64"), _SEG_SIG)
+            with torch.cuda.device(vals.device):
+                _C.check(fn(vals.data_ptr(), self.perm.data_ptr(), self.ptr.data_ptr(), out.data_ptr(), self.N, w,
+                            _C.stream_ptr(vals.device)), "pplie_segment_sum")
+            return out.view((self.N,) + tuple(tail))
+        out = torch.zeros((self.N,) + tuple(tail), dtype=vals.dtype, device=vals.device)
+        return out.index_add_(0, self.idx, vals)
 
 
 def _tangent_width(p):
@@ -54,6 +92,20 @@ class MultiGraphLinearization:
         self.N = [p.shape[0] for p in self.params]
         self.group = getattr(opt, 'group', None)
         self.s = 1.0
+        self._scatters = None
+
+    def scatters(self):
+        """one deterministic scatter-add per slot (incidence lists cached on the optimizer per index vector)"""
+        if self._scatters is None:
+            cache = self.opt.__dict__.setdefault('_multigraph_scatter', {}) if hasattr(self.opt, '__dict__') else {}
+            out = []
+            for k, (pi, idx, _) in enumerate(self.slots):
+                hit = cache.get((k, self.N[pi]))
+                if hit is None or hit.idx.shape != idx.shape or not torch.equal(hit.idx, idx):
+                    hit = cache[(k, self.N[pi])] = _Scatter(idx.clone(), self.N[pi])
+                out.append(hit)
+            self._scatters = out
+        return self._scatters
 
     # -- layouts ------------------------------------------------------------------------------------
     def step_to_nodes(self, D):
@@ -100,9 +152,10 @@ class MultiGraphLinearization:
         q = self._J_times(nodes)
         if self.W is not None:
             q = (self.W * q.unsqueeze(-2)).sum(-1)
-        ys = [torch.zeros_like(n) for n in nodes]
-        for pi, idx, J in self.slots:
-            ys[pi].index_add_(0, idx, (J * q.unsqueeze(-1)).sum(-2))
+        ys = [None] * len(nodes)
+        for (pi, idx, J), sc in zip(self.slots, self.scatters()):
+            y = sc((J * q.unsqueeze(-1)).sum(-2))
+            ys[pi] = y if ys[pi] is None else ys[pi] + y
         return [_all_reduce(y, self.group) for y in ys]
 
     def _assemble(self):
@@ -110,10 +163,10 @@ class MultiGraphLinearization:
         B = [torch.zeros((n, m, m), dtype=dt, device=dev) for n, m in zip(self.N, self.m)]
         g = [torch.zeros((n, m), dtype=dt, device=dev) for n, m in zip(self.N, self.m)]
         Wr = self.R if self.W is None else (self.W * self.R.unsqueeze(-2)).sum(-1)
-        for pi, idx, J in self.slots:
+        for (pi, idx, J), sc in zip(self.slots, self.scatters()):
             WJ = self._WJ(J)
-            B[pi].index_add_(0, idx, (J.unsqueeze(-1) * WJ.unsqueeze(-2)).sum(-3))           # J^T W J  [E,m,m]
-            g[pi].index_add_(0, idx, (J * Wr.unsqueeze(-1)).sum(-2))
+            B[pi] += sc((J.unsqueeze(-1) * WJ.unsqueeze(-2)).sum(-3))                        # J^T W J  [E,m,m]
+            g[pi] += sc((J * Wr.unsqueeze(-1)).sum(-2))
         # two slots of the SAME parameter meeting in the same row (a self loop) put their cross term on the
         # diagonal block as well
         for a, (pa, ia, Ja) in enumerate(self.slots):
@@ -171,9 +224,20 @@ class MultiGraphLinearization:
                 Bd = B.clone()
                 Bd.diagonal(dim1=-2, dim2=-1).copy_(self.s * c)
                 Binv.append(torch.linalg.inv(Bd))
-            matvec = lambda v: self._cat([y + sh * x for y, sh, x in zip(self._Hp(self._split(v)), shift, self._split(v))])
-            precond = lambda v: self._cat([(Bi * x.unsqueeze(-2)).sum(-1) for Bi, x in zip(Binv, self._split(v))])
-            Dn = self._split(solver.solve(matvec, self._cat(b), precond))
+            if self.R.is_cuda and self.group is None and getattr(solver, 'fused', True):
+                cache = self.opt.__dict__.setdefault('_pcg_workspaces', {})
+                key = ("multigraph", self.E, self.dr, tuple(self.N), tuple(self.m), tuple((pi, J.shape[-1]) for pi, _, J in self.slots),
+                       self.R.dtype, self.R.device, self.W is not None, solver.check_every)
+                wsp = cache.get(key)
+                if wsp is None:
+                    wsp = cache[key] = _GraphedPCG(self, solver.check_every)
+                maxiter = tot * 10 if solver.maxiter is None else solver.maxiter
+                x, solver.iterations = wsp.solve(self, shift, Binv, b, solver.tol, maxiter)
+                Dn = self._split(x)
+            else:
+                matvec = lambda v: self._cat([y + sh * x for y, sh, x in zip(self._Hp(self._split(v)), shift, self._split(v))])
+                precond = lambda v: self._cat([(Bi * x.unsqueeze(-2)).sum(-1) for Bi, x in zip(Binv, self._split(v))])
+                Dn = self._split(solver.solve(matvec, self._cat(b), precond))
         assert not any(bool(torch.isnan(d).any()) for d in Dn), 'Linear solve produced NaN (matrix may not be positive-definite)'
         return self.nodes_to_step(Dn)
 
@@ -182,6 +246,87 @@ class MultiGraphLinearization:
 
     def strategy_args(self):
         return MultiGraphOperator(self), self.R.reshape(-1, 1)
+
+
+class _GraphedPCG:
+    """Block-Jacobi PCG of one problem shape with every operand in persistent device buffers, ``check_every``
+    iterations captured in a hipGraph and replayed (the loop is launch-bound: ~40 small kernels per iteration);
+    one host sync per replay for the stopping test.  Reused across LM steps and trial steps."""
+
+    def __init__(self, lin, check_every):
+        dt, dev = lin.R.dtype, lin.R.device
+        self.lin_like = MultiGraphLinearization.__new__(MultiGraphLinearization)
+        L = self.lin_like
+        L.opt, L.params, L.group, L.E, L.dr, L.N, L.m = lin.opt, lin.params, None, lin.E, lin.dr, lin.N, lin.m
+        L.R = torch.empty_like(lin.R)
+        L.W = torch.empty_like(lin.W) if lin.W is not None else None
+        L.slots = [(pi, torch.empty_like(idx), torch.empty_like(J)) for pi, idx, J in lin.slots]
+        L._scatters = None
+        tot = sum(n * m for n, m in zip(lin.N, lin.m))
+        z = lambda *s: torch.zeros(s, dtype=dt, device=dev)
+        self.shift = [z(n, m) for n, m in zip(lin.N, lin.m)]
+        self.Binv = [z(n, m, m) for n, m in zip(lin.N, lin.m)]
+        self.x, self.r, self.p = z(tot), z(tot), z(tot)
+        self.rho = torch.zeros((), dtype=dt, device=dev)
+        self.check_every = check_every
+        self.rr = z(check_every)
+        self.graph = None
+
+    def _iteration(self, k):
+        L = self.lin_like
+        ps = L._split(self.p)
+        q = L._cat([y + sh * x for y, sh, x in zip(L._Hp(ps), self.shift, ps)])
+        pq = (self.p * q).sum()
+        alpha = torch.where(pq != 0, self.rho / pq, torch.zeros_like(pq))       # p.q = 0 only once r = 0
+        self.x.add_(alpha * self.p)
+        self.r.sub_(alpha * q)
+        zv = L._cat([(Bi * x.unsqueeze(-2)).sum(-1) for Bi, x in zip(self.Binv, L._split(self.r))])
+        rho_new = (self.r * zv).sum()
+        beta = torch.where(self.rho != 0, rho_new / self.rho, torch.zeros_like(rho_new))
+        self.p.mul_(beta).add_(zv)
+        self.rho.copy_(rho_new)
+        self.rr[k] = (self.r * self.r).sum()
+
+    def solve(self, lin, shift, Binv, b, tol, maxiter):
+        L = self.lin_like
+        for (_, di, dJ), (_, si, sJ) in zip(L.slots, lin.slots):
+            di.copy_(si)
+            dJ.copy_(sJ)
+        new = lin.scatters()
+        if L._scatters is None or any(a is not b for a, b in zip(L._scatters, new)):
+            L._scatters, self.graph = new, None                     # new edge list: the captured incidence lists are stale
+        if L.W is not None:
+            L.W.copy_(lin.W)
+        for d, s_ in zip(self.shift, shift):
+            d.copy_(s_)
+        for d, s_ in zip(self.Binv, Binv):
+            d.copy_(s_)
+        bv = lin._cat(b)
+        self.x.zero_()
+        self.r.copy_(bv)
+        zv = L._cat([(Bi * x.unsqueeze(-2)).sum(-1) for Bi, x in zip(self.Binv, L._split(self.r))])
+        self.p.copy_(zv)
+        self.rho.copy_((self.r * zv).sum())
+        bn2 = float((bv * bv).sum())
+        if bn2 == 0.0:
+            return self.x.clone(), 0
+        done = 0
+        while done < maxiter:
+            if self.graph is None and done > 0:                   # first block runs eagerly (warm-up), then capture
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    for k in range(self.check_every):
+                        self._iteration(k)
+                self.graph = g
+            if self.graph is not None:
+                self.graph.replay()
+            else:
+                for k in range(self.check_every):
+                    self._iteration(k)
+            done += self.check_every
+            if float(self.rr[-1]) <= tol * tol * bn2:
+                break
+        return self.x.clone(), done
 
 
 def try_multigraph_linearization(opt, pg, input, target, weight, R, params, rec, cache, sig):
