@@ -173,7 +173,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    launched = "WORLD_SIZE" in os.environ and "RANK" in os.environ      # torch.distributed.run (also with one rank)
+    if launched:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -202,7 +203,7 @@ def main():
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(a.steps)]
 
     def barrier():
-        if world > 1:
+        if launched:
             import torch.distributed as dist
             dist.barrier()
 
@@ -220,7 +221,7 @@ def main():
     elapsed = time.perf_counter() - t0
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
+    if launched:
         import torch.distributed as dist
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = t.item()
@@ -259,7 +260,7 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if launched:
         import torch.distributed as dist
         dist.destroy_process_group()
 

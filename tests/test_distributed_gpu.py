@@ -1,0 +1,58 @@
+"""LM(group=...) on the GPU over RCCL (backend "nccl") with a one-rank process group: every collective the
+sharded paths issue (loss, gain-ratio terms, fused partial sums, block diagonal / gradient / H p of pose graphs)
+runs on device tensors and leaves the single-process results unchanged."""
+import os
+
+import pytest
+import torch
+import torch.distributed as dist
+
+import pypose_amd as pp
+from tests.optim_models import InvNet, PoseGraph, T, load_lm_golden
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def group():
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29533", rank=0, world_size=1, device_id=torch.device(DEV))
+    yield dist.group.WORLD
+    dist.destroy_process_group()
+
+
+def _run(make, args, group, fused, steps=4):
+    model, kw = make()
+    opt = pp.optim.LM(model, group=group, **kw)
+    opt.fused = fused
+    losses = [float(opt.step(*args)) for _ in range(steps)]
+    return losses, opt.linearization, [p.detach().clone() for p in model.parameters()]
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_invnet_group_equals_single_process(group, fused):
+    torch.manual_seed(0)
+    init, inp = pp.randn_SE3(1000, device=DEV, dtype=torch.float64), pp.randn_SE3(1000, device=DEV, dtype=torch.float64)
+    make = lambda: (InvNet(init.clone()), {"strategy": pp.optim.strategy.Adaptive(damping=1e-6)})
+    a = _run(make, (inp,), None, fused)
+    b = _run(make, (inp,), group, fused)
+    assert a[1] == b[1] == ("fused:se3inv" if fused else "block")
+    for x, y in zip(a[0], b[0]):
+        assert abs(x - y) <= 1e-9 * max(abs(x), 1e-20) + 1e-25
+    torch.testing.assert_close(a[2][0], b[2][0], rtol=0, atol=1e-12)
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_posegraph_group_equals_single_process(group, fused):
+    G = load_lm_golden()
+    edges, poses = T(G["pgo40/edges"], DEV), pp.SE3(T(G["pgo40/poses"], DEV))
+    make = lambda: (PoseGraph(pp.SE3(T(G["pgo40/init"], DEV))),
+                    {"solver": pp.optim.solver.PCG(tol=1e-12, maxiter=2000), "strategy": pp.optim.strategy.TrustRegion(radius=1e4)})
+    a = _run(make, ((edges, poses),), None, fused)
+    b = _run(make, ((edges, poses),), group, fused)
+    assert a[1] == b[1] == ("fused:pgo" if fused else "graph")
+    for x, y in zip(a[0], b[0]):
+        assert abs(x - y) <= 1e-7 * abs(x)
+    torch.testing.assert_close(a[2][0], b[2][0], rtol=0, atol=1e-7)
