@@ -164,7 +164,8 @@ def match_pgo(trace, gathers, R, params):
     if len(trace.events) != 5 or len(gathers) != 2 or len(R) != 1 or len(params) != 1:
         return None
     P = params[0]
-    if getattr(P, "ltype", None) is not _lt.SE3_type or P.dim() != 2 or any(src is not P for src, _, _ in gathers):
+    if getattr(P, "ltype", None) is not _lt.SE3_type or P.dim() != 2 or not P.is_contiguous() \
+            or any(src is not P for src, _, _ in gathers):
         return None
     by_out = {o[0].data_ptr(): (n, i) for n, i, o in trace.events}
     gat = {out.data_ptr(): ix for _, ix, out in gathers}

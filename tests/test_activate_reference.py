@@ -82,3 +82,36 @@ def test_reference_lm_runs_on_activated_ops(ref_pp):
         finally:
             activate.deactivate()
     np.testing.assert_allclose(losses, G["invnet/constant/loss"][:2], rtol=1e-6)
+
+
+def test_rank4_callers_run_unmodified_on_activated_ops(ref_pp):
+    """the reference's own bspline / geodesic_loss / ape / rpe are pure
+    compositions of hot-path ops -- with the shim active they run on pypose_amd's Functions unmodified."""
+    from pypose_amd import activate
+    from tests.oracle_backend import oracle_backend
+    pp = ref_pp
+    D = torch.float64
+    torch.manual_seed(4)
+    poses = pp.randn_SE3(2, 6, dtype=D, requires_grad=True)
+    est = pp.randn_SE3(12, dtype=D)
+    gt = est @ pp.randn_SE3(12, sigma=0.05, dtype=D)
+    stamps = torch.arange(12, dtype=D)
+
+    def workload():
+        wpts = pp.bspline(poses, interval=0.25)
+        loss = pp.geodesic_loss(wpts, pp.identity_SE3(*wpts.lshape, dtype=D), reduction='sum')
+        (g,) = torch.autograd.grad(loss, poses)
+        ape = pp.metric.ape(stamps, gt, stamps, est)
+        rpe = pp.metric.rpe(stamps, gt, stamps, est)
+        flat = lambda d: torch.stack([torch.as_tensor(v, dtype=D).reshape(-1)[0] for v in d.values()])
+        return [wpts.tensor().detach(), loss.detach(), g, flat(ape), flat(rpe)]
+
+    want = workload()
+    with oracle_backend():
+        activate.activate(pp, force=True)
+        try:
+            got = workload()
+        finally:
+            activate.deactivate()
+    for g, w in zip(got, want):
+        torch.testing.assert_close(g, w, rtol=1e-8, atol=1e-10)
