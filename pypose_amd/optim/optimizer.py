@@ -210,13 +210,15 @@ def _row_count(t):
     return t.numel() // t.shape[-1] if t.dim() >= 1 and t.shape[-1] > 0 else -1
 
 
-def _linearize(opt, pg, input, target, weight):
-    """Pick the cheapest valid linearisation for this model (cached per shape signature)."""
+def _linearize(opt, pg, input, target, weight, gauss_newton=False):
+    """Pick the cheapest valid linearisation for this model (cached per shape signature).  Gauss-Newton solves
+    the rectangular system ``W J d = -W R`` with the user's solver (pseudo-inverse by default, i.e. minimum-norm
+    steps on gauge-free graphs): only the block and dense linearisations reproduce that."""
     params = [p for p in pg['params'] if p.requires_grad]
     cache = opt.__dict__.setdefault('_structure_cache', {})
     if getattr(opt, 'structured', True) and params:
         from . import posegraph as _pg
-        if getattr(opt, 'fused', False):
+        if getattr(opt, 'fused', False) and not gauss_newton:
             from . import fused as _fused
             lin = _fused.try_fused(opt, pg, input, target, weight, cache)
             if lin is not None:
@@ -240,7 +242,7 @@ def _linearize(opt, pg, input, target, weight):
                         verdict = cache[sig] = _blocks.probe_block_structure(R, params, Jb)
                     if verdict:
                         return BlockLinearization(opt, pg, input, target, weight, R, params, Jb)
-            elif rec.events:
+            elif rec.events and not gauss_newton:
                 lin = None
                 if same_rows and cache.get(sig) is not False:
                     lin = _pg.try_graph_linearization(opt, pg, input, target, weight, R, params, rec, cache, sig)
@@ -291,7 +293,7 @@ class GaussNewton(_Optimizer):
     def step(self, input, target=None, weight=None):
         for pg in self.param_groups:
             weight = self.weight if weight is None else weight
-            lin = _linearize(self, pg, input, target, weight)
+            lin = _linearize(self, pg, input, target, weight, gauss_newton=True)
             D = lin.solve_gauss_newton(self.solver)
             self.last = self.loss if hasattr(self, 'loss') else self.model.loss(input, target)
             self.update_parameter(params=pg['params'], step=D)

@@ -76,6 +76,24 @@ def main():
             S[f"{tag}/{k}"] = np.asarray(v)
         S[f"{tag}/K"], S[f"{tag}/C"], S[f"{tag}/P"] = model.K.detach().numpy(), model.C.detach().tensor().numpy(), model.P.detach().numpy()
         print(tag, rec)
+    # Gauss-Newton (pseudo-inverse of the rectangular J) on the gauge-free pose graph pgo12 of lm_golden.npz
+    L = np.load(os.path.join(os.path.dirname(OUT), "lm_golden.npz"))
+
+    class PoseGraph(nn.Module):
+        def __init__(self, nodes):
+            super().__init__()
+            self.nodes = pp.Parameter(nodes)
+
+        def forward(self, edges, poses):
+            n1, n2 = self.nodes[edges[..., 0]], self.nodes[edges[..., 1]]
+            return (poses.Inv() @ n1.Inv() @ n2).Log().tensor()
+
+    edges, poses = torch.from_numpy(L["pgo12/edges"]), pp.SE3(torch.from_numpy(L["pgo12/poses"]))
+    graph = PoseGraph(pp.SE3(torch.from_numpy(L["pgo12/init"])))
+    opt = pp.optim.GN(graph)
+    S["gn_pgo12/loss"] = np.asarray([float(opt.step((edges, poses))) for _ in range(3)])
+    S["gn_pgo12/final"] = graph.nodes.detach().tensor().numpy()
+    print("gn_pgo12", S["gn_pgo12/loss"])
     np.savez_compressed(OUT, **S)
 
 

@@ -80,3 +80,17 @@ def test_self_loop_slots_keep_the_exact_diagonal():
         torch.testing.assert_close(torch.cat([d.reshape(-1) for d in lin.diag_clamped]), dense.A.diagonal())
         lin.damp(0.5), dense.damp(0.5)              # (x[i]*2 + x[j]^2 + y[k] is rank deficient without damping)
         torch.testing.assert_close(lin.solve(pp.optim.solver.Cholesky()), dense.solve(pp.optim.solver.Cholesky()))
+
+
+def test_gauss_newton_on_a_pose_graph_takes_the_reference_path(G):
+    """GN solves the rectangular system with the pseudo-inverse (minimum-norm step on a gauge-free graph): the
+    graph / fused linearisations do not apply, the dense reference algorithm must (and did crash before)."""
+    from tests.optim_models import PoseGraph, T, load_lm_golden
+    L = load_lm_golden()
+    with oracle_backend():
+        edges, poses = T(L["pgo12/edges"]), pp.SE3(T(L["pgo12/poses"]))
+        graph = PoseGraph(pp.SE3(T(L["pgo12/init"])))
+        opt = pp.optim.GN(graph)
+        losses = [float(opt.step((edges, poses))) for _ in range(3)]
+        np.testing.assert_allclose(losses, G["gn_pgo12/loss"], rtol=1e-8)
+        np.testing.assert_allclose(graph.nodes.detach().tensor().numpy(), G["gn_pgo12/final"], atol=1e-8)
