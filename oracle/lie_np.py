@@ -756,6 +756,12 @@ _OPNAMES = ["exp_fwd", "exp_bwd", "log_fwd", "log_bwd", "inv_fwd", "inv_bwd", "m
 OPS = {f"{g}_{o}": globals()[f"{g}_{o}"] for g in GROUPS for o in _OPNAMES}
 OPS["so3_jr_fwd"] = so3_jr_fwd
 OPS["so3_jr_bwd"] = so3_jr_bwd
+# compositions of the above (no golden of their own): p.add_(d) of the optimizers (lietensor.py:60-65),
+# Exp(d[:da]) * p with the step d zero-padded to the group width
+COMPOSED_OPS = {}
+for _g, (_da, _dg) in GROUPS.items():
+    COMPOSED_OPS[f"{_g}_retract"] = (lambda g, da: lambda d, X: (
+        OPS[f"{g}_mul_fwd"](OPS[f"{g}_exp_fwd"](np.ascontiguousarray(d[:, :da]))[0], X)[0],))(_g, _da)
 
 
 def op_signature(name):

@@ -7,6 +7,13 @@
 // width DG; PPLIE_EXPORT_GROUP exports them (TileOf specialisations go in between).
 #define PPLIE_DEFINE_GROUP_OPS(g, DA, DG)                                               \
   namespace pplie {                                                              \
+  /* optimizer update p.add_(d) = Exp(d[:DA]) * p (reference lietensor.py:60-65), d zero-padded to DG */ \
+  template <class S> PP_HD void g##_retract(const S* d, const S* X, S* out) {    \
+    S E[DG];                                                                     \
+    g##_exp<S>(d, E);                                                            \
+    g##_mul<S>(E, X, out);                                                       \
+  }                                                                              \
+  PPLIE_OP_2_1(Op_##g##_retract, g##_retract, DG, DG, DG)                        \
   PPLIE_OP_1_1(Op_##g##_exp_fwd, g##_exp, DA, DG)                                \
   PPLIE_OP_2_1(Op_##g##_exp_bwd, g##_exp_bwd, DA, DG, DA)                        \
   PPLIE_OP_1_1(Op_##g##_log_fwd, g##_log, DG, DA)                                \
@@ -28,6 +35,7 @@
   }
 
 #define PPLIE_EXPORT_GROUP(g)                                                    \
+  PPLIE_EXPORT(pplie_##g##_retract, pplie::Op_##g##_retract)                     \
   PPLIE_EXPORT(pplie_##g##_exp_fwd, pplie::Op_##g##_exp_fwd)                     \
   PPLIE_EXPORT(pplie_##g##_exp_bwd, pplie::Op_##g##_exp_bwd)                     \
   PPLIE_EXPORT(pplie_##g##_log_fwd, pplie::Op_##g##_log_fwd)                     \

@@ -168,7 +168,14 @@ class LieType:
         m = self.manifold[0]
         if not self._is_group:
             return input.copy_(Tensor.as_subclass(input, Tensor) + Tensor.as_subclass(other, Tensor)[..., :m])
-        delta = LieTensor(Tensor.as_subclass(other, Tensor)[..., :m], ltype=self._algebra)
+        raw, x = Tensor.as_subclass(other, Tensor), Tensor.as_subclass(input, Tensor)
+        if raw.shape == x.shape and not (torch.is_grad_enabled() and (raw.requires_grad or x.requires_grad)) \
+                and raw.dtype == x.dtype and not _op._transforms_active():
+            # the optimizer's update (step zero-padded to the group width): one fused kernel Exp(d[:m]) * p
+            out = _op._launch(self._key + "_retract", (raw.detach(), x.detach()), (x.shape[-1],) * 2, (x.shape[-1],))[0]
+            with torch.no_grad():
+                return input.copy_(out)
+        delta = LieTensor(raw[..., :m], ltype=self._algebra)
         return input.copy_(delta.Exp() * input)
 
     # -- views of the components -------------------------------------------------------------

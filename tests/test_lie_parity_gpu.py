@@ -207,3 +207,22 @@ def test_c1_fwd_bwd_through_lietensor_api():
     e, _ = row_rel_err(x.grad.cpu().numpy(), gx)
     assert np.quantile(e, 0.995) < 1e-5
     assert x.grad.shape == (1024, 6) and x.grad.is_cuda
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("group", ["SO3", "SE3", "Sim3", "RxSO3"])
+def test_fused_retraction_equals_exp_then_mul(group, dtype):
+    """pplie_<g>_retract (the optimizers' p.add_(d)) equals the Exp and Mul kernels it fuses up to a few ulp
+    (fusing changes which products the compiler contracts into FMAs)."""
+    import pypose_amd as pp
+    torch.manual_seed(0)
+    X = getattr(pp, "randn_" + group)(1001, device="cuda:0", dtype=dtype)
+    w = X.shape[-1]
+    d = 0.3 * torch.randn(1001, w, device="cuda:0", dtype=dtype)
+    m = X.ltype.manifold[0]
+    want = (pp.LieTensor(d[:, :m], ltype=X.Log().ltype).Exp() * X).tensor()
+    Y = X.clone()
+    Y.add_(d)
+    tol = 1e-14 if dtype == torch.float64 else 1e-6
+    assert (Y.tensor() - want).abs().max().item() <= tol * want.abs().max().item()
+    assert Y.ltype == X.ltype
