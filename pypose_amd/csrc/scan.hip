@@ -19,20 +19,65 @@ namespace pplie {
 
 enum { SC_OK = 0, SC_EBADARG = -1, SC_ELAUNCH = -2 };
 
+// ---- cross-lane moves on the VALU (DPP) instead of ds_bpermute --------------------------------------------
+// A wave-wide inclusive scan is 7 combine steps (GCN3 cross-lane recipe): row_shr:1,2,3 of the ORIGINAL values,
+// row_shr:4 (banks 1-3), row_shr:8 (banks 2-3), row_bcast:15 (rows 1,3), row_bcast:31 (rows 2,3).  A lane a step
+// does not reach keeps `old` (bound_ctrl = 0), which is the identity of the scan's operation, so every lane can
+// combine unconditionally.  Each move is one VALU instruction; __shfl_up/down compile to LDS permutes with an
+// address computation and a wait each -- on these latency-bound scan kernels that was most of the time.
+template <int CTRL, int RM, int BM> __device__ __forceinline__ float dpp_mov(float old, float src) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src), CTRL, RM, BM, false));
+}
+template <int CTRL, int RM, int BM> __device__ __forceinline__ double dpp_mov(double old, double src) {
+  const unsigned long long o = __builtin_bit_cast(unsigned long long, old), v = __builtin_bit_cast(unsigned long long, src);
+  const int lo = __builtin_amdgcn_update_dpp((int)(unsigned)o, (int)(unsigned)v, CTRL, RM, BM, false);
+  const int hi = __builtin_amdgcn_update_dpp((int)(unsigned)(o >> 32), (int)(unsigned)(v >> 32), CTRL, RM, BM, false);
+  return __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo);
+}
+enum { DPP_ROW_SHR1 = 0x111, DPP_ROW_SHR2 = 0x112, DPP_ROW_SHR3 = 0x113, DPP_ROW_SHR4 = 0x114, DPP_ROW_SHR8 = 0x118,
+       DPP_WAVE_SHR1 = 0x138, DPP_ROW_BCAST15 = 0x142, DPP_ROW_BCAST31 = 0x143 };
+
+// value of lane-1 (lane 0 receives `first`)
+template <class T> __device__ __forceinline__ T lane_shift_up1(T v, T first) { return dpp_mov<DPP_WAVE_SHR1, 0xf, 0xf>(first, v); }
+__device__ __forceinline__ float lane_bcast63(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63)); }
+__device__ __forceinline__ double lane_bcast63(double v) {
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, 63), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), 63);
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+
+// inclusive prefix sum over the 64 lanes
+template <class T> __device__ __forceinline__ T wave_prefix_add(T v) {
+  const T v0 = v, z = T(0);
+  v = dpp_mov<DPP_ROW_SHR1, 0xf, 0xf>(z, v0) + v;
+  v = dpp_mov<DPP_ROW_SHR2, 0xf, 0xf>(z, v0) + v;
+  v = dpp_mov<DPP_ROW_SHR3, 0xf, 0xf>(z, v0) + v;
+  v = dpp_mov<DPP_ROW_SHR4, 0xf, 0xe>(z, v) + v;
+  v = dpp_mov<DPP_ROW_SHR8, 0xf, 0xc>(z, v) + v;
+  v = dpp_mov<DPP_ROW_BCAST15, 0xa, 0xf>(z, v) + v;
+  v = dpp_mov<DPP_ROW_BCAST31, 0xc, 0xf>(z, v) + v;
+  return v;
+}
+
 template <class T, int W> __device__ __forceinline__ void shfl_up_vec(const T* v, T* u, int off) {
 #pragma unroll
   for (int k = 0; k < W; ++k) u[k] = __shfl_up(v[k], off, 64);
 }
-template <class T, int W> __device__ __forceinline__ void bcast_vec(const T* v, T* u, int lane) {
+template <class T, int W> __device__ __forceinline__ void bcast_vec(const T* v, T* u, int lane) {   // lane is always 63
 #pragma unroll
-  for (int k = 0; k < W; ++k) u[k] = __shfl(v[k], lane, 64);
+  for (int k = 0; k < W; ++k) u[k] = lane_bcast63(v[k]);
 }
 
 // group products: c = a * b
-template <class T> struct MulSO3 { enum { W = 4 }; static __device__ __forceinline__ void mul(const T* a, const T* b, T* c) { so3_mul<T>(a, b, c); } };
-template <class T> struct MulSE3 { enum { W = 7 }; static __device__ __forceinline__ void mul(const T* a, const T* b, T* c) { se3_mul<T>(a, b, c); } };
-template <class T> struct MulSim3 { enum { W = 8 }; static __device__ __forceinline__ void mul(const T* a, const T* b, T* c) { sim3_mul<T>(a, b, c); } };
-template <class T> struct MulRxSO3 { enum { W = 5 }; static __device__ __forceinline__ void mul(const T* a, const T* b, T* c) { rxso3_mul<T>(a, b, c); } };
+// (ident(k): component k of the group identity)
+template <class T> struct MulSO3 { enum { W = 4 }; static __device__ __forceinline__ void mul(const T* a, const T* b, T* c) { so3_mul<T>(a, b, c); }
+  static __device__ __forceinline__ T ident(int k) { return k == 3 ? T(1) : T(0); } };
+template <class T> struct MulSE3 { enum { W = 7 }; static __device__ __forceinline__ void mul(const T* a, const T* b, T* c) { se3_mul<T>(a, b, c); }
+  static __device__ __forceinline__ T ident(int k) { return k == 6 ? T(1) : T(0); } };
+template <class T> struct MulSim3 { enum { W = 8 }; static __device__ __forceinline__ void mul(const T* a, const T* b, T* c) { sim3_mul<T>(a, b, c); }
+  static __device__ __forceinline__ T ident(int k) { return (k == 6 || k == 7) ? T(1) : T(0); } };
+template <class T> struct MulRxSO3 { enum { W = 5 }; static __device__ __forceinline__ void mul(const T* a, const T* b, T* c) { rxso3_mul<T>(a, b, c); }
+  static __device__ __forceinline__ T ident(int k) { return (k == 3 || k == 4) ? T(1) : T(0); } };
 
 // acc (+) x  with acc the earlier prefix: left ? x * acc : acc * x   (basics/ops.py:49-56)
 template <class T, class G> __device__ __forceinline__ void combine(const T* acc, const T* x, T* out, bool left) {
@@ -42,17 +87,30 @@ template <class T, class G> __device__ __forceinline__ void combine(const T* acc
   for (int k = 0; k < G::W; ++k) out[k] = tmp[k];
 }
 
-// inclusive wave scan of v (one element per lane) with the prefix `carry` (valid iff has_carry)
+// inclusive wave scan of v (one element per lane) with the prefix `carry` (valid iff has_carry): 7 DPP steps,
+// lanes a step does not reach combine with the identity
+template <class T, class G, int CTRL, int RM, int BM>
+__device__ __forceinline__ void scan_step(const T* src, T* v, bool left) {
+  constexpr int W = G::W;
+  T u[W];
+#pragma unroll
+  for (int k = 0; k < W; ++k) u[k] = dpp_mov<CTRL, RM, BM>(G::ident(k), src[k]);
+  combine<T, G>(u, v, v, left);
+}
 template <class T, class G>
 __device__ __forceinline__ void wave_scan(T* v, const T* carry, bool has_carry, bool left, int lane) {
   constexpr int W = G::W;
-  if (has_carry && lane == 0) combine<T, G>(carry, v, v, left);
+  T v0[W];
 #pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    T u[W];
-    shfl_up_vec<T, W>(v, u, off);
-    if (lane >= off) combine<T, G>(u, v, v, left);
-  }
+  for (int k = 0; k < W; ++k) v0[k] = v[k];
+  scan_step<T, G, DPP_ROW_SHR1, 0xf, 0xf>(v0, v, left);
+  scan_step<T, G, DPP_ROW_SHR2, 0xf, 0xf>(v0, v, left);
+  scan_step<T, G, DPP_ROW_SHR3, 0xf, 0xf>(v0, v, left);
+  scan_step<T, G, DPP_ROW_SHR4, 0xf, 0xe>(v, v, left);
+  scan_step<T, G, DPP_ROW_SHR8, 0xf, 0xc>(v, v, left);
+  scan_step<T, G, DPP_ROW_BCAST15, 0xa, 0xf>(v, v, left);
+  scan_step<T, G, DPP_ROW_BCAST31, 0xc, 0xf>(v, v, left);
+  if (has_carry) combine<T, G>(carry, v, v, left);               // uniform branch: every lane takes the carry
 }
 
 template <class T, class G, int WAVES>
@@ -102,14 +160,7 @@ template <class T, class G> int scan_launch(void* data, int64_t nseq, int64_t L,
 //   rot = init_rot * Dr ; vel = init_vel + init_rot Dv ; pos = init_pos + init_rot Dp + init_vel Dt (:422-426)
 // aux (for the covariance): Rk = dr, Rij = [Rij0 *] Dr, a.
 // ---------------------------------------------------------------------------------------------
-template <class T> __device__ __forceinline__ T wave_scan_add(T v, T carry, int lane) {
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    T u = __shfl_up(v, off, 64);
-    if (lane >= off) v += u;
-  }
-  return v + carry;
-}
+template <class T> __device__ __forceinline__ T wave_scan_add(T v, T carry, int lane) { return wave_prefix_add(v) + carry; }
 
 template <class T, int WAVES>
 __global__ void __launch_bounds__(WAVES * 64)
@@ -132,26 +183,45 @@ imu_integrate_kernel(const T* __restrict__ dt, const T* __restrict__ gyro, const
   const V3<T> g = v3<T>(gx, gy, gz);
   T cR[4] = {T(0), T(0), T(0), T(1)};          // carried incre_r (identity before the first step)
   T cV[3] = {T(0), T(0), T(0)}, cP[3] = {T(0), T(0), T(0)}, cT = T(0);
+  // software pipeline: the inputs of chunk c+1 are requested before the scans of chunk c run (one wave owns a
+  // whole sequence, so without this every chunk would pay the full HBM latency on its critical path)
+  T nh = T(0), ng[3] = {T(0), T(0), T(0)}, na[3] = {T(0), T(0), T(0)}, nr[4] = {T(0), T(0), T(0), T(1)};
+  auto fetch = [&](int64_t c0) {
+    const int64_t f = c0 + lane;
+    const bool ok = f < F;
+    const int64_t row = b * F + (ok ? f : 0);
+    nh = ok ? dt[row] : T(0);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { ng[k] = ok ? gyro[row * 3 + k] : T(0); na[k] = ok ? acc[row * 3 + k] : T(0); }
+    if (rot_known) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) nr[k] = ok ? rot_known[row * 4 + k] : (k == 3 ? T(1) : T(0));
+    }
+  };
+  fetch(0);
   for (int64_t c0 = 0; c0 < F; c0 += 64) {
     const int64_t f = c0 + lane;
     const bool valid = f < F;
     const int64_t row = b * F + (valid ? f : 0);
-    const T h = valid ? dt[row] : T(0);
-    T w[3], am[3];
+    const T h = nh;
+    T w[3], am[3], rkn[4];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) { w[k] = valid ? gyro[row * 3 + k] * h : T(0); am[k] = valid ? acc[row * 3 + k] : T(0); }
+    for (int k = 0; k < 3; ++k) { w[k] = ng[k] * h; am[k] = na[k]; }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) rkn[k] = nr[k];
+    if (c0 + 64 < F) fetch(c0 + 64);
     T dr[4];
     so3_exp<T>(w, dr);
     T P[4] = {dr[0], dr[1], dr[2], dr[3]};
     wave_scan<T, MulSO3<T>>(P, cR, true, false, lane);            // inclusive: incre_r[f+1]
-    T Pex[4];
-    shfl_up_vec<T, 4>(P, Pex, 1);
-    if (lane == 0) { Pex[0] = cR[0]; Pex[1] = cR[1]; Pex[2] = cR[2]; Pex[3] = cR[3]; }   // incre_r[f]
+    T Pex[4];                                                     // incre_r[f]: lane-1's product, the carry for lane 0
+#pragma unroll
+    for (int k = 0; k < 4; ++k) Pex[k] = lane_shift_up1(P[k], cR[k]);
     // acceleration in the body frame minus gravity
     T Rw[4];
     if (rot_known) {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) Rw[k] = valid ? rot_known[row * 4 + k] : (k == 3 ? T(1) : T(0));
+      for (int k = 0; k < 4; ++k) Rw[k] = rkn[k];
     } else {
       so3_mul<T>(R0, P, Rw);
     }
@@ -195,8 +265,8 @@ imu_integrate_kernel(const T* __restrict__ dt, const T* __restrict__ gyro, const
     }
     bcast_vec<T, 4>(P, cR, 63);
 #pragma unroll
-    for (int k = 0; k < 3; ++k) { cV[k] = __shfl(Dv[k], 63, 64); cP[k] = __shfl(Dp[k], 63, 64); }
-    cT = __shfl(Dt, 63, 64);
+    for (int k = 0; k < 3; ++k) { cV[k] = lane_bcast63(Dv[k]); cP[k] = lane_bcast63(Dp[k]); }
+    cT = lane_bcast63(Dt);
   }
 }
 
@@ -228,20 +298,12 @@ template <class T> __device__ __forceinline__ void quat_to_matrix(const T* q, T*
 //   X_k = M1_k S_{k+1} + X_{k+1}               (suffix sum of G_k := M1_k S_{k+1})
 //   Y_k = h_k/2 G_k + h_k X_{k+1} + Y_{k+1}    (suffix sum)
 //   t_k = h_k + t_{k+1}                        (suffix sum)
-// so all P_k come from wave-level suffix scans, and  cov = P_0 C_0 P_0^T + sum_{j=0}^{F-1} P_{j+1} Bc(j) P_{j+1}^T,
+// so all P_k come from wave-level scans (lanes hold the chunk's steps in reverse order), and  cov = P_0 C_0 P_0^T + sum_{j=0}^{F-1} P_{j+1} Bc(j) P_{j+1}^T,
 //   P Bc P^T = V (h Cg) V^T + U (h Ca) U^T,  V = [S; X; Y] Jr_j,  U = [0; Rij_j; (t + h_j/2) Rij_j],
 // is a sum over steps that each lane accumulates privately (45 symmetric entries) and the wave reduces
 // once.  One wavefront per sequence walks it backwards in 64-step chunks; no step depends on another
 // except through the scans' carried values.
 // ---------------------------------------------------------------------------------------------
-template <class T> __device__ __forceinline__ T suffix_sum(T v, T carry, int lane) {
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    T u = __shfl_down(v, off, 64);
-    if (lane + off < 64) v += u;
-  }
-  return v + carry;
-}
 template <class T> __device__ __forceinline__ void mat3_mul(const T* A, const T* B, T* C) {
 #pragma unroll
   for (int i = 0; i < 3; ++i)
@@ -266,29 +328,35 @@ imu_cov_scan_kernel(const T* __restrict__ dt, const T* __restrict__ rk, const T*
   for (int i = 0; i < 45; ++i) acc[i] = T(0);
 
   const int64_t nchunks = (F + 63) / 64;
+  // software pipeline (as in imu_integrate_kernel): the next (earlier) chunk's inputs are in flight during the scans
+  T nh = T(0), nq[4] = {T(0), T(0), T(0), T(1)}, nqij[4] = {T(0), T(0), T(0), T(1)}, nav[3] = {T(0), T(0), T(0)};
+  auto fetch = [&](int64_t ch) {
+    const int64_t jj = ch * 64 + (63 - lane);
+    const bool ok = jj < F;
+    const int64_t row = b * F + (ok ? jj : 0);
+    nh = ok ? dt[row] : T(0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { nq[i] = ok ? rk[row * 4 + i] : (i == 3 ? T(1) : T(0)); nqij[i] = ok ? rij[row * 4 + i] : (i == 3 ? T(1) : T(0)); }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) nav[i] = ok ? a[row * 3 + i] : T(0);
+  };
+  fetch(nchunks - 1);
   for (int64_t ch = nchunks - 1; ch >= 0; --ch) {
-    const int64_t j = ch * 64 + lane;
+    const int64_t j = ch * 64 + (63 - lane);   // lanes walk the chunk backwards: a suffix over steps is a prefix over lanes
     const bool valid = j < F;
-    const int64_t row = b * F + (valid ? j : 0);
-    const T h = valid ? dt[row] : T(0);
+    const T h = nh;
     T q[4], qij[4], av[3];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { q[i] = valid ? rk[row * 4 + i] : (i == 3 ? T(1) : T(0)); qij[i] = valid ? rij[row * 4 + i] : (i == 3 ? T(1) : T(0)); }
+    for (int i = 0; i < 4; ++i) { q[i] = nq[i]; qij[i] = nqij[i]; }
 #pragma unroll
-    for (int i = 0; i < 3; ++i) av[i] = valid ? a[row * 3 + i] : T(0);
+    for (int i = 0; i < 3; ++i) av[i] = nav[i];
+    if (ch > 0) fetch(ch - 1);
     // ---- S: suffix product of inverse increments, s_j = dr_j^-1 * s_{j+1}
     T sv[4] = {-q[0], -q[1], -q[2], q[3]};
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      T u[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) u[i] = __shfl_down(sv[i], off, 64);
-      if (lane + off < 64) { T t4[4]; so3_mul<T>(sv, u, t4); sv[0] = t4[0]; sv[1] = t4[1]; sv[2] = t4[2]; sv[3] = t4[3]; }
-    }
-    { T t4[4]; so3_mul<T>(sv, cS, t4); sv[0] = t4[0]; sv[1] = t4[1]; sv[2] = t4[2]; sv[3] = t4[3]; }   // inclusive S_j
+    wave_scan<T, MulSO3<T>>(sv, cS, true, true, lane);             // inclusive S_j = dr_j^-1 ... dr_last^-1 * carry
     T sx[4];                                   // exclusive S_{j+1}
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { T d = __shfl_down(sv[i], 1, 64); sx[i] = lane == 63 ? cS[i] : d; }
+    for (int i = 0; i < 4; ++i) sx[i] = lane_shift_up1(sv[i], cS[i]);
     // ---- G_j = M1_j S_{j+1},  M1_j = -h Rij skew(a)
     T Rj[9], Sx[9], M1[9], G[9];
     quat_to_matrix<T>(qij, Rj);
@@ -304,19 +372,16 @@ imu_cov_scan_kernel(const T* __restrict__ dt, const T* __restrict__ rk, const T*
     T X[9], Xx[9], Y[9], Yx[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i) {
-      X[i] = suffix_sum(G[i], cX[i], lane);
-      T d = __shfl_down(X[i], 1, 64);
-      Xx[i] = lane == 63 ? cX[i] : d;
+      X[i] = wave_prefix_add(G[i]) + cX[i];
+      Xx[i] = lane_shift_up1(X[i], cX[i]);
     }
 #pragma unroll
     for (int i = 0; i < 9; ++i) {
-      Y[i] = suffix_sum(T(0.5) * h * G[i] + h * Xx[i], cY[i], lane);
-      T d = __shfl_down(Y[i], 1, 64);
-      Yx[i] = lane == 63 ? cY[i] : d;
+      Y[i] = wave_prefix_add(T(0.5) * h * G[i] + h * Xx[i]) + cY[i];
+      Yx[i] = lane_shift_up1(Y[i], cY[i]);
     }
-    const T tin = suffix_sum(h, ct, lane);
-    const T tdn = __shfl_down(tin, 1, 64);     // (shuffles stay outside any lane-dependent expression:
-    const T tx = lane == 63 ? ct : tdn;        //  an inactive source lane reads as garbage)
+    const T tin = wave_prefix_add(h) + ct;
+    const T tx = lane_shift_up1(tin, ct);
     // ---- this step's term  P_{j+1} Bc(j) P_{j+1}^T
     if (valid) {
       T phi[3], Jr[9], V[27];
@@ -329,26 +394,41 @@ imu_cov_scan_kernel(const T* __restrict__ dt, const T* __restrict__ rk, const T*
 #pragma unroll
       for (int i = 0; i < 3; ++i) { dg[i] = h * gyro_cov[b * gc_sb + j * gc_sf + i]; da[i] = h * acc_cov[b * ac_sb + j * ac_sf + i]; }
       const T tu = tx + T(0.5) * h;            // U = [0; Rj; tu Rj]
+      // V (h Cg) V^T with the scaled copy Vd = V diag(h Cg) formed once: 3 FMAs per entry of the upper triangle
+      T Vd[27];
+#pragma unroll
+      for (int r = 0; r < 9; ++r)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) Vd[r * 3 + k] = V[r * 3 + k] * dg[k];
+      // Rj (h Ca) Rj^T once (symmetric 3x3); U (h Ca) U^T is that block times 1, tu or tu^2
+      T Wa[9];
+#pragma unroll
+      for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+        for (int cc = rr; cc < 3; ++cc) {
+          const T w = Rj[rr * 3] * da[0] * Rj[cc * 3] + Rj[rr * 3 + 1] * da[1] * Rj[cc * 3 + 1] + Rj[rr * 3 + 2] * da[2] * Rj[cc * 3 + 2];
+          Wa[rr * 3 + cc] = w;
+          Wa[cc * 3 + rr] = w;
+        }
       int e = 0;
 #pragma unroll
       for (int r = 0; r < 9; ++r)
 #pragma unroll
         for (int c = r; c < 9; ++c, ++e) {
-          T sacc = V[r * 3] * dg[0] * V[c * 3] + V[r * 3 + 1] * dg[1] * V[c * 3 + 1] + V[r * 3 + 2] * dg[2] * V[c * 3 + 2];
+          T sacc = Vd[r * 3] * V[c * 3] + Vd[r * 3 + 1] * V[c * 3 + 1] + Vd[r * 3 + 2] * V[c * 3 + 2];
           if (r >= 3) {                        // U rows 0..2 are zero
-            const T fr = r < 6 ? T(1) : tu, fc = c < 6 ? T(1) : tu;
-            const int rr = r % 3, cc = c % 3;
-            sacc += fr * fc * (Rj[rr * 3] * da[0] * Rj[cc * 3] + Rj[rr * 3 + 1] * da[1] * Rj[cc * 3 + 1] + Rj[rr * 3 + 2] * da[2] * Rj[cc * 3 + 2]);
+            const T f = (r < 6 ? T(1) : tu) * (c < 6 ? T(1) : tu);
+            sacc += f * Wa[(r % 3) * 3 + (c % 3)];
           }
           acc[e] += sacc;
         }
     }
-    // ---- carries for the next (earlier) chunk: the inclusive values of lane 0
+    // ---- carries for the next (earlier) chunk: the inclusive values of the chunk's first step (lane 63)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) cS[i] = __shfl(sv[i], 0, 64);
+    for (int i = 0; i < 4; ++i) cS[i] = lane_bcast63(sv[i]);
 #pragma unroll
-    for (int i = 0; i < 9; ++i) { cX[i] = __shfl(X[i], 0, 64); cY[i] = __shfl(Y[i], 0, 64); }
-    ct = __shfl(tin, 0, 64);
+    for (int i = 0; i < 9; ++i) { cX[i] = lane_bcast63(X[i]); cY[i] = lane_bcast63(Y[i]); }
+    ct = lane_bcast63(tin);
   }
   // wave reduction of the per-lane partial sums
 #pragma unroll
