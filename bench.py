@@ -167,6 +167,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--rows", type=int, default=10_000_000, help="rows per GPU (BASELINE configs[1]: 10M)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip lm_pgo / lm_invnet (clean rocprof kernel statistics)")
     a = ap.parse_args()
     import torch
 
@@ -248,7 +249,7 @@ def main():
                          "traffic": traffic, "algorithmic_bytes_per_launch": B * BYTES_PER_ROW[dom],
                          "avg_launch_ms": ms_dom, "other_kernel_ms": {"se3_exp_fwd": ms_exp, "se3_log_fwd": ms_log}},
         }
-        if world == 1:
+        if world == 1 and not a.no_secondary:
             import gc
             gc.collect()
             gc.freeze()                   # (a gen-2 collection with torch loaded is a 40-70 ms pause)
