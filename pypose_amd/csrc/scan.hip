@@ -410,11 +410,11 @@ imu_cov_scan_kernel(const T* __restrict__ dt, const T* __restrict__ rk, const T*
           Wa[rr * 3 + cc] = w;
           Wa[cc * 3 + rr] = w;
         }
-      int e = 0;
 #pragma unroll
       for (int r = 0; r < 9; ++r)
 #pragma unroll
-        for (int c = r; c < 9; ++c, ++e) {
+        for (int c = r; c < 9; ++c) {
+          const int e = r * 9 - (r * (r - 1)) / 2 + (c - r);      // index in the packed upper triangle
           T sacc = Vd[r * 3] * V[c * 3] + Vd[r * 3 + 1] * V[c * 3 + 1] + Vd[r * 3 + 2] * V[c * 3 + 2];
           if (r >= 3) {                        // U rows 0..2 are zero
             const T f = (r < 6 ? T(1) : tu) * (c < 6 ? T(1) : tu);
@@ -456,9 +456,13 @@ imu_cov_scan_kernel(const T* __restrict__ dt, const T* __restrict__ rk, const T*
     for (int i = 0; i < 3; ++i) { P[(3 + i) * 9 + 3 + i] = T(1); P[(6 + i) * 9 + 3 + i] = ct; P[(6 + i) * 9 + 6 + i] = T(1); }
     // the accumulated step terms are symmetric by construction; P_0 init_cov P_0^T is formed in full
     // (the reference does not symmetrise a caller-supplied init_cov)
-    int e = 0;
+    // (fully unrolled: a run-time index into acc[] would move the 45 accumulators of EVERY lane to scratch
+    //  memory for the whole kernel -- measured as 706 MB of HBM writes per launch before this pragma)
+#pragma unroll
     for (int r = 0; r < 9; ++r)
-      for (int c = r; c < 9; ++c, ++e) {
+#pragma unroll
+      for (int c = r; c < 9; ++c) {
+        const int e = r * 9 - (r * (r - 1)) / 2 + (c - r);
         cov[b * 81 + r * 9 + c] = acc[e];
         cov[b * 81 + c * 9 + r] = acc[e];
       }

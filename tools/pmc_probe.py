@@ -1,5 +1,7 @@
-"""Launch the copy / SE3 Exp / SE3 Log kernels a few times at 10M rows so that rocprofv3 --pmc
-can attribute FETCH_SIZE / WRITE_SIZE per dispatch (tools/gpu_pmc.sh post-processes the CSVs)."""
+"""Launch the dominant kernels a few times so that rocprofv3 --pmc can attribute FETCH_SIZE / WRITE_SIZE per
+dispatch (tools/gpu_pmc.sh post-processes the CSVs): copy / SE3 Exp / SE3 Log at 10M rows, the fused LM trial
+kernel at 1M problems, the pose-graph linearise / assemble / SpMV kernels at 100k nodes / 400k edges, and the
+IMU kernels at 4096 x 1024."""
 import ctypes, sys
 import torch
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -18,5 +20,37 @@ for _ in range(3):
     fcopy(src.data_ptr(), dst.data_ptr(), N * 24, 16384, st)     # calibration: 240 MB read + 240 MB written
     X = x.Exp()
     y = X.Log()
+torch.cuda.synchronize()
+del x, X, y, src, dst
+
+# C3: fused InvNet trial kernel, 1M problems (136 B / problem algorithmic)
+from tests.optim_models import InvNet, PoseGraph
+from tests.test_optim_gpu import _synthetic_graph
+B = 1_000_000
+net = InvNet(pp.randn_SE3(B, device=dev))
+inp = pp.randn_SE3(B, device=dev)
+opt = pp.optim.LM(net, strategy=pp.optim.strategy.Constant(damping=1e-4))
+for _ in range(3):
+    opt.step(inp)
+torch.cuda.synchronize()
+del net, inp, opt
+
+# C4: pose graph 100k / 400k
+edges, rel, init = _synthetic_graph(100_000, 400_000, torch.float32)
+graph = PoseGraph(init)
+opt = pp.optim.LM(graph, solver=pp.optim.solver.PCG(tol=1e-4, maxiter=64), strategy=pp.optim.strategy.TrustRegion(radius=1e4))
+for _ in range(2):
+    opt.step((edges, rel))
+torch.cuda.synchronize()
+del graph, opt
+
+# C5: IMU 4096 x 1024 with covariance
+Bq, F = 4096, 1024
+dt = torch.full((Bq, F, 1), 0.005, device=dev)
+gyro = 0.1 * torch.randn(Bq, F, 3, device=dev)
+acc = torch.randn(Bq, F, 3, device=dev) + torch.tensor([0., 0., 9.81], device=dev)
+integ = pp.module.IMUPreintegrator(prop_cov=True, reset=True).to(dev)
+for _ in range(2):
+    integ(dt=dt, gyro=gyro, acc=acc)
 torch.cuda.synchronize()
 print("done")
