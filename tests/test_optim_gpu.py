@@ -273,3 +273,60 @@ def test_c4_pose_graph_10k_and_100k():
         assert opt.linearization == "fused:pgo"
         assert all(b <= a * (1 + 1e-6) for a, b in zip([l_init] + losses, losses)), (l_init, losses)
         assert losses[-1] < 0.2 * l_init, (N, l_init, losses)
+
+
+@pytest.mark.parametrize("group,prior", [("SO3", False), ("Sim3", False), ("SE3", True), ("SO3", True)])
+def test_graph_kernels_other_groups_match_dense_path(group, prior):
+    """The (3,3,2) / (7,7,2) pose-graph and the (6,6,1) / (3,3,1) prior instantiations of the graph kernels: LM on the
+    HIP graph path == LM on the dense reference algorithm (fp64), for SO3 / Sim3 graphs and unary priors."""
+    torch.manual_seed(5)
+    rand = getattr(pp, "randn_" + group)
+    N, E = 30, 80
+    gt = rand(N, sigma=0.4, device=DEV, dtype=torch.float64)
+    e = torch.stack([torch.randint(0, N, (E,)), torch.randint(0, N, (E,))], -1)
+    e[:, 1] = torch.where(e[:, 0] == e[:, 1], (e[:, 1] + 1) % N, e[:, 1])
+    e = e.to(DEV)
+    init = gt @ rand(N, sigma=0.05, device=DEV, dtype=torch.float64)
+
+    class Graph(torch.nn.Module):
+        def __init__(self, nodes):
+            super().__init__()
+            self.nodes = pp.Parameter(nodes)
+
+        def forward(self, edges, rel):
+            n1, n2 = self.nodes[edges[..., 0]], self.nodes[edges[..., 1]]
+            return (rel.Inv() @ n1.Inv() @ n2).Log().tensor()
+
+    class Prior(torch.nn.Module):                      # unary factors: one gather per residual row
+        def __init__(self, nodes):
+            super().__init__()
+            self.nodes = pp.Parameter(nodes)
+
+        def forward(self, idx, meas):
+            return (meas.Inv() @ self.nodes[idx]).Log().tensor()
+
+    if prior:
+        idx = torch.cat([torch.arange(N), torch.randint(0, N, (E - N,))]).to(DEV)
+        args = (idx, gt[idx] @ rand(E, sigma=0.01, device=DEV, dtype=torch.float64))
+        make = lambda: Prior(init.clone())
+    else:
+        args = (e, gt[e[:, 0]].Inv() @ gt[e[:, 1]] @ rand(E, sigma=0.01, device=DEV, dtype=torch.float64))
+        make = lambda: Graph(init.clone())
+    res = {}
+    for mode in ("dense", "graph"):
+        model = make()
+        opt = pp.optim.LM(model, solver=pp.optim.solver.Cholesky(), strategy=pp.optim.strategy.TrustRegion(radius=1e4))
+        opt.structured, opt.fused = mode != "dense", False
+        losses = [float(opt.step(args)) for _ in range(4)]
+        assert opt.linearization == mode
+        res[mode] = (losses, model.nodes.detach().tensor().clone())
+    for a, b in zip(res["dense"][0], res["graph"][0]):
+        assert abs(a - b) <= 1e-8 * max(abs(a), 1e-30) + 1e-20, res
+    assert (res["dense"][1] - res["graph"][1]).abs().max().item() < 1e-7
+    # and the matrix-free PCG on the same kernels (bsr spmv for m in {3, 6, 7})
+    model = make()
+    opt = pp.optim.LM(model, solver=pp.optim.solver.PCG(tol=1e-13, maxiter=3000, check_every=1), strategy=pp.optim.strategy.TrustRegion(radius=1e4))
+    opt.fused = False
+    losses = [float(opt.step(args)) for _ in range(4)]
+    for a, b in zip(res["dense"][0], losses):
+        assert abs(a - b) <= 1e-6 * max(abs(a), 1e-30) + 1e-18, (res["dense"][0], losses)
