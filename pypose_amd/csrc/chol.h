@@ -45,6 +45,18 @@ template <class T, int DP> struct Op_chol_solve {
 };
 
 
+// X = A^-1 for an SPD block A (Cholesky, then the columns of the identity one by one)
+template <class T, int DP> PP_HD void Op_spd_inverse_apply(const T* A, T* X) {
+#pragma unroll
+  for (int c = 0; c < DP; ++c) {
+    T g[DP], x[DP];
+#pragma unroll
+    for (int i = 0; i < DP; ++i) g[i] = (i == c) ? T(-1) : T(0);
+    Op_chol_solve<T, DP>::apply(A, g, nullptr, x, nullptr);
+#pragma unroll
+    for (int i = 0; i < DP; ++i) X[i * DP + c] = x[i];
+  }
+}
 template <class T> PP_HD void Op_chol6_solve(const T* A, const T* g, T* x) { Op_chol_solve<T, 6>::apply(A, g, nullptr, x, nullptr); }
 
 }  // namespace pplie

@@ -14,6 +14,7 @@
 // LDS with dwordx4 like every other kernel here), W [E][DR][DR], idx [E][K] int64,
 // node vectors [N][M].  Scatter uses hardware fp atomics (-munsafe-fp-atomics).
 #include "rowmap.h"
+#include "chol.h"
 
 namespace pplie {
 
@@ -599,4 +600,145 @@ extern "C" int pplie_segment_sum_f32(const void* vals, const void* perm, const v
 }
 extern "C" int pplie_segment_sum_f64(const void* vals, const void* perm, const void* ptr, void* out, int64_t N, int w, void* stream) {
   return pplie::segment_sum<double>(vals, perm, ptr, out, N, w, stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+// PCG set-up in one launch (was ~20 small tensor ops per LM trial step).  Per node n, with B_n the raw diagonal
+// block and g_n the gradient of the normal equations, s = prod(1 + damping):
+//   D_n    = B_n with its diagonal replaced by s * clamp(diag, dmin, dmax)     (optimizer.py:656-657, :666)
+//   shift  = s * clamp(diag) - diag            (the matrix-free path adds it to H p)
+//   Binv_n = D_n^-1 (Cholesky)                 block-Jacobi preconditioner
+//   x = 0,  r = -g,  z = Binv r,  p = z
+//   scal set 0: rho += r.z ;  quantity 3 (otherwise unused) += g.g = |b|^2     (scal / it zeroed by the caller)
+// One lane per node.
+// ---------------------------------------------------------------------------------------------
+namespace pplie {
+enum { Q_BN2 = 3 };
+template <class T, int M>
+__global__ void __launch_bounds__(256)
+pcg_prepare_kernel(const T* __restrict__ B, const T* __restrict__ g, T* __restrict__ D, T* __restrict__ Binv,
+                   T* __restrict__ shift, T* __restrict__ x, T* __restrict__ r, T* __restrict__ z, T* __restrict__ p,
+                   T* scal, T s, T dmin, T dmax, int64_t N) {
+  T a_rho = T(0), a_bn = T(0);
+  for (int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x; n < N; n += (int64_t)gridDim.x * 256) {
+    T A[M * M], X[M * M], rv[M];
+#pragma unroll
+    for (int i = 0; i < M * M; ++i) A[i] = B[n * M * M + i];
+#pragma unroll
+    for (int i = 0; i < M; ++i) {
+      const T d = A[i * M + i];
+      const T c = s * (d < dmin ? dmin : (d > dmax ? dmax : d));
+      shift[n * M + i] = c - d;
+      A[i * M + i] = c;
+      rv[i] = -g[n * M + i];
+      a_bn += rv[i] * rv[i];
+    }
+    Op_spd_inverse_apply<T, M>(A, X);
+#pragma unroll
+    for (int i = 0; i < M * M; ++i) { D[n * M * M + i] = A[i]; Binv[n * M * M + i] = X[i]; }
+#pragma unroll
+    for (int i = 0; i < M; ++i) {
+      T zi = T(0);
+#pragma unroll
+      for (int j = 0; j < M; ++j) zi += X[i * M + j] * rv[j];
+      x[n * M + i] = T(0);
+      r[n * M + i] = rv[i];
+      z[n * M + i] = zi;
+      p[n * M + i] = zi;
+      a_rho += rv[i] * zi;
+    }
+  }
+  T s1 = block_sum(a_rho);
+  T s2 = block_sum(a_bn);
+  if (threadIdx.x == 0) {
+    slot_add(squant(scal, 0, Q_RHO), s1);
+    slot_add(squant(scal, 0, Q_BN2), s2);
+  }
+}
+template <class T>
+int pcg_prepare(const void* B, const void* g, void* D, void* Binv, void* shift, void* x, void* r, void* z, void* p, void* scal,
+                double s, double dmin, double dmax, int64_t N, int m, void* stream) {
+  if (N <= 0) return N == 0 ? PPLIE_OK : PPLIE_EBADARG;
+  if (!B || !g || !D || !Binv || !shift || !x || !r || !z || !p || !scal) return PPLIE_EBADARG;
+  int64_t nb = (N + 255) / 256;
+  int grid = (int)(nb < 2048 ? nb : 2048);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+#define LAUNCH(MM)                                                                                                      \
+  hipLaunchKernelGGL((pcg_prepare_kernel<T, MM>), dim3(grid), dim3(256), 0, st, (const T*)B, (const T*)g, (T*)D, (T*)Binv, \
+                     (T*)shift, (T*)x, (T*)r, (T*)z, (T*)p, (T*)scal, (T)s, (T)dmin, (T)dmax, N);
+  if (m == 6) { LAUNCH(6) } else if (m == 7) { LAUNCH(7) } else if (m == 3) { LAUNCH(3) } else return PPLIE_EBADARG;
+#undef LAUNCH
+  return hipGetLastError() == hipSuccess ? PPLIE_OK : PPLIE_ELAUNCH;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Gain-ratio terms of the damping strategies (strategy.py:144, :261) without forming J D:
+//   JD_e = sum_k J[e,k] d[idx[e,k], :M] ;  partial[w] = { sum JD.JD, sum JD.R } per workgroup w (caller-zeroed
+//   [PPLIE_GAIN_PARTIALS, 2]).  d is the step with row stride `ld` (the zero-padded group width).
+// ---------------------------------------------------------------------------------------------
+constexpr int kGainPartials = 1024;
+template <class T, int DR, int M, int K>
+__global__ void __launch_bounds__(256)
+graph_gain_kernel(const T* __restrict__ J, const int64_t* __restrict__ idx, const T* __restrict__ d, int ld,
+                  const T* __restrict__ R, T* __restrict__ partial, int64_t E) {
+  T a1 = T(0), a2 = T(0);
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < E; e += (int64_t)gridDim.x * 256) {
+    T jd[DR];
+#pragma unroll
+    for (int i = 0; i < DR; ++i) jd[i] = T(0);
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const int64_t n = idx[e * K + k];
+      T dv[M];
+#pragma unroll
+      for (int j = 0; j < M; ++j) dv[j] = d[n * ld + j];
+      const T* Jk = J + (e * K + k) * (DR * M);
+#pragma unroll
+      for (int i = 0; i < DR; ++i)
+#pragma unroll
+        for (int j = 0; j < M; ++j) jd[i] += Jk[i * M + j] * dv[j];
+    }
+#pragma unroll
+    for (int i = 0; i < DR; ++i) { a1 += jd[i] * jd[i]; a2 += jd[i] * R[e * DR + i]; }
+  }
+  T s1 = block_sum(a1);
+  T s2 = block_sum(a2);
+  if (threadIdx.x == 0) { partial[blockIdx.x * 2] = s1; partial[blockIdx.x * 2 + 1] = s2; }
+}
+template <class T, int DR, int M, int K>
+int graph_gain_launch(const void* J, const void* idx, const void* d, int ld, const void* R, void* partial, int64_t E, void* stream) {
+  if (E <= 0) return E == 0 ? PPLIE_OK : PPLIE_EBADARG;
+  if (!J || !idx || !d || !R || !partial || ld < M) return PPLIE_EBADARG;
+  int64_t nb = (E + 255) / 256;
+  int grid = (int)(nb < kGainPartials ? nb : kGainPartials);
+  hipLaunchKernelGGL((graph_gain_kernel<T, DR, M, K>), dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     (const T*)J, (const int64_t*)idx, (const T*)d, ld, (const T*)R, (T*)partial, E);
+  return hipGetLastError() == hipSuccess ? PPLIE_OK : PPLIE_ELAUNCH;
+}
+template <class T>
+int graph_gain_dispatch(int dr, int m, int k, const void* J, const void* idx, const void* d, int ld, const void* R, void* partial,
+                        int64_t E, void* stream) {
+#define X(A, B_, C) \
+  if (dr == A && m == B_ && k == C) return graph_gain_launch<T, A, B_, C>(J, idx, d, ld, R, partial, E, stream);
+  PPLIE_GRAPH_SHAPES(X)
+#undef X
+  return PPLIE_EBADARG;
+}
+}  // namespace pplie
+
+extern "C" int pplie_pcg_prepare_f32(const void* B, const void* g, void* D, void* Binv, void* shift, void* x, void* r, void* z,
+                                     void* p, void* scal, double s, double dmin, double dmax, int64_t N, int m, void* stream) {
+  return pplie::pcg_prepare<float>(B, g, D, Binv, shift, x, r, z, p, scal, s, dmin, dmax, N, m, stream);
+}
+extern "C" int pplie_pcg_prepare_f64(const void* B, const void* g, void* D, void* Binv, void* shift, void* x, void* r, void* z,
+                                     void* p, void* scal, double s, double dmin, double dmax, int64_t N, int m, void* stream) {
+  return pplie::pcg_prepare<double>(B, g, D, Binv, shift, x, r, z, p, scal, s, dmin, dmax, N, m, stream);
+}
+extern "C" int pplie_graph_gain_terms_f32(const void* J, const void* idx, const void* d, int ld, const void* R, void* partial,
+                                          int64_t E, int dr, int m, int k, void* stream) {
+  return pplie::graph_gain_dispatch<float>(dr, m, k, J, idx, d, ld, R, partial, E, stream);
+}
+extern "C" int pplie_graph_gain_terms_f64(const void* J, const void* idx, const void* d, int ld, const void* R, void* partial,
+                                          int64_t E, int dr, int m, int k, void* stream) {
+  return pplie::graph_gain_dispatch<double>(dr, m, k, J, idx, d, ld, R, partial, E, stream);
 }

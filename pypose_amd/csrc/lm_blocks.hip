@@ -54,17 +54,7 @@ namespace pplie {
 // the columns of the identity are solved one by one.
 template <class T, int DP> struct Op_spd_inverse {
   enum { IW0 = DP * DP, IW1 = 0, IW2 = 0, OW0 = DP * DP, OW1 = 0 };
-  static PP_HD void apply(const T* A, const T*, const T*, T* X, T*) {
-#pragma unroll
-    for (int c = 0; c < DP; ++c) {
-      T g[DP], x[DP];
-#pragma unroll
-      for (int i = 0; i < DP; ++i) g[i] = (i == c) ? T(-1) : T(0);
-      Op_chol_solve<T, DP>::apply(A, g, nullptr, x, nullptr);
-#pragma unroll
-      for (int i = 0; i < DP; ++i) X[i * DP + c] = x[i];
-    }
-  }
+  static PP_HD void apply(const T* A, const T*, const T*, T* X, T*) { Op_spd_inverse_apply<T, DP>(A, X); }
 };
 
 // 64-lane workgroups: the per-problem slabs are wide (up to 8x8 + 8x8 + 8 + 64 scalars)

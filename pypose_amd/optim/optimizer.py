@@ -30,7 +30,7 @@ from . import blocks as _blocks
 from .corrector import FastTriggs
 from .functional import modjac
 from .solver import PINV, Cholesky
-from .strategy import TrustRegion
+from .strategy import Adaptive, Constant, TrustRegion
 
 
 class Trivial(nn.Module):
@@ -340,6 +340,17 @@ class LevenbergMarquardt(_Optimizer):
         return loss
 
     def _strategy_update(self, pg, J, D, R):
+        ab = J.gain_terms(D) if hasattr(J, 'gain_terms') and type(self.strategy) in (Constant, Adaptive, TrustRegion) else None
+        if ab is not None:
+            # pose graphs: (J D).(J D) and (J D).R from one kernel; the built-in strategies only need the gain ratio,
+            # which an equivalent 1x1 problem on the host reproduces (x^2 = a, x r = b) without device round trips
+            if self.group is not None:
+                import torch.distributed as dist
+                dist.all_reduce(ab, group=self.group)
+            a, b = ab.tolist()
+            x = max(a, 1e-300) ** 0.5
+            one = torch.ones((1, 1), dtype=torch.float64)
+            return self.strategy.update(pg, last=float(self.last), loss=float(self.loss), J=one, D=x * one, R=(b / x) * one)
         if self.group is None:
             return self.strategy.update(pg, last=self.last, loss=self.loss, J=J, D=D, R=R)
         # the gain ratio needs the GLOBAL (J D)^T (2 R + J D): all-reduce its two dot products and

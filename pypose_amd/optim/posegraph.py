@@ -38,6 +38,9 @@ from . import blocks as _blocks
 _SPMV_SIG = [ctypes.c_void_p] * 5 + [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
 _ASM_SIG = [ctypes.c_void_p] * 7 + [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
 _ASMC_SIG = [ctypes.c_void_p] * 8 + [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+_PREP_SIG = [ctypes.c_void_p] * 10 + [ctypes.c_double] * 3 + [ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]
+_GAIN_SIG = [ctypes.c_void_p] * 3 + [ctypes.c_int] + [ctypes.c_void_p] * 2 + [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+_GAIN_PARTIALS = 1024       # PPLIE_GAIN_PARTIALS
 _BSR_SIG = [ctypes.c_void_p] * 8 + [ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]
 _PCG_SCAL_ELEMS = 2 * 4 * 32 * 32          # PPLIE_PCG_SCAL_ELEMS: two sets of slot-spread scalars (csrc/graph.hip)
 _INV_SIG = [ctypes.c_void_p] * 2 + [ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]
@@ -220,38 +223,38 @@ class FusedPCG:
                          self.it.data_ptr(), self.cap, self.N, self.m, st)
             _C.check(code, "pplie_pcg_stage")
 
-    def solve(self, lin, b, shift, Binv, Bd, tol, maxiter, group):
+    def solve(self, lin, s, dmin, dmax, tol, maxiter, group):
+        """Solve (H + damping) x = -g for the linearisation ``lin`` (raw block diagonal ``lin.B``, gradient ``lin.g``)
+        with the LM clamp [dmin, dmax] and compounded damping factor ``s`` folded in by ``pplie_pcg_prepare``."""
         bsr = lin.HB is not None and group is None and self.m in (3, 6, 7)
         if bsr != getattr(self, 'bsr', None):
             self.graph = None                                       # the captured iteration differs
         self.bsr = bsr
+        if getattr(self, 'D', None) is None:
+            self.D = torch.empty((self.N, self.m, self.m), dtype=self.J.dtype, device=self.J.device)
         if bsr:
             self._csr(lin)
             if getattr(self, 'HB', None) is None:
                 self.HB = torch.empty_like(lin.HB)
-                self.D = torch.empty((self.N, self.m, self.m), dtype=self.J.dtype, device=self.J.device)
             self.HB.copy_(lin.HB)                                   # off-diagonal blocks in incidence order
-            self.D.copy_(Bd)                                        # diagonal blocks incl. clamp + damping
         else:
             self.J.copy_(lin.J)
             self.idx.copy_(lin.idx)
             if self.W is not None:
                 self.W.copy_(lin.W)
-        self.Binv.copy_(Binv)
-        self.shift.copy_(shift)
-        self.x.zero_()
-        self.r.copy_(b)
-        self.z.copy_((self.Binv * self.r.unsqueeze(-2)).sum(-1))
-        self.p.copy_(self.z)
         self.scal.zero_()
-        self.scal[0] = (self.r * self.z).sum()
         self.it.zero_()
-        bn2 = float((b * b).sum())
-        if bn2 == 0.0:
-            return self.x.clone(), 0
-        maxiter = min(maxiter, self.cap - self.check_every)
-        done = 0
         with torch.cuda.device(self.J.device):
+            # one launch: D = clamped + damped block diagonal, Binv = D^-1, shift, x = 0, r = -g, z = Binv r, p = z, r.z, |g|^2
+            code = _C.library().symbol("pplie_pcg_prepare" + self.sfx, _PREP_SIG)(
+                lin.B.data_ptr(), lin.g.data_ptr(), self.D.data_ptr(), self.Binv.data_ptr(), self.shift.data_ptr(),
+                self.x.data_ptr(), self.r.data_ptr(), self.z.data_ptr(), self.p.data_ptr(), self.scal.data_ptr(),
+                float(s), float(dmin), float(dmax), self.N, self.m, _C.stream_ptr(self.J.device))
+            _C.check(code, "pplie_pcg_prepare")
+            bn2_slots = self.scal.view(2, 4, 32, 32)[0, 3, :, 0]    # |b|^2 spread over 32 slots (csrc/graph.hip)
+            bn2 = None
+            maxiter = min(maxiter, self.cap - self.check_every)
+            done = 0
             while done < maxiter:
                 if group is None and self.graph is None and done > 0:
                     g = torch.cuda.CUDAGraph()
@@ -265,7 +268,14 @@ class FusedPCG:
                     for _ in range(self.check_every):
                         self._iteration(group)
                 done += self.check_every
-                if float(self.rr_hist[done - 1]) <= tol * tol * bn2:
+                if bn2 is None:                                     # first check: |b|^2 comes back with the residual norm
+                    vals = torch.cat([self.rr_hist[done - 1:done], bn2_slots]).tolist()
+                    rr, bn2 = vals[0], sum(vals[1:])
+                    if bn2 == 0.0:
+                        return self.x.clone(), 0
+                else:
+                    rr = float(self.rr_hist[done - 1])
+                if rr <= tol * tol * bn2:
                     break
         return self.x.clone(), done
 
@@ -275,6 +285,21 @@ class GraphOperator:
 
     def __init__(self, lin):
         self.lin = lin
+
+    def gain_terms(self, D):
+        """device tensor [(J D).(J D), (J D).R] from one kernel (pplie_graph_gain_terms), or None off the HIP path"""
+        lin = self.lin
+        if not lin._hip():
+            return None
+        Dn = D.reshape(lin.N, lin.wfull)
+        Dn = Dn if Dn.is_contiguous() else Dn.contiguous()
+        part = torch.zeros((_GAIN_PARTIALS, 2), dtype=Dn.dtype, device=Dn.device)
+        fn = _C.library().symbol("pplie_graph_gain_terms" + ("_f32" if Dn.dtype == torch.float32 else "_f64"), _GAIN_SIG)
+        with torch.cuda.device(Dn.device):
+            code = fn(lin.J.data_ptr(), lin.idx.data_ptr(), Dn.data_ptr(), lin.wfull, lin.R.data_ptr(), part.data_ptr(),
+                      lin.E, lin.dr, lin.m, lin.K, _C.stream_ptr(Dn.device))
+        _C.check(code, "pplie_graph_gain_terms")
+        return part.sum(0)
 
     def __matmul__(self, D):
         lin = self.lin
@@ -392,23 +417,29 @@ class GraphLinearization:
     # -- LM interface ------------------------------------------------------------------------------
     def build_normal_equations(self, dmin, dmax):
         self.B, self.g = self._assemble()
-        self.diag_raw = self.B.diagonal(dim1=-2, dim2=-1).clone()
-        self.diag_clamped = self.diag_raw.clamp(dmin, dmax)
+        self.dmin, self.dmax = float(dmin), float(dmax)
         # the parameter components outside the tangent space (7th of SE3, ...) have a structurally
         # zero Jacobian column: the reference clamps their diagonal to ``min`` and solves d = 0.
         self.s = 1.0
+
+    @property
+    def diag_raw(self):
+        return self.B.diagonal(dim1=-2, dim2=-1)
+
+    @property
+    def diag_clamped(self):
+        return self.diag_raw.clamp(self.dmin, self.dmax)
 
     def damp(self, damping):
         self.s = self.s * (1.0 + damping)
 
     def solve(self, solver):
         N, m = self.N, self.m
-        shift = self.s * self.diag_clamped - self.diag_raw          # A = H + diag(shift)
-        b = -self.g
         if not isinstance(solver, PCG) and N * m <= DENSE_LIMIT and self.group is None:
+            shift = self.s * self.diag_clamped - self.diag_raw       # A = H + diag(shift)
             A = self.dense_matrix()
             A.diagonal().add_(shift.reshape(-1))
-            Dn = solver(A=A, b=b.reshape(-1, 1)).reshape(N, m)
+            Dn = solver(A=A, b=(-self.g).reshape(-1, 1)).reshape(N, m)
         else:
             if not isinstance(solver, PCG):
                 if not getattr(self.opt, '_warned_pcg', False):
@@ -416,24 +447,21 @@ class GraphLinearization:
                                   f"using the matrix-free block-Jacobi PCG (tol 1e-10) instead.")
                     self.opt._warned_pcg = True
                 solver = PCG(tol=1e-10, maxiter=max(1000, 2 * N))
-            Bd = self.B.clone()
-            Bd.diagonal(dim1=-2, dim2=-1).copy_(self.s * self.diag_clamped)
-            if self._hip() and getattr(solver, 'fused', True):
-                Binv = torch.empty_like(Bd)                          # block-Jacobi preconditioner
-                fn = _C.library().symbol("pplie_block_spd_inverse" + ("_f32" if Bd.dtype == torch.float32 else "_f64"), _INV_SIG)
-                with torch.cuda.device(Bd.device):
-                    _C.check(fn(Bd.data_ptr(), Binv.data_ptr(), N, m, _C.stream_ptr(Bd.device)), "pplie_block_spd_inverse")
+            maxiter = N * m * 10 if solver.maxiter is None else solver.maxiter
+            if self._hip() and getattr(solver, 'fused', True) and m in (3, 6, 7):
                 cache = self.opt.__dict__.setdefault('_pcg_workspaces', {})
                 key = (self.E, self.K, self.dr, self.m, self.N, self.J.dtype, self.J.device, self.W is not None,
                        solver.check_every)
                 wsp = cache.get(key)
                 if wsp is None:
                     wsp = cache[key] = FusedPCG(*key)
-                maxiter = b.numel() * 10 if solver.maxiter is None else solver.maxiter
-                Dn, solver.iterations = wsp.solve(self, b, shift, Binv, Bd, solver.tol, maxiter, self.group)
+                Dn, solver.iterations = wsp.solve(self, self.s, self.dmin, self.dmax, solver.tol, maxiter, self.group)
             else:
+                shift = self.s * self.diag_clamped - self.diag_raw
+                Bd = self.B.clone()
+                Bd.diagonal(dim1=-2, dim2=-1).copy_(self.s * self.diag_clamped)
                 Binv = torch.linalg.inv(Bd)
-                Dn = solver.solve(lambda p: self._Hp(p) + shift * p, b,
+                Dn = solver.solve(lambda p: self._Hp(p) + shift * p, -self.g,
                                   lambda r: (Binv * r.unsqueeze(-2)).sum(-1))
         assert not torch.any(torch.isnan(Dn)), 'Linear solve produced NaN (matrix may not be positive-definite)'
         return self.nodes_to_step(Dn)
