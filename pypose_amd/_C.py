@@ -91,8 +91,32 @@ def check(code: int, what: str):
         raise RuntimeError(f"pypose_amd: {what} failed: {_ERRORS.get(code, code)}")
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream_ptr(device) -> ctypes.c_void_p:
+    """hipStream_t of torch's current stream on ``device`` (the raw-stream query is ~10x cheaper than building a
+    torch.cuda.Stream object; this sits on the launch path of every op)."""
+    if _raw_stream is not None:
+        idx = device.index if isinstance(device, torch.device) else device
+        return ctypes.c_void_p(_raw_stream(torch.cuda.current_device() if idx is None else idx))
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+class _on_device:
+    """``with torch.cuda.device(d)`` only when ``d`` is not already current (the context manager costs ~5 us)."""
+    __slots__ = ("ctx",)
+
+    def __init__(self, device):
+        self.ctx = None if device.index is None or device.index == torch.cuda.current_device() else torch.cuda.device(device)
+
+    def __enter__(self):
+        if self.ctx is not None:
+            self.ctx.__enter__()
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
 
 
 def row_op(name: str, ins, out_widths):
@@ -125,11 +149,12 @@ def row_op(name: str, ins, out_widths):
     if n == 0:
         return outs
     fn = _lib.symbol("pplie_" + name + suffix)
-    pi = [_ptr(t) for t in ins] + [ctypes.c_void_p(0)] * (3 - len(ins))
-    po = [_ptr(t) for t in outs] + [ctypes.c_void_p(0)] * (2 - len(outs))
-    with torch.cuda.device(x0.device):
-        code = fn(*pi, *po, ctypes.c_int64(n), stream_ptr(x0.device))
-    check(code, "pplie_" + name + suffix)
+    pi = [t.data_ptr() for t in ins] + [None] * (3 - len(ins))
+    po = [t.data_ptr() for t in outs] + [None] * (2 - len(outs))
+    with _on_device(x0.device):
+        code = fn(*pi, *po, n, stream_ptr(x0.device))
+    if code:
+        check(code, "pplie_" + name + suffix)
     return outs
 
 
@@ -158,7 +183,8 @@ def param_op(name: str, ins, out_width: int, prm: float):
         return out
     sig = [ctypes.c_void_p] * (len(ins) + 1) + [ctypes.c_double, ctypes.c_int64, ctypes.c_void_p]
     fn = _lib.symbol("pplie_" + name + suffix, sig)
-    with torch.cuda.device(x0.device):
-        code = fn(*[_ptr(t) for t in ins], _ptr(out), float(prm), n, stream_ptr(x0.device))
-    check(code, "pplie_" + name + suffix)
+    with _on_device(x0.device):
+        code = fn(*[t.data_ptr() for t in ins], out.data_ptr(), float(prm), n, stream_ptr(x0.device))
+    if code:
+        check(code, "pplie_" + name + suffix)
     return out

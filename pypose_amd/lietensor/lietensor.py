@@ -389,6 +389,15 @@ class LieTensor(Tensor):
                 rec.note(args[0], args[1], data)
         if data is None or name not in HANDLED_FUNCTIONS:
             return data
+        if type(data) is Tensor and args and isinstance(args[0], LieTensor):
+            # fast path of the common case (method on a LieTensor returning one plain tensor): no pytree walk
+            ltype = args[0].ltype
+            lt = Tensor.as_subclass(data, LieTensor)
+            lt.ltype = ltype
+            if lt.shape[-1:] != ltype.dimension:
+                warnings.warn('Tensor Shape Invalid by calling {}, go to {}'.format(
+                    func, 'https://pypose.org/docs/main/generated/pypose.LieTensor'))
+            return lt
         flat, _ = tree_flatten(args)
         ltype = next(a.ltype for a in flat if isinstance(a, LieTensor))
 
