@@ -87,11 +87,13 @@ class LieType:
         return _ALGEBRA_OF[self._key]
 
     def _fn(self, kind):
-        cap = {"so3": "SO3", "se3": "SE3", "sim3": "Sim3", "rxso3": "RxSO3"}[self._key]
-        name = {"exp": self._key + "_Exp", "log": cap + "_Log", "inv": cap + "_Inv", "mul": cap + "_Mul",
-                "act": cap + "_Act", "act4": cap + "_Act4", "adj": cap + "_AdjXa", "adjt": cap + "_AdjTXa",
-                "jinvp": cap + "_Jinvp"}[kind]
-        return getattr(_op, name)          # resolved at call time (rebinding-friendly)
+        names = self.__dict__.get("_fn_names")
+        if names is None:                  # (built once per type: this sits on the dispatch path of every op)
+            cap = {"so3": "SO3", "se3": "SE3", "sim3": "Sim3", "rxso3": "RxSO3"}[self._key]
+            names = self.__dict__["_fn_names"] = {
+                "exp": self._key + "_Exp", "log": cap + "_Log", "inv": cap + "_Inv", "mul": cap + "_Mul", "act": cap + "_Act",
+                "act4": cap + "_Act4", "adj": cap + "_AdjXa", "adjt": cap + "_AdjTXa", "jinvp": cap + "_Jinvp"}
+        return getattr(_op, names[kind])   # resolved at call time (rebinding-friendly)
 
     # -- Exp / Log -----------------------------------------------------------------------
     def Exp(self, x):

@@ -259,6 +259,8 @@ def broadcast_inputs(x, y):
     """Reference operation.py:1116-1125: broadcast leading dims and flatten to rows."""
     if y is None:
         return (x.reshape(-1, x.shape[-1]).contiguous(),), tuple(x.shape[:-1])
+    if x.dim() == 2 and y.dim() == 2 and x.shape[0] == y.shape[0] and x.is_contiguous() and y.is_contiguous():
+        return (x, y), (x.shape[0],)                 # already rows: nothing to broadcast, flatten or copy
     # (equal shapes are the common case; torch.broadcast_shapes costs ~10 us of Python)
     out_shape = x.shape[:-1] if x.shape[:-1] == y.shape[:-1] else torch.broadcast_shapes(x.shape[:-1], y.shape[:-1])
     shape = out_shape if out_shape != torch.Size([]) else (1,)
