@@ -330,3 +330,33 @@ def test_graph_kernels_other_groups_match_dense_path(group, prior):
     losses = [float(opt.step(args)) for _ in range(4)]
     for a, b in zip(res["dense"][0], losses):
         assert abs(a - b) <= 1e-6 * max(abs(a), 1e-30) + 1e-18, (res["dense"][0], losses)
+
+
+@pytest.mark.parametrize("problem,fused", [("invnet", True), ("invnet", False), ("pgo", True), ("pgo", False)])
+def test_lm_step_fp32_within_1e5_of_fp64(G, problem, fused):
+    """BASELINE north_star: 'LM-step numerics within 1e-5 of reference'.  One LM step in fp32 against the same step
+    in fp64 (whose trajectories are pinned to the reference's by the tests above), on every structured path."""
+    out = {}
+    for dtype in (torch.float64, torch.float32):
+        if problem == "invnet":
+            torch.manual_seed(3)
+            init = pp.randn_SE3(512, dtype=torch.float64).to(dtype).to(DEV)
+            inp = pp.randn_SE3(512, dtype=torch.float64).to(dtype).to(DEV)
+            model, args, kw = InvNet(init), (inp,), {"strategy": pp.optim.strategy.Constant(damping=1e-4)}
+        else:
+            edges = T(G["pgo40/edges"], DEV)
+            poses = pp.SE3(T(G["pgo40/poses"], DEV).to(dtype))
+            model = PoseGraph(pp.SE3(T(G["pgo40/init"], DEV).to(dtype)))
+            args, kw = ((edges, poses),), {"solver": pp.optim.solver.Cholesky(), "strategy": pp.optim.strategy.TrustRegion(radius=1e4)}
+        opt = pp.optim.LM(model, **kw)
+        opt.fused = fused
+        loss = float(opt.step(*args))
+        P = next(model.parameters()).detach().double().clone()
+        if problem == "pgo":
+            # the graph has no fixed node: a global rigid motion is determined by the damping alone (1e-4 of the
+            # diagonal) and amplifies fp32 rounding by 1/damping -- compare the gauge-invariant poses node_0^-1 node_k
+            P = (pp.SE3(P[:1]).Inv() @ pp.SE3(P)).tensor()
+        out[dtype] = (loss, P, opt.linearization)
+    assert out[torch.float32][2] == out[torch.float64][2]
+    p64, p32 = out[torch.float64][1], out[torch.float32][1]
+    assert (p64 - p32).abs().max().item() <= 1e-5 * max(1.0, p64.abs().max().item()), (p64 - p32).abs().max()
