@@ -174,19 +174,29 @@ def match_pgo(trace, gathers, R, params):
     log = [(n, i, o) for n, i, o in trace.events if n == "se3_log_fwd"]
     if len(log) != 1 or not _same(log[0][2][0], R[0]):
         return None
-    m2 = by_out.get(log[0][1][0].data_ptr())
-    if m2 is None or m2[0] != "se3_mul_fwd" or m2[1][1].data_ptr() not in gat:
+    top = by_out.get(log[0][1][0].data_ptr())
+    if top is None or top[0] != "se3_mul_fwd":
         return None
-    idx1 = gat[m2[1][1].data_ptr()]
-    m1 = by_out.get(m2[1][0].data_ptr())
-    if m1 is None or m1[0] != "se3_mul_fwd":
+    ev = lambda t: by_out.get(t.data_ptr())
+    is_inv_of = lambda e, pred: e is not None and e[0] == "se3_inv_fwd" and pred(e[1][0])
+    gathered = lambda t: t.data_ptr() in gat
+    const = lambda t: not t.requires_grad and not gathered(t) and t.data_ptr() not in by_out
+    a, b = top[1]
+    if gathered(b) and ev(a) is not None and ev(a)[0] == "se3_mul_fwd":
+        # (Inv(Z) * Inv(n_i)) * n_j   -- the association of the reference example, pgo.py:24
+        n_j, (l, r) = b, ev(a)[1]
+        zi, ni = ev(l), ev(r)
+    elif is_inv_of(ev(a), const) and ev(b) is not None and ev(b)[0] == "se3_mul_fwd":
+        # Inv(Z) * (Inv(n_i) * n_j)
+        zi, (l, n_j) = ev(a), ev(b)[1]
+        ni = ev(l)
+        if not gathered(n_j):
+            return None
+    else:
         return None
-    ia, ib = by_out.get(m1[1][0].data_ptr()), by_out.get(m1[1][1].data_ptr())
-    if ia is None or ib is None or ia[0] != "se3_inv_fwd" or ib[0] != "se3_inv_fwd" or ib[1][0].data_ptr() not in gat:
+    if not is_inv_of(zi, const) or not is_inv_of(ni, gathered) or ni[1][0].data_ptr() == n_j.data_ptr():
         return None
-    idx0, Z = gat[ib[1][0].data_ptr()], ia[1][0]
-    if ib[1][0].data_ptr() == m2[1][1].data_ptr() or Z.requires_grad or Z.data_ptr() in gat or Z.data_ptr() in by_out:
-        return None
+    idx0, idx1, Z = gat[ni[1][0].data_ptr()], gat[n_j.data_ptr()], zi[1][0]
     E = R[0].numel() // 6
     if idx0.numel() != E or idx1.numel() != E or Z.numel() != E * 7 or Z.dtype != P.dtype:
         return None

@@ -96,12 +96,23 @@ def test_fused_pgo_is_recognised_only_when_exact(G):
             n1, n2 = self.nodes[edges[..., 0]], self.nodes[edges[..., 1]]
             return (poses.Inv() @ n2.Inv() @ n1).Log().tensor()
 
+    class RightAssociated(PoseGraph):                 # the same residual, multiplied in the other order
+        def forward(self, edges, poses):
+            n1, n2 = self.nodes[edges[..., 0]], self.nodes[edges[..., 1]]
+            return (poses.Inv() @ (n1.Inv() @ n2)).Log().tensor()
+
+    class NoMeasurementInverse(PoseGraph):            # a different program: Z instead of Z^-1
+        def forward(self, edges, poses):
+            n1, n2 = self.nodes[edges[..., 0]], self.nodes[edges[..., 1]]
+            return (poses @ n1.Inv() @ n2).Log().tensor()
+
     class Halved(PoseGraph):
         def forward(self, edges, poses):
             return 0.5 * super().forward(edges, poses)
 
     for cls, kw, want in ((PoseGraph, {}, "fused:pgo"), (PoseGraph, {"kernel": pp.optim.kernel.Huber()}, "fused:pgo"),
-                          (Reversed, {}, "fused:pgo"), (Halved, {}, "graph")):
+                          (Reversed, {}, "fused:pgo"), (RightAssociated, {}, "fused:pgo"), (NoMeasurementInverse, {}, "graph"),
+                          (Halved, {}, "graph")):
         graph = cls(init.clone())
         opt = pp.optim.LM(graph, strategy=pp.optim.strategy.TrustRegion(radius=1e4), **kw)
         l0 = float(opt.model.loss((edges, poses), None).detach())
