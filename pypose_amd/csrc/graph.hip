@@ -742,3 +742,191 @@ extern "C" int pplie_graph_gain_terms_f64(const void* J, const void* idx, const 
                                           int64_t E, int dr, int m, int k, void* stream) {
   return pplie::graph_gain_dispatch<double>(dr, m, k, J, idx, d, ld, R, partial, E, stream);
 }
+
+// ---------------------------------------------------------------------------------------------
+// Two-launch PCG iteration (single-GPU BSR path).  The three-launch scheme above needs its third launch only
+// because beta = rho'/rho waits for the reduction rho' = r'.z' of the second.  With a block-diagonal preconditioner
+//     rho' = (r - alpha q).Binv (r - alpha q) = rho - 2 alpha (q.z) + alpha^2 (q.Binv q),
+// and q.z, q.Binv q are node-local products the SpMV launch can reduce together with p.q.  So
+//   K1  q = A p;  pq += p.q;  qz += q.z;  qMq += q.(Binv q)                       (pplie_pcg2_spmv)
+//   K2  alpha = rho/pq;  beta = (rho - 2 alpha qz + alpha^2 qMq)/rho;
+//       x += alpha p;  r' = r - alpha q;  z = Binv r';  p = z + beta p;  rho_next += r'.z;  rr += r'.r'   (pplie_pcg2_step)
+// The recurrence value only steers beta; z is recomputed from the new residual and alpha of the next iteration uses
+// the freshly reduced rho_next = r.z, so rounding in the recurrence does not accumulate (a recurrence for z itself,
+// z -= alpha Binv q, drifts in fp32 until r.z is meaningless: measured at 10^5 nodes).  Every lane of a node needs the
+// node's whole new residual, so r ping-pongs between two buffers by iteration parity instead of being updated in place.  Scalars: the same two alternating slot-spread sets as above with
+// quantities {rho, pq, rr, bn2 | qz, qMq}: scal is [2 sets][8 quantities][32 slots][32 stride] here
+// (PPLIE_PCG2_SCAL_ELEMS); it[0] = iterations done, it[1] = scratch copy for K2 (written by K1's first lane).
+// ---------------------------------------------------------------------------------------------
+namespace pplie {
+enum { Q2_RHO = 0, Q2_PQ = 1, Q2_RR = 2, Q2_BN2 = 3, Q2_QZ = 4, Q2_QMQ = 5, Q2_COUNT = 8 };
+template <class T> __device__ __forceinline__ T* squant2(T* scal, int set, int q) { return scal + (size_t)((set * Q2_COUNT + q) * kSlots) * kStride; }
+
+template <class T, int M>
+__global__ void __launch_bounds__(256)
+pcg2_spmv_kernel(const int* __restrict__ ptr, const int* __restrict__ other, const T* __restrict__ HB, const T* __restrict__ D,
+                 const T* __restrict__ Binv, const T* __restrict__ p, const T* __restrict__ z, T* __restrict__ q, T* scal,
+                 T* __restrict__ rr_hist, int* it, int cap, int64_t N) {
+  constexpr int NPW = 64 / M;
+  const int done = it[0];
+  const int a = done & 1;
+  if (blockIdx.x == 0) {
+    // bookkeeping by the first workgroup: last iteration's |r|^2 into the history, then clear the idle set
+    if (threadIdx.x == 0) {
+      if (done > 0 && done - 1 < cap) rr_hist[done - 1] = slot_total(squant2(scal, a ^ 1, Q2_RR));
+      it[1] = done;
+    }
+    __syncthreads();
+    if (threadIdx.x < 5 * kSlots) {
+      const int qi = threadIdx.x / kSlots;                      // rho, pq, rr, qz, qMq of the idle set (bn2 stays)
+      const int quant = qi < 3 ? qi : qi + 1;
+      squant2(scal, a ^ 1, quant)[(threadIdx.x % kSlots) * kStride] = T(0);
+    }
+  }
+  const int lane = threadIdx.x & 63;
+  const int sub = lane / M, i = lane % M;
+  const bool active_lane = sub < NPW;
+  const int64_t wave = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * 256) >> 6;
+  T a_pq = T(0), a_qz = T(0), a_qmq = T(0);
+  for (int64_t base = wave * NPW; base < N; base += nwaves * NPW) {
+    const int64_t n = base + sub;
+    const bool act = active_lane && n < N;
+    T acc = T(0), pi = T(0);
+    if (act) {
+      T pv[M];
+#pragma unroll
+      for (int j = 0; j < M; ++j) pv[j] = p[n * M + j];
+      pi = pv[i];
+#pragma unroll
+      for (int j = 0; j < M; ++j) acc += D[(n * M + i) * M + j] * pv[j];
+      const int beg = ptr[n], end = ptr[n + 1];
+      for (int c = beg; c < end; c += 2) {
+        const bool two = c + 1 < end;
+        const int64_t o0 = other[c], o1 = two ? other[c + 1] : o0;
+        const T* h0 = HB + ((int64_t)c * M + i) * M;
+        const T* h1 = two ? h0 + M * M : h0;
+        const T* p0 = p + o0 * M;
+        const T* p1 = p + o1 * M;
+        T s0 = T(0), s1 = T(0);
+#pragma unroll
+        for (int j = 0; j < M; ++j) { s0 += h0[j] * p0[j]; s1 += h1[j] * p1[j]; }
+        acc += two ? s0 + s1 : s0;
+      }
+      q[n * M + i] = acc;
+    }
+    // (Binv q)_i needs the node's whole q: the M lanes of the node exchange their rows (all lanes take part)
+    T bq = T(0);
+#pragma unroll
+    for (int j = 0; j < M; ++j) {
+      const T qj = __shfl(acc, sub * M + j, 64);
+      if (act) bq += Binv[(n * M + i) * M + j] * qj;
+    }
+    if (act) {
+      a_pq += acc * pi;
+      a_qz += acc * z[n * M + i];
+      a_qmq += acc * bq;
+    }
+  }
+  T s1 = block_sum(a_pq);
+  T s2 = block_sum(a_qz);
+  T s3 = block_sum(a_qmq);
+  if (threadIdx.x == 0) {
+    slot_add(squant2(scal, a, Q2_PQ), s1);
+    slot_add(squant2(scal, a, Q2_QZ), s2);
+    slot_add(squant2(scal, a, Q2_QMQ), s3);
+  }
+}
+
+template <class T>
+__global__ void __launch_bounds__(256)
+pcg2_step_kernel(T* __restrict__ x, T* r0, T* r1, T* __restrict__ p, const T* __restrict__ q, T* __restrict__ z,
+                 const T* __restrict__ Binv, T* scal, int* it, int64_t N, int m) {
+  const int done = it[1];
+  const int a = done & 1;
+  const T* __restrict__ rin = a ? r1 : r0;                       // residual of this iteration; the new one goes to the other
+  T* __restrict__ rout = a ? r0 : r1;
+  const T rho = slot_total(squant2(scal, a, Q2_RHO)), pq = slot_total(squant2(scal, a, Q2_PQ));
+  const T qz = slot_total(squant2(scal, a, Q2_QZ)), qmq = slot_total(squant2(scal, a, Q2_QMQ));
+  const T alpha = pq != T(0) ? rho / pq : T(0);                 // p.q = 0 only once r = 0: stay put, no NaN
+  T rho_rec = rho - T(2) * alpha * qz + alpha * alpha * qmq;
+  if (rho_rec < T(0)) rho_rec = T(0);
+  const T beta = rho != T(0) ? rho_rec / rho : T(0);
+  T a1 = T(0), a2 = T(0);
+  const int64_t total = N * m;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int64_t nidx = e / m;
+    const int i = (int)(e - nidx * m);
+    T ze = T(0), re = T(0);
+    for (int j = 0; j < m; ++j) {
+      const T rj = rin[nidx * m + j] - alpha * q[nidx * m + j];
+      if (j == i) re = rj;
+      ze += Binv[e * m + j] * rj;
+    }
+    const T pe = p[e];
+    x[e] += alpha * pe;
+    rout[e] = re;
+    z[e] = ze;
+    p[e] = ze + beta * pe;
+    a1 += re * ze;
+    a2 += re * re;
+  }
+  T s1 = block_sum(a1);
+  T s2 = block_sum(a2);
+  if (threadIdx.x == 0) {
+    slot_add(squant2(scal, a ^ 1, Q2_RHO), s1);
+    slot_add(squant2(scal, a, Q2_RR), s2);
+    if (blockIdx.x == 0) it[0] = done + 1;
+  }
+}
+
+template <class T>
+int pcg2_spmv(const void* ptr, const void* other, const void* HB, const void* D, const void* Binv, const void* p, const void* z,
+              void* q, void* scal, void* rr_hist, void* it, int cap, int64_t N, int m, void* stream) {
+  if (N <= 0) return N == 0 ? PPLIE_OK : PPLIE_EBADARG;
+  if (!ptr || !other || !HB || !D || !Binv || !p || !z || !q || !scal || !rr_hist || !it) return PPLIE_EBADARG;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+#define LAUNCH(MM)                                                                                                    \
+  {                                                                                                                   \
+    int64_t waves = (N + (64 / MM) - 1) / (64 / MM);                                                                  \
+    int64_t blocks = (waves + 3) / 4;                                                                                 \
+    int grid = (int)(blocks < 4096 ? blocks : 4096);                                                                  \
+    hipLaunchKernelGGL((pcg2_spmv_kernel<T, MM>), dim3(grid), dim3(256), 0, st, (const int*)ptr, (const int*)other,   \
+                       (const T*)HB, (const T*)D, (const T*)Binv, (const T*)p, (const T*)z, (T*)q, (T*)scal,          \
+                       (T*)rr_hist, (int*)it, cap, N);                                                                \
+  }
+  if (m == 6) LAUNCH(6) else if (m == 7) LAUNCH(7) else if (m == 3) LAUNCH(3) else return PPLIE_EBADARG;
+#undef LAUNCH
+  return hipGetLastError() == hipSuccess ? PPLIE_OK : PPLIE_ELAUNCH;
+}
+template <class T>
+int pcg2_step(void* x, void* r, void* r_alt, void* p, const void* q, void* z, const void* Binv, void* scal, void* it, int64_t N,
+              int m, void* stream) {
+  if (N <= 0 || m <= 0 || m > 8) return PPLIE_EBADARG;
+  if (!x || !r || !r_alt || r == r_alt || !p || !q || !z || !Binv || !scal || !it) return PPLIE_EBADARG;
+  const int64_t n = N * m;
+  int g1 = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+  hipLaunchKernelGGL((pcg2_step_kernel<T>), dim3(g1), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), (T*)x, (T*)r, (T*)r_alt,
+                     (T*)p, (const T*)q, (T*)z, (const T*)Binv, (T*)scal, (int*)it, N, m);
+  return hipGetLastError() == hipSuccess ? PPLIE_OK : PPLIE_ELAUNCH;
+}
+}  // namespace pplie
+
+extern "C" int pplie_pcg2_spmv_f32(const void* ptr, const void* other, const void* HB, const void* D, const void* Binv,
+                                   const void* p, const void* z, void* q, void* scal, void* rr_hist, void* it, int cap,
+                                   int64_t N, int m, void* stream) {
+  return pplie::pcg2_spmv<float>(ptr, other, HB, D, Binv, p, z, q, scal, rr_hist, it, cap, N, m, stream);
+}
+extern "C" int pplie_pcg2_spmv_f64(const void* ptr, const void* other, const void* HB, const void* D, const void* Binv,
+                                   const void* p, const void* z, void* q, void* scal, void* rr_hist, void* it, int cap,
+                                   int64_t N, int m, void* stream) {
+  return pplie::pcg2_spmv<double>(ptr, other, HB, D, Binv, p, z, q, scal, rr_hist, it, cap, N, m, stream);
+}
+extern "C" int pplie_pcg2_step_f32(void* x, void* r, void* r_alt, void* p, const void* q, void* z, const void* Binv, void* scal,
+                                   void* it, int64_t N, int m, void* stream) {
+  return pplie::pcg2_step<float>(x, r, r_alt, p, q, z, Binv, scal, it, N, m, stream);
+}
+extern "C" int pplie_pcg2_step_f64(void* x, void* r, void* r_alt, void* p, const void* q, void* z, const void* Binv, void* scal,
+                                   void* it, int64_t N, int m, void* stream) {
+  return pplie::pcg2_step<double>(x, r, r_alt, p, q, z, Binv, scal, it, N, m, stream);
+}

@@ -42,7 +42,9 @@ _PREP_SIG = [ctypes.c_void_p] * 10 + [ctypes.c_double] * 3 + [ctypes.c_int64, ct
 _GAIN_SIG = [ctypes.c_void_p] * 3 + [ctypes.c_int] + [ctypes.c_void_p] * 2 + [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
 _GAIN_PARTIALS = 1024       # PPLIE_GAIN_PARTIALS
 _BSR_SIG = [ctypes.c_void_p] * 8 + [ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]
-_PCG_SCAL_ELEMS = 2 * 4 * 32 * 32          # PPLIE_PCG_SCAL_ELEMS: two sets of slot-spread scalars (csrc/graph.hip)
+_PCG_SCAL_ELEMS = 2 * 8 * 32 * 32          # PPLIE_PCG2_SCAL_ELEMS (covers PPLIE_PCG_SCAL_ELEMS): slot-spread scalars (csrc/graph.hip)
+_PCG2_SPMV_SIG = [ctypes.c_void_p] * 11 + [ctypes.c_int, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]
+_PCG2_STEP_SIG = [ctypes.c_void_p] * 9 + [ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]
 _INV_SIG = [ctypes.c_void_p] * 2 + [ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]
 _HIP_SHAPES = {(6, 6, 2), (7, 7, 2), (3, 3, 2), (6, 6, 1), (3, 3, 1)}
 DENSE_LIMIT = 4096          # assemble a dense A for the user's solver up to this many unknowns
@@ -185,6 +187,7 @@ class FusedPCG:
         self.idx = torch.zeros((E, K), dtype=torch.int64, device=device)
         self.Binv, self.shift = z(N, m, m), z(N, m)
         self.x, self.r, self.p, self.q, self.z = (z(N, m) for _ in range(5))
+        self.r2 = z(N, m)                                          # the two-launch iteration ping-pongs the residual
         self.scal = z(_PCG_SCAL_ELEMS)
         self.cap = 1 << 16
         self.rr_hist = z(self.cap)
@@ -202,6 +205,18 @@ class FusedPCG:
     def _iteration(self, group):
         lib = _C.library()
         st = _C.stream_ptr(self.J.device)
+        if self.bsr and self.two_launch:
+            # q = A p with p.q, q.z, q.Binv q ; then every vector update in one launch (csrc/graph.hip, pcg2)
+            code = lib.symbol("pplie_pcg2_spmv" + self.sfx, _PCG2_SPMV_SIG)(
+                self.ptr.data_ptr(), self.other.data_ptr(), self.HB.data_ptr(), self.D.data_ptr(), self.Binv.data_ptr(),
+                self.p.data_ptr(), self.z.data_ptr(), self.q.data_ptr(), self.scal.data_ptr(), self.rr_hist.data_ptr(),
+                self.it.data_ptr(), self.cap, self.N, self.m, st)
+            _C.check(code, "pplie_pcg2_spmv")
+            code = lib.symbol("pplie_pcg2_step" + self.sfx, _PCG2_STEP_SIG)(
+                self.x.data_ptr(), self.r.data_ptr(), self.r2.data_ptr(), self.p.data_ptr(), self.q.data_ptr(),
+                self.z.data_ptr(), self.Binv.data_ptr(), self.scal.data_ptr(), self.it.data_ptr(), self.N, self.m, st)
+            _C.check(code, "pplie_pcg2_step")
+            return
         stage = lib.symbol("pplie_pcg_stage" + self.sfx, _PCG_SIG)
         if self.bsr:
             code = lib.symbol("pplie_graph_bsr_spmv" + self.sfx, _BSR_SIG)(
@@ -230,6 +245,7 @@ class FusedPCG:
         if bsr != getattr(self, 'bsr', None):
             self.graph = None                                       # the captured iteration differs
         self.bsr = bsr
+        self.two_launch = getattr(self, 'two_launch', True)
         if getattr(self, 'D', None) is None:
             self.D = torch.empty((self.N, self.m, self.m), dtype=self.J.dtype, device=self.J.device)
         if bsr:
@@ -251,12 +267,12 @@ class FusedPCG:
                 self.x.data_ptr(), self.r.data_ptr(), self.z.data_ptr(), self.p.data_ptr(), self.scal.data_ptr(),
                 float(s), float(dmin), float(dmax), self.N, self.m, _C.stream_ptr(self.J.device))
             _C.check(code, "pplie_pcg_prepare")
-            bn2_slots = self.scal.view(2, 4, 32, 32)[0, 3, :, 0]    # |b|^2 spread over 32 slots (csrc/graph.hip)
+            bn2_slots = self.scal[3 * 1024:4 * 1024:32]             # |b|^2: set 0, quantity 3, 32 slots (csrc/graph.hip)
             bn2 = None
             maxiter = min(maxiter, self.cap - self.check_every)
             done = 0
             while done < maxiter:
-                if group is None and self.graph is None and done > 0:
+                if group is None and self.graph is None and done > 0 and getattr(self, 'use_graph', True):
                     g = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g):
                         for _ in range(self.check_every):
@@ -268,13 +284,18 @@ class FusedPCG:
                     for _ in range(self.check_every):
                         self._iteration(group)
                 done += self.check_every
+                if bsr and self.two_launch:     # |r|^2 of the last iteration still sits in its slot-spread accumulator
+                    rr_src = self.scal.view(2, 8, 32, 32)[(done - 1) & 1, 2, :, 0]
+                else:
+                    rr_src = self.rr_hist[done - 1:done]
                 if bn2 is None:                                     # first check: |b|^2 comes back with the residual norm
-                    vals = torch.cat([self.rr_hist[done - 1:done], bn2_slots]).tolist()
-                    rr, bn2 = vals[0], sum(vals[1:])
+                    vals = torch.cat([rr_src, bn2_slots]).tolist()
+                    k = rr_src.numel()
+                    rr, bn2 = sum(vals[:k]), sum(vals[k:])
                     if bn2 == 0.0:
                         return self.x.clone(), 0
                 else:
-                    rr = float(self.rr_hist[done - 1])
+                    rr = sum(rr_src.tolist())
                 if rr <= tol * tol * bn2:
                     break
         return self.x.clone(), done
