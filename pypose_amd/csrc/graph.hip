@@ -930,3 +930,157 @@ extern "C" int pplie_pcg2_step_f64(void* x, void* r, void* r_alt, void* p, const
                                    void* it, int64_t N, int m, void* stream) {
   return pplie::pcg2_step<double>(x, r, r_alt, p, q, z, Binv, scal, it, N, m, stream);
 }
+
+// ---------------------------------------------------------------------------------------------
+// Multi-parameter gather-structured problems (bundle adjustment; optim/multigraph.py): residual row e reads one row
+// of each of S "slots" (parameter, index vector, block width m_s <= 8), d_res <= 8.
+//   pplie_mg_jtimes:    q[e, :] = W_e * sum_s J_s[e] p_s[idx_s[e]]           one lane per observation
+//   pplie_mg_jt_segsum: y[n, :] (+)= sum over incidences c of node n of J_s[perm[c]]^T q[perm[c]]
+//                       one wavefront per node over the slot's incidence lists (as pplie_segment_sum, with the
+//                       product formed on the fly instead of materialising [E, m] terms)
+//   pplie_block_matvec: y[n, :] = B[n] x[n, :]                                block-Jacobi preconditioner apply
+// ---------------------------------------------------------------------------------------------
+namespace pplie {
+constexpr int kMgSlots = 4;
+template <class T> struct MgSlots {
+  const T* J[kMgSlots];
+  const int64_t* idx[kMgSlots];
+  const T* p[kMgSlots];
+  int m[kMgSlots];
+  int n;
+};
+
+template <class T>
+__global__ void __launch_bounds__(256)
+mg_jtimes_kernel(MgSlots<T> S, const T* __restrict__ W, T* __restrict__ q, int64_t E, int dr) {
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < E; e += (int64_t)gridDim.x * 256) {
+    T acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = T(0);
+    for (int s = 0; s < S.n; ++s) {
+      const int m = S.m[s];
+      const T* Jr = S.J[s] + e * dr * m;
+      const T* pv = S.p[s] + S.idx[s][e] * m;
+      for (int i = 0; i < dr; ++i) {
+        T a = T(0);
+        for (int j = 0; j < m; ++j) a += Jr[i * m + j] * pv[j];
+        acc[i] += a;
+      }
+    }
+    if (W) {
+      const T* We = W + e * dr * dr;
+      T out[8];
+      for (int i = 0; i < dr; ++i) {
+        T a = T(0);
+        for (int l = 0; l < dr; ++l) a += We[i * dr + l] * acc[l];
+        out[i] = a;
+      }
+      for (int i = 0; i < dr; ++i) q[e * dr + i] = out[i];
+    } else {
+      for (int i = 0; i < dr; ++i) q[e * dr + i] = acc[i];
+    }
+  }
+}
+
+template <class T>
+__global__ void __launch_bounds__(256)
+mg_jt_segsum_kernel(const T* __restrict__ J, const T* __restrict__ q, const int* __restrict__ perm, const int* __restrict__ ptr,
+                    T* __restrict__ y, int64_t N, int dr, int m, int subs, int accumulate) {
+  const int lane = threadIdx.x & 63;
+  const int sub = lane / m, j = lane - sub * m;
+  const bool active = sub < subs;
+  const int64_t wave = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * 256) >> 6;
+  for (int64_t n = wave; n < N; n += nwaves) {
+    const int beg = ptr[n], end = ptr[n + 1];
+    T acc = T(0);
+    if (active) {
+      for (int c = beg + sub; c < end; c += subs) {
+        const int64_t e = perm[c];
+        const T* Je = J + e * dr * m;
+        const T* qe = q + e * dr;
+        for (int i = 0; i < dr; ++i) acc += Je[i * m + j] * qe[i];
+      }
+    }
+    for (int off = subs >> 1; off > 0; off >>= 1) acc += __shfl_down(acc, off * m, 64);
+    if (lane < m) {
+      if (accumulate) y[n * m + lane] += acc;
+      else y[n * m + lane] = acc;
+    }
+  }
+}
+
+template <class T>
+__global__ void __launch_bounds__(256)
+block_matvec_kernel(const T* __restrict__ B, const T* __restrict__ x, T* __restrict__ y, int64_t N, int m) {
+  const int64_t total = N * m;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int64_t n = e / m;
+    T a = T(0);
+    for (int j = 0; j < m; ++j) a += B[e * m + j] * x[n * m + j];
+    y[e] = a;
+  }
+}
+
+template <class T>
+int mg_jtimes(int nslots, const void* const* J, const void* const* idx, const void* const* p, const int* m, const void* W, void* q,
+              int64_t E, int dr, void* stream) {
+  if (E <= 0) return E == 0 ? PPLIE_OK : PPLIE_EBADARG;
+  if (nslots <= 0 || nslots > kMgSlots || dr <= 0 || dr > 8 || !J || !idx || !p || !m || !q) return PPLIE_EBADARG;
+  MgSlots<T> S;
+  S.n = nslots;
+  for (int s = 0; s < nslots; ++s) {
+    if (!J[s] || !idx[s] || !p[s] || m[s] <= 0 || m[s] > 8) return PPLIE_EBADARG;
+    S.J[s] = (const T*)J[s]; S.idx[s] = (const int64_t*)idx[s]; S.p[s] = (const T*)p[s]; S.m[s] = m[s];
+  }
+  int64_t nb = (E + 255) / 256;
+  int grid = (int)(nb < (1 << 20) ? nb : (1 << 20));
+  hipLaunchKernelGGL((mg_jtimes_kernel<T>), dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), S, (const T*)W, (T*)q, E, dr);
+  return hipGetLastError() == hipSuccess ? PPLIE_OK : PPLIE_ELAUNCH;
+}
+template <class T>
+int mg_jt_segsum(const void* J, const void* q, const void* perm, const void* ptr, void* y, int64_t N, int dr, int m, int accumulate,
+                 void* stream) {
+  if (N <= 0) return N == 0 ? PPLIE_OK : PPLIE_EBADARG;
+  if (!J || !q || !perm || !ptr || !y || dr <= 0 || dr > 8 || m <= 0 || m > 8) return PPLIE_EBADARG;
+  int subs = 1;
+  while (subs * 2 * m <= 64) subs *= 2;
+  int64_t blocks = (N + 3) / 4;
+  int grid = (int)(blocks < (1 << 20) ? blocks : (1 << 20));
+  hipLaunchKernelGGL((mg_jt_segsum_kernel<T>), dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), (const T*)J,
+                     (const T*)q, (const int*)perm, (const int*)ptr, (T*)y, N, dr, m, subs, accumulate);
+  return hipGetLastError() == hipSuccess ? PPLIE_OK : PPLIE_ELAUNCH;
+}
+template <class T> int block_matvec(const void* B, const void* x, void* y, int64_t N, int m, void* stream) {
+  if (N <= 0) return N == 0 ? PPLIE_OK : PPLIE_EBADARG;
+  if (!B || !x || !y || m <= 0 || m > 16) return PPLIE_EBADARG;
+  int64_t nb = (N * m + 255) / 256;
+  int grid = (int)(nb < (1 << 20) ? nb : (1 << 20));
+  hipLaunchKernelGGL((block_matvec_kernel<T>), dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), (const T*)B,
+                     (const T*)x, (T*)y, N, m);
+  return hipGetLastError() == hipSuccess ? PPLIE_OK : PPLIE_ELAUNCH;
+}
+}  // namespace pplie
+
+extern "C" int pplie_mg_jtimes_f32(int nslots, const void* const* J, const void* const* idx, const void* const* p, const int* m,
+                                   const void* W, void* q, int64_t E, int dr, void* stream) {
+  return pplie::mg_jtimes<float>(nslots, J, idx, p, m, W, q, E, dr, stream);
+}
+extern "C" int pplie_mg_jtimes_f64(int nslots, const void* const* J, const void* const* idx, const void* const* p, const int* m,
+                                   const void* W, void* q, int64_t E, int dr, void* stream) {
+  return pplie::mg_jtimes<double>(nslots, J, idx, p, m, W, q, E, dr, stream);
+}
+extern "C" int pplie_mg_jt_segsum_f32(const void* J, const void* q, const void* perm, const void* ptr, void* y, int64_t N, int dr,
+                                      int m, int accumulate, void* stream) {
+  return pplie::mg_jt_segsum<float>(J, q, perm, ptr, y, N, dr, m, accumulate, stream);
+}
+extern "C" int pplie_mg_jt_segsum_f64(const void* J, const void* q, const void* perm, const void* ptr, void* y, int64_t N, int dr,
+                                      int m, int accumulate, void* stream) {
+  return pplie::mg_jt_segsum<double>(J, q, perm, ptr, y, N, dr, m, accumulate, stream);
+}
+extern "C" int pplie_block_matvec_f32(const void* B, const void* x, void* y, int64_t N, int m, void* stream) {
+  return pplie::block_matvec<float>(B, x, y, N, m, stream);
+}
+extern "C" int pplie_block_matvec_f64(const void* B, const void* x, void* y, int64_t N, int m, void* stream) {
+  return pplie::block_matvec<double>(B, x, y, N, m, stream);
+}

@@ -31,21 +31,51 @@ from .posegraph import DENSE_LIMIT, PCG, _all_reduce
 
 
 _SEG_SIG = [ctypes.c_void_p] * 4 + [ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]
+_MGJ_SIG = [ctypes.c_int] + [ctypes.c_void_p] * 6 + [ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]
+_MGS_SIG = [ctypes.c_void_p] * 5 + [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+_BMV_SIG = [ctypes.c_void_p] * 3 + [ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]
 
 
 class _Scatter:
     """``out.index_add_(0, idx, vals)`` into N rows for a FIXED index vector: on a HIP device a segmented sum over
     the incidence lists (``pplie_segment_sum``: deterministic, no atomics -- a camera row of a BA problem receives
-    ~10^3 contributions); elsewhere ``index_add_``."""
+    ~10^3 contributions); elsewhere ``index_add_``.  Rows with long lists are split into chunks of ``CHUNK`` incidences
+    summed by one wavefront each, then a second segmented sum adds a row's chunk partials (one wavefront looping
+    over 10^3 incidences of a camera row was the critical path of the whole matvec)."""
+    CHUNK = 128
 
     def __init__(self, idx, N):
         self.idx, self.N = idx, N
         self.hip = idx.is_cuda and _C._test_backend is None and idx.numel() < (1 << 31)
+        self.two_level = False
         if self.hip:
             order = torch.argsort(idx, stable=True)
             self.perm = order.to(torch.int32)
-            self.ptr = torch.zeros(N + 1, dtype=torch.int32, device=idx.device)
-            self.ptr[1:] = torch.cumsum(torch.bincount(idx, minlength=N), 0).to(torch.int32)
+            counts = torch.bincount(idx, minlength=N)
+            ptr64 = torch.zeros(N + 1, dtype=torch.int64, device=idx.device)
+            ptr64[1:] = torch.cumsum(counts, 0)
+            self.ptr = ptr64.to(torch.int32)
+            if int(counts.max()) > 2 * self.CHUNK:
+                C = self.CHUNK
+                per = (counts + C - 1) // C                                  # chunks per row
+                nptr = torch.zeros(N + 1, dtype=torch.int64, device=idx.device)
+                nptr[1:] = torch.cumsum(per, 0)
+                nch = int(nptr[-1])
+                row = torch.repeat_interleave(torch.arange(N, device=idx.device), per)
+                k = torch.arange(nch, device=idx.device) - nptr[row]
+                starts = ptr64[row] + k * C
+                self.cptr = torch.cat([starts, ptr64[-1:]]).to(torch.int32)  # incidence range of every chunk
+                self.nptr = nptr.to(torch.int32)                             # chunk range of every row
+                self.ident = torch.arange(nch, dtype=torch.int32, device=idx.device)
+                self.nch, self.two_level = nch, True
+
+    def _segsum(self, vals, perm, ptr, n, w):
+        out = torch.empty((n, w), dtype=vals.dtype, device=vals.device)
+        fn = _C.library().symbol("pplie_segment_sum" + ("_f32" if vals.dtype == torch.float32 else "_f64"), _SEG_SIG)
+        with torch.cuda.device(vals.device):
+            _C.check(fn(vals.data_ptr(), perm.data_ptr(), ptr.data_ptr(), out.data_ptr(), n, w, _C.stream_ptr(vals.device)),
+                     "pplie_segment_sum")
+        return out
 
     def __call__(self, vals):
         """vals [E, ...] -> [N, ...] (trailing dims flattened for the kernel, at most 64 values per row)"""
@@ -55,14 +85,34 @@ class _Scatter:
             w *= t
         if self.hip and w <= 64 and vals.dtype in (torch.float32, torch.float64):
             vals = vals.reshape(vals.shape[0], w).contiguous()
-            out = torch.empty((self.N, w), dtype=vals.dtype, device=vals.device)
-            fn = _C.library().symbol("pplie_segment_sum" + ("_f32" if vals.dtype == torch.float32 else "_f64"), _SEG_SIG)
-            with torch.cuda.device(vals.device):
-                _C.check(fn(vals.data_ptr(), self.perm.data_ptr(), self.ptr.data_ptr(), out.data_ptr(), self.N, w,
-                            _C.stream_ptr(vals.device)), "pplie_segment_sum")
+            if self.two_level:
+                out = self._segsum(self._segsum(vals, self.perm, self.cptr, self.nch, w), self.ident, self.nptr, self.N, w)
+            else:
+                out = self._segsum(vals, self.perm, self.ptr, self.N, w)
             return out.view((self.N,) + tuple(tail))
         out = torch.zeros((self.N,) + tuple(tail), dtype=vals.dtype, device=vals.device)
         return out.index_add_(0, self.idx, vals)
+
+    def jt_q(self, J, q, out, accumulate):
+        """out [N, m] (+)= scatter-add over this slot of J[e]^T q[e]  (pplie_mg_jt_segsum, chunked like __call__)"""
+        dr, m = J.shape[-2], J.shape[-1]
+        sfx = "_f32" if J.dtype == torch.float32 else "_f64"
+        fn = _C.library().symbol("pplie_mg_jt_segsum" + sfx, _MGS_SIG)
+        st = _C.stream_ptr(J.device)
+        with torch.cuda.device(J.device):
+            if self.two_level:
+                part = torch.empty((self.nch, m), dtype=J.dtype, device=J.device)
+                _C.check(fn(J.data_ptr(), q.data_ptr(), self.perm.data_ptr(), self.cptr.data_ptr(), part.data_ptr(), self.nch, dr, m,
+                            0, st), "pplie_mg_jt_segsum")
+                if accumulate:
+                    out += self._segsum(part, self.ident, self.nptr, self.N, m)
+                else:
+                    fs = _C.library().symbol("pplie_segment_sum" + sfx, _SEG_SIG)
+                    _C.check(fs(part.data_ptr(), self.ident.data_ptr(), self.nptr.data_ptr(), out.data_ptr(), self.N, m, st),
+                             "pplie_segment_sum")
+            else:
+                _C.check(fn(J.data_ptr(), q.data_ptr(), self.perm.data_ptr(), self.ptr.data_ptr(), out.data_ptr(), self.N, dr, m,
+                            1 if accumulate else 0, st), "pplie_mg_jt_segsum")
 
 
 def _tangent_width(p):
@@ -137,6 +187,45 @@ class MultiGraphLinearization:
     @staticmethod
     def _cat(xs):
         return torch.cat([x.reshape(-1) for x in xs])
+
+    # -- HIP products on flat vectors (csrc/graph.hip: pplie_mg_jtimes / pplie_mg_jt_segsum / pplie_block_matvec) ------
+    def hip_ok(self):
+        return (self.R.is_cuda and _C._test_backend is None and self.group is None and self.dr <= 8 and len(self.slots) <= 4
+                and max(self.m) <= 8 and self.R.dtype in (torch.float32, torch.float64)
+                and all(sc.hip for sc in self.scatters()))
+
+    def _sfx(self):
+        return "_f32" if self.R.dtype == torch.float32 else "_f64"
+
+    def matvec_flat(self, v, shift_flat):
+        """(H + diag(shift)) v on the concatenated unknowns: one edge-parallel launch for q = W J v, one segmented
+        J^T q per slot written straight into the output vector."""
+        lib, st = _C.library(), _C.stream_ptr(v.device)
+        xs = self._split(v)
+        S = len(self.slots)
+        arr = lambda ts: (ctypes.c_void_p * S)(*[t.data_ptr() for t in ts])
+        q = torch.empty((self.E, self.dr), dtype=v.dtype, device=v.device)
+        ms = (ctypes.c_int * S)(*[J.shape[-1] for _, _, J in self.slots])
+        with torch.cuda.device(v.device):
+            code = lib.symbol("pplie_mg_jtimes" + self._sfx(), _MGJ_SIG)(
+                S, arr([J for _, _, J in self.slots]), arr([i for _, i, _ in self.slots]), arr([xs[pi] for pi, _, _ in self.slots]),
+                ms, self.W.data_ptr() if self.W is not None else None, q.data_ptr(), self.E, self.dr, st)
+            _C.check(code, "pplie_mg_jtimes")
+            out = torch.empty_like(v)
+            outs, seen = self._split(out), set()
+            for (pi, _, J), sc in zip(self.slots, self.scatters()):
+                sc.jt_q(J, q, outs[pi], pi in seen)
+                seen.add(pi)
+        return out.addcmul_(shift_flat, v)
+
+    def precond_flat(self, v, Binv):
+        lib, st = _C.library(), _C.stream_ptr(v.device)
+        out = torch.empty_like(v)
+        fn = lib.symbol("pplie_block_matvec" + self._sfx(), _BMV_SIG)
+        with torch.cuda.device(v.device):
+            for Bi, x, y, n, m in zip(Binv, self._split(v), self._split(out), self.N, self.m):
+                _C.check(fn(Bi.data_ptr(), x.data_ptr(), y.data_ptr(), n, m, st), "pplie_block_matvec")
+        return out
 
     # -- products -----------------------------------------------------------------------------------
     def _WJ(self, J):
@@ -262,10 +351,12 @@ class _GraphedPCG:
         L.W = torch.empty_like(lin.W) if lin.W is not None else None
         L.slots = [(pi, torch.empty_like(idx), torch.empty_like(J)) for pi, idx, J in lin.slots]
         L._scatters = None
-        tot = sum(n * m for n, m in zip(lin.N, lin.m))
         z = lambda *s: torch.zeros(s, dtype=dt, device=dev)
-        self.shift = [z(n, m) for n, m in zip(lin.N, lin.m)]
+        tot = sum(n * m for n, m in zip(lin.N, lin.m))
+        self.shift_flat = z(tot)
+        self.shift = lin._split(self.shift_flat)
         self.Binv = [z(n, m, m) for n, m in zip(lin.N, lin.m)]
+        self.hip = lin.hip_ok()
         self.x, self.r, self.p = z(tot), z(tot), z(tot)
         self.rho = torch.zeros((), dtype=dt, device=dev)
         self.check_every = check_every
@@ -274,13 +365,17 @@ class _GraphedPCG:
 
     def _iteration(self, k):
         L = self.lin_like
-        ps = L._split(self.p)
-        q = L._cat([y + sh * x for y, sh, x in zip(L._Hp(ps), self.shift, ps)])
+        if self.hip:
+            q = L.matvec_flat(self.p, self.shift_flat)
+        else:
+            ps = L._split(self.p)
+            q = L._cat([y + sh * x for y, sh, x in zip(L._Hp(ps), self.shift, ps)])
         pq = (self.p * q).sum()
         alpha = torch.where(pq != 0, self.rho / pq, torch.zeros_like(pq))       # p.q = 0 only once r = 0
         self.x.add_(alpha * self.p)
         self.r.sub_(alpha * q)
-        zv = L._cat([(Bi * x.unsqueeze(-2)).sum(-1) for Bi, x in zip(self.Binv, L._split(self.r))])
+        zv = L.precond_flat(self.r, self.Binv) if self.hip else \
+            L._cat([(Bi * x.unsqueeze(-2)).sum(-1) for Bi, x in zip(self.Binv, L._split(self.r))])
         rho_new = (self.r * zv).sum()
         beta = torch.where(self.rho != 0, rho_new / self.rho, torch.zeros_like(rho_new))
         self.p.mul_(beta).add_(zv)

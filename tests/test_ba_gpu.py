@@ -61,3 +61,36 @@ def test_ba_bal_scale():
     # noise floor: 0.2 px per coordinate -> sum of squares ~ 0.04 * 2 E; the start is far above it
     E = args[0].shape[0]
     assert losses[-1] < 0.2 * l0 and losses[-1] < 4 * 0.04 * 2 * E, (l0, losses)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-12), (torch.float32, 2e-5)])
+@pytest.mark.parametrize("weighted", [False, True])
+def test_multigraph_hip_products_match_tensor_formulation(dtype, tol, weighted):
+    """pplie_mg_jtimes / pplie_mg_jt_segsum / pplie_block_matvec against the device-agnostic formulation of the same
+    matrix-free products (which the CPU suite pins to the dense reference algebra)."""
+    from pypose_amd.optim import multigraph
+    torch.manual_seed(1)
+    E, dr = 5003, 2
+    N, m = [37, 37, 901], [3, 6, 3]
+    params = [torch.zeros(n, w, dtype=dtype, device=DEV) for n, w in zip(N, (3, 6, 3))]
+    slots = [(k, torch.randint(0, N[k], (E,), device=DEV), torch.randn(E, dr, m[k], dtype=dtype, device=DEV)) for k in range(3)]
+    slots.append((2, torch.randint(0, N[2], (E,), device=DEV), torch.randn(E, dr, 3, dtype=dtype, device=DEV)))   # two slots, one parameter
+    W = None
+    if weighted:
+        A = torch.randn(E, dr, dr, dtype=dtype, device=DEV)
+        W = A @ A.mT + torch.eye(dr, dtype=dtype, device=DEV)
+
+    class Opt:
+        group = None
+    lin = multigraph.MultiGraphLinearization(Opt(), W, torch.randn(E, dr, dtype=dtype, device=DEV), params, slots)
+    assert lin.hip_ok()
+    tot = sum(n * k for n, k in zip(N, m))
+    v, shift = torch.randn(tot, dtype=dtype, device=DEV), torch.rand(tot, dtype=dtype, device=DEV)
+    got = lin.matvec_flat(v, shift)
+    xs = lin._split(v)
+    want = lin._cat([y + sh * x for y, sh, x in zip(lin._Hp(xs), lin._split(shift), xs)])
+    assert (got - want).abs().max().item() <= tol * want.abs().max().item()
+    Binv = [torch.randn(n, k, k, dtype=dtype, device=DEV) for n, k in zip(N, m)]
+    got = lin.precond_flat(v, Binv)
+    want = lin._cat([(Bi * x.unsqueeze(-2)).sum(-1) for Bi, x in zip(Binv, xs)])
+    assert (got - want).abs().max().item() <= tol * want.abs().max().item()
