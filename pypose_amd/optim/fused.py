@@ -252,35 +252,67 @@ def try_fused(opt, pg, input, target, weight, cache):
     if not (P.is_cuda and _blocks._suffix(P) and target is None and len(opt.param_groups) == 1):
         return None
     trivial = all(isinstance(c, Trivial) for c in opt.corrector) and all(isinstance(k, Trivial) for k in opt.model.kernel)
+    solver_ok = (isinstance(opt.solver, Cholesky) and not opt.solver.upper) or isinstance(opt.solver, _pg.PCG)
+    if getattr(opt, 'static', False) and cache.get("fused") is True:
+        # LM(static=True): the caller promises that the model's residual program and its non-parameter operands do
+        # not change between step() calls with the same ``input`` object -- the verified program of the previous
+        # step is evaluated directly, without running the model again to re-derive it
+        hit = cache.get("program")
+        if hit is not None and _same_input(hit[0], input) and hit[1] is P:
+            kind, operands = hit[2], hit[3]
+            if kind == "se3inv" and weight is None and trivial and solver_ok:
+                X = operands
+                Z = _C.row_op("se3_mul_fwd", [P.detach().reshape(-1, 7), X.reshape(-1, 7)], (7,))[0]
+                (r,) = _C.row_op("se3_log_fwd", [Z], (6,))
+                return Se3InvLinearization(opt, P, X, r)
+            if kind == "pgo" and len(opt.corrector) == 1:
+                return _pgo_linearization(opt, operands, weight, P, trivial)
     with torch.no_grad(), OpTracer() as tr, _pg.GatherRecorder(params) as rec:
         R = list(opt.model(input, target))
     m = match_se3inv(tr, R, params) if not rec.events else None
-    if m is not None and weight is None and trivial and \
-            ((isinstance(opt.solver, Cholesky) and not opt.solver.upper) or isinstance(opt.solver, _pg.PCG)):
+    if m is not None and weight is None and trivial and solver_ok:
+        cache["program"] = (input, P, "se3inv", m[1].detach())
         return Se3InvLinearization(opt, *m)
     m = match_pgo(tr, rec.events, R, params)
     if m is not None and len(opt.corrector) == 1:
         prog = PgoProgram(*m)
-        r, J = prog.linearize()
-        lin = _pg.build_graph_linearization(opt, weight, r, J, prog.idx, P, 7, 6)
-        lin.kind = "fused:pgo"
-        def verify(ref, dmin, dmax, rtol=1e-3):
-            """residuals and blocks against the autograd-derived pose-graph linearisation (whose edge ends are in
-            gather order, ours in (inverted node, other node) order)"""
-            if ref.J.shape != lin.J.shape:
-                return False
-            if torch.equal(ref.idx, lin.idx):
-                Jr = ref.J
-            elif torch.equal(ref.idx, lin.idx.flip(-1)):
-                Jr = ref.J.flip(1)
-            else:
-                return False
-            return bool((ref.R - lin.R).abs().max() <= rtol * ref.R.abs().max().clamp_min(1e-30)) \
-                and bool((Jr - lin.J).abs().max() <= rtol * Jr.abs().max().clamp_min(1e-30))
-        lin.verify = verify
-        lin.reference_kind = "graph"
-        if trivial:
-            lin.fast_loss = lambda: prog.loss(opt.group)
-        return lin
+        cache["program"] = (input, P, "pgo", prog)
+        return _pgo_linearization(opt, prog, weight, P, trivial)
     cache["fused"] = False
     return None
+
+
+def _same_input(a, b):
+    if a is b:
+        return True
+    if isinstance(a, (tuple, list)) and isinstance(b, (tuple, list)) and len(a) == len(b):
+        return all(x is y for x, y in zip(a, b))
+    if isinstance(a, dict) and isinstance(b, dict) and a.keys() == b.keys():
+        return all(a[k] is b[k] for k in a)
+    return False
+
+
+def _pgo_linearization(opt, prog, weight, P, trivial):
+    from . import posegraph as _pg
+    r, J = prog.linearize()
+    lin = _pg.build_graph_linearization(opt, weight, r, J, prog.idx, P, 7, 6)
+    lin.kind = "fused:pgo"
+
+    def verify(ref, dmin, dmax, rtol=1e-3):
+        """residuals and blocks against the autograd-derived pose-graph linearisation (whose edge ends are in
+        gather order, ours in (inverted node, other node) order)"""
+        if ref.J.shape != lin.J.shape:
+            return False
+        if torch.equal(ref.idx, lin.idx):
+            Jr = ref.J
+        elif torch.equal(ref.idx, lin.idx.flip(-1)):
+            Jr = ref.J.flip(1)
+        else:
+            return False
+        return bool((ref.R - lin.R).abs().max() <= rtol * ref.R.abs().max().clamp_min(1e-30)) \
+            and bool((Jr - lin.J).abs().max() <= rtol * Jr.abs().max().clamp_min(1e-30))
+    lin.verify = verify
+    lin.reference_kind = "graph"
+    if trivial:
+        lin.fast_loss = lambda: prog.loss(opt.group)
+    return lin

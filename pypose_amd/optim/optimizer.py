@@ -309,7 +309,7 @@ class LevenbergMarquardt(_Optimizer):
     """
 
     def __init__(self, model, solver=None, strategy=None, kernel=None, corrector=None,
-                 weight=None, reject=16, min=1e-6, max=1e32, vectorize=True, sparse=False, *, group=None):
+                 weight=None, reject=16, min=1e-6, max=1e32, vectorize=True, sparse=False, *, group=None, static=False):
         assert min > 0, ValueError("min value has to be positive: {}".format(min))
         assert max > 0, ValueError("max value has to be positive: {}".format(max))
         self.strategy = TrustRegion() if strategy is None else strategy
@@ -320,6 +320,10 @@ class LevenbergMarquardt(_Optimizer):
         # the flag only records the intent; a model without detectable structure still runs densely.
         self.sparse = bool(sparse)
         self.fused = True          # whole-step kernels for recognised residual programs (optim/fused.py)
+        # static=True: a promise (like capturing a hipGraph) that the model's residual program and its non-parameter
+        # operands do not change between step() calls with the same `input` object; a recognised + verified program
+        # is then evaluated directly instead of being re-derived from a traced forward every step
+        self.static = bool(static)
         # torch.distributed process group: independent problems / graph edges are sharded over its
         # ranks (one process per GPU, RCCL); the loss, the gain ratio and -- for pose graphs -- the
         # normal-equation pieces are all-reduced so that every rank takes the same decisions.

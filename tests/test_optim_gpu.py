@@ -371,3 +371,39 @@ def test_lm_step_fp32_within_1e5_of_fp64(G, problem, fused):
     assert out[torch.float32][2] == out[torch.float64][2]
     p64, p32 = out[torch.float64][1], out[torch.float32][1]
     assert (p64 - p32).abs().max().item() <= 1e-5 * max(1.0, p64.abs().max().item()), (p64 - p32).abs().max()
+
+
+@pytest.mark.parametrize("problem", ["invnet", "pgo"])
+def test_static_option_gives_identical_steps(G, problem):
+    """LM(static=True) evaluates the verified program directly instead of re-tracing the model every step: same
+    iterates as the default; a different `input` object falls back to tracing."""
+    runs = {}
+    for static in (False, True):
+        torch.manual_seed(9)
+        if problem == "invnet":
+            model = InvNet(pp.randn_SE3(300, device=DEV, dtype=torch.float64))
+            args = (pp.randn_SE3(300, device=DEV, dtype=torch.float64),)
+            opt = pp.optim.LM(model, strategy=pp.optim.strategy.Adaptive(damping=1e-6), static=static)
+            call = lambda: opt.step(args[0])
+        else:
+            edges, poses = T(G["pgo40/edges"], DEV), pp.SE3(T(G["pgo40/poses"], DEV))
+            model = PoseGraph(pp.SE3(T(G["pgo40/init"], DEV)))
+            inp = (edges, poses)
+            opt = pp.optim.LM(model, solver=pp.optim.solver.PCG(tol=1e-12, maxiter=2000), strategy=pp.optim.strategy.TrustRegion(radius=1e4),
+                              static=static)
+            call = lambda: opt.step(inp)
+        losses = [float(call()) for _ in range(4)]
+        if static:
+            assert opt.__dict__["_structure_cache"].get("program") is not None
+            # a new input object (equal values) is not trusted: traced again, same result path
+            if problem == "invnet":
+                losses.append(float(opt.step(args[0].clone())))
+            else:
+                losses.append(float(opt.step((edges.clone(), poses))))
+        else:
+            losses.append(float(call()))
+        runs[static] = (losses, next(model.parameters()).detach().clone(), opt.linearization)
+    assert runs[True][2] == runs[False][2] and runs[True][2].startswith("fused:")
+    for a, b in zip(runs[False][0], runs[True][0]):
+        assert abs(a - b) <= 1e-9 * max(abs(a), 1e-30) + 1e-24, (runs[False][0], runs[True][0])
+    torch.testing.assert_close(runs[True][1], runs[False][1], rtol=0, atol=1e-11)
