@@ -226,3 +226,30 @@ def test_fused_retraction_equals_exp_then_mul(group, dtype):
     tol = 1e-14 if dtype == torch.float64 else 1e-6
     assert (Y.tensor() - want).abs().max().item() <= tol * want.abs().max().item()
     assert Y.ltype == X.ltype
+
+
+def test_more_than_2_31_elements():
+    """Maximum sizes: 3.2 x 10^8 SE3 rows = 2.24 x 10^9 elements (> 2^31) through Exp and Log; the rows at the far
+    end of the buffers (where 32-bit element offsets would have wrapped) are checked against the oracle."""
+    import pypose_amd as pp
+    from oracle import lie_np
+    n = 320_000_000
+    free, _ = torch.cuda.mem_get_info()
+    if free < 60 * 2**30:
+        pytest.skip("needs ~40 GB of free HBM")
+    g = torch.Generator(device="cuda:0").manual_seed(0)
+    x = torch.empty((n, 6), dtype=torch.float32, device="cuda:0")
+    x.normal_(generator=g)
+    x[:, 3:] *= 0.5                                               # |phi| well inside (0, pi): Log(Exp(x)) == x
+    X = pp.se3(x).Exp()
+    y = X.Log().tensor()
+    assert X.shape == (n, 7) and y.shape == (n, 6)
+    tail = slice(n - 1000, n)
+    want = lie_np.se3_exp_fwd(x[tail].double().cpu().numpy())[0]
+    assert np.abs(X.tensor()[tail].double().cpu().numpy() - want).max() < 2e-6
+    for sl in (slice(0, 1000), slice(n // 2, n // 2 + 1000), tail):
+        assert (y[sl] - x[sl]).abs().max().item() < 2e-5
+    # a cheap whole-buffer property: every quaternion is unit, every row finite
+    q = X.tensor()[:, 3:]
+    assert (q.square().sum(-1) - 1).abs().max().item() < 1e-5
+    assert bool(torch.isfinite(y).all())
