@@ -162,13 +162,19 @@ def test_posegraph_trajectory_matches_reference(G, tag, wname, mode):
     torch.testing.assert_close(graph.nodes.detach().tensor().cpu(), T(G[f"{tag}/{wname}/final"]), rtol=0, atol=1e-7)
 
 
-def test_posegraph_pcg_matrix_free_on_gpu(G):
+@pytest.mark.parametrize("two_launch", [True, False])
+def test_posegraph_pcg_matrix_free_on_gpu(G, two_launch, monkeypatch):
+    """Reference trajectory through the device-resident PCG: the two-launch iteration (pplie_pcg2_*) and the
+    three-launch one (pplie_graph_bsr_spmv + pplie_pcg_stage, also the form the edge-sharded path uses)."""
+    from pypose_amd.optim import posegraph
+    monkeypatch.setattr(posegraph.FusedPCG, "two_launch", two_launch, raising=False)
     edges, poses = T(G["pgo40/edges"], DEV), pp.SE3(T(G["pgo40/poses"], DEV))
     graph = PoseGraph(pp.SE3(T(G["pgo40/init"], DEV)))
     opt = pp.optim.LM(graph, solver=pp.optim.solver.PCG(tol=1e-13, maxiter=2000, check_every=1),
                       strategy=pp.optim.strategy.TrustRegion(radius=1e4), min=1e-6)
     rec = run_steps(opt, ((edges, poses),), {"weight": T(G["pgo40/infos"], DEV)}, 5)
     assert set(rec["kind"]) == {"fused:pgo"}
+    assert all(w.two_launch == two_launch for w in opt._pcg_workspaces.values())
     compare_trajectory(rec, G, "pgo40/infos", floor=1e-12, rtol=1e-7)
 
 
