@@ -4,13 +4,13 @@
 // ceil(log2 L) rounds of index_select x2 + op + index_copy_, i.e. O(L log L) work and ~3 log2 L
 // launches (11 rounds x 4 kernels at L = 1025), and pypose/module/imu_preintegrator.py:314-465
 // chains two such scans (SO3 and 9x9 matrices) with a dozen eager ops and [B,F+1,9,9] temporaries.
-// Here one wavefront owns one sequence and walks it in 64-element chunks: a wave-level
-// shuffle scan inside the chunk (6 steps), a carried prefix between chunks -- O(L) work, ONE
+// Here one wavefront owns one sequence and walks it in 64-element chunks: a wave-level scan on DPP
+// cross-lane moves inside the chunk (7 steps), a carried prefix between chunks -- O(L) work, ONE
 // launch, every element read and written once.
 //
 //   pplie_scan_<group>     in-place inclusive product scan of [outer, L, inner, W] group elements
 //   pplie_imu_integrate    dt/gyro/acc -> rot/vel/pos (+ the per-step terms the covariance needs)
-//   pplie_imu_cov          9x9 covariance by the backward recurrence S_k = Bc_k + A_k S_{k+1} A_k^T
+//   pplie_imu_cov          9x9 covariance  sum_k P_k Bc_k P_k^T  (P_k = A_k ... A_{F-1}) from suffix scans + one reduction
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "lie_math.h"
