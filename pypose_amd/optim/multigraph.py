@@ -29,6 +29,8 @@ from ..lietensor import lietensor as _lt
 from . import blocks as _blocks
 from .posegraph import DENSE_LIMIT, PCG, _all_reduce
 
+SCHUR_LIMIT = 12288        # largest reduced (non-eliminated) system assembled densely for the user's solver
+
 
 _SEG_SIG = [ctypes.c_void_p] * 4 + [ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]
 _MGJ_SIG = [ctypes.c_int] + [ctypes.c_void_p] * 6 + [ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]
@@ -301,6 +303,10 @@ class MultiGraphLinearization:
             A = self.dense_matrix()
             A.diagonal().add_(self._cat(shift))
             Dn = self._split(solver(A=A, b=self._cat(b).view(-1, 1)).reshape(-1))
+        elif not isinstance(solver, PCG) and self.group is None and self.schur_plan() is not None:
+            # a direct solver was asked for and the problem is bipartite (bundle adjustment): eliminate the large,
+            # mutually independent set of rows exactly and hand the small reduced system to the user's solver
+            Dn = self._schur_solve(solver, shift, b)
         else:
             if not isinstance(solver, PCG):
                 if not getattr(self.opt, '_warned_pcg', False):
@@ -329,6 +335,90 @@ class MultiGraphLinearization:
                 Dn = self._split(solver.solve(matvec, self._cat(b), precond))
         assert not any(bool(torch.isnan(d).any()) for d in Dn), 'Linear solve produced NaN (matrix may not be positive-definite)'
         return self.nodes_to_step(Dn)
+
+    # -- Schur complement (bipartite problems) -----------------------------------------------------------
+    def schur_plan(self):
+        """Bipartite structure, or None.  Slots sharing one index vector form a group (BA: {K, C} by camera index, {P} by
+        point index); with exactly two groups, each parameter in one slot, the group with more rows is eliminated:
+        its rows couple only through the other group, so its block of the normal equations is block diagonal.  The
+        plan (cached on the optimizer per index structure) lists, for every pair of observations of the same
+        eliminated row, the two observation ids -- the fill of the reduced system."""
+        if hasattr(self, '_plan'):
+            return self._plan
+        self._plan = None
+        groups = []
+        for k, (pi, idx, _) in enumerate(self.slots):
+            for g in groups:
+                if idx.shape == g[0].shape and (idx.data_ptr() == g[0].data_ptr() or torch.equal(idx, g[0])):
+                    g[1].append(k)
+                    break
+            else:
+                groups.append((idx, [k]))
+        used = [pi for pi, _, _ in self.slots]
+        if len(groups) != 2 or len(set(used)) != len(used):
+            return None
+        rows = [self.N[self.slots[g[1][0]][0]] for g in groups]
+        if any(self.N[self.slots[k][0]] != r for g, r in zip(groups, rows) for k in g[1]):
+            return None
+        a, b = (0, 1) if rows[0] >= rows[1] else (1, 0)
+        mb = sum(self.m[self.slots[k][0]] for k in groups[b][1])
+        if rows[b] * mb > SCHUR_LIMIT:
+            return None
+        cache = self.opt.__dict__.setdefault('_schur_plans', {}) if hasattr(self.opt, '__dict__') else {}
+        ia, ib = groups[a][0], groups[b][0]
+        hit = cache.get((self.E, rows[a], rows[b]))
+        if hit is None or not (torch.equal(hit["ia"], ia) and torch.equal(hit["ib"], ib)):
+            perm = torch.argsort(ia, stable=True)
+            k = torch.bincount(ia, minlength=rows[a])
+            ptr = torch.zeros(rows[a] + 1, dtype=torch.int64, device=ia.device)
+            ptr[1:] = torch.cumsum(k, 0)
+            kc = k[ia[perm]]                                           # partners of every sorted incidence
+            left = torch.repeat_interleave(torch.arange(self.E, device=ia.device), kc)
+            start = torch.cumsum(kc, 0) - kc
+            right = ptr[ia[perm][left]] + (torch.arange(left.numel(), device=ia.device) - start[left])
+            e1, e2 = perm[left], perm[right]
+            hit = {"ia": ia.clone(), "ib": ib.clone(), "e1": e1, "e2": e2, "key": ib[e1] * rows[b] + ib[e2]}
+            cache[(self.E, rows[a], rows[b])] = hit
+        self._plan = {"a": groups[a][1], "b": groups[b][1], "Na": rows[a], "Nb": rows[b], **hit}
+        return self._plan
+
+    def _schur_solve(self, solver, shift, b):
+        P = self._plan
+        dt, dev = self.R.dtype, self.R.device
+        cat_J = lambda ks: torch.cat([self.slots[k][2] for k in ks], dim=-1)          # [E, dr, m_group]
+        cat_p = lambda xs, ks: torch.cat([xs[self.slots[k][0]] for k in ks], dim=-1)    # per-parameter rows -> group rows
+        Ja, Jb, ia, ib, Na, Nb = cat_J(P["a"]), cat_J(P["b"]), P["ia"], P["ib"], P["Na"], P["Nb"]
+        ma, mb = Ja.shape[-1], Jb.shape[-1]
+        WJa = self._WJ(Ja)
+        Wr = self.R if self.W is None else (self.W * self.R.unsqueeze(-2)).sum(-1)
+        mm = lambda A, B: (A.unsqueeze(-1) * B.unsqueeze(-2)).sum(-3)                 # A^T B over d_res: [E, ., .]
+        Va = torch.zeros((Na, ma, ma), dtype=dt, device=dev).index_add_(0, ia, mm(Ja, WJa))
+        Vb = torch.zeros((Nb, mb, mb), dtype=dt, device=dev).index_add_(0, ib, mm(Jb, self._WJ(Jb)))
+        ga = torch.zeros((Na, ma), dtype=dt, device=dev).index_add_(0, ia, (Ja * Wr.unsqueeze(-1)).sum(-2))
+        gb = torch.zeros((Nb, mb), dtype=dt, device=dev).index_add_(0, ib, (Jb * Wr.unsqueeze(-1)).sum(-2))
+        Va.diagonal(dim1=-2, dim2=-1).add_(cat_p(shift, P["a"]))                      # LM clamp + damping
+        Vb.diagonal(dim1=-2, dim2=-1).add_(cat_p(shift, P["b"]))
+        Vinv = torch.linalg.inv(Va)
+        Eba = mm(Jb, WJa)                                                             # [E, mb, ma] coupling blocks
+        Y = (Eba.unsqueeze(-1) * Vinv[ia].unsqueeze(-3)).sum(-2)                      # E_e Vinv_p(e)
+        # reduced (camera) system: S = Vb - sum over pairs (e, e') of one eliminated row of Y_e E_e'^T
+        blocks = (Y[P["e1"]].unsqueeze(-2) * Eba[P["e2"]].unsqueeze(-3)).sum(-1)      # [pairs, mb, mb]
+        S = torch.zeros((Nb * Nb, mb, mb), dtype=dt, device=dev).index_add_(0, P["key"], -blocks)
+        S = S.view(Nb, Nb, mb, mb)
+        S[torch.arange(Nb, device=dev), torch.arange(Nb, device=dev)] += Vb
+        S = S.permute(0, 2, 1, 3).reshape(Nb * mb, Nb * mb)
+        rhs = gb - torch.zeros((Nb, mb), dtype=dt, device=dev).index_add_(0, ib, (Y * ga[ia].unsqueeze(-2)).sum(-1))
+        xb = solver(A=S, b=-rhs.reshape(-1, 1)).reshape(Nb, mb)
+        t = torch.zeros((Na, ma), dtype=dt, device=dev).index_add_(0, ia, (Eba * xb[ib].unsqueeze(-1)).sum(-2))
+        xa = -(Vinv * (ga + t).unsqueeze(-2)).sum(-1)
+        out = [None] * len(self.params)
+        for x, ks in ((xa, P["a"]), (xb, P["b"])):
+            off = 0
+            for k in ks:
+                pi = self.slots[k][0]
+                out[pi] = x[:, off:off + self.m[pi]].contiguous()
+                off += self.m[pi]
+        return out
 
     def solve_gauss_newton(self, solver):
         raise NotImplementedError

@@ -17,15 +17,19 @@ def G():
     return load_ba_golden()
 
 
-@pytest.mark.parametrize("structured", [False, True])
+@pytest.mark.parametrize("structured", [False, True, "schur"])
 @pytest.mark.parametrize("tag", ["ba_small", "ba_huber"])
-def test_ba_trajectory_matches_reference(G, tag, structured):
+def test_ba_trajectory_matches_reference(G, tag, structured, monkeypatch):
     from pypose_amd import _C
+    from pypose_amd.optim import multigraph
     assert _C._test_backend is None
     model, opt, args = ba_case(G, tag, DEV)
-    opt.structured = structured
+    if structured == "schur":
+        monkeypatch.setattr(multigraph, "DENSE_LIMIT", 0)        # force the Schur-complement solve on the small problem
+    opt.structured = bool(structured)
     rec = run_steps(opt, (args,), {}, 6)
     assert set(rec["kind"]) == ({"multigraph"} if structured else {"dense"}), rec["kind"]
+    assert (structured == "schur") == bool(opt.__dict__.get("_schur_plans"))
     compare_trajectory(rec, G, tag, floor=1e-12, rtol=1e-7)
     np.testing.assert_allclose(model.P.detach().cpu().numpy(), G[f"{tag}/P"], atol=1e-6)
     np.testing.assert_allclose(model.C.detach().tensor().cpu().numpy(), G[f"{tag}/C"], atol=1e-6)
@@ -48,12 +52,15 @@ def synthetic_ba(Nc, Np, per_point, dtype, seed=0):
     return (obs, cidx, pidx), (K0, C0, P0)
 
 
-def test_ba_bal_scale():
+@pytest.mark.parametrize("solver", ["pcg", "cholesky"])
+def test_ba_bal_scale(solver):
+    """PCG on the full matrix-free system, or -- when a direct solver is asked for -- exact elimination of the points
+    (Schur complement) and a dense Cholesky of the 2313 x 2313 camera system."""
     Nc, Np = 257, 65_132
     args, (K0, C0, P0) = synthetic_ba(Nc, Np, 4, torch.float64)          # ~260 k observations
     model = Reproj(K0, C0, P0)
-    opt = pp.optim.LM(model, solver=pp.optim.solver.PCG(tol=1e-4, maxiter=250), strategy=pp.optim.strategy.TrustRegion(radius=1e4),
-                      reject=30)
+    sol = pp.optim.solver.PCG(tol=1e-4, maxiter=250) if solver == "pcg" else pp.optim.solver.Cholesky()
+    opt = pp.optim.LM(model, solver=sol, strategy=pp.optim.strategy.TrustRegion(radius=1e4), reject=30)
     l0 = float(opt.model.loss(args, None).detach())
     losses = [float(opt.step(args)) for _ in range(4)]
     assert opt.linearization == "multigraph"

@@ -94,3 +94,21 @@ def test_gauss_newton_on_a_pose_graph_takes_the_reference_path(G):
         losses = [float(opt.step((edges, poses))) for _ in range(3)]
         np.testing.assert_allclose(losses, G["gn_pgo12/loss"], rtol=1e-8)
         np.testing.assert_allclose(graph.nodes.detach().tensor().numpy(), G["gn_pgo12/final"], atol=1e-8)
+
+
+@pytest.mark.parametrize("tag", ["ba_small", "ba_huber"])
+def test_schur_complement_path_matches_reference(G, tag, monkeypatch):
+    """With a direct solver and more unknowns than the dense limit, bipartite problems eliminate the point rows exactly
+    (Schur complement) and hand the reduced camera system to the user's solver: same trajectory as the reference's
+    dense Cholesky."""
+    from pypose_amd.optim import multigraph
+    monkeypatch.setattr(multigraph, "DENSE_LIMIT", 0)
+    with oracle_backend():
+        model, opt, args = ba_case(G, tag)
+        rec = run_steps(opt, (args,), {}, 6)
+        assert set(rec["kind"]) == {"multigraph"}
+        lin_plans = opt.__dict__.get("_schur_plans")
+        assert lin_plans, "the Schur plan was not built"
+        compare_trajectory(rec, G, tag, floor=1e-12, rtol=1e-7)
+        np.testing.assert_allclose(model.P.detach().numpy(), G[f"{tag}/P"], atol=1e-6)
+        np.testing.assert_allclose(model.C.detach().tensor().numpy(), G[f"{tag}/C"], atol=1e-6)
