@@ -61,11 +61,13 @@ def main(argv=None):
     ap.add_argument("--points", type=int, default=65132)
     ap.add_argument("--per-point", type=int, default=4)
     ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--solver", choices=["pcg", "cholesky"], default="pcg",
+                    help="pcg: matrix-free PCG on the full system (the reference example); cholesky: exact Schur-complement solve")
     a = ap.parse_args(argv)
     args, (K0, C0, P0) = synthetic(a.cameras, a.points, a.per_point, a.device)
     model = Reproj(K0, C0, P0)
-    optimizer = pp.optim.LM(model, solver=pp.optim.solver.PCG(tol=1e-4, maxiter=250), strategy=pp.optim.strategy.TrustRegion(radius=1e4),
-                            reject=30, sparse=True)
+    solver = pp.optim.solver.PCG(tol=1e-4, maxiter=250) if a.solver == "pcg" else pp.optim.solver.Cholesky()
+    optimizer = pp.optim.LM(model, solver=solver, strategy=pp.optim.strategy.TrustRegion(radius=1e4), reject=30, sparse=True)
     loss0 = float(optimizer.model.loss(args, None).detach())
     t0 = time.perf_counter()
     for k in range(a.steps):
