@@ -1084,3 +1084,75 @@ extern "C" int pplie_block_matvec_f32(const void* B, const void* x, void* y, int
 extern "C" int pplie_block_matvec_f64(const void* B, const void* x, void* y, int64_t N, int m, void* stream) {
   return pplie::block_matvec<double>(B, x, y, N, m, stream);
 }
+
+// ---------------------------------------------------------------------------------------------
+// PCG vector stages on FLAT vectors (optim/multigraph.py: unknowns of several parameters concatenated, the
+// preconditioner applied per parameter by pplie_block_matvec in between).  Scalars as for pplie_pcg_stage
+// ([2 sets][4: rho, pq, rr, -][32 slots][32 stride], sets alternating by iteration parity, it: int32[2]):
+//   pplie_pcg_stage(0)            q += shift o p ; pq += p.q ; clears the idle set            (existing)
+//   pplie_pcg_flat(0)  "update"   alpha = rho/pq ; x += alpha p ; r -= alpha q ; rr += r.r ; it[1] = it[0] + 1
+//   pplie_pcg_flat(1)  "dot"      rho' (idle set) += r.z
+//   pplie_pcg_flat(2)  "direct"   beta = rho'/rho ; p = z + beta p ; rr_hist[it] = rr ; ++it[0]
+// ---------------------------------------------------------------------------------------------
+namespace pplie {
+template <class T> __global__ void __launch_bounds__(256)
+pcg_flat_update_kernel(T* __restrict__ x, T* __restrict__ r, const T* __restrict__ p, const T* __restrict__ q, T* scal, int* it, int64_t n) {
+  const int a = it[0] & 1;
+  const T rho = slot_total(squant(scal, a, Q_RHO)), pq = slot_total(squant(scal, a, Q_PQ));
+  const T alpha = pq != T(0) ? rho / pq : T(0);
+  T acc = T(0);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    x[i] += alpha * p[i];
+    const T ri = r[i] - alpha * q[i];
+    r[i] = ri;
+    acc += ri * ri;
+  }
+  T s = block_sum(acc);
+  if (threadIdx.x == 0) {
+    slot_add(squant(scal, a, Q_RR), s);
+    if (blockIdx.x == 0) it[1] = it[0] + 1;
+  }
+}
+template <class T> __global__ void __launch_bounds__(256)
+pcg_flat_dot_kernel(const T* __restrict__ r, const T* __restrict__ z, T* scal, const int* it, int64_t n) {
+  const int a = (it[1] - 1) & 1;
+  T acc = T(0);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) acc += r[i] * z[i];
+  T s = block_sum(acc);
+  if (threadIdx.x == 0) slot_add(squant(scal, a ^ 1, Q_RHO), s);
+}
+template <class T> __global__ void __launch_bounds__(256)
+pcg_flat_direction_kernel(T* __restrict__ p, const T* __restrict__ z, T* scal, T* __restrict__ rr_hist, int* it, int cap, int64_t n) {
+  const int done = it[1] - 1;
+  const int a = done & 1;
+  const T rho = slot_total(squant(scal, a, Q_RHO)), rho_new = slot_total(squant(scal, a ^ 1, Q_RHO));
+  const T beta = rho != T(0) ? rho_new / rho : T(0);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) p[i] = z[i] + beta * p[i];
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (done < cap) rr_hist[done] = slot_total(squant(scal, a, Q_RR));
+    it[0] = done + 1;
+  }
+}
+template <class T>
+int pcg_flat(int stage, void* x, void* r, void* p, const void* q, const void* z, void* scal, void* rr_hist, void* it, int cap,
+             int64_t n, void* stream) {
+  if (n <= 0 || !scal || !it) return PPLIE_EBADARG;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  int g1 = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+  switch (stage) {
+    case 0: hipLaunchKernelGGL((pcg_flat_update_kernel<T>), dim3(g1), dim3(256), 0, st, (T*)x, (T*)r, (const T*)p, (const T*)q, (T*)scal, (int*)it, n); break;
+    case 1: hipLaunchKernelGGL((pcg_flat_dot_kernel<T>), dim3(g1), dim3(256), 0, st, (const T*)r, (const T*)z, (T*)scal, (const int*)it, n); break;
+    case 2: hipLaunchKernelGGL((pcg_flat_direction_kernel<T>), dim3(g1), dim3(256), 0, st, (T*)p, (const T*)z, (T*)scal, (T*)rr_hist, (int*)it, cap, n); break;
+    default: return PPLIE_EBADARG;
+  }
+  return hipGetLastError() == hipSuccess ? PPLIE_OK : PPLIE_ELAUNCH;
+}
+}  // namespace pplie
+extern "C" int pplie_pcg_flat_f32(int stage, void* x, void* r, void* p, const void* q, const void* z, void* scal, void* rr_hist,
+                                  void* it, int cap, int64_t n, void* stream) {
+  return pplie::pcg_flat<float>(stage, x, r, p, q, z, scal, rr_hist, it, cap, n, stream);
+}
+extern "C" int pplie_pcg_flat_f64(int stage, void* x, void* r, void* p, const void* q, const void* z, void* scal, void* rr_hist,
+                                  void* it, int cap, int64_t n, void* stream) {
+  return pplie::pcg_flat<double>(stage, x, r, p, q, z, scal, rr_hist, it, cap, n, stream);
+}

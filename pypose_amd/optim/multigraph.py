@@ -36,6 +36,8 @@ _SEG_SIG = [ctypes.c_void_p] * 4 + [ctypes.c_int64, ctypes.c_int, ctypes.c_void_
 _MGJ_SIG = [ctypes.c_int] + [ctypes.c_void_p] * 6 + [ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]
 _MGS_SIG = [ctypes.c_void_p] * 5 + [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
 _BMV_SIG = [ctypes.c_void_p] * 3 + [ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]
+_STAGE_SIG = [ctypes.c_int] + [ctypes.c_void_p] * 10 + [ctypes.c_int, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]   # pplie_pcg_stage
+_FLAT_SIG = [ctypes.c_int] + [ctypes.c_void_p] * 8 + [ctypes.c_int, ctypes.c_int64, ctypes.c_void_p]                    # pplie_pcg_flat
 
 
 class _Scatter:
@@ -218,7 +220,7 @@ class MultiGraphLinearization:
             for (pi, _, J), sc in zip(self.slots, self.scatters()):
                 sc.jt_q(J, q, outs[pi], pi in seen)
                 seen.add(pi)
-        return out.addcmul_(shift_flat, v)
+        return out if shift_flat is None else out.addcmul_(shift_flat, v)
 
     def precond_flat(self, v, Binv):
         lib, st = _C.library(), _C.stream_ptr(v.device)
@@ -452,20 +454,44 @@ class _GraphedPCG:
         self.check_every = check_every
         self.rr = z(check_every)
         self.graph = None
+        # HIP iteration: every scalar on the device (csrc/graph.hip, pplie_pcg_stage(0) + pplie_pcg_flat)
+        self.z = z(tot)
+        self.scal = z(2 * 4 * 32 * 32)
+        self.cap = 1 << 16
+        self.rr_hist = z(self.cap)
+        self.it = torch.zeros(2, dtype=torch.int32, device=dev)
+        self.tot = tot
+
+    def _iteration_hip(self):
+        """11 launches: q = H p (1 + one per slot), q += shift o p with p.q, x / r update with |r|^2, z = Binv r per parameter,
+        r.z, p = z + beta p -- scalars stay in the slot-spread device sets of the pose-graph PCG."""
+        L, lib, st = self.lin_like, _C.library(), _C.stream_ptr(self.p.device)
+        sfx = L._sfx()
+        q = L.matvec_flat(self.p, None)
+        stage, flat = lib.symbol("pplie_pcg_stage" + sfx, _STAGE_SIG), lib.symbol("pplie_pcg_flat" + sfx, _FLAT_SIG)
+        with torch.cuda.device(self.p.device):
+            _C.check(stage(0, None, None, self.p.data_ptr(), q.data_ptr(), None, None, self.shift_flat.data_ptr(), self.scal.data_ptr(),
+                           None, self.it.data_ptr(), self.cap, self.tot, 1, st), "pplie_pcg_stage")
+            _C.check(flat(0, self.x.data_ptr(), self.r.data_ptr(), self.p.data_ptr(), q.data_ptr(), None, self.scal.data_ptr(),
+                          self.rr_hist.data_ptr(), self.it.data_ptr(), self.cap, self.tot, st), "pplie_pcg_flat")
+            fn = lib.symbol("pplie_block_matvec" + sfx, _BMV_SIG)
+            for Bi, x, y, n, m in zip(self.Binv, L._split(self.r), L._split(self.z), L.N, L.m):
+                _C.check(fn(Bi.data_ptr(), x.data_ptr(), y.data_ptr(), n, m, st), "pplie_block_matvec")
+            for s_ in (1, 2):
+                _C.check(flat(s_, None, self.r.data_ptr(), self.p.data_ptr(), None, self.z.data_ptr(), self.scal.data_ptr(),
+                              self.rr_hist.data_ptr(), self.it.data_ptr(), self.cap, self.tot, st), "pplie_pcg_flat")
 
     def _iteration(self, k):
         L = self.lin_like
         if self.hip:
-            q = L.matvec_flat(self.p, self.shift_flat)
-        else:
-            ps = L._split(self.p)
-            q = L._cat([y + sh * x for y, sh, x in zip(L._Hp(ps), self.shift, ps)])
+            return self._iteration_hip()
+        ps = L._split(self.p)
+        q = L._cat([y + sh * x for y, sh, x in zip(L._Hp(ps), self.shift, ps)])
         pq = (self.p * q).sum()
         alpha = torch.where(pq != 0, self.rho / pq, torch.zeros_like(pq))       # p.q = 0 only once r = 0
         self.x.add_(alpha * self.p)
         self.r.sub_(alpha * q)
-        zv = L.precond_flat(self.r, self.Binv) if self.hip else \
-            L._cat([(Bi * x.unsqueeze(-2)).sum(-1) for Bi, x in zip(self.Binv, L._split(self.r))])
+        zv = L._cat([(Bi * x.unsqueeze(-2)).sum(-1) for Bi, x in zip(self.Binv, L._split(self.r))])
         rho_new = (self.r * zv).sum()
         beta = torch.where(self.rho != 0, rho_new / self.rho, torch.zeros_like(rho_new))
         self.p.mul_(beta).add_(zv)
@@ -492,10 +518,15 @@ class _GraphedPCG:
         zv = L._cat([(Bi * x.unsqueeze(-2)).sum(-1) for Bi, x in zip(self.Binv, L._split(self.r))])
         self.p.copy_(zv)
         self.rho.copy_((self.r * zv).sum())
+        if self.hip:
+            self.scal.zero_()
+            self.scal[0] = self.rho                                 # set 0, rho, slot 0
+            self.it.zero_()
         bn2 = float((bv * bv).sum())
         if bn2 == 0.0:
             return self.x.clone(), 0
         done = 0
+        maxiter = min(maxiter, self.cap - self.check_every)
         while done < maxiter:
             if self.graph is None and done > 0:                   # first block runs eagerly (warm-up), then capture
                 g = torch.cuda.CUDAGraph()
@@ -509,7 +540,8 @@ class _GraphedPCG:
                 for k in range(self.check_every):
                     self._iteration(k)
             done += self.check_every
-            if float(self.rr[-1]) <= tol * tol * bn2:
+            rr = float(self.rr_hist[done - 1]) if self.hip else float(self.rr[-1])
+            if rr <= tol * tol * bn2:
                 break
         return self.x.clone(), done
 
