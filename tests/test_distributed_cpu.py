@@ -35,6 +35,15 @@ def _worker(rank, world, port, kind, q):
             net = InvNet(pp.SE3(init.tensor()[lo:hi].clone()))
             opt = pp.optim.LM(net, strategy=pp.optim.strategy.Adaptive(damping=1e-2), group=dist.group.WORLD)
             rec = run_steps(opt, (pp.SE3(inp.tensor()[lo:hi].clone()),), {}, 3)
+        elif kind == "ba":
+            from tests.optim_models import ba_case, load_ba_golden
+            B = load_ba_golden()
+            model, opt0, args = ba_case(B, "ba_small")
+            sel = torch.arange(rank, args[0].shape[0], world)            # observations sharded, parameters replicated
+            opt = pp.optim.LM(model, solver=pp.optim.solver.PCG(tol=1e-14, maxiter=5000, check_every=1),
+                              strategy=pp.optim.strategy.TrustRegion(radius=1e4), min=1e-6, group=dist.group.WORLD)
+            rec = run_steps(opt, (tuple(a[sel] for a in args),), {}, 4)
+            rec["nodes"] = model.P.detach().numpy()
         else:
             edges, poses, infos = T(G["pgo40/edges"]), T(G["pgo40/poses"]), T(G["pgo40/infos"])
             sel = torch.arange(rank, edges.shape[0], world)              # interleaved edge shard
@@ -84,3 +93,17 @@ def test_sharded_pose_graph_matches_reference_trajectory():
         np.testing.assert_allclose(out[r]["loss"][:3], G["pgo40/infos/loss"][:3], rtol=1e-7)
         np.testing.assert_allclose(out[r]["damping"][:3], G["pgo40/infos/damping"][:3], rtol=1e-12)
     np.testing.assert_allclose(out[0]["nodes"], out[1]["nodes"], rtol=0, atol=1e-12)   # replicas stay in lock-step
+
+
+@pytest.mark.timeout(300)
+def test_sharded_bundle_adjustment_matches_reference_trajectory():
+    """observations sharded over two ranks, K / C / P replicated: the multi-parameter path all-reduces its block
+    diagonals, gradients, every H p, the loss and the gain-ratio terms"""
+    from tests.optim_models import load_ba_golden
+    out = _run("ba")
+    B = load_ba_golden()
+    for r in (0, 1):
+        assert out[r]["kind"] == ["multigraph"] * 4
+        np.testing.assert_allclose(out[r]["loss"][:3], B["ba_small/loss"][:3], rtol=1e-6)
+        np.testing.assert_allclose(out[r]["damping"][:3], B["ba_small/damping"][:3], rtol=1e-12)
+    np.testing.assert_allclose(out[0]["nodes"], out[1]["nodes"], rtol=0, atol=1e-12)
