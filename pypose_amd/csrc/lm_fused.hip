@@ -15,6 +15,8 @@
 // model's own forward pass); the update is applied to P_cur, which differs from P_lin by rounding after
 // a rejected trial -- exactly as in the reference, where J and R are not refreshed between retries.
 // P_new may alias P_cur (each row is read into LDS before its tile is written back).
+// With R = NULL the kernel takes P_cur as the linearisation point, computes R = Log(P_cur X) itself and (if R_out is
+// given) writes it for the retries of the same step: read P 28 + X 28, write P' 28 + d 28 + R 24.
 #include "rowmap.h"
 #include "chol.h"
 
@@ -24,15 +26,16 @@ constexpr int kTrialPartials = 4096;   // = PPLIE_LM_TRIAL_PARTIALS in include/p
 
 template <class T, int BLOCK>
 __global__ void __launch_bounds__(BLOCK)
-lm_se3inv_trial_kernel(const T* __restrict__ R, const T* Pcur, const T* __restrict__ X,
+lm_se3inv_trial_kernel(const T* __restrict__ R, T* __restrict__ Rout, const T* Pcur, const T* __restrict__ X,
                        T* Pnew, T* __restrict__ D, T* __restrict__ sums /* [kTrialPartials, 4] */,
                        T s, T dmin, T dmax, int64_t n) {
-  __shared__ __attribute__((aligned(16))) T lds[BLOCK * 7 * 5];
+  __shared__ __attribute__((aligned(16))) T lds[BLOCK * 7 * 6];
   T* sR = lds;                 // 6 wide, in a 7-wide slot
   T* sPc = lds + BLOCK * 7;
   T* sX = lds + BLOCK * 14;
   T* sPn = lds + BLOCK * 21;
   T* sD = lds + BLOCK * 28;
+  T* sRo = lds + BLOCK * 35;     // residual at the linearisation point, written out when the kernel computed it
   T a_new = T(0), a_old = T(0), a_jj = T(0), a_jr = T(0);
   const int64_t ntiles = (n + BLOCK - 1) / BLOCK;
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -40,16 +43,23 @@ lm_se3inv_trial_kernel(const T* __restrict__ R, const T* Pcur, const T* __restri
     const int64_t left = n - row0;
     const bool full = left >= BLOCK;
     const int rows = full ? BLOCK : (int)left;
-    slab_g2s<T, BLOCK, BLOCK * 6, true>(R + row0 * 6, sR, rows * 6, full);
+    if (R) slab_g2s<T, BLOCK, BLOCK * 6, true>(R + row0 * 6, sR, rows * 6, full);
     slab_g2s<T, BLOCK, BLOCK * 7, true>(Pcur + row0 * 7, sPc, rows * 7, full);
     slab_g2s<T, BLOCK, BLOCK * 7, true>(X + row0 * 7, sX, rows * 7, full);
     __syncthreads();
     const int t = threadIdx.x;
     if (t < rows) {
       T pc[7], x[7], r[6];
-      row_ld<6>(sR + t * 6, r);
       row_ld<7>(sPc + t * 7, pc);
       row_ld<7>(sX + t * 7, x);
+      if (R) {
+        row_ld<6>(sR + t * 6, r);
+      } else {                       // first trial of a step: P_cur is the linearisation point, r = Log(P X) here
+        T z0[7];
+        se3_mul<T>(pc, x, z0);
+        se3_log<T>(z0, r);
+        if (Rout) row_st<6>(sRo + t * 6, r);
+      }
       // J6 = se3_Jl_inv(r) = [[Ji, -Ji Q Ji], [0, Ji]] built column by column (operation.py:68-75)
       V3<T> tau = v3(r), phi = v3(r + 3);
       const T th2 = norm2(phi);
@@ -108,6 +118,7 @@ lm_se3inv_trial_kernel(const T* __restrict__ R, const T* Pcur, const T* __restri
     __syncthreads();
     slab_s2g<T, BLOCK, BLOCK * 7, true>(sPn, Pnew + row0 * 7, rows * 7, full);
     slab_s2g<T, BLOCK, BLOCK * 7, true>(sD, D + row0 * 7, rows * 7, full);
+    if (!R && Rout) slab_s2g<T, BLOCK, BLOCK * 6, true>(sRo, Rout + row0 * 6, rows * 6, full);
   }
   T v0 = block_sum(a_new), v1 = block_sum(a_old), v2 = block_sum(a_jj), v3_ = block_sum(a_jr);
   // one row of partial sums per workgroup, summed by the caller: 4k same-address float atomics serialise
@@ -120,26 +131,26 @@ lm_se3inv_trial_kernel(const T* __restrict__ R, const T* Pcur, const T* __restri
 }
 
 template <class T>
-int lm_se3inv_trial(const void* R, const void* Pcur, const void* X, void* Pnew, void* D, void* sums, double s, double dmin,
+int lm_se3inv_trial(const void* R, void* Rout, const void* Pcur, const void* X, void* Pnew, void* D, void* sums, double s, double dmin,
                     double dmax, int64_t n, void* stream) {
   if (n < 0) return PPLIE_EBADARG;
   if (n == 0) return PPLIE_OK;
-  if (!R || !Pcur || !X || !Pnew || !D || !sums) return PPLIE_EBADARG;
-  if (!aligned16(R) || !aligned16(Pcur) || !aligned16(X) || !aligned16(Pnew) || !aligned16(D)) return PPLIE_EBADARG;
+  if (!Pcur || !X || !Pnew || !D || !sums) return PPLIE_EBADARG;
+  if ((R && !aligned16(R)) || (Rout && !aligned16(Rout)) || !aligned16(Pcur) || !aligned16(X) || !aligned16(Pnew) || !aligned16(D)) return PPLIE_EBADARG;
   constexpr int BLOCK = 256;
   int64_t nt = (n + BLOCK - 1) / BLOCK;
   int grid = (int)(nt < kTrialPartials ? nt : kTrialPartials);       // grid-stride: one atomic per workgroup on the four sums
   hipLaunchKernelGGL((lm_se3inv_trial_kernel<T, BLOCK>), dim3(grid), dim3(BLOCK), 0, reinterpret_cast<hipStream_t>(stream),
-                     (const T*)R, (const T*)Pcur, (const T*)X, (T*)Pnew, (T*)D, (T*)sums, (T)s, (T)dmin, (T)dmax, n);
+                     (const T*)R, (T*)Rout, (const T*)Pcur, (const T*)X, (T*)Pnew, (T*)D, (T*)sums, (T)s, (T)dmin, (T)dmax, n);
   return hipGetLastError() == hipSuccess ? PPLIE_OK : PPLIE_ELAUNCH;
 }
 }  // namespace pplie
 
-extern "C" int pplie_lm_se3inv_trial_f32(const void* R, const void* Pcur, const void* X, void* Pnew, void* D, void* sums,
+extern "C" int pplie_lm_se3inv_trial_f32(const void* R, void* Rout, const void* Pcur, const void* X, void* Pnew, void* D, void* sums,
                                          double s, double dmin, double dmax, int64_t n, void* stream) {
-  return pplie::lm_se3inv_trial<float>(R, Pcur, X, Pnew, D, sums, s, dmin, dmax, n, stream);
+  return pplie::lm_se3inv_trial<float>(R, Rout, Pcur, X, Pnew, D, sums, s, dmin, dmax, n, stream);
 }
-extern "C" int pplie_lm_se3inv_trial_f64(const void* R, const void* Pcur, const void* X, void* Pnew, void* D, void* sums,
+extern "C" int pplie_lm_se3inv_trial_f64(const void* R, void* Rout, const void* Pcur, const void* X, void* Pnew, void* D, void* sums,
                                          double s, double dmin, double dmax, int64_t n, void* stream) {
-  return pplie::lm_se3inv_trial<double>(R, Pcur, X, Pnew, D, sums, s, dmin, dmax, n, stream);
+  return pplie::lm_se3inv_trial<double>(R, Rout, Pcur, X, Pnew, D, sums, s, dmin, dmax, n, stream);
 }

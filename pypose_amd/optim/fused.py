@@ -32,7 +32,7 @@ from ..lietensor import operation as _op
 from . import blocks as _blocks
 
 _PARTIALS = 4096          # PPLIE_LM_TRIAL_PARTIALS: rows of per-workgroup partial sums the kernel may write
-_TRIAL_SIG = [ctypes.c_void_p] * 6 + [ctypes.c_double] * 3 + [ctypes.c_int64, ctypes.c_void_p]
+_TRIAL_SIG = [ctypes.c_void_p] * 7 + [ctypes.c_double] * 3 + [ctypes.c_int64, ctypes.c_void_p]
 
 
 class OpTracer:
@@ -83,7 +83,9 @@ class Se3InvLinearization:
         self.opt, self.P = opt, P
         self.n = P.numel() // 7
         self.X = X.detach().reshape(self.n, 7).contiguous()
-        self.R = r.detach().reshape(self.n, 6).contiguous()
+        # r = None (LM(static=True)): the first trial kernel of the step computes Log(P X) itself and leaves it in a
+        # buffer for the retries, so the step needs no separate residual evaluation at all
+        self.R = r.detach().reshape(self.n, 6).contiguous() if r is not None else None
         self.scale = 1.0
         self.sums = None
 
@@ -100,10 +102,14 @@ class Se3InvLinearization:
         D = torch.empty((self.n, 7), dtype=pt.dtype, device=pt.device)
         part = torch.zeros((_PARTIALS, 4), dtype=pt.dtype, device=pt.device)
         fn = _C.library().symbol("pplie_lm_se3inv_trial" + _blocks._suffix(pt), _TRIAL_SIG)
+        rbuf = torch.empty((self.n, 6), dtype=pt.dtype, device=pt.device) if self.R is None else None
         with torch.cuda.device(pt.device):
-            code = fn(self.R.data_ptr(), pt.data_ptr(), self.X.data_ptr(), out.data_ptr(), D.data_ptr(), part.data_ptr(),
+            code = fn(self.R.data_ptr() if self.R is not None else None, rbuf.data_ptr() if rbuf is not None else None,
+                      pt.data_ptr(), self.X.data_ptr(), out.data_ptr(), D.data_ptr(), part.data_ptr(),
                       scale, self.dmin, self.dmax, self.n, _C.stream_ptr(pt.device))
         _C.check(code, "pplie_lm_se3inv_trial")
+        if rbuf is not None:
+            self.R = rbuf                            # retries of this step linearise at the same point
         return D, part.sum(0)
 
     def verify(self, ref, dmin, dmax, rtol=1e-3):
@@ -261,10 +267,7 @@ def try_fused(opt, pg, input, target, weight, cache):
         if hit is not None and _same_input(hit[0], input) and hit[1] is P:
             kind, operands = hit[2], hit[3]
             if kind == "se3inv" and weight is None and trivial and solver_ok:
-                X = operands
-                Z = _C.row_op("se3_mul_fwd", [P.detach().reshape(-1, 7), X.reshape(-1, 7)], (7,))[0]
-                (r,) = _C.row_op("se3_log_fwd", [Z], (6,))
-                return Se3InvLinearization(opt, P, X, r)
+                return Se3InvLinearization(opt, P, operands, None)
             if kind == "pgo" and len(opt.corrector) == 1:
                 return _pgo_linearization(opt, operands, weight, P, trivial)
     with torch.no_grad(), OpTracer() as tr, _pg.GatherRecorder(params) as rec:

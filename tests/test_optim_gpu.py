@@ -44,6 +44,7 @@ def test_fused_se3inv_trial_kernel_vs_oracle(dtype, tol, n):
     P = pp.Parameter(pp.randn_SE3(n, dtype=dtype, device=DEV))
     X = pp.randn_SE3(n, dtype=dtype, device=DEV)
     r = (P @ X).Log().tensor().detach()
+    P0 = P.detach().tensor().clone()
 
     class Opt:
         group = None
@@ -62,6 +63,14 @@ def test_fused_se3inv_trial_kernel_vs_oracle(dtype, tol, n):
     # in place: P_new written over P_cur gives the same result
     D2, sums2 = lin._trial(None, 1.37)
     assert torch.equal(P.detach().tensor(), out) and torch.equal(D2, D) and torch.equal(sums2, sums)
+    # R = NULL: the kernel computes the residual at P_cur itself and leaves it for the retries of the step
+    P3 = pp.Parameter(pp.SE3(P0))
+    lin3 = fused.Se3InvLinearization(Opt(), P3, X, None)
+    lin3.build_normal_equations(1e-6, 1e32)
+    out3 = torch.empty((n, 7), dtype=dtype, device=DEV)
+    D3, sums3 = lin3._trial(out3, 1.37)
+    assert (D3 - D).abs().max().item() <= tol * max(1.0, D.abs().max().item()) and (out3 - out).abs().max().item() <= tol
+    assert lin3.R is not None and (lin3.R - r).abs().max().item() <= tol
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-11), (torch.float32, 3e-5)])
