@@ -42,12 +42,16 @@ class _Dispatch:
         return getattr(self._theirs, item)
 
 
-def activate(pypose=None, force: bool = False):
+def activate(pypose=None, force: bool = False, optim: bool = False):
     """Rebind the Lie-op Functions inside ``pypose`` to the HIP-backed ones.
 
     pypose: the imported reference package (default: ``import pypose``).
     force:  route every call to pypose_amd regardless of device (used by the test-suite, where
             the HIP launcher is replaced by a stand-in).
+    optim:  also rebind ``pypose.optim.LM / LevenbergMarquardt / GN / GaussNewton`` to pypose_amd's optimizers, which
+            keep the reference's constructor and ``step`` contract and add the structured (block / pose-graph /
+            multi-parameter / fused) linearisations; the reference's own solver, strategy, kernel and corrector objects
+            are accepted as they are (same call shapes), its LieTensor parameters are recognised by their ``ltype``.
     """
     pypose = importlib.import_module("pypose") if pypose is None else pypose
     mods = [importlib.import_module(pypose.__name__ + ".lietensor.operation"),
@@ -61,6 +65,15 @@ def activate(pypose=None, force: bool = False):
             if hasattr(m, name):
                 _saved[(m, name)] = getattr(m, name)
                 setattr(m, name, shim)
+    if optim:
+        from .optim import optimizer as _ours
+        omods = [importlib.import_module(pypose.__name__ + ".optim"), importlib.import_module(pypose.__name__ + ".optim.optimizer")]
+        for name, cls in (("LM", _ours.LevenbergMarquardt), ("LevenbergMarquardt", _ours.LevenbergMarquardt),
+                          ("GN", _ours.GaussNewton), ("GaussNewton", _ours.GaussNewton)):
+            for m in omods:
+                if hasattr(m, name):
+                    _saved[(m, name)] = getattr(m, name)
+                    setattr(m, name, cls)
     return pypose
 
 

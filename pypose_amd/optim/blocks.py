@@ -26,6 +26,15 @@ _CH_SIG = [ctypes.c_void_p] * 3 + [ctypes.c_int64, ctypes.c_int, ctypes.c_void_p
 _HIP_DR, _HIP_DP = (3, 4, 6, 7), (3, 4, 5, 6, 7, 8)
 
 
+def lie_manifold_width(p):
+    """Tangent width of a Lie-GROUP parameter (whose gradients are zero-padded to the stored width), else None.
+    Duck-typed on ``.ltype`` so that LieTensors of an activated reference ``pypose`` count as well."""
+    lt = getattr(p, "ltype", None)
+    if lt is None or not hasattr(lt, "manifold") or not hasattr(lt, "dimension"):
+        return None
+    return int(lt.manifold[0]) if tuple(lt.dimension) != tuple(lt.manifold) else None
+
+
 def _suffix(t):
     return {torch.float32: "_f32", torch.float64: "_f64"}.get(t.dtype)
 

@@ -52,6 +52,13 @@ class OpTracer:
         self.events.append((name, tuple(ins), tuple(outs)))
 
 
+def _is_se3_group(P):
+    """an SE3 group LieTensor of this package or of an activated reference pypose (same type name, 7-wide, 6 dof)"""
+    lt = getattr(P, "ltype", None)
+    return lt is _lt.SE3_type or (lt is not None and type(lt).__name__ == "SE3Type" and tuple(getattr(lt, "dimension", ())) == (7,)
+                                  and tuple(getattr(lt, "manifold", ())) == (6,))
+
+
 def _same(a, b):
     # (the Lie methods flatten leading dims to rows before launching: same storage, same element count)
     return a.data_ptr() == b.data_ptr() and a.numel() == b.numel() and a.dtype == b.dtype and a.is_contiguous() and b.is_contiguous()
@@ -63,7 +70,7 @@ def match_se3inv(trace, R, params):
         return None
     (n0, i0, o0), (n1, i1, o1) = trace.events
     P = params[0]
-    if n0 != "se3_mul_fwd" or n1 != "se3_log_fwd" or getattr(P, "ltype", None) is not _lt.SE3_type:
+    if n0 != "se3_mul_fwd" or n1 != "se3_log_fwd" or not _is_se3_group(P):
         return None
     A, X = i0
     if not _same(A, P) or X.requires_grad or X.numel() != P.numel() or P.dim() < 2 or not _same(i1[0], o0[0]):
@@ -170,7 +177,7 @@ def match_pgo(trace, gathers, R, params):
     if len(trace.events) != 5 or len(gathers) != 2 or len(R) != 1 or len(params) != 1:
         return None
     P = params[0]
-    if getattr(P, "ltype", None) is not _lt.SE3_type or P.dim() != 2 or not P.is_contiguous() \
+    if not _is_se3_group(P) or P.dim() != 2 or not P.is_contiguous() \
             or any(src is not P for src, _, _ in gathers):
         return None
     by_out = {o[0].data_ptr(): (n, i) for n, i, o in trace.events}

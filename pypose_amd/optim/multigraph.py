@@ -120,7 +120,8 @@ class _Scatter:
 
 
 def _tangent_width(p):
-    return int(p.ltype.manifold[0]) if isinstance(p, _lt.LieTensor) and not p.ltype.on_manifold else p.shape[-1]
+    m = _blocks.lie_manifold_width(p)
+    return p.shape[-1] if m is None else m
 
 
 class MultiGraphOperator:

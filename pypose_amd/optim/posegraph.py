@@ -540,7 +540,7 @@ def try_graph_linearization(opt, pg, input, target, weight, R, params, rec, cach
     if not cache[sig]:
         return None
     # tangent width: gradients of LieTensor group parameters are zero-padded to the embedding
-    m = int(param.ltype.manifold[0]) if isinstance(param, _lt.LieTensor) and not param.ltype.on_manifold else wfull
+    m = _blocks.lie_manifold_width(param) or wfull
     J = Jcat.reshape(E, dr, K, wfull)[..., :m].permute(0, 2, 1, 3)    # [E, K, dr, m]
     return build_graph_linearization(opt, weight, r.detach().reshape(E, dr), J, torch.stack(node_idx, dim=-1), param, wfull, m)
 

@@ -115,3 +115,55 @@ def test_rank4_callers_run_unmodified_on_activated_ops(ref_pp):
             activate.deactivate()
     for g, w in zip(got, want):
         torch.testing.assert_close(g, w, rtol=1e-8, atol=1e-10)
+
+
+def test_reference_code_gets_the_structured_optimizers(ref_pp):
+    """activate(pypose, optim=True): the reference's own `pp.optim.LM(...)` call sites -- its PoseGraph example model
+    built from `pypose.LieTensor` / `pypose.Parameter`, its solver and strategy objects -- run on pypose_amd's optimizer,
+    take the pose-graph / block linearisations and walk the trajectory recorded from the un-activated reference."""
+    from pypose_amd import activate
+    from tests.optim_models import load_lm_golden
+    from tests.oracle_backend import oracle_backend
+    pp = ref_pp
+    G = load_lm_golden()
+    D = torch.float64
+
+    class PoseGraph(torch.nn.Module):                      # examples/module/pgo/pgo.py:15-25, with the REFERENCE's types
+        def __init__(self, nodes):
+            super().__init__()
+            self.nodes = pp.Parameter(nodes)
+
+        def forward(self, edges, poses):
+            node1 = self.nodes[edges[..., 0]]
+            node2 = self.nodes[edges[..., 1]]
+            error = poses.Inv() @ node1.Inv() @ node2
+            return error.Log().tensor()
+
+    class InvNet(torch.nn.Module):
+        def __init__(self, init):
+            super().__init__()
+            self.pose = pp.Parameter(init)
+
+        def forward(self, input):
+            return (self.pose @ input).Log().tensor()
+
+    with oracle_backend():
+        activate.activate(pp, force=True, optim=True)
+        try:
+            assert pp.optim.LM.__module__.startswith("pypose_amd")
+            edges = torch.from_numpy(G["pgo40/edges"])
+            poses = pp.SE3(torch.from_numpy(G["pgo40/poses"]))
+            graph = PoseGraph(pp.SE3(torch.from_numpy(G["pgo40/init"])))
+            opt = pp.optim.LM(graph, solver=pp.optim.solver.Cholesky(), strategy=pp.optim.strategy.TrustRegion(radius=1e4), min=1e-6)
+            losses = [float(opt.step((edges, poses), weight=torch.from_numpy(G["pgo40/infos"]))) for _ in range(4)]
+            assert opt.linearization == "graph"
+            np.testing.assert_allclose(losses, G["pgo40/infos/loss"][:4], rtol=1e-7)
+            net = InvNet(pp.SE3(torch.from_numpy(G["invnet/init"])))
+            opt = pp.optim.LM(net, strategy=pp.optim.strategy.Adaptive(damping=1e-6))
+            inp = pp.SE3(torch.from_numpy(G["invnet/input"]))
+            losses = [float(opt.step(inp)) for _ in range(3)]
+            assert opt.linearization == "block"
+            np.testing.assert_allclose(losses, G["invnet/adaptive/loss"][:3], rtol=1e-6, atol=1e-16)
+        finally:
+            activate.deactivate()
+    assert pp.optim.LM.__module__.startswith("pypose.")
