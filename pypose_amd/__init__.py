@@ -23,4 +23,6 @@ from . import optim
 from . import module
 from . import io
 from . import function
-from .function import cart2homo, homo2cart, point2pixel, pixel2point, reprojerr
+from . import testing
+from . import func
+from .function import cart2homo, homo2cart, point2pixel, pixel2point, reprojerr, is_lietensor, is_SE3, hasnan

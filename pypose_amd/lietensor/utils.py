@@ -48,42 +48,61 @@ def identity_like(liegroup, **kwargs):
     return liegroup.ltype.identity_like(*liegroup.lshape, **kwargs)
 
 
+def _needs_lietensor(fn):
+    """The free functions refuse a first argument that is not a LieTensor (reference utils.py:1345-1351)."""
+    @functools.wraps(fn)
+    def checked(*args, **kwargs):
+        assert isinstance(args[0], LieTensor), "Invalid LieTensor Type."
+        return fn(*args, **kwargs)
+    return checked
+
+
+@_needs_lietensor
 def Exp(input):
     return input.Exp()
 
 
+@_needs_lietensor
 def Log(input):
     return input.Log()
 
 
+@_needs_lietensor
 def Inv(input):
     return input.Inv()
 
 
+@_needs_lietensor
 def Mul(input, other):
     return input * other
 
 
+@_needs_lietensor
 def Retr(X, a):
     return X.Retr(a)
 
 
+@_needs_lietensor
 def Act(X, p):
     return X.Act(p)
 
 
+@_needs_lietensor
 def Adj(input, p):
     return input.Adj(p)
 
 
+@_needs_lietensor
 def AdjT(input, p):
     return input.AdjT(p)
 
 
+@_needs_lietensor
 def Jinvp(input, p):
     return input.Jinvp(p)
 
 
+@_needs_lietensor
 def Jr(input):
     return input.Jr()
 

@@ -216,7 +216,9 @@ def _linearize(opt, pg, input, target, weight, gauss_newton=False):
     steps on gauge-free graphs): only the block and dense linearisations reproduce that."""
     params = [p for p in pg['params'] if p.requires_grad]
     cache = opt.__dict__.setdefault('_structure_cache', {})
-    if getattr(opt, 'structured', True) and params:
+    # Under torch.inference_mode nothing can be recorded for backward sweeps: only the reference's own
+    # functional-jacobian linearisation (DenseLinearization) applies (tests/optim/test_optimizer.py:153-159).
+    if getattr(opt, 'structured', True) and params and not torch.is_inference_mode_enabled():
         from . import posegraph as _pg
         if getattr(opt, 'fused', False) and not gauss_newton:
             from . import fused as _fused
