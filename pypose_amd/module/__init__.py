@@ -1,1 +1,2 @@
 from .imu_preintegrator import IMUPreintegrator
+from .loss import GeodesicLoss, geodesic_loss

@@ -213,7 +213,9 @@ def _row_count(t):
 def _linearize(opt, pg, input, target, weight, gauss_newton=False):
     """Pick the cheapest valid linearisation for this model (cached per shape signature).  Gauss-Newton solves
     the rectangular system ``W J d = -W R`` with the user's solver (pseudo-inverse by default, i.e. minimum-norm
-    steps on gauge-free graphs): only the block and dense linearisations reproduce that."""
+    steps on gauge-free graphs): the block and dense linearisations reproduce that literally; single-parameter
+    graphs too large for a dense J (or run with a PCG solver) get the same step from plain CG on the normal
+    equations (posegraph.GraphLinearization.solve_gauss_newton)."""
     params = [p for p in pg['params'] if p.requires_grad]
     cache = opt.__dict__.setdefault('_structure_cache', {})
     # Under torch.inference_mode nothing can be recorded for backward sweeps: only the reference's own
@@ -244,11 +246,11 @@ def _linearize(opt, pg, input, target, weight, gauss_newton=False):
                         verdict = cache[sig] = _blocks.probe_block_structure(R, params, Jb)
                     if verdict:
                         return BlockLinearization(opt, pg, input, target, weight, R, params, Jb)
-            elif rec.events and not gauss_newton:
+            elif rec.events and (not gauss_newton or _pg.gauss_newton_on_graph(opt, params)):
                 lin = None
                 if same_rows and cache.get(sig) is not False:
-                    lin = _pg.try_graph_linearization(opt, pg, input, target, weight, R, params, rec, cache, sig)
-                if lin is None and all(p.dim() == 2 for p in params) and R[0].dim() >= 2:
+                    lin = _pg.try_graph_linearization(opt, pg, input, target, weight, R, params, rec, cache, sig, gauss_newton)
+                if lin is None and not gauss_newton and all(p.dim() == 2 for p in params) and R[0].dim() >= 2:
                     from . import multigraph as _mg       # several parameters / widths (bundle adjustment)
                     lin = _mg.try_multigraph_linearization(opt, pg, input, target, weight, R, params, rec, cache, sig)
                 if lin is not None:

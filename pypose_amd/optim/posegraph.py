@@ -238,9 +238,11 @@ class FusedPCG:
                          self.it.data_ptr(), self.cap, self.N, self.m, st)
             _C.check(code, "pplie_pcg_stage")
 
-    def solve(self, lin, s, dmin, dmax, tol, maxiter, group):
+    def solve(self, lin, s, dmin, dmax, tol, maxiter, group, plain=False):
         """Solve (H + damping) x = -g for the linearisation ``lin`` (raw block diagonal ``lin.B``, gradient ``lin.g``)
-        with the LM clamp [dmin, dmax] and compounded damping factor ``s`` folded in by ``pplie_pcg_prepare``."""
+        with the LM clamp [dmin, dmax] and compounded damping factor ``s`` folded in by ``pplie_pcg_prepare``.
+        ``plain=True`` runs the same launches with the identity as preconditioner: from x = 0 plain CG stays in
+        range(H) and converges to the minimum-norm solution of a singular H (Gauss-Newton's pseudo-inverse step)."""
         bsr = lin.HB is not None and group is None and self.m in (3, 6, 7)
         if bsr != getattr(self, 'bsr', None):
             self.graph = None                                       # the captured iteration differs
@@ -267,6 +269,11 @@ class FusedPCG:
                 self.x.data_ptr(), self.r.data_ptr(), self.z.data_ptr(), self.p.data_ptr(), self.scal.data_ptr(),
                 float(s), float(dmin), float(dmax), self.N, self.m, _C.stream_ptr(self.J.device))
             _C.check(code, "pplie_pcg_prepare")
+            if plain:                                               # z = r, p = r, rho = r.r = |b|^2, Binv = I
+                self.Binv.copy_(torch.eye(self.m, dtype=self.Binv.dtype, device=self.Binv.device).expand_as(self.Binv))
+                self.z.copy_(self.r)
+                self.p.copy_(self.r)
+                self.scal[0:1024].copy_(self.scal[3 * 1024:4 * 1024])
             bn2_slots = self.scal[3 * 1024:4 * 1024:32]             # |b|^2: set 0, quantity 3, 32 slots (csrc/graph.hip)
             bn2 = None
             maxiter = min(maxiter, self.cap - self.check_every)
@@ -462,30 +469,39 @@ class GraphLinearization:
             A.diagonal().add_(shift.reshape(-1))
             Dn = solver(A=A, b=(-self.g).reshape(-1, 1)).reshape(N, m)
         else:
-            if not isinstance(solver, PCG):
-                if not getattr(self.opt, '_warned_pcg', False):
-                    warnings.warn(f"{type(solver).__name__} cannot factor a {N * m}-unknown pose graph densely; "
-                                  f"using the matrix-free block-Jacobi PCG (tol 1e-10) instead.")
-                    self.opt._warned_pcg = True
-                solver = PCG(tol=1e-10, maxiter=max(1000, 2 * N))
-            maxiter = N * m * 10 if solver.maxiter is None else solver.maxiter
-            if self._hip() and getattr(solver, 'fused', True) and m in (3, 6, 7):
-                cache = self.opt.__dict__.setdefault('_pcg_workspaces', {})
-                key = (self.E, self.K, self.dr, self.m, self.N, self.J.dtype, self.J.device, self.W is not None,
-                       solver.check_every)
-                wsp = cache.get(key)
-                if wsp is None:
-                    wsp = cache[key] = FusedPCG(*key)
-                Dn, solver.iterations = wsp.solve(self, self.s, self.dmin, self.dmax, solver.tol, maxiter, self.group)
-            else:
-                shift = self.s * self.diag_clamped - self.diag_raw
-                Bd = self.B.clone()
-                Bd.diagonal(dim1=-2, dim2=-1).copy_(self.s * self.diag_clamped)
-                Binv = torch.linalg.inv(Bd)
-                Dn = solver.solve(lambda p: self._Hp(p) + shift * p, -self.g,
-                                  lambda r: (Binv * r.unsqueeze(-2)).sum(-1))
+            Dn = self._pcg(solver, self.s, self.dmin, self.dmax, plain=False)
         assert not torch.any(torch.isnan(Dn)), 'Linear solve produced NaN (matrix may not be positive-definite)'
         return self.nodes_to_step(Dn)
+
+    def _pcg(self, solver, s, dmin, dmax, plain):
+        """(H + damping) d = -g by the matrix-free conjugate gradient (block-Jacobi preconditioned unless ``plain``)."""
+        N, m = self.N, self.m
+        if not isinstance(solver, PCG):
+            if not getattr(self.opt, '_warned_pcg', False):
+                warnings.warn(f"{type(solver).__name__} cannot factor a {N * m}-unknown pose graph densely; "
+                              f"using the matrix-free {'conjugate gradient' if plain else 'block-Jacobi PCG'} (tol 1e-10) instead.")
+                self.opt._warned_pcg = True
+            solver = PCG(tol=1e-10, maxiter=max(1000, 2 * N))
+        maxiter = N * m * 10 if solver.maxiter is None else solver.maxiter
+        if self._hip() and getattr(solver, 'fused', True) and m in (3, 6, 7):
+            cache = self.opt.__dict__.setdefault('_pcg_workspaces', {})
+            key = (self.E, self.K, self.dr, self.m, self.N, self.J.dtype, self.J.device, self.W is not None,
+                   solver.check_every)
+            wsp = cache.get(key)
+            if wsp is None:
+                wsp = cache[key] = FusedPCG(*key)
+            Dn, solver.iterations = wsp.solve(self, s, dmin, dmax, solver.tol, maxiter, self.group, plain=plain)
+            return Dn
+        clamped = self.diag_raw.clamp(dmin, dmax)
+        shift = s * clamped - self.diag_raw
+        if plain:
+            precond = lambda r: r.clone()
+        else:
+            Bd = self.B.clone()
+            Bd.diagonal(dim1=-2, dim2=-1).copy_(s * clamped)
+            Binv = torch.linalg.inv(Bd)
+            precond = lambda r: (Binv * r.unsqueeze(-2)).sum(-1)
+        return solver.solve(lambda p: self._Hp(p) + shift * p, -self.g, precond)
 
     def dense_matrix(self):
         """H = J^T W J as a dense [N m, N m] matrix (small graphs / parity tests)."""
@@ -498,13 +514,26 @@ class GraphLinearization:
         return A.view(N, N, m, m).permute(0, 2, 1, 3).reshape(N * m, N * m).contiguous()
 
     def solve_gauss_newton(self, solver):
-        raise NotImplementedError
+        """The reference solves the rectangular ``W J d = -W R`` with its solver (pseudo-inverse by default,
+        optimizer.py:318-326): the least-squares step of minimum norm.  That is the minimum-norm solution of the
+        normal equations ``J^T (W^T W) J d = -J^T (W^T W) R`` (this linearisation was built with ``W^T W``), which
+        unpreconditioned CG started at zero converges to -- also on gauge-free graphs, where H is singular."""
+        self.B, self.g = self._assemble()
+        inf = float('inf')
+        Dn = self._pcg(solver, 1.0, -inf, inf, plain=True)
+        assert not torch.any(torch.isnan(Dn)), 'Linear solve produced NaN'
+        return self.nodes_to_step(Dn)
 
     def strategy_args(self):
         return GraphOperator(self), self.R.reshape(-1, 1)
 
 
-def try_graph_linearization(opt, pg, input, target, weight, R, params, rec, cache, sig):
+def gauss_newton_on_graph(opt, params):
+    """Gauss-Newton takes the graph path when the user asks for an iterative solver or a dense J is out of reach."""
+    return len(params) == 1 and (isinstance(opt.solver, PCG) or params[0].numel() > DENSE_LIMIT)
+
+
+def try_graph_linearization(opt, pg, input, target, weight, R, params, rec, cache, sig, gauss_newton=False):
     """Build a GraphLinearization if the recorded gathers explain the whole Jacobian."""
     if len(params) != 1 or len(R) != 1 or params[0].dim() != 2:
         cache[sig] = False
@@ -542,11 +571,14 @@ def try_graph_linearization(opt, pg, input, target, weight, R, params, rec, cach
     # tangent width: gradients of LieTensor group parameters are zero-padded to the embedding
     m = _blocks.lie_manifold_width(param) or wfull
     J = Jcat.reshape(E, dr, K, wfull)[..., :m].permute(0, 2, 1, 3)    # [E, K, dr, m]
-    return build_graph_linearization(opt, weight, r.detach().reshape(E, dr), J, torch.stack(node_idx, dim=-1), param, wfull, m)
+    return build_graph_linearization(opt, weight, r.detach().reshape(E, dr), J, torch.stack(node_idx, dim=-1), param, wfull, m,
+                                     gauss_newton)
 
 
-def build_graph_linearization(opt, weight, r, J, idx, param, wfull, m):
-    """Corrector and weights applied to per-edge residuals r [E,dr] and blocks J [E,K,dr,m] -> GraphLinearization."""
+def build_graph_linearization(opt, weight, r, J, idx, param, wfull, m, gauss_newton=False):
+    """Corrector and weights applied to per-edge residuals r [E,dr] and blocks J [E,K,dr,m] -> GraphLinearization.
+    Gauss-Newton weights both sides of its rectangular system with W (optimizer.py:318-322), so its normal
+    equations carry ``W^T W`` where Levenberg-Marquardt's ``J^T W J`` carries ``W``."""
     E, K, dr, _ = J.shape
     c = opt.corrector[0]                                              # row-local: acts on [E, dr, K*m]
     Rc, Jc = c(R=r, J=J.permute(0, 2, 1, 3).reshape(E, dr, K * m))
@@ -556,4 +588,6 @@ def build_graph_linearization(opt, weight, r, J, idx, param, wfull, m):
         w = weight[0] if isinstance(weight, (tuple, list)) else weight
         ws, ni = opt.model._weight_blocks(w, r)
         Wb = ws.repeat(ni, 1, 1).contiguous()
+        if gauss_newton:
+            Wb = (Wb.mT @ Wb).contiguous()
     return GraphLinearization(opt, Wb, Rc, param, idx, Jc, wfull, m)

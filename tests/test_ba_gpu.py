@@ -101,3 +101,28 @@ def test_multigraph_hip_products_match_tensor_formulation(dtype, tol, weighted):
     got = lin.precond_flat(v, Binv)
     want = lin._cat([(Bi * x.unsqueeze(-2)).sum(-1) for Bi, x in zip(Binv, xs)])
     assert (got - want).abs().max().item() <= tol * want.abs().max().item()
+
+
+def test_gauss_newton_graph_path_on_device(G):
+    """GN with a PCG solver on the HIP graph path (plain CG through the fused PCG launches): the reference's
+    pseudo-inverse steps on the gauge-free 12-node graph (golden recorded from the real reference), then the same
+    algorithm at 10^4 nodes, where no dense J exists."""
+    from tests.optim_models import PoseGraph, T, load_lm_golden
+    from tests.test_optim_gpu import _synthetic_graph
+    L = load_lm_golden()
+    edges, poses = T(L["pgo12/edges"], DEV), pp.SE3(T(L["pgo12/poses"], DEV))
+    graph = PoseGraph(pp.SE3(T(L["pgo12/init"], DEV)))
+    opt = pp.optim.GN(graph, solver=pp.optim.solver.PCG(tol=1e-13, maxiter=512, check_every=4))
+    losses = [float(opt.step((edges, poses))) for _ in range(3)]
+    np.testing.assert_allclose(losses, G["gn_pgo12/loss"], rtol=1e-7)
+    np.testing.assert_allclose(graph.nodes.detach().tensor().cpu().numpy(), G["gn_pgo12/final"], atol=1e-7)
+    assert opt.__dict__.get("_pcg_workspaces"), "the fused PCG workspace was not used"
+
+    edges, rel, init = _synthetic_graph(10_000, 40_000, torch.float64)
+    big = PoseGraph(init)
+    opt = pp.optim.GN(big)                      # default PINV solver: too large for a dense J -> graph path, warns once
+    with pytest.warns(UserWarning, match="conjugate gradient"):
+        first = float(opt.step((edges, rel)))
+    start = float(opt.last)
+    second = float(opt.step((edges, rel)))
+    assert first < 0.05 * start and second <= first * 1.0001

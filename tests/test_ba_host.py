@@ -112,3 +112,39 @@ def test_schur_complement_path_matches_reference(G, tag, monkeypatch):
         compare_trajectory(rec, G, tag, floor=1e-12, rtol=1e-7)
         np.testing.assert_allclose(model.P.detach().numpy(), G[f"{tag}/P"], atol=1e-6)
         np.testing.assert_allclose(model.C.detach().tensor().numpy(), G[f"{tag}/C"], atol=1e-6)
+
+
+def test_gauss_newton_graph_path_reproduces_the_pseudo_inverse_steps(G):
+    """With a PCG solver (or a graph too large for a dense J) Gauss-Newton runs on the graph linearisation: plain CG
+    from zero on the singular, gauge-free normal equations gives the reference's minimum-norm (pinv) steps."""
+    from tests.optim_models import PoseGraph, T, load_lm_golden
+    from pypose_amd.optim.optimizer import _linearize
+    L = load_lm_golden()
+    with oracle_backend():
+        edges, poses = T(L["pgo12/edges"]), pp.SE3(T(L["pgo12/poses"]))
+        graph = PoseGraph(pp.SE3(T(L["pgo12/init"])))
+        opt = pp.optim.GN(graph, solver=pp.optim.solver.PCG(tol=1e-13, maxiter=500, check_every=1))
+        with torch.no_grad():
+            assert _linearize(opt, opt.param_groups[0], (edges, poses), None, None, gauss_newton=True).kind == "graph"
+        losses = [float(opt.step((edges, poses))) for _ in range(3)]
+        np.testing.assert_allclose(losses, G["gn_pgo12/loss"], rtol=1e-7)
+        np.testing.assert_allclose(graph.nodes.detach().tensor().numpy(), G["gn_pgo12/final"], atol=1e-7)
+
+
+def test_gauss_newton_graph_path_weights_both_sides():
+    """GN's rectangular system is W J d = -W R: its normal equations carry W^T W (the dense path is the reference)."""
+    from tests.optim_models import PoseGraph, T, load_lm_golden
+    L = load_lm_golden()
+    torch.manual_seed(4)
+    M = torch.randn(6, 6, dtype=torch.float64)
+    W = M @ M.T / 6 + torch.eye(6, dtype=torch.float64)
+    with oracle_backend():
+        edges, poses = T(L["pgo12/edges"]), pp.SE3(T(L["pgo12/poses"]))
+        out = []
+        for solver in (None, pp.optim.solver.PCG(tol=1e-13, maxiter=500, check_every=1)):
+            graph = PoseGraph(pp.SE3(T(L["pgo12/init"])))
+            opt = pp.optim.GN(graph, solver=solver, weight=W)
+            losses = [float(opt.step((edges, poses))) for _ in range(2)]
+            out.append((losses, graph.nodes.detach().tensor().clone()))
+        np.testing.assert_allclose(out[1][0], out[0][0], rtol=1e-7)
+        torch.testing.assert_close(out[1][1], out[0][1], rtol=0, atol=1e-7)
