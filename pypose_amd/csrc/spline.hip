@@ -30,26 +30,32 @@ se3_bspline_kernel(const T* __restrict__ data, const T* __restrict__ w /* [3][K+
   const int64_t L = nseg * K + 1;                // output poses per trajectory
   const int64_t total = nb * L;
   const int64_t ntiles = (total + BLOCK - 1) / BLOCK;
-  auto locate = [&](int64_t o, int64_t& b, int64_t& s, int64_t& k) {
-    b = o / L;
-    const int64_t r = o - b * L;
-    s = r / K;
-    if (s > nseg - 1) s = nseg - 1;              // the closing pose belongs to the last segment, k == K
-    k = r - s * K;
-  };
+  const uint32_t Lu = (uint32_t)L, Ku = (uint32_t)K, nsegu = (uint32_t)nseg;      // L < 2^31 (checked by the launcher)
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int64_t row0 = tile * BLOCK;
     const int64_t left = total - row0;
     const bool full = left >= BLOCK;
     const int rows = full ? BLOCK : (int)left;
-    int64_t b0, s0, k0, b1, s1, k1;
-    locate(row0, b0, s0, k0);
-    locate(row0 + rows - 1, b1, s1, k1);
+    const int64_t tb = row0 / L;                                  // one 64-bit division per tile (wave-uniform) ...
+    const uint32_t tr = (uint32_t)(row0 - tb * L);
+    // ... and 32-bit ones per lane: row0 + d sits tr + d rows into trajectory tb (tr + d < 2^31 + 256)
+    auto locate = [&](uint32_t d, int64_t& b, uint32_t& s, uint32_t& k) {
+      const uint32_t q = (tr + d) / Lu;
+      const uint32_t r = (tr + d) - q * Lu;
+      b = tb + q;
+      s = r / Ku;
+      if (s > nsegu - 1) s = nsegu - 1;            // the closing pose belongs to the last segment, k == K
+      k = r - s * Ku;
+    };
+    int64_t b0, b1;
+    uint32_t s0, k0, s1, k1;
+    locate(0, b0, s0, k0);
+    locate((uint32_t)(rows - 1), b1, s1, k1);
     const int64_t g0 = b0 * nseg + s0;
     const int segs = (int)(b1 * nseg + s1 - g0) + 1;
     for (int j = threadIdx.x; j < segs; j += BLOCK) {
-      const int64_t g = g0 + j;
-      const int64_t b = g / nseg, s = g - b * nseg;
+      const uint32_t sj = s0 + (uint32_t)j, qj = sj / nsegu;        // segment j of the tile, counted from (b0, s0)
+      const int64_t b = b0 + qj, s = sj - qj * nsegu;
       const T* p = data + (b * N + s) * 7;
       T P[4][7];
 #pragma unroll
@@ -72,9 +78,10 @@ se3_bspline_kernel(const T* __restrict__ data, const T* __restrict__ w /* [3][K+
     __syncthreads();
     const int t = threadIdx.x;
     if (t < rows) {
-      int64_t b, s, k;
-      locate(row0 + t, b, s, k);
-      const T* src = s_seg + (int)(b * nseg + s - g0) * SP;
+      int64_t b;
+      uint32_t sg, k;
+      locate((uint32_t)t, b, sg, k);
+      const T* src = s_seg + (int)(b * nseg + sg - g0) * SP;
       T A[3][7];
 #pragma unroll
       for (int a = 0; a < 3; ++a) {
@@ -99,36 +106,39 @@ se3_bspline_kernel(const T* __restrict__ data, const T* __restrict__ w /* [3][K+
 }
 
 // out[b, o, c] = hh[o,0] p[i] + hh[o,1] m[i] + hh[o,2] p[i+1] + hh[o,3] m[i+1],  i = seg[o],
-// m = finite-difference tangents (unit knot spacing): one-sided at the two ends, mean of both sides inside
+// m = finite-difference tangents (unit knot spacing): one-sided at the two ends, mean of both sides inside.
+// One lane per sample o (its basis row and segment are loaded once), looping over the trajectories of its
+// blockIdx.y slice and the C channels: no index division, each lane writes C consecutive values, a wave a
+// contiguous 64 C run.
 template <class T, int BLOCK>
 __global__ void __launch_bounds__(BLOCK)
 chspline_kernel(const T* __restrict__ pts, const T* __restrict__ hh, const int64_t* __restrict__ seg,
                 T* __restrict__ out, int64_t nb, int64_t N, int64_t C, int64_t M) {
-  const int64_t total = nb * M * C;
-  for (int64_t e = (int64_t)blockIdx.x * BLOCK + threadIdx.x; e < total; e += (int64_t)gridDim.x * BLOCK) {
-    const int64_t c = e % C;
-    const int64_t o = (e / C) % M;
-    const int64_t b = e / (C * M);
-    const int64_t i = seg[o];
-    const T* p = pts + b * N * C + c;
-    const T p0 = p[i * C], p1 = p[(i + 1) * C];
-    const T d = p1 - p0;
-    const T dl = i > 0 ? p0 - p[(i - 1) * C] : d;
-    const T dr = i + 2 < N ? p[(i + 2) * C] - p1 : d;
-    const T m0 = i > 0 ? (d + dl) / T(2) : d;
-    const T m1 = i + 2 < N ? (dr + d) / T(2) : d;
-    const T* h = hh + o * 4;
-    T v = h[0] * p0;
-    v += h[1] * m0;
-    v += h[2] * p1;
-    v += h[3] * m1;
-    out[e] = v;
+  const int64_t o = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (o >= M) return;
+  const int64_t i = seg[o];
+  const T h0 = hh[o * 4], h1 = hh[o * 4 + 1], h2 = hh[o * 4 + 2], h3 = hh[o * 4 + 3];
+  const bool has_left = i > 0, has_right = i + 2 < N;
+  for (int64_t b = blockIdx.y; b < nb; b += gridDim.y) {
+    const T* p = pts + (b * N + i) * C;
+    T* dst = out + (b * M + o) * C;
+    for (int64_t c = 0; c < C; ++c) {
+      const T p0 = p[c], p1 = p[C + c];
+      const T d = p1 - p0;
+      const T m0 = has_left ? (d + (p0 - p[c - C])) / T(2) : d;
+      const T m1 = has_right ? ((p[2 * C + c] - p1) + d) / T(2) : d;
+      T v = h0 * p0;
+      v += h1 * m0;
+      v += h2 * p1;
+      v += h3 * m1;
+      dst[c] = v;
+    }
   }
 }
 
 template <class T>
 int se3_bspline(const void* data, const void* w, void* out, int64_t nb, int64_t N, int64_t K, void* stream) {
-  if (nb < 0 || N < 4 || K < 2) return PPLIE_EBADARG;
+  if (nb < 0 || N < 4 || K < 2 || (N - 3) * K + 1 >= ((int64_t)1 << 31) - 256) return PPLIE_EBADARG;
   if (nb == 0) return PPLIE_OK;
   if (!data || !w || !out || !aligned16(out)) return PPLIE_EBADARG;
   constexpr int BLOCK = 256;
@@ -146,10 +156,11 @@ int chspline(const void* pts, const void* hh, const void* seg, void* out, int64_
   if (nb == 0 || M == 0) return PPLIE_OK;
   if (!pts || !hh || !seg || !out) return PPLIE_EBADARG;
   constexpr int BLOCK = 256;
-  const int64_t total = nb * M * C;
-  const int64_t nt = (total + BLOCK - 1) / BLOCK;
-  const int grid = (int)(nt < (1 << 16) ? nt : (1 << 16));
-  hipLaunchKernelGGL((chspline_kernel<T, BLOCK>), dim3(grid), dim3(BLOCK), 0, reinterpret_cast<hipStream_t>(stream),
+  const int64_t nt = (M + BLOCK - 1) / BLOCK;
+  if (nt > 0x7fffffff) return PPLIE_EBADARG;
+  const int64_t want = (int64_t)16384 / nt + 1;                     // enough workgroups to fill the chip, then loop
+  const int gy = (int)(nb < want ? nb : (want < 65535 ? want : 65535));
+  hipLaunchKernelGGL((chspline_kernel<T, BLOCK>), dim3((unsigned)nt, (unsigned)gy), dim3(BLOCK), 0, reinterpret_cast<hipStream_t>(stream),
                      (const T*)pts, (const T*)hh, (const int64_t*)seg, (T*)out, nb, N, C, M);
   return hipGetLastError() == hipSuccess ? PPLIE_OK : PPLIE_ELAUNCH;
 }

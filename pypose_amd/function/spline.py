@@ -6,6 +6,7 @@ the same product of exponentials out of the differentiable Lie kernels (a compos
 reference's), and the Hermite spline as plain tensor arithmetic.
 """
 import ctypes
+import functools
 
 import torch
 
@@ -38,9 +39,10 @@ def _fused_ok(*tensors):
 # ---------------------------------------------------------------------------------------------------------------
 # cubic Hermite spline
 # ---------------------------------------------------------------------------------------------------------------
+@functools.lru_cache(maxsize=64)
 def _hermite_tables(N, interval, dtype, device):
     """Sample times, their segment index and the four Hermite basis values per sample (spline.py:78-96): shared by
-    every trajectory and channel."""
+    every trajectory and channel (and cached: ~15 tiny launches otherwise precede a ~0.1 ms kernel)."""
     steps = torch.arange(0, 1, interval, dtype=dtype, device=device)
     knots = torch.arange(0, N, dtype=dtype, device=device)
     times = (knots.unsqueeze(-1) + steps).view(-1)[:-(steps.shape[0] - 1)]     # 0 ... N-1, closing knot included
@@ -82,6 +84,7 @@ def chspline(points, interval=0.1):
 # ---------------------------------------------------------------------------------------------------------------
 # cumulative B-spline on SE3
 # ---------------------------------------------------------------------------------------------------------------
+@functools.lru_cache(maxsize=64)
 def _bspline_weights(interval, dtype, device):
     """``w [3, K+1]``: the cumulative basis at u = 0, interval, 2 interval, ... (spline.py:206-212) and, in the last
     column, at u = 1 -- the row sums of the basis matrix, used for the closing pose (:216)."""

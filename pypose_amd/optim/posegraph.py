@@ -47,6 +47,8 @@ _PCG2_SPMV_SIG = [ctypes.c_void_p] * 11 + [ctypes.c_int, ctypes.c_int64, ctypes.
 _PCG2_STEP_SIG = [ctypes.c_void_p] * 9 + [ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]
 _INV_SIG = [ctypes.c_void_p] * 2 + [ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]
 _HIP_SHAPES = {(6, 6, 2), (7, 7, 2), (3, 3, 2), (6, 6, 1), (3, 3, 1)}
+_STALL_CHECKS = 64          # plain CG on a singular system: give up after this many checks without a new best residual,
+_DIVERGED = 100.0           # or as soon as the residual norm is this far above the best one; return the best iterate
 DENSE_LIMIT = 4096          # assemble a dense A for the user's solver up to this many unknowns
 
 
@@ -130,7 +132,10 @@ class PCG(nn.Module):
         super().__init__()
         self.maxiter, self.tol, self.check_every = maxiter, tol, check_every
 
-    def solve(self, matvec, b, precond):
+    def solve(self, matvec, b, precond, stall=None):
+        """``stall`` (singular systems): keep the iterate of smallest residual and stop once the residual has
+        grown ``_DIVERGED`` times above it or after ``stall`` checks without a new minimum -- past the rounding floor
+        the null-space part of r dominates rho, alpha = rho / p.Ap explodes and x drifts along the null space."""
         x = torch.zeros_like(b)
         r = b.clone()
         bn = torch.linalg.norm(b)
@@ -140,13 +145,24 @@ class PCG(nn.Module):
         z = precond(r)
         p = z.clone()
         rho = (r * z).sum()
+        best, stalled = float('inf'), 0
         for it in range(maxiter):
             q = matvec(p)
             alpha = rho / (p * q).sum()
             x.add_(alpha * p)
             r.sub_(alpha * q)
-            if (it + 1) % self.check_every == 0 and torch.linalg.norm(r) <= self.tol * bn:
-                break
+            if (it + 1) % self.check_every == 0:
+                rn = torch.linalg.norm(r)
+                if rn <= self.tol * bn:
+                    break
+                if stall is not None:
+                    if rn < best:
+                        best, stalled, xbest = float(rn), 0, x.clone()
+                    else:
+                        stalled += 1
+                        if stalled >= stall or rn > _DIVERGED * best:
+                            x = xbest
+                            break
             z = precond(r)
             rho_new = (r * z).sum()
             p.mul_(rho_new / rho).add_(z)
@@ -277,7 +293,7 @@ class FusedPCG:
             bn2_slots = self.scal[3 * 1024:4 * 1024:32]             # |b|^2: set 0, quantity 3, 32 slots (csrc/graph.hip)
             bn2 = None
             maxiter = min(maxiter, self.cap - self.check_every)
-            done = 0
+            done, best, stalled, xbest = 0, float('inf'), 0, None
             while done < maxiter:
                 if group is None and self.graph is None and done > 0 and getattr(self, 'use_graph', True):
                     g = torch.cuda.CUDAGraph()
@@ -304,8 +320,15 @@ class FusedPCG:
                 else:
                     rr = sum(rr_src.tolist())
                 if rr <= tol * tol * bn2:
-                    break
-        return self.x.clone(), done
+                    return self.x.clone(), done
+                if plain:               # singular H: past the rounding floor x drifts along the null space (PCG.solve)
+                    if rr < best:
+                        best, stalled, xbest = rr, 0, self.x.clone()
+                    else:
+                        stalled += 1
+                        if stalled >= _STALL_CHECKS or rr > _DIVERGED ** 2 * best:
+                            break
+        return (xbest if plain and xbest is not None else self.x.clone()), done
 
 
 class GraphOperator:
@@ -501,7 +524,7 @@ class GraphLinearization:
             Bd.diagonal(dim1=-2, dim2=-1).copy_(s * clamped)
             Binv = torch.linalg.inv(Bd)
             precond = lambda r: (Binv * r.unsqueeze(-2)).sum(-1)
-        return solver.solve(lambda p: self._Hp(p) + shift * p, -self.g, precond)
+        return solver.solve(lambda p: self._Hp(p) + shift * p, -self.g, precond, stall=_STALL_CHECKS if plain else None)
 
     def dense_matrix(self):
         """H = J^T W J as a dense [N m, N m] matrix (small graphs / parity tests)."""
