@@ -1,3 +1,3 @@
-from .geometry import cart2homo, homo2cart, point2pixel, pixel2point, reprojerr
+from .geometry import cart2homo, homo2cart, point2pixel, pixel2point, reprojerr, svdtf, svdstf
 from .checking import is_lietensor, is_SE3, hasnan
 from .spline import chspline, bspline

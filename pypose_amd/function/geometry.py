@@ -66,3 +66,48 @@ def reprojerr(points, pixels, intrinsics, extrinsics=None, reduction='none'):
     _need(reduction in {'norm', 'sum', 'none'}, "Reduction method can only be 'norm'|'sum'|'none'.")
     err = point2pixel(points, intrinsics, extrinsics) - pixels
     return {'none': lambda e: e, 'norm': lambda e: e.norm(dim=-1), 'sum': lambda e: e.sum(dim=-1)}[reduction](err)
+
+
+def _centred(points):
+    centre = points.mean(dim=-2, keepdim=True)
+    return points - centre, centre
+
+
+def svdtf(source, target):
+    """Rigid transform (SE3) that best maps the point cloud ``source [..., N, 3]`` onto ``target [..., N, 3]`` in the
+    least-squares sense, by the SVD of the cross-covariance (Kabsch; reference geometry.py:315-358).  A reflection
+    (det = -1) is flipped to the nearest rotation the way the reference does (R -> -R)."""
+    from ..lietensor.convert import mat2SE3
+    assert source.size(-2) == target.size(-2), {"The number of points N has to be the same for both point clouds."}
+    src, c_src = _centred(source)
+    tgt, c_tgt = _centred(target)
+    U, _, Vh = torch.linalg.svd(torch.einsum('...Na, ...Nb -> ...ab', tgt, src))
+    R = U @ Vh
+    mirrored = (R.det() + 1).abs() < 1e-6
+    R[mirrored] = -R[mirrored]
+    t = c_tgt.mT - R @ c_src.mT
+    return mat2SE3(torch.cat((R, t), dim=-1), check=False)
+
+
+def svdstf(source, target, with_scale=True):
+    """Similarity transform (Sim3: scale, rotation, translation) that best maps ``source [..., N, 3]`` onto
+    ``target [..., N, 3]`` (Umeyama 1991; reference geometry.py:361-433); ``with_scale=False`` fixes the scale to 1."""
+    from ..lietensor.convert import mat2Sim3
+    assert source.size(-2) == target.size(-2), {"The number of points N has to be the same for both point clouds."}
+    assert source.size(-1) == 3, {"The source point dim should be 3"}
+    assert target.size(-1) == 3, {"The target point dim should be 3"}
+    N, m = source.shape[-2:]
+    src, c_src = _centred(source)
+    tgt, c_tgt = _centred(target)
+    U, D, Vh = torch.linalg.svd(tgt.transpose(-2, -1) @ src / N)
+    flip = torch.eye(m, dtype=U.dtype, device=U.device).expand_as(U).clone()      # diag(1, 1, det(U Vh)): proper rotation
+    flip[..., -1, -1] = torch.sign(torch.det(U @ Vh))
+    if with_scale:
+        spread = (src.norm(dim=-1) ** 2).mean(dim=-1, keepdim=True)
+        scale = torch.sum(torch.diagonal(flip, dim1=-1, dim2=-2) * D, keepdim=True, dim=-1) / spread
+    else:
+        scale = torch.ones_like(D[..., 0:1])
+    scale = scale.unsqueeze(-1)
+    R = U @ flip @ Vh
+    t = c_tgt.transpose(-2, -1) - scale * R @ c_src.transpose(-2, -1)
+    return mat2Sim3(torch.cat((scale * R, t), dim=-1), check=True)

@@ -18,7 +18,7 @@ REF = Path("/root/reference/tests")
 ROOT = Path(__file__).resolve().parents[1]
 FILES = ["lietensor/test_lietensor.py", "optim/test_optimizer.py", "optim/test_jacobian.py", "optim/test_solver.py",
          "optim/test_scheduler.py", "optim/test_sparse_lm.py", "basics/test_ops.py", "basics/test_func.py",
-         "function/test_checking.py"]
+         "function/test_checking.py", "function/test_spline.py", "module/test_loss.py"]
 KNOWN = re.compile(r"test_parameter_dispatch")
 
 
@@ -32,4 +32,4 @@ def test_reference_tests_pass_against_this_package():
     unexpected = [l for l in failed if not KNOWN.search(l)]
     assert not unexpected, "\n".join(unexpected) + "\n" + text[-3000:]
     m = re.search(r"(\d+) passed", text)
-    assert m and int(m.group(1)) >= 55, text[-3000:]
+    assert m and int(m.group(1)) >= 60, text[-3000:]

@@ -20,7 +20,7 @@ import pypose_amd  # noqa: E402
 
 SUBMODULES = ("optim", "optim.solver", "optim.strategy", "optim.kernel", "optim.corrector", "optim.scheduler",
               "optim.functional", "optim.optimizer", "lietensor", "lietensor.lietensor", "lietensor.operation",
-              "lietensor.utils", "basics", "module", "autograd", "autograd.function", "function", "testing", "func")
+              "lietensor.utils", "basics", "module", "autograd", "autograd.function", "function", "testing", "func", "metric")
 
 
 def alias_as_pypose():
