@@ -189,18 +189,23 @@ _PCG_SIG = [ctypes.c_int] + [ctypes.c_void_p] * 10 + [ctypes.c_int, ctypes.c_int
 class FusedPCG:
     """Device-resident block-Jacobi PCG for one graph shape (csrc/graph.hip).
 
-    Three launches per iteration (``pplie_graph_bsr_spmv`` fused with p.q, then stages 1 and 2 of
-    ``pplie_pcg_stage``) with every scalar kept on the device; ``check_every`` iterations are captured
-    into one hipGraph and replayed, so the loop costs neither Python dispatch nor a host sync per
-    iteration.  Buffers (and the graph) are cached per shape and reused across LM steps.
+    Two launches per iteration on one GPU (``pplie_pcg2_spmv`` streams the off-diagonal blocks in incidence order
+    and reduces p.q, q.z, q.Binv q; ``pplie_pcg2_step`` does every vector update), three plus an all-reduce on edge
+    shards (``pplie_graph_spmv``, ``pplie_pcg_stage`` 0-2); every scalar stays on the device.  ``check_every``
+    iterations are captured into one hipGraph and replayed, so the loop costs neither Python dispatch nor a host
+    sync per iteration.  Buffers (and the graph) are cached per shape and reused across LM steps.
     """
+
+    two_launch = True        # class-level switches (tools/ and tests compare the three-launch / graph-less variants)
+    use_graph = True
 
     def __init__(self, E, K, dr, m, N, dtype, device, has_w, check_every):
         z = lambda *s: torch.zeros(s, dtype=dtype, device=device)
         self.key = (E, K, dr, m, N, dtype, device, has_w, check_every)
         self.E, self.K, self.dr, self.m, self.N, self.check_every = E, K, dr, m, N, check_every
-        self.J, self.W = z(E, K, dr, m), (z(E, dr, dr) if has_w else None)
-        self.idx = torch.zeros((E, K), dtype=torch.int64, device=device)
+        self.dtype, self.device, self.has_w = dtype, device, has_w
+        self.J = self.W = self.idx = None                          # per-edge copies: only the matrix-free (sharded) path
+        self.D, self.HB = z(N, m, m), None                         # damped diagonal blocks; off-diagonal blocks (bsr path)
         self.Binv, self.shift = z(N, m, m), z(N, m)
         self.x, self.r, self.p, self.q, self.z = (z(N, m) for _ in range(5))
         self.r2 = z(N, m)                                          # the two-launch iteration ping-pongs the residual
@@ -209,18 +214,20 @@ class FusedPCG:
         self.rr_hist = z(self.cap)
         self.it = torch.zeros(2, dtype=torch.int32, device=device)
         self.sfx = "_f32" if dtype == torch.float32 else "_f64"
-        self.graph = None
+        self.graph = None                                          # captured check_every iterations
+        self.bsr = None                                            # which iteration the graph holds
+        self._csr_obj = None
 
     def _csr(self, lin):
         """incidence lists sorted by node (shared with the assembly kernel, rebuilt only when the edge list changes)"""
         csr = lin.csr()
-        if getattr(self, '_csr_obj', None) is not csr:
+        if self._csr_obj is not csr:
             self._csr_obj, (self.ptr, self.blk, self.other) = csr, csr
             self.graph = None                                       # captured pointers are stale
 
     def _iteration(self, group):
         lib = _C.library()
-        st = _C.stream_ptr(self.J.device)
+        st = _C.stream_ptr(self.device)
         if self.bsr and self.two_launch:
             # q = A p with p.q, q.z, q.Binv q ; then every vector update in one launch (csrc/graph.hip, pcg2)
             code = lib.symbol("pplie_pcg2_spmv" + self.sfx, _PCG2_SPMV_SIG)(
@@ -260,30 +267,30 @@ class FusedPCG:
         ``plain=True`` runs the same launches with the identity as preconditioner: from x = 0 plain CG stays in
         range(H) and converges to the minimum-norm solution of a singular H (Gauss-Newton's pseudo-inverse step)."""
         bsr = lin.HB is not None and group is None and self.m in (3, 6, 7)
-        if bsr != getattr(self, 'bsr', None):
+        if bsr != self.bsr:
             self.graph = None                                       # the captured iteration differs
         self.bsr = bsr
-        self.two_launch = getattr(self, 'two_launch', True)
-        if getattr(self, 'D', None) is None:
-            self.D = torch.empty((self.N, self.m, self.m), dtype=self.J.dtype, device=self.J.device)
         if bsr:
             self._csr(lin)
-            if getattr(self, 'HB', None) is None:
+            if self.HB is None:
                 self.HB = torch.empty_like(lin.HB)
             self.HB.copy_(lin.HB)                                   # off-diagonal blocks in incidence order
         else:
+            if self.J is None:
+                self.J, self.idx = torch.empty_like(lin.J), torch.empty_like(lin.idx)
+                self.W = torch.empty_like(lin.W) if self.has_w else None
             self.J.copy_(lin.J)
             self.idx.copy_(lin.idx)
             if self.W is not None:
                 self.W.copy_(lin.W)
         self.scal.zero_()
         self.it.zero_()
-        with torch.cuda.device(self.J.device):
+        with torch.cuda.device(self.device):
             # one launch: D = clamped + damped block diagonal, Binv = D^-1, shift, x = 0, r = -g, z = Binv r, p = z, r.z, |g|^2
             code = _C.library().symbol("pplie_pcg_prepare" + self.sfx, _PREP_SIG)(
                 lin.B.data_ptr(), lin.g.data_ptr(), self.D.data_ptr(), self.Binv.data_ptr(), self.shift.data_ptr(),
                 self.x.data_ptr(), self.r.data_ptr(), self.z.data_ptr(), self.p.data_ptr(), self.scal.data_ptr(),
-                float(s), float(dmin), float(dmax), self.N, self.m, _C.stream_ptr(self.J.device))
+                float(s), float(dmin), float(dmax), self.N, self.m, _C.stream_ptr(self.device))
             _C.check(code, "pplie_pcg_prepare")
             if plain:                                               # z = r, p = r, rho = r.r = |b|^2, Binv = I
                 self.Binv.copy_(torch.eye(self.m, dtype=self.Binv.dtype, device=self.Binv.device).expand_as(self.Binv))
@@ -295,7 +302,7 @@ class FusedPCG:
             maxiter = min(maxiter, self.cap - self.check_every)
             done, best, stalled, xbest = 0, float('inf'), 0, None
             while done < maxiter:
-                if group is None and self.graph is None and done > 0 and getattr(self, 'use_graph', True):
+                if group is None and self.graph is None and done > 0 and self.use_graph:
                     g = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g):
                         for _ in range(self.check_every):
