@@ -141,6 +141,64 @@ def pgo_lm_rate(dev, nodes=10_000, edges=40_000, steps=3, reps=5):
     return out
 
 
+def pgo_sharded_lm_rate(dev, rank, world, nodes=100_000, edges=400_000, steps=3, reps=3):
+    """BASELINE configs[3]: pose-graph LM, 100k SE3 nodes / 400k relative-pose edges, the EDGES sharded over the
+    ranks (rank r owns edges r::world, nodes replicated); per LM step the block diagonal + gradient of J^T J are
+    all-reduced once and the J^T J p vector once per PCG iteration (RCCL over xGMI), loss / gain-ratio scalars as
+    three-number all-reduces -- `LM(group=...)`, SURVEY.md section 8(e).  Same generator, solver and strategy as
+    `pgo_lm_rate`.  Collective: every rank calls this; rank 0's figures are reported.  Not part of `value`."""
+    import torch
+    import torch.distributed as dist
+    import pypose_amd as pp
+
+    class PoseGraph(torch.nn.Module):
+        def __init__(self, init):
+            super().__init__()
+            self.nodes = pp.Parameter(init)
+
+        def forward(self, e, poses):
+            n1, n2 = self.nodes[e[..., 0]], self.nodes[e[..., 1]]
+            return (poses.Inv() @ n1.Inv() @ n2).Log().tensor()
+
+    g = torch.Generator().manual_seed(0)
+    torch.manual_seed(0)
+    gt = pp.cumprod(pp.randn_SE3(nodes, sigma=0.3, device=dev), dim=0, left=False)
+    chain = torch.stack([torch.arange(nodes - 1), torch.arange(1, nodes)], -1)
+    extra = torch.randint(0, nodes, (edges - (nodes - 1), 2), generator=g)
+    extra[:, 1] = torch.where(extra[:, 0] == extra[:, 1], (extra[:, 1] + 1) % nodes, extra[:, 1])
+    e = torch.cat([chain, extra], 0).to(dev)
+    rel = (gt[e[:, 0]].Inv() @ gt[e[:, 1]] @ pp.randn_SE3(edges, sigma=0.01, device=dev)).tensor().contiguous()
+    init = (gt @ pp.randn_SE3(nodes, sigma=0.05, device=dev)).tensor().contiguous()
+    for t in (e, rel, init):                      # one problem on every rank, whatever the device RNGs produced
+        dist.broadcast(t, src=0)
+    e_mine, rel_mine = e[rank::world].contiguous(), pp.SE3(rel[rank::world].contiguous())
+    graph = PoseGraph(pp.SE3(init.clone()))
+    solver = pp.optim.solver.PCG(tol=1e-4, maxiter=250)
+    opt = pp.optim.LM(graph, solver=solver, strategy=pp.optim.strategy.TrustRegion(radius=1e4), group=dist.group.WORLD)
+    times, losses, its = [], [], []
+    for rep in range(reps + 1):                   # repetition 0 (structure probe, kernel verification) is untimed
+        graph.nodes.data.copy_(init)
+        if hasattr(opt, "loss"):
+            del opt.loss
+        opt.param_groups[0].update(opt.strategy.defaults)
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        losses, its = [], []
+        for _ in range(steps):
+            losses.append(float(opt.step((e_mine, rel_mine))))
+            its.append(solver.iterations)
+        torch.cuda.synchronize()
+        if rep:
+            times.append((time.perf_counter() - t0) / steps)
+    dt = sorted(times)[len(times) // 2]
+    return {"metric": "LM iters/sec, pose graph 100k nodes / 400k edges, edges sharded over the ranks (BASELINE configs[3])",
+            "value": 1.0 / dt, "unit": "LM steps/s", "n_gpus": world, "nodes": nodes, "edges": edges,
+            "edges_per_rank": int(e_mine.shape[0]), "path": opt.linearization, "losses": losses, "pcg_iterations": its,
+            "collectives_per_step": "1 all-reduce of N*(36+6) floats + 1 of N*6 floats per PCG iteration + scalars",
+            "repetitions_ms_per_step": [round(t * 1e3, 3) for t in times]}
+
+
 def invnet_lm_rate(dev, B=1_000_000, steps=3, reps=5):
     """BASELINE configs[2]: LM on the reference's README InvNet, B independent SE3 problems, fp32
     (SURVEY.md section 8d C3).  Each repetition restarts from the same random initial poses and takes `steps`
@@ -272,6 +330,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = t.item()
 
+    out = None
     if rank == 0:
         ms_exp = sum(e[0].elapsed_time(e[1]) for e in ev.values()) / len(ev)
         ms_log = sum(e[1].elapsed_time(e[2]) for e in ev.values()) / len(ev)
@@ -305,6 +364,31 @@ def main():
                     out[key] = {"error": repr(e)}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
+    sharded = launched and not a.no_secondary and (world > 1 or os.environ.get("PPLIE_BENCH_SHARDED_PGO") == "1")
+    if sharded:
+        # every rank takes part; a watchdog keeps the headline line if a collective wedges (nothing in the timed
+        # region above depends on this)
+        import threading
+        finished, printed = threading.Event(), threading.Lock()
+
+        def emit(extra):
+            if printed.acquire(blocking=False) and rank == 0:
+                out["lm_pgo_sharded"] = extra
+                print(json.dumps(out), flush=True)
+
+        def watchdog():
+            if not finished.wait(float(os.environ.get("PPLIE_BENCH_SHARDED_TIMEOUT", "120"))):
+                emit({"error": "timed out"})
+                os._exit(0)
+
+        threading.Thread(target=watchdog, daemon=True).start()
+        try:
+            extra = pgo_sharded_lm_rate(dev, rank, world)
+        except Exception as e:
+            extra = {"error": repr(e)}
+        finished.set()
+        emit(extra)
+    elif rank == 0:
         print(json.dumps(out), flush=True)
     if launched:
         import torch.distributed as dist
