@@ -352,14 +352,14 @@ class LevenbergMarquardt(_Optimizer):
         if ab is not None:
             # pose graphs: (J D).(J D) and (J D).R from one kernel; the built-in strategies only need the gain ratio,
             # which an equivalent 1x1 problem on the host reproduces (x^2 = a, x r = b) without device round trips
-            if self.group is not None:
+            if self.group is not None and not getattr(J, 'replicated', False):
                 import torch.distributed as dist
                 dist.all_reduce(ab, group=self.group)
             a, b = ab.tolist()
             x = max(a, 1e-300) ** 0.5
             one = torch.ones((1, 1), dtype=torch.float64)
             return self.strategy.update(pg, last=float(self.last), loss=float(self.loss), J=one, D=x * one, R=(b / x) * one)
-        if self.group is None:
+        if self.group is None or getattr(J, 'replicated', False):
             return self.strategy.update(pg, last=self.last, loss=self.loss, J=J, D=D, R=R)
         # the gain ratio needs the GLOBAL (J D)^T (2 R + J D): all-reduce its two dot products and
         # hand the strategy an equivalent 1x1 problem x (2 r + x) with x^2 = a, x r = b
@@ -381,6 +381,7 @@ class LevenbergMarquardt(_Optimizer):
                                    "linearisation is not sharded")
             lin.build_normal_equations(pg['min'], pg['max'])
             self.linearization = lin.kind
+            self._last_replicated = getattr(lin, 'replicated', False)
             if hasattr(lin, 'run_trials'):              # whole-step fused kernels (optim/fused.py)
                 lin.run_trials(self, pg)
                 continue
@@ -402,4 +403,16 @@ class LevenbergMarquardt(_Optimizer):
                     self.loss, self.reject_count = self.last, self.reject_count + 1
                 else:
                     break
+            if self.group is not None and getattr(lin, 'replicated', False):
+                self._sync_replicas(pg['params'])
         return self.loss
+
+    def _sync_replicas(self, params):
+        """Every rank solved the same system by itself; atomic summation order may leave last-bit differences
+        between the ranks' steps, so the first rank's parameters are broadcast (N * width floats per LM step)."""
+        import torch.distributed as dist
+        src = dist.get_global_rank(self.group, 0)
+        for p in params:
+            if p.requires_grad:
+                data = p.data
+                dist.broadcast(data.tensor() if hasattr(data, 'ltype') else data, src=src, group=self.group)

@@ -343,6 +343,7 @@ class GraphOperator:
 
     def __init__(self, lin):
         self.lin = lin
+        self.replicated = lin.replicated
 
     def gain_terms(self, D):
         """device tensor [(J D).(J D), (J D).R] from one kernel (pplie_graph_gain_terms), or None off the HIP path"""
@@ -379,6 +380,7 @@ class GraphLinearization:
         self.N, self.wfull = param.shape[0], wfull
         self.W = weight
         self.group = getattr(opt, 'group', None)
+        self.replicated = False  # True: the edges of ALL shards are held here, nothing below is a collective
         self.s = 1.0            # compounded damping factor prod(1 + lambda_i)
         self.HB = None
 
@@ -605,6 +607,35 @@ def try_graph_linearization(opt, pg, input, target, weight, R, params, rec, cach
                                      gauss_newton)
 
 
+REPLICATE_LIMIT = 8 << 30   # bytes of gathered Jacobian blocks up to which edge shards solve on every rank (below)
+
+
+def _gather_edge_shards(group, tensors, limit):
+    """All-gather the per-edge tensors of every rank's shard (first dimension = local edge count, padded with zero
+    rows to the largest shard: a zero block / zero residual contributes nothing anywhere).  Returns None when the
+    gathered blocks would exceed ``limit`` bytes -- decided from the exchanged counts, so identically on all ranks."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    ref = next(t for t in tensors if t is not None)
+    count = torch.tensor([ref.shape[0]], dtype=torch.int64, device=ref.device)
+    counts = [torch.zeros_like(count) for _ in range(world)]
+    dist.all_gather(counts, count, group=group)
+    most = int(torch.cat(counts).max())
+    if world * most * sum(t[0].numel() * t.element_size() for t in tensors if t is not None) > limit:
+        return None
+    out = []
+    for t in tensors:
+        if t is None:
+            out.append(None)
+            continue
+        mine = t.new_zeros((most,) + tuple(t.shape[1:]))
+        mine[:t.shape[0]] = t
+        parts = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine, group=group)
+        out.append(torch.cat(parts, 0))
+    return out
+
+
 def build_graph_linearization(opt, weight, r, J, idx, param, wfull, m, gauss_newton=False):
     """Corrector and weights applied to per-edge residuals r [E,dr] and blocks J [E,K,dr,m] -> GraphLinearization.
     Gauss-Newton weights both sides of its rectangular system with W (optimizer.py:318-322), so its normal
@@ -620,4 +651,16 @@ def build_graph_linearization(opt, weight, r, J, idx, param, wfull, m, gauss_new
         Wb = ws.repeat(ni, 1, 1).contiguous()
         if gauss_newton:
             Wb = (Wb.mT @ Wb).contiguous()
+    # Edge shards (LM(group=...)).  The linear solve dominates a pose-graph step and is latency-bound when every PCG
+    # iteration carries an all-reduce, so while the blocks of all shards fit on one GPU they are gathered ONCE per
+    # LM step -- the J^T J / J^T r accumulators of every rank are then built from the same blocks -- and each rank
+    # runs the un-sharded solve (streaming SpMV, graph-captured iterations, no collective).  Larger problems keep
+    # the blocks distributed and all-reduce diag / gradient once per step and H p once per iteration.
+    group = getattr(opt, 'group', None)
+    if group is not None and getattr(opt, 'replicate_solve', True):
+        gathered = _gather_edge_shards(group, [Rc.contiguous(), Jc.contiguous(), idx.contiguous(), Wb], REPLICATE_LIMIT)
+        if gathered is not None:
+            lin = GraphLinearization(opt, gathered[3], gathered[0], param, gathered[2], gathered[1], wfull, m)
+            lin.group, lin.replicated = None, True
+            return lin
     return GraphLinearization(opt, Wb, Rc, param, idx, Jc, wfull, m)

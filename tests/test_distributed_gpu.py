@@ -23,10 +23,11 @@ def group():
     dist.destroy_process_group()
 
 
-def _run(make, args, group, fused, steps=4):
+def _run(make, args, group, fused, steps=4, replicate=True):
     model, kw = make()
     opt = pp.optim.LM(model, group=group, **kw)
     opt.fused = fused
+    opt.replicate_solve = replicate
     losses = [float(opt.step(*args)) for _ in range(steps)]
     return losses, opt.linearization, [p.detach().clone() for p in model.parameters()]
 
@@ -44,14 +45,15 @@ def test_invnet_group_equals_single_process(group, fused):
     torch.testing.assert_close(a[2][0], b[2][0], rtol=0, atol=1e-12)
 
 
+@pytest.mark.parametrize("replicate", [True, False])
 @pytest.mark.parametrize("fused", [False, True])
-def test_posegraph_group_equals_single_process(group, fused):
+def test_posegraph_group_equals_single_process(group, fused, replicate):
     G = load_lm_golden()
     edges, poses = T(G["pgo40/edges"], DEV), pp.SE3(T(G["pgo40/poses"], DEV))
     make = lambda: (PoseGraph(pp.SE3(T(G["pgo40/init"], DEV))),
                     {"solver": pp.optim.solver.PCG(tol=1e-12, maxiter=2000), "strategy": pp.optim.strategy.TrustRegion(radius=1e4)})
     a = _run(make, ((edges, poses),), None, fused)
-    b = _run(make, ((edges, poses),), group, fused)
+    b = _run(make, ((edges, poses),), group, fused, replicate=replicate)    # gathered blocks | all-reduce per H p
     assert a[1] == b[1] == ("fused:pgo" if fused else "graph")
     for x, y in zip(a[0], b[0]):
         assert abs(x - y) <= 1e-7 * abs(x)
