@@ -143,9 +143,10 @@ def pgo_lm_rate(dev, nodes=10_000, edges=40_000, steps=3, reps=5):
 
 def pgo_sharded_lm_rate(dev, rank, world, nodes=100_000, edges=400_000, steps=3, reps=3):
     """BASELINE configs[3]: pose-graph LM, 100k SE3 nodes / 400k relative-pose edges, the EDGES sharded over the
-    ranks (rank r owns edges r::world, nodes replicated); per LM step the block diagonal + gradient of J^T J are
-    all-reduced once and the J^T J p vector once per PCG iteration (RCCL over xGMI), loss / gain-ratio scalars as
-    three-number all-reduces -- `LM(group=...)`, SURVEY.md section 8(e).  Same generator, solver and strategy as
+    ranks (rank r owns edges r::world, nodes replicated) -- `LM(group=...)`, SURVEY.md section 8(e).  Each rank
+    linearises its edges; the per-edge blocks are all-gathered once per LM step and every rank assembles J^T J / J^T r
+    and solves (no collective inside the PCG) while the blocks fit one GPU, else diag / gradient are all-reduced per
+    step and J^T J p per PCG iteration (RCCL over xGMI); the loss is a one-number all-reduce per trial.  Same generator, solver and strategy as
     `pgo_lm_rate`.  Collective: every rank calls this; rank 0's figures are reported.  Not part of `value`."""
     import torch
     import torch.distributed as dist
@@ -195,7 +196,10 @@ def pgo_sharded_lm_rate(dev, rank, world, nodes=100_000, edges=400_000, steps=3,
     return {"metric": "LM iters/sec, pose graph 100k nodes / 400k edges, edges sharded over the ranks (BASELINE configs[3])",
             "value": 1.0 / dt, "unit": "LM steps/s", "n_gpus": world, "nodes": nodes, "edges": edges,
             "edges_per_rank": int(e_mine.shape[0]), "path": opt.linearization, "losses": losses, "pcg_iterations": its,
-            "collectives_per_step": "1 all-reduce of N*(36+6) floats + 1 of N*6 floats per PCG iteration + scalars",
+            "replicated_solve": bool(getattr(opt, "_last_replicated", False)),
+            "collectives_per_step": ("all-gather of the per-edge residuals / Jacobian blocks / indices (E*(6+72)*4 B + E*16 B), "
+                                     "loss scalar per trial, broadcast of the nodes" if getattr(opt, "_last_replicated", False) else
+                                     "1 all-reduce of N*(36+6) floats + 1 of N*6 floats per PCG iteration + scalars"),
             "repetitions_ms_per_step": [round(t * 1e3, 3) for t in times]}
 
 
