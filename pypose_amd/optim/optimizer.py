@@ -248,7 +248,7 @@ def _linearize(opt, pg, input, target, weight, gauss_newton=False):
                         return BlockLinearization(opt, pg, input, target, weight, R, params, Jb)
             elif rec.events and (not gauss_newton or _pg.gauss_newton_on_graph(opt, params)):
                 lin = None
-                if same_rows and cache.get(sig) is not False:
+                if (same_rows or len(R) > 1) and cache.get(sig) is not False:
                     lin = _pg.try_graph_linearization(opt, pg, input, target, weight, R, params, rec, cache, sig, gauss_newton)
                 if lin is None and not gauss_newton and all(p.dim() == 2 for p in params) and R[0].dim() >= 2:
                     from . import multigraph as _mg       # several parameters / widths (bundle adjustment)

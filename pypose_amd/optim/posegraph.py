@@ -566,45 +566,95 @@ def gauss_newton_on_graph(opt, params):
 
 
 def try_graph_linearization(opt, pg, input, target, weight, R, params, rec, cache, sig, gauss_newton=False):
-    """Build a GraphLinearization if the recorded gathers explain the whole Jacobian."""
-    if len(params) != 1 or len(R) != 1 or params[0].dim() != 2:
+    """Build a GraphLinearization if the recorded gathers explain the whole Jacobian.
+
+    One residual: every gather feeds it.  Several residuals (``model`` returns a tuple -- e.g. odometry edges, loop
+    closures under their own robust kernel, unary priors; reference optimizer.py:644-654 handles them as stacked
+    rows of one dense J): each is attributed the gathers it depends on, gets its own corrector / weight
+    (``corrector[i]``, ``weight[i]``), and the per-edge terms are stacked with zero padding up to the largest
+    residual width and gather count (a zero row / zero block adds nothing to J^T W J or J^T W r)."""
+    if len(params) != 1 or params[0].dim() != 2 or any(r.dim() < 2 for r in R) \
+            or len(opt.corrector) not in (1, len(R)):
         cache[sig] = False
         return None
-    param, r = params[0], R[0]
-    E = r.numel() // r.shape[-1]
-    events = [(src, ix, out) for src, ix, out in rec.events if ix.numel() == E and out.numel() == E * param.shape[-1]]
-    if not events or len(events) != len(rec.events) or any(ev[0] is not events[0][0] for ev in events):
+    if weight is not None and len(R) > 1 and not (isinstance(weight, (tuple, list)) and len(weight) == len(R)):
         cache[sig] = False
         return None
-    outs = [out for _, _, out in events]
-    K, wfull, dr = len(events), param.shape[-1], r.shape[-1]
+    param = params[0]
+    wfull = param.shape[-1]
+    events = list(rec.events)
+    if not events or any(ev[0] is not events[0][0] or ev[2].numel() != ev[1].numel() * wfull for ev in events):
+        cache[sig] = False
+        return None
+    outs_all = [out for _, _, out in events]
+    parts = []
     with torch.enable_grad():
         back = _rows_of_parameter(events[0][0], param)
         if back is None:
             cache[sig] = False
             return None
-        node_idx = [back[ix.reshape(-1)] for _, ix, _ in events]      # parameter row per edge end (-1: fixed)
-        Jcat = _blocks.jacobian_blocks([r], outs)                    # [E, dr, K*wfull]
-        for k, ni in enumerate(node_idx):                            # a fixed end contributes no unknowns
-            Jcat[:, :, k * wfull:(k + 1) * wfull] *= (ni >= 0).to(Jcat.dtype).view(E, 1, 1)
-        node_idx = [ni.clamp_min(0) for ni in node_idx]
+        for r in R:
+            E, dr = r.numel() // r.shape[-1], r.shape[-1]
+            if len(R) == 1:
+                mine = events
+            else:       # which gathers does this residual see?
+                seen = torch.autograd.grad(r.sum(), outs_all, retain_graph=True, allow_unused=True)
+                mine = [ev for ev, g in zip(events, seen) if g is not None]
+            if not mine or any(ix.numel() != E for _, ix, _ in mine):
+                cache[sig] = False
+                return None
+            node_idx = [back[ix.reshape(-1)] for _, ix, _ in mine]       # parameter row per edge end (-1: fixed)
+            Jcat = _blocks.jacobian_blocks([r], [out for _, _, out in mine])     # [E, dr, K*wfull]
+            for k, ni in enumerate(node_idx):                            # a fixed end contributes no unknowns
+                Jcat[:, :, k * wfull:(k + 1) * wfull] *= (ni >= 0).to(Jcat.dtype).view(E, 1, 1)
+            parts.append((r, E, dr, Jcat, [ni.clamp_min(0) for ni in node_idx]))
         if cache.get(sig) is None:
             # probe: u^T dR/dnodes by one real backward == scatter-add of the per-edge blocks
-            u = torch.randn_like(r)
-            true = torch.autograd.grad([r], [param], [u], retain_graph=True)[0]
+            us = [torch.randn_like(r) for r in R]
+            true = torch.autograd.grad(list(R), [param], us, retain_graph=True)[0]
             got = torch.zeros_like(true)
-            contrib = (u.reshape(E, dr).unsqueeze(-1) * Jcat).sum(-2)
-            for k, ni in enumerate(node_idx):
-                got.index_add_(0, ni, contrib[:, k * wfull:(k + 1) * wfull])
+            for u, (r, E, dr, Jcat, node_idx) in zip(us, parts):
+                contrib = (u.reshape(E, dr).unsqueeze(-1) * Jcat).sum(-2)
+                for k, ni in enumerate(node_idx):
+                    got.index_add_(0, ni, contrib[:, k * wfull:(k + 1) * wfull])
             scale = true.abs().max().clamp_min(torch.finfo(true.dtype).tiny)
             cache[sig] = bool((got - true).abs().max() <= 1e-3 * scale)
     if not cache[sig]:
         return None
     # tangent width: gradients of LieTensor group parameters are zero-padded to the embedding
     m = _blocks.lie_manifold_width(param) or wfull
-    J = Jcat.reshape(E, dr, K, wfull)[..., :m].permute(0, 2, 1, 3)    # [E, K, dr, m]
-    return build_graph_linearization(opt, weight, r.detach().reshape(E, dr), J, torch.stack(node_idx, dim=-1), param, wfull, m,
-                                     gauss_newton)
+    terms = []
+    for i, (r, E, dr, Jcat, node_idx) in enumerate(parts):
+        K = len(node_idx)
+        J = Jcat.reshape(E, dr, K, wfull)[..., :m].permute(0, 2, 1, 3)    # [E, K, dr, m]
+        corrector = opt.corrector[0] if len(opt.corrector) == 1 else opt.corrector[i]
+        w = weight[i] if isinstance(weight, (tuple, list)) else weight
+        terms.append(_edge_terms(opt, corrector, w, r.detach().reshape(E, dr), J, gauss_newton) + (torch.stack(node_idx, dim=-1),))
+    Rc, Jc, Wb, idx = terms[0] if len(terms) == 1 else _stack_edge_terms(terms)
+    return _finish_graph_linearization(opt, Rc, Jc, idx, Wb, param, wfull, m)
+
+
+def _stack_edge_terms(terms):
+    """Residuals of different width / gather count as one edge list: zero-pad to (max dr, max K)."""
+    dr = max(t[0].shape[-1] for t in terms)
+    K = max(t[1].shape[1] for t in terms)
+    weighted = any(t[2] is not None for t in terms)
+    Rs, Js, Ws, Is = [], [], [], []
+    for Rc, Jc, Wb, idx in terms:
+        E, k, d, m = Jc.shape
+        R2 = Rc.new_zeros((E, dr))
+        R2[:, :d] = Rc
+        J2 = Jc.new_zeros((E, K, dr, m))
+        J2[:, :k, :d] = Jc
+        I2 = idx.new_zeros((E, K))
+        I2[:, :k] = idx
+        Rs.append(R2), Js.append(J2), Is.append(I2)
+        if weighted:
+            W2 = torch.eye(dr, dtype=Jc.dtype, device=Jc.device).repeat(E, 1, 1)
+            if Wb is not None:
+                W2[:, :d, :d] = Wb
+            Ws.append(W2)
+    return torch.cat(Rs), torch.cat(Js), (torch.cat(Ws) if weighted else None), torch.cat(Is)
 
 
 REPLICATE_LIMIT = 8 << 30   # bytes of gathered Jacobian blocks up to which edge shards solve on every rank (below)
@@ -636,21 +686,30 @@ def _gather_edge_shards(group, tensors, limit):
     return out
 
 
-def build_graph_linearization(opt, weight, r, J, idx, param, wfull, m, gauss_newton=False):
-    """Corrector and weights applied to per-edge residuals r [E,dr] and blocks J [E,K,dr,m] -> GraphLinearization.
-    Gauss-Newton weights both sides of its rectangular system with W (optimizer.py:318-322), so its normal
-    equations carry ``W^T W`` where Levenberg-Marquardt's ``J^T W J`` carries ``W``."""
-    E, K, dr, _ = J.shape
-    c = opt.corrector[0]                                              # row-local: acts on [E, dr, K*m]
-    Rc, Jc = c(R=r, J=J.permute(0, 2, 1, 3).reshape(E, dr, K * m))
+def _edge_terms(opt, corrector, weight, r, J, gauss_newton=False):
+    """Corrector and weight of ONE residual applied to its per-edge residuals r [E,dr] and blocks J [E,K,dr,m]:
+    (Rc, Jc, Wb or None).  Gauss-Newton weights both sides of its rectangular system with W (optimizer.py:318-322),
+    so its normal equations carry ``W^T W`` where Levenberg-Marquardt's ``J^T W J`` carries ``W``."""
+    E, K, dr, m = J.shape
+    Rc, Jc = corrector(R=r, J=J.permute(0, 2, 1, 3).reshape(E, dr, K * m))           # row-local: acts on [E, dr, K*m]
     Jc = Jc.reshape(E, dr, K, m).permute(0, 2, 1, 3)
     Wb = None
     if weight is not None:
-        w = weight[0] if isinstance(weight, (tuple, list)) else weight
-        ws, ni = opt.model._weight_blocks(w, r)
+        ws, ni = opt.model._weight_blocks(weight, r)
         Wb = ws.repeat(ni, 1, 1).contiguous()
         if gauss_newton:
             Wb = (Wb.mT @ Wb).contiguous()
+    return Rc, Jc, Wb
+
+
+def build_graph_linearization(opt, weight, r, J, idx, param, wfull, m, gauss_newton=False):
+    """Single-residual entry (also used by the fused pose-graph program): r [E,dr], J [E,K,dr,m] -> GraphLinearization."""
+    w = weight[0] if isinstance(weight, (tuple, list)) else weight
+    Rc, Jc, Wb = _edge_terms(opt, opt.corrector[0], w, r, J, gauss_newton)
+    return _finish_graph_linearization(opt, Rc, Jc, idx, Wb, param, wfull, m)
+
+
+def _finish_graph_linearization(opt, Rc, Jc, idx, Wb, param, wfull, m):
     # Edge shards (LM(group=...)).  The linear solve dominates a pose-graph step and is latency-bound when every PCG
     # iteration carries an all-reduce, so while the blocks of all shards fit on one GPU they are gathered ONCE per
     # LM step -- the J^T J / J^T r accumulators of every rank are then built from the same blocks -- and each rank

@@ -116,3 +116,37 @@ def ba_case(G, tag, device="cpu"):
     opt = pp.optim.LM(model, solver=pp.optim.solver.Cholesky(), strategy=pp.optim.strategy.TrustRegion(radius=1e4),
                       kernel=kernel, min=1e-6)
     return model, opt, args
+
+
+class MixedGraph(nn.Module):
+    """Three residuals over one node set: odometry edges, loop closures, position priors
+    (tests/golden/make_multires_golden.py recorded the reference's dense LM on it)."""
+
+    def __init__(self, nodes):
+        super().__init__()
+        self.nodes = pp.Parameter(nodes)
+
+    def forward(self, odo, zodo, loop, zloop, pidx, prior):
+        a = (zodo.Inv() @ self.nodes[odo[:, 0]].Inv() @ self.nodes[odo[:, 1]]).Log().tensor()
+        b = (zloop.Inv() @ self.nodes[loop[:, 0]].Inv() @ self.nodes[loop[:, 1]]).Log().tensor()
+        c = (prior.Inv() @ self.nodes[pidx]).Log().tensor()[..., :3]
+        return a, b, c
+
+
+def load_multires_golden():
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "multires_golden.npz"))
+
+
+def multires_case(G, tag, device="cpu", **lm_kw):
+    D = torch.float64
+    t = lambda k: T(G[k], device)
+    args = (t("odo"), pp.SE3(t("zodo")), t("loop"), pp.SE3(t("zloop")), t("pidx"), pp.SE3(t("prior")))
+    kw = {"plain": {}, "kernels": {"kernel": [None, pp.optim.kernel.Huber(delta=0.3), None]},
+          "kernels_weights": {"kernel": [None, pp.optim.kernel.Cauchy(delta=0.5), None]}}[tag]
+    weight = None
+    if tag == "kernels_weights":
+        weight = [torch.eye(6, dtype=D, device=device) * 2.0, t("Wloop"), torch.eye(3, dtype=D, device=device) * 10.0]
+    model = MixedGraph(pp.SE3(t("init")))
+    lm_kw.setdefault("solver", pp.optim.solver.Cholesky())
+    opt = pp.optim.LM(model, strategy=pp.optim.strategy.TrustRegion(radius=1e4), min=1e-6, **kw, **lm_kw)
+    return model, opt, args, weight

@@ -126,3 +126,21 @@ def test_gauss_newton_graph_path_on_device(G):
     start = float(opt.last)
     second = float(opt.step((edges, rel)))
     assert first < 0.05 * start and second <= first * 1.0001
+
+
+@pytest.mark.parametrize("tag", ["plain", "kernels", "kernels_weights"])
+def test_multi_residual_pose_graph_on_device(tag):
+    """three residuals (6-row binary edges x 2, 3-row unary priors) stacked with zero padding onto the (6, 6, 2) HIP
+    graph kernels: the reference's recorded dense trajectory"""
+    from tests.optim_models import load_multires_golden, multires_case
+    M = load_multires_golden()
+    for solver in (pp.optim.solver.Cholesky(), pp.optim.solver.PCG(tol=1e-13, maxiter=4096, check_every=8)):
+        model, opt, args, weight = multires_case(M, tag, DEV, solver=solver)
+        rec = run_steps(opt, (args,), {"weight": weight}, 6 if isinstance(solver, pp.optim.solver.Cholesky) else 2)
+        assert set(rec["kind"]) == {"graph"}
+        if isinstance(solver, pp.optim.solver.Cholesky):
+            compare_trajectory(rec, M, tag, floor=1e-12, rtol=1e-6)
+            np.testing.assert_allclose(model.nodes.detach().tensor().cpu().numpy(), M[f"{tag}/nodes"], atol=1e-6)
+        else:
+            np.testing.assert_allclose(rec["loss"][:2], M[f"{tag}/loss"][:2], rtol=1e-6)
+            assert opt.__dict__.get("_pcg_workspaces")

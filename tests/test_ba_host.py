@@ -148,3 +148,22 @@ def test_gauss_newton_graph_path_weights_both_sides():
             out.append((losses, graph.nodes.detach().tensor().clone()))
         np.testing.assert_allclose(out[1][0], out[0][0], rtol=1e-7)
         torch.testing.assert_close(out[1][1], out[0][1], rtol=0, atol=1e-7)
+
+
+@pytest.mark.parametrize("tag", ["plain", "kernels", "kernels_weights"])
+def test_multi_residual_pose_graph_matches_reference(tag):
+    """A model returning three residuals of different width / gather count (odometry, loop closures with their own
+    kernel and information matrix, 3-row priors on single nodes) takes the graph path and reproduces the reference's
+    dense trajectory -- including its 16-fold rejections when weights and kernels pull apart."""
+    from tests.optim_models import load_multires_golden, multires_case
+    M = load_multires_golden()
+    with oracle_backend():
+        model, opt, args, weight = multires_case(M, tag)
+        rec = run_steps(opt, (args,), {"weight": weight}, 6)
+        assert set(rec["kind"]) == {"graph"}
+        compare_trajectory(rec, M, tag, floor=1e-12, rtol=1e-6)
+        np.testing.assert_allclose(model.nodes.detach().tensor().numpy(), M[f"{tag}/nodes"], atol=1e-6)
+        # and through the matrix-free PCG instead of the dense assembly
+        model, opt, args, weight = multires_case(M, tag, solver=pp.optim.solver.PCG(tol=1e-13, maxiter=3000, check_every=1))
+        rec = run_steps(opt, (args,), {"weight": weight}, 3)
+        np.testing.assert_allclose(rec["loss"][:2], M[f"{tag}/loss"][:2], rtol=1e-6)
