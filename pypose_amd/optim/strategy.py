@@ -1,31 +1,49 @@
-"""Damping policies of Levenberg-Marquardt (reference pypose/optim/strategy.py).
+"""Damping policies of Levenberg-Marquardt (API of pypose/optim/strategy.py).
 
-``update(pg, last, loss, J, D, R)`` mutates ``pg['damping']`` (and, for TrustRegion,
-``pg['radius']`` / ``pg['down']``).  ``J`` only needs to support ``J @ D``: the structured fast
-paths of :mod:`pypose_amd.optim.optimizer` pass a block operator instead of a dense matrix, so
-the gain ratio costs one block mat-vec + two dot products instead of a dense ``[N_res, N_par]``
-product.
+``update(pg, last, loss, J, D, R)`` rewrites ``pg['damping']`` (TrustRegion also ``pg['radius']`` / ``pg['down']``).
+``J`` only needs ``J @ D``: the structured paths of optim/optimizer.py pass a block operator (or, for graphs, an
+equivalent 1 x 1 problem built from two device-side dot products), so the gain ratio never costs a dense
+``[N_res, N_par]`` product.
+
+Both adaptive policies grade a step by its gain ratio against two thresholds; what differs is what "good", "fair"
+and "poor" do to the damping.
 """
-import torch
+GOOD, FAIR, POOR = 1, 0, -1
 
 
-def _gain_ratio(last, loss, J, D, R):
-    """(actual decrease) / (decrease predicted by the linear model), reference strategy.py:144/261."""
+def gain_ratio(last, loss, J, D, R):
+    """Actual decrease of the loss over the decrease the linear model predicted, ``-(J D)^T (2 R + J D)``
+    (strategy.py:144, :261) -- as a dot product: the reference's [1,n] @ [n,1] matmul is the same number, but lands
+    on a GEMM kernel that takes milliseconds at n ~ 10^6."""
     JD = J @ D
-    # (JD)^T (2R + JD) as a dot product: the reference's [1,n] @ [n,1] matmul is the same number but
-    # lands on a GEMM kernel that takes milliseconds at n ~ 10^6
     return (last - loss) / -(JD * (2 * R + JD)).sum()
 
 
-def _clip(x, lo, hi):
-    return max(lo, min(x, hi))
+def _positive(value, text):
+    assert value > 0, ValueError(text.format(value))
+
+
+def _check_thresholds(high, low, up, down):
+    _positive(high, "high has to be positive: {}")
+    _positive(low, "low for decrease has to be positive: {}")
+    assert 0 < down < 1, ValueError("down factor has to be smaller than 1: {}".format(down))
+    assert 1 < up, ValueError("up factor has to be larger than 1: {}".format(up))
+
+
+def _bounded(x, lo, hi):
+    return lo if x < lo else (hi if x > hi else x)
+
+
+def _grade(pg, last, loss, J, D, R):
+    quality = gain_ratio(last, loss, J, D, R)
+    return GOOD if quality > pg['high'] else (FAIR if quality > pg['low'] else POOR)
 
 
 class Constant(object):
-    """Fixed damping (reference strategy.py:5-46)."""
+    """The damping never changes (strategy.py:41-46)."""
 
     def __init__(self, damping=1e-6):
-        assert damping > 0, ValueError("damping has to be positive: {}".format(damping))
+        _positive(damping, "damping has to be positive: {}")
         self.defaults = {'damping': damping}
 
     def update(self, pg, *args, **kwargs):
@@ -33,51 +51,39 @@ class Constant(object):
 
 
 class Adaptive(object):
-    """Damping scaled down / kept / up by the gain ratio (reference strategy.py:49-151)."""
+    """Good step: damping * down; fair: unchanged; poor: damping * up; kept inside [min, max] (strategy.py:134-151)."""
 
     def __init__(self, damping=1e-6, high=0.5, low=1e-3, up=2., down=.5, min=1e-6, max=1e16):
-        assert damping > 0, ValueError("damping has to be positive: {}".format(damping))
-        assert high > 0, ValueError("high has to be positive: {}".format(high))
-        assert low > 0, ValueError("low for decrease has to be positive: {}".format(low))
-        assert 0 < down < 1, ValueError("down factor has to be smaller than 1: {}".format(down))
-        assert 1 < up, ValueError("up factor has to be larger than 1: {}".format(up))
+        _positive(damping, "damping has to be positive: {}")
+        _check_thresholds(high, low, up, down)
         self.defaults = {'damping': damping, 'high': high, 'low': low, 'up': up, 'down': down}
         self.min, self.max = min, max
 
     def update(self, pg, last, loss, J, D, R, *args, **kwargs):
-        quality = _gain_ratio(last, loss, J, D, R)
-        if quality > pg['high']:
-            pg['damping'] = pg['damping'] * pg['down']
-        elif quality > pg['low']:
-            pg['damping'] = pg['damping']
-        else:
-            pg['damping'] = pg['damping'] * pg['up']
-        pg['damping'] = _clip(pg['damping'], self.min, self.max)
+        factor = {GOOD: pg['down'], FAIR: 1, POOR: pg['up']}[_grade(pg, last, loss, J, D, R)]
+        pg['damping'] = _bounded(pg['damping'] * factor, self.min, self.max)
 
 
 class TrustRegion(object):
-    """Trust-region radius policy, damping = 1/radius (reference strategy.py:154-274)."""
+    """Damping = 1 / radius.  Good step: radius * up and the shrink factor resets; fair: only the reset; poor: radius
+    * down and the shrink factor itself shrinks by ``factor``, so repeated failures contract the region ever faster
+    (strategy.py:248-274)."""
 
     def __init__(self, radius=1e6, high=.5, low=1e-3, up=2., down=.5, factor=.5, min=1e-6, max=1e16):
-        assert radius > 0, ValueError("trust region radius has to be positive: {}".format(radius))
-        assert high > 0, ValueError("high has to be positive: {}".format(high))
-        assert low > 0, ValueError("low for decrease has to be positive: {}".format(low))
-        assert 0 < down < 1, ValueError("down factor has to be smaller than 1: {}".format(down))
-        assert 1 < up, ValueError("up factor has to be larger than 1: {}".format(up))
+        _positive(radius, "trust region radius has to be positive: {}")
+        _check_thresholds(high, low, up, down)
         assert 0 < factor < 1, ValueError("factor has to be smaller than 1: {}".format(factor))
         self.min, self.max, self.down = min, max, down
         self.defaults = {'radius': radius, 'damping': 1 / radius, 'high': high, 'low': low,
                          'up': up, 'down': down, 'factor': factor}
 
     def update(self, pg, last, loss, J, D, R, *args, **kwargs):
-        quality = _gain_ratio(last, loss, J, D, R)
-        pg['radius'] = 1. / pg['damping']
-        if quality > pg['high']:
-            pg['radius'], pg['down'] = pg['up'] * pg['radius'], self.down
-        elif quality > pg['low']:
-            pg['down'] = self.down
+        grade = _grade(pg, last, loss, J, D, R)
+        radius = 1. / pg['damping']
+        if grade == POOR:
+            radius, shrink = radius * pg['down'], pg['down'] * pg['factor']
         else:
-            pg['radius'], pg['down'] = pg['radius'] * pg['down'], pg['down'] * pg['factor']
-        pg['down'] = _clip(pg['down'], self.min, self.max)
-        pg['radius'] = _clip(pg['radius'], self.min, self.max)
+            radius, shrink = (radius * pg['up'] if grade == GOOD else radius), self.down
+        pg['down'] = _bounded(shrink, self.min, self.max)
+        pg['radius'] = _bounded(radius, self.min, self.max)
         pg['damping'] = 1. / pg['radius']
