@@ -227,41 +227,48 @@ template <class S> PP_HD void rot_coef_BC(S th2, S& B, S& C) {
   }
 }
 
-template <class S> PP_HD RotCoef<S> rot_coef(S th2) {
+// power series of B, C, D, E in t = theta^2 (used below series2(); no trigonometric call)
+template <class S> PP_HD RotCoef<S> rot_coef_series(S th2) {
   typedef typename Num<S>::base T;
   RotCoef<S> k;
-  if (pp_val(th2) < Num<T>::series2()) {
-    k.B = poly8<S>(th2, S(T(1.0 / 2)), S(T(-1.0 / 24)), S(T(1.0 / 720)), S(T(-1.0 / 40320)), S(T(1.0 / 3628800)),
-                   S(T(-1.0 / 479001600)), S(T(1.0 / 87178291200.0)), S(T(-1.0 / 20922789888000.0)));
-    k.C = poly8<S>(th2, S(T(1.0 / 6)), S(T(-1.0 / 120)), S(T(1.0 / 5040)), S(T(-1.0 / 362880)), S(T(1.0 / 39916800)),
-                   S(T(-1.0 / 6227020800.0)), S(T(1.0 / 1307674368000.0)), S(T(-1.0 / 355687428096000.0)));
-    // D = sum (-1)^j t^j / (2j+4)!
-    k.D = poly8<S>(th2, S(T(1.0 / 24)), S(T(-1.0 / 720)), S(T(1.0 / 40320)), S(T(-1.0 / 3628800)), S(T(1.0 / 479001600)),
-                   S(T(-1.0 / 87178291200.0)), S(T(1.0 / 20922789888000.0)), S(T(-1.0 / 6402373705728000.0)));
-    // E = sum (-1)^j (j+1) t^j / (2j+5)!
-    k.E = poly8<S>(th2, S(T(1.0 / 120)), S(T(-2.0 / 5040)), S(T(3.0 / 362880)), S(T(-4.0 / 39916800)),
-                   S(T(5.0 / 6227020800.0)), S(T(-6.0 / 1307674368000.0)), S(T(7.0 / 355687428096000.0)),
-                   S(T(-8.0 / 121645100408832000.0)));
-  } else {
-    S th = pp_sqrt(th2);
-    S sh, ch;
-    pp_sincos(S(T(0.5)) * th, sh, ch);
-    k.B = S(T(2)) * sh * sh / th2;
-    k.C = (th - S(T(2)) * sh * ch) / (th2 * th);
-    k.D = (S(T(0.5)) - k.B) / th2;                       // == (t^2 + 2cos t - 2)/(2 t^4)
-    k.E = (S(T(3)) * k.C - k.B) / (S(T(2)) * th2);       // == (2t - 3 sin t + t cos t)/(2 t^5)
-  }
+  k.B = poly8<S>(th2, S(T(1.0 / 2)), S(T(-1.0 / 24)), S(T(1.0 / 720)), S(T(-1.0 / 40320)), S(T(1.0 / 3628800)),
+                 S(T(-1.0 / 479001600)), S(T(1.0 / 87178291200.0)), S(T(-1.0 / 20922789888000.0)));
+  k.C = poly8<S>(th2, S(T(1.0 / 6)), S(T(-1.0 / 120)), S(T(1.0 / 5040)), S(T(-1.0 / 362880)), S(T(1.0 / 39916800)),
+                 S(T(-1.0 / 6227020800.0)), S(T(1.0 / 1307674368000.0)), S(T(-1.0 / 355687428096000.0)));
+  // D = sum (-1)^j t^j / (2j+4)!
+  k.D = poly8<S>(th2, S(T(1.0 / 24)), S(T(-1.0 / 720)), S(T(1.0 / 40320)), S(T(-1.0 / 3628800)), S(T(1.0 / 479001600)),
+                 S(T(-1.0 / 87178291200.0)), S(T(1.0 / 20922789888000.0)), S(T(-1.0 / 6402373705728000.0)));
+  // E = sum (-1)^j (j+1) t^j / (2j+5)!
+  k.E = poly8<S>(th2, S(T(1.0 / 120)), S(T(-2.0 / 5040)), S(T(3.0 / 362880)), S(T(-4.0 / 39916800)),
+                 S(T(5.0 / 6227020800.0)), S(T(-6.0 / 1307674368000.0)), S(T(7.0 / 355687428096000.0)),
+                 S(T(-8.0 / 121645100408832000.0)));
+  return k;
+}
+
+template <class S> PP_HD RotCoef<S> rot_coef(S th2) {
+  typedef typename Num<S>::base T;
+  if (pp_val(th2) < Num<T>::series2()) return rot_coef_series(th2);
+  RotCoef<S> k;
+  S th = pp_sqrt(th2);
+  S sh, ch;
+  pp_sincos(S(T(0.5)) * th, sh, ch);
+  k.B = S(T(2)) * sh * sh / th2;
+  k.C = (th - S(T(2)) * sh * ch) / (th2 * th);
+  k.D = (S(T(0.5)) - k.B) / th2;                       // == (t^2 + 2cos t - 2)/(2 t^4)
+  k.E = (S(T(3)) * k.C - k.B) / (S(T(2)) * th2);       // == (2t - 3 sin t + t cos t)/(2 t^5)
   return k;
 }
 
 // F of so3_Jl_inv
+template <class S> PP_HD S rot_coef_F_series(S th2) {
+  typedef typename Num<S>::base T;
+  // (t/2)cot(t/2) = 1 - t^2/12 - t^4/720 - t^6/30240 - ... (Bernoulli numbers)
+  return poly8<S>(th2, S(T(1.0 / 12)), S(T(1.0 / 720)), S(T(1.0 / 30240)), S(T(1.0 / 1209600)), S(T(1.0 / 47900160)),
+                  S(T(691.0 / 1307674368000.0)), S(T(1.0 / 74724249600.0)), S(T(3617.0 / 10670622842880000.0)));
+}
 template <class S> PP_HD S rot_coef_F(S th2) {
   typedef typename Num<S>::base T;
-  if (pp_val(th2) < Num<T>::series2()) {
-    // (t/2)cot(t/2) = 1 - t^2/12 - t^4/720 - t^6/30240 - ... (Bernoulli numbers)
-    return poly8<S>(th2, S(T(1.0 / 12)), S(T(1.0 / 720)), S(T(1.0 / 30240)), S(T(1.0 / 1209600)), S(T(1.0 / 47900160)),
-                    S(T(691.0 / 1307674368000.0)), S(T(1.0 / 74724249600.0)), S(T(3617.0 / 10670622842880000.0)));
-  }
+  if (pp_val(th2) < Num<T>::series2()) return rot_coef_F_series(th2);
   S th = pp_sqrt(th2);
   S sh, ch;
   pp_sincos(S(T(0.5)) * th, sh, ch);
@@ -669,10 +676,46 @@ template <class S> PP_HD void se3_adjt_bwd(const S* X, const S* a, const S* g, S
   gX[6] = S(T(0));
 }
 // SE3 Jinvp (lietensor.py:422-429): se3_Jl_inv(Log X) p = [Ji p_t - Ji Q Ji p_p, Ji p_p]
+// Jinvp = Jl_inv(Log X) p (lietensor.py:422-429) without a single sincos: with phi = f v (f = SO3_Log's factor, its three
+// branches, operation.py:315-322) the half angle is atan(|v|/w) (or +-pi/2 when |w| <= eps), so its sine and cosine are
+// |v|/|q| and |w|/|q| -- every coefficient of Jl_inv and Q comes out of the quaternion with one atan and two square
+// roots; small angles take the power series.  (se3_log + se3_jlinv_p, the composition, evaluates sincos twice.)
 template <class S> PP_HD void se3_jinvp(const S* X, const S* p, S* out) {
-  S x[6];
-  se3_log(X, x);
-  se3_jlinv_p(x, p, out);
+  typedef typename Num<S>::base T;
+  const V3<S> v = v3(X + 3);
+  const S w = X[6];
+  const S vn2 = norm2(v);
+  const S vn = pp_sqrt(vn2);
+  const bool vbig = pp_val(vn) > Num<T>::eps();
+  const bool wbig = pp_val(pp_abs(w)) > Num<T>::eps();
+  S f;
+  if (vbig && wbig)
+    f = pp_nan_to_num(S(T(2)) * pp_atan(vn / w) / vn);
+  else if (vbig)
+    f = pp_nan_to_num(pp_pm(w) * S(T(3.14159265358979323846)) / vn);
+  else
+    f = pp_nan_to_num(S(T(2)) * (S(T(1)) / w - vn2 / (S(T(3)) * w * w * w)));
+  const V3<S> phi = f * v;
+  const S th2 = norm2(phi);
+  RotCoef<S> k;
+  S F;
+  if (pp_val(th2) < Num<T>::series2()) {
+    k = rot_coef_series(th2);
+    F = rot_coef_F_series(th2);
+  } else {
+    const S th = pp_abs(f) * vn;
+    const S rn = S(T(1)) / pp_sqrt(vn2 + w * w);
+    const S sh = vn * rn, ch = pp_abs(w) * rn;               // sin, cos of theta/2
+    k.B = S(T(2)) * sh * sh / th2;
+    k.C = (th - S(T(2)) * sh * ch) / (th2 * th);
+    k.D = (S(T(0.5)) - k.B) / th2;
+    k.E = (S(T(3)) * k.C - k.B) / (S(T(2)) * th2);
+    F = pp_nan_to_num((S(T(1)) - S(T(0.5)) * th * pp_abs(w) / vn) / th2);     // (theta/2) cot(theta/2) = (theta/2) |w|/|v|
+  }
+  const V3<S> tau = jlinv_apply(F, phi, v3(X));
+  const V3<S> b = jlinv_apply(F, phi, v3(p + 3));
+  put(b, out + 3);
+  put(jlinv_apply(F, phi, v3(p) - q_apply(k, tau, phi, b)), out);
 }
 
 // ---------------------------------------------------------------------------------------
