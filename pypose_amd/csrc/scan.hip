@@ -270,6 +270,155 @@ imu_integrate_kernel(const T* __restrict__ dt, const T* __restrict__ gyro, const
   }
 }
 
+// K consecutive steps per lane (chunks of 64 K steps): the local products / sums of a lane's K steps are formed
+// sequentially, ONE wave scan runs over the 64 lane totals, and the K per-step values are rebuilt from the exclusive
+// prefix.  The kernel above is bound by the instruction issue of its cross-lane scans (~800 VALU instructions per
+// 64-step chunk, ~300 of them the SO3 product scan); here a scan is paid once per K steps.  States only: the variant
+// that also writes the covariance's aux streams is store-bound and gains nothing (launcher below).
+template <class T, int WAVES, int K, bool KNOWN>
+__global__ void __launch_bounds__(WAVES * 64)
+imu_integrate_multi_kernel(const T* __restrict__ dt, const T* __restrict__ gyro, const T* __restrict__ acc,
+                           const T* __restrict__ rot_known, const T* __restrict__ init_rot, const T* __restrict__ init_vel,
+                           const T* __restrict__ init_pos, T gx, T gy, T gz,
+                           T* __restrict__ out_rot, T* __restrict__ out_vel, T* __restrict__ out_pos, int64_t B, int F) {
+  const int lane = threadIdx.x & 63;
+  const int64_t b = (int64_t)blockIdx.x * WAVES + (threadIdx.x >> 6);
+  if (b >= B) return;
+  // this sequence's streams: 64-bit base once, 32-bit offsets inside the sequence (4 F < 2^31, checked by the launcher)
+  dt += b * F; gyro += b * F * 3; acc += b * F * 3;
+  out_rot += b * F * 4; out_vel += b * F * 3; out_pos += b * F * 3;
+  if (KNOWN) rot_known += b * F * 4;
+  T R0[4], v0[3], p0[3];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) R0[k] = init_rot[b * 4 + k];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { v0[k] = init_vel[b * 3 + k]; p0[k] = init_pos[b * 3 + k]; }
+  const V3<T> g = v3<T>(gx, gy, gz);
+  T cR[4] = {T(0), T(0), T(0), T(1)};
+  T cV[3] = {T(0), T(0), T(0)}, cP[3] = {T(0), T(0), T(0)}, cT = T(0);
+  T nh[K], ng[K][3], na[K][3], nr[KNOWN ? K : 1][4];
+  auto fetch = [&](int c0) {
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      const int f = c0 + lane * K + j;
+      const bool ok = f < F;
+      const int row = ok ? f : 0;
+      nh[j] = ok ? dt[row] : T(0);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { ng[j][k] = ok ? gyro[row * 3 + k] : T(0); na[j][k] = ok ? acc[row * 3 + k] : T(0); }
+      if (KNOWN) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) nr[j][k] = ok ? rot_known[row * 4 + k] : (k == 3 ? T(1) : T(0));
+      }
+    }
+  };
+  fetch(0);
+  constexpr int CH = 64 * K;
+  for (int c0 = 0; c0 < F; c0 += CH) {
+    T h[K], am[K][3], rkn[KNOWN ? K : 1][4], dr[K][4];
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      h[j] = nh[j];
+      T w[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { w[k] = ng[j][k] * h[j]; am[j][k] = na[j][k]; }
+      if (KNOWN) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) rkn[j][k] = nr[j][k];
+      }
+      so3_exp<T>(w, dr[j]);
+    }
+    if (c0 + CH < F) fetch(c0 + CH);
+    // products: L[j] = dr[0] .. dr[j] inside the lane, P = scan of the lane totals, E = the product before this lane
+    T L[K][4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) L[0][k] = dr[0][k];
+#pragma unroll
+    for (int j = 1; j < K; ++j) so3_mul<T>(L[j - 1], dr[j], L[j]);
+    T P[4] = {L[K - 1][0], L[K - 1][1], L[K - 1][2], L[K - 1][3]};
+    wave_scan<T, MulSO3<T>>(P, cR, true, false, lane);
+    T E[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) E[k] = lane_shift_up1(P[k], cR[k]);
+    T Pj[K][4];                                                  // incre_r[f+1] of each of the lane's steps
+#pragma unroll
+    for (int j = 0; j < K - 1; ++j) so3_mul<T>(E, L[j], Pj[j]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) Pj[K - 1][k] = P[k];
+    T u[K][3], dv[K][3];
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      T Rw[4];
+      if (KNOWN) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) Rw[k] = rkn[j][k];
+      } else {
+        so3_mul<T>(R0, Pj[j], Rw);
+      }
+      const V3<T> gi = quat_rotate(-v3(Rw), Rw[3], g);
+      const V3<T> aj = v3(am[j]) - gi;
+      const T* Pex = j == 0 ? E : Pj[j - 1];                     // incre_r[f]
+      const V3<T> uj = quat_rotate(v3(Pex), Pex[3], aj);
+      put(uj, u[j]);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) dv[j][k] = u[j][k] * h[j];
+    }
+    // velocity / position / time: exclusive lane prefix + running sum inside the lane
+    T Dv[K][3], Dp[K][3], Dt[K], endV[3], endP[3], endT;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      T tot = dv[0][k];
+#pragma unroll
+      for (int j = 1; j < K; ++j) tot += dv[j][k];
+      endV[k] = wave_scan_add(tot, cV[k], lane);
+      T run = lane_shift_up1(endV[k], cV[k]);
+#pragma unroll
+      for (int j = 0; j < K; ++j) { run += dv[j][k]; Dv[j][k] = run; }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      T dp[K];
+      T tot = T(0);
+#pragma unroll
+      for (int j = 0; j < K; ++j) {
+        dp[j] = (Dv[j][k] - dv[j][k]) * h[j] + u[j][k] * (T(0.5) * h[j] * h[j]);   // incre_v[f] dt + R a dt^2 / 2
+        tot += dp[j];
+      }
+      endP[k] = wave_scan_add(tot, cP[k], lane);
+      T run = lane_shift_up1(endP[k], cP[k]);
+#pragma unroll
+      for (int j = 0; j < K; ++j) { run += dp[j]; Dp[j][k] = run; }
+    }
+    {
+      T tot = h[0];
+#pragma unroll
+      for (int j = 1; j < K; ++j) tot += h[j];
+      endT = wave_scan_add(tot, cT, lane);
+      T run = lane_shift_up1(endT, cT);
+#pragma unroll
+      for (int j = 0; j < K; ++j) { run += h[j]; Dt[j] = run; }
+    }
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      const int f = c0 + lane * K + j;
+      if (f < F) {
+        T Rf[4];
+        so3_mul<T>(R0, Pj[j], Rf);
+        const V3<T> vel = v3(v0) + quat_rotate(v3(R0), R0[3], v3(Dv[j]));
+        const V3<T> pos = v3(p0) + quat_rotate(v3(R0), R0[3], v3(Dp[j])) + Dt[j] * v3(v0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) out_rot[f * 4 + k] = Rf[k];
+        put(vel, out_vel + f * 3);
+        put(pos, out_pos + f * 3);
+      }
+    }
+    bcast_vec<T, 4>(P, cR, 63);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { cV[k] = lane_bcast63(endV[k]); cP[k] = lane_bcast63(endP[k]); }
+    cT = lane_bcast63(endT);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Covariance (imu_preintegrator.py:428-465).  The reference's code evaluates
 //   cov = sum_{k=0..F} P_k Bc_k P_k^T,   P_k = A_k A_{k+1} ... A_{F-1} (P_F = I),   Bc_0 = init_cov
@@ -492,10 +641,24 @@ int imu_integrate_launch(const void* dt, const void* gyro, const void* acc, cons
   if ((ark != nullptr) != (arij != nullptr) || (ark != nullptr) != (aa != nullptr)) return SC_EBADARG;
   constexpr int WAVES = 4;
   int64_t blocks = (B + WAVES - 1) / WAVES;
-  hipLaunchKernelGGL((imu_integrate_kernel<T, WAVES>), dim3((unsigned)blocks), dim3(WAVES * 64), 0,
-                     reinterpret_cast<hipStream_t>(stream), (const T*)dt, (const T*)gyro, (const T*)acc, (const T*)rot,
-                     (const T*)r0, (const T*)v0, (const T*)p0, (const T*)rij0, (T)g[0], (T)g[1], (T)g[2], (T*)orot, (T*)ovel,
-                     (T*)opos, (T*)ark, (T*)arij, (T*)aa, B, F);
+  const char* env = getenv("PPLIE_IMU_STEPS_PER_LANE");          // tuning switch: 1 = one step per lane
+  const int kk = env ? atoi(env) : 2;
+  // two steps per lane pay off when the kernel only writes the states (77 vs 94 us at 4096 x 1024); with the covariance's
+  // aux streams the stores dominate and both variants take ~100 us: those keep one step per lane (K = 4: 98 us, slower)
+  if (kk >= 2 && F >= 256 && F < (int64_t(1) << 29) && ark == nullptr) {
+#define PPLIE_IMU_MULTI(KN)                                                                                                  \
+  hipLaunchKernelGGL((imu_integrate_multi_kernel<T, WAVES, 2, KN>), dim3((unsigned)blocks), dim3(WAVES * 64), 0,             \
+                     reinterpret_cast<hipStream_t>(stream), (const T*)dt, (const T*)gyro, (const T*)acc, (const T*)rot,       \
+                     (const T*)r0, (const T*)v0, (const T*)p0, (T)g[0], (T)g[1], (T)g[2], (T*)orot, (T*)ovel, (T*)opos, B, (int)F)
+    if (rot != nullptr) PPLIE_IMU_MULTI(true);
+    else PPLIE_IMU_MULTI(false);
+#undef PPLIE_IMU_MULTI
+  }
+  else
+    hipLaunchKernelGGL((imu_integrate_kernel<T, WAVES>), dim3((unsigned)blocks), dim3(WAVES * 64), 0,
+                       reinterpret_cast<hipStream_t>(stream), (const T*)dt, (const T*)gyro, (const T*)acc, (const T*)rot,
+                       (const T*)r0, (const T*)v0, (const T*)p0, (const T*)rij0, (T)g[0], (T)g[1], (T)g[2], (T*)orot, (T*)ovel,
+                       (T*)opos, (T*)ark, (T*)arij, (T*)aa, B, F);
   return hipGetLastError() == hipSuccess ? SC_OK : SC_ELAUNCH;
 }
 

@@ -111,3 +111,31 @@ def test_c5_full_size_fp32():
     C = o["cov"].double()
     assert (C - C.mT).abs().max().item() < 1e-6 * C.abs().max().item()
     assert torch.linalg.eigvalsh((C + C.mT) / 2).min().item() > -1e-6 * C.abs().max().item()
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-10), (torch.float32, 2e-5)])
+@pytest.mark.parametrize("F", [256, 257, 389, 1024])
+@pytest.mark.parametrize("known", [False, True])
+def test_two_steps_per_lane_kernel_matches_oracle(dtype, tol, F, known):
+    """states only (no covariance) and F >= 256 take imu_integrate_multi_kernel (two consecutive steps per lane, one
+    wave scan per 128 steps); ragged lengths exercise the padded tail; one-step-per-lane kernel on the same inputs
+    (through the covariance route) gives the same states."""
+    B = 37
+    g = torch.Generator(device=DEV).manual_seed(F)
+    dt = (0.004 + 0.002 * torch.rand(B, F, 1, device=DEV, generator=g, dtype=torch.float64)).to(dtype)
+    gyro = (0.3 * torch.randn(B, F, 3, device=DEV, generator=g, dtype=torch.float64)).to(dtype)
+    acc = (torch.randn(B, F, 3, device=DEV, generator=g, dtype=torch.float64) + torch.tensor([0, 0, 9.81], device=DEV)).to(dtype)
+    ref = imu_np.preintegrate(dt.cpu().numpy().astype(np.float64), gyro.cpu().numpy().astype(np.float64),
+                              acc.cpu().numpy().astype(np.float64))
+    rot = pp.SO3(torch.from_numpy(ref["rot"]).to(dtype).to(DEV)) if known else None
+    if known:       # the oracle with the orientations given (they equal its own, so the states are the same)
+        ref = imu_np.preintegrate(dt.cpu().numpy().astype(np.float64), gyro.cpu().numpy().astype(np.float64),
+                                  acc.cpu().numpy().astype(np.float64), rot=ref["rot"])
+    o = _module(dtype, reset=True, prop_cov=False)(dt, gyro, acc, rot=rot)
+    quat_close(o["rot"].cpu().numpy(), ref["rot"], tol)
+    for key in ("vel", "pos"):
+        assert np.abs(o[key].cpu().numpy() - ref[key]).max() < tol * max(1, np.abs(ref[key]).max()) + 0.1 * tol * F, key
+    o1 = _module(dtype, reset=True, prop_cov=True)(dt, gyro, acc, rot=rot)
+    quat_close(o1["rot"].cpu().numpy(), o["rot"].cpu().numpy(), tol)
+    for key in ("vel", "pos"):
+        assert (o1[key] - o[key]).abs().max().item() < tol * max(1, o[key].abs().max().item()) + 0.1 * tol * F, key
