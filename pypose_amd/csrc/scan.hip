@@ -113,7 +113,10 @@ __device__ __forceinline__ void wave_scan(T* v, const T* carry, bool has_carry, 
   if (has_carry) combine<T, G>(carry, v, v, left);               // uniform branch: every lane takes the carry
 }
 
-template <class T, class G, int WAVES>
+// K consecutive elements per lane: their running products are formed inside the lane, one wave scan combines the 64
+// lane totals, and the exclusive prefix is folded back into the K values -- the cross-lane scan (the dominant cost: 7
+// DPP steps of W-wide group products) is paid once per 64 K elements.
+template <class T, class G, int WAVES, int K>
 __global__ void __launch_bounds__(WAVES * 64)
 scan_kernel(T* __restrict__ data, int64_t nseq, int64_t L, int64_t inner, int left) {
   constexpr int W = G::W;
@@ -121,22 +124,47 @@ scan_kernel(T* __restrict__ data, int64_t nseq, int64_t L, int64_t inner, int le
   const int64_t seq = (int64_t)blockIdx.x * WAVES + (threadIdx.x >> 6);
   if (seq >= nseq) return;
   const int64_t o = seq / inner, in = seq % inner;
+  const bool lf = left != 0;
   T carry[W];
 #pragma unroll
-  for (int k = 0; k < W; ++k) carry[k] = T(0);
-  for (int64_t c0 = 0; c0 < L; c0 += 64) {
-    const int64_t i = c0 + lane;
-    const bool valid = i < L;
-    T* p = data + ((o * L + (valid ? i : 0)) * inner + in) * W;
-    T v[W];
+  for (int k = 0; k < W; ++k) carry[k] = G::ident(k);
+  for (int64_t c0 = 0; c0 < L; c0 += 64 * K) {
+    T v[K][W];
 #pragma unroll
-    for (int k = 0; k < W; ++k) v[k] = valid ? p[k] : T(0);
-    wave_scan<T, G>(v, carry, c0 > 0, left != 0, lane);
-    if (valid) {
+    for (int j = 0; j < K; ++j) {
+      const int64_t i = c0 + (int64_t)lane * K + j;
+      const bool valid = i < L;
+      const T* p = data + ((o * L + (valid ? i : 0)) * inner + in) * W;
 #pragma unroll
-      for (int k = 0; k < W; ++k) p[k] = v[k];
+      for (int k = 0; k < W; ++k) v[j][k] = valid ? p[k] : G::ident(k);     // padding: the identity changes nothing
     }
-    bcast_vec<T, W>(v, carry, 63);
+#pragma unroll
+    for (int j = 1; j < K; ++j) combine<T, G>(v[j - 1], v[j], v[j], lf);     // running products inside the lane
+    T tot[W];
+#pragma unroll
+    for (int k = 0; k < W; ++k) tot[k] = v[K - 1][k];
+    wave_scan<T, G>(tot, carry, c0 > 0, lf, lane);                          // inclusive over lane totals (+ carry)
+    if (K > 1) {
+      T ex[W];                                                              // what precedes this lane's first element
+#pragma unroll
+      for (int k = 0; k < W; ++k) ex[k] = lane_shift_up1(tot[k], carry[k]);
+      if (c0 > 0 || lane > 0) {
+#pragma unroll
+        for (int j = 0; j < K - 1; ++j) combine<T, G>(ex, v[j], v[j], lf);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < W; ++k) v[K - 1][k] = tot[k];
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      const int64_t i = c0 + (int64_t)lane * K + j;
+      if (i < L) {
+        T* p = data + ((o * L + i) * inner + in) * W;
+#pragma unroll
+        for (int k = 0; k < W; ++k) p[k] = v[j][k];
+      }
+    }
+    bcast_vec<T, W>(tot, carry, 63);
   }
 }
 
@@ -146,8 +174,12 @@ template <class T, class G> int scan_launch(void* data, int64_t nseq, int64_t L,
   if (!data) return SC_EBADARG;
   constexpr int WAVES = 4;
   int64_t blocks = (nseq + WAVES - 1) / WAVES;
-  hipLaunchKernelGGL((scan_kernel<T, G, WAVES>), dim3((unsigned)blocks), dim3(WAVES * 64), 0,
-                     reinterpret_cast<hipStream_t>(stream), static_cast<T*>(data), nseq, L, inner, left);
+  if (L >= 256)                 // (K = 4 measured no better than K = 1 at [4096, 1025] SO3: 48 us; K = 2: 43 us)
+    hipLaunchKernelGGL((scan_kernel<T, G, WAVES, 2>), dim3((unsigned)blocks), dim3(WAVES * 64), 0,
+                       reinterpret_cast<hipStream_t>(stream), static_cast<T*>(data), nseq, L, inner, left);
+  else
+    hipLaunchKernelGGL((scan_kernel<T, G, WAVES, 1>), dim3((unsigned)blocks), dim3(WAVES * 64), 0,
+                       reinterpret_cast<hipStream_t>(stream), static_cast<T*>(data), nseq, L, inner, left);
   return hipGetLastError() == hipSuccess ? SC_OK : SC_ELAUNCH;
 }
 

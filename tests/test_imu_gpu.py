@@ -139,3 +139,19 @@ def test_two_steps_per_lane_kernel_matches_oracle(dtype, tol, F, known):
     quat_close(o1["rot"].cpu().numpy(), o["rot"].cpu().numpy(), tol)
     for key in ("vel", "pos"):
         assert (o1[key] - o[key]).abs().max().item() < tol * max(1, o[key].abs().max().item()) + 0.1 * tol * F, key
+
+
+@pytest.mark.parametrize("left", [True, False])
+@pytest.mark.parametrize("L", [256, 300, 1025])
+def test_two_elements_per_lane_scan(left, L):
+    """L >= 256 takes scan_kernel<K = 2>: fp64 against a sequential float64 product, both orders, ragged lengths, a
+    scan dimension that is not the last batch dimension (inner = 3), and the first element left untouched."""
+    for name, rnd in (("so3", pp.randn_SO3), ("se3", pp.randn_SE3), ("sim3", pp.randn_Sim3), ("rxso3", pp.randn_RxSO3)):
+        torch.manual_seed(L)
+        Z = rnd(2, L, 3, sigma=0.3, device=DEV, dtype=torch.float64)
+        out = pp.cumprod(Z, dim=1, left=left)
+        mul = lambda a, b: lie_np.OPS[f"{name}_mul_fwd"](a, b)[0]
+        zn = Z.cpu().numpy()
+        ref = np.stack([imu_np.cumprod(zn[:, :, i], mul, left=left) for i in range(3)], axis=2)
+        assert np.abs(out.cpu().numpy() - ref).max() < 1e-11 * max(1.0, np.abs(ref).max()), name
+        assert torch.equal(out.tensor()[:, 0], Z.tensor()[:, 0])
