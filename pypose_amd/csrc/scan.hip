@@ -116,28 +116,39 @@ __device__ __forceinline__ void wave_scan(T* v, const T* carry, bool has_carry, 
 // K consecutive elements per lane: their running products are formed inside the lane, one wave scan combines the 64
 // lane totals, and the exclusive prefix is folded back into the K values -- the cross-lane scan (the dominant cost: 7
 // DPP steps of W-wide group products) is paid once per 64 K elements.
-template <class T, class G, int WAVES, int K>
+template <class T, class G, int WAVES, int K, bool LEFT>
 __global__ void __launch_bounds__(WAVES * 64)
-scan_kernel(T* __restrict__ data, int64_t nseq, int64_t L, int64_t inner, int left) {
+scan_kernel(T* __restrict__ data, int64_t nseq, int64_t L, int64_t inner) {
   constexpr int W = G::W;
   const int lane = threadIdx.x & 63;
   const int64_t seq = (int64_t)blockIdx.x * WAVES + (threadIdx.x >> 6);
   if (seq >= nseq) return;
   const int64_t o = seq / inner, in = seq % inner;
-  const bool lf = left != 0;
+  constexpr bool lf = LEFT;            // compile-time operand order: as a runtime flag it costs 8 v_cndmask per scan step
   T carry[W];
 #pragma unroll
   for (int k = 0; k < W; ++k) carry[k] = G::ident(k);
-  for (int64_t c0 = 0; c0 < L; c0 += 64 * K) {
-    T v[K][W];
+  // software pipeline: the next chunk's elements are requested before this chunk's scan runs (one wave owns the whole
+  // sequence, so every chunk would otherwise pay the full HBM latency on its critical path)
+  T nxt[K][W];
+  auto fetch = [&](int64_t c0) {
 #pragma unroll
     for (int j = 0; j < K; ++j) {
       const int64_t i = c0 + (int64_t)lane * K + j;
       const bool valid = i < L;
       const T* p = data + ((o * L + (valid ? i : 0)) * inner + in) * W;
 #pragma unroll
-      for (int k = 0; k < W; ++k) v[j][k] = valid ? p[k] : G::ident(k);     // padding: the identity changes nothing
+      for (int k = 0; k < W; ++k) nxt[j][k] = valid ? p[k] : G::ident(k);   // padding: the identity changes nothing
     }
+  };
+  fetch(0);
+  for (int64_t c0 = 0; c0 < L; c0 += 64 * K) {
+    T v[K][W];
+#pragma unroll
+    for (int j = 0; j < K; ++j)
+#pragma unroll
+      for (int k = 0; k < W; ++k) v[j][k] = nxt[j][k];
+    if (c0 + 64 * K < L) fetch(c0 + 64 * K);      // (reads rows this iteration does not write: the scan is in place)
 #pragma unroll
     for (int j = 1; j < K; ++j) combine<T, G>(v[j - 1], v[j], v[j], lf);     // running products inside the lane
     T tot[W];
@@ -174,12 +185,15 @@ template <class T, class G> int scan_launch(void* data, int64_t nseq, int64_t L,
   if (!data) return SC_EBADARG;
   constexpr int WAVES = 4;
   int64_t blocks = (nseq + WAVES - 1) / WAVES;
-  if (L >= 256)                 // (K = 4 measured no better than K = 1 at [4096, 1025] SO3: 48 us; K = 2: 43 us)
-    hipLaunchKernelGGL((scan_kernel<T, G, WAVES, 2>), dim3((unsigned)blocks), dim3(WAVES * 64), 0,
-                       reinterpret_cast<hipStream_t>(stream), static_cast<T*>(data), nseq, L, inner, left);
-  else
-    hipLaunchKernelGGL((scan_kernel<T, G, WAVES, 1>), dim3((unsigned)blocks), dim3(WAVES * 64), 0,
-                       reinterpret_cast<hipStream_t>(stream), static_cast<T*>(data), nseq, L, inner, left);
+#define PPLIE_SCAN(KK, LF)                                                                                   \
+  hipLaunchKernelGGL((scan_kernel<T, G, WAVES, KK, LF>), dim3((unsigned)blocks), dim3(WAVES * 64), 0,          \
+                     reinterpret_cast<hipStream_t>(stream), static_cast<T*>(data), nseq, L, inner)
+  if (L >= 256) {               // (K = 4 measured no better than K = 1 at [4096, 1025] SO3: 48 us; K = 2: 43 us)
+    if (left) PPLIE_SCAN(2, true); else PPLIE_SCAN(2, false);
+  } else {
+    if (left) PPLIE_SCAN(1, true); else PPLIE_SCAN(1, false);
+  }
+#undef PPLIE_SCAN
   return hipGetLastError() == hipSuccess ? SC_OK : SC_ELAUNCH;
 }
 
