@@ -106,7 +106,7 @@ def _bspline_composed(data, w):
     inner = first.unsqueeze(-2) * (steps[..., 0, :] * steps[..., 1, :] * steps[..., 2, :])
     tail = (xi[..., -1, :, :] * w[:, K:]).Exp()                                 # [.., 3, 7] last segment at u = 1
     close = first[..., -1:, :] * (tail[..., 0:1, :] * tail[..., 1:2, :] * tail[..., 2:3, :])
-    return torch.cat((inner.reshape(data.shape[:-2] + (-1, 7)), close), dim=-2)
+    return torch.cat((inner.reshape(data.shape[:-2] + ((N - 3) * K, 7)), close), dim=-2)
 
 
 def bspline(data, interval=0.1, extrapolate=False):

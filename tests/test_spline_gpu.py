@@ -93,6 +93,8 @@ def test_bspline_stream_and_noncontiguous_input():
         out = pp.bspline(data, 0.2)
     s.synchronize()
     pose_close(out.tensor(), ref.tensor(), 0)
+    assert pp.bspline(pp.SE3(torch.zeros(0, 5, 7, device=DEV)), 0.25).shape == (0, 9, 7)           # empty batch: no launch
+    assert pp.chspline(torch.zeros(0, 5, 3, device=DEV), 0.25).shape == (0, 17, 3)
     host = pp.bspline(data.cpu(), 0.2)                     # host tensors are staged through the GPU kernels
     assert host.device.type == "cpu"
     pose_close(host.tensor(), ref.tensor(), 1e-12)

@@ -64,6 +64,8 @@ def test_bspline_argument_checks():
     with pytest.raises(AssertionError, match="smaller than 1"):
         pp.bspline(pp.randn_SE3(2, 5), interval=1.0)
     assert pp.bspline(pp.randn_SE3(3), extrapolate=True).shape == (4 * 10 + 1, 7)       # 3 + 4 padded poses
+    assert pp.bspline(pp.SE3(torch.zeros(0, 5, 7)), 0.25).shape == (0, 2 * 4 + 1, 7)    # empty batch
+    assert pp.chspline(torch.zeros(0, 5, 3), 0.25).shape == (0, 17, 3)
 
 
 def test_chspline_matches_reference():
