@@ -21,7 +21,8 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
                 acc[row["Kernel_Name"]].append(float(row["Counter_Value"]))
         names = {"copy16": "copy16", "se3_exp_fwd": "se3_exp_fwd", "se3_log_fwd": "se3_log_fwd", "lm_se3inv_trial": "lm_se3inv_trial",
                  "pgo_linearize": "pgo_linearize", "graph_assemble_csr": "graph_assemble_csr", "graph_bsr_spmv": "graph_bsr_spmv",
-                 "pcg_update": "pcg_update", "imu_integrate": "imu_integrate", "imu_cov_scan": "imu_cov_scan"}
+                 "pcg_update": "pcg_update", "imu_integrate_multi": "imu_integrate_multi", "imu_integrate_kernel": "imu_integrate", "imu_cov_scan": "imu_cov_scan",
+                 "MulSO3": "scan_so3", "MulSE3": "scan_se3", "se3_bspline": "se3_bspline", "chspline": "chspline", "pcg2_spmv": "pcg2_spmv", "pcg2_step": "pcg2_step"}
         for k, v in acc.items():
             short = next((s for n, s in names.items() if n in k), None)
             if short:

@@ -53,4 +53,26 @@ integ = pp.module.IMUPreintegrator(prop_cov=True, reset=True).to(dev)
 for _ in range(2):
     integ(dt=dt, gyro=gyro, acc=acc)
 torch.cuda.synchronize()
+# states only: the two-steps-per-lane kernel (117 MB read, 168 MB written algorithmically)
+integ0 = pp.module.IMUPreintegrator(prop_cov=False, reset=True).to(dev)
+for _ in range(2):
+    integ0(dt=dt, gyro=gyro, acc=acc)
+torch.cuda.synchronize()
+del dt, gyro, acc
+
+# group scan in place: [4096, 1025] SO3 (67 MB read + 67 MB written) and SE3 (118 + 118 MB)
+for rnd in (pp.randn_SO3, pp.randn_SE3):
+    Z = rnd(4096, 1025, device=dev)
+    for _ in range(2):
+        pp.cumprod_(Z, dim=1)
+    torch.cuda.synchronize()
+    del Z
+
+# callers: B-spline 4096 x 1024 control poses, interval 0.1 (1171 MB written, 117 MB read), Hermite spline 4096 x 1024 x 3
+ctrl = pp.randn_SE3(4096, 1024, sigma=0.5, device=dev)
+pts = torch.randn(4096, 1024, 3, device=dev)
+for _ in range(2):
+    pp.bspline(ctrl, 0.1)
+    pp.chspline(pts, 0.1)
+torch.cuda.synchronize()
 print("done")
