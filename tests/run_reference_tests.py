@@ -1,6 +1,6 @@
 """Run the REFERENCE's own pytest files against this package, imported under the name ``pypose``.
 
-    python tools/run_reference_tests.py [--cpu-oracle] /root/reference/tests/lietensor/test_lietensor.py ...
+    python tests/run_reference_tests.py [--cpu-oracle] /root/reference/tests/lietensor/test_lietensor.py ...
 
 This is the drop-in check of SURVEY.md section 8(b): the files are executed where they lie (nothing is copied) with
 ``sys.modules["pypose"]`` pointing at ``pypose_amd``.  On a GPU box the kernels run; ``--cpu-oracle`` installs the

@@ -1,5 +1,5 @@
 """Drop-in check: the reference's OWN test files, run unmodified from /root/reference against this package aliased
-as ``pypose`` (tools/run_reference_tests.py).  Only possible where the reference is mounted (this container); on the
+as ``pypose`` (tests/run_reference_tests.py).  Only possible where the reference is mounted (this container); on the
 GPU box the test skips -- nothing under -m gpu reads /root/reference.
 
 Known, intended difference (everything else must pass):
@@ -25,7 +25,7 @@ KNOWN = re.compile(r"test_parameter_dispatch")
 @pytest.mark.skipif(not REF.exists(), reason="reference checkout not mounted")
 def test_reference_tests_pass_against_this_package():
     env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")
-    out = subprocess.run([sys.executable, str(ROOT / "tools" / "run_reference_tests.py"), "--cpu-oracle",
+    out = subprocess.run([sys.executable, str(ROOT / "tests" / "run_reference_tests.py"), "--cpu-oracle",
                           *[str(REF / f) for f in FILES]], capture_output=True, text=True, env=env, cwd="/tmp", timeout=1500)
     text = out.stdout + out.stderr
     failed = [l for l in text.splitlines() if l.startswith(("FAILED", "ERROR"))]

@@ -4,7 +4,19 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import pypose_amd as pp
 from pypose_amd import _C
-from oracle.lie_np import op_signature, GROUPS
+
+GROUPS = {"so3": (3, 4), "se3": (6, 7), "sim3": (7, 8), "rxso3": (4, 5)}      # (algebra width, group width)
+
+
+def op_signature(name):
+    """(input widths, output widths) of row op ``name`` as the C ABI takes them (include/pplie.h)."""
+    g, o = name.split("_", 1)
+    da, dg = GROUPS[g]
+    return {"exp_fwd": ((da,), (dg,)), "exp_bwd": ((da, dg), (da,)), "log_fwd": ((dg,), (da,)), "log_bwd": ((da, da), (dg,)),
+            "inv_fwd": ((dg,), (dg,)), "inv_bwd": ((dg, dg), (dg,)), "mul_fwd": ((dg, dg), (dg,)), "mul_bwd": ((dg, dg), (dg, dg)),
+            "act_fwd": ((dg, 3), (3,)), "act_bwd": ((dg, 3, 3), (dg, 3)), "adj_fwd": ((dg, da), (da,)), "adjt_fwd": ((dg, da), (da,)),
+            "jinvp_fwd": ((dg, da), (da,)), "jinvp_bwd": ((dg, da, da), (dg, da))}[o]
+
 
 dev = torch.device("cuda:0")
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
