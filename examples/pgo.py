@@ -63,6 +63,7 @@ def main(argv=None):
     solver = pp.optim.solver.PCG(tol=1e-4, maxiter=250) if big else pp.optim.solver.Cholesky()
     optimizer = pp.optim.LM(graph, solver=solver, strategy=pp.optim.strategy.TrustRegion(radius=a.radius), min=1e-6)
     scheduler = pp.optim.scheduler.StopOnPlateau(optimizer, steps=a.steps, patience=3, decreasing=1e-3, verbose=True)
+    pp.optim.freeze_gc()          # a full Python GC pass with torch loaded costs tens of LM steps
     t0 = time.perf_counter()
     while scheduler.continual():
         loss = optimizer.step(input=(edges, poses), weight=infos)
