@@ -387,6 +387,9 @@ def main():
 
         threading.Thread(target=watchdog, daemon=True).start()
         try:
+            import gc
+            gc.collect()
+            gc.freeze()                   # (a gen-2 collection with torch loaded is a 40-70 ms pause)
             extra = pgo_sharded_lm_rate(dev, rank, world)
         except Exception as e:
             extra = {"error": repr(e)}
