@@ -441,7 +441,7 @@ class LieTensor(Tensor):
         return self.clone().add_(other=alpha * other)
 
     def add_(self, other, alpha=1):
-        return self.ltype.add_(self, other=alpha * other)
+        return self.ltype.add_(self, other=other if alpha == 1 else alpha * other)      # (alpha * other is a launch)
 
     def __add__(self, other):
         return self.add(other=other)

@@ -399,8 +399,8 @@ class GraphLinearization:
         cache = self.opt.__dict__.setdefault('_graph_csr', {})
         key = (self.E, self.K, self.N, self.idx.device)
         hit = cache.get(key)
-        if hit is not None and torch.equal(hit[0], self.idx):
-            return hit[1]
+        if hit is not None and ((hit[2] is self.idx and hit[3] == self.idx._version) or torch.equal(hit[0], self.idx)):
+            return hit[1]                                          # (same object, unmodified: no compare kernel / sync)
         E, N, K, idx = self.E, self.N, self.K, self.idx
         flat = idx.t().reshape(-1)                                 # [side 0 entries | side 1 entries | ...]
         order = torch.argsort(flat, stable=True)
@@ -410,7 +410,7 @@ class GraphLinearization:
         blk = (K * e + side).to(torch.int32)
         other = idx[e, 1 - side].to(torch.int32) if K == 2 else torch.zeros_like(blk)
         csr = (ptr, blk, other)
-        cache[key] = (idx.clone(), csr)
+        cache[key] = (idx.clone(), csr, idx, idx._version)
         return csr
 
     # -- kernels ---------------------------------------------------------------------------------
@@ -691,8 +691,12 @@ def _edge_terms(opt, corrector, weight, r, J, gauss_newton=False):
     (Rc, Jc, Wb or None).  Gauss-Newton weights both sides of its rectangular system with W (optimizer.py:318-322),
     so its normal equations carry ``W^T W`` where Levenberg-Marquardt's ``J^T W J`` carries ``W``."""
     E, K, dr, m = J.shape
-    Rc, Jc = corrector(R=r, J=J.permute(0, 2, 1, 3).reshape(E, dr, K * m))           # row-local: acts on [E, dr, K*m]
-    Jc = Jc.reshape(E, dr, K, m).permute(0, 2, 1, 3)
+    from .optimizer import Trivial
+    if isinstance(corrector, Trivial):          # no kernel: skip the [E, dr, K*m] round trip (two copies of J)
+        Rc, Jc = r, J
+    else:
+        Rc, Jc = corrector(R=r, J=J.permute(0, 2, 1, 3).reshape(E, dr, K * m))       # row-local: acts on [E, dr, K*m]
+        Jc = Jc.reshape(E, dr, K, m).permute(0, 2, 1, 3)
     Wb = None
     if weight is not None:
         ws, ni = opt.model._weight_blocks(weight, r)

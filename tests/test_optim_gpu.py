@@ -479,3 +479,28 @@ def test_pcg_prepare_gain_terms_segment_sum_vs_tensor_formulation(dtype, tol):
         want = torch.zeros(500, 3, 3, dtype=dtype, device=DEV).index_add_(0, idxv, vals)
         assert sc.hip and (sc(vals) - want).abs().max().item() <= 50 * tol * want.abs().max().item()
     assert sc.two_level
+
+
+@pytest.mark.parametrize("static", [False, True])
+def test_edge_list_written_in_place_between_steps_is_seen(G, static):
+    """The stacked edge list and its incidence lists are cached across steps (keyed on the index tensors' storage and
+    version counter): rewiring ``edges`` IN PLACE must invalidate both -- the next step equals a fresh optimizer's."""
+    edges, poses = T(G["pgo40/edges"], DEV).clone(), pp.SE3(T(G["pgo40/poses"], DEV))
+    mk = lambda g: pp.optim.LM(g, solver=pp.optim.solver.PCG(tol=1e-12, maxiter=2000),
+                               strategy=pp.optim.strategy.TrustRegion(radius=1e4), static=static)
+    graph = PoseGraph(pp.SE3(T(G["pgo40/init"], DEV)))
+    opt = mk(graph)
+    for _ in range(2):
+        opt.step((edges, poses))
+    assert opt.linearization == "fused:pgo"
+    edges[3, 1] = (edges[3, 1] + 7) % 40                   # same tensor object, new graph
+    edges[10, 0] = (edges[10, 0] + 11) % 40
+    before = graph.nodes.detach().tensor().clone()
+    loss = float(opt.step((edges, poses)))
+    fresh = PoseGraph(pp.SE3(before.clone()))
+    ref = mk(fresh)
+    opt2_loss = float(ref.step((edges.clone(), poses)))
+    # (the two optimizers differ in their trust-region state; the residual program -- hence the loss BEFORE the step --
+    # must be the same, and the rewired graph's loss differs from the old graph's by far more than rounding)
+    assert abs(float(ref.last) - float(opt.last)) <= 1e-9 * abs(float(ref.last))
+    assert loss > 0 and opt2_loss > 0
