@@ -119,14 +119,21 @@ class _on_device:
             self.ctx.__exit__(*exc)
 
 
-def row_op(name: str, ins, out_widths):
+def row_op(name: str, ins, out_widths, out=None):
     """Launch ``pplie_<name>_{f32,f64}`` on contiguous ``[N, W]`` inputs.
 
     ins: 1-3 tensors, same dtype/device, same N, contiguous. out_widths: 1-2 ints.
-    Returns a tuple of freshly allocated ``[N, W_out]`` tensors.
+    Returns a tuple of freshly allocated ``[N, W_out]`` tensors, or of the caller's ``out`` tensors (contiguous
+    ``[N, W_out]``; an output may alias an input of the same width: every row kernel reads a tile's rows into LDS /
+    registers before it writes that tile).
     """
     if _test_backend is not None:
-        return _test_backend(name, ins, out_widths)
+        res = _test_backend(name, ins, out_widths)
+        if out is None:
+            return res
+        for o, r in zip(out, res):
+            o.copy_(r)
+        return tuple(out)
     x0 = ins[0]
     if not x0.is_cuda:
         # Host tensors are staged through the GPU (the arithmetic still runs in the HIP kernel);
@@ -137,7 +144,11 @@ def row_op(name: str, ins, out_widths):
                 f"there is no CPU compute path.")
         dev = torch.device("cuda", torch.cuda.current_device())
         outs = row_op(name, [t.to(dev) for t in ins], out_widths)
-        return tuple(o.to(x0.device) for o in outs)
+        if out is None:
+            return tuple(o.to(x0.device) for o in outs)
+        for o, r in zip(out, outs):
+            o.copy_(r)
+        return tuple(out)
     suffix = _SUFFIX.get(x0.dtype)
     if suffix is None:
         raise TypeError(f"pypose_amd: op {name} supports float32/float64, got {x0.dtype}")
@@ -145,7 +156,13 @@ def row_op(name: str, ins, out_widths):
     for t in ins:
         if t.dtype != x0.dtype or t.device != x0.device or t.shape[0] != n or t.dim() != 2 or not t.is_contiguous():
             raise ValueError(f"pypose_amd: op {name}: inputs must be contiguous [N,W], same N/dtype/device")
-    outs = tuple(torch.empty((n, w), dtype=x0.dtype, device=x0.device) for w in out_widths)
+    if out is None:
+        outs = tuple(torch.empty((n, w), dtype=x0.dtype, device=x0.device) for w in out_widths)
+    else:
+        outs = tuple(out)
+        for o, w in zip(outs, out_widths):
+            if o.shape != (n, w) or o.dtype != x0.dtype or o.device != x0.device or not o.is_contiguous():
+                raise ValueError(f"pypose_amd: op {name}: `out` must be contiguous [N,{w}] of the inputs' dtype / device")
     if n == 0:
         return outs
     fn = _lib.symbol("pplie_" + name + suffix)

@@ -22,6 +22,7 @@ import torch
 from torch import Tensor, nn
 from torch.utils._pytree import tree_flatten, tree_map
 
+from .. import _C
 from . import operation as _op
 from .operation import broadcast_inputs
 
@@ -173,8 +174,14 @@ class LieType:
         raw, x = Tensor.as_subclass(other, Tensor), Tensor.as_subclass(input, Tensor)
         if raw.shape == x.shape and not (torch.is_grad_enabled() and (raw.requires_grad or x.requires_grad)) \
                 and raw.dtype == x.dtype and not _op._transforms_active():
-            # the optimizer's update (step zero-padded to the group width): one fused kernel Exp(d[:m]) * p
-            out = _op._launch(self._key + "_retract", (raw.detach(), x.detach()), (x.shape[-1],) * 2, (x.shape[-1],))[0]
+            # the optimizer's update (step zero-padded to the group width): one fused kernel Exp(d[:m]) * p, written
+            # in place when the storage allows it
+            w = x.shape[-1]
+            if x.is_contiguous() and raw.is_contiguous() and not _op._op_tracers:
+                xr = x.detach().view(-1, w)
+                _C.row_op(self._key + "_retract", [raw.detach().view(-1, w), xr], (w,), out=[xr])
+                return input
+            out = _op._launch(self._key + "_retract", (raw.detach(), x.detach()), (w,) * 2, (w,))[0]
             with torch.no_grad():
                 return input.copy_(out)
         delta = LieTensor(raw[..., :m], ltype=self._algebra)

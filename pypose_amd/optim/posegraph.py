@@ -326,6 +326,7 @@ class FusedPCG:
                         return self.x.clone(), 0
                 else:
                     rr = sum(rr_src.tolist())
+                assert rr == rr, 'Linear solve produced NaN (matrix may not be positive-definite)'
                 if rr <= tol * tol * bn2:
                     return self.x.clone(), done
                 if plain:               # singular H: past the rounding floor x drifts along the null space (PCG.solve)
@@ -500,9 +501,9 @@ class GraphLinearization:
             A = self.dense_matrix()
             A.diagonal().add_(shift.reshape(-1))
             Dn = solver(A=A, b=(-self.g).reshape(-1, 1)).reshape(N, m)
+            assert not torch.any(torch.isnan(Dn)), 'Linear solve produced NaN (matrix may not be positive-definite)'
         else:
-            Dn = self._pcg(solver, self.s, self.dmin, self.dmax, plain=False)
-        assert not torch.any(torch.isnan(Dn)), 'Linear solve produced NaN (matrix may not be positive-definite)'
+            Dn = self._pcg(solver, self.s, self.dmin, self.dmax, plain=False)     # (checks its residual norm for NaN)
         return self.nodes_to_step(Dn)
 
     def _pcg(self, solver, s, dmin, dmax, plain):
@@ -533,7 +534,9 @@ class GraphLinearization:
             Bd.diagonal(dim1=-2, dim2=-1).copy_(s * clamped)
             Binv = torch.linalg.inv(Bd)
             precond = lambda r: (Binv * r.unsqueeze(-2)).sum(-1)
-        return solver.solve(lambda p: self._Hp(p) + shift * p, -self.g, precond, stall=_STALL_CHECKS if plain else None)
+        Dn = solver.solve(lambda p: self._Hp(p) + shift * p, -self.g, precond, stall=_STALL_CHECKS if plain else None)
+        assert not torch.any(torch.isnan(Dn)), 'Linear solve produced NaN (matrix may not be positive-definite)'
+        return Dn
 
     def dense_matrix(self):
         """H = J^T W J as a dense [N m, N m] matrix (small graphs / parity tests)."""
