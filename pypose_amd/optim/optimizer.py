@@ -347,7 +347,19 @@ class LevenbergMarquardt(_Optimizer):
             dist.all_reduce(loss, group=self.group)
         return loss
 
-    def _strategy_update(self, pg, J, D, R):
+    def _host(self, t):
+        """Value of a scalar loss tensor on the host.  A read-back is a synchronisation, and the trial loop compares
+        ``last`` and ``loss`` several times per trial: the value is remembered for the tensor object it came from."""
+        hit = self.__dict__.get('_host_loss')
+        if hit is not None and hit[0] is t:
+            return hit[1]
+        v = float(t)
+        self._host_loss = (t, v)
+        return v
+
+    def _strategy_update(self, pg, J, D, R, last_h):
+        """strategy.update(...) for this trial; returns the new loss as a host float (read back together with the
+        gain-ratio terms where the linearisation provides them)."""
         ab = J.gain_terms(D) if hasattr(J, 'gain_terms') and type(self.strategy) in (Constant, Adaptive, TrustRegion) else None
         if ab is not None:
             # pose graphs: (J D).(J D) and (J D).R from one kernel; the built-in strategies only need the gain ratio,
@@ -355,12 +367,14 @@ class LevenbergMarquardt(_Optimizer):
             if self.group is not None and not getattr(J, 'replicated', False):
                 import torch.distributed as dist
                 dist.all_reduce(ab, group=self.group)
-            a, b = ab.tolist()
+            a, b, loss_h = torch.cat([ab.reshape(-1).double(), self.loss.detach().reshape(1).double()]).tolist()
             x = max(a, 1e-300) ** 0.5
             one = torch.ones((1, 1), dtype=torch.float64)
-            return self.strategy.update(pg, last=float(self.last), loss=float(self.loss), J=one, D=x * one, R=(b / x) * one)
+            self.strategy.update(pg, last=last_h, loss=loss_h, J=one, D=x * one, R=(b / x) * one)
+            return loss_h
         if self.group is None or getattr(J, 'replicated', False):
-            return self.strategy.update(pg, last=self.last, loss=self.loss, J=J, D=D, R=R)
+            self.strategy.update(pg, last=self.last, loss=self.loss, J=J, D=D, R=R)
+            return float(self.loss)
         # the gain ratio needs the GLOBAL (J D)^T (2 R + J D): all-reduce its two dot products and
         # hand the strategy an equivalent 1x1 problem x (2 r + x) with x^2 = a, x r = b
         import torch.distributed as dist
@@ -369,7 +383,8 @@ class LevenbergMarquardt(_Optimizer):
         dist.all_reduce(ab, group=self.group)
         x = ab[0].sqrt().clamp_min(torch.finfo(ab.dtype).tiny)
         one = torch.ones((1, 1), dtype=ab.dtype, device=ab.device)
-        return self.strategy.update(pg, last=self.last, loss=self.loss, J=one, D=x * one, R=(ab[1] / x) * one)
+        self.strategy.update(pg, last=self.last, loss=self.loss, J=one, D=x * one, R=(ab[1] / x) * one)
+        return float(self.loss)
 
     @torch.no_grad()
     def step(self, input, target=None, weight=None):
@@ -388,7 +403,10 @@ class LevenbergMarquardt(_Optimizer):
             self.last = self.loss = self.loss if hasattr(self, 'loss') else self._loss(input, target)
             self.reject_count = 0
             J, R = lin.strategy_args()
-            while self.last <= self.loss:
+            # the loop's decisions are taken on host copies of last / loss (one read-back per trial instead of a
+            # synchronising tensor comparison at every `<` / `<=`); self.last / self.loss stay tensors
+            last_h = loss_h = self._host(self.loss)
+            while last_h <= loss_h:
                 lin.damp(pg['damping'])
                 try:
                     D = lin.solve(self.solver)
@@ -397,12 +415,13 @@ class LevenbergMarquardt(_Optimizer):
                     break
                 self.update_parameter(pg['params'], D)
                 self.loss = lin.fast_loss() if hasattr(lin, 'fast_loss') else self._loss(input, target)
-                self._strategy_update(pg, J, D, R)
-                if self.last < self.loss and self.reject_count < self.reject:     # reject the step
+                loss_h = self._strategy_update(pg, J, D, R, last_h)
+                if last_h < loss_h and self.reject_count < self.reject:           # reject the step
                     self.update_parameter(params=pg['params'], step=-D)
-                    self.loss, self.reject_count = self.last, self.reject_count + 1
+                    self.loss, self.reject_count, loss_h = self.last, self.reject_count + 1, last_h
                 else:
                     break
+            self._host_loss = (self.loss, loss_h)
             if self.group is not None and getattr(lin, 'replicated', False):
                 self._sync_replicas(pg['params'])
         return self.loss
