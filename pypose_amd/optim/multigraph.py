@@ -548,33 +548,52 @@ class _GraphedPCG:
 
 
 def try_multigraph_linearization(opt, pg, input, target, weight, R, params, rec, cache, sig):
-    """A MultiGraphLinearization if every optimised parameter enters the residual only through recorded gathers."""
+    """A MultiGraphLinearization if every optimised parameter enters the residual(s) only through recorded gathers.
+
+    Several residuals (reprojection errors + priors on some cameras, ...; reference optimizer.py:644-654 stacks them
+    as rows of one dense J) are stacked as rows here too: residual i owns rows [o_i, o_i + E_i), is attributed the
+    gathers it depends on, gets ``corrector[i]`` / ``weight[i]``, and is zero-padded to the widest residual.  The
+    j-th gather of parameter k in each residual shares ONE slot (row ranges are disjoint), so a prior on the cameras
+    adds rows to the camera slot instead of a mostly-zero slot of its own."""
     key = (sig, "multi")
-    if cache.get(key) is False or len(R) != 1 or len(opt.corrector) != 1:
+    if cache.get(key) is False or len(opt.corrector) not in (1, len(R)) or any(r.dim() < 2 for r in R):
         return None
-    r = R[0]
-    dr = r.shape[-1]
-    E = r.numel() // dr
+    if weight is not None and len(R) > 1 and not (isinstance(weight, (tuple, list)) and len(weight) == len(R)):
+        return None
     pos = {id(p): k for k, p in enumerate(params)}
-    events = [(src, ix, out) for src, ix, out in rec.events if id(src) in pos and ix.numel() == E
-              and out.numel() == E * src.shape[-1] and src.dim() == 2]
+    events = [(src, ix, out) for src, ix, out in rec.events if id(src) in pos and src.dim() == 2
+              and out.numel() == ix.numel() * src.shape[-1]]
     if not events or len(events) != len(rec.events) or {id(s) for s, _, _ in events} != set(pos):
         cache[key] = False
         return None
-    outs = [out for _, _, out in events]
-    widths = [src.shape[-1] for src, _, _ in events]
+    outs_all = [out for _, _, out in events]
+    parts = []
     with torch.enable_grad():
-        Jcat = _blocks.jacobian_blocks([r], outs)                              # [E, dr, sum widths]
+        for r in R:
+            dr = r.shape[-1]
+            E = r.numel() // dr
+            if len(R) == 1:
+                mine = events
+            else:
+                seen = torch.autograd.grad(r.sum(), outs_all, retain_graph=True, allow_unused=True)
+                mine = [ev for ev, g in zip(events, seen) if g is not None]
+            if not mine or any(ix.numel() != E for _, ix, _ in mine):
+                cache[key] = False
+                return None
+            Jcat = _blocks.jacobian_blocks([r], [out for _, _, out in mine])    # [E, dr, sum widths]
+            parts.append((r, E, dr, mine, Jcat))
         if cache.get(key) is None:
             # probe: u^T dR/dparams by one real backward == scatter-add of the per-observation blocks
-            u = torch.randn_like(r)
-            true = torch.autograd.grad([r], params, [u], retain_graph=True, allow_unused=True)
-            contrib = (u.reshape(E, dr).unsqueeze(-1) * Jcat).sum(-2)
+            us = [torch.randn_like(r) for r in R]
+            true = torch.autograd.grad(list(R), params, us, retain_graph=True, allow_unused=True)
             got = [torch.zeros_like(p) for p in params]
-            off = 0
-            for (src, ix, _), w in zip(events, widths):
-                got[pos[id(src)]].index_add_(0, ix.reshape(-1), contrib[:, off:off + w])
-                off += w
+            for u, (r, E, dr, mine, Jcat) in zip(us, parts):
+                contrib = (u.reshape(E, dr).unsqueeze(-1) * Jcat).sum(-2)
+                off = 0
+                for src, ix, _ in mine:
+                    w = src.shape[-1]
+                    got[pos[id(src)]].index_add_(0, ix.reshape(-1), contrib[:, off:off + w])
+                    off += w
             ok = True
             for t, gt in zip(true, got):
                 t = torch.zeros_like(gt) if t is None else t
@@ -582,20 +601,41 @@ def try_multigraph_linearization(opt, pg, input, target, weight, R, params, rec,
             cache[key] = ok
     if not cache[key]:
         return None
-    ms = [_tangent_width(src) for src, _, _ in events]
-    # corrector: row-local on the concatenated tangent blocks
-    cols, off = [], 0
-    for w, m in zip(widths, ms):
-        cols.append(Jcat[:, :, off:off + m])
-        off += w
-    Rc, Jc = opt.corrector[0](R=r.detach().reshape(E, dr), J=torch.cat(cols, -1))
-    slots, off = [], 0
-    for (src, ix, _), m in zip(events, ms):
-        slots.append((pos[id(src)], ix.reshape(-1), Jc[:, :, off:off + m].contiguous()))
-        off += m
-    Wb = None
-    if weight is not None:
-        w = weight[0] if isinstance(weight, (tuple, list)) else weight
-        ws, ni = opt.model._weight_blocks(w, r)
-        Wb = ws.repeat(ni, 1, 1).contiguous()
-    return MultiGraphLinearization(opt, Wb, Rc, params, slots)
+    dr_max = max(p[2] for p in parts)
+    E_tot = sum(p[1] for p in parts)
+    dt, dev = parts[0][0].dtype, parts[0][0].device
+    weighted = weight is not None
+    Rs, Ws, rows0 = [], [], 0
+    slot_of = {}                     # (parameter, ordinal of its gather inside a residual) -> [idx [E_tot], J [E_tot, dr_max, m]]
+    for i, (r, E, dr, mine, Jcat) in enumerate(parts):
+        ms = [_tangent_width(src) for src, _, _ in mine]
+        cols, off = [], 0
+        for (src, _, _), m in zip(mine, ms):
+            cols.append(Jcat[:, :, off:off + m])
+            off += src.shape[-1]
+        corrector = opt.corrector[0] if len(opt.corrector) == 1 else opt.corrector[i]
+        Rc, Jc = corrector(R=r.detach().reshape(E, dr), J=torch.cat(cols, -1))   # row-local on the concatenated tangent blocks
+        Rp = torch.zeros((E, dr_max), dtype=dt, device=dev)
+        Rp[:, :dr] = Rc
+        Rs.append(Rp)
+        if weighted:
+            Wp = torch.eye(dr_max, dtype=dt, device=dev).repeat(E, 1, 1)
+            w = weight[i] if isinstance(weight, (tuple, list)) else weight
+            if w is not None:
+                ws, ni = opt.model._weight_blocks(w, r)
+                Wp[:, :dr, :dr] = ws.repeat(ni, 1, 1)
+            Ws.append(Wp)
+        ordinal, off = {}, 0
+        for (src, ix, _), m in zip(mine, ms):
+            k = pos[id(src)]
+            j = ordinal.get(k, 0)
+            ordinal[k] = j + 1
+            if (k, j) not in slot_of:
+                slot_of[(k, j)] = [torch.zeros(E_tot, dtype=torch.int64, device=dev), torch.zeros((E_tot, dr_max, m), dtype=dt, device=dev)]
+            sl = slot_of[(k, j)]
+            sl[0][rows0:rows0 + E] = ix.reshape(-1)
+            sl[1][rows0:rows0 + E, :dr] = Jc[:, :, off:off + m]
+            off += m
+        rows0 += E
+    slots = [(k, ix, J) for (k, _), (ix, J) in sorted(slot_of.items())]
+    return MultiGraphLinearization(opt, torch.cat(Ws) if weighted else None, torch.cat(Rs), params, slots)

@@ -150,3 +150,33 @@ def multires_case(G, tag, device="cpu", **lm_kw):
     lm_kw.setdefault("solver", pp.optim.solver.Cholesky())
     opt = pp.optim.LM(model, strategy=pp.optim.strategy.TrustRegion(radius=1e4), min=1e-6, **kw, **lm_kw)
     return model, opt, args, weight
+
+
+class ReprojWithPriors(nn.Module):
+    """Bundle adjustment with position priors on some cameras and some points: three residuals over three parameters
+    (tests/golden/make_ba_prior_golden.py recorded the reference's dense LM on it)."""
+
+    def __init__(self, K, C, P):
+        super().__init__()
+        self.K = pp.Parameter(K)
+        self.C = pp.Parameter(C)
+        self.P = pp.Parameter(P)
+
+    def forward(self, observe, cidx, pidx, cam_ids, cam_pos, pt_ids, pt_pos):
+        reproj = Reproj.project(self.K[cidx], self.C[cidx], self.P[pidx]) - observe
+        return reproj, self.C[cam_ids].translation() - cam_pos, self.P[pt_ids] - pt_pos
+
+
+def ba_prior_case(tag, device="cpu", **lm_kw):
+    G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ba_prior_golden.npz"))
+    t = lambda k: T(G[k], device)
+    D = torch.float64
+    model = ReprojWithPriors(t("K0"), pp.SE3(t("C0")), t("P0"))
+    args = (t("obs"), t("cidx"), t("pidx"), t("cam_ids"), t("cam_pos"), t("pt_ids"), t("pt_pos"))
+    kw, weight = {}, None
+    if tag == "kernel_weights":
+        kw = {"kernel": [pp.optim.kernel.Huber(delta=1.0), None, None]}
+        weight = [torch.eye(2, dtype=D, device=device), torch.eye(3, dtype=D, device=device) * 25.0, torch.eye(3, dtype=D, device=device) * 4.0]
+    lm_kw.setdefault("solver", pp.optim.solver.Cholesky())
+    opt = pp.optim.LM(model, strategy=pp.optim.strategy.TrustRegion(radius=1e4), min=1e-6, **kw, **lm_kw)
+    return G, model, opt, args, weight

@@ -144,3 +144,23 @@ def test_multi_residual_pose_graph_on_device(tag):
         else:
             np.testing.assert_allclose(rec["loss"][:2], M[f"{tag}/loss"][:2], rtol=1e-6)
             assert opt.__dict__.get("_pcg_workspaces")
+
+
+@pytest.mark.parametrize("mode", ["dense", "pcg", "schur"])
+@pytest.mark.parametrize("tag", ["plain", "kernel_weights"])
+def test_bundle_adjustment_with_prior_residuals_on_device(tag, mode, monkeypatch):
+    """three residuals over three parameters (priors share the camera / point slots of the reprojection rows) through
+    the HIP multi-parameter kernels: dense assembly, matrix-free PCG, and the Schur complement"""
+    from pypose_amd.optim import multigraph
+    from tests.optim_models import ba_prior_case
+    if mode == "schur":
+        monkeypatch.setattr(multigraph, "DENSE_LIMIT", 0)
+    solver = pp.optim.solver.PCG(tol=1e-14, maxiter=5000, check_every=8) if mode == "pcg" else pp.optim.solver.Cholesky()
+    G, model, opt, args, weight = ba_prior_case(tag, DEV, solver=solver)
+    rec = run_steps(opt, (args,), {"weight": weight}, 6 if mode != "pcg" else 3)
+    assert set(rec["kind"]) == {"multigraph"}
+    if mode == "pcg":
+        np.testing.assert_allclose(rec["loss"][:3], G[f"{tag}/loss"][:3], rtol=1e-6)
+    else:
+        compare_trajectory(rec, G, tag, floor=1e-12, rtol=1e-6)
+        np.testing.assert_allclose(model.P.detach().cpu().numpy(), G[f"{tag}/P"], atol=1e-6)

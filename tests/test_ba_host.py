@@ -167,3 +167,21 @@ def test_multi_residual_pose_graph_matches_reference(tag):
         model, opt, args, weight = multires_case(M, tag, solver=pp.optim.solver.PCG(tol=1e-13, maxiter=3000, check_every=1))
         rec = run_steps(opt, (args,), {"weight": weight}, 3)
         np.testing.assert_allclose(rec["loss"][:2], M[f"{tag}/loss"][:2], rtol=1e-6)
+
+
+@pytest.mark.parametrize("tag", ["plain", "kernel_weights"])
+def test_bundle_adjustment_with_prior_residuals_matches_reference(tag):
+    """Three residuals (reprojection 2 rows, camera-position prior 3 rows, point prior 3 rows) over three parameters:
+    the multi-parameter graph path stacks them (priors share the camera / point slots) and reproduces the reference's
+    dense trajectory, rejected steps included; also through the matrix-free PCG."""
+    from tests.optim_models import ba_prior_case
+    with oracle_backend():
+        G, model, opt, args, weight = ba_prior_case(tag)
+        rec = run_steps(opt, (args,), {"weight": weight}, 6)
+        assert set(rec["kind"]) == {"multigraph"}
+        compare_trajectory(rec, G, tag, floor=1e-12, rtol=1e-6)
+        np.testing.assert_allclose(model.P.detach().numpy(), G[f"{tag}/P"], atol=1e-6)
+        np.testing.assert_allclose(model.C.detach().tensor().numpy(), G[f"{tag}/C"], atol=1e-6)
+        G, model, opt, args, weight = ba_prior_case(tag, solver=pp.optim.solver.PCG(tol=1e-14, maxiter=5000, check_every=1))
+        rec = run_steps(opt, (args,), {"weight": weight}, 3)
+        np.testing.assert_allclose(rec["loss"][:3], G[f"{tag}/loss"][:3], rtol=1e-6)
