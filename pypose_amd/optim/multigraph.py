@@ -424,6 +424,10 @@ class MultiGraphLinearization:
         return out
 
     def solve_gauss_newton(self, solver):
+        # Gauss-Newton's pseudo-inverse step is not reproduced here: the normal equations of bundle adjustment are too
+        # ill-conditioned (focal lengths ~ 10^3 next to unit-scale points, plus the 7-dof gauge) for CG to reach the
+        # exact minimum-norm solution the reference's SVD returns -- tried, the iterates differ by O(1).  GN on
+        # several parameters therefore stays on the dense linearisation.
         raise NotImplementedError
 
     def strategy_args(self):

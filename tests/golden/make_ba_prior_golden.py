@@ -60,6 +60,20 @@ def main():
             S[f"{tag}/{k}"] = np.asarray(v)
         S[f"{tag}/K"], S[f"{tag}/C"], S[f"{tag}/P"] = model.K.detach().numpy(), model.C.detach().tensor().numpy(), model.P.detach().numpy()
         print(tag, rec)
+    # Gauss-Newton (pseudo-inverse of the rectangular W J) on the same problem: without priors (gauge-free: minimum-norm
+    # steps) and with the weighted priors
+    for tag, use_priors in (("gn_plain", False), ("gn_priors", True)):
+        if use_priors:
+            model = ReprojWithPriors(K0.clone(), C0.clone(), P0.clone())
+            args = (obs, cidx, pidx, cam_ids, cam_pos, pt_ids, pt_pos)
+            weight = [torch.eye(2, dtype=D), Wc, torch.eye(3, dtype=D) * 4.0]
+        else:
+            model = Reproj(K0.clone(), C0.clone(), P0.clone())
+            args, weight = (obs, cidx, pidx), None
+        opt = pp.optim.GN(model)
+        S[f"{tag}/loss"] = np.asarray([float(opt.step(args, weight=weight)) for _ in range(3)])
+        S[f"{tag}/P"], S[f"{tag}/C"] = model.P.detach().numpy(), model.C.detach().tensor().numpy()
+        print(tag, S[f"{tag}/loss"])
     np.savez_compressed(OUT, **S)
 
 

@@ -185,3 +185,20 @@ def test_bundle_adjustment_with_prior_residuals_matches_reference(tag):
         G, model, opt, args, weight = ba_prior_case(tag, solver=pp.optim.solver.PCG(tol=1e-14, maxiter=5000, check_every=1))
         rec = run_steps(opt, (args,), {"weight": weight}, 3)
         np.testing.assert_allclose(rec["loss"][:3], G[f"{tag}/loss"][:3], rtol=1e-6)
+
+
+
+@pytest.mark.parametrize("tag", ["gn_plain", "gn_priors"])
+def test_gauss_newton_on_bundle_adjustment_keeps_the_reference_algorithm(tag):
+    """GN on several parameters stays on the dense linearisation (the pseudo-inverse of an ill-conditioned J is not
+    something CG reproduces): the reference's recorded, non-monotone GN trajectory, with and without weighted priors."""
+    from tests.optim_models import ba_prior_case, Reproj
+    with oracle_backend():
+        G, model, _, args, _ = ba_prior_case("kernel_weights")
+        D = torch.float64
+        weight = [torch.eye(2, dtype=D), torch.eye(3, dtype=D) * 25.0, torch.eye(3, dtype=D) * 4.0]
+        if tag == "gn_plain":
+            model, args, weight = Reproj(model.K.detach().clone(), pp.SE3(model.C.detach().tensor().clone()), model.P.detach().clone()), args[:3], None
+        opt = pp.optim.GN(model)
+        losses = [float(opt.step(args, weight=weight)) for _ in range(3)]
+        np.testing.assert_allclose(losses, G[f"{tag}/loss"], rtol=1e-4)
