@@ -124,3 +124,43 @@ def test_solver_known_answer():
         torch.testing.assert_close(x, x_true, atol=2e-3, rtol=1e-2)
     x = pp.optim.solver.CG()(A.to_sparse_csr(), b)
     torch.testing.assert_close(x, x_true, atol=2e-2, rtol=1e-1)
+
+
+def test_pgo_program_edge_list_cache_follows_the_version_counter():
+    """fused.PgoProgram reuses the stacked edge list while the user's index tensors are the same storage and
+    unwritten; an in-place write (version bump) or other tensors rebuild it (host logic, no kernel involved)."""
+    from pypose_amd.optim import fused
+    edges = torch.randint(0, 9, (20, 2))
+    nodes, Z, cache = torch.zeros(9, 7), torch.zeros(20, 7), {}
+    a = fused.PgoProgram(nodes, edges[:, 0], edges[:, 1], Z, cache=cache)
+    b = fused.PgoProgram(nodes, edges[:, 0], edges[:, 1], Z, cache=cache)          # new views, same storage
+    assert b.idx is a.idx
+    edges[3, 1] = (edges[3, 1] + 1) % 9                                             # in place: version counter moves
+    c = fused.PgoProgram(nodes, edges[:, 0], edges[:, 1], Z, cache=cache)
+    assert c.idx is not a.idx and torch.equal(c.idx, edges)
+    other = edges.clone()
+    d = fused.PgoProgram(nodes, other[:, 0], other[:, 1], Z, cache=cache)
+    assert d.idx is not c.idx and torch.equal(d.idx, edges)
+    assert fused.PgoProgram(nodes, edges[:, 0], edges[:, 1], Z).idx is not a.idx     # no cache given
+
+
+def test_row_op_writes_into_caller_buffers_and_freeze_gc():
+    import gc
+    from pypose_amd import _C
+    from tests.oracle_backend import oracle_backend
+    with oracle_backend():
+        x = pp.randn_SE3(5, dtype=torch.float64)
+        d = torch.zeros(5, 7, dtype=torch.float64)
+        d[:, :6] = 0.1 * torch.randn(5, 6, dtype=torch.float64)
+        want = (pp.se3(d[:, :6]).Exp() * x).tensor()
+        buf = x.tensor().clone()
+        out = _C.row_op("se3_retract", [d, buf], (7,), out=[buf])                  # in place, as LieTensor.add_ does
+        assert out[0] is buf
+        torch.testing.assert_close(buf, want)
+        y = x.clone()
+        y.add_(d)
+        torch.testing.assert_close(y.tensor(), want)
+    before = gc.get_freeze_count()
+    pp.optim.freeze_gc()
+    assert gc.get_freeze_count() >= before
+    gc.unfreeze()
