@@ -24,8 +24,13 @@ ARCH = "gfx950"
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # fp32 a/b and sqrt lower to v_rcp/v_sqrt (<= 2.5 ulp) instead of the ~10-instruction correctly
 # rounded sequences: the kernels sit close enough to the VALU roof for that to matter.
+# -fapprox-func: a / b lowers to v_rcp_f32 + v_mul (2 instructions, <= 2 ulp) instead of the 8-instruction
+# frexp / ldexp range-safe sequence, sqrtf to a bare v_sqrt_f32 -- every division on the hot paths is guarded
+# against tiny divisors by the reference's own eps switches.  -fno-slp-vectorize: the SLP vectoriser pairs fp32
+# operations into v_pk_* and pays more v_mov to assemble the register pairs than it saves (LM trial row: 1456 -> 1272
+# VALU; with both flags 1090; tools/isa_count.py).
 CFLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc",
-          "-fno-hip-fp32-correctly-rounded-divide-sqrt", "-munsafe-fp-atomics",
+          "-fno-hip-fp32-correctly-rounded-divide-sqrt", "-munsafe-fp-atomics", "-fapprox-func", "-fno-slp-vectorize",
           f"-I{CSRC}", f"-I{PKG.parent / 'include'}"]
 
 

@@ -9,21 +9,21 @@ namespace pplie {
 template <class T, int DP> struct Op_chol_solve {
   enum { IW0 = DP * DP, IW1 = DP, IW2 = 0, OW0 = DP, OW1 = 0 };
   static PP_HD void apply(const T* A, const T* g, const T*, T* x, T*) {
-    T L[DP * DP];
+    // only 1 / L_jj is ever needed (the diagonal divides every entry below it and both triangular solves): one
+    // reciprocal square root per column instead of a square root and 1 + 2 divisions -- a third of the instructions
+    T L[DP * DP], inv[DP];
 #pragma unroll
     for (int j = 0; j < DP; ++j) {
       T d = A[j * DP + j];
 #pragma unroll
       for (int k = 0; k < j; ++k) d -= L[j * DP + k] * L[j * DP + k];
-      T ljj = pp_sqrt(d);          // d <= 0 -> NaN (or 0 -> inf below), propagates to x
-      L[j * DP + j] = ljj;
-      T inv = T(1) / ljj;
+      inv[j] = pp_rsqrt(d);        // d < 0 -> NaN, d = 0 -> inf: propagates to x
 #pragma unroll
       for (int i = j + 1; i < DP; ++i) {
         T s = A[i * DP + j];
 #pragma unroll
         for (int k = 0; k < j; ++k) s -= L[i * DP + k] * L[j * DP + k];
-        L[i * DP + j] = s * inv;
+        L[i * DP + j] = s * inv[j];
       }
     }
     T y[DP];
@@ -32,14 +32,14 @@ template <class T, int DP> struct Op_chol_solve {
       T s = -g[i];
 #pragma unroll
       for (int k = 0; k < i; ++k) s -= L[i * DP + k] * y[k];
-      y[i] = s / L[i * DP + i];
+      y[i] = s * inv[i];
     }
 #pragma unroll
     for (int i = DP - 1; i >= 0; --i) {   // L^T x = y
       T s = y[i];
 #pragma unroll
       for (int k = i + 1; k < DP; ++k) s -= L[k * DP + i] * x[k];
-      x[i] = s / L[i * DP + i];
+      x[i] = s * inv[i];
     }
   }
 };

@@ -34,15 +34,22 @@ template <> struct Num<float> {
   typedef float base;
   static PP_HD float eps() { return 1.1920928955078125e-07f; }   // torch.finfo(float32).eps
   static PP_HD float max() { return FLT_MAX; }
-  // below theta^2 < series2 the rotation coefficient functions use their power series
-  // (the closed forms cancel catastrophically in fp32: SURVEY.md section 7 "hard parts")
-  static PP_HD float series2() { return 2.25f; }
+  static PP_HD float min_normal() { return FLT_MIN; }
+  // below theta^2 < series2 the coefficient functions B, C, D, E use their power series (the closed forms cancel
+  // catastrophically in fp32: SURVEY.md section 7 "hard parts").  The 8-term series are good to 2-3 ulp up to
+  // theta = pi (tests/hostmath: max rel. error 2.7e-7 on [0, 9.9]), so every rotation angle a Log can return takes the
+  // series and the closed-form branch is dynamically rare -- with the switch at 1.5 rad nearly every wave executed both
+  // sides.  F = (1 - (t/2)cot(t/2))/t^2 has a pole at 2 pi: its series keeps the old switch.
+  static PP_HD float series2() { return 9.9f; }
+  static PP_HD float seriesF2() { return 2.25f; }
 };
 template <> struct Num<double> {
   typedef double base;
   static PP_HD double eps() { return 2.220446049250313e-16; }     // torch.finfo(float64).eps
   static PP_HD double max() { return DBL_MAX; }
+  static PP_HD double min_normal() { return DBL_MIN; }
   static PP_HD double series2() { return 0.0625; }
+  static PP_HD double seriesF2() { return 0.0625; }
 };
 
 PP_HD float pp_sin(float x) { return ::sinf(x); }
@@ -51,6 +58,13 @@ PP_HD float pp_cos(float x) { return ::cosf(x); }
 PP_HD double pp_cos(double x) { return ::cos(x); }
 PP_HD float pp_sqrt(float x) { return ::sqrtf(x); }
 PP_HD double pp_sqrt(double x) { return ::sqrt(x); }
+// 1 / sqrt(x): v_rsq_f32 (1 ulp) on the device; NaN for x < 0, inf at 0
+#if defined(__HIP_DEVICE_COMPILE__)
+PP_HD float pp_rsqrt(float x) { return __builtin_amdgcn_rsqf(x); }
+#else
+PP_HD float pp_rsqrt(float x) { return 1.0f / ::sqrtf(x); }
+#endif
+PP_HD double pp_rsqrt(double x) { return 1.0 / ::sqrt(x); }
 PP_HD float pp_atan(float x) { return ::atanf(x); }
 PP_HD double pp_atan(double x) { return ::atan(x); }
 PP_HD float pp_exp(float x) { return ::expf(x); }
@@ -268,7 +282,7 @@ template <class S> PP_HD S rot_coef_F_series(S th2) {
 }
 template <class S> PP_HD S rot_coef_F(S th2) {
   typedef typename Num<S>::base T;
-  if (pp_val(th2) < Num<T>::series2()) return rot_coef_F_series(th2);
+  if (pp_val(th2) < Num<T>::seriesF2()) return rot_coef_F_series(th2);
   S th = pp_sqrt(th2);
   S sh, ch;
   pp_sincos(S(T(0.5)) * th, sh, ch);
@@ -525,7 +539,7 @@ template <class S> PP_HD void se3_log(const S* X, S* x) {
     put(phi, x + 3);
     S th2 = norm2(phi);
     S F;
-    if (pp_val(th2) < Num<T>::series2())
+    if (pp_val(th2) < Num<T>::seriesF2())
       F = rot_coef_F(th2);
     else
       F = pp_nan_to_num((S(T(1)) - pp_abs(half) * pp_abs(w) / vn) / th2);
@@ -699,18 +713,20 @@ template <class S> PP_HD void se3_jinvp(const S* X, const S* p, S* out) {
   const S th2 = norm2(phi);
   RotCoef<S> k;
   S F;
-  if (pp_val(th2) < Num<T>::series2()) {
-    k = rot_coef_series(th2);
-    F = rot_coef_F_series(th2);
-  } else {
+  const bool kser = pp_val(th2) < Num<T>::series2(), fser = pp_val(th2) < Num<T>::seriesF2();
+  if (kser) k = rot_coef_series(th2);
+  if (fser) F = rot_coef_F_series(th2);
+  if (!kser || !fser) {
     const S th = pp_abs(f) * vn;
-    const S rn = S(T(1)) / pp_sqrt(vn2 + w * w);
-    const S sh = vn * rn, ch = pp_abs(w) * rn;               // sin, cos of theta/2
-    k.B = S(T(2)) * sh * sh / th2;
-    k.C = (th - S(T(2)) * sh * ch) / (th2 * th);
-    k.D = (S(T(0.5)) - k.B) / th2;
-    k.E = (S(T(3)) * k.C - k.B) / (S(T(2)) * th2);
-    F = pp_nan_to_num((S(T(1)) - S(T(0.5)) * th * pp_abs(w) / vn) / th2);     // (theta/2) cot(theta/2) = (theta/2) |w|/|v|
+    if (!kser) {
+      const S rn = S(T(1)) / pp_sqrt(vn2 + w * w);
+      const S sh = vn * rn, ch = pp_abs(w) * rn;               // sin, cos of theta/2
+      k.B = S(T(2)) * sh * sh / th2;
+      k.C = (th - S(T(2)) * sh * ch) / (th2 * th);
+      k.D = (S(T(0.5)) - k.B) / th2;
+      k.E = (S(T(3)) * k.C - k.B) / (S(T(2)) * th2);
+    }
+    if (!fser) F = pp_nan_to_num((S(T(1)) - S(T(0.5)) * th * pp_abs(w) / vn) / th2);   // (theta/2) cot(theta/2) = (theta/2) |w|/|v|
   }
   const V3<S> tau = jlinv_apply(F, phi, v3(X));
   const V3<S> b = jlinv_apply(F, phi, v3(p + 3));
@@ -865,7 +881,7 @@ template <class S> PP_HD V3<S> ws_inv_apply(S A, S B, S C, const V3<S>& phi, con
   S b = -A / den;
   V3<S> kv = cross(phi, v);
   V3<S> r = a * v + b * kv;
-  if (pp_val(th2) > T(0)) {
+  if (pp_val(th2) >= Num<T>::min_normal()) {      // (a subnormal divisor has no fast reciprocal; the term is O(theta^2) there)
     S c = (a - alpha / den) / th2;
     r = r + c * cross(phi, kv);
   }

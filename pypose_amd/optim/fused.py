@@ -86,9 +86,10 @@ class Se3InvLinearization:
     kind = "fused:se3inv"
     reference_kind = "block"
 
-    def __init__(self, opt, P, X, r):
+    def __init__(self, opt, P, X, r, input=None):
         self.opt, self.P = opt, P
         self.n = P.numel() // 7
+        self.X_src, self.input = X, input
         self.X = X.detach().reshape(self.n, 7).contiguous()
         # r = None (LM(static=True)): the first trial kernel of the step computes Log(P X) itself and leaves it in a
         # buffer for the retries, so the step needs no separate residual evaluation at all
@@ -131,41 +132,282 @@ class Se3InvLinearization:
         return ok and bool((sums[1] - Rr.square().sum()).abs() <= rtol * Rr.square().sum().clamp_min(1e-30))
 
     def run_trials(self, opt, pg):
-        """The trial loop of LM.step (reference optimizer.py:662-678) with every decision taken on host
-        scalars: one kernel and one 4-float read-back per trial."""
-        strategy, P = opt.strategy, self.P
-        have = hasattr(opt, 'loss')
-        cached = opt.__dict__.get('_host_loss', (None, None))
-        last = loss = (cached[1] if cached[0] is opt.loss else float(opt.loss)) if have else None
-        opt.reject_count = 0
-        if have:
-            opt.last = opt.loss
-        while True:
-            self.damp(pg['damping'])
-            # P_new is written in place: this IS update_parameter (p.add_(d) = Exp(d) * p, lietensor.py:442)
-            D, sums = self._trial(None, self.scale)
-            if opt.group is not None:
-                import torch.distributed as dist
-                dist.all_reduce(sums, group=opt.group)
-            new, old, jdjd, jdr = sums.tolist()
-            assert new == new, 'Cholesky decomposition failed. Check your matrix (may not be positive-definite)'
-            if last is None:                          # first step ever: |R|^2 is the loss before the update
-                last = old
-                opt.last = sums[1]
-            loss, opt.loss = new, sums[0]
-            # gain ratio from the two reduced dot products: an equivalent 1x1 problem on the host
-            x = max(jdjd, 1e-300) ** 0.5
-            one = torch.ones((1, 1), dtype=torch.float64)
-            strategy.update(pg, last=last, loss=loss, J=one, D=x * one, R=(jdr / x) * one)
-            if last < loss and opt.reject_count < opt.reject:          # reject the step
-                opt.update_parameter(params=pg['params'], step=-D.view(-1, 1))
-                loss, opt.loss, opt.reject_count = last, opt.last, opt.reject_count + 1
-            else:
-                break
-            if not last <= loss:
-                break
-        opt._host_loss = (opt.loss, loss)
+        """The trial loop of LM.step (reference optimizer.py:662-678) on the device: see :class:`DeviceLM`."""
+        dev = opt.__dict__.get('_device_lm')
+        if dev is None or dev.P is not self.P or not dev.same_operand(self.X_src):
+            dev = opt._device_lm = DeviceLM(opt, self.P, self.X_src, self.input)
+        else:
+            dev.rearm(self.input)
+        return dev.step()
+
+
+# ---------------------------------------------------------------------------------------------
+# the LM step with its loop state in device memory (csrc/lm_step.hip)
+# ---------------------------------------------------------------------------------------------
+class _LmCfg(ctypes.Structure):       # = pplie_lm_cfg (include/pplie.h)
+    _fields_ = [(k, ctypes.c_double) for k in ("high", "low", "up", "factor", "smin", "smax", "sdown", "dmin", "dmax",
+                                               "host_damping", "host_down")] + \
+               [(k, ctypes.c_int) for k in ("strategy", "reject", "flags", "grid_cap")]
+
+
+_STEP_SIG = [ctypes.c_void_p] * 7 + [ctypes.POINTER(_LmCfg), ctypes.c_int64] + [ctypes.c_void_p] * 3
+_SUMS_SIG = [ctypes.c_void_p] * 5 + [ctypes.POINTER(_LmCfg), ctypes.c_int, ctypes.c_int64] + [ctypes.c_void_p] * 2
+_DECIDE_SIG = [ctypes.c_void_p] * 2 + [ctypes.POINTER(_LmCfg), ctypes.c_int] + [ctypes.c_void_p] * 4
+_ST_DAMPING, _ST_RADIUS, _ST_DOWN, _ST_SCALE, _ST_LAST, _ST_LOSS, _ST_REJECTS, _ST_DONE, _ST_FAILED, _ST_TRIALS = range(10)
+_LM_STATE = 16            # PPLIE_LM_STATE
+_LOSS_BLOCK = 1024        # loss / last scalars handed out as views of one allocation per 1024 steps
+_RETRACE = 64             # the model's forward is traced again every so many steps (the program could have changed)
+_LAZY_KEYS = frozenset(("damping", "radius", "down"))
+import os as _os
+_TUNE_FLAGS = int(_os.environ.get("PPLIE_LM_FLAGS", "0"))       # tuning knobs of the trial kernel (tools/time_c3_device.py)
+_TUNE_GRID = int(_os.environ.get("PPLIE_LM_GRID", "0"))
+
+
+class LazyGroup(dict):
+    """The optimizer's param group while its ``damping`` / ``radius`` / ``down`` entries live in device memory: reading
+    one of them first brings the host copy up to date (one small read-back), writing one makes the host copy the
+    authority again.  Everything else is a plain dict, so ``state_dict()``, ``repr`` and user code keep working."""
+
+    __slots__ = ("sync",)
+
+    def _pull(self):
+        s = self.sync
+        if s is not None and s.pending:
+            s.flush()
+
+    def _push(self):
+        s = self.sync
+        if s is not None:
+            if s.pending:
+                s.flush()
+            s.host_dirty = True
+
+    def __getitem__(self, k):
+        if k in _LAZY_KEYS:
+            self._pull()
+        return dict.__getitem__(self, k)
+
+    def get(self, k, default=None):
+        if k in _LAZY_KEYS:
+            self._pull()
+        return dict.get(self, k, default)
+
+    def __setitem__(self, k, v):
+        if k in _LAZY_KEYS:
+            self._push()
+        dict.__setitem__(self, k, v)
+
+    def update(self, *a, **kw):
+        self._push()
+        dict.update(self, *a, **kw)
+
+    def setdefault(self, k, default=None):
+        self._push()
+        return dict.setdefault(self, k, default)
+
+    def pop(self, *a):
+        self._push()
+        return dict.pop(self, *a)
+
+    def items(self):
+        self._pull()
+        return dict.items(self)
+
+    def values(self):
+        self._pull()
+        return dict.values(self)
+
+    def copy(self):
+        self._pull()
+        return dict(self)
+
+    def __repr__(self):
+        self._pull()
+        return dict.__repr__(self)
+
+    def __reduce__(self):
+        self._pull()
+        return (dict, (dict(self),))
+
+
+class DeviceLM:
+    """Levenberg-Marquardt steps of the ``se3inv`` program whose loop state -- damping, trust-region radius, last /
+    current loss, reject count -- stays in device memory (``pplie_lm_se3inv_step``): a step is two kernel launches
+    and NO host synchronisation; ``opt.loss`` is a device scalar as in the reference, ``pg['damping']`` /
+    ``pg['radius']`` / ``opt.reject_count`` are read back on first use (:class:`LazyGroup`).
+
+    The reference's semantics are kept (optimizer.py:659-678): ONE loss, ONE damping, ONE accept / reject decision
+    per trial over all problems; the damping compounds over rejected retries; a rejected trial restarts from the
+    linearisation point (the reference returns there by ``Exp(-d)``, i.e. up to rounding)."""
+
+    def __init__(self, opt, P, X_src, input):
+        from .strategy import Adaptive, Constant, TrustRegion
+        self.opt, self.P, self.X_src = opt, P, X_src
+        self.kind = {Constant: 0, Adaptive: 1, TrustRegion: 2}[type(opt.strategy)]
+        self.strategy = opt.strategy
+        pt = P.detach()
+        self.n = pt.numel() // 7
+        self.dtype, self.device = pt.dtype, pt.device
+        self.X = X_src.detach().reshape(self.n, 7)
+        assert self.X.is_contiguous()
+        self.x_ptr, self.x_version = self.X.data_ptr(), X_src._version
+        self.p_ptr = pt.data_ptr()
+        z = dict(dtype=self.dtype, device=self.device)
+        self.save = torch.empty((self.n, 7), **z)
+        self.partials = torch.empty((_PARTIALS, 4), **z)
+        self.sums = torch.zeros(4, **z)
+        # double-buffered loop state: a step reads the buffer the previous step wrote and writes the other one
+        self.state = torch.zeros((2, _LM_STATE), dtype=torch.float64, device=self.device)
+        self.cur = 0                  # buffer holding the latest state
+        self.sync = torch.zeros(8, dtype=torch.int32, device=self.device)
+        self.cfg = _LmCfg()
+        sfx = _blocks._suffix(pt)
+        self.fn = _C.library().symbol("pplie_lm_se3inv_step" + sfx, _STEP_SIG)
+        self.fn_sums = _C.library().symbol("pplie_lm_se3inv_trial_sums" + sfx, _SUMS_SIG)
+        self.fn_decide = _C.library().symbol("pplie_lm_decide" + sfx, _DECIDE_SIG)
+        sp = self.state.data_ptr()
+        self.ptrs = (self.save.data_ptr(), self.partials.data_ptr(), (sp, sp + 8 * _LM_STATE), self.sync.data_ptr())
+        self.item = pt.element_size()
+        self.k = _LOSS_BLOCK
+        self.pending = False          # device state newer than the host mirrors
+        self.host_dirty = True        # host param group newer than the device state
+        self.last_loss = None         # the loss tensor handed out by the previous step
+        self.rearm(input)
+        self._wrap_group()
+
+    # ---- validity of the shortcut that skips the traced forward ------------------------------------------------
+    def same_operand(self, X_src):
+        return X_src.data_ptr() == self.x_ptr and X_src.numel() == self.n * 7 and X_src.dtype == self.dtype
+
+    def rearm(self, input):
+        self.input = input
+        self.budget = (1 << 62) if getattr(self.opt, 'static', False) else _RETRACE
+
+    def _wrap_group(self):
+        opt = self.opt
+        pg = opt.param_groups[0]
+        if type(pg) is not LazyGroup:
+            new = LazyGroup(pg)
+            new.sync = self
+            opt.param_groups[0] = new
+            self.host_dirty = True
+        elif pg.sync is not self:
+            if pg.sync is not None and pg.sync.pending:
+                pg.sync.flush()
+            pg.sync = self
+            self.host_dirty = True
+        return opt.param_groups[0]
+
+    def try_step(self, input, target, weight):
+        """The whole of ``LM.step`` when nothing the verified program depends on has changed, else None."""
+        opt = self.opt
+        if self.budget <= 0 or target is not None or weight is not None or opt.weight is not None \
+                or not _same_input(self.input, input) or self.X_src._version != self.x_version \
+                or self.X_src.data_ptr() != self.x_ptr or self.P.data_ptr() != self.p_ptr \
+                or opt.strategy is not self.strategy or not opt.fused or not getattr(opt, 'structured', True) \
+                or len(opt.param_groups) != 1 or torch.is_inference_mode_enabled():
+            return None
+        self.budget -= 1
+        opt.linearization = Se3InvLinearization.kind
+        return self.step()
+
+    # ---- one step ----------------------------------------------------------------------------------------------
+    def _fill_cfg(self, pg):
+        cfg, opt, st = self.cfg, self.opt, self.strategy
+        g = dict.get
+        cfg.high, cfg.low, cfg.up, cfg.factor = g(pg, 'high', 0.5), g(pg, 'low', 1e-3), g(pg, 'up', 2.0), g(pg, 'factor', 0.5)
+        cfg.smin, cfg.smax, cfg.sdown = getattr(st, 'min', 0.0), getattr(st, 'max', 0.0), getattr(st, 'down', 0.5)
+        cfg.dmin, cfg.dmax = g(pg, 'min'), g(pg, 'max')
+        cfg.strategy, cfg.reject = self.kind, int(opt.reject)
+        flags = 0
+        if self.host_dirty:
+            flags |= 1
+            cfg.host_damping, cfg.host_down = g(pg, 'damping'), g(pg, 'down', 0.5)
+        loss = opt.__dict__.get('loss')
+        if loss is None:
+            flags |= 2
+        elif loss is not self.last_loss:            # set by the user or by another linearisation's step
+            self.state[self.cur, _ST_LOSS:_ST_LOSS + 1].copy_(torch.as_tensor(loss).detach().reshape(1))
+        cfg.flags = flags | _TUNE_FLAGS
+        cfg.grid_cap = _TUNE_GRID
+
+    def _slot(self):
+        if self.k == _LOSS_BLOCK:
+            self.block = torch.empty((2, _LOSS_BLOCK), dtype=self.dtype, device=self.device)
+            self.loss_views, self.last_views = self.block[0].unbind(0), self.block[1].unbind(0)
+            self.block_ptr = self.block.data_ptr()
+            self.k = 0
+        k = self.k
+        self.k = k + 1
+        return k, self.block_ptr + k * self.item, self.block_ptr + (_LOSS_BLOCK + k) * self.item
+
+    def step(self):
+        opt = self.opt
+        pg = opt.param_groups[0]
+        if type(pg) is not LazyGroup or pg.sync is not self:
+            pg = self._wrap_group()
+        self._fill_cfg(pg)
+        k, loss_ptr, last_ptr = self._slot()
+        save, partials, state, sync = self.ptrs
+        st_in, st_out = state[self.cur], state[1 - self.cur]
+        stream = _C.stream_ptr(self.device)
+        if opt.group is None:
+            with _C._on_device(self.device):
+                code = self.fn(self.p_ptr, self.x_ptr, save, partials, st_in, st_out, sync, self.cfg, self.n, loss_ptr, last_ptr, stream)
+            if code:
+                _C.check(code, "pplie_lm_se3inv_step")
+            self.cur = 1 - self.cur
+        else:
+            self._sharded(st_in, st_out, loss_ptr, last_ptr, stream)
+        torch.autograd.graph.increment_version(self.P)       # P was rewritten through its raw pointer
+        self.host_dirty, self.pending = False, True
+        opt.loss = self.last_loss = self.loss_views[k]
+        opt._last_view = self.last_views[k]
+        opt.__dict__.pop('_host_loss', None)
         return opt.loss
+
+    def _sharded(self, st_in, st_out, loss_ptr, last_ptr, stream):
+        """LM(group=...): every rank runs the trial on its problems; the four sums are all-reduced so that all ranks
+        take the same decision (3 scalars per trial); retries are driven from the host (one flag read per
+        trial) because the all-reduce cannot run inside the finish kernel."""
+        import torch.distributed as dist
+        save, partials, _, _ = self.ptrs
+        first, sums = 1, self.sums.data_ptr()
+        self.cur = 1 - self.cur
+        while True:
+            with _C._on_device(self.device):
+                _C.check(self.fn_sums(self.p_ptr, self.x_ptr, save, partials, st_in if first else st_out, self.cfg, first, self.n, sums,
+                                      stream), "pplie_lm_se3inv_trial_sums")
+                dist.all_reduce(self.sums, group=self.opt.group)
+                _C.check(self.fn_decide(st_in if first else st_out, st_out, self.cfg, first, sums, loss_ptr, last_ptr, stream),
+                         "pplie_lm_decide")
+            st = self.state[self.cur].tolist()
+            if st[_ST_FAILED]:
+                self.P.detach().reshape(self.n, 7).copy_(self.save)
+                break
+            if st[_ST_DONE]:
+                break
+            first = 0
+
+    # ---- host mirrors --------------------------------------------------------------------------------------------
+    def flush(self):
+        if not self.pending:
+            return
+        self.pending = False
+        st = self.state[self.cur].tolist()                    # the one read-back
+        opt = self.opt
+        pg = opt.param_groups[0]
+        dict.__setitem__(pg, 'damping', st[_ST_DAMPING])
+        if self.kind == 2:
+            dict.__setitem__(pg, 'radius', st[_ST_RADIUS])
+            dict.__setitem__(pg, 'down', st[_ST_DOWN])
+        opt.__dict__['_reject_count'] = int(st[_ST_REJECTS])
+        opt.__dict__['_trials'] = int(st[_ST_TRIALS])
+        if opt.loss is self.last_loss:
+            opt._host_loss = (opt.loss, st[_ST_LOSS])
+        if st[_ST_FAILED]:
+            print('Cholesky decomposition failed. Check your matrix (may not be positive-definite)',
+                  "\nLinear solver failed. Breaking optimization step...")
 
 
 _PGO_SIG = [ctypes.c_void_p] * 5 + [ctypes.c_int64, ctypes.c_void_p]
@@ -280,6 +522,10 @@ def try_fused(opt, pg, input, target, weight, cache):
         return None
     trivial = all(isinstance(c, Trivial) for c in opt.corrector) and all(isinstance(k, Trivial) for k in opt.model.kernel)
     solver_ok = (isinstance(opt.solver, Cholesky) and not opt.solver.upper) or isinstance(opt.solver, _pg.PCG)
+    # the device-side decision implements exactly the three built-in damping policies; a user-defined or subclassed
+    # strategy sees the real J, D, R of the block linearisation instead
+    from .strategy import Adaptive, Constant, TrustRegion
+    builtin = type(opt.strategy) in (Constant, Adaptive, TrustRegion)
     if getattr(opt, 'static', False) and cache.get("fused") is True:
         # LM(static=True): the caller promises that the model's residual program and its non-parameter operands do
         # not change between step() calls with the same ``input`` object -- the verified program of the previous
@@ -287,16 +533,16 @@ def try_fused(opt, pg, input, target, weight, cache):
         hit = cache.get("program")
         if hit is not None and _same_input(hit[0], input) and hit[1] is P:
             kind, operands = hit[2], hit[3]
-            if kind == "se3inv" and weight is None and trivial and solver_ok:
-                return Se3InvLinearization(opt, P, operands, None)
+            if kind == "se3inv" and weight is None and trivial and solver_ok and builtin:
+                return Se3InvLinearization(opt, P, operands, None, input)
             if kind == "pgo" and len(opt.corrector) == 1:
                 return _pgo_linearization(opt, operands, weight, P, trivial)
     with torch.no_grad(), OpTracer() as tr, _pg.GatherRecorder(params) as rec:
         R = list(opt.model(input, target))
     m = match_se3inv(tr, R, params) if not rec.events else None
-    if m is not None and weight is None and trivial and solver_ok:
-        cache["program"] = (input, P, "se3inv", m[1].detach())
-        return Se3InvLinearization(opt, *m)
+    if m is not None and weight is None and trivial and solver_ok and builtin:
+        cache["program"] = (input, P, "se3inv", m[1])
+        return Se3InvLinearization(opt, *m, input)
     m = match_pgo(tr, rec.events, R, params)
     if m is not None and len(opt.corrector) == 1:
         prog = PgoProgram(*m, cache=cache)

@@ -25,6 +25,7 @@ from __future__ import annotations
 import torch
 from torch import nn
 from torch.optim import Optimizer
+from torch.optim import optimizer as _torch_opt
 
 from . import blocks as _blocks
 from .corrector import FastTriggs
@@ -386,8 +387,46 @@ class LevenbergMarquardt(_Optimizer):
         self.strategy.update(pg, last=self.last, loss=self.loss, J=one, D=x * one, R=(ab[1] / x) * one)
         return float(self.loss)
 
-    @torch.no_grad()
+    # ---- values a device-resident step leaves in device memory until somebody looks (optim/fused.py DeviceLM) ----
+    @property
+    def reject_count(self):
+        dev = self.__dict__.get('_device_lm')
+        if dev is not None and dev.pending:
+            dev.flush()
+        return self.__dict__.get('_reject_count', 0)
+
+    @reject_count.setter
+    def reject_count(self, value):
+        self.__dict__['_reject_count'] = value
+
+    @property
+    def last(self):
+        """the loss before the latest step (reference: ``self.last``, optimizer.py:659)"""
+        d = self.__dict__
+        if '_last_view' in d:
+            return d['_last_view']
+        raise AttributeError('last')
+
+    @last.setter
+    def last(self, value):
+        self.__dict__['_last_view'] = value
+
     def step(self, input, target=None, weight=None):
+        dev = self.__dict__.get('_device_lm')
+        if dev is not None and not (self._optimizer_step_pre_hooks or self._optimizer_step_post_hooks or _torch_opt._global_optimizer_pre_hooks
+                                    or _torch_opt._global_optimizer_post_hooks):
+            # a verified fused program whose operands have not changed: the whole step is two kernel launches, the
+            # model is not run (it is traced again every few dozen steps, and whenever anything it was verified on
+            # changes).  Nothing here touches autograd, and torch.optim's per-step profiler range + hook dispatch (a good
+            # 15 us) is only entered when somebody registered a hook.
+            out = dev.try_step(input, target, weight)
+            if out is not None:
+                return out
+        return self._step_general(input, target, weight)
+    step.hooked = True              # torch.optim.Optimizer.__init__ must not wrap it again: _step_general carries the wrapper
+
+    @torch.no_grad()
+    def _step_general(self, input, target=None, weight=None):
         for pg in self.param_groups:
             weight = self.weight if weight is None else weight
             lin = _linearize(self, pg, input, target, weight)
@@ -435,3 +474,7 @@ class LevenbergMarquardt(_Optimizer):
             if p.requires_grad:
                 data = p.data
                 dist.broadcast(data.tensor() if hasattr(data, 'ltype') else data, src=src, group=self.group)
+
+
+# the general path keeps torch.optim's step wrapper (profiler range, optimizer step pre / post hooks)
+LevenbergMarquardt._step_general = Optimizer.profile_hook_step(LevenbergMarquardt._step_general)
