@@ -1,6 +1,6 @@
-"""bench.py -- BASELINE.json's metric on its configs[1] workload.
+"""bench.py -- BASELINE.json's metric on its configs[1] workload, plus one block per other BASELINE config.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W        (N > 1 launches itself: one process per GPU over RCCL)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Workload ("se3_explog_b10m"): batched SE3 Exp -> Log forward, B = 10,000,000 rows of fp32 per GPU
@@ -11,8 +11,15 @@ Exp+Log pairs per second summed over all ranks (weak scaling: rows are independe
 owns its own B rows, no data-path collective).
 
 Printed JSON line (rank 0): the driver contract + "roofline" (dominant kernel, HIP-event timed
-inside the timed region) + "cpu_baseline" (the oracle -- a numpy port of the reference's
-algorithm -- timed on this box's host cores on a bounded sample of the same workload).
+inside the timed region) + "cpu_baseline" (the reference's own PyTorch-CPU path, shipped as oracle/_ref, timed on
+this box's host cores on a bounded sample of the same workload; the numpy port of round 1 beside it) + one block per
+other BASELINE config, each with its own roofline figures:
+    c1          configs[0]  fwd + bwd of Exp().Log() at B = 1024 (plumbing latency)
+    lm_invnet   configs[2]  LM on InvNet SE3, 10^6 independent problems
+    lm_pgo      metric      LM iterations / s on a 10 k-pose graph;  lm_pgo_100k  configs[3] on one GPU
+    imu         configs[4]  IMUPreintegrator 4096 x 1024 with and without covariance
+With N > 1 (one process per GPU) the sharded legs replace them: lm_invnet_sharded (problems), imu_sharded (sequences),
+lm_pgo_sharded (configs[3]: edges / solve sharded).
 """
 from __future__ import annotations
 
@@ -32,6 +39,9 @@ HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 BYTES_PER_ROW = {"se3_exp_fwd": 24 + 28, "se3_log_fwd": 28 + 24}    # 52 B/row each
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# cpu_baseline
+# ---------------------------------------------------------------------------------------------------------------
 def _cpu_worker(args):
     import numpy as np
     from oracle import lie_np
@@ -46,7 +56,7 @@ def _cpu_worker(args):
     return time.perf_counter() - t0, float(y[0, 0])
 
 
-def cpu_baseline(budget_s: float = 12.0):
+def cpu_baseline_port(budget_s: float = 6.0):
     """Oracle (numpy port of operation.py's se3_Exp / SE3_Log) on all host cores, bounded sample."""
     import multiprocessing as mp
     cores = os.cpu_count() or 1
@@ -67,23 +77,65 @@ def cpu_baseline(budget_s: float = 12.0):
                       f"{cores} processes x {chunk}-row chunks, {wall:.1f} s wall)"}
 
 
-def pgo_lm_rate(dev, nodes=10_000, edges=40_000, steps=3, reps=5):
-    """Second half of BASELINE.json's metric: LM iterations/s on a synthetic pose graph
-    (SURVEY.md section 8d C4 generator: chain + random loop closures, sigma 0.01 edge noise, sigma 0.05
-    initial error; the reference's own PoseGraph model, examples/module/pgo/pgo.py:15-25; PCG tol 1e-4 /
-    maxiter 250 as examples/module/ba, TrustRegion(radius=1e4) as pgo.py:67).  Not part of `value`."""
+def cpu_baseline(budget_s: float = 12.0):
+    """The REFERENCE's own path -- `pp.randn_se3(B).Exp().Log()` of the PyPose package shipped as oracle/_ref -- on
+    PyTorch-CPU with all host cores (intra-op threads), bounded sample; the numpy port of round 1 rides along."""
+    import torch
+    from oracle import ref_loader
+    port = None
+    try:
+        port = cpu_baseline_port()
+    except Exception as e:           # never lose the headline line
+        port = {"error": repr(e)}
+    if not ref_loader.available():
+        port["note"] = "oracle/_ref not shipped: numpy port only"
+        return port
+    rpp = ref_loader.load()
+    cores = os.cpu_count() or 1
+    old = torch.get_num_threads()
+    B = 1_000_000
+    torch.manual_seed(0)
+    x = rpp.randn_se3(B, dtype=torch.float32)
+    # PyTorch's intra-op pool does not scale to every core of a large host on this chain of ~100 small aten ops (256 threads
+    # measured 20x slower than 32 on the MI355X box): a short probe picks the thread count, the rest of the budget times it
+    best_t, best_rate, tried = 1, 0.0, {}
+    try:
+        with torch.no_grad():
+            for t in sorted({min(cores, c) for c in (8, 16, 32, 64, cores)}):
+                torch.set_num_threads(t)
+                xs = x[:100_000]
+                xs.Exp().Log()
+                t0 = time.perf_counter()
+                xs.Exp().Log()
+                rate = 100_000 / (time.perf_counter() - t0)
+                tried[t] = rate
+                if rate > best_rate:
+                    best_t, best_rate = t, rate
+            torch.set_num_threads(best_t)
+            x.Exp().Log()                                   # warm-up
+            t0 = time.perf_counter()
+            passes = 0
+            while time.perf_counter() - t0 < budget_s and passes < 20:
+                x.Exp().Log()
+                passes += 1
+            wall = time.perf_counter() - t0
+    finally:
+        torch.set_num_threads(old)
+    return {"value": B * passes / wall, "unit": "SE3 Exp+Log pairs/s", "cores": best_t, "host_cores": cores, "kind": "reference",
+            "sample": f"{passes} passes of pp.randn_se3({B}).Exp().Log() (fp32, torch {torch.__version__} CPU, {best_t} intra-op "
+                      f"threads -- the fastest of {sorted(tried)} in a 100k-row probe, {wall:.1f} s wall) through the reference package "
+                      f"itself (PyPose {getattr(rpp, '__version__', '?')}, oracle/_ref)",
+            "thread_probe_pairs_per_s": {str(k): v for k, v in tried.items()},
+            "numpy_port": port}
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# secondary workloads
+# ---------------------------------------------------------------------------------------------------------------
+def _pose_graph_problem(dev, nodes, edges):
+    """SURVEY.md section 8d C4 generator: chain + random loop closures, sigma 0.01 edge noise, sigma 0.05 initial error."""
     import torch
     import pypose_amd as pp
-
-    class PoseGraph(torch.nn.Module):
-        def __init__(self, init):
-            super().__init__()
-            self.nodes = pp.Parameter(init)
-
-        def forward(self, e, poses):
-            n1, n2 = self.nodes[e[..., 0]], self.nodes[e[..., 1]]
-            return (poses.Inv() @ n1.Inv() @ n2).Log().tensor()
-
     g = torch.Generator().manual_seed(0)
     torch.manual_seed(0)
     gt = pp.cumprod(pp.randn_SE3(nodes, sigma=0.3, device=dev), dim=0, left=False)
@@ -93,66 +145,14 @@ def pgo_lm_rate(dev, nodes=10_000, edges=40_000, steps=3, reps=5):
     e = torch.cat([chain, extra], 0).to(dev)
     rel = gt[e[:, 0]].Inv() @ gt[e[:, 1]] @ pp.randn_SE3(edges, sigma=0.01, device=dev)
     init = gt @ pp.randn_SE3(nodes, sigma=0.05, device=dev)
-    graph = PoseGraph(init.clone())
-    solver = pp.optim.solver.PCG(tol=1e-4, maxiter=250)
-    opt = pp.optim.LM(graph, solver=solver, strategy=pp.optim.strategy.TrustRegion(radius=1e4))
-    l0 = float(graph(e, rel).detach().square().sum())
-    # every repetition restarts from the same initial estimate and takes the `steps` LM steps that do the
-    # actual descent (this problem reaches its noise floor in 3-4); repetition 0 (structure probe, kernel
-    # verification, hipGraph capture) is untimed; the rate is the median repetition
-    times, losses, its = [], [], []
-    for rep in range(reps + 1):
-        graph.nodes.data.copy_(init.tensor())
-        if hasattr(opt, "loss"):
-            del opt.loss
-        opt.param_groups[0].update(opt.strategy.defaults)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        losses, its = [], []
-        for _ in range(steps):
-            losses.append(opt.step((e, rel)))
-            its.append(solver.iterations)
-        torch.cuda.synchronize()
-        if rep:
-            times.append((time.perf_counter() - t0) / steps)
-    dt = sorted(times)[len(times) // 2]
-    out = {"metric": "LM iters/sec (PGO 10k poses)", "value": 1.0 / dt, "unit": "LM steps/s", "nodes": nodes, "edges": edges,
-           "path": opt.linearization, "initial_loss": l0, "losses": [float(l) for l in losses], "pcg_iterations": its,
-           "steps_per_repetition": steps, "repetitions_ms_per_step": [round(t * 1e3, 3) for t in times]}
-    # the same with LM(static=True): the caller's promise that the model's residual program does not change between
-    # steps lets the optimizer skip re-deriving it from a traced forward (reported separately; `value` is the default)
-    opt2 = pp.optim.LM(PoseGraph(init.clone()), solver=pp.optim.solver.PCG(tol=1e-4, maxiter=250),
-                       strategy=pp.optim.strategy.TrustRegion(radius=1e4), static=True)
-    g2, times2 = opt2.model.model, []
-    for rep in range(reps + 1):
-        g2.nodes.data.copy_(init.tensor())
-        if hasattr(opt2, "loss"):
-            del opt2.loss
-        opt2.param_groups[0].update(opt2.strategy.defaults)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            last = opt2.step((e, rel))
-        torch.cuda.synchronize()
-        if rep:
-            times2.append((time.perf_counter() - t0) / steps)
-    out["static_model_value"] = 1.0 / sorted(times2)[len(times2) // 2]
-    out["static_model_final_loss"] = float(last)
-    return out
+    return e, rel, init
 
 
-def pgo_sharded_lm_rate(dev, rank, world, nodes=100_000, edges=400_000, steps=3, reps=3):
-    """BASELINE configs[3]: pose-graph LM, 100k SE3 nodes / 400k relative-pose edges, the EDGES sharded over the
-    ranks (rank r owns edges r::world, nodes replicated) -- `LM(group=...)`, SURVEY.md section 8(e).  Each rank
-    linearises its edges; the per-edge blocks are all-gathered once per LM step and every rank assembles J^T J / J^T r
-    and solves (no collective inside the PCG) while the blocks fit one GPU, else diag / gradient are all-reduced per
-    step and J^T J p per PCG iteration (RCCL over xGMI); the loss is a one-number all-reduce per trial.  Same generator, solver and strategy as
-    `pgo_lm_rate`.  Collective: every rank calls this; rank 0's figures are reported.  Not part of `value`."""
+def _pose_graph_model(init):
     import torch
-    import torch.distributed as dist
     import pypose_amd as pp
 
-    class PoseGraph(torch.nn.Module):
+    class PoseGraph(torch.nn.Module):           # the reference's own model, examples/module/pgo/pgo.py:15-25
         def __init__(self, init):
             super().__init__()
             self.nodes = pp.Parameter(init)
@@ -160,53 +160,71 @@ def pgo_sharded_lm_rate(dev, rank, world, nodes=100_000, edges=400_000, steps=3,
         def forward(self, e, poses):
             n1, n2 = self.nodes[e[..., 0]], self.nodes[e[..., 1]]
             return (poses.Inv() @ n1.Inv() @ n2).Log().tensor()
+    return PoseGraph(init)
 
-    g = torch.Generator().manual_seed(0)
-    torch.manual_seed(0)
-    gt = pp.cumprod(pp.randn_SE3(nodes, sigma=0.3, device=dev), dim=0, left=False)
-    chain = torch.stack([torch.arange(nodes - 1), torch.arange(1, nodes)], -1)
-    extra = torch.randint(0, nodes, (edges - (nodes - 1), 2), generator=g)
-    extra[:, 1] = torch.where(extra[:, 0] == extra[:, 1], (extra[:, 1] + 1) % nodes, extra[:, 1])
-    e = torch.cat([chain, extra], 0).to(dev)
-    rel = (gt[e[:, 0]].Inv() @ gt[e[:, 1]] @ pp.randn_SE3(edges, sigma=0.01, device=dev)).tensor().contiguous()
-    init = (gt @ pp.randn_SE3(nodes, sigma=0.05, device=dev)).tensor().contiguous()
-    for t in (e, rel, init):                      # one problem on every rank, whatever the device RNGs produced
-        dist.broadcast(t, src=0)
-    e_mine, rel_mine = e[rank::world].contiguous(), pp.SE3(rel[rank::world].contiguous())
-    graph = PoseGraph(pp.SE3(init.clone()))
-    solver = pp.optim.solver.PCG(tol=1e-4, maxiter=250)
-    opt = pp.optim.LM(graph, solver=solver, strategy=pp.optim.strategy.TrustRegion(radius=1e4), group=dist.group.WORLD)
-    times, losses, its = [], [], []
-    for rep in range(reps + 1):                   # repetition 0 (structure probe, kernel verification) is untimed
-        graph.nodes.data.copy_(init)
-        if hasattr(opt, "loss"):
-            del opt.loss
-        opt.param_groups[0].update(opt.strategy.defaults)
+
+def _sync(dev):
+    import torch
+    if dev.type == "cuda":
         torch.cuda.synchronize()
-        dist.barrier()
-        t0 = time.perf_counter()
-        losses, its = [], []
-        for _ in range(steps):
-            losses.append(float(opt.step((e_mine, rel_mine))))
-            its.append(solver.iterations)
-        torch.cuda.synchronize()
-        if rep:
-            times.append((time.perf_counter() - t0) / steps)
-    dt = sorted(times)[len(times) // 2]
-    return {"metric": "LM iters/sec, pose graph 100k nodes / 400k edges, edges sharded over the ranks (BASELINE configs[3])",
-            "value": 1.0 / dt, "unit": "LM steps/s", "n_gpus": world, "nodes": nodes, "edges": edges,
-            "edges_per_rank": int(e_mine.shape[0]), "path": opt.linearization, "losses": losses, "pcg_iterations": its,
-            "replicated_solve": bool(getattr(opt, "_last_replicated", False)),
-            "collectives_per_step": ("all-gather of the per-edge residuals / Jacobian blocks / indices (E*(6+72)*4 B + E*16 B), "
-                                     "loss scalar per trial, broadcast of the nodes" if getattr(opt, "_last_replicated", False) else
-                                     "1 all-reduce of N*(36+6) floats + 1 of N*6 floats per PCG iteration + scalars"),
-            "repetitions_ms_per_step": [round(t * 1e3, 3) for t in times]}
 
 
-def invnet_lm_rate(dev, B=1_000_000, steps=3, reps=5):
-    """BASELINE configs[2]: LM on the reference's README InvNet, B independent SE3 problems, fp32
-    (SURVEY.md section 8d C3).  Each repetition restarts from the same random initial poses and takes `steps`
-    LM steps (the problem converges in 2-3); LM steps/s over the best repetition.  Not part of `value`."""
+def pgo_lm_rate(dev, nodes=10_000, edges=40_000, steps=3, reps=5, with_static=True):
+    """Second half of BASELINE.json's metric: LM iterations/s on a synthetic pose graph (PCG tol 1e-4 / maxiter 250 as
+    examples/module/ba, TrustRegion(radius=1e4) as pgo.py:67).  Every repetition restarts from the same initial estimate
+    and takes the `steps` LM steps that do the actual descent (this problem reaches its noise floor in 3-4); repetition 0
+    (structure probe, kernel verification, hipGraph capture) is untimed; the rate is the median repetition."""
+    import pypose_amd as pp
+    e, rel, init = _pose_graph_problem(dev, nodes, edges)
+
+    def run(static):
+        graph = _pose_graph_model(init.clone())
+        solver = pp.optim.solver.PCG(tol=1e-4, maxiter=250)
+        opt = pp.optim.LM(graph, solver=solver, strategy=pp.optim.strategy.TrustRegion(radius=1e4), static=static)
+        times, losses, its = [], [], []
+        for rep in range(reps + 1):
+            graph.nodes.data.copy_(init.tensor())
+            if hasattr(opt, "loss"):
+                del opt.loss
+            opt.param_groups[0].update(opt.strategy.defaults)
+            _sync(dev)
+            t0 = time.perf_counter()
+            losses, its = [], []
+            for _ in range(steps):
+                losses.append(opt.step((e, rel)))
+                its.append(solver.iterations)
+            _sync(dev)
+            if rep:
+                times.append((time.perf_counter() - t0) / steps)
+        return opt, sorted(times)[len(times) // 2], times, [float(l) for l in losses], its
+
+    graph0 = _pose_graph_model(init.clone())
+    l0 = float(graph0(e, rel).detach().square().sum())
+    opt, dt, times, losses, its = run(False)
+    # SURVEY 8(d) C4: one PCG iteration streams ~400 B / edge (J^T J blocks + indices + vectors), the linearisation 388 B / edge
+    # + 168 B / node; the whole-step figure below bills every iteration and the linearisation to the measured step time
+    it_bytes = 400.0 * edges
+    step_bytes = sum(its) / len(its) * it_bytes + 388.0 * edges + 168.0 * nodes
+    out = {"metric": f"LM iters/sec (PGO {nodes} poses / {edges} edges)", "value": 1.0 / dt, "unit": "LM steps/s", "nodes": nodes,
+           "edges": edges, "path": opt.linearization, "initial_loss": l0, "losses": losses, "pcg_iterations": its,
+           "steps_per_repetition": steps, "repetitions_ms_per_step": [round(t * 1e3, 3) for t in times],
+           "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBPS, "achieved": step_bytes / dt / 1e9,
+                        "frac": step_bytes / dt / 1e9 / HBM_PEAK_GBPS,
+                        "algorithmic_bytes_per_step": step_bytes, "per": "LM step (linearise + mean PCG iterations x 400 B/edge)"}}
+    if with_static:
+        # LM(static=True): the caller's promise that the residual program does not change between steps
+        opt2, dt2, _, losses2, _ = run(True)
+        out["static_model_value"] = 1.0 / dt2
+        out["static_model_final_loss"] = losses2[-1]
+    return out
+
+
+def invnet_lm_rate(dev, B=1_000_000, steps=3, reps=40, group=None):
+    """BASELINE configs[2]: LM on the reference's README InvNet, B independent SE3 problems (per rank), fp32
+    (SURVEY.md section 8d C3).  A repetition restarts from the same random poses and takes `steps` LM steps (the problem
+    converges in 2-3; later steps sit at the rounding floor where every trial is a coin-flip rejection).  The step is
+    asynchronous -- loop state and decisions live on the device -- so `reps` repetitions are enqueued back to back and
+    timed with ONE synchronisation at the end; the 28 MB pose reset per repetition is inside the timed region."""
     import torch
     import pypose_amd as pp
 
@@ -218,44 +236,184 @@ def invnet_lm_rate(dev, B=1_000_000, steps=3, reps=5):
         def forward(self, input):
             return (self.pose @ input).Log().tensor()
 
-    torch.manual_seed(0)
+    torch.manual_seed(0 if group is None else 1 + torch.distributed.get_rank())
     init = pp.randn_SE3(B, device=dev)
     inp = pp.randn_SE3(B, device=dev)
     net = InvNet(init.clone())
-    opt = pp.optim.LM(net, strategy=pp.optim.strategy.Constant(damping=1e-4))
+    opt = pp.optim.LM(net, strategy=pp.optim.strategy.Constant(damping=1e-4), group=group)
     l0 = float(net(inp).detach().square().sum())
-    best, loss = float("inf"), None
-    for rep in range(reps + 1):                               # repetition 0 = structure probe / verification, untimed
+
+    def reset():
         net.pose.data.copy_(init.tensor())
         if hasattr(opt, "loss"):
             del opt.loss
-        torch.cuda.synchronize()
+
+    def run(n):
+        for _ in range(n):
+            reset()
+            for _ in range(steps):
+                loss = opt.step(inp)
+        return loss
+
+    run(2)                                                    # structure probe / verification, untimed
+    _sync(dev)
+    best, sync_best, loss = float("inf"), float("inf"), None
+    for _ in range(3):
+        if group is not None:
+            torch.distributed.barrier()
+        _sync(dev)
+        t0 = time.perf_counter()
+        loss = run(reps)
+        _sync(dev)
+        best = min(best, (time.perf_counter() - t0) / (reps * steps))
+    for _ in range(3):                                        # the round-1 protocol: synchronise after every repetition
+        reset()
+        _sync(dev)
         t0 = time.perf_counter()
         for _ in range(steps):
             loss = opt.step(inp)
-        torch.cuda.synchronize()
-        if rep:
-            best = min(best, (time.perf_counter() - t0) / steps)
-    out = {"metric": "LM iters/sec (InvNet SE3, 1M independent problems)", "value": 1.0 / best, "unit": "LM steps/s",
-           "problems": B, "problem_steps_per_s": B / best, "path": opt.linearization, "initial_loss": l0,
-           "final_loss": float(loss), "algorithmic_bytes_per_problem_step": 84,
-           "hbm_fraction_of_8TBps": 84.0 * B / best / 8e12}
-    net2 = InvNet(init.clone())                                # LM(static=True): see pgo_lm_rate
-    opt2 = pp.optim.LM(net2, strategy=pp.optim.strategy.Constant(damping=1e-4), static=True)
-    best2 = float("inf")
-    for rep in range(reps + 1):
-        net2.pose.data.copy_(init.tensor())
-        if hasattr(opt2, "loss"):
-            del opt2.loss
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            opt2.step(inp)
-        torch.cuda.synchronize()
-        if rep:
-            best2 = min(best2, (time.perf_counter() - t0) / steps)
-    out["static_model_value"] = 1.0 / best2
+        _sync(dev)
+        sync_best = min(sync_best, (time.perf_counter() - t0) / steps)
+    world = 1 if group is None else torch.distributed.get_world_size(group)
+    ach = 84.0 * B / best / 1e9
+    return {"metric": "LM iters/sec (InvNet SE3, 1M independent problems per GPU)", "value": 1.0 / best, "unit": "LM steps/s",
+            "problems_per_gpu": B, "n_gpus": world, "problem_steps_per_s": world * B / best, "path": opt.linearization,
+            "initial_loss": l0, "final_loss": float(loss), "steps_per_repetition": steps, "repetitions_in_flight": reps,
+            "value_with_a_sync_per_repetition": 1.0 / sync_best,
+            "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBPS, "achieved": ach, "frac": ach / HBM_PEAK_GBPS,
+                         "algorithmic_bytes_per_step": 84 * B, "per": "LM step per GPU (SURVEY 8d C3: pose 28 r + input 28 r + pose 28 w)",
+                         "kernel": "lm_se3inv_trial2_kernel + lm_se3inv_finish_kernel (pplie_lm_se3inv_step_f32)"}}
+
+
+def imu_rate(dev, B=4096, F=1024, reps=20, inner=4):
+    """BASELINE configs[4]: IMUPreintegrator, B sequences x F steps, fp32, with and without covariance propagation
+    (28 r + 40 w = 68 B / step, + 324 B / sequence for the covariance)."""
+    import torch
+    import pypose_amd as pp
+    torch.manual_seed(0)
+    dt = torch.full((B, F, 1), 0.005, device=dev)
+    gyro = 0.1 * torch.randn(B, F, 3, device=dev)
+    acc = torch.randn(B, F, 3, device=dev) + torch.tensor([0., 0., 9.81], device=dev)
+    out = {"metric": "IMU pre-integration steps/s", "sequences": B, "steps": F, "unit": "steps/s"}
+    for cov in (False, True):
+        integ = pp.module.IMUPreintegrator(prop_cov=cov, reset=True).to(dev)
+        f = lambda: integ(dt=dt, gyro=gyro, acc=acc)
+        f()
+        _sync(dev)
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            for _ in range(inner):
+                f()
+            _sync(dev)
+            ts.append((time.perf_counter() - t0) / inner)
+        t = sorted(ts)[len(ts) // 2]
+        nbytes = 68.0 * B * F + (324.0 * B if cov else 0.0)
+        out["with_covariance" if cov else "states_only"] = {
+            "value": B * F / t, "ms": t * 1e3,
+            "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBPS, "achieved": nbytes / t / 1e9,
+                         "frac": nbytes / t / 1e9 / HBM_PEAK_GBPS, "algorithmic_bytes_per_launch": nbytes,
+                         "per": "module forward (68 B / step" + (" + 324 B / sequence)" if cov else ")")}}
+    out["value"] = out["with_covariance"]["value"]
     return out
+
+
+def c1_latency(dev, B=1024):
+    """BASELINE configs[0]: pp.randn_se3(1024).Exp().Log() forward + backward -- here the wall time of that call chain on
+    the GPU (4 kernels; launch-latency bound at this size).  Bytes: 256 B / row forward + backward."""
+    import torch
+    import pypose_amd as pp
+    torch.manual_seed(0)
+    x = pp.randn_se3(B, device=dev, requires_grad=True)
+
+    def fwd_bwd():
+        x.grad = None
+        x.Exp().Log().tensor().sum().backward()
+
+    def fwd():
+        with torch.no_grad():
+            return x.Exp().Log()
+    out = {"metric": "configs[0]: randn_se3(1024).Exp().Log() forward + backward", "B": B, "unit": "us per call chain"}
+    for name, f in (("fwd_us", fwd), ("fwd_bwd_us", fwd_bwd)):
+        for _ in range(20):
+            f()
+        _sync(dev)
+        t = time.perf_counter()
+        for _ in range(200):
+            f()
+        _sync(dev)
+        out[name] = (time.perf_counter() - t) / 200 * 1e6
+    out["value"] = out["fwd_bwd_us"]
+    out["roofline"] = {"bound": "launch latency", "note": "1024 rows x 256 B = 0.26 MB per call chain: 33 ns at the HBM peak; "
+                       "the figure is host dispatch + 4 dependent launches"}
+    return out
+
+
+def imu_sharded_rate(dev, rank, world, B=4096, F=1024):
+    """configs[4] with the SEQUENCES sharded: every rank integrates its own B sequences, no collective."""
+    import torch
+    import torch.distributed as dist
+    r = imu_rate(dev, B, F, reps=8)
+    t = torch.tensor([r["with_covariance"]["ms"], r["states_only"]["ms"]], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    ms_cov, ms_plain = t.tolist()
+    return {"metric": "IMU pre-integration steps/s, sequences sharded over the ranks (no collective)", "unit": "steps/s", "n_gpus": world,
+            "sequences_per_gpu": B, "steps": F, "value": world * B * F / (ms_cov * 1e-3), "states_only_value": world * B * F / (ms_plain * 1e-3),
+            "ms_max_over_ranks": {"with_covariance": ms_cov, "states_only": ms_plain}}
+
+
+def pgo_sharded_lm_rate(dev, rank, world, nodes=100_000, edges=400_000, steps=3, reps=3):
+    """BASELINE configs[3]: pose-graph LM, 100k SE3 nodes / 400k relative-pose edges, sharded over the ranks --
+    `LM(group=...)`, SURVEY.md section 8(e).  Same generator, solver and strategy as `pgo_lm_rate`.  Collective: every rank
+    calls this; rank 0's figures are reported.  Not part of `value`."""
+    import torch
+    import torch.distributed as dist
+    import pypose_amd as pp
+    e, rel, init = _pose_graph_problem(dev, nodes, edges)
+    rel, init = rel.tensor().contiguous(), init.tensor().contiguous()
+    for t in (e, rel, init):                      # one problem on every rank, whatever the device RNGs produced
+        dist.broadcast(t, src=0)
+    e_mine, rel_mine = e[rank::world].contiguous(), pp.SE3(rel[rank::world].contiguous())
+    graph = _pose_graph_model(pp.SE3(init.clone()))
+    solver = pp.optim.solver.PCG(tol=1e-4, maxiter=250)
+    opt = pp.optim.LM(graph, solver=solver, strategy=pp.optim.strategy.TrustRegion(radius=1e4), group=dist.group.WORLD)
+    times, losses, its = [], [], []
+    for rep in range(reps + 1):                   # repetition 0 (structure probe, kernel verification) is untimed
+        graph.nodes.data.copy_(init)
+        if hasattr(opt, "loss"):
+            del opt.loss
+        opt.param_groups[0].update(opt.strategy.defaults)
+        _sync(dev)
+        dist.barrier()
+        t0 = time.perf_counter()
+        losses, its = [], []
+        for _ in range(steps):
+            losses.append(float(opt.step((e_mine, rel_mine))))
+            its.append(solver.iterations)
+        _sync(dev)
+        if rep:
+            times.append((time.perf_counter() - t0) / steps)
+    dt = sorted(times)[len(times) // 2]
+    return {"metric": "LM iters/sec, pose graph 100k nodes / 400k edges sharded over the ranks (BASELINE configs[3])",
+            "value": 1.0 / dt, "unit": "LM steps/s", "n_gpus": world, "nodes": nodes, "edges": edges,
+            "edges_per_rank": int(e_mine.shape[0]), "path": opt.linearization, "losses": losses, "pcg_iterations": its,
+            "mode": getattr(opt, "_last_shard_mode", "replicated" if getattr(opt, "_last_replicated", False) else "edge-sharded"),
+            "repetitions_ms_per_step": [round(t * 1e3, 3) for t in times]}
+
+
+# ---------------------------------------------------------------------------------------------------------------
+def _self_launch(a):
+    """`python bench.py --gpus N` with N > 1 and no launcher: re-execute under torch.distributed.run, one process per GPU."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["PPLIE_BENCH_SELF_LAUNCHED"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    os.execvpe(sys.executable, cmd, env)
 
 
 def main():
@@ -265,27 +423,44 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--rows", type=int, default=10_000_000, help="rows per GPU (BASELINE configs[1]: 10M)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-secondary", action="store_true", help="skip lm_pgo / lm_invnet (clean rocprof kernel statistics)")
+    ap.add_argument("--no-secondary", action="store_true", help="headline only (clean rocprof kernel statistics)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo + --standin: CPU dry run of the multi-process plumbing (tests/test_bench_launch.py)")
+    ap.add_argument("--standin", action="store_true",
+                    help="TEST ONLY: run on CPU tensors with the oracle stand-in of the HIP library (tests/oracle_backend.py); "
+                         "nothing it prints is a measurement")
     a = ap.parse_args()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        _self_launch(a)
     import torch
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     launched = "WORLD_SIZE" in os.environ and "RANK" in os.environ      # torch.distributed.run (also with one rank)
+    standin = a.standin
+    if standin:
+        assert a.backend == "gloo", "--standin is the CPU dry run: use --backend gloo"
+        from tests.oracle_backend import oracle_row_op
+        from pypose_amd import _C as _C0
+        _C0.set_backend_for_testing(oracle_row_op)
+        dev = torch.device("cpu")
+    else:
+        dev = torch.device("cuda", local)
+        torch.cuda.set_device(dev)
     if launched:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
-    dev = torch.device("cuda", local)
-    torch.cuda.set_device(dev)
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
 
     import pypose_amd as pp
     from pypose_amd import _C
-    assert _C._test_backend is None
+    assert standin or _C._test_backend is None
 
     B = a.rows
     torch.manual_seed(rank)
@@ -297,13 +472,13 @@ def main():
 
     for _ in range(a.warmup):
         y = step()
-    torch.cuda.synchronize()
+    _sync(dev)
 
     # HIP events bracket both kernels on every `EV`-th step of the timed region (default: every step).  Each record is
     # a packet in the stream: on every step they cost ~3% of `value`, but bracketing only some steps makes exactly
     # those launches slower (92-96 us instead of 90 for Log), so the per-kernel figure is taken on all of them
     EV = max(1, int(os.environ.get("PPLIE_BENCH_EVENT_STRIDE", "1")))
-    ev = {k: [torch.cuda.Event(enable_timing=True) for _ in range(3)] for k in range(0, a.steps, EV)}
+    ev = {} if standin else {k: [torch.cuda.Event(enable_timing=True) for _ in range(3)] for k in range(0, a.steps, EV)}
 
     def barrier():
         if launched:
@@ -311,7 +486,7 @@ def main():
             dist.barrier()
 
     barrier()
-    torch.cuda.synchronize()
+    _sync(dev)
     t0 = time.perf_counter()
     for k in range(a.steps):
         e = ev.get(k)
@@ -324,7 +499,7 @@ def main():
             e[1].record()
             y = X.Log()
             e[2].record()
-    torch.cuda.synchronize()
+    _sync(dev)
     barrier()
     elapsed = time.perf_counter() - t0
 
@@ -336,8 +511,11 @@ def main():
 
     out = None
     if rank == 0:
-        ms_exp = sum(e[0].elapsed_time(e[1]) for e in ev.values()) / len(ev)
-        ms_log = sum(e[1].elapsed_time(e[2]) for e in ev.values()) / len(ev)
+        if ev:
+            ms_exp = sum(e[0].elapsed_time(e[1]) for e in ev.values()) / len(ev)
+            ms_log = sum(e[1].elapsed_time(e[2]) for e in ev.values()) / len(ev)
+        else:
+            ms_exp = ms_log = elapsed / a.steps * 1e3 / 2
         dom, ms_dom = ("se3_log_fwd", ms_log) if ms_log >= ms_exp else ("se3_exp_fwd", ms_exp)
         achieved = B * BYTES_PER_ROW[dom] / (ms_dom * 1e-3) / 1e9
         traffic = None
@@ -349,52 +527,69 @@ def main():
             "value": world * B * a.steps / elapsed,
             "unit": "SE3 Exp+Log pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic" if not standin else "DRY RUN on the CPU stand-in: not a measurement",
             "config": {"workload": "se3_explog_b10m (BASELINE configs[1]: batched SE3 Exp then Log, fp32, forward)",
-                       "rows_per_gpu": B, "parallelism": f"rows sharded x{world}, no collective"},
+                       "rows_per_gpu": B, "parallelism": f"rows sharded x{world}, no collective",
+                       "ranks": world, "collective_backend": (a.backend if launched else None),
+                       "launch": "self-launched torch.distributed.run" if os.environ.get("PPLIE_BENCH_SELF_LAUNCHED") else
+                                 ("torch.distributed.run" if launched else "single process")},
             "roofline": {"bound": "hbm", "kernel": f"rowmap_lds_kernel<{dom}> (pplie_{dom}_f32)",
                          "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": traffic, "algorithmic_bytes_per_launch": B * BYTES_PER_ROW[dom],
                          "avg_launch_ms": ms_dom, "timed_launches": len(ev), "other_kernel_ms": {"se3_exp_fwd": ms_exp, "se3_log_fwd": ms_log}},
         }
-        if world == 1 and not a.no_secondary:
-            import gc
-            gc.collect()
-            gc.freeze()                   # (a gen-2 collection with torch loaded is a 40-70 ms pause)
-            for key, fn in (("lm_pgo", pgo_lm_rate), ("lm_invnet", invnet_lm_rate)):
-                try:
-                    out[key] = fn(dev)
-                except Exception as e:    # never lose the headline line over a secondary figure
-                    out[key] = {"error": repr(e)}
-        if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
-    sharded = launched and not a.no_secondary and (world > 1 or os.environ.get("PPLIE_BENCH_SHARDED_PGO") == "1")
+    import gc
+    gc.collect()
+    gc.freeze()                   # (a gen-2 collection with torch loaded is a 40-70 ms pause)
+    small = standin                # the dry run shrinks every leg: it checks plumbing, not speed
+    if world == 1 and not a.no_secondary and rank == 0:
+        legs = (("c1", lambda: c1_latency(dev)),
+                ("lm_invnet", lambda: invnet_lm_rate(dev, B=2000 if small else 1_000_000, reps=2 if small else 40)),
+                ("lm_pgo", lambda: pgo_lm_rate(dev, *((60, 150) if small else (10_000, 40_000)), reps=1 if small else 5)),
+                ("lm_pgo_100k", lambda: pgo_lm_rate(dev, *((80, 200) if small else (100_000, 400_000)), reps=1 if small else 3,
+                                                    with_static=False)),
+                ("imu", lambda: imu_rate(dev, *((8, 64) if small else (4096, 1024)), reps=2 if small else 20)))
+        for key, fn in legs:
+            try:
+                out[key] = fn()
+            except Exception as e:    # never lose the headline line over a secondary figure
+                out[key] = {"error": repr(e)}
+    if world == 1 and not a.no_cpu_baseline and rank == 0 and not standin:
+        out["cpu_baseline"] = cpu_baseline()
+    sharded = launched and not a.no_secondary and (world > 1 or os.environ.get("PPLIE_BENCH_SHARDED") == "1")
     if sharded:
         # every rank takes part; a watchdog keeps the headline line if a collective wedges (nothing in the timed
         # region above depends on this)
         import threading
+        import torch.distributed as dist
         finished, printed = threading.Event(), threading.Lock()
 
-        def emit(extra):
+        def emit():
             if printed.acquire(blocking=False) and rank == 0:
-                out["lm_pgo_sharded"] = extra
                 print(json.dumps(out), flush=True)
 
         def watchdog():
-            if not finished.wait(float(os.environ.get("PPLIE_BENCH_SHARDED_TIMEOUT", "120"))):
-                emit({"error": "timed out"})
+            if not finished.wait(float(os.environ.get("PPLIE_BENCH_SHARDED_TIMEOUT", "240"))):
+                if rank == 0:
+                    out["sharded_legs"] = "timed out"
+                emit()
                 os._exit(0)
 
         threading.Thread(target=watchdog, daemon=True).start()
-        try:
-            import gc
-            gc.collect()
-            gc.freeze()                   # (a gen-2 collection with torch loaded is a 40-70 ms pause)
-            extra = pgo_sharded_lm_rate(dev, rank, world)
-        except Exception as e:
-            extra = {"error": repr(e)}
+        legs = (("lm_invnet_sharded", lambda: invnet_lm_rate(dev, B=2000 if small else 1_000_000, reps=2 if small else 40,
+                                                             group=dist.group.WORLD)),
+                ("imu_sharded", lambda: imu_sharded_rate(dev, rank, world, *((8, 64) if small else (4096, 1024)))),
+                ("lm_pgo_sharded", lambda: pgo_sharded_lm_rate(dev, rank, world, *((80, 200) if small else (100_000, 400_000)),
+                                                               reps=1 if small else 3)))
+        for key, fn in legs:
+            try:
+                res = fn()
+            except Exception as e:
+                res = {"error": repr(e)}
+            if rank == 0:
+                out[key] = res
         finished.set()
-        emit(extra)
+        emit()
     elif rank == 0:
         print(json.dumps(out), flush=True)
     if launched:

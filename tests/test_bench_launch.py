@@ -1,0 +1,43 @@
+"""bench.py's multi-process plumbing on the CPU: `python bench.py --gpus 2` launches itself (torch.distributed.run, one
+process per rank, gloo), runs the headline and every sharded leg on the oracle stand-in, and prints one JSON line.
+Nothing it prints is a measurement; this checks that the N > 1 command the driver runs cannot die in the plumbing."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args, env_extra=None, timeout=600):
+    env = dict(os.environ, PYTHONPATH=ROOT, OMP_NUM_THREADS="1")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True, env=env, timeout=timeout,
+                       cwd=ROOT)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, (r.returncode, r.stdout[-2000:], r.stderr[-3000:])
+    return json.loads(lines[0])
+
+
+def test_two_ranks_self_launched_dry_run():
+    out = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--rows", "1000", "--backend", "gloo", "--standin"])
+    assert out["n_gpus"] == 2 and out["config"]["ranks"] == 2 and out["config"]["collective_backend"] == "gloo"
+    assert out["config"]["launch"].startswith("self-launched")
+    assert out["value"] > 0 and out["scaling"] == "weak"
+    for leg in ("lm_invnet_sharded", "imu_sharded", "lm_pgo_sharded"):
+        assert "error" not in out[leg], (leg, out[leg])
+        assert out[leg]["n_gpus"] == 2 and out[leg]["value"] > 0
+    assert out["lm_pgo_sharded"]["losses"][-1] < out["lm_pgo_sharded"]["losses"][0]
+
+
+def test_single_process_dry_run_has_every_config():
+    out = _run(["--gpus", "1", "--steps", "2", "--warmup", "1", "--rows", "1000", "--backend", "gloo", "--standin"])
+    assert out["n_gpus"] == 1 and out["config"]["launch"] == "single process"
+    for leg in ("c1", "lm_invnet", "lm_pgo", "lm_pgo_100k", "imu"):
+        assert "error" not in out[leg], (leg, out[leg])
+    assert out["lm_invnet"]["roofline"]["algorithmic_bytes_per_step"] == 84 * out["lm_invnet"]["problems_per_gpu"]
+    assert set(out["imu"]) >= {"states_only", "with_covariance"}
