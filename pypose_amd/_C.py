@@ -119,6 +119,14 @@ class _on_device:
             self.ctx.__exit__(*exc)
 
 
+def mark_written(t):
+    """Bump the version counter of a tensor a kernel has just written through its raw pointer.  Autograd detects in-place
+    modification of tensors saved for backward by comparing version counters; a raw-pointer write that skipped this
+    would turn "one of the variables needed for gradient computation has been modified" into silently wrong gradients."""
+    if _test_backend is None:          # (the stand-in writes with copy_, which already bumps it)
+        torch.autograd.graph.increment_version(t)
+
+
 def row_op(name: str, ins, out_widths, out=None):
     """Launch ``pplie_<name>_{f32,f64}`` on contiguous ``[N, W]`` inputs.
 

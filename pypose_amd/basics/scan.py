@@ -36,4 +36,5 @@ def try_scan_(input, dim, left):
     with torch.cuda.device(input.device):
         code = fn(input.data_ptr(), outer * inner, L, inner, 1 if left else 0, _C.stream_ptr(input.device))
     _C.check(code, f"pplie_scan_{key}")
+    _C.mark_written(input)                # the scan wrote through the raw pointer
     return input

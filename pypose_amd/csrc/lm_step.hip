@@ -37,6 +37,7 @@
 //   J d = [Ji (d_tau - N d_phi), Ji d_phi]
 #include "rowmap.h"
 #include "chol.h"
+#include "gridsync.h"
 
 namespace pplie {
 
@@ -466,26 +467,6 @@ __global__ void lm_decide_kernel(const double* st_in, double* st_out, LmCfg cfg,
     lm_decide(st_in, o, cfg, first != 0, (double)sums[0], (double)sums[1], (double)sums[2], (double)sums[3]);
     lm_store_state<T>(o, st_out, loss_out, last_out);
   }
-}
-
-// sense-reversing grid barrier; needs every workgroup of the launch resident (grid <= CUs x occupancy)
-__device__ __forceinline__ void grid_barrier(unsigned* count, unsigned* gen) {
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const unsigned g = __hip_atomic_load(gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __threadfence();
-    if (atomicAdd(count, 1u) == gridDim.x - 1) {
-      __hip_atomic_store(count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __threadfence();
-      __hip_atomic_fetch_add(gen, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-      // bounded: a workgroup that never arrives (an over-subscribed launch) must not wedge the GPU; ~1 s
-      for (long spin = 0; spin < (1L << 24) && __hip_atomic_load(gen, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == g; ++spin)
-        __builtin_amdgcn_s_sleep(8);
-    }
-    __threadfence();
-  }
-  __syncthreads();
 }
 
 // Everything after the first trial of a step.  EVERY workgroup adds up the trial kernel's partial sums (same rows, same

@@ -129,8 +129,9 @@ template <class A> struct SameType<A, A> { static constexpr bool v = true; };
 
 template <class T, class Op, int RPT, int BLOCK, bool VEC, bool ROLL = false, class Prm = NoParam>
 __global__ void __launch_bounds__(BLOCK)
-rowmap_lds_kernel(const T* __restrict__ i0, const T* __restrict__ i1, const T* __restrict__ i2,
-                  T* __restrict__ o0, T* __restrict__ o1, int64_t n, Prm prm = Prm()) {
+rowmap_lds_kernel(const T* i0, const T* i1, const T* i2, T* o0, T* o1, int64_t n, Prm prm = Prm()) {
+  // (no __restrict__: an output may be the buffer of an input -- the optimizer's in-place retraction -- and every tile is
+  //  in LDS before any of its rows is written back)
   constexpr int TILE = RPT * BLOCK;
   constexpr int IW0 = Op::IW0, IW1 = Op::IW1, IW2 = Op::IW2, OW0 = Op::OW0, OW1 = Op::OW1;
   constexpr int OFF_I1 = TILE * IW0, OFF_I2 = OFF_I1 + TILE * IW1, OFF_O0 = OFF_I2 + TILE * IW2,

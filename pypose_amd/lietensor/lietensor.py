@@ -180,6 +180,7 @@ class LieType:
             if x.is_contiguous() and raw.is_contiguous() and not _op._op_tracers:
                 xr = x.detach().view(-1, w)
                 _C.row_op(self._key + "_retract", [raw.detach().view(-1, w), xr], (w,), out=[xr])
+                _C.mark_written(input)            # the kernel wrote through the raw pointer: autograd must see the in-place edit
                 return input
             out = _op._launch(self._key + "_retract", (raw.detach(), x.detach()), (w,) * 2, (w,))[0]
             with torch.no_grad():

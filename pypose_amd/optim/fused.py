@@ -116,6 +116,8 @@ class Se3InvLinearization:
                       pt.data_ptr(), self.X.data_ptr(), out.data_ptr(), D.data_ptr(), part.data_ptr(),
                       scale, self.dmin, self.dmax, self.n, _C.stream_ptr(pt.device))
         _C.check(code, "pplie_lm_se3inv_trial")
+        if out is pt:
+            _C.mark_written(self.P)
         if rbuf is not None:
             self.R = rbuf                            # retries of this step linearise at the same point
         return D, part.sum(0)
@@ -359,7 +361,7 @@ class DeviceLM:
             self.cur = 1 - self.cur
         else:
             self._sharded(st_in, st_out, loss_ptr, last_ptr, stream)
-        torch.autograd.graph.increment_version(self.P)       # P was rewritten through its raw pointer
+        _C.mark_written(self.P)                              # P was rewritten through its raw pointer
         self.host_dirty, self.pending = False, True
         opt.loss = self.last_loss = self.loss_views[k]
         opt._last_view = self.last_views[k]
@@ -476,6 +478,9 @@ class PgoProgram:
             self.idx = hit[2]
         else:
             self.idx = torch.stack([idx0, idx1], dim=-1).contiguous()
+            # gather indices may be negative (nodes[-1] is the last node, as in torch indexing and the reference's dense
+            # path): the kernels address rows directly, so they are normalised once per edge list
+            self.idx = torch.where(self.idx < 0, self.idx + P.shape[0], self.idx)
             if cache is not None:
                 cache["pgo_idx"] = ((idx0, idx1), (idx0._version, idx1._version), self.idx)
         self.Z = Z.detach().reshape(-1, 7).contiguous()
@@ -526,12 +531,17 @@ def try_fused(opt, pg, input, target, weight, cache):
     # strategy sees the real J, D, R of the block linearisation instead
     from .strategy import Adaptive, Constant, TrustRegion
     builtin = type(opt.strategy) in (Constant, Adaptive, TrustRegion)
-    if getattr(opt, 'static', False) and cache.get("fused") is True:
-        # LM(static=True): the caller promises that the model's residual program and its non-parameter operands do
-        # not change between step() calls with the same ``input`` object -- the verified program of the previous
-        # step is evaluated directly, without running the model again to re-derive it
-        hit = cache.get("program")
-        if hit is not None and _same_input(hit[0], input) and hit[1] is P:
+    hit = cache.get("program")
+    if cache.get("fused") is True and hit is not None and _same_input(hit[0], input) and hit[1] is P:
+        # The verified program of the previous step is evaluated directly, without running the model again to re-derive
+        # it, while nothing it was derived from has changed: the same `input` object(s), every operand tensor at the
+        # same address with the same version counter (an in-place edit bumps it).  The model's own code could still
+        # change behaviour without touching a tensor, so the forward is traced again every _RETRACE steps;
+        # LM(static=True) is the caller's promise that it does not (never re-traced).
+        static = getattr(opt, 'static', False)
+        fresh = static or (hit[5][0] > 0 and all(t.data_ptr() == ptr and t._version == ver for t, ptr, ver in hit[4]))
+        if fresh:
+            hit[5][0] -= 1
             kind, operands = hit[2], hit[3]
             if kind == "se3inv" and weight is None and trivial and solver_ok and builtin:
                 return Se3InvLinearization(opt, P, operands, None, input)
@@ -541,15 +551,20 @@ def try_fused(opt, pg, input, target, weight, cache):
         R = list(opt.model(input, target))
     m = match_se3inv(tr, R, params) if not rec.events else None
     if m is not None and weight is None and trivial and solver_ok and builtin:
-        cache["program"] = (input, P, "se3inv", m[1])
+        cache["program"] = (input, P, "se3inv", m[1], _sources(m[1]), [0])     # (DeviceLM.try_step is this program's shortcut)
         return Se3InvLinearization(opt, *m, input)
     m = match_pgo(tr, rec.events, R, params)
     if m is not None and len(opt.corrector) == 1:
         prog = PgoProgram(*m, cache=cache)
-        cache["program"] = (input, P, "pgo", prog)
+        cache["program"] = (input, P, "pgo", prog, _sources(*m[1:]), [_RETRACE])
         return _pgo_linearization(opt, prog, weight, P, trivial)
     cache["fused"] = False
     return None
+
+
+def _sources(*tensors):
+    """(tensor, address, version) of the operands a program was matched on"""
+    return [(t, t.data_ptr(), t._version) for t in tensors]
 
 
 def _same_input(a, b):

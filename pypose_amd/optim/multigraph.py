@@ -565,7 +565,9 @@ def try_multigraph_linearization(opt, pg, input, target, weight, R, params, rec,
     if weight is not None and len(R) > 1 and not (isinstance(weight, (tuple, list)) and len(weight) == len(R)):
         return None
     pos = {id(p): k for k, p in enumerate(params)}
-    events = [(src, ix, out) for src, ix, out in rec.events if id(src) in pos and src.dim() == 2
+    # (gather indices may be negative, as in torch indexing and the reference's dense path: every scatter / segment sum /
+    #  kernel below addresses rows directly, so they are normalised here, once)
+    events = [(src, torch.where(ix < 0, ix + src.shape[0], ix), out) for src, ix, out in rec.events if id(src) in pos and src.dim() == 2
               and out.numel() == ix.numel() * src.shape[-1]]
     if not events or len(events) != len(rec.events) or {id(s) for s, _, _ in events} != set(pos):
         cache[key] = False

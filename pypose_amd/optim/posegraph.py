@@ -45,6 +45,13 @@ _BSR_SIG = [ctypes.c_void_p] * 8 + [ctypes.c_int64, ctypes.c_int, ctypes.c_void_
 _PCG_SCAL_ELEMS = 2 * 8 * 32 * 32          # PPLIE_PCG2_SCAL_ELEMS (covers PPLIE_PCG_SCAL_ELEMS): slot-spread scalars (csrc/graph.hip)
 _PCG2_SPMV_SIG = [ctypes.c_void_p] * 11 + [ctypes.c_int, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]
 _PCG2_STEP_SIG = [ctypes.c_void_p] * 9 + [ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]
+_PERSIST_SIG = [ctypes.c_void_p] * 15 + [ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]
+_PERSIST_GRID_MAX = 256     # PPLIE_PCG_PERSIST_GRID
+import os as _os
+# graphs up to this many nodes run the whole PCG solve in ONE persistent launch (csrc/pcg_persist.hip); larger ones need
+# the whole chip's bandwidth per iteration and keep the two-launch hipGraph iteration
+PERSIST_NODES = int(_os.environ.get("PPLIE_PCG_PERSIST_NODES", "32768"))
+PERSIST_GRID = int(_os.environ.get("PPLIE_PCG_PERSIST_GRID", "256"))   # one 1024-lane workgroup per CU: 64 -> 675, 128 -> 788, 256 -> 850 LM steps/s at 10 k nodes
 _INV_SIG = [ctypes.c_void_p] * 2 + [ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]
 _HIP_SHAPES = {(6, 6, 2), (7, 7, 2), (3, 3, 2), (6, 6, 1), (3, 3, 1)}
 _STALL_CHECKS = 64          # plain CG on a singular system: give up after this many checks without a new best residual,
@@ -198,6 +205,7 @@ class FusedPCG:
 
     two_launch = True        # class-level switches (tools/ and tests compare the three-launch / graph-less variants)
     use_graph = True
+    persist = True           # one persistent launch per solve on small graphs (csrc/pcg_persist.hip)
 
     def __init__(self, E, K, dr, m, N, dtype, device, has_w, check_every):
         z = lambda *s: torch.zeros(s, dtype=dtype, device=device)
@@ -213,6 +221,9 @@ class FusedPCG:
         self.cap = 1 << 16
         self.rr_hist = z(self.cap)
         self.it = torch.zeros(2, dtype=torch.int32, device=device)
+        self.part = torch.zeros(2 * _PERSIST_GRID_MAX * 8, dtype=torch.int64, device=device)   # persistent solve: tagged partial sums
+        self.bar = torch.zeros(64 + 32 * 32, dtype=torch.int32, device=device)      # PPLIE_GRID_BAR_WORDS
+        self.info = z(4)
         self.sfx = "_f32" if dtype == torch.float32 else "_f64"
         self.graph = None                                          # captured check_every iterations
         self.bsr = None                                            # which iteration the graph holds
@@ -297,6 +308,19 @@ class FusedPCG:
                 self.z.copy_(self.r)
                 self.p.copy_(self.r)
                 self.scal[0:1024].copy_(self.scal[3 * 1024:4 * 1024])
+            if bsr and self.two_launch and self.persist and not plain and self.N <= PERSIST_NODES:
+                # the whole solve in one launch: iteration, reductions and the convergence test stay on the device
+                maxit = min(maxiter, self.cap)
+                self.part.zero_()                                   # sequence tags restart at 1
+                code = _C.library().symbol("pplie_pcg_persist" + self.sfx, _PERSIST_SIG)(
+                    self.ptr.data_ptr(), self.other.data_ptr(), self.HB.data_ptr(), self.D.data_ptr(), self.Binv.data_ptr(),
+                    self.x.data_ptr(), self.r.data_ptr(), self.p.data_ptr(), self.q.data_ptr(), self.z.data_ptr(),
+                    self.part.data_ptr(), self.bar.data_ptr(), self.rr_hist.data_ptr(), self.info.data_ptr(), self.it.data_ptr(),
+                    float(tol), int(maxit), self.cap, PERSIST_GRID, self.N, self.m, _C.stream_ptr(self.device))
+                _C.check(code, "pplie_pcg_persist")
+                its, rr, bn2, flag = self.info.tolist()             # the solve's one read-back
+                assert flag != 2.0 and rr == rr, 'Linear solve produced NaN (matrix may not be positive-definite)'
+                return self.x.clone(), int(its)
             bn2_slots = self.scal[3 * 1024:4 * 1024:32]             # |b|^2: set 0, quantity 3, 32 slots (csrc/graph.hip)
             bn2 = None
             maxiter = min(maxiter, self.cap - self.check_every)

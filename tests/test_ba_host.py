@@ -202,3 +202,21 @@ def test_gauss_newton_on_bundle_adjustment_keeps_the_reference_algorithm(tag):
         opt = pp.optim.GN(model)
         losses = [float(opt.step(args, weight=weight)) for _ in range(3)]
         np.testing.assert_allclose(losses, G[f"{tag}/loss"], rtol=1e-4)
+
+
+def test_negative_gather_indices_are_accepted_like_the_dense_path(G):
+    """`self.C[cidx]` with -1 for the last camera (valid torch indexing; the reference's dense path accepts it): the
+    structured path must take the same steps as with the equivalent non-negative indices."""
+    with oracle_backend():
+        recs = []
+        for negative in (False, True):
+            model, opt, (obs, cidx, pidx) = ba_case(G, "ba_small")
+            if negative:
+                cidx = torch.where(cidx == model.C.shape[0] - 1, torch.full_like(cidx, -1), cidx)
+                pidx = torch.where(pidx == model.P.shape[0] - 1, torch.full_like(pidx, -1), pidx)
+                assert (cidx < 0).any() and (pidx < 0).any()
+            rec = run_steps(opt, ((obs, cidx, pidx),), {}, 4)
+            assert set(rec["kind"]) == {"multigraph"}
+            recs.append((rec, model.P.detach().clone()))
+        assert recs[0][0]["loss"] == pytest.approx(recs[1][0]["loss"], rel=1e-12)
+        torch.testing.assert_close(recs[0][1], recs[1][1], rtol=0, atol=1e-12)

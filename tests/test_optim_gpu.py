@@ -508,3 +508,22 @@ def test_edge_list_written_in_place_between_steps_is_seen(G):
         ref.step((edges.clone(), poses))
     assert abs(float(opt.loss) - float(ref.loss)) <= 1e-6 * float(ref.loss)
     np.testing.assert_allclose(float(ref.loss), float(fresh(edges, poses).detach().square().sum()), rtol=1e-9)
+
+
+def test_negative_edge_indices_on_the_fused_pose_graph_path(G):
+    """`nodes[edges[..., 0]]` with -1 for the last node: the fused program addresses node rows directly in its kernels,
+    so the indices are normalised once per edge list; same steps as with the equivalent non-negative indices."""
+    edges, poses = T(G["pgo40/edges"], DEV), pp.SE3(T(G["pgo40/poses"], DEV))
+    out = []
+    for negative in (False, True):
+        e = edges.clone()
+        if negative:
+            e = torch.where(e == 39, torch.full_like(e, -1), e)
+            assert (e < 0).any()
+        graph = PoseGraph(pp.SE3(T(G["pgo40/init"], DEV)))
+        opt = pp.optim.LM(graph, solver=pp.optim.solver.Cholesky(), strategy=pp.optim.strategy.TrustRegion(radius=1e4))
+        losses = [float(opt.step((e, poses))) for _ in range(3)]
+        assert opt.linearization == "fused:pgo"
+        out.append((losses, graph.nodes.detach().tensor().clone()))
+    assert out[0][0] == pytest.approx(out[1][0], rel=1e-12)
+    torch.testing.assert_close(out[0][1], out[1][1], rtol=0, atol=1e-12)
