@@ -362,7 +362,7 @@ def imu_sharded_rate(dev, rank, world, B=4096, F=1024):
             "ms_max_over_ranks": {"with_covariance": ms_cov, "states_only": ms_plain}}
 
 
-def pgo_sharded_lm_rate(dev, rank, world, nodes=100_000, edges=400_000, steps=3, reps=3):
+def pgo_sharded_lm_rate(dev, rank, world, nodes=100_000, edges=400_000, steps=3, reps=3, shard="edges"):
     """BASELINE configs[3]: pose-graph LM, 100k SE3 nodes / 400k relative-pose edges, sharded over the ranks --
     `LM(group=...)`, SURVEY.md section 8(e).  Same generator, solver and strategy as `pgo_lm_rate`.  Collective: every rank
     calls this; rank 0's figures are reported.  Not part of `value`."""
@@ -376,7 +376,7 @@ def pgo_sharded_lm_rate(dev, rank, world, nodes=100_000, edges=400_000, steps=3,
     e_mine, rel_mine = e[rank::world].contiguous(), pp.SE3(rel[rank::world].contiguous())
     graph = _pose_graph_model(pp.SE3(init.clone()))
     solver = pp.optim.solver.PCG(tol=1e-4, maxiter=250)
-    opt = pp.optim.LM(graph, solver=solver, strategy=pp.optim.strategy.TrustRegion(radius=1e4), group=dist.group.WORLD)
+    opt = pp.optim.LM(graph, solver=solver, strategy=pp.optim.strategy.TrustRegion(radius=1e4), group=dist.group.WORLD, shard=shard)
     times, losses, its = [], [], []
     for rep in range(reps + 1):                   # repetition 0 (structure probe, kernel verification) is untimed
         graph.nodes.data.copy_(init)
@@ -580,7 +580,9 @@ def main():
                                                              group=dist.group.WORLD)),
                 ("imu_sharded", lambda: imu_sharded_rate(dev, rank, world, *((8, 64) if small else (4096, 1024)))),
                 ("lm_pgo_sharded", lambda: pgo_sharded_lm_rate(dev, rank, world, *((80, 200) if small else (100_000, 400_000)),
-                                                               reps=1 if small else 3)))
+                                                               reps=1 if small else 3)),
+                ("lm_pgo_node_sharded", lambda: pgo_sharded_lm_rate(dev, rank, world, *((80, 200) if small else (100_000, 400_000)),
+                                                                    reps=1 if small else 2, shard="nodes")))
         for key, fn in legs:
             try:
                 res = fn()

@@ -146,6 +146,16 @@ class Se3InvLinearization:
 # ---------------------------------------------------------------------------------------------
 # the LM step with its loop state in device memory (csrc/lm_step.hip)
 # ---------------------------------------------------------------------------------------------
+def _strategy_kind(strategy):
+    """0 / 1 / 2 for exactly the built-in Constant / Adaptive / TrustRegion policies -- of this package or of an
+    activated reference pypose (same class, same module name, same attributes: strategy.py:41, :134, :248) -- else None:
+    the device-side decision implements these three and nothing else (a subclass may override update())."""
+    t = type(strategy)
+    if t.__module__.split(".")[-2:] != ["optim", "strategy"] or t.__module__.split(".")[0] not in ("pypose", "pypose_amd"):
+        return None
+    return {"Constant": 0, "Adaptive": 1, "TrustRegion": 2}.get(t.__name__)
+
+
 class _LmCfg(ctypes.Structure):       # = pplie_lm_cfg (include/pplie.h)
     _fields_ = [(k, ctypes.c_double) for k in ("high", "low", "up", "factor", "smin", "smax", "sdown", "dmin", "dmax",
                                                "host_damping", "host_down")] + \
@@ -243,9 +253,8 @@ class DeviceLM:
     linearisation point (the reference returns there by ``Exp(-d)``, i.e. up to rounding)."""
 
     def __init__(self, opt, P, X_src, input):
-        from .strategy import Adaptive, Constant, TrustRegion
         self.opt, self.P, self.X_src = opt, P, X_src
-        self.kind = {Constant: 0, Adaptive: 1, TrustRegion: 2}[type(opt.strategy)]
+        self.kind = _strategy_kind(opt.strategy)
         self.strategy = opt.strategy
         pt = P.detach()
         self.n = pt.numel() // 7
@@ -529,8 +538,7 @@ def try_fused(opt, pg, input, target, weight, cache):
     solver_ok = (isinstance(opt.solver, Cholesky) and not opt.solver.upper) or isinstance(opt.solver, _pg.PCG)
     # the device-side decision implements exactly the three built-in damping policies; a user-defined or subclassed
     # strategy sees the real J, D, R of the block linearisation instead
-    from .strategy import Adaptive, Constant, TrustRegion
-    builtin = type(opt.strategy) in (Constant, Adaptive, TrustRegion)
+    builtin = _strategy_kind(opt.strategy) is not None
     hit = cache.get("program")
     if cache.get("fused") is True and hit is not None and _same_input(hit[0], input) and hit[1] is P:
         # The verified program of the previous step is evaluated directly, without running the model again to re-derive

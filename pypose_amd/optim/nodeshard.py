@@ -1,0 +1,247 @@
+"""Pose-graph LM with the LINEAR SOLVE sharded over the ranks by node rows (``LM(group=..., shard="nodes")``).
+
+SURVEY.md section 8(e) row 3 / BASELINE configs[3] ("J^T J sharded 8 GPUs via RCCL/xGMI").  The edge-sharded modes of
+optim/posegraph.py either replicate the solve on every rank (no speed-up of the dominant cost) or all-reduce a whole
+node vector per PCG iteration (every rank still touches all N rows).  Here each rank OWNS a contiguous range of node rows
+of the normal equations:
+
+  once per LM step   every rank linearises its edge shard; the per-edge residuals / Jacobian blocks are all-gathered
+                     (E (6 + 72) floats + indices; each rank then keeps the incidences of its own rows) -- the only
+                     volume-bound collective, 131 MB at configs[3], ~0.1 ms over 7 xGMI links;
+  assembly           diagonal blocks, gradient and off-diagonal blocks of the OWNED rows only: complete locally, no
+                     collective (an edge cut by the partition is simply seen by both owners);
+  PCG iteration      q_own = (D + H_offdiag) p over owned rows -- needs p of the owned rows and of their HALO (the remote
+                     neighbours); one all-gather of the owned p slices (N m floats in total: 2.4 MB at configs[3], 300 KB
+                     per rank) refreshes the halo, one all-reduce of three scalars carries p.q and, one iteration late,
+                     r.z and r.r.  Everything else (x, r, z, preconditioner) is owner-local.
+
+Per iteration a rank therefore streams 1/R of the blocks and takes part in two latency-bound collectives; DESIGN.md
+section 6 carries the byte / latency model.  This module is the device-agnostic formulation (torch ops + the node-parallel
+HIP kernels for assembly and SpMV where they apply); it is what the world-size-2 / 4 gloo tests run, and what RCCL runs
+one process per GPU.  Trajectories equal the single-process ones up to the summation order of the dot products.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+
+from .. import _C
+
+
+def _bounds(N, world, rank):
+    chunk = -(-N // world)
+    a = min(N, rank * chunk)
+    return chunk, a, min(N, a + chunk)
+
+
+class NodeShard:
+    """Ownership, local incidence lists and halo map of one rank for one edge list (cached on the optimizer)."""
+
+    def __init__(self, lin, group):
+        import torch.distributed as dist
+        self.group = group
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        N, K = lin.N, lin.K
+        assert K == 2, "node-sharded solve: pairwise edges"
+        self.N, self.m = N, lin.m
+        self.chunk, self.a, self.b = _bounds(N, self.world, self.rank)
+        self.n_own = self.b - self.a
+        ptr, blk, other = lin.csr()
+        lo, hi = (int(v) for v in ptr[[self.a, self.b]].tolist())          # (once per edge list)
+        dev = ptr.device
+        self.ptr = (ptr[self.a:self.b + 1] - lo).to(torch.int32).contiguous()
+        self.blk = blk[lo:hi].contiguous()
+        oth = other[lo:hi].long()
+        own = (oth >= self.a) & (oth < self.b)
+        self.halo = torch.unique(oth[~own])                                  # sorted global ids of the remote neighbours
+        slot = torch.searchsorted(self.halo, oth.clamp_max(max(N - 1, 0))) if self.halo.numel() else torch.zeros_like(oth)
+        self.other = torch.where(own, oth - self.a, self.n_own + slot).to(torch.int32).contiguous()
+        counts = (self.ptr[1:] - self.ptr[:-1]).long()
+        self.row = torch.repeat_interleave(torch.arange(self.n_own, device=dev), counts)    # owned row of every incidence
+        self.edge, self.side = (self.blk // K).long(), (self.blk % K).long()
+        # halo rows inside the all-gathered [world * chunk, m] buffer: global id g sits at row g (chunks are contiguous)
+        self.halo_rows = self.halo
+
+    # ---- collectives -----------------------------------------------------------------------------------------------
+    def gather_rows(self, own_rows):
+        """[n_own, m] owned rows of every rank -> the full [N, m] vector (one all-gather of equal-size padded slices)."""
+        import torch.distributed as dist
+        m = own_rows.shape[-1]
+        mine = own_rows.new_zeros((self.chunk, m))
+        mine[:self.n_own] = own_rows
+        parts = [torch.empty_like(mine) for _ in range(self.world)]
+        dist.all_gather(parts, mine, group=self.group)
+        return torch.cat(parts, 0)[:self.N]
+
+    def sum_scalars(self, t):
+        import torch.distributed as dist
+        dist.all_reduce(t, group=self.group)
+        return t
+
+
+class NodeShardedSystem:
+    """Owned rows of (J^T W J + damping) and their PCG (see the module docstring)."""
+
+    def __init__(self, lin, shard):
+        self.lin, self.sh = lin, shard
+        self.B = self.g = self.HB = None
+
+    def _hip(self):
+        return self.lin._hip() and self.lin.m in (3, 6, 7)
+
+    def group_is_device(self):
+        import torch.distributed as dist
+        return dist.get_backend(self.sh.group) == "nccl"
+
+    def assemble(self):
+        lin, sh = self.lin, self.sh
+        m, dt, dev = lin.m, lin.J.dtype, lin.J.device
+        n, C = sh.n_own, sh.blk.numel()
+        if self._hip() and n > 0:
+            from . import posegraph as _pg
+            sfx = "_f32" if dt == torch.float32 else "_f64"
+            self.B = torch.empty((n, m, m), dtype=dt, device=dev)
+            self.g = torch.empty((n, m), dtype=dt, device=dev)
+            self.HB = torch.empty((max(C, 1), m, m), dtype=dt, device=dev)
+            with torch.cuda.device(dev):
+                code = _C.library().symbol("pplie_graph_assemble_csr" + sfx, _pg._ASMC_SIG)(
+                    sh.ptr.data_ptr(), sh.blk.data_ptr(), lin.J.data_ptr(), lin.W.data_ptr() if lin.W is not None else None,
+                    lin.R.data_ptr(), self.B.data_ptr(), self.g.data_ptr(), self.HB.data_ptr(), n, lin.dr, m, lin.K,
+                    _C.stream_ptr(dev))
+            _C.check(code, "pplie_graph_assemble_csr")
+            return
+        Jn = lin.J[sh.edge, sh.side]                                   # [C, dr, m] block of the owned end
+        Jf = lin.J[sh.edge, 1 - sh.side]                               # block of the far end
+        JtW = Jn.mT if lin.W is None else Jn.mT @ lin.W[sh.edge]
+        self.B = torch.zeros((n, m, m), dtype=dt, device=dev).index_add_(0, sh.row, JtW @ Jn)
+        self.g = torch.zeros((n, m), dtype=dt, device=dev).index_add_(0, sh.row, (JtW @ lin.R[sh.edge].unsqueeze(-1)).squeeze(-1))
+        self.HB = JtW @ Jf
+
+    def matvec(self, D, p_loc):
+        """q_own = D p_own + sum over the owned rows' incidences of HB[c] p_loc[other[c]]"""
+        sh, m = self.sh, self.lin.m
+        n = sh.n_own
+        if self._hip() and n > 0:
+            from . import posegraph as _pg
+            q = torch.empty((n, m), dtype=p_loc.dtype, device=p_loc.device)
+            if not hasattr(self, "_scal"):
+                self._scal = torch.zeros(_pg._PCG_SCAL_ELEMS, dtype=p_loc.dtype, device=p_loc.device)
+                self._it = torch.zeros(2, dtype=torch.int32, device=p_loc.device)
+            sfx = "_f32" if p_loc.dtype == torch.float32 else "_f64"
+            with torch.cuda.device(p_loc.device):
+                code = _C.library().symbol("pplie_graph_bsr_spmv" + sfx, _pg._BSR_SIG)(
+                    sh.ptr.data_ptr(), sh.other.data_ptr(), self.HB.data_ptr(), D.data_ptr(), p_loc.data_ptr(), q.data_ptr(),
+                    self._scal.data_ptr(), self._it.data_ptr(), n, m, _C.stream_ptr(p_loc.device))
+            _C.check(code, "pplie_graph_bsr_spmv")
+            return q
+        q = (D @ p_loc[:n].unsqueeze(-1)).squeeze(-1)
+        if sh.blk.numel():
+            q = q.index_add(0, sh.row, (self.HB @ p_loc[sh.other.long()].unsqueeze(-1)).squeeze(-1))
+        return q
+
+    def _solve_hip(self, s, dmin, dmax, tol, maxiter, check_every):
+        """The same iteration on the fused kernels of the single-GPU path (csrc/graph.hip): pplie_pcg_prepare once, then per
+        iteration pplie_pcg2_spmv and pplie_pcg2_step on the OWNED rows (local incidence lists, p laid out as
+        [owned rows padded to the chunk | halo rows]), with the two exchanges between them: the slot-spread partial sums
+        { r.z, p.q, q.z, q.Binv q } are totalled, all-reduced (one 4-float collective) and written back, and the owned p
+        slices are all-gathered to refresh the halo.  No host synchronisation except the convergence test every
+        `check_every` iterations."""
+        import torch.distributed as dist
+        from . import posegraph as _pg
+        sh, m, lin = self.sh, self.lin.m, self.lin
+        n, chunk, dev, dt = sh.n_own, sh.chunk, self.g.device, self.g.dtype
+        sfx = "_f32" if dt == torch.float32 else "_f64"
+        lib, st = _C.library(), _C.stream_ptr(dev)
+        z = lambda *shape: torch.zeros(shape, dtype=dt, device=dev)
+        w = self.__dict__.get('_ws')
+        if w is None or w['key'] != (n, chunk, sh.halo.numel(), dt):
+            w = self._ws = dict(key=(n, chunk, sh.halo.numel(), dt), D=z(n, m, m), Binv=z(n, m, m), shift=z(n, m), x=z(n, m), r=z(n, m),
+                                r2=z(n, m), q=z(n, m), z=z(n, m), p=z(chunk + sh.halo.numel(), m), full=z(sh.world * chunk, m),
+                                scal=z(_pg._PCG_SCAL_ELEMS), rr_hist=z(1 << 16), it=torch.zeros(2, dtype=torch.int32, device=dev),
+                                other=torch.where(sh.other >= n, sh.other + (chunk - n), sh.other).contiguous(),
+                                qsel=torch.tensor([0, 1, 4, 5], device=dev))
+        w['scal'].zero_()
+        w['it'].zero_()
+        w['p'].zero_()
+        S = w['scal'].view(2, 8, 32, 32)
+        with torch.cuda.device(dev):
+            _C.check(lib.symbol("pplie_pcg_prepare" + sfx, _pg._PREP_SIG)(
+                self.B.data_ptr(), self.g.data_ptr(), w['D'].data_ptr(), w['Binv'].data_ptr(), w['shift'].data_ptr(), w['x'].data_ptr(),
+                w['r'].data_ptr(), w['z'].data_ptr(), w['p'].data_ptr(), w['scal'].data_ptr(), float(s), float(dmin), float(dmax), n, m, st),
+                "pplie_pcg_prepare")
+            bn2 = S[0, 3, :, 0].sum().reshape(1)
+            dist.all_reduce(bn2, group=sh.group)
+            bn2 = float(bn2)
+            if bn2 == 0.0:
+                return sh.gather_rows(w['x']), 0
+            spmv = lib.symbol("pplie_pcg2_spmv" + sfx, _pg._PCG2_SPMV_SIG)
+            step = lib.symbol("pplie_pcg2_step" + sfx, _pg._PCG2_STEP_SIG)
+            done, thresh = 0, tol * tol * bn2
+            maxiter = min(maxiter, (1 << 16) - check_every)
+            while done < maxiter:
+                a = done & 1
+                dist.all_gather_into_tensor(w['full'], w['p'][:chunk], group=sh.group)       # halo refresh
+                if sh.halo.numel():
+                    torch.index_select(w['full'], 0, sh.halo_rows, out=w['p'][chunk:])
+                _C.check(spmv(sh.ptr.data_ptr(), w['other'].data_ptr(), self.HB.data_ptr(), w['D'].data_ptr(), w['Binv'].data_ptr(),
+                              w['p'].data_ptr(), w['z'].data_ptr(), w['q'].data_ptr(), w['scal'].data_ptr(), w['rr_hist'].data_ptr(),
+                              w['it'].data_ptr(), 1 << 16, n, m, st), "pplie_pcg2_spmv")
+                tot = S[a, :, :, 0].sum(-1)                                                   # [8] totals of this rank
+                dist.all_reduce(tot, group=sh.group)
+                S[a, w['qsel'], :, 0] = 0
+                S[a, w['qsel'], 0, 0] = tot[w['qsel']]
+                _C.check(step(w['x'].data_ptr(), w['r'].data_ptr(), w['r2'].data_ptr(), w['p'].data_ptr(), w['q'].data_ptr(), w['z'].data_ptr(),
+                              w['Binv'].data_ptr(), w['scal'].data_ptr(), w['it'].data_ptr(), n, m, st), "pplie_pcg2_step")
+                done += 1
+                if done % check_every == 0 or done >= maxiter:
+                    rr = S[a, 2, :, 0].sum().reshape(1)
+                    dist.all_reduce(rr, group=sh.group)
+                    rr = float(rr)
+                    assert rr == rr, 'Linear solve produced NaN (matrix may not be positive-definite)'
+                    if rr <= thresh:
+                        break
+        return sh.gather_rows(w['x']), done
+
+    def solve(self, s, dmin, dmax, tol, maxiter, check_every=8):
+        """(H + damping) d = -g over all ranks; returns the FULL step [N, m] (all-gathered) and the iteration count."""
+        sh, m = self.sh, self.lin.m
+        n = sh.n_own
+        if self._hip() and n > 0 and self.group_is_device():
+            return self._solve_hip(s, dmin, dmax, tol, maxiter, check_every)
+        diag = self.B.diagonal(dim1=-2, dim2=-1)
+        D = self.B.clone()
+        D.diagonal(dim1=-2, dim2=-1).copy_(s * diag.clamp(dmin, dmax))        # optimizer.py:656-657, :666
+        Binv = torch.linalg.inv(D) if n else D
+        apply_Binv = lambda v: (Binv @ v.unsqueeze(-1)).squeeze(-1)
+        x = torch.zeros_like(self.g)
+        r = -self.g
+        z = apply_Binv(r)
+        p = z.clone()
+        sums = sh.sum_scalars(torch.stack([(r * z).sum(), (r * r).sum()]))
+        rho, bn2 = sums[0], sums[1]
+        if float(bn2) == 0.0:
+            return sh.gather_rows(x), 0
+        thresh = tol * tol * float(bn2)
+        done = 0
+        while done < maxiter:
+            p_full = sh.gather_rows(p)                                        # halo refresh (one all-gather)
+            p_loc = torch.cat([p, p_full[sh.halo_rows]], 0) if sh.halo.numel() else p
+            q = self.matvec(D, p_loc)
+            pq = sh.sum_scalars((p * q).sum().reshape(1))[0]
+            alpha = torch.where(pq != 0, rho / pq, torch.zeros_like(pq))
+            x = x + alpha * p
+            r = r - alpha * q
+            z = apply_Binv(r)
+            sums = sh.sum_scalars(torch.stack([(r * z).sum(), (r * r).sum()]))
+            rho_new, rr = sums[0], sums[1]
+            done += 1
+            if done % check_every == 0 or done >= maxiter:
+                rr_h = float(rr)
+                assert rr_h == rr_h, 'Linear solve produced NaN (matrix may not be positive-definite)'
+                if rr_h <= thresh:
+                    break
+            beta = torch.where(rho != 0, rho_new / rho, torch.zeros_like(rho))
+            p = z + beta * p
+            rho = rho_new
+        return sh.gather_rows(x), done

@@ -314,7 +314,7 @@ class LevenbergMarquardt(_Optimizer):
     """
 
     def __init__(self, model, solver=None, strategy=None, kernel=None, corrector=None,
-                 weight=None, reject=16, min=1e-6, max=1e32, vectorize=True, sparse=False, *, group=None, static=False):
+                 weight=None, reject=16, min=1e-6, max=1e32, vectorize=True, sparse=False, *, group=None, static=False, shard="edges"):
         assert min > 0, ValueError("min value has to be positive: {}".format(min))
         assert max > 0, ValueError("max value has to be positive: {}".format(max))
         self.strategy = TrustRegion() if strategy is None else strategy
@@ -333,6 +333,11 @@ class LevenbergMarquardt(_Optimizer):
         # ranks (one process per GPU, RCCL); the loss, the gain ratio and -- for pose graphs -- the
         # normal-equation pieces are all-reduced so that every rank takes the same decisions.
         self.group = group
+        # shard="nodes" (pose graphs, with group=): the linear solve is sharded by node rows -- each rank assembles and
+        # iterates on the rows it owns, one all-gather of p + one scalar all-reduce per PCG iteration (optim/nodeshard.py);
+        # "edges" (default): edge shards with the solve replicated / all-reduced (optim/posegraph.py)
+        assert shard in ("edges", "nodes"), ValueError("shard has to be 'edges' or 'nodes': {}".format(shard))
+        self.shard = shard
         self.jackwargs = {'vectorize': vectorize}
         self.solver = Cholesky() if solver is None else solver
         self.reject, self.reject_count = reject, 0

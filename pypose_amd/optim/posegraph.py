@@ -408,6 +408,7 @@ class GraphLinearization:
         self.replicated = False  # True: the edges of ALL shards are held here, nothing below is a collective
         self.s = 1.0            # compounded damping factor prod(1 + lambda_i)
         self.HB = None
+        self.node_group = None  # process group over which the SOLVE is sharded by node rows (optim/nodeshard.py)
 
     # -- index helpers -------------------------------------------------------------------------
     def step_to_nodes(self, D):
@@ -501,8 +502,19 @@ class GraphLinearization:
 
     # -- LM interface ------------------------------------------------------------------------------
     def build_normal_equations(self, dmin, dmax):
-        self.B, self.g = self._assemble()
         self.dmin, self.dmax = float(dmin), float(dmax)
+        self.s = 1.0
+        if self.node_group is not None:
+            from . import nodeshard as _ns
+            cache = self.opt.__dict__.setdefault('_node_shards', {})
+            csr = self.csr()
+            hit = cache.get('shard')
+            if hit is None or hit[0] is not csr:                    # (the csr object changes exactly when the edge list does)
+                hit = cache['shard'] = (csr, _ns.NodeShard(self, self.node_group))
+            self.ns = _ns.NodeShardedSystem(self, hit[1])
+            self.ns.assemble()
+            return
+        self.B, self.g = self._assemble()
         # the parameter components outside the tangent space (7th of SE3, ...) have a structurally
         # zero Jacobian column: the reference clamps their diagonal to ``min`` and solves d = 0.
         self.s = 1.0
@@ -520,6 +532,12 @@ class GraphLinearization:
 
     def solve(self, solver):
         N, m = self.N, self.m
+        if self.node_group is not None:
+            pcg = solver if isinstance(solver, PCG) else PCG(tol=1e-10, maxiter=max(1000, 2 * N))
+            maxiter = N * m * 10 if pcg.maxiter is None else pcg.maxiter
+            Dn, its = self.ns.solve(self.s, self.dmin, self.dmax, pcg.tol, maxiter, pcg.check_every)
+            solver.iterations = its
+            return self.nodes_to_step(Dn)
         if not isinstance(solver, PCG) and N * m <= DENSE_LIMIT and self.group is None:
             shift = self.s * self.diag_clamped - self.diag_raw       # A = H + diag(shift)
             A = self.dense_matrix()
@@ -747,10 +765,17 @@ def _finish_graph_linearization(opt, Rc, Jc, idx, Wb, param, wfull, m):
     # runs the un-sharded solve (streaming SpMV, graph-captured iterations, no collective).  Larger problems keep
     # the blocks distributed and all-reduce diag / gradient once per step and H p once per iteration.
     group = getattr(opt, 'group', None)
-    if group is not None and getattr(opt, 'replicate_solve', True):
+    nodes = group is not None and getattr(opt, 'shard', 'edges') == 'nodes' and Jc.shape[1] == 2
+    if group is not None and (getattr(opt, 'replicate_solve', True) or nodes):
         gathered = _gather_edge_shards(group, [Rc.contiguous(), Jc.contiguous(), idx.contiguous(), Wb], REPLICATE_LIMIT)
         if gathered is not None:
             lin = GraphLinearization(opt, gathered[3], gathered[0], param, gathered[2], gathered[1], wfull, m)
             lin.group, lin.replicated = None, True
+            # shard="nodes": every rank holds the blocks of all edges (gathered once per LM step, above) but assembles
+            # and solves only the node rows it owns -- optim/nodeshard.py
+            lin.node_group = group if nodes else None
+            opt._last_shard_mode = "node-sharded solve" if nodes else "replicated solve"
             return lin
+    if group is not None:
+        opt._last_shard_mode = "edge-sharded (all-reduce per PCG iteration)"
     return GraphLinearization(opt, Wb, Rc, param, idx, Jc, wfull, m)

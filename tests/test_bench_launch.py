@@ -28,10 +28,12 @@ def test_two_ranks_self_launched_dry_run():
     assert out["n_gpus"] == 2 and out["config"]["ranks"] == 2 and out["config"]["collective_backend"] == "gloo"
     assert out["config"]["launch"].startswith("self-launched")
     assert out["value"] > 0 and out["scaling"] == "weak"
-    for leg in ("lm_invnet_sharded", "imu_sharded", "lm_pgo_sharded"):
+    for leg in ("lm_invnet_sharded", "imu_sharded", "lm_pgo_sharded", "lm_pgo_node_sharded"):
         assert "error" not in out[leg], (leg, out[leg])
         assert out[leg]["n_gpus"] == 2 and out[leg]["value"] > 0
     assert out["lm_pgo_sharded"]["losses"][-1] < out["lm_pgo_sharded"]["losses"][0]
+    assert out["lm_pgo_node_sharded"]["mode"] == "node-sharded solve"
+    assert out["lm_pgo_node_sharded"]["losses"] == pytest.approx(out["lm_pgo_sharded"]["losses"], rel=1e-4)
 
 
 def test_single_process_dry_run_has_every_config():

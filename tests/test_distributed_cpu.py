@@ -51,23 +51,26 @@ def _worker(rank, world, port, kind, q):
                 sel = torch.arange(70) if rank == 0 else torch.arange(70, edges.shape[0])
             graph = PoseGraph(pp.SE3(T(G["pgo40/init"])))                 # nodes replicated
             opt = pp.optim.LM(graph, solver=pp.optim.solver.PCG(tol=1e-13, maxiter=2000, check_every=1),
-                              strategy=pp.optim.strategy.TrustRegion(radius=1e4), min=1e-6, group=dist.group.WORLD)
+                              strategy=pp.optim.strategy.TrustRegion(radius=1e4), min=1e-6, group=dist.group.WORLD,
+                              shard="nodes" if kind == "graph_nodes" else "edges")
             opt.replicate_solve = kind != "graph_distributed"            # gathered blocks + local solve | all-reduce per H p
             rec = run_steps(opt, ((edges[sel], pp.SE3(poses[sel])),), {"weight": infos[sel]}, 4)
             rec["replicated"] = bool(opt.__dict__.get("_last_replicated"))
+            rec["mode"] = opt.__dict__.get("_last_shard_mode")
+            rec["pcg_iterations"] = opt.solver.iterations
             rec["nodes"] = graph.nodes.detach().tensor().numpy()
     q.put((rank, rec))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def _run(kind):
+def _run(kind, world=2):
     ctx = mp.get_context("spawn")
     q = ctx.SimpleQueue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, kind, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, kind, q)) for r in range(world)]
     [p.start() for p in procs]
-    out = dict(q.get() for _ in range(2))
+    out = dict(q.get() for _ in range(world))
     [p.join(60) for p in procs]
     assert all(p.exitcode == 0 for p in procs)
     return out
@@ -115,3 +118,19 @@ def test_sharded_bundle_adjustment_matches_reference_trajectory():
         np.testing.assert_allclose(out[r]["loss"][:3], B["ba_small/loss"][:3], rtol=1e-6)
         np.testing.assert_allclose(out[r]["damping"][:3], B["ba_small/damping"][:3], rtol=1e-12)
     np.testing.assert_allclose(out[0]["nodes"], out[1]["nodes"], rtol=0, atol=1e-12)
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("world", [2, 4])
+def test_node_sharded_solve_matches_reference_trajectory(world):
+    """LM(group=, shard="nodes"): every rank linearises its (interleaved) edge shard, the blocks are gathered once per
+    step, and the SOLVE is sharded by node rows -- each rank assembles and iterates on the 40 / world rows it owns, one
+    all-gather of p and scalar all-reduces per PCG iteration (optim/nodeshard.py).  Reference trajectory pgo40/infos."""
+    out = _run("graph_nodes", world)
+    G = load_lm_golden()
+    for r in range(world):
+        assert out[r]["kind"] == ["graph"] * 4 and out[r]["mode"] == "node-sharded solve"
+        assert out[r]["pcg_iterations"] > 0
+        np.testing.assert_allclose(out[r]["loss"][:3], G["pgo40/infos/loss"][:3], rtol=1e-7)
+        np.testing.assert_allclose(out[r]["damping"][:3], G["pgo40/infos/damping"][:3], rtol=1e-12)
+        np.testing.assert_allclose(out[r]["nodes"], out[0]["nodes"], rtol=0, atol=1e-12)
