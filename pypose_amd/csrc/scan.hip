@@ -677,6 +677,290 @@ imu_cov_scan_kernel(const T* __restrict__ dt, const T* __restrict__ rk, const T*
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Covariance, version 2: a LANE owns LS consecutive steps (a segment) and walks them sequentially; the cross-lane scan
+// is paid once per 64 LS steps instead of once per 64, and the kernel reads the RAW inputs (dt, gyro, acc) plus the
+// integrated rotations instead of three auxiliary streams the integration kernel had to write for it.
+//
+//   per chunk of 64 LS steps (processed from the end of the sequence backwards; lane l holds segment 63 - l):
+//     walk 1   the segment's own product  L = A_first ... A_last  in the closed structure [[S,0,0],[X,I,0],[Y,tI,I]]
+//              (recurrences above, started from the identity)
+//     scan     inclusive products over the lanes (later segments first) and the carry of the later chunks:
+//              P_after(segment) = product of everything behind it            -- 7 DPP steps on 23 values
+//     walk 2   the same steps again from P_after, adding each step's  V (h Cg) V^T + U (h Ca) U^T  to 45 accumulators
+//   a step costs ~240 (walk 1) + ~590 (walk 2) VALU instructions + 1/LS of the scan (~1300), against ~1750 for the
+//   one-step-per-lane kernel above with its 19 scalar scans and SO3 scan per 64 steps.
+// Per step it needs: h, dr = Exp(gyro h) (recomputed), a = acc - Rw^-1 g (Rw: the integrated or the known rotation),
+// Rij = C * Rout (C = Rij0 * r0^-1 per sequence), and Jr(Log dr) = Jr(gyro h) for |gyro h| < pi.
+// ---------------------------------------------------------------------------------------------
+template <class T> __device__ __forceinline__ void quat_matrix(const T* q, T* M) {
+  // the matrix of SO3_Act (p + 2 w v x p + 2 v x (v x p)) column by column, in closed form: (1 - 2|v|^2) I + 2 v v^T + 2 w [v]x
+  const T x = q[0], y = q[1], z = q[2], w = q[3];
+  const T xx = x * x, yy = y * y, zz = z * z, xy = x * y, xz = x * z, yz = y * z, wx = w * x, wy = w * y, wz = w * z;
+  M[0] = T(1) - T(2) * (yy + zz); M[1] = T(2) * (xy - wz);        M[2] = T(2) * (xz + wy);
+  M[3] = T(2) * (xy + wz);        M[4] = T(1) - T(2) * (xx + zz); M[5] = T(2) * (yz - wx);
+  M[6] = T(2) * (xz - wy);        M[7] = T(2) * (yz + wx);        M[8] = T(1) - T(2) * (xx + yy);
+}
+
+// the structured 9x9 products: element = { S quaternion [0:4], X [4:13], Y [13:22], t [22] };  c = a b
+template <class T> struct MulImuP {
+  enum { W = 23 };
+  static __device__ __forceinline__ void mul(const T* a, const T* b, T* c) {
+    T Sb[9], XS[9], YS[9], q[4];
+    quat_matrix<T>(b, Sb);
+    mat3_mul<T>(a + 4, Sb, XS);
+    mat3_mul<T>(a + 13, Sb, YS);
+    so3_mul<T>(a, b, q);
+    const T ta = a[22];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      const T bx = b[4 + i];
+      c[13 + i] = YS[i] + ta * bx + b[13 + i];
+      c[4 + i] = XS[i] + bx;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) c[i] = q[i];
+    c[22] = ta + b[22];
+  }
+  static __device__ __forceinline__ T ident(int k) { return k == 3 ? T(1) : T(0); }
+};
+
+// one step of the backward recurrence  P <- A_j P  on the structured state (S, X, Y, t); optionally (ACC) first adds the
+// step's noise term  P Bc_j P^T  to the accumulators
+template <class T, bool ACC>
+__device__ __forceinline__ void imu_cov_step(T* P, T h, const T* gy, const T* av, const T* qij, const T* dg, const T* da, T* acc) {
+  T S[9], Rj[9], M1[9], G[9];
+  quat_matrix<T>(P, S);
+  quat_matrix<T>(qij, Rj);
+  T w[3] = {gy[0] * h, gy[1] * h, gy[2] * h};
+  T dr[4];
+  so3_exp<T>(w, dr);
+  if (ACC) {
+    T phi[3] = {w[0], w[1], w[2]};
+    if (!(w[0] * w[0] + w[1] * w[1] + w[2] * w[2] < T(9.8))) so3_log<T>(dr, phi);   // Log(Exp(w)) = w below pi
+    T Jr[9], V[27];
+    so3_jr<T>(phi, Jr);
+    mat3_mul<T>(S, Jr, V);
+    mat3_mul<T>(P + 4, Jr, V + 9);
+    mat3_mul<T>(P + 13, Jr, V + 18);
+    const T tu = P[22] + T(0.5) * h;            // U = [0; Rj; tu Rj]
+    T Vd[27];
+#pragma unroll
+    for (int r = 0; r < 9; ++r)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) Vd[r * 3 + k] = V[r * 3 + k] * (h * dg[k]);
+    T Wa[9];
+#pragma unroll
+    for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+      for (int cc = rr; cc < 3; ++cc) {
+        const T ww = h * (Rj[rr * 3] * da[0] * Rj[cc * 3] + Rj[rr * 3 + 1] * da[1] * Rj[cc * 3 + 1] + Rj[rr * 3 + 2] * da[2] * Rj[cc * 3 + 2]);
+        Wa[rr * 3 + cc] = ww;
+        Wa[cc * 3 + rr] = ww;
+      }
+#pragma unroll
+    for (int r = 0; r < 9; ++r)
+#pragma unroll
+      for (int c = r; c < 9; ++c) {
+        const int e = r * 9 - (r * (r - 1)) / 2 + (c - r);
+        T sacc = Vd[r * 3] * V[c * 3] + Vd[r * 3 + 1] * V[c * 3 + 1] + Vd[r * 3 + 2] * V[c * 3 + 2];
+        if (r >= 3) {
+          const T f = (r < 6 ? T(1) : tu) * (c < 6 ? T(1) : tu);
+          sacc += f * Wa[(r % 3) * 3 + (c % 3)];
+        }
+        acc[e] += sacc;
+      }
+  }
+  // M1 = -h Rj skew(a): column i of Rj skew(a) is Rj (a x e_i)
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    M1[r * 3 + 0] = -h * (av[2] * Rj[r * 3 + 1] - av[1] * Rj[r * 3 + 2]);
+    M1[r * 3 + 1] = -h * (av[0] * Rj[r * 3 + 2] - av[2] * Rj[r * 3 + 0]);
+    M1[r * 3 + 2] = -h * (av[1] * Rj[r * 3 + 0] - av[0] * Rj[r * 3 + 1]);
+  }
+  mat3_mul<T>(M1, S, G);
+  const T hh = T(0.5) * h;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    const T x0 = P[4 + i];
+    P[13 + i] += hh * G[i] + h * x0;
+    P[4 + i] = x0 + G[i];
+  }
+  const T si[4] = {-dr[0], -dr[1], -dr[2], dr[3]};
+  T q[4];
+  so3_mul<T>(si, P, q);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) P[i] = q[i];
+  P[22] += h;
+}
+
+template <class T, int WAVES, int LS>
+__global__ void __launch_bounds__(WAVES * 64, 3)
+imu_cov_seg_kernel(const T* __restrict__ dt, const T* __restrict__ gyro, const T* __restrict__ accel, const T* __restrict__ rout,
+                   const T* __restrict__ rw, const T* __restrict__ C, const T* __restrict__ init_cov, const T* __restrict__ gyro_cov,
+                   int64_t gc_sb, int64_t gc_sf, const T* __restrict__ acc_cov, int64_t ac_sb, int64_t ac_sf, T g0, T g1, T g2,
+                   T* __restrict__ cov, int64_t B, int64_t F) {
+  __shared__ T sd[WAVES * LS * 11 * 64];          // [wave][step of the segment][field][lane]
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t b = (int64_t)blockIdx.x * WAVES + wv;
+  if (b >= B) return;
+  T carry[23];
+#pragma unroll
+  for (int i = 0; i < 23; ++i) carry[i] = MulImuP<T>::ident(i);
+  T acc[45];
+#pragma unroll
+  for (int i = 0; i < 45; ++i) acc[i] = T(0);
+  T cq[4] = {T(0), T(0), T(0), T(1)};
+  if (C) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) cq[i] = C[b * 4 + i];
+  }
+  const bool per_step_cov = gc_sf != 0 || ac_sf != 0;
+  T dg0[3], da0[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) { dg0[i] = gyro_cov[b * gc_sb + i]; da0[i] = acc_cov[b * ac_sb + i]; }
+  const int64_t CH = 64 * LS;
+  const int64_t nchunks = (F + CH - 1) / CH;
+  const int seg = 63 - lane;                      // lanes walk a chunk's segments backwards: a suffix over steps is a prefix over lanes
+  for (int64_t ch = nchunks - 1; ch >= 0; --ch) {
+    const int64_t j0 = ch * CH + (int64_t)seg * LS;
+    // ---- this segment's steps: raw inputs -> (h, gyro, a, Rij), parked in lane-private LDS slots for the two walks
+    // (11 values per step; held in registers the unrolled walks need > 256 VGPRs)
+#pragma unroll 1
+    for (int s = 0; s < LS; ++s) {
+      const int64_t j = j0 + s;
+      const bool ok = j < F;
+      const int64_t row = b * F + (ok ? j : 0);
+      T ro[4], rwq[4], ac[3], gyv[3], qq[4];
+      const T hv = ok ? dt[row] : T(0);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) { gyv[i] = ok ? gyro[row * 3 + i] : T(0); ac[i] = ok ? accel[row * 3 + i] : T(0); }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { ro[i] = ok ? rout[row * 4 + i] : (i == 3 ? T(1) : T(0)); rwq[i] = ok ? rw[row * 4 + i] : (i == 3 ? T(1) : T(0)); }
+      const V3<T> gb = quat_rotate_inv(v3(rwq), rwq[3], v3<T>(g0, g1, g2));       // Rw^-1 g
+      if (C) so3_mul<T>(cq, ro, qq);
+      else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) qq[i] = ro[i];
+      }
+      T* slot = sd + ((size_t)(wv * LS + s) * 11) * 64 + lane;
+      slot[0] = hv;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) slot[(1 + i) * 64] = gyv[i];
+      slot[4 * 64] = ok ? ac[0] - gb.x : T(0); slot[5 * 64] = ok ? ac[1] - gb.y : T(0); slot[6 * 64] = ok ? ac[2] - gb.z : T(0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) slot[(7 + i) * 64] = qq[i];
+    }
+    // ---- walk 1: the segment's own product
+    T P[23];
+#pragma unroll
+    for (int i = 0; i < 23; ++i) P[i] = MulImuP<T>::ident(i);
+#pragma unroll 1
+    for (int s = LS - 1; s >= 0; --s) {
+      const T* slot = sd + ((size_t)(wv * LS + s) * 11) * 64 + lane;
+      const T gy[3] = {slot[64], slot[128], slot[192]}, av[3] = {slot[256], slot[320], slot[384]};
+      const T qij[4] = {slot[448], slot[512], slot[576], slot[640]};
+      imu_cov_step<T, false>(P, slot[0], gy, av, qij, nullptr, nullptr, nullptr);
+    }
+    // ---- scan over the lanes (later segments sit in lower lanes) and the later chunks' carry
+    wave_scan<T, MulImuP<T>>(P, carry, true, true, lane);
+    T Q[23];                                     // exclusive: everything behind this segment
+#pragma unroll
+    for (int i = 0; i < 23; ++i) Q[i] = lane_shift_up1(P[i], carry[i]);
+#pragma unroll
+    for (int i = 0; i < 23; ++i) carry[i] = lane_bcast63(P[i]);
+    // ---- walk 2: the true suffix products and the noise terms
+#pragma unroll 1
+    for (int s = LS - 1; s >= 0; --s) {
+      T dg[3], da[3];
+      if (per_step_cov) {
+        const int64_t j = j0 + s < F ? j0 + s : 0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { dg[i] = gyro_cov[b * gc_sb + j * gc_sf + i]; da[i] = acc_cov[b * ac_sb + j * ac_sf + i]; }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { dg[i] = dg0[i]; da[i] = da0[i]; }
+      }
+      const T* slot = sd + ((size_t)(wv * LS + s) * 11) * 64 + lane;
+      const T gy[3] = {slot[64], slot[128], slot[192]}, av[3] = {slot[256], slot[320], slot[384]};
+      const T qij[4] = {slot[448], slot[512], slot[576], slot[640]};
+      imu_cov_step<T, true>(Q, slot[0], gy, av, qij, dg, da, acc);
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 45; ++e) {
+    T v = acc[e];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    acc[e] = v;
+  }
+  if (lane == 0) {
+    // P_0 = the final carry; cov = P_0 init_cov P_0^T + sum (init_cov is not symmetrised, as in the reference)
+    T Pm[81], S0[9];
+#pragma unroll
+    for (int i = 0; i < 81; ++i) Pm[i] = T(0);
+    quat_matrix<T>(carry, S0);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int jj = 0; jj < 3; ++jj) {
+        Pm[i * 9 + jj] = S0[i * 3 + jj];
+        Pm[(3 + i) * 9 + jj] = carry[4 + i * 3 + jj];
+        Pm[(6 + i) * 9 + jj] = carry[13 + i * 3 + jj];
+      }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { Pm[(3 + i) * 9 + 3 + i] = T(1); Pm[(6 + i) * 9 + 3 + i] = carry[22]; Pm[(6 + i) * 9 + 6 + i] = T(1); }
+#pragma unroll
+    for (int r = 0; r < 9; ++r)
+#pragma unroll
+      for (int c = r; c < 9; ++c) {
+        const int e = r * 9 - (r * (r - 1)) / 2 + (c - r);
+        cov[b * 81 + r * 9 + c] = acc[e];
+        cov[b * 81 + c * 9 + r] = acc[e];
+      }
+    for (int r = 0; r < 9; ++r) {
+      T tl[9];
+      for (int l = 0; l < 9; ++l) {
+        T s0 = T(0);
+        for (int mm = 0; mm < 9; ++mm) s0 += Pm[r * 9 + mm] * init_cov[b * 81 + mm * 9 + l];
+        tl[l] = s0;
+      }
+      for (int c = 0; c < 9; ++c) {
+        T s1 = T(0);
+        for (int l = 0; l < 9; ++l) s1 += tl[l] * Pm[c * 9 + l];
+        cov[b * 81 + r * 9 + c] += s1;
+      }
+    }
+  }
+}
+
+template <class T>
+int imu_cov2_launch(const void* dt, const void* gyro, const void* acc, const void* rout, const void* rw, const void* C,
+                    const void* init_cov, const void* gc, int64_t gc_sb, int64_t gc_sf, const void* ac, int64_t ac_sb, int64_t ac_sf,
+                    const double* g, void* cov, int64_t B, int64_t F, void* stream) {
+  if (B < 0 || F < 0) return SC_EBADARG;
+  if (B == 0) return SC_OK;
+  if (!dt || !gyro || !acc || !rout || !rw || !init_cov || !gc || !ac || !cov || !g) return SC_EBADARG;
+  if (F == 0) {
+    hipMemcpyAsync(cov, init_cov, (size_t)B * 81 * sizeof(T), hipMemcpyDeviceToDevice, reinterpret_cast<hipStream_t>(stream));
+    return hipGetLastError() == hipSuccess ? SC_OK : SC_ELAUNCH;
+  }
+  constexpr int WAVES = 2;
+  const int64_t blocks = (B + WAVES - 1) / WAVES;
+#define PPLIE_COV2(LSN)                                                                                                        \
+  hipLaunchKernelGGL((imu_cov_seg_kernel<T, WAVES, LSN>), dim3((unsigned)blocks), dim3(WAVES * 64), 0,                          \
+                     reinterpret_cast<hipStream_t>(stream), (const T*)dt, (const T*)gyro, (const T*)acc, (const T*)rout,        \
+                     (const T*)rw, (const T*)C, (const T*)init_cov, (const T*)gc, gc_sb, gc_sf, (const T*)ac, ac_sb, ac_sf, (T)g[0], \
+                     (T)g[1], (T)g[2], (T*)cov, B, F)
+  const char* env = getenv("PPLIE_IMU_COV_LS");                   // tuning switch: steps per lane
+  const int ls = env ? atoi(env) : 4;
+  if (F <= 128 || ls == 2) PPLIE_COV2(2);
+  else if (ls == 8) PPLIE_COV2(8);
+  else PPLIE_COV2(4);
+#undef PPLIE_COV2
+  return hipGetLastError() == hipSuccess ? SC_OK : SC_ELAUNCH;
+}
+
 template <class T>
 int imu_integrate_launch(const void* dt, const void* gyro, const void* acc, const void* rot, const void* r0, const void* v0,
                          const void* p0, const void* rij0, const double* g, void* orot, void* ovel, void* opos, void* ark,
@@ -753,6 +1037,20 @@ extern "C" int pplie_imu_integrate_f64(const void* dt, const void* gyro, const v
                                        int64_t B, int64_t F, void* stream) {
   return pplie::imu_integrate_launch<double>(dt, gyro, acc, rot, init_rot, init_vel, init_pos, rij0, gravity, out_rot, out_vel,
                                              out_pos, aux_rk, aux_rij, aux_a, B, F, stream);
+}
+extern "C" int pplie_imu_cov2_f32(const void* dt, const void* gyro, const void* acc, const void* rot_out, const void* rot_world,
+                                  const void* C, const void* init_cov, const void* gyro_cov, int64_t gc_sb, int64_t gc_sf,
+                                  const void* acc_cov, int64_t ac_sb, int64_t ac_sf, const double* gravity, void* cov, int64_t B,
+                                  int64_t F, void* stream) {
+  return pplie::imu_cov2_launch<float>(dt, gyro, acc, rot_out, rot_world, C, init_cov, gyro_cov, gc_sb, gc_sf, acc_cov, ac_sb, ac_sf,
+                                       gravity, cov, B, F, stream);
+}
+extern "C" int pplie_imu_cov2_f64(const void* dt, const void* gyro, const void* acc, const void* rot_out, const void* rot_world,
+                                  const void* C, const void* init_cov, const void* gyro_cov, int64_t gc_sb, int64_t gc_sf,
+                                  const void* acc_cov, int64_t ac_sb, int64_t ac_sf, const double* gravity, void* cov, int64_t B,
+                                  int64_t F, void* stream) {
+  return pplie::imu_cov2_launch<double>(dt, gyro, acc, rot_out, rot_world, C, init_cov, gyro_cov, gc_sb, gc_sf, acc_cov, ac_sb, ac_sf,
+                                        gravity, cov, B, F, stream);
 }
 extern "C" int pplie_imu_cov_f32(const void* dt, const void* rk, const void* rij, const void* a, const void* init_cov,
                                  const void* gyro_cov, int64_t gc_sb, int64_t gc_sf, const void* acc_cov, int64_t ac_sb,

@@ -26,6 +26,8 @@ from ..lietensor import LieTensor, SO3, identity_SO3, so3, vec2skew
 
 _INT_SIG = [ctypes.c_void_p] * 8 + [ctypes.POINTER(ctypes.c_double)] + [ctypes.c_void_p] * 6 + \
            [ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p]
+_COV2_SIG = [ctypes.c_void_p] * 8 + [ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
+             ctypes.POINTER(ctypes.c_double), ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p]
 _COV_SIG = [ctypes.c_void_p] * 6 + [ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
                                     ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p]
 
@@ -81,11 +83,19 @@ class IMUPreintegrator(nn.Module):
 
         fused = self._fused_ok(dt, gyro, acc, rot, init_state)
         if fused:
-            predict, aux = self._fused_integrate(dt, gyro, acc, rot, init_state, Rij0 if self.prop_cov else None)
+            # states: one kernel writing rot / vel / pos only; covariance: a second kernel that re-derives what it needs per
+            # step (increment, gravity-free acceleration, Rij) from the raw inputs and the integrated rotations -- no
+            # auxiliary [B, F, 4 + 4 + 3] streams between the two (csrc/scan.hip)
+            predict, _ = self._fused_integrate(dt, gyro, acc, rot, init_state, None, aux=False)
             if self.prop_cov:
-                Rij = LieTensor(aux['Rij'], ltype=init_state['rot'].ltype) if isinstance(init_state['rot'], LieTensor) \
-                    else SO3(aux['Rij'])
-                cov = {'cov': self._fused_cov(dt, aux, init_cov, gyro_cov, acc_cov), 'Rij': Rij[..., -1:, :]}
+                # Rij_k = Rij0 * Dr_k = (Rij0 * r0^-1) * rot_k  (reference :283-286 with rot_k = r0 * Dr_k, :422)
+                r0 = init_state['rot'] if isinstance(init_state['rot'], LieTensor) else SO3(init_state['rot'])
+                Cq = r0.Inv() if Rij0 is None else Rij0 * r0.Inv()
+                Cq = torch.Tensor.as_subclass(Cq, torch.Tensor).expand(B, 1, 4).reshape(B, 4).contiguous()
+                last = SO3(Cq.unsqueeze(1)) * SO3(torch.Tensor.as_subclass(predict['rot'], torch.Tensor)[:, -1:, :])
+                Rij = LieTensor(torch.Tensor.as_subclass(last, torch.Tensor), ltype=init_state['rot'].ltype) \
+                    if isinstance(init_state['rot'], LieTensor) else last
+                cov = {'cov': self._fused_cov2(dt, gyro, acc, rot, predict['rot'], Cq, init_cov, gyro_cov, acc_cov), 'Rij': Rij}
             else:
                 cov = {'cov': None}
         else:
@@ -116,7 +126,40 @@ class IMUPreintegrator(nn.Module):
             return False
         return dt.dtype in (torch.float32, torch.float64) and all(t.dtype == dt.dtype for t in ts)
 
-    def _fused_integrate(self, dt, gyro, acc, rot, init_state, Rij0):
+    def _gravity_host(self):
+        """the gravity vector as a C array (read back once per value: the buffer lives on the device)"""
+        gt = self.gravity
+        hit = self.__dict__.get('_g_host')
+        if hit is None or hit[0] is not gt or hit[1] != gt._version:
+            hit = self.__dict__['_g_host'] = (gt, gt._version, (ctypes.c_double * 3)(*[float(x) for x in gt.tolist()]))
+        return hit[2]
+
+    def _fused_cov2(self, dt, gyro, acc, rot, rot_out, Cq, init_cov, gyro_cov, acc_cov):
+        """pplie_imu_cov2: covariance from the raw inputs + the integrated rotations (segment-walk kernel)."""
+        B, F = dt.shape[:2]
+        cov = torch.empty((B, 9, 9), dtype=dt.dtype, device=dt.device)
+
+        def strided(cv):            # [B or 1, F or 1, 3] -> element strides over (b, f)
+            cv = cv.to(dt.dtype)
+            cv = cv if cv.dim() == 3 else cv.reshape(-1, 1, 3)
+            cv = cv.contiguous()
+            return cv, (cv.stride(0) if cv.shape[0] > 1 else 0), (cv.stride(1) if cv.shape[1] > 1 else 0)
+        gc, gsb, gsf = strided(gyro_cov)
+        ac, asb, asf = strided(acc_cov)
+        ic = init_cov.to(dt.dtype).expand(B, 9, 9).contiguous()
+        ro = torch.Tensor.as_subclass(rot_out, torch.Tensor).contiguous()
+        rw = torch.Tensor.as_subclass(rot, torch.Tensor).expand(B, F, 4).contiguous() if rot is not None else ro
+        g = self._gravity_host()
+        fn = _C.library().symbol("pplie_imu_cov2" + _sfx(dt), _COV2_SIG)
+        dtc, gyc, acc_c = dt.contiguous(), gyro.contiguous(), acc.contiguous()     # (held: a temporary's block could be reused
+        with torch.cuda.device(dt.device):                                           #  by the next allocation before the launch)
+            code = fn(dtc.data_ptr(), gyc.data_ptr(), acc_c.data_ptr(), ro.data_ptr(), rw.data_ptr(),
+                      Cq.data_ptr(), ic.data_ptr(), gc.data_ptr(), gsb, gsf, ac.data_ptr(), asb, asf, g, cov.data_ptr(), B, F,
+                      _C.stream_ptr(dt.device))
+        _C.check(code, "pplie_imu_cov2")
+        return cov
+
+    def _fused_integrate(self, dt, gyro, acc, rot, init_state, Rij0, aux=None):
         B, F = dt.shape[:2]
         dev, dty = dt.device, dt.dtype
         c = lambda t: t.contiguous()
@@ -129,11 +172,12 @@ class IMUPreintegrator(nn.Module):
         orot = torch.empty((B, F, 4), dtype=dty, device=dev)
         ovel = torch.empty((B, F, 3), dtype=dty, device=dev)
         opos = torch.empty((B, F, 3), dtype=dty, device=dev)
+        want_aux = self.prop_cov if aux is None else aux
         aux = {}
-        if self.prop_cov:
+        if want_aux:
             aux = {'Rk': torch.empty((B, F, 4), dtype=dty, device=dev), 'Rij': torch.empty((B, F, 4), dtype=dty, device=dev),
                    'a': torch.empty((B, F, 3), dtype=dty, device=dev)}
-        g = (ctypes.c_double * 3)(*[float(x) for x in self.gravity.tolist()])
+        g = self._gravity_host()
         P = lambda t: t.data_ptr() if t is not None else None
         fn = _C.library().symbol("pplie_imu_integrate" + _sfx(dt), _INT_SIG)
         with torch.cuda.device(dev):
