@@ -65,4 +65,70 @@ __device__ __forceinline__ void grid_rendezvous(unsigned* bar) {
 template <class T> __device__ __forceinline__ void xwg_store(T* p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 template <class T> __device__ __forceinline__ T xwg_load(const T* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
+
+// ---- reductions across workgroups without a separate barrier ---------------------------------------------------------
+// Every workgroup publishes its partial sums as 64-bit words { sequence number | 32 value bits } (one agent-scope store
+// each: tag and payload can never be seen apart) and then collects everybody's: a row whose tags all equal the expected
+// sequence number is complete, so the poll IS the barrier -- one memory round trip instead of three (arrival counter,
+// release flag, table read).  Rows are added in a fixed order, identically in every workgroup.  Phase A and phase B use
+// separate tables: a workgroup can only overwrite its phase-A row after everyone published phase B, i.e. after everyone
+// finished reading phase A.
+typedef unsigned long long u64;
+template <class T> __device__ __forceinline__ void put_tagged(u64* row, int q, T v, unsigned seq) {
+  constexpr int NW = sizeof(T) / 4;
+  unsigned w[NW];
+  __builtin_memcpy(w, &v, sizeof(T));
+#pragma unroll
+  for (int k = 0; k < NW; ++k) xwg_store(row + q * NW + k, ((u64)seq << 32) | (u64)w[k]);
+}
+// sums of Q quantities over `rows` rows (first wave polls; result broadcast to the workgroup); false on a timeout
+template <class T, int Q> __device__ __forceinline__ bool gather_tagged(const u64* tab, int rows, unsigned seq, T out[Q], T* sh) {
+  constexpr int NW = sizeof(T) / 4, RW = 4 * NW;            // words per table row (4 quantities reserved)
+  __shared__ int ok_sh;
+  if (threadIdx.x < 64) {
+    T a[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) a[q] = T(0);
+    bool ok = true;
+    for (int i = threadIdx.x; i < rows; i += 64) {
+      u64 w[Q * NW];
+      bool got = false;
+      for (long spin = 0; spin < (1L << 22) && !got; ++spin) {
+        got = true;
+#pragma unroll
+        for (int k = 0; k < Q * NW; ++k) {
+          w[k] = xwg_load(tab + (size_t)i * RW + k);
+          got = got && (unsigned)(w[k] >> 32) == seq;
+        }
+      }
+      ok = ok && got;
+#pragma unroll
+      for (int q = 0; q < Q; ++q) {
+        unsigned bits[NW];
+#pragma unroll
+        for (int k = 0; k < NW; ++k) bits[k] = (unsigned)w[q * NW + k];
+        T v;
+        __builtin_memcpy(&v, bits, sizeof(T));
+        a[q] += v;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) a[q] += __shfl_xor(a[q], off, 64);
+    }
+    ok = __all(ok);
+    if (threadIdx.x == 0) {
+#pragma unroll
+      for (int q = 0; q < Q; ++q) sh[q] = a[q];
+      ok_sh = ok ? 1 : 0;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < Q; ++q) out[q] = sh[q];
+  const bool ok = ok_sh != 0;
+  __syncthreads();
+  return ok;
+}
 }  // namespace pplie

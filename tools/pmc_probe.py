@@ -44,6 +44,15 @@ for _ in range(2):
 torch.cuda.synchronize()
 del graph, opt
 
+# the metric's 10 k-pose graph: the persistent PCG kernel
+edges, rel, init = _synthetic_graph(10_000, 40_000, torch.float32)
+graph = PoseGraph(init)
+opt = pp.optim.LM(graph, solver=pp.optim.solver.PCG(tol=1e-4, maxiter=250), strategy=pp.optim.strategy.TrustRegion(radius=1e4))
+for _ in range(3):
+    opt.step((edges, rel))
+torch.cuda.synchronize()
+del graph, opt
+
 # C5: IMU 4096 x 1024 with covariance
 Bq, F = 4096, 1024
 dt = torch.full((Bq, F, 1), 0.005, device=dev)
