@@ -111,7 +111,11 @@ def _make_bwd(qualname, kernel, in_widths, out_widths):
 
         @staticmethod
         def backward(ctx, *grads):
-            raise NotImplementedError(f"{qualname}: double backward is not supported")
+            raise NotImplementedError(
+                f"{qualname}: double backward through the HIP Lie-group kernels is not supported (create_graph=True, Hessians, "
+                f"modjac(create_graph=True)): their backward passes are single kernels, not compositions of differentiable "
+                f"torch ops as in the reference (pypose/lietensor/operation.py).  First derivatives, vmap and "
+                f"jacobian(vectorize=True) are.")
 
         @staticmethod
         def vmap(info, in_dims, *ins):

@@ -207,6 +207,9 @@ class BlockLinearization:
         return self.op, self.Rb.reshape(-1, 1)
 
 
+_REPROBE = 64
+
+
 def _row_count(t):
     return t.numel() // t.shape[-1] if t.dim() >= 1 and t.shape[-1] > 0 else -1
 
@@ -219,6 +222,14 @@ def _linearize(opt, pg, input, target, weight, gauss_newton=False):
     equations (posegraph.GraphLinearization.solve_gauss_newton)."""
     params = [p for p in pg['params'] if p.requires_grad]
     cache = opt.__dict__.setdefault('_structure_cache', {})
+    # A structure verdict (block / graph / multi-parameter probe, fused-program cross-check) is keyed on shapes only; a
+    # model whose row dependence changes with its input values at fixed shapes would keep a stale "yes".  Positive
+    # verdicts therefore expire every _REPROBE linearisations and are re-established by a fresh probe (one extra
+    # vector-Jacobian product); negative ones stay (the dense path is always correct).
+    uses = cache['_uses'] = cache.get('_uses', 0) + 1
+    if uses % _REPROBE == 0:
+        for k in [k for k, v in cache.items() if v is True]:
+            cache[k] = None
     # Under torch.inference_mode nothing can be recorded for backward sweeps: only the reference's own
     # functional-jacobian linearisation (DenseLinearization) applies (tests/optim/test_optimizer.py:153-159).
     if getattr(opt, 'structured', True) and params and not torch.is_inference_mode_enabled():
