@@ -1,0 +1,84 @@
+"""The reference's sparse LM (tests/optim/test_sparse_lm.py cases + a two-parameter reprojection problem) on the MI355X:
+the `bae` plugin stand-in (pypose_amd/compat/bae) drives the reference's own optimizer code, the model's Lie ops are
+rebound to the HIP kernels by activate(pypose); iterates must equal the un-activated reference's on the CPU."""
+import warnings
+
+import pytest
+import torch
+
+from oracle import ref_loader
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not ref_loader.available(), reason="oracle/_ref not shipped")]
+warnings.filterwarnings("ignore", message="Sparse CSR tensor support is in beta")
+DEV = "cuda:0"
+
+from tests.bae_compat_util import load_reference, models, chain_problem, reproj_problem   # noqa: E402
+
+
+def _run(pp, case, dev, steps=3):
+    import pypose.optim.solver as ppos
+    _, Chain, Reproj = models(pp)
+    if case == "chain":
+        gt, edges, rel, init = chain_problem(pp, device=dev)
+        m, inp = Chain(gt[:1], init.clone()), (edges, rel)
+    else:
+        poses, pts, cam, pt, pixel, f = reproj_problem(pp, device=dev)
+        m, inp = Reproj(poses.clone(), pts.clone()), (cam, pt, pixel, f)
+    m = m.to(dev)
+    opt = pp.optim.LM(m, solver=ppos.PCG(maxiter=2000, tol=1e-14), strategy=pp.optim.strategy.Constant(damping=1e-3),
+                      sparse=True, min=1e-6)
+    losses = [opt.step(input=inp).item() for _ in range(steps)]
+    return losses, [torch.Tensor.as_subclass(p.detach(), torch.Tensor).cpu() for p in m.parameters()]
+
+
+@pytest.mark.parametrize("case", ["chain", "reproj"])
+def test_reference_sparse_lm_on_hip_kernels(case):
+    from pypose_amd import _C, activate
+    pp = load_reference()
+    want_l, want_p = _run(pp, case, "cpu")
+    activate.activate(pp)
+    try:
+        launched = []
+        real = _C.row_op
+        from pypose_amd.lietensor import operation as _op
+        _C.row_op = _op._C.row_op = lambda name, *a, **k: (launched.append(name), real(name, *a, **k))[1]
+        try:
+            got_l, got_p = _run(pp, case, DEV)
+        finally:
+            _C.row_op = _op._C.row_op = real
+    finally:
+        activate.deactivate()
+    need = {"se3_log_fwd", "se3_log_bwd", "se3_mul_fwd", "se3_mul_bwd"} if case == "chain" else {"se3_act_fwd", "se3_act_bwd"}
+    assert need <= set(launched), sorted(set(launched))
+    for g, w in zip(got_l, want_l):
+        assert g == pytest.approx(w, rel=1e-6, abs=1e-16)
+    for g, w in zip(got_p, want_p):
+        torch.testing.assert_close(g, w, rtol=1e-7, atol=1e-9)
+
+
+def test_reference_sparse_lm_cases_on_the_device():
+    """tests/optim/test_sparse_lm.py:43-150 as written there (cuda, float64, model.to(device)), un-activated"""
+    import pypose.optim.solver as ppos
+    pp = load_reference()
+    Identity, Chain, _ = models(pp)
+    torch.manual_seed(0)
+    dt = torch.float64
+    xt = torch.randn(8, 1, device=DEV, dtype=dt)
+    x0 = xt + 0.1 * torch.randn_like(xt)
+    m = Identity(x0).to(DEV)
+    opt = pp.optim.LM(m, solver=ppos.PCG(), strategy=pp.optim.strategy.Constant(damping=1e-6), sparse=True)
+    for _ in range(6):
+        loss = opt.step(input=(), target=xt).item()
+    torch.testing.assert_close(m.x.tensor(), xt, rtol=1e-4, atol=1e-4)
+    gt = pp.SE3(torch.tensor([[0., 0, 0, 0, 0, 0, 1], [1., 0, 0, 0, 0, 0, 1], [2., 0, 0, 0, 0, 0, 1]], device=DEV, dtype=dt))
+    edges = torch.tensor([[0, 1], [1, 2]], device=DEV)
+    rel = gt[edges[:, 0]].Inv() @ gt[edges[:, 1]]
+    init = gt[1:] * pp.randn_SE3(2, sigma=0.1, device=DEV, dtype=dt)
+    m = Chain(gt[:1], init).to(DEV)
+    opt = pp.optim.LM(m, solver=ppos.PCG(), strategy=pp.optim.strategy.Constant(damping=1e-4), sparse=True)
+    for _ in range(5):
+        loss = opt.step(input=(edges, rel)).item()
+        if loss < 1e-5:
+            break
+    assert loss < 1e-5
+    torch.testing.assert_close(pp.SE3(m.nodes).translation(), gt[1:].translation(), rtol=1e-3, atol=1e-3)
