@@ -157,7 +157,8 @@ class TrackingTensor(torch.Tensor):
     def __torch_function__(cls, func, types, args=(), kwargs=None):
         kwargs = kwargs or {}
         name = getattr(func, "__name__", "")
-        if name in ("__get__", "__set__", "__delete__") or name in _INFO or name.startswith("is_"):          # attribute access (requires_grad, grad, data, shape ...)
+        if name in ("__get__", "__set__", "__delete__") or name in _INFO or name.startswith("is_") \
+                or (getattr(func, "__module__", None) or "").startswith("torch.autograd"):        # attribute access (requires_grad, grad, data, shape ...)
             with torch._C.DisableTorchFunctionSubclass():
                 return func(*args, **kwargs)
         tracked = [a for a in args if isinstance(a, TrackingTensor)]

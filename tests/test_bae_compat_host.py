@@ -146,3 +146,42 @@ def test_diagonal_op_and_pcg():
     b = torch.randn(12, 1, generator=g, dtype=torch.float64)
     x = PCG(tol=1e-12)(A=S, b=b)
     torch.testing.assert_close(x, torch.linalg.solve(ref, b), rtol=1e-8, atol=1e-10)
+
+
+def test_reference_sparse_call_site_on_the_structured_optimizer(pp):
+    """install_bae() + activate(pypose, optim=True): the reference's sparse-LM call site as its users write it
+    (pp.Parameter(sjac=True), @psjac, solver.PCG, LM(sparse=True)) lands on pypose_amd's pose-graph linearisation and
+    walks the trajectory recorded from the reference's dense LM (tests/golden/lm_golden.npz, pgo40/noweight)."""
+    import numpy as np
+    from pypose_amd import activate
+    from tests.optim_models import load_lm_golden
+    from tests.oracle_backend import oracle_backend
+    from pypose.autograd.function import psjac
+    G = load_lm_golden()
+
+    @psjac
+    def err(n1, n2, poses):
+        return (poses.Inv() @ n1.Inv() @ n2).Log().tensor()
+
+    class PoseGraph(torch.nn.Module):
+        def __init__(self, nodes):
+            super().__init__()
+            self.nodes = pp.Parameter(nodes, sjac=True)
+
+        def forward(self, edges, poses):
+            return err(self.nodes[edges[..., 0]], self.nodes[edges[..., 1]], poses)
+
+    with oracle_backend():
+        activate.activate(pp, force=True, optim=True)
+        try:
+            edges = torch.from_numpy(G["pgo40/edges"])
+            poses = pp.SE3(torch.from_numpy(G["pgo40/poses"]))
+            graph = PoseGraph(pp.SE3(torch.from_numpy(G["pgo40/init"])))
+            opt = pp.optim.LM(graph, solver=pp.optim.solver.PCG(tol=1e-12), strategy=pp.optim.strategy.TrustRegion(radius=1e4),
+                              min=1e-6, sparse=True)
+            assert type(opt).__module__.startswith("pypose_amd")
+            losses = [float(opt.step((edges, poses))) for _ in range(4)]
+            assert opt.linearization == "graph"
+            np.testing.assert_allclose(losses, G["pgo40/noweight/loss"][:4], rtol=1e-7)
+        finally:
+            activate.deactivate()
