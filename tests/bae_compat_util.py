@@ -83,3 +83,41 @@ def reproj_problem(pp, C=4, N=30, dtype=torch.float64, device="cpu", seed=1):
     pts0 = pts + 0.05 * torch.randn(N, 3, generator=g, dtype=dtype)
     mv = lambda x: x.to(device)
     return mv(poses0), mv(pts0), mv(cam), mv(pt), mv(pixel), f
+
+
+def ba_example(pp, sjac, NC=5, NP=40, dtype=torch.float64, device="cpu"):
+    """examples/module/ba/bundle_adjustment.py:16-43 as written there (three tracked parameters: intrinsics, camera poses,
+    points; dict input), on a synthetic BAL-shaped problem"""
+    from pypose.autograd.function import psjac
+
+    class Reproj(nn.Module):
+        def __init__(self, K, C, P):
+            super().__init__()
+            self.K = pp.Parameter(K, sjac=True) if sjac else nn.Parameter(K)
+            self.C = pp.Parameter(C, sjac=sjac)
+            self.P = pp.Parameter(P, sjac=True) if sjac else nn.Parameter(P)
+
+        def forward(self, observe, cidx, pidx):
+            return Reproj.project(self.K[cidx], self.C[cidx], self.P[pidx]) - observe
+
+        @psjac
+        def project(K, C, P):
+            cp = C.Act(P)
+            n = - cp[..., :2] / cp[..., [2]]
+            radius = n.square().sum(dim=-1, keepdim=True)
+            focal, k1, k2 = K[..., :1], K[..., 1:2], K[..., 2:3]
+            distortion = 1 + k1 * radius + k2 * radius.square()
+            return focal * distortion * n
+
+    g = torch.Generator().manual_seed(0)
+    P = torch.randn(NP, 3, generator=g, dtype=dtype)
+    P[:, 2] -= 6
+    C = pp.se3(0.1 * torch.randn(NC, 6, generator=g, dtype=dtype)).Exp()
+    K = torch.tensor([[500., 1e-2, 1e-4]], dtype=dtype).repeat(NC, 1)
+    cidx, pidx = torch.arange(NC).repeat_interleave(NP), torch.arange(NP).repeat(NC)
+    obs = Reproj.project(K[cidx], C[cidx], P[pidx])
+    C0 = C * pp.se3(0.01 * torch.randn(NC, 6, generator=g, dtype=dtype)).Exp()
+    P0 = P + 0.02 * torch.randn(NP, 3, generator=g, dtype=dtype)
+    K0 = K * (1 + 0.01 * torch.randn(NC, 3, generator=g, dtype=dtype))
+    inp = {"observe": obs.to(device), "cidx": cidx.to(device), "pidx": pidx.to(device)}
+    return Reproj(K0.to(device), C0.to(device), P0.to(device)).to(device), inp

@@ -12,7 +12,7 @@ pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not ref_loader.available(), re
 warnings.filterwarnings("ignore", message="Sparse CSR tensor support is in beta")
 DEV = "cuda:0"
 
-from tests.bae_compat_util import load_reference, models, chain_problem, reproj_problem   # noqa: E402
+from tests.bae_compat_util import load_reference, models, chain_problem, reproj_problem, ba_example   # noqa: E402
 
 
 def _run(pp, case, dev, steps=3):
@@ -118,3 +118,27 @@ def test_reference_sparse_call_site_on_the_fused_pose_graph_path():
         np.testing.assert_allclose(losses, G["pgo40/noweight/loss"][:4], rtol=1e-7)
     finally:
         activate.deactivate()
+
+
+def test_reference_ba_example_model_on_the_device():
+    """examples/module/ba/bundle_adjustment.py:16-43, 71-73 on the MI355X: the reference's sparse LM over the stand-in with
+    HIP Lie kernels (activate), and the same call site on pypose_amd's optimizer (activate(optim=True)); both equal the
+    reference's dense LM on the CPU"""
+    from pypose_amd import activate
+    pp = load_reference()
+    from pypose.optim.solver import PCG, Cholesky
+    strat = lambda: pp.optim.strategy.TrustRegion(up=2.0, down=0.5 ** 4)
+    md, inp = ba_example(pp, False)
+    od = pp.optim.LM(md, solver=Cholesky(), strategy=strat(), reject=30, vectorize=True)
+    want = [od.step(inp).item() for _ in range(3)]
+    for optim in (False, True):
+        activate.activate(pp, optim=optim)
+        try:
+            m, inp = ba_example(pp, True, device=DEV)
+            opt = pp.optim.LM(m, solver=pp.optim.solver.PCG(tol=1e-14, maxiter=5000), strategy=strat(), reject=30, sparse=True)
+            assert type(opt).__module__.startswith("pypose_amd" if optim else "pypose.")
+            got = [opt.step(inp).item() for _ in range(3)]
+        finally:
+            activate.deactivate()
+        for g, w in zip(got, want):
+            assert g == pytest.approx(w, rel=1e-6, abs=1e-15), (optim, got, want)

@@ -11,7 +11,7 @@ from oracle import ref_loader
 pytestmark = pytest.mark.skipif(not ref_loader.available(), reason="oracle/_ref not shipped")
 warnings.filterwarnings("ignore", message="Sparse CSR tensor support is in beta")
 
-from tests.bae_compat_util import load_reference, models, chain_problem, reproj_problem   # noqa: E402
+from tests.bae_compat_util import load_reference, models, chain_problem, reproj_problem, ba_example   # noqa: E402
 
 
 @pytest.fixture(scope="module")
@@ -185,3 +185,36 @@ def test_reference_sparse_call_site_on_the_structured_optimizer(pp):
             np.testing.assert_allclose(losses, G["pgo40/noweight/loss"][:4], rtol=1e-7)
         finally:
             activate.deactivate()
+
+
+def test_reference_ba_example_model(pp):
+    """the reference's bundle-adjustment example model and optimizer lines (examples/module/ba/bundle_adjustment.py:16-43,
+    71-73) unmodified: (a) through the reference's own sparse LM on the stand-in == the reference's dense LM;
+    (b) under activate(optim=True) on pypose_amd's multi-parameter graph linearisation == the same iterates"""
+    from pypose.optim import LM
+    from pypose.optim.solver import PCG, Cholesky
+    from pypose_amd import activate
+    from tests.oracle_backend import oracle_backend
+    strat = lambda: pp.optim.strategy.TrustRegion(up=2.0, down=0.5 ** 4)
+    ms, inp = ba_example(pp, True)
+    md, _ = ba_example(pp, False)
+    os_ = LM(ms, solver=PCG(tol=1e-14, maxiter=5000), strategy=strat(), reject=30, sparse=True)
+    od = LM(md, solver=Cholesky(), strategy=strat(), reject=30, vectorize=True)
+    want = []
+    for _ in range(3):
+        ls, ld = os_.step(inp).item(), od.step(inp).item()
+        assert ls == pytest.approx(ld, rel=1e-6, abs=1e-16)
+        want.append(ld)
+    assert want[-1] < 1e-8 * want[0]
+    with oracle_backend():
+        activate.activate(pp, force=True, optim=True)
+        try:
+            ma, inp = ba_example(pp, True)
+            oa = pp.optim.LM(ma, solver=pp.optim.solver.PCG(tol=1e-14, maxiter=5000), strategy=strat(), reject=30, sparse=True)
+            assert type(oa).__module__.startswith("pypose_amd")
+            got = [oa.step(inp).item() for _ in range(3)]
+            assert oa.linearization == "multigraph"
+        finally:
+            activate.deactivate()
+    for g, w in zip(got, want):
+        assert g == pytest.approx(w, rel=1e-6, abs=1e-16)
