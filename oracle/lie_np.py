@@ -758,6 +758,53 @@ OPS["so3_jr_fwd"] = so3_jr_fwd
 OPS["so3_jr_bwd"] = so3_jr_bwd
 # compositions of the above (no golden of their own): p.add_(d) of the optimizers (lietensor.py:60-65),
 # Exp(d[:da]) * p with the step d zero-padded to the group width
+# ---- pinhole reprojection with closed-form blocks (function/geometry.py:37-57 homo2cart, :60-113 point2pixel, :171-226 reprojerr)
+def _reproj_parts(X, p, cam):
+    q = se3_act_fwd(X, p)[0]
+    K = cam[:, :9].reshape(-1, 3, 3)
+    h = _mv(K, q)
+    hz = h[:, 2]
+    tiny = np.finfo(X.dtype).tiny
+    az = np.abs(hz)
+    clamped = az < tiny
+    den = np.where(hz < 0, -1.0, 1.0).astype(X.dtype) * np.maximum(az, tiny)     # pm(0) = +1
+    return q, K, h, den, clamped
+
+
+def se3_reproj_fwd(X, p, cam):
+    """reprojerr(points, pixels, K, pose, reduction='none') for one (pose, point) pair per row: geometry.py:224-226"""
+    q, K, h, den, _ = _reproj_parts(X, p, cam)
+    return (h[:, :2] / den[:, None] - cam[:, 9:11],)
+
+
+def se3_reproj_lin(X, p, cam):
+    """the residual and its Jacobian blocks [d r/d pose (2x6) | d r/d point (2x3)] in closed form: chain rule through
+    homo2cart (abs().clamp_() passes no gradient where it clamps), K, and SE3_Act.backward's [I | -skew(q)] / R (op.py:561-568)"""
+    q, K, h, den, clamped = _reproj_parts(X, p, cam)
+    n = X.shape[0]
+    inv = 1.0 / den
+    pix = h[:, :2] * inv[:, None]
+    D = np.zeros((n, 2, 3), dtype=X.dtype)
+    D[:, 0, 0] = inv
+    D[:, 1, 1] = inv
+    D[:, :, 2] = -pix * np.where(clamped, 0.0, inv)[:, None]
+    M = D @ K                                                     # [n, 2, 3]
+    Jq = np.concatenate([np.broadcast_to(np.eye(3, dtype=X.dtype), (n, 3, 3)), -vec2skew(q)], -1)    # [n, 3, 6]
+    R = SE3_Matrix(X)[:, :3, :3]
+    J = np.concatenate([M @ Jq, M @ R], -1)                        # [n, 2, 9]
+    return (pix - cam[:, 9:11], J.reshape(n, 18))
+
+
+def reproj_vjp(J, g):
+    Jm = J.reshape(-1, 2, 9)
+    v = _vm(g, Jm)
+    return (np.concatenate([v[:, :6], _zero_col(J)], -1), v[:, 6:9])
+
+
+OPS["se3_reproj_fwd"] = se3_reproj_fwd
+OPS["se3_reproj_lin"] = se3_reproj_lin
+OPS["reproj_vjp"] = reproj_vjp
+
 COMPOSED_OPS = {}
 for _g, (_da, _dg) in GROUPS.items():
     COMPOSED_OPS[f"{_g}_retract"] = (lambda g, da: lambda d, X: (

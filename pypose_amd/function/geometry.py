@@ -2,12 +2,77 @@
 
 Host-side mirror of the five pinhole helpers of pypose/function/geometry.py (cart2homo :8, homo2cart :37,
 point2pixel :60, pixel2point :115, reprojerr :171): same names, argument meaning, broadcasting and assertion
-messages.  The rigid transform inside ``point2pixel`` is the HIP ``SE3_Act`` kernel (autograd included); the
-pinhole algebra around it is plain tensor arithmetic on whatever device the inputs live on.
+messages.  With extrinsics, ``point2pixel`` / ``reprojerr`` are ONE kernel per direction (csrc/reproj.hip): the forward
+``pplie_se3_reproj_lin`` returns the residual together with its closed-form Jacobian blocks [d r/d pose | d r/d point],
+the backward ``pplie_reproj_vjp`` contracts them -- and the LM optimizers take the blocks as they are instead of
+sweeping the autograd graph (``closed_form_blocks`` below, optim/multigraph.py).  Without extrinsics the pinhole
+algebra is plain tensor arithmetic on whatever device the inputs live on.
 """
 import torch
 
 from ..lietensor import LieTensor
+from ..lietensor import operation as _op
+
+_ReprojVjp = _op._make_bwd("ReprojVjp", "reproj_vjp", (18, 2), (7, 3))
+_closed_recorders = []          # optim: active recorders of (residual, inputs, closed-form blocks)
+
+
+class _Reproj(torch.autograd.Function):
+    """r = homo2cart(K (X . p)) - pixel for broadcastable (pose [...,7], point [...,3], cam [...,11]); saves J [...,18]."""
+
+    @staticmethod
+    def forward(X, p, cam):
+        r, J = _op._launch("se3_reproj_lin", (X, p, cam), (7, 3, 11), (2, 18))
+        return r, J
+
+    @staticmethod
+    def setup_context(ctx, inputs, output):
+        ctx.save_for_backward(*inputs, output[1])
+        ctx.mark_non_differentiable(output[1])
+        ctx.shapes = [tuple(t.shape) for t in inputs]
+
+    @staticmethod
+    def backward(ctx, g, _gJ):
+        X, p, cam, J = ctx.saved_tensors
+        gX, gp = _ReprojVjp.apply(J, g)
+        gcam = None
+        if ctx.needs_input_grad[2]:
+            # intrinsics / observed pixel (rarely optimised): d r/d K = (d pix/d h) (x) q, d r/d pixel = -I
+            q = _op._launch("se3_act_fwd", (X, p), (7, 3), (3,))[0]
+            K = cam[..., :9].reshape(cam.shape[:-1] + (3, 3))
+            h = (K @ q.unsqueeze(-1)).squeeze(-1)
+            hz = h[..., 2:]
+            tiny = torch.finfo(h.dtype).tiny
+            clamped = hz.abs() < tiny
+            den = torch.where(hz < 0, -torch.ones_like(hz), torch.ones_like(hz)) * hz.abs().clamp(min=tiny)
+            pix = h[..., :2] / den
+            gh = torch.cat([g / den, -(pix * g).sum(-1, keepdim=True) / den * (~clamped)], -1)
+            gcam = torch.cat([(gh.unsqueeze(-1) * q.unsqueeze(-2)).reshape(gh.shape[:-1] + (9,)), -g], -1)
+        out = []
+        for grad, shape in zip((gX, gp, gcam), ctx.shapes):
+            out.append(None if grad is None else grad.sum_to_size(shape) if tuple(grad.shape) != shape else grad)
+        return tuple(out)
+
+    @staticmethod
+    def vmap(info, in_dims, X, p, cam):
+        X, p, cam = _op._fold_vmap(in_dims, (X, p, cam))
+        return _Reproj.apply(X, p, cam), (0, 0)
+
+
+def _reproject(points, intrinsics, extrinsics, pixels):
+    """(..., N, 2) residual through the fused kernels; the closed-form blocks are offered to an active optimizer trace."""
+    X = extrinsics.tensor().unsqueeze(-2)                                           # (..., 1, 7): one pose, N points
+    K9 = intrinsics.reshape(intrinsics.shape[:-2] + (1, 9))
+    lead = torch.broadcast_shapes(points.shape[:-1], X.shape[:-1], K9.shape[:-1], pixels.shape[:-1] if pixels is not None else ())
+    uv = pixels if pixels is not None else points.new_zeros(lead + (2,))
+    cam = torch.cat([K9.expand(lead + (9,)).to(points.dtype), uv.expand(lead + (2,))], -1)
+    r, J = _Reproj.apply(X, points, cam)
+    if _closed_recorders:
+        Jm = J.reshape(J.shape[:-1] + (2, 9))
+        for rec in _closed_recorders:
+            rec.note_closed(r, [(extrinsics, Jm[..., :6]), (points, Jm[..., 6:9])],
+                            blockers=[t for t in (intrinsics, pixels) if t is not None and t.requires_grad])
+    return r
 
 
 def _need(cond, msg):
@@ -42,8 +107,9 @@ def point2pixel(points, intrinsics, extrinsics=None):
         _need(isinstance(extrinsics, LieTensor) and extrinsics.shape[-1] == 7, "Type incorrect.")
         lead.append(extrinsics.shape[:-1])
     torch.broadcast_shapes(*lead)                                      # raises on incompatible batch dims
-    cam = points if extrinsics is None else extrinsics.unsqueeze(-2).Act(points)
-    return homo2cart(cam @ intrinsics.mT)
+    if extrinsics is not None:
+        return _reproject(points, intrinsics, extrinsics, None)
+    return homo2cart(points @ intrinsics.mT)
 
 
 def pixel2point(pixels, depth, intrinsics):
@@ -64,7 +130,12 @@ def reprojerr(points, pixels, intrinsics, extrinsics=None, reduction='none'):
     torch.broadcast_shapes(points.shape[:-2], pixels.shape[:-2], intrinsics.shape[:-2])
     _need(points.size(-1) == 3 and pixels.size(-1) == 2 and _is_k(intrinsics), "Shape not compatible.")
     _need(reduction in {'norm', 'sum', 'none'}, "Reduction method can only be 'norm'|'sum'|'none'.")
-    err = point2pixel(points, intrinsics, extrinsics) - pixels
+    if extrinsics is not None:
+        _need(isinstance(extrinsics, LieTensor) and extrinsics.shape[-1] == 7, "Type incorrect.")
+        torch.broadcast_shapes(points.shape[:-2], intrinsics.shape[:-2], extrinsics.shape[:-1])
+        err = _reproject(points, intrinsics, extrinsics, pixels)
+    else:
+        err = point2pixel(points, intrinsics) - pixels
     return {'none': lambda e: e, 'norm': lambda e: e.norm(dim=-1), 'sum': lambda e: e.sum(dim=-1)}[reduction](err)
 
 

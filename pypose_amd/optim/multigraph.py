@@ -574,6 +574,7 @@ def try_multigraph_linearization(opt, pg, input, target, weight, R, params, rec,
         return None
     outs_all = [out for _, _, out in events]
     parts = []
+    closed = True
     with torch.enable_grad():
         for r in R:
             dr = r.shape[-1]
@@ -586,7 +587,10 @@ def try_multigraph_linearization(opt, pg, input, target, weight, R, params, rec,
             if not mine or any(ix.numel() != E for _, ix, _ in mine):
                 cache[key] = False
                 return None
-            Jcat = _blocks.jacobian_blocks([r], [out for _, _, out in mine])    # [E, dr, sum widths]
+            Jcat = rec.closed_blocks(r, mine) if getattr(opt, "closed_form", True) else None   # [E, dr, sum widths]
+            closed = closed and Jcat is not None
+            if Jcat is None:
+                Jcat = _blocks.jacobian_blocks([r], [out for _, _, out in mine])
             parts.append((r, E, dr, mine, Jcat))
         if cache.get(key) is None:
             # probe: u^T dR/dparams by one real backward == scatter-add of the per-observation blocks
@@ -644,4 +648,5 @@ def try_multigraph_linearization(opt, pg, input, target, weight, R, params, rec,
             off += m
         rows0 += E
     slots = [(k, ix, J) for (k, _), (ix, J) in sorted(slot_of.items())]
+    opt._last_blocks = "closed-form" if closed else "autograd"
     return MultiGraphLinearization(opt, torch.cat(Ws) if weighted else None, torch.cat(Rs), params, slots)

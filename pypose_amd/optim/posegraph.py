@@ -65,8 +65,42 @@ class GatherRecorder:
     def __init__(self, params):
         self.ids = {id(p): p for p in params}
         self.events = []      # (param, index LongTensor [E], gathered rows [E, w])
+        self.closed = []      # (residual, [(input tensor, d residual / d input blocks)], blockers): ops that know their Jacobian
+
+    def note_closed(self, residual, inputs, blockers=()):
+        self.closed.append((residual, list(inputs), list(blockers)))
+
+    def closed_blocks(self, r, mine):
+        """``[E, dr, sum widths]`` blocks of residual ``r`` with respect to the gathered rows ``mine`` when ``r`` is the output
+        of an op that handed over its own closed-form Jacobian (function/geometry.py reprojerr) and every input of that op is
+        one of the gathers, row for row; None otherwise (the caller sweeps the autograd graph)."""
+        for cr, inputs, blockers in self.closed:
+            if blockers or cr.data_ptr() != r.data_ptr() or cr.numel() != r.numel() or cr.dtype != r.dtype:
+                continue
+            dr = r.shape[-1]
+            E = r.numel() // dr
+            cols, used = [], set()
+            for src, ix, out in mine:
+                hit = [k for k, (inp, blk) in enumerate(inputs) if inp.data_ptr() == out.data_ptr() and inp.numel() == out.numel()
+                       and k not in used]
+                if len(hit) != 1 or inputs[hit[0]][1].numel() % (E * dr) != 0:
+                    return None
+                used.add(hit[0])
+                blk = inputs[hit[0]][1].reshape(E, dr, -1)
+                w = src.shape[-1]
+                if blk.shape[-1] > w:
+                    return None
+                if blk.shape[-1] < w:          # group parameters: tangent blocks, zero-padded to the stored width like their gradients
+                    blk = torch.cat([blk, blk.new_zeros((E, dr, w - blk.shape[-1]))], -1)
+                cols.append(blk)
+            if any(inp.requires_grad for k, (inp, _) in enumerate(inputs) if k not in used):
+                return None
+            return torch.cat(cols, -1).contiguous()
+        return None
 
     def __enter__(self):
+        from ..function import geometry as _geo
+        _geo._closed_recorders.append(self)
         _lt._gather_recorders.append(self)
         # plain nn.Parameters (e.g. intrinsics / 3-D points of a bundle-adjustment model) do not pass through
         # LieTensor.__torch_function__: a TorchFunctionMode sees their ``param[index]`` too
@@ -79,6 +113,8 @@ class GatherRecorder:
         if self._mode is not None:
             self._mode.__exit__(*exc)
         _lt._gather_recorders.remove(self)
+        from ..function import geometry as _geo
+        _geo._closed_recorders.remove(self)
 
     def note(self, source, index, out):
         # gathers on a tracked parameter, or on a tensor derived from one (e.g. ``cat((root, nodes))`` in
