@@ -455,7 +455,9 @@ extern "C" int pplie_graph_bsr_spmv_f64(const void* ptr, const void* other, cons
 // (The edge-parallel kernel above needs 84 atomics per edge: 1.65 ms per LM step at 4e5 edges vs 0.1 ms.)
 // ---------------------------------------------------------------------------------------------
 namespace pplie {
-template <class T, int DR, int M, int K, bool HAS_W>
+//   SYM: HB is [E, M, M], one block per EDGE (the side-0 incidence writes H_e = J_0^T W J_1; the side-1 incidence of the
+//   same edge needs H_e^T, which the SpMV reads transposed) -- valid for symmetric W; halves the off-diagonal bytes.
+template <class T, int DR, int M, int K, bool HAS_W, bool SYM = false>
 __global__ void __launch_bounds__(256)
 graph_assemble_csr_kernel(const int* __restrict__ ptr, const int* __restrict__ blk, const T* __restrict__ J,
                           const T* __restrict__ W, const T* __restrict__ R, T* __restrict__ Bdiag, T* __restrict__ grad,
@@ -497,7 +499,7 @@ graph_assemble_csr_kernel(const int* __restrict__ ptr, const int* __restrict__ b
           for (int b = 0; b < M; ++b) row[b] += v[l] * Jc[l * M + b];
         }
         if constexpr (K == 2) {
-          if (HB) {   // row i of J_c^T W J_far: the block that multiplies the far node in q_n = sum_c HB[c] p[other[c]]
+          if (HB && (!SYM || (bk & 1) == 0)) {   // row i of J_c^T W J_far: the block that multiplies the far node in q_n = sum_c HB[c] p[other[c]]
             const T* Jo = J + (bk ^ 1) * (DR * M);
             T hb[M];
 #pragma unroll
@@ -507,7 +509,7 @@ graph_assemble_csr_kernel(const int* __restrict__ ptr, const int* __restrict__ b
 #pragma unroll
               for (int b = 0; b < M; ++b) hb[b] += v[l] * Jo[l * M + b];
 #pragma unroll
-            for (int b = 0; b < M; ++b) HB[((int64_t)c * M + i) * M + b] = hb[b];
+            for (int b = 0; b < M; ++b) HB[((SYM ? e : (int64_t)c) * M + i) * M + b] = hb[b];
           }
         }
       }
@@ -520,13 +522,22 @@ graph_assemble_csr_kernel(const int* __restrict__ ptr, const int* __restrict__ b
 
 template <class T, int DR, int M, int K>
 int graph_assemble_csr_launch(const void* ptr, const void* blk, const void* J, const void* W, const void* R, void* B, void* g,
-                              void* HB, int64_t N, void* stream) {
+                              void* HB, int64_t N, void* stream, bool sym = false) {
   if (N <= 0) return N == 0 ? PPLIE_OK : PPLIE_EBADARG;
   if (!ptr || !blk || !J || !R || !B || !g) return PPLIE_EBADARG;
   constexpr int NPW = 64 / M;
   int64_t blocks = ((N + NPW - 1) / NPW + 3) / 4;
   int grid = (int)(blocks < (1 << 20) ? blocks : (1 << 20));
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (sym && K == 2 && HB) {
+    if (W)
+      hipLaunchKernelGGL((graph_assemble_csr_kernel<T, DR, M, K, true, true>), dim3(grid), dim3(256), 0, st, (const int*)ptr,
+                         (const int*)blk, (const T*)J, (const T*)W, (const T*)R, (T*)B, (T*)g, (T*)HB, N);
+    else
+      hipLaunchKernelGGL((graph_assemble_csr_kernel<T, DR, M, K, false, true>), dim3(grid), dim3(256), 0, st, (const int*)ptr,
+                         (const int*)blk, (const T*)J, (const T*)nullptr, (const T*)R, (T*)B, (T*)g, (T*)HB, N);
+    return hipGetLastError() == hipSuccess ? PPLIE_OK : PPLIE_ELAUNCH;
+  }
   if (W)
     hipLaunchKernelGGL((graph_assemble_csr_kernel<T, DR, M, K, true>), dim3(grid), dim3(256), 0, st, (const int*)ptr,
                        (const int*)blk, (const T*)J, (const T*)W, (const T*)R, (T*)B, (T*)g, (T*)HB, N);
@@ -537,9 +548,9 @@ int graph_assemble_csr_launch(const void* ptr, const void* blk, const void* J, c
 }
 template <class T>
 int graph_assemble_csr_dispatch(int dr, int m, int k, const void* ptr, const void* blk, const void* J, const void* W,
-                                const void* R, void* B, void* g, void* HB, int64_t N, void* stream) {
+                                const void* R, void* B, void* g, void* HB, int64_t N, void* stream, bool sym = false) {
 #define X(A, B_, C) \
-  if (dr == A && m == B_ && k == C) return graph_assemble_csr_launch<T, A, B_, C>(ptr, blk, J, W, R, B, g, HB, N, stream);
+  if (dr == A && m == B_ && k == C) return graph_assemble_csr_launch<T, A, B_, C>(ptr, blk, J, W, R, B, g, HB, N, stream, sym);
   PPLIE_GRAPH_SHAPES(X)
 #undef X
   return PPLIE_EBADARG;
@@ -553,6 +564,16 @@ extern "C" int pplie_graph_assemble_csr_f32(const void* ptr, const void* blk, co
 extern "C" int pplie_graph_assemble_csr_f64(const void* ptr, const void* blk, const void* J, const void* W, const void* R,
                                             void* Bdiag, void* grad, void* HB, int64_t N, int dr, int m, int k, void* stream) {
   return pplie::graph_assemble_csr_dispatch<double>(dr, m, k, ptr, blk, J, W, R, Bdiag, grad, HB, N, stream);
+}
+
+// the same with ONE off-diagonal block per edge: HB [E, M, M] = J_0^T W J_1 (W symmetric; pplie_pcg2_spmv_sym reads it)
+extern "C" int pplie_graph_assemble_csr_sym_f32(const void* ptr, const void* blk, const void* J, const void* W, const void* R,
+                                                void* Bdiag, void* grad, void* HB, int64_t N, int dr, int m, int k, void* stream) {
+  return pplie::graph_assemble_csr_dispatch<float>(dr, m, k, ptr, blk, J, W, R, Bdiag, grad, HB, N, stream, true);
+}
+extern "C" int pplie_graph_assemble_csr_sym_f64(const void* ptr, const void* blk, const void* J, const void* W, const void* R,
+                                                void* Bdiag, void* grad, void* HB, int64_t N, int dr, int m, int k, void* stream) {
+  return pplie::graph_assemble_csr_dispatch<double>(dr, m, k, ptr, blk, J, W, R, Bdiag, grad, HB, N, stream, true);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -762,11 +783,12 @@ namespace pplie {
 enum { Q2_RHO = 0, Q2_PQ = 1, Q2_RR = 2, Q2_BN2 = 3, Q2_QZ = 4, Q2_QMQ = 5, Q2_COUNT = 8 };
 template <class T> __device__ __forceinline__ T* squant2(T* scal, int set, int q) { return scal + (size_t)((set * Q2_COUNT + q) * kSlots) * kStride; }
 
-template <class T, int M>
+// SYM: HB holds one block per edge, blk[c] = 2 edge + side says which and whether this incidence reads it transposed
+template <class T, int M, bool SYM = false>
 __global__ void __launch_bounds__(256)
 pcg2_spmv_kernel(const int* __restrict__ ptr, const int* __restrict__ other, const T* __restrict__ HB, const T* __restrict__ D,
                  const T* __restrict__ Binv, const T* __restrict__ p, const T* __restrict__ z, T* __restrict__ q, T* scal,
-                 T* __restrict__ rr_hist, int* it, int cap, int64_t N) {
+                 T* __restrict__ rr_hist, int* it, int cap, int64_t N, const int* __restrict__ blk = nullptr) {
   constexpr int NPW = 64 / M;
   const int done = it[0];
   const int a = done & 1;
@@ -804,13 +826,23 @@ pcg2_spmv_kernel(const int* __restrict__ ptr, const int* __restrict__ other, con
       for (int c = beg; c < end; c += 2) {
         const bool two = c + 1 < end;
         const int64_t o0 = other[c], o1 = two ? other[c + 1] : o0;
-        const T* h0 = HB + ((int64_t)c * M + i) * M;
-        const T* h1 = two ? h0 + M * M : h0;
         const T* p0 = p + o0 * M;
         const T* p1 = p + o1 * M;
         T s0 = T(0), s1 = T(0);
+        if constexpr (SYM) {
+          const int b0 = blk[c], b1 = two ? blk[c + 1] : b0;
+          const T* h0 = HB + (int64_t)(b0 >> 1) * (M * M);
+          const T* h1 = HB + (int64_t)(b1 >> 1) * (M * M);
+          const int r0 = (b0 & 1) ? 1 : M, c0 = (b0 & 1) ? M : 1;        // element (i, j) of H or of H^T
+          const int r1 = (b1 & 1) ? 1 : M, c1 = (b1 & 1) ? M : 1;
 #pragma unroll
-        for (int j = 0; j < M; ++j) { s0 += h0[j] * p0[j]; s1 += h1[j] * p1[j]; }
+          for (int j = 0; j < M; ++j) { s0 += h0[i * r0 + j * c0] * p0[j]; s1 += h1[i * r1 + j * c1] * p1[j]; }
+        } else {
+          const T* h0 = HB + ((int64_t)c * M + i) * M;
+          const T* h1 = two ? h0 + M * M : h0;
+#pragma unroll
+          for (int j = 0; j < M; ++j) { s0 += h0[j] * p0[j]; s1 += h1[j] * p1[j]; }
+        }
         acc += two ? s0 + s1 : s0;
       }
       q[n * M + i] = acc;
@@ -838,38 +870,79 @@ pcg2_spmv_kernel(const int* __restrict__ ptr, const int* __restrict__ other, con
   }
 }
 
-template <class T>
+// the sum of a quantity's kSlots slots, fetched ONCE per workgroup (wave 0: one slot per lane of each half... lanes 0-31) and
+// handed to every thread through LDS: with every wave reading all 4 x 32 slot lines itself, the ~8k waves of the step kernel
+// put a million requests on the same 128 L2 lines -- that, not the vector update, was most of its 15.6 us at 10^5 nodes
+template <class T, int NQ>
+__device__ __forceinline__ void slot_totals_wg(const T* const (&base)[NQ], T (&out)[NQ]) {
+  __shared__ T tot[NQ];
+  if (threadIdx.x < 64) {
+    const int lane = threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < NQ; ++k) {
+      T v = lane < kSlots ? base[k][lane * kStride] : T(0);
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+      if (lane == 0) tot[k] = v;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < NQ; ++k) out[k] = tot[k];
+}
+
+// M lanes per node (the spmv kernel's layout): lane i owns component i, the node's new residual goes round its lanes by
+// shuffles -- 10 loads per component instead of 21
+template <class T, int M>
 __global__ void __launch_bounds__(256)
 pcg2_step_kernel(T* __restrict__ x, T* r0, T* r1, T* __restrict__ p, const T* __restrict__ q, T* __restrict__ z,
-                 const T* __restrict__ Binv, T* scal, int* it, int64_t N, int m) {
+                 const T* __restrict__ Binv, T* scal, int* it, int64_t N) {
+  constexpr int NPW = 64 / M;
   const int done = it[1];
   const int a = done & 1;
   const T* __restrict__ rin = a ? r1 : r0;                       // residual of this iteration; the new one goes to the other
   T* __restrict__ rout = a ? r0 : r1;
-  const T rho = slot_total(squant2(scal, a, Q2_RHO)), pq = slot_total(squant2(scal, a, Q2_PQ));
-  const T qz = slot_total(squant2(scal, a, Q2_QZ)), qmq = slot_total(squant2(scal, a, Q2_QMQ));
+  const T* const bases[4] = {squant2(scal, a, Q2_RHO), squant2(scal, a, Q2_PQ), squant2(scal, a, Q2_QZ), squant2(scal, a, Q2_QMQ)};
+  T tv[4];
+  slot_totals_wg<T, 4>(bases, tv);
+  const T rho = tv[0], pq = tv[1], qz = tv[2], qmq = tv[3];
   const T alpha = pq != T(0) ? rho / pq : T(0);                 // p.q = 0 only once r = 0: stay put, no NaN
   T rho_rec = rho - T(2) * alpha * qz + alpha * alpha * qmq;
   if (rho_rec < T(0)) rho_rec = T(0);
   const T beta = rho != T(0) ? rho_rec / rho : T(0);
   T a1 = T(0), a2 = T(0);
-  const int64_t total = N * m;
-  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
-    const int64_t nidx = e / m;
-    const int i = (int)(e - nidx * m);
-    T ze = T(0), re = T(0);
-    for (int j = 0; j < m; ++j) {
-      const T rj = rin[nidx * m + j] - alpha * q[nidx * m + j];
-      if (j == i) re = rj;
-      ze += Binv[e * m + j] * rj;
+  const int lane = threadIdx.x & 63;
+  const int sub = lane / M, i = lane % M;
+  const bool active_lane = sub < NPW;
+  const int64_t wave = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * 256) >> 6;
+  for (int64_t base = wave * NPW; base < N; base += nwaves * NPW) {
+    const int64_t n = base + sub;
+    const bool act = active_lane && n < N;
+    const int64_t e = n * M + i;
+    T re = T(0), pe = T(0), xe = T(0);
+    T brow[M];
+    if (act) {
+      re = rin[e] - alpha * q[e];
+      pe = p[e];
+      xe = x[e];
+#pragma unroll
+      for (int j = 0; j < M; ++j) brow[j] = Binv[e * M + j];
     }
-    const T pe = p[e];
-    x[e] += alpha * pe;
-    rout[e] = re;
-    z[e] = ze;
-    p[e] = ze + beta * pe;
-    a1 += re * ze;
-    a2 += re * re;
+    T ze = T(0);
+#pragma unroll
+    for (int j = 0; j < M; ++j) {
+      const T rj = __shfl(re, sub * M + j, 64);
+      if (act) ze += brow[j] * rj;
+    }
+    if (act) {
+      x[e] = xe + alpha * pe;
+      rout[e] = re;
+      z[e] = ze;
+      p[e] = ze + beta * pe;
+      a1 += re * ze;
+      a2 += re * re;
+    }
   }
   T s1 = block_sum(a1);
   T s2 = block_sum(a2);
@@ -882,7 +955,7 @@ pcg2_step_kernel(T* __restrict__ x, T* r0, T* r1, T* __restrict__ p, const T* __
 
 template <class T>
 int pcg2_spmv(const void* ptr, const void* other, const void* HB, const void* D, const void* Binv, const void* p, const void* z,
-              void* q, void* scal, void* rr_hist, void* it, int cap, int64_t N, int m, void* stream) {
+              void* q, void* scal, void* rr_hist, void* it, int cap, int64_t N, int m, void* stream, const void* blk = nullptr) {
   if (N <= 0) return N == 0 ? PPLIE_OK : PPLIE_EBADARG;
   if (!ptr || !other || !HB || !D || !Binv || !p || !z || !q || !scal || !rr_hist || !it) return PPLIE_EBADARG;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -891,9 +964,14 @@ int pcg2_spmv(const void* ptr, const void* other, const void* HB, const void* D,
     int64_t waves = (N + (64 / MM) - 1) / (64 / MM);                                                                  \
     int64_t blocks = (waves + 3) / 4;                                                                                 \
     int grid = (int)(blocks < 4096 ? blocks : 4096);                                                                  \
-    hipLaunchKernelGGL((pcg2_spmv_kernel<T, MM>), dim3(grid), dim3(256), 0, st, (const int*)ptr, (const int*)other,   \
-                       (const T*)HB, (const T*)D, (const T*)Binv, (const T*)p, (const T*)z, (T*)q, (T*)scal,          \
-                       (T*)rr_hist, (int*)it, cap, N);                                                                \
+    if (blk)                                                                                                          \
+      hipLaunchKernelGGL((pcg2_spmv_kernel<T, MM, true>), dim3(grid), dim3(256), 0, st, (const int*)ptr, (const int*)other, \
+                         (const T*)HB, (const T*)D, (const T*)Binv, (const T*)p, (const T*)z, (T*)q, (T*)scal,        \
+                         (T*)rr_hist, (int*)it, cap, N, (const int*)blk);                                             \
+    else                                                                                                              \
+      hipLaunchKernelGGL((pcg2_spmv_kernel<T, MM>), dim3(grid), dim3(256), 0, st, (const int*)ptr, (const int*)other, \
+                         (const T*)HB, (const T*)D, (const T*)Binv, (const T*)p, (const T*)z, (T*)q, (T*)scal,        \
+                         (T*)rr_hist, (int*)it, cap, N, (const int*)nullptr);                                         \
   }
   if (m == 6) LAUNCH(6) else if (m == 7) LAUNCH(7) else if (m == 3) LAUNCH(3) else return PPLIE_EBADARG;
 #undef LAUNCH
@@ -904,10 +982,16 @@ int pcg2_step(void* x, void* r, void* r_alt, void* p, const void* q, void* z, co
               int m, void* stream) {
   if (N <= 0 || m <= 0 || m > 8) return PPLIE_EBADARG;
   if (!x || !r || !r_alt || r == r_alt || !p || !q || !z || !Binv || !scal || !it) return PPLIE_EBADARG;
-  const int64_t n = N * m;
-  int g1 = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
-  hipLaunchKernelGGL((pcg2_step_kernel<T>), dim3(g1), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), (T*)x, (T*)r, (T*)r_alt,
-                     (T*)p, (const T*)q, (T*)z, (const T*)Binv, (T*)scal, (int*)it, N, m);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+#define LAUNCH(MM)                                                                                                     \
+  {                                                                                                                    \
+    const int64_t blocks = ((N + (64 / MM) - 1) / (64 / MM) + 3) / 4;                                                  \
+    const int grid = (int)(blocks < 1024 ? blocks : 1024);                                                             \
+    hipLaunchKernelGGL((pcg2_step_kernel<T, MM>), dim3(grid), dim3(256), 0, st, (T*)x, (T*)r, (T*)r_alt, (T*)p,        \
+                       (const T*)q, (T*)z, (const T*)Binv, (T*)scal, (int*)it, N);                                     \
+  }
+  if (m == 6) LAUNCH(6) else if (m == 7) LAUNCH(7) else if (m == 3) LAUNCH(3) else return PPLIE_EBADARG;
+#undef LAUNCH
   return hipGetLastError() == hipSuccess ? PPLIE_OK : PPLIE_ELAUNCH;
 }
 }  // namespace pplie
@@ -921,6 +1005,19 @@ extern "C" int pplie_pcg2_spmv_f64(const void* ptr, const void* other, const voi
                                    const void* p, const void* z, void* q, void* scal, void* rr_hist, void* it, int cap,
                                    int64_t N, int m, void* stream) {
   return pplie::pcg2_spmv<double>(ptr, other, HB, D, Binv, p, z, q, scal, rr_hist, it, cap, N, m, stream);
+}
+// HB [E, M, M] per edge (pplie_graph_assemble_csr_sym), blk [nnz] = 2 edge + side of every incidence
+extern "C" int pplie_pcg2_spmv_sym_f32(const void* ptr, const void* other, const void* blk, const void* HB, const void* D,
+                                       const void* Binv, const void* p, const void* z, void* q, void* scal, void* rr_hist,
+                                       void* it, int cap, int64_t N, int m, void* stream) {
+  if (!blk) return pplie::PPLIE_EBADARG;
+  return pplie::pcg2_spmv<float>(ptr, other, HB, D, Binv, p, z, q, scal, rr_hist, it, cap, N, m, stream, blk);
+}
+extern "C" int pplie_pcg2_spmv_sym_f64(const void* ptr, const void* other, const void* blk, const void* HB, const void* D,
+                                       const void* Binv, const void* p, const void* z, void* q, void* scal, void* rr_hist,
+                                       void* it, int cap, int64_t N, int m, void* stream) {
+  if (!blk) return pplie::PPLIE_EBADARG;
+  return pplie::pcg2_spmv<double>(ptr, other, HB, D, Binv, p, z, q, scal, rr_hist, it, cap, N, m, stream, blk);
 }
 extern "C" int pplie_pcg2_step_f32(void* x, void* r, void* r_alt, void* p, const void* q, void* z, const void* Binv, void* scal,
                                    void* it, int64_t N, int m, void* stream) {

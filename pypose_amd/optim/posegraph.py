@@ -239,6 +239,11 @@ class FusedPCG:
     sync per iteration.  Buffers (and the graph) are cached per shape and reused across LM steps.
     """
 
+    # one off-diagonal block per edge on graphs beyond the persistent solve (pplie_pcg2_spmv_sym).  OFF: measured slower on
+    # the BASELINE graph (10^5 nodes, 75 % uniformly random loop closures): 52 us per SpMV against 41 -- the per-incidence
+    # blocks are one sequential stream per node, the per-edge blocks are 144-byte gathers (two 128-byte lines each) and the
+    # second touch of a random closure's block is never a cache hit; it pays only on graphs whose edges are local in node order
+    sym_blocks = False
     two_launch = True        # class-level switches (tools/ and tests compare the three-launch / graph-less variants)
     use_graph = True
     persist = True           # one persistent launch per solve on small graphs (csrc/pcg_persist.hip)
@@ -263,6 +268,7 @@ class FusedPCG:
         self.sfx = "_f32" if dtype == torch.float32 else "_f64"
         self.graph = None                                          # captured check_every iterations
         self.bsr = None                                            # which iteration the graph holds
+        self.sym = False                                           # HB holds one block per edge
         self._csr_obj = None
 
     def _csr(self, lin):
@@ -277,10 +283,16 @@ class FusedPCG:
         st = _C.stream_ptr(self.device)
         if self.bsr and self.two_launch:
             # q = A p with p.q, q.z, q.Binv q ; then every vector update in one launch (csrc/graph.hip, pcg2)
-            code = lib.symbol("pplie_pcg2_spmv" + self.sfx, _PCG2_SPMV_SIG)(
-                self.ptr.data_ptr(), self.other.data_ptr(), self.HB.data_ptr(), self.D.data_ptr(), self.Binv.data_ptr(),
-                self.p.data_ptr(), self.z.data_ptr(), self.q.data_ptr(), self.scal.data_ptr(), self.rr_hist.data_ptr(),
-                self.it.data_ptr(), self.cap, self.N, self.m, st)
+            if self.sym:
+                code = lib.symbol("pplie_pcg2_spmv_sym" + self.sfx, [ctypes.c_void_p] + _PCG2_SPMV_SIG)(
+                    self.ptr.data_ptr(), self.other.data_ptr(), self.blk.data_ptr(), self.HB.data_ptr(), self.D.data_ptr(),
+                    self.Binv.data_ptr(), self.p.data_ptr(), self.z.data_ptr(), self.q.data_ptr(), self.scal.data_ptr(),
+                    self.rr_hist.data_ptr(), self.it.data_ptr(), self.cap, self.N, self.m, st)
+            else:
+                code = lib.symbol("pplie_pcg2_spmv" + self.sfx, _PCG2_SPMV_SIG)(
+                    self.ptr.data_ptr(), self.other.data_ptr(), self.HB.data_ptr(), self.D.data_ptr(), self.Binv.data_ptr(),
+                    self.p.data_ptr(), self.z.data_ptr(), self.q.data_ptr(), self.scal.data_ptr(), self.rr_hist.data_ptr(),
+                    self.it.data_ptr(), self.cap, self.N, self.m, st)
             _C.check(code, "pplie_pcg2_spmv")
             code = lib.symbol("pplie_pcg2_step" + self.sfx, _PCG2_STEP_SIG)(
                 self.x.data_ptr(), self.r.data_ptr(), self.r2.data_ptr(), self.p.data_ptr(), self.q.data_ptr(),
@@ -319,9 +331,10 @@ class FusedPCG:
         self.bsr = bsr
         if bsr:
             self._csr(lin)
-            if self.HB is None:
-                self.HB = torch.empty_like(lin.HB)
-            self.HB.copy_(lin.HB)                                   # off-diagonal blocks in incidence order
+            sym = bool(getattr(lin, "HB_sym", False))
+            if self.HB is None or self.HB.shape != lin.HB.shape or sym != self.sym:
+                self.HB, self.sym, self.graph = torch.empty_like(lin.HB), sym, None
+            self.HB.copy_(lin.HB)                                   # off-diagonal blocks in incidence (or edge) order
         else:
             if self.J is None:
                 self.J, self.idx = torch.empty_like(lin.J), torch.empty_like(lin.idx)
@@ -444,6 +457,7 @@ class GraphLinearization:
         self.replicated = False  # True: the edges of ALL shards are held here, nothing below is a collective
         self.s = 1.0            # compounded damping factor prod(1 + lambda_i)
         self.HB = None
+        self.HB_sym = False     # True: HB holds one block per EDGE (symmetric weights, large graphs)
         self.node_group = None  # process group over which the SOLVE is sharded by node rows (optim/nodeshard.py)
 
     # -- index helpers -------------------------------------------------------------------------
@@ -475,6 +489,17 @@ class GraphLinearization:
         cache[key] = (idx.clone(), csr, idx, idx._version)
         return csr
 
+    def _weights_symmetric(self):
+        """W_e == W_e^T for every edge (information matrices are; a user could pass anything): checked once per weight
+        tensor version, one small reduction + read-back"""
+        if self.W is None:
+            return True
+        cache = self.opt.__dict__.setdefault('_w_sym', {})
+        key = (self.W.data_ptr(), self.W._version, tuple(self.W.shape))
+        if cache.get('key') != key:
+            cache['key'], cache['ok'] = key, bool(torch.equal(self.W, self.W.mT))
+        return cache['ok']
+
     # -- kernels ---------------------------------------------------------------------------------
     def _hip(self):
         return (_C._test_backend is None and self.J.is_cuda and (self.dr, self.m, self.K) in _HIP_SHAPES
@@ -493,9 +518,13 @@ class GraphLinearization:
                     B = torch.empty((N, m, m), dtype=dt, device=dev)
                     g = torch.empty((N, m), dtype=dt, device=dev)
                     ptr, blk, _ = self.csr()
-                    # off-diagonal blocks in incidence order feed the streaming node-parallel SpMV of the PCG
-                    self.HB = torch.empty((self.E * 2, m, m), dtype=dt, device=dev) if self.K == 2 else None
-                    code = lib.symbol("pplie_graph_assemble_csr" + sfx, _ASMC_SIG)(
+                    # off-diagonal blocks in incidence order feed the streaming node-parallel SpMV of the PCG; graphs too
+                    # large for the persistent solve keep ONE block per edge (H_ji = H_ij^T for symmetric weights):
+                    # half the bytes every SpMV streams
+                    self.HB_sym = (self.K == 2 and FusedPCG.two_launch and not (FusedPCG.persist and N <= PERSIST_NODES)
+                                   and FusedPCG.sym_blocks and self._weights_symmetric())
+                    self.HB = torch.empty((self.E * (1 if self.HB_sym else 2), m, m), dtype=dt, device=dev) if self.K == 2 else None
+                    code = lib.symbol("pplie_graph_assemble_csr" + ("_sym" if self.HB_sym else "") + sfx, _ASMC_SIG)(
                         ptr.data_ptr(), blk.data_ptr(), self.J.data_ptr(), wptr, self.R.data_ptr(), B.data_ptr(),
                         g.data_ptr(), self.HB.data_ptr() if self.HB is not None else None, N, self.dr, self.m, self.K, st)
                     _C.check(code, "pplie_graph_assemble_csr")

@@ -187,6 +187,23 @@ def test_posegraph_pcg_matrix_free_on_gpu(G, two_launch, monkeypatch):
     compare_trajectory(rec, G, "pgo40/infos", floor=1e-12, rtol=1e-7)
 
 
+def test_posegraph_pcg_one_block_per_edge(G, monkeypatch):
+    """the opt-in symmetric storage (pplie_graph_assemble_csr_sym + pplie_pcg2_spmv_sym: H_ji read as H_ij^T) walks the
+    reference's trajectory too, weighted (symmetric information matrices) and unweighted"""
+    from pypose_amd.optim import posegraph
+    monkeypatch.setattr(posegraph.FusedPCG, "sym_blocks", True, raising=False)
+    monkeypatch.setattr(posegraph.FusedPCG, "persist", False, raising=False)
+    edges, poses = T(G["pgo40/edges"], DEV), pp.SE3(T(G["pgo40/poses"], DEV))
+    for tag, kw in (("pgo40/infos", {"weight": T(G["pgo40/infos"], DEV)}), ("pgo40/noweight", {})):
+        graph = PoseGraph(pp.SE3(T(G["pgo40/init"], DEV)))
+        opt = pp.optim.LM(graph, solver=pp.optim.solver.PCG(tol=1e-13, maxiter=2000, check_every=1),
+                          strategy=pp.optim.strategy.TrustRegion(radius=1e4), min=1e-6)
+        rec = run_steps(opt, ((edges, poses),), kw, 5)
+        assert set(rec["kind"]) == {"fused:pgo"}
+        assert all(w.sym for w in opt._pcg_workspaces.values())
+        compare_trajectory(rec, G, tag, floor=1e-12, rtol=1e-7)
+
+
 @pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-12), (torch.float32, 2e-5)])
 @pytest.mark.parametrize("dr,dp,has_w", [(6, 7, False), (6, 7, True), (3, 4, False), (7, 8, True), (4, 5, False), (6, 6, True)])
 def test_block_kernels_vs_oracle(dtype, tol, dr, dp, has_w):
