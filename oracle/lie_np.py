@@ -801,9 +801,7 @@ def reproj_vjp(J, g):
     return (np.concatenate([v[:, :6], _zero_col(J)], -1), v[:, 6:9])
 
 
-OPS["se3_reproj_fwd"] = se3_reproj_fwd
-OPS["se3_reproj_lin"] = se3_reproj_lin
-OPS["reproj_vjp"] = reproj_vjp
+EXTRA_OPS = {"se3_reproj_fwd": se3_reproj_fwd, "se3_reproj_lin": se3_reproj_lin, "reproj_vjp": reproj_vjp}
 
 COMPOSED_OPS = {}
 for _g, (_da, _dg) in GROUPS.items():

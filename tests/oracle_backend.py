@@ -27,7 +27,7 @@ def oracle_row_op(name, ins, out_widths, prm=None):
         outs = getattr(optim_np, name)(*[t.detach().cpu().numpy() for t in ins])
         res = tuple(torch.from_numpy(np.ascontiguousarray(o)) for o in outs)
         return res if name == "block_normal_eq" else res[0]
-    fn = lie_np.OPS[name] if name in lie_np.OPS else lie_np.COMPOSED_OPS[name]
+    fn = lie_np.OPS[name] if name in lie_np.OPS else (lie_np.EXTRA_OPS[name] if name in lie_np.EXTRA_OPS else lie_np.COMPOSED_OPS[name])
     arrs = [t.detach().cpu().numpy() for t in ins]
     n = arrs[0].shape[0]
     if n == 0:
