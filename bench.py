@@ -546,7 +546,7 @@ def main():
         legs = (("c1", lambda: c1_latency(dev)),
                 ("lm_invnet", lambda: invnet_lm_rate(dev, B=2000 if small else 1_000_000, reps=2 if small else 40)),
                 ("lm_pgo", lambda: pgo_lm_rate(dev, *((60, 150) if small else (10_000, 40_000)), reps=1 if small else 5)),
-                ("lm_pgo_100k", lambda: pgo_lm_rate(dev, *((80, 200) if small else (100_000, 400_000)), reps=1 if small else 3,
+                ("lm_pgo_100k", lambda: pgo_lm_rate(dev, *((80, 200) if small else (100_000, 400_000)), reps=1 if small else 5,
                                                     with_static=False)),
                 ("imu", lambda: imu_rate(dev, *((8, 64) if small else (4096, 1024)), reps=2 if small else 20)))
         for key, fn in legs:
