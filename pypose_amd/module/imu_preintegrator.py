@@ -73,10 +73,12 @@ class IMUPreintegrator(nn.Module):
         if init_state is None:
             init_state = {'pos': self.pos, 'rot': self.rot, 'vel': self.vel}
         if self.prop_cov:
-            gyro_cov = self.gyro_cov.repeat([B, 1, 1]) if gyro_cov is None else gyro_cov
-            acc_cov = self.acc_cov.repeat([B, 1, 1]) if acc_cov is None else acc_cov
+            # (the fused kernel broadcasts a [1, 1, 3] covariance by stride; the composed route repeats it as the reference does)
+            own_gc, own_ac = gyro_cov is None, acc_cov is None
+            gyro_cov = self.gyro_cov if own_gc else gyro_cov
+            acc_cov = self.acc_cov if own_ac else acc_cov
             if 'cov' not in init_state or init_state['cov'] is None:
-                init_cov = self.cov.expand(B, 9, 9)
+                init_cov = self.cov                      # [1, 9, 9]: broadcast by the consumer (the fused route keeps a copy)
             else:
                 init_cov = init_state['cov']
             Rij0 = init_state['Rij'] if 'Rij' in init_state else self.Rij
@@ -89,9 +91,7 @@ class IMUPreintegrator(nn.Module):
             predict, _ = self._fused_integrate(dt, gyro, acc, rot, init_state, None, aux=False)
             if self.prop_cov:
                 # Rij_k = Rij0 * Dr_k = (Rij0 * r0^-1) * rot_k  (reference :283-286 with rot_k = r0 * Dr_k, :422)
-                r0 = init_state['rot'] if isinstance(init_state['rot'], LieTensor) else SO3(init_state['rot'])
-                Cq = r0.Inv() if Rij0 is None else Rij0 * r0.Inv()
-                Cq = torch.Tensor.as_subclass(Cq, torch.Tensor).expand(B, 1, 4).reshape(B, 4).contiguous()
+                Cq = self._rij_offset(init_state['rot'], Rij0, B)
                 last = SO3(Cq.unsqueeze(1)) * SO3(torch.Tensor.as_subclass(predict['rot'], torch.Tensor)[:, -1:, :])
                 Rij = LieTensor(torch.Tensor.as_subclass(last, torch.Tensor), ltype=init_state['rot'].ltype) \
                     if isinstance(init_state['rot'], LieTensor) else last
@@ -102,10 +102,13 @@ class IMUPreintegrator(nn.Module):
             inte_state = self.integrate(dt, gyro, acc, rot=rot, init_rot=init_state['rot'])
             predict = self.predict(init_state, inte_state)
             if self.prop_cov:
+                gyro_cov = gyro_cov.repeat([B, 1, 1]) if own_gc else gyro_cov
+                acc_cov = acc_cov.repeat([B, 1, 1]) if own_ac else acc_cov
                 Rij = Rij0 * inte_state['Dr'] if Rij0 is not None else inte_state['Dr']
                 cov_input_state = {'Rij': Rij.detach(), 'Rk': inte_state['w'].detach(),
                                    'Ha': vec2skew(inte_state['a'].detach()), 'dt': dt.detach()}
-                cov = self.propagate_cov(cov_input=cov_input_state, init_cov=init_cov, gyro_cov=gyro_cov, acc_cov=acc_cov)
+                cov = self.propagate_cov(cov_input=cov_input_state, init_cov=init_cov.expand(B, 9, 9), gyro_cov=gyro_cov,
+                                         acc_cov=acc_cov)
             else:
                 cov = {'cov': None}
 
@@ -125,6 +128,37 @@ class IMUPreintegrator(nn.Module):
         if torch.is_grad_enabled() and any(t.requires_grad for t in ts):
             return False
         return dt.dtype in (torch.float32, torch.float64) and all(t.dtype == dt.dtype for t in ts)
+
+    def _rij_offset(self, rot0, Rij0, B):
+        """Rij0 * r0^-1 as [B, 4] (kept while both tensors stay the same objects at the same versions)"""
+        raw = torch.Tensor.as_subclass(rot0, torch.Tensor)
+        rawj = torch.Tensor.as_subclass(Rij0, torch.Tensor) if Rij0 is not None else None
+        key = (rot0, raw._version, Rij0, rawj._version if rawj is not None else -1, B)
+        hit = self.__dict__.get('_cq_cache')
+        if hit is not None and hit[0][0] is key[0] and hit[0][2] is key[2] and hit[0][1] == key[1] and hit[0][3] == key[3] \
+                and hit[0][4] == B:
+            return hit[1]
+        r0 = rot0 if isinstance(rot0, LieTensor) else SO3(rot0)
+        Cq = r0.Inv() if Rij0 is None else Rij0 * r0.Inv()
+        Cq = torch.Tensor.as_subclass(Cq, torch.Tensor).expand(B, 1, 4).reshape(B, 4).contiguous()
+        self.__dict__['_cq_cache'] = (key, Cq)
+        return Cq
+
+    def _bcast(self, slot, t, B, w):
+        """``t`` (one row, or B rows) as a contiguous [B, w] buffer.  Broadcast copies are kept per slot for as long as the
+        source tensor object and its version stay the same: a module called in a loop with the same initial state launched
+        a dozen 5 us expand-copies per forward, a third of the time of the integration itself."""
+        raw = torch.Tensor.as_subclass(t, torch.Tensor)
+        if raw.numel() == B * w and raw.is_contiguous():
+            return raw.view(B, w)
+        cache = self.__dict__.setdefault('_bcast_cache', {})
+        hit = cache.get(slot)
+        if hit is not None and hit[0] is t and hit[1] == raw._version and hit[2].shape[0] == B and hit[2].dtype == raw.dtype \
+                and hit[2].device == raw.device:
+            return hit[2]
+        out = raw.reshape(-1, w).expand(B, w).contiguous() if raw.numel() == w else raw.reshape(B, w).contiguous()
+        cache[slot] = (t, raw._version, out)
+        return out
 
     def _gravity_host(self):
         """the gravity vector as a C array (read back once per value: the buffer lives on the device)"""
@@ -146,7 +180,7 @@ class IMUPreintegrator(nn.Module):
             return cv, (cv.stride(0) if cv.shape[0] > 1 else 0), (cv.stride(1) if cv.shape[1] > 1 else 0)
         gc, gsb, gsf = strided(gyro_cov)
         ac, asb, asf = strided(acc_cov)
-        ic = init_cov.to(dt.dtype).expand(B, 9, 9).contiguous()
+        ic = self._bcast('cov0', init_cov if init_cov.dtype == dt.dtype else init_cov.to(dt.dtype), B, 81)
         ro = torch.Tensor.as_subclass(rot_out, torch.Tensor).contiguous()
         rw = torch.Tensor.as_subclass(rot, torch.Tensor).expand(B, F, 4).contiguous() if rot is not None else ro
         g = self._gravity_host()
@@ -163,9 +197,9 @@ class IMUPreintegrator(nn.Module):
         B, F = dt.shape[:2]
         dev, dty = dt.device, dt.dtype
         c = lambda t: t.contiguous()
-        r0 = c(torch.Tensor.as_subclass(init_state['rot'], torch.Tensor).expand(B, 1, 4).reshape(B, 4))
-        v0 = c(init_state['vel'].expand(B, 1, 3).reshape(B, 3))
-        p0 = c(init_state['pos'].expand(B, 1, 3).reshape(B, 3))
+        r0 = self._bcast('r0', init_state['rot'], B, 4)
+        v0 = self._bcast('v0', init_state['vel'], B, 3)
+        p0 = self._bcast('p0', init_state['pos'], B, 3)
         dtc, gy, ac = c(dt), c(gyro), c(acc)
         rk = c(torch.Tensor.as_subclass(rot, torch.Tensor).expand(B, F, 4)) if rot is not None else None
         q0 = c(torch.Tensor.as_subclass(Rij0, torch.Tensor).expand(B, 1, 4).reshape(B, 4)) if Rij0 is not None else None
