@@ -44,6 +44,14 @@ def _raw(t):
     return t.tensor() if isinstance(t, LieTensor) else t
 
 
+def _wrap(t, ltype):
+    """an op's plain output as a LieTensor, past LieTensor.__init__'s shape assertion (``self.shape`` on a tensor subclass
+    is a __torch_function__ round trip: ~5 us on the dispatch path of every op; the kernels fix the width)"""
+    lt = Tensor.as_subclass(t, LieTensor)
+    lt.ltype = ltype
+    return lt
+
+
 class LieType:
     """Descriptor + behaviour of one Lie type (group or algebra).
 
@@ -100,17 +108,17 @@ class LieType:
     def Exp(self, x):
         if self._is_group:
             raise AttributeError("Lie Group has no Exp attribute")
-        return LieTensor(self._fn("exp").apply(_raw(x)), ltype=self._group)
+        return _wrap(self._fn("exp").apply(_raw(x)), self._group)
 
     def Log(self, X):
         if not self._is_group:
             raise AttributeError("Lie Algebra has no Log attribute")
-        return LieTensor(self._fn("log").apply(_raw(X)), ltype=self._algebra)
+        return _wrap(self._fn("log").apply(_raw(X)), self._algebra)
 
     def Inv(self, X):
         if not self._is_group:
             return LieTensor(-X, ltype=self)
-        return LieTensor(self._fn("inv").apply(_raw(X)), ltype=self)
+        return _wrap(self._fn("inv").apply(_raw(X)), self)
 
     # -- binary ops ------------------------------------------------------------------------
     def _binary(self, kind, X, other, out_ltype):
@@ -118,7 +126,7 @@ class LieType:
         out = self._fn(kind).apply(x, y)
         width = -1 if out.nelement() != 0 else y.shape[-1]
         out = out.view(tuple(out_shape) + (width,))
-        return out if out_ltype is None else LieTensor(out, ltype=out_ltype)
+        return out if out_ltype is None else _wrap(out, out_ltype)
 
     def Act(self, X, p):
         if not self._is_group:
@@ -133,7 +141,7 @@ class LieType:
                 (x, y), out_shape = broadcast_inputs(_raw(X), _raw(Y))
                 out = self._fn("mul").apply(x, y)
                 width = -1 if out.nelement() != 0 else x.shape[-1]
-                return LieTensor(out.view(tuple(out_shape) + (width,)), ltype=self)
+                return _wrap(out.view(tuple(out_shape) + (width,)), self)
             if isinstance(Y, Tensor) and not isinstance(Y, LieTensor):     # transform o points
                 return self.Act(X, Y)
             raise NotImplementedError('Invalid __mul__ operation')

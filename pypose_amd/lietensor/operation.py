@@ -151,8 +151,12 @@ def _make_fwd(clsname, g, kind, doc):
             # nothing to record (no_grad, or no input requires grad) and no functorch transform:
             # launch directly -- Function.apply costs ~40 us of Python per call (signature binding,
             # context set-up), which is the whole budget of a small kernel inside LM.step
-            if not _transforms_active() and not (torch.is_grad_enabled() and any(t.requires_grad for t in ins)):
-                return _launch(fwd_kernel, ins, fin, (fout,))[0]
+            if not _transforms_active():
+                if not (torch.is_grad_enabled() and any(t.requires_grad for t in ins)):
+                    return _launch(fwd_kernel, ins, fin, (fout,))[0]
+                # recorded, but no functorch transform: the engine's own apply, past Function.apply's per-call
+                # inspect.signature binding of forward()'s defaults (~15 us; there are none)
+                return super(torch.autograd.Function, cls).apply(*ins)
             return super().apply(*ins)
 
         @staticmethod
