@@ -209,6 +209,12 @@ pcg_persist_kernel(const int* __restrict__ ptr, const int* __restrict__ other, c
     if (!(rr == rr)) flag = 2;
     else if (rr <= tol2 * bn2) flag = 1;
   }
+  if (flag >= 2) {
+    // a failed solve (NaN, or a workgroup that never arrived) hands back x = 0: the caller may have queued the parameter
+    // update behind this launch and look at `info` only afterwards (one read-back per LM trial) -- Exp(0) p = p
+    for (int64_t n = n0 + w * NPW + sub; n < n1; n += WV * NPW)
+      if (lane_on) x[n * M + i] = T(0);
+  }
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     info[0] = (T)it; info[1] = rr; info[2] = bn2; info[3] = (T)flag;
     it_out[0] = it;

@@ -25,6 +25,7 @@ from __future__ import annotations
 import torch
 from torch import nn
 from torch.optim import Optimizer
+from .posegraph import SolveFailed as _SolveFailed
 from torch.optim import optimizer as _torch_opt
 
 from . import blocks as _blocks
@@ -384,7 +385,16 @@ class LevenbergMarquardt(_Optimizer):
             if self.group is not None and not getattr(J, 'replicated', False):
                 import torch.distributed as dist
                 dist.all_reduce(ab, group=self.group)
-            a, b, loss_h = torch.cat([ab.reshape(-1).double(), self.loss.detach().reshape(1).double()]).tolist()
+            lin = getattr(J, 'lin', None)
+            pend = getattr(lin, 'pending_info', None) if lin is not None else None
+            parts = [ab.reshape(-1).double(), self.loss.detach().reshape(1).double()]
+            if pend is not None:                 # the persistent PCG's (iterations, rr, bn2, flag) ride along: one read-back
+                parts.append(pend.info.double())
+            vals = torch.cat(parts).tolist()
+            a, b, loss_h = vals[:3]
+            if pend is not None:
+                lin.pending_info = None
+                lin._pending_solver.iterations = pend.resolve(vals[3:7])     # raises like an eager solve would have
             x = max(a, 1e-300) ** 0.5
             one = torch.ones((1, 1), dtype=torch.float64)
             self.strategy.update(pg, last=last_h, loss=loss_h, J=one, D=x * one, R=(b / x) * one)
@@ -461,16 +471,32 @@ class LevenbergMarquardt(_Optimizer):
             # the loop's decisions are taken on host copies of last / loss (one read-back per trial instead of a
             # synchronising tensor comparison at every `<` / `<=`); self.last / self.loss stay tensors
             last_h = loss_h = self._host(self.loss)
+            # pose graphs on the persistent PCG: the solve's own (iterations, flag) read-back is deferred into the one that
+            # fetches the trial's loss and gain terms -- the update, loss and gain kernels queue up behind the solve instead of
+            # waiting for the host to have looked at it (a failed solve returns a zero step)
+            defer = (self.group is None and hasattr(J, 'gain_terms') and type(self.strategy) in (Constant, Adaptive, TrustRegion)
+                     and getattr(getattr(J, 'lin', None), '_hip', lambda: False)())
             while last_h <= loss_h:
                 lin.damp(pg['damping'])
+                self._defer_solver_info = defer
                 try:
                     D = lin.solve(self.solver)
                 except Exception as e:
                     print(e, "\nLinear solver failed. Breaking optimization step...")
                     break
+                finally:
+                    self._defer_solver_info = False
                 self.update_parameter(pg['params'], D)
                 self.loss = lin.fast_loss() if hasattr(lin, 'fast_loss') else self._loss(input, target)
-                loss_h = self._strategy_update(pg, J, D, R, last_h)
+                try:
+                    loss_h = self._strategy_update(pg, J, D, R, last_h)
+                except _SolveFailed as e:       # noticed after the fact; the step was zero, the parameters are where they were
+                    print(e, "\nLinear solver failed. Breaking optimization step...")
+                    self.loss = self.last
+                    break
+                if getattr(lin, 'pending_info', None) is not None:     # (a strategy path that did not pick it up)
+                    pend, lin.pending_info = lin.pending_info, None
+                    lin._pending_solver.iterations = pend.resolve()
                 if last_h < loss_h and self.reject_count < self.reject:           # reject the step
                     self.update_parameter(params=pg['params'], step=-D)
                     self.loss, self.reject_count, loss_h = self.last, self.reject_count + 1, last_h

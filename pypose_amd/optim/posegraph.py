@@ -229,6 +229,23 @@ def _all_reduce(t, group):
 _PCG_SIG = [ctypes.c_int] + [ctypes.c_void_p] * 10 + [ctypes.c_int, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]
 
 
+class SolveFailed(AssertionError):
+    """a linear solve whose failure was noticed after the fact (deferred read-back); the parameters were not touched"""
+
+
+class _PendingInfo:
+    """(iterations, |r|^2, |b|^2, flag) of a persistent solve, still on the device"""
+
+    def __init__(self, info):
+        self.info = info
+
+    def resolve(self, values=None):
+        its, rr, bn2, flag = self.info.tolist() if values is None else values
+        if flag == 2.0 or rr != rr:
+            raise SolveFailed('Linear solve produced NaN (matrix may not be positive-definite)')
+        return int(its)
+
+
 class FusedPCG:
     """Device-resident block-Jacobi PCG for one graph shape (csrc/graph.hip).
 
@@ -320,7 +337,7 @@ class FusedPCG:
                          self.it.data_ptr(), self.cap, self.N, self.m, st)
             _C.check(code, "pplie_pcg_stage")
 
-    def solve(self, lin, s, dmin, dmax, tol, maxiter, group, plain=False):
+    def solve(self, lin, s, dmin, dmax, tol, maxiter, group, plain=False, defer=False):
         """Solve (H + damping) x = -g for the linearisation ``lin`` (raw block diagonal ``lin.B``, gradient ``lin.g``)
         with the LM clamp [dmin, dmax] and compounded damping factor ``s`` folded in by ``pplie_pcg_prepare``.
         ``plain=True`` runs the same launches with the identity as preconditioner: from x = 0 plain CG stays in
@@ -367,6 +384,10 @@ class FusedPCG:
                     self.part.data_ptr(), self.bar.data_ptr(), self.rr_hist.data_ptr(), self.info.data_ptr(), self.it.data_ptr(),
                     float(tol), int(maxit), self.cap, PERSIST_GRID, self.N, self.m, _C.stream_ptr(self.device))
                 _C.check(code, "pplie_pcg_persist")
+                if defer:
+                    # the caller reads `info` together with the trial's loss and gain terms (ONE read-back per LM trial);
+                    # a failed solve returns x = 0, so whatever was queued behind it left the parameters alone
+                    return self.x.clone(), _PendingInfo(self.info.clone())
                 its, rr, bn2, flag = self.info.tolist()             # the solve's one read-back
                 assert flag != 2.0 and rr == rr, 'Linear solve produced NaN (matrix may not be positive-definite)'
                 return self.x.clone(), int(its)
@@ -457,6 +478,7 @@ class GraphLinearization:
         self.replicated = False  # True: the edges of ALL shards are held here, nothing below is a collective
         self.s = 1.0            # compounded damping factor prod(1 + lambda_i)
         self.HB = None
+        self.pending_info = None  # a deferred read-back of the persistent PCG's (iterations, rr, bn2, flag)
         self.HB_sym = False     # True: HB holds one block per EDGE (symmetric weights, large graphs)
         self.node_group = None  # process group over which the SOLVE is sharded by node rows (optim/nodeshard.py)
 
@@ -630,7 +652,12 @@ class GraphLinearization:
             wsp = cache.get(key)
             if wsp is None:
                 wsp = cache[key] = FusedPCG(*key)
-            Dn, solver.iterations = wsp.solve(self, s, dmin, dmax, solver.tol, maxiter, self.group, plain=plain)
+            defer = bool(getattr(self.opt, '_defer_solver_info', False)) and not plain
+            Dn, its = wsp.solve(self, s, dmin, dmax, solver.tol, maxiter, self.group, plain=plain, defer=defer)
+            if isinstance(its, _PendingInfo):
+                self.pending_info, self._pending_solver = its, solver
+            else:
+                solver.iterations = its
             return Dn
         clamped = self.diag_raw.clamp(dmin, dmax)
         shift = s * clamped - self.diag_raw
