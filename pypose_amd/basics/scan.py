@@ -33,7 +33,7 @@ def try_scan_(input, dim, left):
     for s in input.shape[dim + 1:-1]:
         inner *= s
     fn = _C.library().symbol(f"pplie_scan_{key}" + ("_f32" if input.dtype == torch.float32 else "_f64"), _SIG)
-    with torch.cuda.device(input.device):
+    with _C._on_device(input.device):
         code = fn(input.data_ptr(), outer * inner, L, inner, 1 if left else 0, _C.stream_ptr(input.device))
     _C.check(code, f"pplie_scan_{key}")
     _C.mark_written(input)                # the scan wrote through the raw pointer

@@ -186,7 +186,7 @@ class IMUPreintegrator(nn.Module):
         g = self._gravity_host()
         fn = _C.library().symbol("pplie_imu_cov2" + _sfx(dt), _COV2_SIG)
         dtc, gyc, acc_c = dt.contiguous(), gyro.contiguous(), acc.contiguous()     # (held: a temporary's block could be reused
-        with torch.cuda.device(dt.device):                                           #  by the next allocation before the launch)
+        with _C._on_device(dt.device):                                           #  by the next allocation before the launch)
             code = fn(dtc.data_ptr(), gyc.data_ptr(), acc_c.data_ptr(), ro.data_ptr(), rw.data_ptr(),
                       Cq.data_ptr(), ic.data_ptr(), gc.data_ptr(), gsb, gsf, ac.data_ptr(), asb, asf, g, cov.data_ptr(), B, F,
                       _C.stream_ptr(dt.device))
@@ -214,7 +214,7 @@ class IMUPreintegrator(nn.Module):
         g = self._gravity_host()
         P = lambda t: t.data_ptr() if t is not None else None
         fn = _C.library().symbol("pplie_imu_integrate" + _sfx(dt), _INT_SIG)
-        with torch.cuda.device(dev):
+        with _C._on_device(dev):
             code = fn(P(dtc), P(gy), P(ac), P(rk), P(r0), P(v0), P(p0), P(q0), g, P(orot), P(ovel), P(opos),
                       P(aux.get('Rk')), P(aux.get('Rij')), P(aux.get('a')), B, F, _C.stream_ptr(dev))
         _C.check(code, "pplie_imu_integrate")
@@ -236,7 +236,7 @@ class IMUPreintegrator(nn.Module):
         ac, asb, asf = strided(acc_cov)
         ic = init_cov.to(dt.dtype).expand(B, 9, 9).contiguous()
         fn = _C.library().symbol("pplie_imu_cov" + _sfx(dt), _COV_SIG)
-        with torch.cuda.device(dt.device):
+        with _C._on_device(dt.device):
             code = fn(dt.contiguous().data_ptr(), aux['Rk'].data_ptr(), aux['Rij'].data_ptr(), aux['a'].data_ptr(),
                       ic.data_ptr(), gc.data_ptr(), gsb, gsf, ac.data_ptr(), asb, asf, cov.data_ptr(), B, F,
                       _C.stream_ptr(dt.device))

@@ -50,7 +50,7 @@ def normal_equations(J, R, W=None):
         A = torch.empty((n, dp, dp), dtype=J.dtype, device=J.device)
         g = torch.empty((n, dp), dtype=J.dtype, device=J.device)
         fn = _C.library().symbol("pplie_block_normal_eq" + _suffix(J), _NE_SIG)
-        with torch.cuda.device(J.device):
+        with _C._on_device(J.device):
             code = fn(J.data_ptr(), R.data_ptr(), W.data_ptr() if W is not None else None, A.data_ptr(), g.data_ptr(),
                       n, dr, dp, _C.stream_ptr(J.device))
         _C.check(code, "pplie_block_normal_eq")
@@ -69,7 +69,7 @@ def chol_solve(A, g):
         A, g = A.contiguous(), g.contiguous()
         x = torch.empty((n, dp), dtype=A.dtype, device=A.device)
         fn = _C.library().symbol("pplie_block_chol_solve" + _suffix(A), _CH_SIG)
-        with torch.cuda.device(A.device):
+        with _C._on_device(A.device):
             code = fn(A.data_ptr(), g.data_ptr(), x.data_ptr(), n, dp, _C.stream_ptr(A.device))
         _C.check(code, "pplie_block_chol_solve")
         return x

@@ -111,7 +111,7 @@ class Se3InvLinearization:
         part = torch.zeros((_PARTIALS, 4), dtype=pt.dtype, device=pt.device)
         fn = _C.library().symbol("pplie_lm_se3inv_trial" + _blocks._suffix(pt), _TRIAL_SIG)
         rbuf = torch.empty((self.n, 6), dtype=pt.dtype, device=pt.device) if self.R is None else None
-        with torch.cuda.device(pt.device):
+        with _C._on_device(pt.device):
             code = fn(self.R.data_ptr() if self.R is not None else None, rbuf.data_ptr() if rbuf is not None else None,
                       pt.data_ptr(), self.X.data_ptr(), out.data_ptr(), D.data_ptr(), part.data_ptr(),
                       scale, self.dmin, self.dmax, self.n, _C.stream_ptr(pt.device))
@@ -501,7 +501,7 @@ class PgoProgram:
         R = torch.empty((self.E, 6), dtype=nodes.dtype, device=nodes.device)
         J = torch.empty((self.E, 2, 6, 6), dtype=nodes.dtype, device=nodes.device)
         fn = _C.library().symbol("pplie_pgo_linearize" + _blocks._suffix(nodes), _PGO_SIG)
-        with torch.cuda.device(nodes.device):
+        with _C._on_device(nodes.device):
             code = fn(nodes.data_ptr(), self.idx.data_ptr(), self.Z.data_ptr(), R.data_ptr(), J.data_ptr(), self.E,
                       _C.stream_ptr(nodes.device))
         _C.check(code, "pplie_pgo_linearize")
@@ -512,7 +512,7 @@ class PgoProgram:
         nodes = self.P.detach()
         part = torch.zeros(_PGO_PARTIALS, dtype=nodes.dtype, device=nodes.device)
         fn = _C.library().symbol("pplie_pgo_residual" + _blocks._suffix(nodes), _PGO_SIG)
-        with torch.cuda.device(nodes.device):
+        with _C._on_device(nodes.device):
             code = fn(nodes.data_ptr(), self.idx.data_ptr(), self.Z.data_ptr(), None, part.data_ptr(), self.E,
                       _C.stream_ptr(nodes.device))
         _C.check(code, "pplie_pgo_residual")

@@ -76,7 +76,7 @@ class _Scatter:
     def _segsum(self, vals, perm, ptr, n, w):
         out = torch.empty((n, w), dtype=vals.dtype, device=vals.device)
         fn = _C.library().symbol("pplie_segment_sum" + ("_f32" if vals.dtype == torch.float32 else "_f64"), _SEG_SIG)
-        with torch.cuda.device(vals.device):
+        with _C._on_device(vals.device):
             _C.check(fn(vals.data_ptr(), perm.data_ptr(), ptr.data_ptr(), out.data_ptr(), n, w, _C.stream_ptr(vals.device)),
                      "pplie_segment_sum")
         return out
@@ -103,7 +103,7 @@ class _Scatter:
         sfx = "_f32" if J.dtype == torch.float32 else "_f64"
         fn = _C.library().symbol("pplie_mg_jt_segsum" + sfx, _MGS_SIG)
         st = _C.stream_ptr(J.device)
-        with torch.cuda.device(J.device):
+        with _C._on_device(J.device):
             if self.two_level:
                 part = torch.empty((self.nch, m), dtype=J.dtype, device=J.device)
                 _C.check(fn(J.data_ptr(), q.data_ptr(), self.perm.data_ptr(), self.cptr.data_ptr(), part.data_ptr(), self.nch, dr, m,
@@ -211,7 +211,7 @@ class MultiGraphLinearization:
         arr = lambda ts: (ctypes.c_void_p * S)(*[t.data_ptr() for t in ts])
         q = torch.empty((self.E, self.dr), dtype=v.dtype, device=v.device)
         ms = (ctypes.c_int * S)(*[J.shape[-1] for _, _, J in self.slots])
-        with torch.cuda.device(v.device):
+        with _C._on_device(v.device):
             code = lib.symbol("pplie_mg_jtimes" + self._sfx(), _MGJ_SIG)(
                 S, arr([J for _, _, J in self.slots]), arr([i for _, i, _ in self.slots]), arr([xs[pi] for pi, _, _ in self.slots]),
                 ms, self.W.data_ptr() if self.W is not None else None, q.data_ptr(), self.E, self.dr, st)
@@ -227,7 +227,7 @@ class MultiGraphLinearization:
         lib, st = _C.library(), _C.stream_ptr(v.device)
         out = torch.empty_like(v)
         fn = lib.symbol("pplie_block_matvec" + self._sfx(), _BMV_SIG)
-        with torch.cuda.device(v.device):
+        with _C._on_device(v.device):
             for Bi, x, y, n, m in zip(Binv, self._split(v), self._split(out), self.N, self.m):
                 _C.check(fn(Bi.data_ptr(), x.data_ptr(), y.data_ptr(), n, m, st), "pplie_block_matvec")
         return out
@@ -474,7 +474,7 @@ class _GraphedPCG:
         sfx = L._sfx()
         q = L.matvec_flat(self.p, None)
         stage, flat = lib.symbol("pplie_pcg_stage" + sfx, _STAGE_SIG), lib.symbol("pplie_pcg_flat" + sfx, _FLAT_SIG)
-        with torch.cuda.device(self.p.device):
+        with _C._on_device(self.p.device):
             _C.check(stage(0, None, None, self.p.data_ptr(), q.data_ptr(), None, None, self.shift_flat.data_ptr(), self.scal.data_ptr(),
                            None, self.it.data_ptr(), self.cap, self.tot, 1, st), "pplie_pcg_stage")
             _C.check(flat(0, self.x.data_ptr(), self.r.data_ptr(), self.p.data_ptr(), q.data_ptr(), None, self.scal.data_ptr(),

@@ -104,7 +104,7 @@ class NodeShardedSystem:
             self.B = torch.empty((n, m, m), dtype=dt, device=dev)
             self.g = torch.empty((n, m), dtype=dt, device=dev)
             self.HB = torch.empty((max(C, 1), m, m), dtype=dt, device=dev)
-            with torch.cuda.device(dev):
+            with _C._on_device(dev):
                 code = _C.library().symbol("pplie_graph_assemble_csr" + sfx, _pg._ASMC_SIG)(
                     sh.ptr.data_ptr(), sh.blk.data_ptr(), lin.J.data_ptr(), lin.W.data_ptr() if lin.W is not None else None,
                     lin.R.data_ptr(), self.B.data_ptr(), self.g.data_ptr(), self.HB.data_ptr(), n, lin.dr, m, lin.K,
@@ -129,7 +129,7 @@ class NodeShardedSystem:
                 self._scal = torch.zeros(_pg._PCG_SCAL_ELEMS, dtype=p_loc.dtype, device=p_loc.device)
                 self._it = torch.zeros(2, dtype=torch.int32, device=p_loc.device)
             sfx = "_f32" if p_loc.dtype == torch.float32 else "_f64"
-            with torch.cuda.device(p_loc.device):
+            with _C._on_device(p_loc.device):
                 code = _C.library().symbol("pplie_graph_bsr_spmv" + sfx, _pg._BSR_SIG)(
                     sh.ptr.data_ptr(), sh.other.data_ptr(), self.HB.data_ptr(), D.data_ptr(), p_loc.data_ptr(), q.data_ptr(),
                     self._scal.data_ptr(), self._it.data_ptr(), n, m, _C.stream_ptr(p_loc.device))
@@ -165,7 +165,7 @@ class NodeShardedSystem:
         w['it'].zero_()
         w['p'].zero_()
         S = w['scal'].view(2, 8, 32, 32)
-        with torch.cuda.device(dev):
+        with _C._on_device(dev):
             _C.check(lib.symbol("pplie_pcg_prepare" + sfx, _pg._PREP_SIG)(
                 self.B.data_ptr(), self.g.data_ptr(), w['D'].data_ptr(), w['Binv'].data_ptr(), w['shift'].data_ptr(), w['x'].data_ptr(),
                 w['r'].data_ptr(), w['z'].data_ptr(), w['p'].data_ptr(), w['scal'].data_ptr(), float(s), float(dmin), float(dmax), n, m, st),

@@ -209,6 +209,7 @@ class BlockLinearization:
 
 
 _REPROBE = 64
+_REVERIFY = 1024      # (a multiple of _REPROBE)
 
 
 def _row_count(t):
@@ -227,9 +228,12 @@ def _linearize(opt, pg, input, target, weight, gauss_newton=False):
     # model whose row dependence changes with its input values at fixed shapes would keep a stale "yes".  Positive
     # verdicts therefore expire every _REPROBE linearisations and are re-established by a fresh probe (one extra
     # vector-Jacobian product); negative ones stay (the dense path is always correct).
+    # The fused programs' verdict is the expensive one to re-establish (a whole autograd linearisation to compare with: 5 ms
+    # on a 10k-pose graph, 8 % of the run if paid every 64 steps) and the least exposed -- a recognised program is re-derived
+    # from a traced forward every fused._RETRACE steps anyway -- so it expires every _REVERIFY linearisations instead.
     uses = cache['_uses'] = cache.get('_uses', 0) + 1
     if uses % _REPROBE == 0:
-        for k in [k for k, v in cache.items() if v is True]:
+        for k in [k for k, v in cache.items() if v is True and (k != "fused" or uses % _REVERIFY == 0)]:
             cache[k] = None
     # Under torch.inference_mode nothing can be recorded for backward sweeps: only the reference's own
     # functional-jacobian linearisation (DenseLinearization) applies (tests/optim/test_optimizer.py:153-159).

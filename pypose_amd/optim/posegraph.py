@@ -275,11 +275,15 @@ class FusedPCG:
         self.Binv, self.shift = z(N, m, m), z(N, m)
         self.x, self.r, self.p, self.q, self.z = (z(N, m) for _ in range(5))
         self.r2 = z(N, m)                                          # the two-launch iteration ping-pongs the residual
-        self.scal = z(_PCG_SCAL_ELEMS)
+        # scal | part | it share ONE allocation: a solve clears them with a single fill instead of three
+        esz = 4 if dtype == torch.float32 else 8
+        nb_scal, nb_part, nb_it = _PCG_SCAL_ELEMS * esz, 2 * _PERSIST_GRID_MAX * 8 * 8, 16
+        self._ctl = torch.zeros(nb_scal + nb_part + nb_it, dtype=torch.uint8, device=device)
+        self.scal = self._ctl[:nb_scal].view(dtype)
         self.cap = 1 << 16
         self.rr_hist = z(self.cap)
-        self.it = torch.zeros(2, dtype=torch.int32, device=device)
-        self.part = torch.zeros(2 * _PERSIST_GRID_MAX * 8, dtype=torch.int64, device=device)   # persistent solve: tagged partial sums
+        self.part = self._ctl[nb_scal:nb_scal + nb_part].view(torch.int64)   # persistent solve: tagged partial sums
+        self.it = self._ctl[nb_scal + nb_part:].view(torch.int32)[:2]
         self.bar = torch.zeros(64 + 32 * 32, dtype=torch.int32, device=device)      # PPLIE_GRID_BAR_WORDS
         self.info = z(4)
         self.sfx = "_f32" if dtype == torch.float32 else "_f64"
@@ -349,9 +353,14 @@ class FusedPCG:
         if bsr:
             self._csr(lin)
             sym = bool(getattr(lin, "HB_sym", False))
-            if self.HB is None or self.HB.shape != lin.HB.shape or sym != self.sym:
-                self.HB, self.sym, self.graph = torch.empty_like(lin.HB), sym, None
-            self.HB.copy_(lin.HB)                                   # off-diagonal blocks in incidence (or edge) order
+            if self.two_launch and self.persist and not plain and self.N <= PERSIST_NODES and not sym:
+                self.HB, self.sym = lin.HB, sym                     # the persistent solve reads the linearisation's blocks in place
+            else:                                                   # captured iterations point at a buffer of the workspace
+                own = self.__dict__.get('_own_HB')
+                if own is None or own.shape != lin.HB.shape or own.dtype != lin.HB.dtype or sym != self.sym or self.HB is not own:
+                    own = self._own_HB = torch.empty_like(lin.HB) if own is None or own.shape != lin.HB.shape else own
+                    self.HB, self.sym, self.graph = own, sym, None
+                self.HB.copy_(lin.HB)                               # off-diagonal blocks in incidence (or edge) order
         else:
             if self.J is None:
                 self.J, self.idx = torch.empty_like(lin.J), torch.empty_like(lin.idx)
@@ -360,9 +369,8 @@ class FusedPCG:
             self.idx.copy_(lin.idx)
             if self.W is not None:
                 self.W.copy_(lin.W)
-        self.scal.zero_()
-        self.it.zero_()
-        with torch.cuda.device(self.device):
+        self._ctl.zero_()                                           # scal, part (sequence tags restart at 1), it
+        with _C._on_device(self.device):
             # one launch: D = clamped + damped block diagonal, Binv = D^-1, shift, x = 0, r = -g, z = Binv r, p = z, r.z, |g|^2
             code = _C.library().symbol("pplie_pcg_prepare" + self.sfx, _PREP_SIG)(
                 lin.B.data_ptr(), lin.g.data_ptr(), self.D.data_ptr(), self.Binv.data_ptr(), self.shift.data_ptr(),
@@ -377,7 +385,6 @@ class FusedPCG:
             if bsr and self.two_launch and self.persist and not plain and self.N <= PERSIST_NODES:
                 # the whole solve in one launch: iteration, reductions and the convergence test stay on the device
                 maxit = min(maxiter, self.cap)
-                self.part.zero_()                                   # sequence tags restart at 1
                 code = _C.library().symbol("pplie_pcg_persist" + self.sfx, _PERSIST_SIG)(
                     self.ptr.data_ptr(), self.other.data_ptr(), self.HB.data_ptr(), self.D.data_ptr(), self.Binv.data_ptr(),
                     self.x.data_ptr(), self.r.data_ptr(), self.p.data_ptr(), self.q.data_ptr(), self.z.data_ptr(),
@@ -449,7 +456,7 @@ class GraphOperator:
         Dn = Dn if Dn.is_contiguous() else Dn.contiguous()
         part = torch.zeros((_GAIN_PARTIALS, 2), dtype=Dn.dtype, device=Dn.device)
         fn = _C.library().symbol("pplie_graph_gain_terms" + ("_f32" if Dn.dtype == torch.float32 else "_f64"), _GAIN_SIG)
-        with torch.cuda.device(Dn.device):
+        with _C._on_device(Dn.device):
             code = fn(lin.J.data_ptr(), lin.idx.data_ptr(), Dn.data_ptr(), lin.wfull, lin.R.data_ptr(), part.data_ptr(),
                       lin.E, lin.dr, lin.m, lin.K, _C.stream_ptr(Dn.device))
         _C.check(code, "pplie_graph_gain_terms")
@@ -535,7 +542,7 @@ class GraphLinearization:
             lib, st = _C.library(), _C.stream_ptr(dev)
             wptr = self.W.data_ptr() if self.W is not None else None
             csr_ok = self.group is None and self.E * self.K < (1 << 31)
-            with torch.cuda.device(dev):
+            with _C._on_device(dev):
                 if csr_ok:      # node-parallel: every block / gradient row written once, no atomics, no zero-fill
                     B = torch.empty((N, m, m), dtype=dt, device=dev)
                     g = torch.empty((N, m), dtype=dt, device=dev)
@@ -573,7 +580,7 @@ class GraphLinearization:
         if self._hip():
             sfx = "_f32" if p.dtype == torch.float32 else "_f64"
             fn = _C.library().symbol("pplie_graph_spmv" + sfx, _SPMV_SIG)
-            with torch.cuda.device(p.device):
+            with _C._on_device(p.device):
                 code = fn(self.J.data_ptr(), self.W.data_ptr() if self.W is not None else None, self.idx.data_ptr(),
                           p.data_ptr(), y.data_ptr(), self.E, self.dr, self.m, self.K, _C.stream_ptr(p.device))
             _C.check(code, "pplie_graph_spmv")
