@@ -100,6 +100,41 @@ template <class T> int chol_dispatch(int dp, const void* A, const void* g, void*
   return PPLIE_EBADARG;
 }
 
+// x = (A with its diagonal clamped to [dmin, dmax] and scaled by s)^-1 (-g): the LM trial's damped solve on the RAW normal
+// equations (optimizer.py:655-657, 666: clamp once, `A.diag += A.diag * damping` on every retry -> s = prod (1 + damping_i)).
+// The diagonal is adjusted in registers; A is not written, so a retry is the same launch with a larger s -- three strided
+// elementwise passes over the [n, dp, dp] blocks per trial gone.
+template <class T> struct DampParam { T s, dmin, dmax; };
+template <class T, int DP> struct Op_damped_chol_solve {
+  enum { IW0 = DP * DP, IW1 = DP, IW2 = 0, OW0 = DP, OW1 = 0 };
+  static PP_HD void apply(const T* A, const T* g, const T*, T* x, T*, DampParam<T> prm) {
+    T Ad[DP * DP];
+#pragma unroll
+    for (int i = 0; i < DP * DP; ++i) Ad[i] = A[i];
+#pragma unroll
+    for (int j = 0; j < DP; ++j) {
+      const T d0 = A[j * DP + j];
+      // torch.clamp(min, max) semantics (NaN stays NaN)
+      const T d = d0 < prm.dmin ? prm.dmin : (d0 > prm.dmax ? prm.dmax : d0);
+      Ad[j * DP + j] = d * prm.s;
+    }
+    Op_chol_solve<T, DP>::apply(Ad, g, nullptr, x, nullptr);
+  }
+};
+template <class T> int damped_chol_dispatch(int dp, const void* A, const void* g, void* x, int64_t n, double s, double dmin,
+                                            double dmax, void* stream) {
+  const DampParam<T> prm{(T)s, (T)dmin, (T)dmax};
+#define PPLIE_DCS(DPN)                                                                                                 \
+  case DPN:                                                                                                            \
+    return launch_rowmap<T, Op_damped_chol_solve<T, DPN>, 1, 64, false, DampParam<T>>(A, g, nullptr, x, nullptr, n, stream, \
+                                                                                      kGridCap, prm);
+  switch (dp) {
+    PPLIE_DCS(3) PPLIE_DCS(4) PPLIE_DCS(5) PPLIE_DCS(6) PPLIE_DCS(7) PPLIE_DCS(8)
+  }
+#undef PPLIE_DCS
+  return PPLIE_EBADARG;
+}
+
 template <class T> int spd_inverse_dispatch(int dp, const void* A, void* X, int64_t n, void* stream) {
   switch (dp) {
     case 3: return launch_rowmap<T, Op_spd_inverse<T, 3>, 1, 64>(A, nullptr, nullptr, X, nullptr, n, stream);
@@ -129,4 +164,12 @@ extern "C" int pplie_block_chol_solve_f32(const void* A, const void* g, void* x,
 }
 extern "C" int pplie_block_chol_solve_f64(const void* A, const void* g, void* x, int64_t n, int dp, void* stream) {
   return pplie::chol_dispatch<double>(dp, A, g, x, n, stream);
+}
+extern "C" int pplie_block_damped_chol_solve_f32(const void* A, const void* g, void* x, int64_t n, int dp, double s, double dmin,
+                                                 double dmax, void* stream) {
+  return pplie::damped_chol_dispatch<float>(dp, A, g, x, n, s, dmin, dmax, stream);
+}
+extern "C" int pplie_block_damped_chol_solve_f64(const void* A, const void* g, void* x, int64_t n, int dp, double s, double dmin,
+                                                 double dmax, void* stream) {
+  return pplie::damped_chol_dispatch<double>(dp, A, g, x, n, s, dmin, dmax, stream);
 }

@@ -23,6 +23,7 @@ from .. import _C
 
 _NE_SIG = [ctypes.c_void_p] * 5 + [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
 _CH_SIG = [ctypes.c_void_p] * 3 + [ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]
+_DCH_SIG = [ctypes.c_void_p] * 3 + [ctypes.c_int64, ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_void_p]
 _HIP_DR, _HIP_DP = (3, 4, 6, 7), (3, 4, 5, 6, 7, 8)
 
 
@@ -77,6 +78,21 @@ def chol_solve(A, g):
     return torch.cholesky_solve(-g.unsqueeze(-1), L).squeeze(-1)
 
 
+def damped_chol_solve(A, g, s, dmin, dmax):
+    """x [n,dp] with (A, diagonal clamped to [dmin, dmax] and scaled by s) x = -g, or None where only the two-pass route applies
+    (off the HIP path, block sizes outside the kernel table).  A is NOT modified: the LM trial loop damps by growing ``s``."""
+    n, dp, _ = A.shape
+    if _C._test_backend is not None or not (A.is_cuda and _suffix(A) and dp in _HIP_DP and n > 0):
+        return None
+    A, g = A.contiguous(), g.contiguous()
+    x = torch.empty((n, dp), dtype=A.dtype, device=A.device)
+    fn = _C.library().symbol("pplie_block_damped_chol_solve" + _suffix(A), _DCH_SIG)
+    with _C._on_device(A.device):
+        code = fn(A.data_ptr(), g.data_ptr(), x.data_ptr(), n, dp, float(s), float(dmin), float(dmax), _C.stream_ptr(A.device))
+    _C.check(code, "pplie_block_damped_chol_solve")
+    return x
+
+
 def jacobian_blocks(residuals, params):
     """Per-row Jacobian blocks under the row-independence hypothesis.
 
@@ -100,8 +116,9 @@ def jacobian_blocks(residuals, params):
                 cols.append(torch.zeros((n, d, w), dtype=r.dtype, device=r.device))
             else:
                 cols.append(gr.reshape(d, n, w).permute(1, 0, 2))
-        rows.append(torch.cat(cols, dim=-1))
-    return torch.cat(rows, dim=-2).contiguous()
+        rows.append(cols[0] if len(cols) == 1 else torch.cat(cols, dim=-1))      # (cat of one tensor is still a copy)
+    # one residual, one parameter: the [d, n, w] sweep output is transposed exactly once
+    return (rows[0] if len(rows) == 1 else torch.cat(rows, dim=-2)).contiguous()
 
 
 def probe_block_structure(residuals, params, J, rtol=1e-3):

@@ -179,18 +179,31 @@ class BlockLinearization:
         self.op = _blocks.BlockJacobian(self.Jb, [p.shape[-1] for p in params])
 
     def build_normal_equations(self, dmin, dmax):
-        self.A, self.g = _blocks.normal_equations(self.Jb, self.Rb, self.Wb)
-        self.A.diagonal(dim1=-2, dim2=-1).clamp_(dmin, dmax)
+        # the blocks stay RAW; clamping and the (compounding) damping of the trial loop are a scale factor applied to the
+        # diagonal -- inside the solve kernel where there is one (pplie_block_damped_chol_solve), else materialised on demand
+        self.A_raw, self.g = _blocks.normal_equations(self.Jb, self.Rb, self.Wb)
+        self.dmin, self.dmax, self.s, self._A = dmin, dmax, 1.0, None
 
     def damp(self, damping):
-        d = self.A.diagonal(dim1=-2, dim2=-1)
-        d.add_(d * damping)
+        self.s, self._A = self.s * (1.0 + damping), None
+
+    @property
+    def A(self):
+        """the damped normal equations as a tensor (user solver objects, tests): diag <- clamp(diag) * s"""
+        if self._A is None:
+            A = self.A_raw.clone()
+            d = A.diagonal(dim1=-2, dim2=-1)
+            d.copy_(d.clamp(self.dmin, self.dmax) * self.s)
+            self._A = A
+        return self._A
 
     def solve(self, solver):
         from .posegraph import PCG
         if (isinstance(solver, Cholesky) and not solver.upper) or isinstance(solver, PCG):
             # (an iterative solver has nothing to iterate on for d_par x d_par blocks: factor them)
-            Db = _blocks.chol_solve(self.A, self.g)
+            Db = _blocks.damped_chol_solve(self.A_raw, self.g, self.s, self.dmin, self.dmax)
+            if Db is None:
+                Db = _blocks.chol_solve(self.A, self.g)
             assert not torch.any(torch.isnan(Db)), \
                 'Cholesky decomposition failed. Check your matrix (may not be positive-definite)'
         else:   # any other solver object: batched call, block by block
