@@ -65,8 +65,10 @@ def _launch(name, ins, in_widths, out_widths, prm=None):
         lvl = _legacy_level(next(t for t in ins if _is_legacy_batched(t)))
         phys = [torch._remove_batch_dim(t, lvl, 1, 0) if _is_legacy_batched(t) else None for t in ins]
         bsz = next(p.shape[0] for p in phys if p is not None)
-        phys = [p if p is not None else t.unsqueeze(0).expand((bsz,) + tuple(t.shape)) for p, t in zip(phys, ins)]
-        outs = _launch(name, phys, in_widths, out_widths, prm)
+        outs = _launch_slices(name, ins, phys, bsz, in_widths, out_widths) if prm is None and not _op_tracers else None
+        if outs is None:
+            phys = [p if p is not None else t.unsqueeze(0).expand((bsz,) + tuple(t.shape)) for p, t in zip(phys, ins)]
+            outs = _launch(name, phys, in_widths, out_widths, prm)
         return tuple(torch._add_batch_dim(o, 0, lvl) for o in outs)
     lead = ins[0].shape[:-1]
     if any(t.shape[:-1] != lead for t in ins[1:]):
@@ -81,6 +83,43 @@ def _launch(name, ins, in_widths, out_widths, prm=None):
     for tr in _op_tracers:
         tr.note(name, ins, outs)
     return outs
+
+
+_SLICE_ROWS = 1 << 16          # per-slice launches pay off once a slice is this many rows (a launch is ~10 us of host time)
+
+
+def _launch_slices(name, ins, phys, bsz, in_widths, out_widths):
+    """The batched backward of the block linearisations (d_res cotangents against the SAME saved operands): one launch per
+    batch slice straight into the [bsz, rows, w] outputs, the un-batched operands read in place -- expanding them to the
+    batch and flattening costs a bsz-fold copy per operand per kernel (3 x 170 MB per LM step at 10^6 problems).  None when
+    it does not apply (everything batched, small slices, broadcasting between the operands)."""
+    if bsz > 16 or all(p is not None for p in phys):
+        return None
+    lead = None
+    for t, p in zip(ins, phys):
+        shp = tuple((p if p is not None else t).shape[(1 if p is not None else 0):-1])
+        if lead is None:
+            lead = shp
+        elif shp != lead:
+            return None
+    rows = 1
+    for v in lead:
+        rows *= v
+    if rows < _SLICE_ROWS:
+        return None
+    flat = []
+    for t, p, w in zip(ins, phys, in_widths):
+        if p is None:
+            flat.append(_rows(t, w))                                   # [rows, w], shared by every slice
+        else:
+            if p.shape[-1] != w:
+                raise ValueError(f"expected last dimension {w}, got shape {tuple(p.shape)}")
+            flat.append(p.reshape(bsz, rows, w).contiguous())          # [bsz, rows, w]
+    x0 = flat[0]
+    outs = tuple(torch.empty((bsz, rows, w), dtype=x0.dtype, device=x0.device) for w in out_widths)
+    for b in range(bsz):
+        _C.row_op(name, [f if f.dim() == 2 else f[b] for f in flat], out_widths, out=[o[b] for o in outs])
+    return tuple(o.view((bsz,) + lead + (w,)) for o, w in zip(outs, out_widths))
 
 
 def _fold_vmap(in_dims, args):

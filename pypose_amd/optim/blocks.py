@@ -93,6 +93,27 @@ def damped_chol_solve(A, g, s, dmin, dmax):
     return x
 
 
+_COT_CACHE = {}
+_COT_CACHE_BYTES = 1 << 28
+
+
+def _one_hot_cotangents(d, r):
+    """[d, *r.shape]: cotangent k is one-hot in residual component k, for every row.  Constant per (shape, dtype, device):
+    large ones are kept MATERIALISED (the first backward kernel needs contiguous rows; as an expanded view the d-fold copy
+    is made again on every linearisation -- 144 MB at 10^6 problems), one entry, up to 256 MB."""
+    eye = torch.eye(d, dtype=r.dtype, device=r.device)
+    view = eye.view((d,) + (1,) * (r.dim() - 1) + (d,)).expand((d,) + tuple(r.shape))
+    nbytes = view.numel() * r.element_size()
+    if not r.is_cuda or nbytes < (1 << 22) or nbytes > _COT_CACHE_BYTES:
+        return view
+    key = (d, tuple(r.shape), r.dtype, r.device)
+    hit = _COT_CACHE.get(key)
+    if hit is None:
+        _COT_CACHE.clear()
+        hit = _COT_CACHE[key] = view.contiguous()
+    return hit
+
+
 def jacobian_blocks(residuals, params):
     """Per-row Jacobian blocks under the row-independence hypothesis.
 
@@ -106,8 +127,7 @@ def jacobian_blocks(residuals, params):
     rows = []
     for k, r in enumerate(residuals):
         d = r.shape[-1]
-        eye = torch.eye(d, dtype=r.dtype, device=r.device)
-        cot = eye.view((d,) + (1,) * (r.dim() - 1) + (d,)).expand((d,) + tuple(r.shape))
+        cot = _one_hot_cotangents(d, r)
         grads = torch.autograd.grad(r, params, cot, is_grads_batched=True, retain_graph=True, allow_unused=True)
         cols = []
         for p, gr in zip(params, grads):
