@@ -18,6 +18,7 @@ other BASELINE config, each with its own roofline figures:
     lm_invnet   configs[2]  LM on InvNet SE3, 10^6 independent problems
     lm_pgo      metric      LM iterations / s on a 10 k-pose graph;  lm_pgo_100k  configs[3] on one GPU
     imu         configs[4]  IMUPreintegrator 4096 x 1024 with and without covariance
+    ba_reproj   SURVEY 8(f) rank 3: reprojection residual + closed-form Jacobian blocks, 4 M observations
 With N > 1 (one process per GPU) the sharded legs replace them: lm_invnet_sharded (problems), imu_sharded (sequences),
 lm_pgo_sharded (configs[3]: edges / solve sharded).
 """
@@ -349,6 +350,45 @@ def c1_latency(dev, B=1024):
     return out
 
 
+def reproj_rate(dev, E=4_000_000, reps=10):
+    """reprojection residual + closed-form Jacobian blocks of E (camera pose, point) observations in one
+    kernel (pplie_se3_reproj_lin: 84 B read + 80 B written per observation), beside the same blocks from two batched backward
+    sweeps of the unfused composition (SE3_Act kernel + tensor algebra)."""
+    import torch
+    import pypose_amd as pp
+    from pypose_amd import _C
+    from pypose_amd.optim import blocks as _blocks
+    torch.manual_seed(0)
+    X = pp.randn_SE3(E, sigma=0.3, device=dev).tensor().contiguous()
+    p = (torch.randn(E, 3, device=dev) + torch.tensor([0, 0, 6.0], device=dev)).contiguous()
+    K = torch.tensor([[500.0, 0, 320], [0, 500, 240], [0, 0, 1]], device=dev)
+    cam = torch.cat([K.reshape(1, 9).expand(E, 9), torch.randn(E, 2, device=dev)], -1).contiguous()
+
+    def med_ms(f, n):
+        f(); _sync(dev)
+        ts = []
+        for _ in range(n):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(); f(); b.record(); _sync(dev)
+            ts.append(a.elapsed_time(b))
+        return sorted(ts)[len(ts) // 2]
+
+    ms = med_ms(lambda: _C.row_op("se3_reproj_lin", [X, p, cam], (2, 18)), reps)
+
+    def sweeps():
+        Xp = pp.SE3(X).requires_grad_(True)
+        pr = p.clone().requires_grad_(True)
+        r = pp.homo2cart(Xp.Act(pr) @ K.mT) - cam[:, 9:]
+        return _blocks.jacobian_blocks([r], [Xp, pr])
+    ms_auto = med_ms(sweeps, max(2, reps // 3))
+    nbytes = 164.0 * E
+    return {"metric": "reprojection linearisation (residual + closed-form blocks), observations/s", "unit": "observations/s",
+            "observations": E, "value": E / (ms * 1e-3), "ms": ms, "autograd_blocks_ms": ms_auto,
+            "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBPS, "achieved": nbytes / ms / 1e6,
+                         "frac": nbytes / ms / 1e6 / HBM_PEAK_GBPS, "algorithmic_bytes_per_launch": nbytes,
+                         "per": "observation: pose 28 + point 12 + intrinsics / pixel 44 read, residual 8 + blocks 72 written"}}
+
+
 def imu_sharded_rate(dev, rank, world, B=4096, F=1024):
     """configs[4] with the SEQUENCES sharded: every rank integrates its own B sequences, no collective."""
     import torch
@@ -548,7 +588,8 @@ def main():
                 ("lm_pgo", lambda: pgo_lm_rate(dev, *((60, 150) if small else (10_000, 40_000)), reps=1 if small else 5)),
                 ("lm_pgo_100k", lambda: pgo_lm_rate(dev, *((80, 200) if small else (100_000, 400_000)), reps=1 if small else 5,
                                                     with_static=False)),
-                ("imu", lambda: imu_rate(dev, *((8, 64) if small else (4096, 1024)), reps=2 if small else 20)))
+                ("imu", lambda: imu_rate(dev, *((8, 64) if small else (4096, 1024)), reps=2 if small else 20)),
+                ("ba_reproj", lambda: reproj_rate(dev, 2000 if small else 4_000_000, reps=2 if small else 10)))
         for key, fn in legs:
             try:
                 out[key] = fn()

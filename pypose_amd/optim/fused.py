@@ -496,7 +496,7 @@ class PgoProgram:
         self.E = self.idx.shape[0]
 
     def linearize(self):
-        nodes = self.P.detach()
+        nodes = torch.Tensor.as_subclass(self.P, torch.Tensor).detach()     # (plain: no __torch_function__ round trips below)
         assert nodes.is_contiguous()
         R = torch.empty((self.E, 6), dtype=nodes.dtype, device=nodes.device)
         J = torch.empty((self.E, 2, 6, 6), dtype=nodes.dtype, device=nodes.device)
@@ -509,7 +509,7 @@ class PgoProgram:
 
     def loss(self, group=None):
         """sum |r|^2 at the current parameter values (the Trivial-kernel loss of optimizer.py:118-125)."""
-        nodes = self.P.detach()
+        nodes = torch.Tensor.as_subclass(self.P, torch.Tensor).detach()     # (plain: no __torch_function__ round trips below)
         part = torch.zeros(_PGO_PARTIALS, dtype=nodes.dtype, device=nodes.device)
         fn = _C.library().symbol("pplie_pgo_residual" + _blocks._suffix(nodes), _PGO_SIG)
         with _C._on_device(nodes.device):
