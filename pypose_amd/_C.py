@@ -119,6 +119,31 @@ class _on_device:
             self.ctx.__exit__(*exc)
 
 
+class graph_capture:
+    """``with torch.cuda.graph(g)`` without a cyclic-GC pass inside the capture: a collection may finalise unrelated device
+    objects (another captured graph, events, streams) whose destructors call HIP APIs that are illegal while a stream is
+    capturing -- the process aborts.  (torch.cuda.graph collects once on entry; a Python-heavy capture body can trigger
+    another.)"""
+
+    def __init__(self, g):
+        self.ctx = torch.cuda.graph(g)
+
+    def __enter__(self):
+        import gc
+        self.was_enabled = gc.isenabled()
+        self.ctx.__enter__()
+        gc.disable()
+        return self
+
+    def __exit__(self, *exc):
+        import gc
+        try:
+            return self.ctx.__exit__(*exc)
+        finally:
+            if self.was_enabled:
+                gc.enable()
+
+
 def mark_written(t):
     """Bump the version counter of a tensor a kernel has just written through its raw pointer.  Autograd detects in-place
     modification of tensors saved for backward by comparing version counters; a raw-pointer write that skipped this

@@ -639,7 +639,10 @@ template <class T, int M>
 __global__ void __launch_bounds__(256)
 pcg_prepare_kernel(const T* __restrict__ B, const T* __restrict__ g, T* __restrict__ D, T* __restrict__ Binv,
                    T* __restrict__ shift, T* __restrict__ x, T* __restrict__ r, T* __restrict__ z, T* __restrict__ p,
-                   T* scal, T s, T dmin, T dmax, int64_t N) {
+                   T* scal, T s_host, T dmin, T dmax, int64_t N, const double* __restrict__ s_dev) {
+  // the compounded damping factor: a launch argument, or (s_dev) a device scalar -- a captured hipGraph of the whole LM trial
+  // is replayed with the factor of the day written there
+  const T s = s_dev ? (T)s_dev[0] : s_host;
   T a_rho = T(0), a_bn = T(0);
   for (int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x; n < N; n += (int64_t)gridDim.x * 256) {
     T A[M * M], X[M * M], rv[M];
@@ -678,7 +681,7 @@ pcg_prepare_kernel(const T* __restrict__ B, const T* __restrict__ g, T* __restri
 }
 template <class T>
 int pcg_prepare(const void* B, const void* g, void* D, void* Binv, void* shift, void* x, void* r, void* z, void* p, void* scal,
-                double s, double dmin, double dmax, int64_t N, int m, void* stream) {
+                double s, double dmin, double dmax, int64_t N, int m, void* stream, const void* s_dev = nullptr) {
   if (N <= 0) return N == 0 ? PPLIE_OK : PPLIE_EBADARG;
   if (!B || !g || !D || !Binv || !shift || !x || !r || !z || !p || !scal) return PPLIE_EBADARG;
   int64_t nb = (N + 255) / 256;
@@ -686,7 +689,7 @@ int pcg_prepare(const void* B, const void* g, void* D, void* Binv, void* shift, 
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 #define LAUNCH(MM)                                                                                                      \
   hipLaunchKernelGGL((pcg_prepare_kernel<T, MM>), dim3(grid), dim3(256), 0, st, (const T*)B, (const T*)g, (T*)D, (T*)Binv, \
-                     (T*)shift, (T*)x, (T*)r, (T*)z, (T*)p, (T*)scal, (T)s, (T)dmin, (T)dmax, N);
+                     (T*)shift, (T*)x, (T*)r, (T*)z, (T*)p, (T*)scal, (T)s, (T)dmin, (T)dmax, N, (const double*)s_dev);
   if (m == 6) { LAUNCH(6) } else if (m == 7) { LAUNCH(7) } else if (m == 3) { LAUNCH(3) } else return PPLIE_EBADARG;
 #undef LAUNCH
   return hipGetLastError() == hipSuccess ? PPLIE_OK : PPLIE_ELAUNCH;
@@ -754,6 +757,19 @@ extern "C" int pplie_pcg_prepare_f32(const void* B, const void* g, void* D, void
 extern "C" int pplie_pcg_prepare_f64(const void* B, const void* g, void* D, void* Binv, void* shift, void* x, void* r, void* z,
                                      void* p, void* scal, double s, double dmin, double dmax, int64_t N, int m, void* stream) {
   return pplie::pcg_prepare<double>(B, g, D, Binv, shift, x, r, z, p, scal, s, dmin, dmax, N, m, stream);
+}
+// the same with the damping factor read from device memory (s_dev: one double) at execution time
+extern "C" int pplie_pcg_prepare_dev_f32(const void* B, const void* g, void* D, void* Binv, void* shift, void* x, void* r, void* z,
+                                         void* p, void* scal, const void* s_dev, double dmin, double dmax, int64_t N, int m,
+                                         void* stream) {
+  if (!s_dev) return pplie::PPLIE_EBADARG;
+  return pplie::pcg_prepare<float>(B, g, D, Binv, shift, x, r, z, p, scal, 1.0, dmin, dmax, N, m, stream, s_dev);
+}
+extern "C" int pplie_pcg_prepare_dev_f64(const void* B, const void* g, void* D, void* Binv, void* shift, void* x, void* r, void* z,
+                                         void* p, void* scal, const void* s_dev, double dmin, double dmax, int64_t N, int m,
+                                         void* stream) {
+  if (!s_dev) return pplie::PPLIE_EBADARG;
+  return pplie::pcg_prepare<double>(B, g, D, Binv, shift, x, r, z, p, scal, 1.0, dmin, dmax, N, m, stream, s_dev);
 }
 extern "C" int pplie_graph_gain_terms_f32(const void* J, const void* idx, const void* d, int ld, const void* R, void* partial,
                                           int64_t E, int dr, int m, int k, void* stream) {

@@ -535,7 +535,7 @@ class _GraphedPCG:
         while done < maxiter:
             if self.graph is None and done > 0:                   # first block runs eagerly (warm-up), then capture
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                with _C.graph_capture(g):
                     for k in range(self.check_every):
                         self._iteration(k)
                 self.graph = g

@@ -465,6 +465,14 @@ class LevenbergMarquardt(_Optimizer):
             out = dev.try_step(input, target, weight)
             if out is not None:
                 return out
+        gs = self.__dict__.get('_pgo_graph_step')
+        if gs is not None and not (self._optimizer_step_pre_hooks or self._optimizer_step_post_hooks
+                                   or _torch_opt._global_optimizer_pre_hooks or _torch_opt._global_optimizer_post_hooks):
+            pg = self.param_groups[0]
+            w = self.weight if weight is None else weight
+            if gs.usable(pg, input, target, w):
+                with torch.no_grad():
+                    return gs.step(pg)
         return self._step_general(input, target, weight)
     step.hooked = True              # torch.optim.Optimizer.__init__ must not wrap it again: _step_general carries the wrapper
 
@@ -493,36 +501,77 @@ class LevenbergMarquardt(_Optimizer):
             # waiting for the host to have looked at it (a failed solve returns a zero step)
             defer = (self.group is None and hasattr(J, 'gain_terms') and type(self.strategy) in (Constant, Adaptive, TrustRegion)
                      and getattr(getattr(J, 'lin', None), '_hip', lambda: False)())
-            while last_h <= loss_h:
-                lin.damp(pg['damping'])
-                self._defer_solver_info = defer
-                try:
-                    D = lin.solve(self.solver)
-                except Exception as e:
-                    print(e, "\nLinear solver failed. Breaking optimization step...")
-                    break
-                finally:
-                    self._defer_solver_info = False
-                self.update_parameter(pg['params'], D)
-                self.loss = lin.fast_loss() if hasattr(lin, 'fast_loss') else self._loss(input, target)
-                try:
-                    loss_h = self._strategy_update(pg, J, D, R, last_h)
-                except _SolveFailed as e:       # noticed after the fact; the step was zero, the parameters are where they were
-                    print(e, "\nLinear solver failed. Breaking optimization step...")
-                    self.loss = self.last
-                    break
-                if getattr(lin, 'pending_info', None) is not None:     # (a strategy path that did not pick it up)
-                    pend, lin.pending_info = lin.pending_info, None
-                    lin._pending_solver.iterations = pend.resolve()
-                if last_h < loss_h and self.reject_count < self.reject:           # reject the step
-                    self.update_parameter(params=pg['params'], step=-D)
-                    self.loss, self.reject_count, loss_h = self.last, self.reject_count + 1, last_h
-                else:
-                    break
+            loss_h = self._trial_loop(pg, lin, J, R, input, target, last_h, loss_h, defer)
+            self._consider_graph_step(pg, lin, input, target, weight, defer)
             self._host_loss = (self.loss, loss_h)
             if self.group is not None and getattr(lin, 'replicated', False):
                 self._sync_replicas(pg['params'])
         return self.loss
+
+    def _trial_loop(self, pg, lin, J, R, input, target, last_h, loss_h, defer):
+        """damp / solve / update / loss / strategy / accept-or-reject until a trial is accepted (optimizer.py:662-678);
+        returns the accepted loss as a host float"""
+        while last_h <= loss_h:
+            lin.damp(pg['damping'])
+            self._defer_solver_info = defer
+            try:
+                D = lin.solve(self.solver)
+            except Exception as e:
+                print(e, "\nLinear solver failed. Breaking optimization step...")
+                break
+            finally:
+                self._defer_solver_info = False
+            self.update_parameter(pg['params'], D)
+            self.loss = lin.fast_loss() if hasattr(lin, 'fast_loss') else self._loss(input, target)
+            try:
+                loss_h = self._strategy_update(pg, J, D, R, last_h)
+            except _SolveFailed as e:       # noticed after the fact; the step was zero, the parameters are where they were
+                print(e, "\nLinear solver failed. Breaking optimization step...")
+                self.loss = self.last
+                break
+            if getattr(lin, 'pending_info', None) is not None:     # (a strategy path that did not pick it up)
+                pend, lin.pending_info = lin.pending_info, None
+                lin._pending_solver.iterations = pend.resolve()
+            if last_h < loss_h and self.reject_count < self.reject:           # reject the step
+                self.update_parameter(params=pg['params'], step=-D)
+                self.loss, self.reject_count, loss_h = self.last, self.reject_count + 1, last_h
+            else:
+                break
+        return loss_h
+
+    def _consider_graph_step(self, pg, lin, input, target, weight, defer):
+        """After PgoGraphStep.MIN_STREAK ordinary steps on the same verified pose-graph program: capture the trial as one
+        hipGraph (optim/pgograph.py); LevenbergMarquardt.step replays it while nothing it was captured on changes."""
+        from .pgograph import PgoGraphStep
+        from .posegraph import PCG, PERSIST_NODES, FusedPCG
+        d = self.__dict__
+        ok = (defer and lin.kind == "fused:pgo" and hasattr(lin, 'fast_loss') and target is None and len(self.param_groups) == 1
+              and isinstance(self.solver, PCG) and getattr(self.solver, 'fused', True) and lin.N <= PERSIST_NODES
+              and FusedPCG.persist and FusedPCG.two_launch and getattr(self, 'graph_step', True)
+              and not isinstance(weight, (tuple, list)))
+        cache = d.get('_structure_cache') or {}
+        hit = cache.get("program")
+        if not ok or hit is None or hit[2] != "pgo" or cache.get("fused") is not True:
+            d['_pgo_streak'] = (None, 0)
+            d.pop('_pgo_graph_step', None)
+            return
+        prog = hit[3]
+        cur = d.get('_pgo_graph_step')
+        if cur is not None and cur.prog is prog:
+            return
+        prev, n = d.get('_pgo_streak', (None, 0))
+        n = n + 1 if prev is prog else 1
+        d['_pgo_streak'] = (prog, n)
+        if n >= PgoGraphStep.MIN_STREAK:
+            params = [p for p in pg['params'] if p.requires_grad]
+            trivial = all(isinstance(c, Trivial) for c in self.corrector) and all(isinstance(k, Trivial) for k in self.model.kernel)
+            try:
+                d['_pgo_graph_step'] = PgoGraphStep(self, pg, prog, input, weight, params[0], trivial)
+            except Exception as e:                       # capture is an optimisation: the ordinary path stays correct
+                d['_pgo_graph_step'] = None
+                d['_pgo_streak'] = (None, -(1 << 30))
+                import warnings
+                warnings.warn(f"pypose_amd: the pose-graph trial could not be captured as a hipGraph ({e}); continuing un-captured")
 
     def _sync_replicas(self, params):
         """Every rank solved the same system by itself; atomic summation order may leave last-bit differences

@@ -39,6 +39,7 @@ _SPMV_SIG = [ctypes.c_void_p] * 5 + [ctypes.c_int64, ctypes.c_int, ctypes.c_int,
 _ASM_SIG = [ctypes.c_void_p] * 7 + [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
 _ASMC_SIG = [ctypes.c_void_p] * 8 + [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
 _PREP_SIG = [ctypes.c_void_p] * 10 + [ctypes.c_double] * 3 + [ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]
+_PREP_DEV_SIG = [ctypes.c_void_p] * 11 + [ctypes.c_double] * 2 + [ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]
 _GAIN_SIG = [ctypes.c_void_p] * 3 + [ctypes.c_int] + [ctypes.c_void_p] * 2 + [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
 _GAIN_PARTIALS = 1024       # PPLIE_GAIN_PARTIALS
 _BSR_SIG = [ctypes.c_void_p] * 8 + [ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]
@@ -372,10 +373,17 @@ class FusedPCG:
         self._ctl.zero_()                                           # scal, part (sequence tags restart at 1), it
         with _C._on_device(self.device):
             # one launch: D = clamped + damped block diagonal, Binv = D^-1, shift, x = 0, r = -g, z = Binv r, p = z, r.z, |g|^2
-            code = _C.library().symbol("pplie_pcg_prepare" + self.sfx, _PREP_SIG)(
-                lin.B.data_ptr(), lin.g.data_ptr(), self.D.data_ptr(), self.Binv.data_ptr(), self.shift.data_ptr(),
-                self.x.data_ptr(), self.r.data_ptr(), self.z.data_ptr(), self.p.data_ptr(), self.scal.data_ptr(),
-                float(s), float(dmin), float(dmax), self.N, self.m, _C.stream_ptr(self.device))
+            s_dev = getattr(lin, 's_dev', None)
+            if s_dev is not None:       # (a captured trial: the damping factor of the day is written to a device scalar)
+                code = _C.library().symbol("pplie_pcg_prepare_dev" + self.sfx, _PREP_DEV_SIG)(
+                    lin.B.data_ptr(), lin.g.data_ptr(), self.D.data_ptr(), self.Binv.data_ptr(), self.shift.data_ptr(),
+                    self.x.data_ptr(), self.r.data_ptr(), self.z.data_ptr(), self.p.data_ptr(), self.scal.data_ptr(),
+                    s_dev.data_ptr(), float(dmin), float(dmax), self.N, self.m, _C.stream_ptr(self.device))
+            else:
+                code = _C.library().symbol("pplie_pcg_prepare" + self.sfx, _PREP_SIG)(
+                    lin.B.data_ptr(), lin.g.data_ptr(), self.D.data_ptr(), self.Binv.data_ptr(), self.shift.data_ptr(),
+                    self.x.data_ptr(), self.r.data_ptr(), self.z.data_ptr(), self.p.data_ptr(), self.scal.data_ptr(),
+                    float(s), float(dmin), float(dmax), self.N, self.m, _C.stream_ptr(self.device))
             _C.check(code, "pplie_pcg_prepare")
             if plain:                                               # z = r, p = r, rho = r.r = |b|^2, Binv = I
                 self.Binv.copy_(torch.eye(self.m, dtype=self.Binv.dtype, device=self.Binv.device).expand_as(self.Binv))
@@ -405,7 +413,7 @@ class FusedPCG:
             while done < maxiter:
                 if group is None and self.graph is None and done > 0 and self.use_graph:
                     g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g):
+                    with _C.graph_capture(g):
                         for _ in range(self.check_every):
                             self._iteration(None)
                     self.graph = g
@@ -504,8 +512,12 @@ class GraphLinearization:
         cache = self.opt.__dict__.setdefault('_graph_csr', {})
         key = (self.E, self.K, self.N, self.idx.device)
         hit = cache.get(key)
-        if hit is not None and ((hit[2] is self.idx and hit[3] == self.idx._version) or torch.equal(hit[0], self.idx)):
-            return hit[1]                                          # (same object, unmodified: no compare kernel / sync)
+        if hit is not None:
+            if hit[2] is self.idx and hit[3] == self.idx._version:
+                return hit[1]                                      # (same object, unmodified: no compare kernel / sync)
+            if torch.equal(hit[0], self.idx):                      # an equal edge list in a new tensor: remember THAT object, so
+                cache[key] = (hit[0], hit[1], self.idx, self.idx._version)     # that the next look-up is by identity again
+                return hit[1]
         E, N, K, idx = self.E, self.N, self.K, self.idx
         flat = idx.t().reshape(-1)                                 # [side 0 entries | side 1 entries | ...]
         order = torch.argsort(flat, stable=True)

@@ -187,6 +187,40 @@ def test_posegraph_pcg_matrix_free_on_gpu(G, two_launch, monkeypatch):
     compare_trajectory(rec, G, "pgo40/infos", floor=1e-12, rtol=1e-7)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("weighted", [False, True])
+def test_posegraph_captured_trial_equals_the_uncaptured_step(G, dtype, weighted):
+    """optim/pgograph.py: after three ordinary steps the LM trial of the recognised pose-graph program is replayed as one
+    hipGraph.  Same kernels on the same numbers: losses, damping, reject counts and parameters must be IDENTICAL to the
+    un-captured path -- through the descent, at the rounding floor (where trials are rejected and the captured trial hands
+    over to the ordinary retry loop), after the caller rewrites the parameters in place, and when the input objects change."""
+    edges, poses = T(G["pgo40/edges"], DEV), pp.SE3(T(G["pgo40/poses"], DEV).to(dtype))
+    kw = {"weight": T(G["pgo40/infos"], DEV).to(dtype)} if weighted else {}
+    runs = {}
+    for captured in (True, False):
+        graph = PoseGraph(pp.SE3(T(G["pgo40/init"], DEV).to(dtype)))
+        opt = pp.optim.LM(graph, solver=pp.optim.solver.PCG(tol=1e-6, maxiter=500), strategy=pp.optim.strategy.TrustRegion(radius=1e4),
+                          min=1e-6)
+        opt.graph_step = captured
+        rec = run_steps(opt, ((edges, poses),), kw, 14)
+        assert (opt.__dict__.get('_pgo_graph_step') is not None) == captured
+        with torch.no_grad():                                  # the caller moves the parameters: the replay linearises where they are
+            graph.nodes.copy_(pp.SE3(T(G["pgo40/init"], DEV).to(dtype)))
+        del opt.loss
+        rec2 = run_steps(opt, ((edges, poses),), kw, 5)
+        edges2 = edges.clone()                                 # new input objects: the capture does not apply, a new one is made
+        rec3 = run_steps(opt, ((edges2, poses),), kw, 5)
+        runs[captured] = (rec, rec2, rec3, graph.nodes.detach().tensor().clone(), opt.solver.iterations)
+    for a, b in zip(runs[True][:3], runs[False][:3]):
+        assert a["loss"] == b["loss"] and a["damping"] == b["damping"] and a["reject"] == b["reject"], (a, b)
+        assert set(a["kind"]) == {"fused:pgo"}
+    assert sum(runs[True][0]["reject"]) > 0                   # the floor was reached: rejected trials went through the hand-over
+    assert torch.equal(runs[True][3], runs[False][3]) and runs[True][4] == runs[False][4]
+    if dtype == torch.float64:
+        compare_trajectory({k: v[:5] for k, v in runs[True][0].items()}, G, "pgo40/infos" if weighted else "pgo40/noweight",
+                           floor=1e-12, rtol=1e-5)
+
+
 def test_posegraph_pcg_one_block_per_edge(G, monkeypatch):
     """the opt-in symmetric storage (pplie_graph_assemble_csr_sym + pplie_pcg2_spmv_sym: H_ji read as H_ij^T) walks the
     reference's trajectory too, weighted (symmetric information matrices) and unweighted"""
