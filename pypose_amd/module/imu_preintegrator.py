@@ -23,6 +23,7 @@ from torch import nn
 from .. import _C
 from ..basics import cumprod
 from ..lietensor import LieTensor, SO3, identity_SO3, so3, vec2skew
+from ..lietensor import lietensor as _lt
 
 _INT_SIG = [ctypes.c_void_p] * 8 + [ctypes.POINTER(ctypes.c_double)] + [ctypes.c_void_p] * 6 + \
            [ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p]
@@ -122,7 +123,12 @@ class IMUPreintegrator(nn.Module):
 
     # ---- fused route ---------------------------------------------------------------------------
     def _fused_ok(self, dt, gyro, acc, rot, init_state):
-        ts = [dt, gyro, acc, init_state['pos'], init_state['rot'], init_state['vel']] + ([rot] if rot is not None else [])
+        # (attribute reads on LieTensors are __torch_function__ round trips: the initial state is looked at through plain
+        #  aliases, and the verdict for the module's own unchanged buffers is remembered)
+        plain = torch.Tensor.as_subclass
+        ts = [dt, gyro, acc, init_state['pos'], plain(init_state['rot'], torch.Tensor), init_state['vel']]
+        if rot is not None:
+            ts.append(plain(rot, torch.Tensor))
         if _C._test_backend is not None or not all(t.is_cuda for t in ts):
             return False
         if torch.is_grad_enabled() and any(t.requires_grad for t in ts):
@@ -218,7 +224,8 @@ class IMUPreintegrator(nn.Module):
             code = fn(P(dtc), P(gy), P(ac), P(rk), P(r0), P(v0), P(p0), P(q0), g, P(orot), P(ovel), P(opos),
                       P(aux.get('Rk')), P(aux.get('Rij')), P(aux.get('a')), B, F, _C.stream_ptr(dev))
         _C.check(code, "pplie_imu_integrate")
-        rot_out = LieTensor(orot, ltype=init_state['rot'].ltype) if isinstance(init_state['rot'], LieTensor) else SO3(orot)
+        r_in = init_state['rot']
+        rot_out = _lt._wrap(orot, r_in.ltype if isinstance(r_in, LieTensor) else _lt.SO3_type)
         return {'rot': rot_out, 'vel': ovel, 'pos': opos}, aux
 
     def _fused_cov(self, dt, aux, init_cov, gyro_cov, acc_cov):

@@ -84,7 +84,11 @@ class PgoGraphStep:
             return False
         if P.data_ptr() != self.ptr or [p for p in pg['params'] if p.requires_grad] != self.params:
             return False
-        if _fused._strategy_kind(opt.strategy) is None or opt.group is not None:
+        if _fused._strategy_kind(opt.strategy) is None or opt.group is not None or len(opt.param_groups) != 1:
+            return False
+        from .optimizer import Trivial
+        if (all(isinstance(c, Trivial) for c in opt.corrector) and all(isinstance(k, Trivial) for k in opt.model.kernel)) != self.trivial \
+                or len(opt.corrector) != 1:
             return False
         from .optimizer import _REPROBE
         uses = cache['_uses'] = cache.get('_uses', 0) + 1
