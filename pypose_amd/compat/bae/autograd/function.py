@@ -21,7 +21,7 @@ from functools import wraps
 import torch
 
 _TAPE = []          # (root parameter, row index or None for "all rows", gathered rows as they appear in the graph)
-_TAPE_CAP = 256
+_TAPE_CAP = 32           # a model has a handful of gathers; jacobian() empties the tape, this bounds what forward-only use retains
 _PRESERVE = {"detach", "requires_grad_", "clone", "to", "cuda", "cpu", "contiguous", "double", "float", "half", "type",
              "__deepcopy__", "share_memory_", "pin_memory"}
 _INFO = {"dim", "size", "stride", "numel", "nelement", "ndimension", "data_ptr", "element_size", "storage_offset", "get_device",

@@ -432,8 +432,26 @@ __device__ __forceinline__ void lm_reduce_partials(const T* partials, int rows, 
         a[k] += (double)__hip_atomic_load(partials + (size_t)i * 4 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
+  // the four sums with ONE pair of barriers (this sits on the critical path of every LM step)
+  __shared__ double part4[4][BLOCK / 64];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) out[k] = wg_sum<double, BLOCK>(a[k]);
+  for (int k = 0; k < 4; ++k) {
+    double v = a[k];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if ((threadIdx.x & 63) == 0) part4[k][threadIdx.x >> 6] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      double sum = 0.0;
+#pragma unroll
+      for (int w = 0; w < BLOCK / 64; ++w) sum += part4[k][w];
+      out[k] = sum;
+    }
+  }
+  __syncthreads();
 }
 
 // One trial of every problem, per-workgroup partial sums only.  FIRST: linearise at P, keep P in `save`; else a retry
