@@ -286,9 +286,11 @@ def invnet_lm_rate(dev, B=1_000_000, steps=3, reps=40, group=None):
                          "kernel": "lm_se3inv_trial2_kernel + lm_se3inv_finish_kernel (pplie_lm_se3inv_step_f32)"}}
 
 
-def imu_rate(dev, B=4096, F=1024, reps=20, inner=4):
+def imu_rate(dev, B=4096, F=1024, reps=20, inner=16):
     """BASELINE configs[4]: IMUPreintegrator, B sequences x F steps, fp32, with and without covariance propagation
-    (28 r + 40 w = 68 B / step, + 324 B / sequence for the covariance)."""
+    (28 r + 40 w = 68 B / step, + 324 B / sequence for the covariance).  `inner` forwards are enqueued back to
+    back per synchronisation (a sync costs ~40 us of launch + wake-up latency: amortised over 4 forwards it read as 11 us
+    of each 70 us forward)."""
     import torch
     import pypose_amd as pp
     torch.manual_seed(0)
