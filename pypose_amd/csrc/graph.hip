@@ -800,18 +800,32 @@ enum { Q2_RHO = 0, Q2_PQ = 1, Q2_RR = 2, Q2_BN2 = 3, Q2_QZ = 4, Q2_QMQ = 5, Q2_C
 template <class T> __device__ __forceinline__ T* squant2(T* scal, int set, int q) { return scal + (size_t)((set * Q2_COUNT + q) * kSlots) * kStride; }
 
 // SYM: HB holds one block per edge, blk[c] = 2 edge + side says which and whether this incidence reads it transposed
-template <class T, int M, bool SYM = false>
+// STOP: the convergence test runs on the device.  it[2] is a stop flag (0 running, 1 converged, 2 NaN) that the first
+// workgroup raises when the residual of the iteration just finished meets |r|^2 <= tol2 |b|^2 (the reference's CG tests
+// every iteration, solver.py:276-340); every later launch of either kernel returns at once, so the host may queue several
+// captured chunks of iterations per read-back and the solve still ends in the iteration that converged.  it[0] then holds
+// the iteration count.  (it must be 4 ints, zeroed by the caller.)
+template <class T, int M, bool SYM = false, bool STOP = false>
 __global__ void __launch_bounds__(256)
 pcg2_spmv_kernel(const int* __restrict__ ptr, const int* __restrict__ other, const T* __restrict__ HB, const T* __restrict__ D,
                  const T* __restrict__ Binv, const T* __restrict__ p, const T* __restrict__ z, T* __restrict__ q, T* scal,
-                 T* __restrict__ rr_hist, int* it, int cap, int64_t N, const int* __restrict__ blk = nullptr) {
+                 T* __restrict__ rr_hist, int* it, int cap, int64_t N, const int* __restrict__ blk = nullptr, T tol2 = T(0)) {
   constexpr int NPW = 64 / M;
+  if (STOP && it[2] != 0) return;
   const int done = it[0];
   const int a = done & 1;
   if (blockIdx.x == 0) {
     // bookkeeping by the first workgroup: last iteration's |r|^2 into the history, then clear the idle set
     if (threadIdx.x == 0) {
-      if (done > 0 && done - 1 < cap) rr_hist[done - 1] = slot_total(squant2(scal, a ^ 1, Q2_RR));
+      if (done > 0) {
+        const T rr = slot_total(squant2(scal, a ^ 1, Q2_RR));
+        if (done - 1 < cap) rr_hist[done - 1] = rr;
+        if (STOP) {
+          const T bn2 = slot_total(squant2(scal, 0, Q2_BN2));
+          if (!(rr == rr)) it[2] = 2;
+          else if (rr <= tol2 * bn2) it[2] = 1;           // this launch's q is not applied: the step kernel sees the flag
+        }
+      }
       it[1] = done;
     }
     __syncthreads();
@@ -909,11 +923,12 @@ __device__ __forceinline__ void slot_totals_wg(const T* const (&base)[NQ], T (&o
 
 // M lanes per node (the spmv kernel's layout): lane i owns component i, the node's new residual goes round its lanes by
 // shuffles -- 10 loads per component instead of 21
-template <class T, int M>
+template <class T, int M, bool STOP = false>
 __global__ void __launch_bounds__(256)
 pcg2_step_kernel(T* __restrict__ x, T* r0, T* r1, T* __restrict__ p, const T* __restrict__ q, T* __restrict__ z,
                  const T* __restrict__ Binv, T* scal, int* it, int64_t N) {
   constexpr int NPW = 64 / M;
+  if (STOP && it[2] != 0) return;
   const int done = it[1];
   const int a = done & 1;
   const T* __restrict__ rin = a ? r1 : r0;                       // residual of this iteration; the new one goes to the other
@@ -971,7 +986,8 @@ pcg2_step_kernel(T* __restrict__ x, T* r0, T* r1, T* __restrict__ p, const T* __
 
 template <class T>
 int pcg2_spmv(const void* ptr, const void* other, const void* HB, const void* D, const void* Binv, const void* p, const void* z,
-              void* q, void* scal, void* rr_hist, void* it, int cap, int64_t N, int m, void* stream, const void* blk = nullptr) {
+              void* q, void* scal, void* rr_hist, void* it, int cap, int64_t N, int m, void* stream, const void* blk = nullptr,
+              bool stop = false, double tol2 = 0.0) {
   if (N <= 0) return N == 0 ? PPLIE_OK : PPLIE_EBADARG;
   if (!ptr || !other || !HB || !D || !Binv || !p || !z || !q || !scal || !rr_hist || !it) return PPLIE_EBADARG;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -980,7 +996,11 @@ int pcg2_spmv(const void* ptr, const void* other, const void* HB, const void* D,
     int64_t waves = (N + (64 / MM) - 1) / (64 / MM);                                                                  \
     int64_t blocks = (waves + 3) / 4;                                                                                 \
     int grid = (int)(blocks < 4096 ? blocks : 4096);                                                                  \
-    if (blk)                                                                                                          \
+    if (stop && !blk)                                                                                                 \
+      hipLaunchKernelGGL((pcg2_spmv_kernel<T, MM, false, true>), dim3(grid), dim3(256), 0, st, (const int*)ptr,         \
+                         (const int*)other, (const T*)HB, (const T*)D, (const T*)Binv, (const T*)p, (const T*)z, (T*)q, \
+                         (T*)scal, (T*)rr_hist, (int*)it, cap, N, (const int*)nullptr, (T)tol2);                        \
+    else if (blk)                                                                                                     \
       hipLaunchKernelGGL((pcg2_spmv_kernel<T, MM, true>), dim3(grid), dim3(256), 0, st, (const int*)ptr, (const int*)other, \
                          (const T*)HB, (const T*)D, (const T*)Binv, (const T*)p, (const T*)z, (T*)q, (T*)scal,        \
                          (T*)rr_hist, (int*)it, cap, N, (const int*)blk);                                             \
@@ -995,7 +1015,7 @@ int pcg2_spmv(const void* ptr, const void* other, const void* HB, const void* D,
 }
 template <class T>
 int pcg2_step(void* x, void* r, void* r_alt, void* p, const void* q, void* z, const void* Binv, void* scal, void* it, int64_t N,
-              int m, void* stream) {
+              int m, void* stream, bool stop = false) {
   if (N <= 0 || m <= 0 || m > 8) return PPLIE_EBADARG;
   if (!x || !r || !r_alt || r == r_alt || !p || !q || !z || !Binv || !scal || !it) return PPLIE_EBADARG;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -1003,8 +1023,12 @@ int pcg2_step(void* x, void* r, void* r_alt, void* p, const void* q, void* z, co
   {                                                                                                                    \
     const int64_t blocks = ((N + (64 / MM) - 1) / (64 / MM) + 3) / 4;                                                  \
     const int grid = (int)(blocks < 1024 ? blocks : 1024);                                                             \
-    hipLaunchKernelGGL((pcg2_step_kernel<T, MM>), dim3(grid), dim3(256), 0, st, (T*)x, (T*)r, (T*)r_alt, (T*)p,        \
-                       (const T*)q, (T*)z, (const T*)Binv, (T*)scal, (int*)it, N);                                     \
+    if (stop)                                                                                                          \
+      hipLaunchKernelGGL((pcg2_step_kernel<T, MM, true>), dim3(grid), dim3(256), 0, st, (T*)x, (T*)r, (T*)r_alt, (T*)p, \
+                         (const T*)q, (T*)z, (const T*)Binv, (T*)scal, (int*)it, N);                                   \
+    else                                                                                                               \
+      hipLaunchKernelGGL((pcg2_step_kernel<T, MM>), dim3(grid), dim3(256), 0, st, (T*)x, (T*)r, (T*)r_alt, (T*)p,      \
+                         (const T*)q, (T*)z, (const T*)Binv, (T*)scal, (int*)it, N);                                   \
   }
   if (m == 6) LAUNCH(6) else if (m == 7) LAUNCH(7) else if (m == 3) LAUNCH(3) else return PPLIE_EBADARG;
 #undef LAUNCH
@@ -1021,6 +1045,26 @@ extern "C" int pplie_pcg2_spmv_f64(const void* ptr, const void* other, const voi
                                    const void* p, const void* z, void* q, void* scal, void* rr_hist, void* it, int cap,
                                    int64_t N, int m, void* stream) {
   return pplie::pcg2_spmv<double>(ptr, other, HB, D, Binv, p, z, q, scal, rr_hist, it, cap, N, m, stream);
+}
+// the pair with the convergence test on the device: it [4 ints, zeroed]: it[2] = stop flag (1 converged: |r|^2 <= tol2 |b|^2,
+// 2 NaN), raised by the spmv launch that finds it; later launches of both return at once; it[0] = iterations done
+extern "C" int pplie_pcg2_spmv_stop_f32(const void* ptr, const void* other, const void* HB, const void* D, const void* Binv,
+                                        const void* p, const void* z, void* q, void* scal, void* rr_hist, void* it, int cap,
+                                        int64_t N, int m, double tol2, void* stream) {
+  return pplie::pcg2_spmv<float>(ptr, other, HB, D, Binv, p, z, q, scal, rr_hist, it, cap, N, m, stream, nullptr, true, tol2);
+}
+extern "C" int pplie_pcg2_spmv_stop_f64(const void* ptr, const void* other, const void* HB, const void* D, const void* Binv,
+                                        const void* p, const void* z, void* q, void* scal, void* rr_hist, void* it, int cap,
+                                        int64_t N, int m, double tol2, void* stream) {
+  return pplie::pcg2_spmv<double>(ptr, other, HB, D, Binv, p, z, q, scal, rr_hist, it, cap, N, m, stream, nullptr, true, tol2);
+}
+extern "C" int pplie_pcg2_step_stop_f32(void* x, void* r, void* r_alt, void* p, const void* q, void* z, const void* Binv, void* scal,
+                                        void* it, int64_t N, int m, void* stream) {
+  return pplie::pcg2_step<float>(x, r, r_alt, p, q, z, Binv, scal, it, N, m, stream, true);
+}
+extern "C" int pplie_pcg2_step_stop_f64(void* x, void* r, void* r_alt, void* p, const void* q, void* z, const void* Binv, void* scal,
+                                        void* it, int64_t N, int m, void* stream) {
+  return pplie::pcg2_step<double>(x, r, r_alt, p, q, z, Binv, scal, it, N, m, stream, true);
 }
 // HB [E, M, M] per edge (pplie_graph_assemble_csr_sym), blk [nnz] = 2 edge + side of every incidence
 extern "C" int pplie_pcg2_spmv_sym_f32(const void* ptr, const void* other, const void* blk, const void* HB, const void* D,

@@ -45,6 +45,7 @@ _GAIN_PARTIALS = 1024       # PPLIE_GAIN_PARTIALS
 _BSR_SIG = [ctypes.c_void_p] * 8 + [ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]
 _PCG_SCAL_ELEMS = 2 * 8 * 32 * 32          # PPLIE_PCG2_SCAL_ELEMS (covers PPLIE_PCG_SCAL_ELEMS): slot-spread scalars (csrc/graph.hip)
 _PCG2_SPMV_SIG = [ctypes.c_void_p] * 11 + [ctypes.c_int, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]
+_PCG2_SPMV_STOP_SIG = [ctypes.c_void_p] * 11 + [ctypes.c_int, ctypes.c_int64, ctypes.c_int, ctypes.c_double, ctypes.c_void_p]
 _PCG2_STEP_SIG = [ctypes.c_void_p] * 9 + [ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]
 _PERSIST_SIG = [ctypes.c_void_p] * 15 + [ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]
 _PERSIST_GRID_MAX = 256     # PPLIE_PCG_PERSIST_GRID
@@ -262,6 +263,7 @@ class FusedPCG:
     # blocks are one sequential stream per node, the per-edge blocks are 144-byte gathers (two 128-byte lines each) and the
     # second touch of a random closure's block is never a cache hit; it pays only on graphs whose edges are local in node order
     sym_blocks = False
+    device_stop = True       # large graphs: the two-launch iteration tests convergence on the device (pplie_pcg2_*_stop)
     two_launch = True        # class-level switches (tools/ and tests compare the three-launch / graph-less variants)
     use_graph = True
     persist = True           # one persistent launch per solve on small graphs (csrc/pcg_persist.hip)
@@ -284,13 +286,14 @@ class FusedPCG:
         self.cap = 1 << 16
         self.rr_hist = z(self.cap)
         self.part = self._ctl[nb_scal:nb_scal + nb_part].view(torch.int64)   # persistent solve: tagged partial sums
-        self.it = self._ctl[nb_scal + nb_part:].view(torch.int32)[:2]
+        self.it = self._ctl[nb_scal + nb_part:].view(torch.int32)[:4]     # iterations done, scratch, stop flag, -
         self.bar = torch.zeros(64 + 32 * 32, dtype=torch.int32, device=device)      # PPLIE_GRID_BAR_WORDS
         self.info = z(4)
         self.sfx = "_f32" if dtype == torch.float32 else "_f64"
         self.graph = None                                          # captured check_every iterations
         self.bsr = None                                            # which iteration the graph holds
         self.sym = False                                           # HB holds one block per edge
+        self.stop_tol2 = None                                      # tol^2 when the captured iterations carry the device-side stop
         self._csr_obj = None
 
     def _csr(self, lin):
@@ -305,6 +308,18 @@ class FusedPCG:
         st = _C.stream_ptr(self.device)
         if self.bsr and self.two_launch:
             # q = A p with p.q, q.z, q.Binv q ; then every vector update in one launch (csrc/graph.hip, pcg2)
+            if self.stop_tol2 is not None and not self.sym:
+                # convergence test on the device: a launch after the converging iteration returns at once (csrc/graph.hip)
+                code = lib.symbol("pplie_pcg2_spmv_stop" + self.sfx, _PCG2_SPMV_STOP_SIG)(
+                    self.ptr.data_ptr(), self.other.data_ptr(), self.HB.data_ptr(), self.D.data_ptr(), self.Binv.data_ptr(),
+                    self.p.data_ptr(), self.z.data_ptr(), self.q.data_ptr(), self.scal.data_ptr(), self.rr_hist.data_ptr(),
+                    self.it.data_ptr(), self.cap, self.N, self.m, self.stop_tol2, st)
+                _C.check(code, "pplie_pcg2_spmv_stop")
+                code = lib.symbol("pplie_pcg2_step_stop" + self.sfx, _PCG2_STEP_SIG)(
+                    self.x.data_ptr(), self.r.data_ptr(), self.r2.data_ptr(), self.p.data_ptr(), self.q.data_ptr(),
+                    self.z.data_ptr(), self.Binv.data_ptr(), self.scal.data_ptr(), self.it.data_ptr(), self.N, self.m, st)
+                _C.check(code, "pplie_pcg2_step_stop")
+                return
             if self.sym:
                 code = lib.symbol("pplie_pcg2_spmv_sym" + self.sfx, [ctypes.c_void_p] + _PCG2_SPMV_SIG)(
                     self.ptr.data_ptr(), self.other.data_ptr(), self.blk.data_ptr(), self.HB.data_ptr(), self.D.data_ptr(),
@@ -410,6 +425,38 @@ class FusedPCG:
             bn2 = None
             maxiter = min(maxiter, self.cap - self.check_every)
             done, best, stalled, xbest = 0, float('inf'), 0, None
+            if bsr and self.two_launch and not plain and group is None and not self.sym and self.device_stop:
+                # The two-launch iteration with the convergence test ON THE DEVICE: chunks of `check_every` captured iterations
+                # are queued `ahead` at a time per read-back of the 4-int control word; the launch that finds
+                # |r|^2 <= tol^2 |b|^2 raises a flag and every later one returns at once, so the solve ends in the iteration
+                # that converged (as the reference's CG does) however many chunks were queued.
+                tol2 = float(tol) * float(tol)
+                if self.stop_tol2 != tol2:
+                    self.stop_tol2, self.graph = tol2, None        # (tol^2 is a launch argument of the captured chunk)
+                ahead = 2           # (a schedule guessed from the previous solve's count loses more in no-op launches than it saves)
+                while done < maxiter:
+                    for _ in range(ahead):
+                        if self.graph is None and done > 0 and self.use_graph:
+                            g = torch.cuda.CUDAGraph()
+                            with _C.graph_capture(g):
+                                for _ in range(self.check_every):
+                                    self._iteration(None)
+                            self.graph = g
+                        if self.graph is not None:
+                            self.graph.replay()
+                        else:
+                            for _ in range(self.check_every):
+                                self._iteration(None)
+                        done += self.check_every
+                        if done >= maxiter:
+                            break
+                    its, _, flag, _ = self.it.tolist()
+                    assert flag != 2, 'Linear solve produced NaN (matrix may not be positive-definite)'
+                    if flag == 1:
+                        return self.x.clone(), int(its)
+                return self.x.clone(), done
+            if self.stop_tol2 is not None:
+                self.stop_tol2, self.graph = None, None
             while done < maxiter:
                 if group is None and self.graph is None and done > 0 and self.use_graph:
                     g = torch.cuda.CUDAGraph()
