@@ -376,7 +376,8 @@ class FusedPCG:
                 if own is None or own.shape != lin.HB.shape or own.dtype != lin.HB.dtype or sym != self.sym or self.HB is not own:
                     own = self._own_HB = torch.empty_like(lin.HB) if own is None or own.shape != lin.HB.shape else own
                     self.HB, self.sym, self.graph = own, sym, None
-                self.HB.copy_(lin.HB)                               # off-diagonal blocks in incidence (or edge) order
+                if lin.HB is not self.HB:                           # (assembled in place when the workspace already existed)
+                    self.HB.copy_(lin.HB)                           # off-diagonal blocks in incidence (or edge) order
         else:
             if self.J is None:
                 self.J, self.idx = torch.empty_like(lin.J), torch.empty_like(lin.idx)
@@ -611,7 +612,18 @@ class GraphLinearization:
                     # half the bytes every SpMV streams
                     self.HB_sym = (self.K == 2 and FusedPCG.two_launch and not (FusedPCG.persist and N <= PERSIST_NODES)
                                    and FusedPCG.sym_blocks and self._weights_symmetric())
-                    self.HB = torch.empty((self.E * (1 if self.HB_sym else 2), m, m), dtype=dt, device=dev) if self.K == 2 else None
+                    self.HB = None
+                    if self.K == 2:
+                        shape = (self.E * (1 if self.HB_sym else 2), m, m)
+                        # large graphs: assemble straight into the PCG workspace's block buffer (the captured iterations point
+                        # at it) instead of into a fresh tensor that is then copied there -- 115 MB per LM step at 4e5 edges
+                        for w in (self.opt.__dict__.get('_pcg_workspaces') or {}).values():
+                            own = w.__dict__.get('_own_HB')
+                            if own is not None and own.shape == shape and own.dtype == dt and own.device == dev and w.sym == self.HB_sym:
+                                self.HB = own
+                                break
+                        if self.HB is None:
+                            self.HB = torch.empty(shape, dtype=dt, device=dev)
                     code = lib.symbol("pplie_graph_assemble_csr" + ("_sym" if self.HB_sym else "") + sfx, _ASMC_SIG)(
                         ptr.data_ptr(), blk.data_ptr(), self.J.data_ptr(), wptr, self.R.data_ptr(), B.data_ptr(),
                         g.data_ptr(), self.HB.data_ptr() if self.HB is not None else None, N, self.dr, self.m, self.K, st)
