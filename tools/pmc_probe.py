@@ -85,3 +85,13 @@ for _ in range(2):
     pp.chspline(pts, 0.1)
 torch.cuda.synchronize()
 print("done")
+
+# reprojection residual + closed-form blocks, 4M observations (84 B read + 80 B written per observation)
+E = 4_000_000
+Xr = pp.randn_SE3(E, sigma=0.3, device=dev).tensor().contiguous()
+pr = (torch.randn(E, 3, device=dev) + torch.tensor([0, 0, 6.0], device=dev)).contiguous()
+Kr = torch.tensor([[500.0, 0, 320], [0, 500, 240], [0, 0, 1]], device=dev)
+camr = torch.cat([Kr.reshape(1, 9).expand(E, 9), torch.randn(E, 2, device=dev)], -1).contiguous()
+for _ in range(3):
+    _C.row_op("se3_reproj_lin", [Xr, pr, camr], (2, 18))
+torch.cuda.synchronize()
