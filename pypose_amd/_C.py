@@ -152,6 +152,20 @@ def mark_written(t):
         torch.autograd.graph.increment_version(t)
 
 
+_staging_warned = False
+
+
+def _warn_staging(name):
+    """once per process: host tensors are computed on the GPU and copied back (the reference computes them on the CPU)"""
+    global _staging_warned
+    if not _staging_warned and not os.environ.get("PPLIE_QUIET_STAGING"):
+        _staging_warned = True
+        import warnings
+        warnings.warn(f"pypose_amd: op {name} received host tensors; they are staged through the current HIP device (there is no "
+                      f"CPU compute path) -- move the data to the device once instead (set PPLIE_QUIET_STAGING=1 to silence)",
+                      stacklevel=4)
+
+
 def row_op(name: str, ins, out_widths, out=None):
     """Launch ``pplie_<name>_{f32,f64}`` on contiguous ``[N, W]`` inputs.
 
@@ -175,6 +189,7 @@ def row_op(name: str, ins, out_widths, out=None):
             raise RuntimeError(
                 f"pypose_amd: op {name} needs a HIP device (got {x0.device} tensors and no GPU is visible); "
                 f"there is no CPU compute path.")
+        _warn_staging(name)
         dev = torch.device("cuda", torch.cuda.current_device())
         outs = row_op(name, [t.to(dev) for t in ins], out_widths)
         if out is None:
@@ -219,6 +234,7 @@ def param_op(name: str, ins, out_width: int, prm: float):
             raise RuntimeError(
                 f"pypose_amd: op {name} needs a HIP device (got {x0.device} tensors and no GPU is visible); "
                 f"there is no CPU compute path.")
+        _warn_staging(name)
         dev = torch.device("cuda", torch.cuda.current_device())
         return param_op(name, [t.to(dev) for t in ins], out_width, prm).to(x0.device)
     suffix = _SUFFIX.get(x0.dtype)
