@@ -458,6 +458,27 @@ def _self_launch(a):
     os.execvpe(sys.executable, cmd, env)
 
 
+_REAL_STDOUT = None
+
+
+def _claim_stdout():
+    """The contract is ONE JSON line on stdout.  RCCL prints a version banner to stdout through C stdio (it lands before or
+    after the line depending on buffering), other libraries may chat too: fd 1 is pointed at stderr for the whole run and
+    the line goes to a private duplicate of the real stdout."""
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.dup(1)
+        os.dup2(2, 1)
+
+
+def _emit_line(text):
+    if _REAL_STDOUT is None:
+        print(text, flush=True)
+    else:
+        os.write(_REAL_STDOUT, (text + "\n").encode())
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -474,6 +495,7 @@ def main():
     a = ap.parse_args()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         _self_launch(a)
+    _claim_stdout()
     import torch
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -609,7 +631,7 @@ def main():
 
         def emit():
             if printed.acquire(blocking=False) and rank == 0:
-                print(json.dumps(out), flush=True)
+                _emit_line(json.dumps(out))
 
         def watchdog():
             if not finished.wait(float(os.environ.get("PPLIE_BENCH_SHARDED_TIMEOUT", "240"))):
@@ -636,7 +658,7 @@ def main():
         finished.set()
         emit()
     elif rank == 0:
-        print(json.dumps(out), flush=True)
+        _emit_line(json.dumps(out))
     if launched:
         import torch.distributed as dist
         dist.destroy_process_group()
