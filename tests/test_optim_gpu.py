@@ -221,6 +221,34 @@ def test_posegraph_captured_trial_equals_the_uncaptured_step(G, dtype, weighted)
                            floor=1e-12, rtol=1e-5)
 
 
+def test_batched_sweeps_by_slices_equal_the_expanded_launch(monkeypatch):
+    """lietensor/operation._launch_slices: from 64k rows per cotangent slice the batched backward of the block linearisations
+    launches once per slice against the saved operands in place instead of expanding them d-fold -- same blocks, bit for bit"""
+    from pypose_amd.lietensor import operation as _op
+    from pypose_amd.optim import blocks as _blocks
+    n = 70_001
+    torch.manual_seed(3)
+    P = pp.Parameter(pp.randn_SE3(n, device=DEV))
+    X = pp.randn_SE3(n, device=DEV)
+    a = pp.randn_se3(n, device=DEV).tensor()
+
+    def blocks():
+        r1 = (P @ X).Log().tensor()
+        r2 = P.Inv().Adj(pp.se3(a)).tensor() + P.Act(a[:, :3]).repeat(1, 2)
+        return _blocks.jacobian_blocks([r1, r2], [P])
+
+    calls = []
+    real = _op._launch_slices
+    monkeypatch.setattr(_op, "_launch_slices", lambda *a_, **k: (calls.append(1), real(*a_, **k))[1])
+    J_slices = blocks()
+    assert len(calls) >= 4
+    monkeypatch.setattr(_op, "_SLICE_ROWS", 1 << 40)
+    _blocks._COT_CACHE.clear()
+    J_expand = blocks()
+    assert torch.equal(J_slices, J_expand)
+    assert J_slices.shape == (n, 12, 7) and float(J_slices.abs().max()) > 0
+
+
 def test_posegraph_pcg_one_block_per_edge(G, monkeypatch):
     """the opt-in symmetric storage (pplie_graph_assemble_csr_sym + pplie_pcg2_spmv_sym: H_ji read as H_ij^T) walks the
     reference's trajectory too, weighted (symmetric information matrices) and unweighted"""
