@@ -171,12 +171,14 @@ def test_posegraph_trajectory_matches_reference(G, tag, wname, mode):
     torch.testing.assert_close(graph.nodes.detach().tensor().cpu(), T(G[f"{tag}/{wname}/final"]), rtol=0, atol=1e-7)
 
 
-@pytest.mark.parametrize("two_launch", [True, False])
-def test_posegraph_pcg_matrix_free_on_gpu(G, two_launch, monkeypatch):
-    """Reference trajectory through the device-resident PCG: the two-launch iteration (pplie_pcg2_*) and the
-    three-launch one (pplie_graph_bsr_spmv + pplie_pcg_stage, also the form the edge-sharded path uses)."""
+@pytest.mark.parametrize("two_launch,persist", [(True, True), (True, False), (False, True)])
+def test_posegraph_pcg_matrix_free_on_gpu(G, two_launch, persist, monkeypatch):
+    """Reference trajectory through the device-resident PCG: the persistent one-launch solve, the two-launch iteration with
+    the convergence test on the device (pplie_pcg2_*_stop: what graphs beyond 32k nodes take) and the three-launch one
+    (pplie_graph_bsr_spmv + pplie_pcg_stage, also the form the edge-sharded path uses)."""
     from pypose_amd.optim import posegraph
     monkeypatch.setattr(posegraph.FusedPCG, "two_launch", two_launch, raising=False)
+    monkeypatch.setattr(posegraph.FusedPCG, "persist", persist, raising=False)
     edges, poses = T(G["pgo40/edges"], DEV), pp.SE3(T(G["pgo40/poses"], DEV))
     graph = PoseGraph(pp.SE3(T(G["pgo40/init"], DEV)))
     opt = pp.optim.LM(graph, solver=pp.optim.solver.PCG(tol=1e-13, maxiter=2000, check_every=1),
@@ -219,6 +221,28 @@ def test_posegraph_captured_trial_equals_the_uncaptured_step(G, dtype, weighted)
     if dtype == torch.float64:
         compare_trajectory({k: v[:5] for k, v in runs[True][0].items()}, G, "pgo40/infos" if weighted else "pgo40/noweight",
                            floor=1e-12, rtol=1e-5)
+
+
+def test_two_launch_pcg_stops_in_the_converging_iteration(G, monkeypatch):
+    """pplie_pcg2_*_stop: chunks of 8 captured iterations are queued two at a time, yet the solve ends in the iteration that
+    meets the tolerance -- the same count as the persistent solve, which tests every iteration on the device too"""
+    from pypose_amd.optim import posegraph
+    edges, poses = T(G["pgo40/edges"], DEV), pp.SE3(T(G["pgo40/poses"], DEV))
+    seen = {}
+    for persist in (True, False):
+        monkeypatch.setattr(posegraph.FusedPCG, "persist", persist, raising=False)
+        graph = PoseGraph(pp.SE3(T(G["pgo40/init"], DEV)))
+        solver = pp.optim.solver.PCG(tol=1e-6, maxiter=400, check_every=8)
+        opt = pp.optim.LM(graph, solver=solver, strategy=pp.optim.strategy.TrustRegion(radius=1e4), min=1e-6)
+        opt.graph_step = False
+        its, losses = [], []
+        for _ in range(4):
+            losses.append(float(opt.step((edges, poses))))
+            its.append(solver.iterations)
+        seen[persist] = (its, losses)
+    assert seen[True][0] == seen[False][0], seen
+    assert any(i % 8 for i in seen[False][0])                  # not a multiple of the chunk: the stop came from the device
+    np.testing.assert_allclose(seen[True][1], seen[False][1], rtol=1e-9)
 
 
 def test_batched_sweeps_by_slices_equal_the_expanded_launch(monkeypatch):
