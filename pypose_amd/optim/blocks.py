@@ -169,8 +169,19 @@ class BlockJacobian:
     parameter order (parameter by parameter); ``J @ D`` returns ``[n * dr, 1]`` in row-block order
     (the order of :attr:`R` built by the same linearisation)."""
 
-    def __init__(self, blocks, param_widths):
-        self.blocks, self.param_widths = blocks, list(param_widths)
+    gain_is_costly = True       # (tensor passes over the blocks; the pose-graph operator has a kernel for it)
+
+    def __init__(self, blocks, param_widths, R=None):
+        self.blocks, self.param_widths, self.R = blocks, list(param_widths), R
+
+    def gain_terms(self, D):
+        """device tensor [(J D).(J D), (J D).R] -- all the built-in damping strategies need of J, D and R (strategy.py:144,
+        261); the optimizer reads it back together with the trial's loss (one synchronisation instead of the strategy's own
+        tensor comparisons)"""
+        if self.R is None:
+            return None
+        JD = (self.blocks * self.step_to_blocks(D).unsqueeze(-2)).sum(-1)
+        return torch.stack([(JD * JD).sum(), (JD * self.R.reshape(JD.shape)).sum()])
 
     def step_to_blocks(self, D):
         n = self.blocks.shape[0]

@@ -176,7 +176,7 @@ class BlockLinearization:
                 ws, ni = model._weight_blocks(w, r)
                 self.Wb[:, off:off + d, off:off + d] = ws.repeat(ni, 1, 1)
                 off += d
-        self.op = _blocks.BlockJacobian(self.Jb, [p.shape[-1] for p in params])
+        self.op = _blocks.BlockJacobian(self.Jb, [p.shape[-1] for p in params], R=self.Rb)
 
     def build_normal_equations(self, dmin, dmax):
         # the blocks stay RAW; clamping and the (compounding) damping of the trial loop are a scale factor applied to the
@@ -395,7 +395,15 @@ class LevenbergMarquardt(_Optimizer):
     def _strategy_update(self, pg, J, D, R, last_h):
         """strategy.update(...) for this trial; returns the new loss as a host float (read back together with the
         gain-ratio terms where the linearisation provides them)."""
-        ab = J.gain_terms(D) if hasattr(J, 'gain_terms') and type(self.strategy) in (Constant, Adaptive, TrustRegion) else None
+        builtin = hasattr(J, 'gain_terms') and type(self.strategy) in (Constant, Adaptive, TrustRegion)
+        if builtin and type(self.strategy) is Constant and getattr(J, 'gain_is_costly', False):
+            # Constant never looks at J, D, R (strategy.py:66-69): on the block path their gain terms are three passes over the
+            # [n, dr, dp] blocks that nobody reads
+            loss_h = float(self.loss)
+            one = torch.ones((1, 1), dtype=torch.float64)
+            self.strategy.update(pg, last=last_h, loss=loss_h, J=one, D=one, R=one)
+            return loss_h
+        ab = J.gain_terms(D) if builtin else None
         if ab is not None:
             # pose graphs: (J D).(J D) and (J D).R from one kernel; the built-in strategies only need the gain ratio,
             # which an equivalent 1x1 problem on the host reproduces (x^2 = a, x r = b) without device round trips

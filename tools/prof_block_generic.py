@@ -10,7 +10,8 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 dev = "cuda:0"
 torch.manual_seed(0); net = InvNet(pp.randn_SE3(B, device=dev))
 torch.manual_seed(1); inp = pp.randn_SE3(B, device=dev)
-opt = pp.optim.LM(net, strategy=pp.optim.strategy.Constant(damping=1e-4))
+strat = pp.optim.strategy.TrustRegion(radius=1e4) if os.environ.get('STRAT') == 'tr' else pp.optim.strategy.Constant(damping=1e-4)
+opt = pp.optim.LM(net, strategy=strat)
 opt.fused = False
 init = net.pose.detach().tensor().clone()
 opt.step(inp); opt.step(inp)
