@@ -94,7 +94,7 @@ def cpu_baseline(budget_s: float = 12.0):
     rpp = ref_loader.load()
     cores = os.cpu_count() or 1
     old = torch.get_num_threads()
-    B = 1_000_000
+    B = 10_000_000                  # BASELINE configs[1]'s own size ("C2: full 10 M fwd")
     torch.manual_seed(0)
     x = rpp.randn_se3(B, dtype=torch.float32)
     # PyTorch's intra-op pool does not scale to every core of a large host on this chain of ~100 small aten ops (256 threads
@@ -128,6 +128,116 @@ def cpu_baseline(budget_s: float = 12.0):
                       f"itself (PyPose {getattr(rpp, '__version__', '?')}, oracle/_ref)",
             "thread_probe_pairs_per_s": {str(k): v for k, v in tried.items()},
             "numpy_port": port}
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# per-leg cpu_baseline (BASELINE.md section 3 / SURVEY.md 8(c)-(d)): the reference itself at the largest size it can run,
+# and the reference-function restatement of its LM loop (oracle/ref_restate.py) at the leg's full size
+# ---------------------------------------------------------------------------------------------------------------
+def leg_cpu_baselines(threads):
+    """{leg: cpu_baseline block}; `threads` intra-op threads (the count the headline's probe found fastest on this host)."""
+    import torch
+    from oracle import ref_loader, ref_restate
+    if not ref_loader.available():
+        return {}
+    rpp = ref_loader.load()
+    cores = os.cpu_count() or 1
+    old = torch.get_num_threads()
+    torch.set_num_threads(threads)
+    out = {}
+
+    def block(value, unit, kind, sample, **kw):
+        return {"value": value, "unit": unit, "cores": threads, "host_cores": cores, "kind": kind, "sample": sample, **kw}
+
+    def guarded(name, fn):
+        try:
+            out[name] = fn()
+        except Exception as e:
+            out[name] = {"error": repr(e)}
+
+    class RefInvNet(torch.nn.Module):
+        def __init__(self, init):
+            super().__init__()
+            self.pose = rpp.Parameter(init)
+
+        def forward(self, input):
+            return (self.pose @ input).Log().tensor()
+
+    class RefPoseGraph(torch.nn.Module):
+        def __init__(self, init):
+            super().__init__()
+            self.nodes = rpp.Parameter(init)
+
+        def forward(self, e, poses):
+            n1, n2 = self.nodes[e[..., 0]], self.nodes[e[..., 1]]
+            return (poses.Inv() @ n1.Inv() @ n2).Log().tensor()
+
+    def invnet():
+        B = 1_000_000
+        torch.manual_seed(0)
+        init, inp = rpp.randn_SE3(B).tensor(), rpp.randn_SE3(B).tensor()
+        rec = ref_restate.invnet_lm(init, inp, 3, strategy="constant", strategy_kw=dict(damping=1e-4))
+        t = sum(rec["step_seconds"]) / 3
+        Br = 1024
+        torch.manual_seed(0)
+        net = RefInvNet(rpp.randn_SE3(Br))
+        x = rpp.randn_SE3(Br)
+        opt = rpp.optim.LM(net, strategy=rpp.optim.strategy.Constant(damping=1e-4))
+        opt.step(x)
+        t0 = time.perf_counter()
+        opt.step(x)
+        tr = time.perf_counter() - t0
+        return block(1.0 / t, "LM steps/s", "port", f"3 LM steps at B = {B} fp32: oracle/ref_restate.invnet_lm -- the reference's loop "
+                     "(optimizer.py:644-679) on [B,7,7] blocks, every formula a reference function (se3_Jl_inv, SE3 ops, cholesky_ex, "
+                     "its own strategy object)", problem_steps_per_s=B / t, losses=rec["loss"],
+                     reference_at_largest_runnable_size=block(1.0 / tr, "LM steps/s", "reference", f"one pp.optim.LM step of the reference "
+                                                                 f"package itself (dense modjac J [6B,7B]) at B = {Br}", problem_steps_per_s=Br / tr))
+
+    def pgo(N, E, steps):
+        def f():
+            e, rel, init = ref_restate.pose_graph_problem(N, E, dtype=torch.float32)
+            rec = ref_restate.pgo_lm(init, e, rel, steps, radius=1e4, tol=1e-4, maxiter=250)
+            t = sum(rec["step_seconds"]) / steps
+            Nr, Er = 200, 560
+            er, relr, initr = ref_restate.pose_graph_problem(Nr, Er, dtype=torch.float32)
+            g = RefPoseGraph(rpp.SE3(initr))
+            opt = rpp.optim.LM(g, solver=rpp.optim.solver.Cholesky(), strategy=rpp.optim.strategy.TrustRegion(radius=1e4))
+            opt.step((er, rpp.SE3(relr)))
+            t0 = time.perf_counter()
+            opt.step((er, rpp.SE3(relr)))
+            tr = time.perf_counter() - t0
+            return block(1.0 / t, "LM steps/s", "port", f"{steps} LM step(s) at {N} nodes / {E} edges fp32: oracle/ref_restate.pgo_lm -- "
+                         "per-edge blocks from the reference's se3_Jl_inv / SE3_Adj, J as torch.sparse_csr, A = J^T J in CSR (the reference's "
+                         "sparse branch, optimizer.py:640-643), the reference's CG (solver.py:276-340, tol 1e-4, maxiter 250) with a "
+                         "block-Jacobi M, TrustRegion(radius=1e4)", losses=rec["loss"], solve_seconds_per_step=sum(rec["solve_seconds"]) / steps,
+                         reference_at_largest_runnable_size=block(1.0 / tr, "LM steps/s", "reference", "one pp.optim.LM step of the reference "
+                                                                     f"package itself (dense J, Cholesky) at {Nr} nodes / {Er} edges"))
+        return f
+
+    def imu():
+        B, F = 512, 1024
+        torch.manual_seed(0)
+        dt = torch.full((B, F, 1), 0.005)
+        gyro = 0.1 * torch.randn(B, F, 3)
+        acc = torch.randn(B, F, 3) + torch.tensor([0., 0., 9.81])
+        res = {}
+        for cov in (True, False):
+            ref_restate.imu_forward(dt[:8], gyro[:8], acc[:8], cov)
+            t0 = time.perf_counter()
+            ref_restate.imu_forward(dt, gyro, acc, cov)
+            res[cov] = time.perf_counter() - t0
+        return block(B * F / res[True], "steps/s", "reference", f"one forward of the reference's IMUPreintegrator(prop_cov=True) at "
+                     f"{B} sequences x {F} steps fp32 (its largest size here: SURVEY 8d 'C5: B <= 512')", states_only_value=B * F / res[False])
+
+    try:
+        with torch.no_grad():
+            guarded("lm_invnet", invnet)
+            guarded("lm_pgo", pgo(10_000, 40_000, 3))
+            guarded("lm_pgo_100k", pgo(100_000, 400_000, 1))
+            guarded("imu", imu)
+    finally:
+        torch.set_num_threads(old)
+    return out
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -599,7 +709,9 @@ def main():
                                  ("torch.distributed.run" if launched else "single process")},
             "roofline": {"bound": "hbm", "kernel": f"rowmap_lds_kernel<{dom}> (pplie_{dom}_f32)",
                          "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                         "traffic": traffic, "algorithmic_bytes_per_launch": B * BYTES_PER_ROW[dom],
+                         "traffic": traffic, "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc passes of an earlier run of "
+                         "this kernel on this workload; not collected in this run)" if traffic is not None else None,
+                         "algorithmic_bytes_per_launch": B * BYTES_PER_ROW[dom],
                          "avg_launch_ms": ms_dom, "timed_launches": len(ev), "other_kernel_ms": {"se3_exp_fwd": ms_exp, "se3_log_fwd": ms_log}},
         }
     import gc
@@ -621,6 +733,14 @@ def main():
                 out[key] = {"error": repr(e)}
     if world == 1 and not a.no_cpu_baseline and rank == 0 and not standin:
         out["cpu_baseline"] = cpu_baseline()
+        if not a.no_secondary:
+            try:
+                per_leg = leg_cpu_baselines(int(out["cpu_baseline"].get("cores") or 8) if out["cpu_baseline"].get("kind") == "reference" else 8)
+            except Exception as e:
+                per_leg = {"error": repr(e)}
+            for key, blk in per_leg.items():
+                if isinstance(out.get(key), dict):
+                    out[key]["cpu_baseline"] = blk
     sharded = launched and not a.no_secondary and (world > 1 or os.environ.get("PPLIE_BENCH_SHARDED") == "1")
     if sharded:
         # every rank takes part; a watchdog keeps the headline line if a collective wedges (nothing in the timed
