@@ -350,48 +350,58 @@ def invnet_lm_rate(dev, B=1_000_000, steps=3, reps=40, group=None):
     torch.manual_seed(0 if group is None else 1 + torch.distributed.get_rank())
     init = pp.randn_SE3(B, device=dev)
     inp = pp.randn_SE3(B, device=dev)
-    net = InvNet(init.clone())
-    opt = pp.optim.LM(net, strategy=pp.optim.strategy.Constant(damping=1e-4), group=group)
-    l0 = float(net(inp).detach().square().sum())
+    l0 = float(InvNet(init)(inp).detach().square().sum())
 
-    def reset():
-        net.pose.data.copy_(init.tensor())
-        if hasattr(opt, "loss"):
-            del opt.loss
+    def measure(static):
+        net = InvNet(init.clone())
+        opt = pp.optim.LM(net, strategy=pp.optim.strategy.Constant(damping=1e-4), group=group, static=static)
 
-    def run(n):
-        for _ in range(n):
+        def reset():
+            net.pose.data.copy_(init.tensor())
+            if hasattr(opt, "loss"):
+                del opt.loss
+
+        def run(n):
+            for _ in range(n):
+                reset()
+                for _ in range(steps):
+                    loss = opt.step(inp)
+            return loss
+
+        run(2)                                                    # structure probe / verification, untimed
+        _sync(dev)
+        best, sync_best, loss = float("inf"), float("inf"), None
+        for _ in range(3):
+            if group is not None:
+                torch.distributed.barrier()
+            _sync(dev)
+            t0 = time.perf_counter()
+            loss = run(reps)
+            _sync(dev)
+            best = min(best, (time.perf_counter() - t0) / (reps * steps))
+        for _ in range(3):                                        # the round-1 protocol: synchronise after every repetition
             reset()
+            _sync(dev)
+            t0 = time.perf_counter()
             for _ in range(steps):
                 loss = opt.step(inp)
-        return loss
+            _sync(dev)
+            sync_best = min(sync_best, (time.perf_counter() - t0) / steps)
+        return best, sync_best, float(loss), opt.linearization
 
-    run(2)                                                    # structure probe / verification, untimed
-    _sync(dev)
-    best, sync_best, loss = float("inf"), float("inf"), None
-    for _ in range(3):
-        if group is not None:
-            torch.distributed.barrier()
-        _sync(dev)
-        t0 = time.perf_counter()
-        loss = run(reps)
-        _sync(dev)
-        best = min(best, (time.perf_counter() - t0) / (reps * steps))
-    for _ in range(3):                                        # the round-1 protocol: synchronise after every repetition
-        reset()
-        _sync(dev)
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            loss = opt.step(inp)
-        _sync(dev)
-        sync_best = min(sync_best, (time.perf_counter() - t0) / steps)
+    # default: the model's forward runs (dry) at every step, the reference's semantics; static=True: the caller's promise
+    # that the residual program does not change, the model is not run
+    best, sync_best, loss, path = measure(False)
+    best_static, _, loss_static, _ = measure(True)
     world = 1 if group is None else torch.distributed.get_world_size(group)
     ach = 84.0 * B / best / 1e9
     return {"metric": "LM iters/sec (InvNet SE3, 1M independent problems per GPU)", "value": 1.0 / best, "unit": "LM steps/s",
-            "problems_per_gpu": B, "n_gpus": world, "problem_steps_per_s": world * B / best, "path": opt.linearization,
-            "initial_loss": l0, "final_loss": float(loss), "steps_per_repetition": steps, "repetitions_in_flight": reps,
+            "static_model_value": 1.0 / best_static, "static_model_final_loss": loss_static,
+            "problems_per_gpu": B, "n_gpus": world, "problem_steps_per_s": world * B / best, "path": path,
+            "initial_loss": l0, "final_loss": loss, "steps_per_repetition": steps, "repetitions_in_flight": reps,
             "value_with_a_sync_per_repetition": 1.0 / sync_best,
             "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBPS, "achieved": ach, "frac": ach / HBM_PEAK_GBPS,
+                         "frac_static_model": 84.0 * B / best_static / 1e9 / HBM_PEAK_GBPS,
                          "algorithmic_bytes_per_step": 84 * B, "per": "LM step per GPU (SURVEY 8d C3: pose 28 r + input 28 r + pose 28 w)",
                          "kernel": "lm_se3inv_trial2_kernel + lm_se3inv_finish_kernel (pplie_lm_se3inv_step_f32)"}}
 

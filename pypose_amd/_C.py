@@ -18,7 +18,9 @@ import torch
 
 _LIB_PATH = Path(__file__).resolve().parent / "lib" / "libpplie.so"
 
-_ERRORS = {-1: "bad argument (negative row count or null pointer)", -2: "kernel launch failed (hipGetLastError)"}
+_ERRORS = {-1: "bad argument (negative row count or null pointer)", -2: "kernel launch failed (hipGetLastError)",
+           -3: "the problem does not fit the device-resident variant (nothing launched)"}
+ECAPACITY = -3
 
 _ROW_SIG = [ctypes.c_void_p] * 5 + [ctypes.c_int64, ctypes.c_void_p]
 
@@ -94,9 +96,25 @@ def check(code: int, what: str):
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 
 
+class DryTraceEscape(RuntimeError):
+    """a kernel launch was attempted during a dry trace (optim/fused.py DryTracer): the model does something a dry run
+    cannot follow; the caller falls back to a real forward"""
+
+
+import threading as _threading
+_tls = _threading.local()          # .dry > 0: this thread is running a model's Python WITHOUT launching kernels (optim/fused.py)
+
+
+def dry_tracing() -> bool:
+    return getattr(_tls, "dry", 0) > 0
+
+
 def stream_ptr(device) -> ctypes.c_void_p:
     """hipStream_t of torch's current stream on ``device`` (the raw-stream query is ~10x cheaper than building a
-    torch.cuda.Stream object; this sits on the launch path of every op)."""
+    torch.cuda.Stream object; this sits on the launch path of every op).  Every launch of the library asks for its stream
+    here, which makes this the one place where a dry trace stops anything that is not a traced row op."""
+    if getattr(_tls, "dry", 0):
+        raise DryTraceEscape("pypose_amd: kernel launch during a dry trace")
     if _raw_stream is not None:
         idx = device.index if isinstance(device, torch.device) else device
         return ctypes.c_void_p(_raw_stream(torch.cuda.current_device() if idx is None else idx))

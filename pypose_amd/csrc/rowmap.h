@@ -25,7 +25,7 @@ typedef int __attribute__((ext_vector_type(4))) raw16;
 typedef int __attribute__((ext_vector_type(2))) raw8;
 
 // error codes returned through the C ABI
-enum { PPLIE_OK = 0, PPLIE_EBADARG = -1, PPLIE_ELAUNCH = -2 };
+enum { PPLIE_OK = 0, PPLIE_EBADARG = -1, PPLIE_ELAUNCH = -2, PPLIE_ECAPACITY = -3 };
 
 template <int W, class T> __device__ __forceinline__ void row_ld(const T* __restrict__ p, T* r) {
   if constexpr ((W * sizeof(T)) % 16 == 0) {

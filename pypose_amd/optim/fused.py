@@ -52,6 +52,30 @@ class OpTracer:
         self.events.append((name, tuple(ins), tuple(outs)))
 
 
+class DryTracer(OpTracer):
+    """The same recording with NOTHING launched: while it is active on this thread the Lie Functions return `meta` tensors
+    (lietensor/operation.py:_launch), row gathers on tracked parameters are noted but not executed (LieTensor.__torch_function__)
+    and any other launch of the library raises (_C.stream_ptr).  The model's own Python runs for real -- every step, as in
+    the reference (optimizer.py:631, 646) -- so a change that touches no tensor (an attribute flipped, a buffer rebound, a
+    different branch taken) shows up in the trace of the very next step; what a dry run cannot follow (a model that looks at
+    VALUES of intermediate results) raises out of it and the caller runs a real forward instead."""
+
+    def __enter__(self):
+        _C._tls.dry = getattr(_C._tls, "dry", 0) + 1
+        return super().__enter__()
+
+    def __exit__(self, *exc):
+        super().__exit__(*exc)
+        _C._tls.dry -= 1
+
+
+def _key(t):
+    """identity of a tensor's memory: the address, or (dry-trace outputs have none) storage object + offset"""
+    if t.device.type == "meta":
+        return ("meta", t.untyped_storage()._cdata, t.storage_offset())
+    return t.data_ptr()
+
+
 def _is_se3_group(P):
     """an SE3 group LieTensor of this package or of an activated reference pypose (same type name, 7-wide, 6 dof)"""
     lt = getattr(P, "ltype", None)
@@ -61,7 +85,8 @@ def _is_se3_group(P):
 
 def _same(a, b):
     # (the Lie methods flatten leading dims to rows before launching: same storage, same element count)
-    return a.data_ptr() == b.data_ptr() and a.numel() == b.numel() and a.dtype == b.dtype and a.is_contiguous() and b.is_contiguous()
+    return a.device == b.device and _key(a) == _key(b) and a.numel() == b.numel() and a.dtype == b.dtype \
+        and a.is_contiguous() and b.is_contiguous()
 
 
 def match_se3inv(trace, R, params):
@@ -73,7 +98,8 @@ def match_se3inv(trace, R, params):
     if n0 != "se3_mul_fwd" or n1 != "se3_log_fwd" or not _is_se3_group(P):
         return None
     A, X = i0
-    if not _same(A, P) or X.requires_grad or X.numel() != P.numel() or P.dim() < 2 or not _same(i1[0], o0[0]):
+    if not _same(A, P) or X.requires_grad or X.numel() != P.numel() or P.dim() < 2 or not _same(i1[0], o0[0]) \
+            or X.dtype != P.dtype or X.device != P.device or not X.is_contiguous():
         return None
     if not _same(o1[0], R[0]) or R[0].shape[-1] != 6:
         return None
@@ -168,7 +194,6 @@ _DECIDE_SIG = [ctypes.c_void_p] * 2 + [ctypes.POINTER(_LmCfg), ctypes.c_int] + [
 _ST_DAMPING, _ST_RADIUS, _ST_DOWN, _ST_SCALE, _ST_LAST, _ST_LOSS, _ST_REJECTS, _ST_DONE, _ST_FAILED, _ST_TRIALS = range(10)
 _LM_STATE = 16            # PPLIE_LM_STATE
 _LOSS_BLOCK = 1024        # loss / last scalars handed out as views of one allocation per 1024 steps
-_RETRACE = 64             # the model's forward is traced again every so many steps (the program could have changed)
 _LAZY_KEYS = frozenset(("damping", "radius", "down"))
 import os as _os
 _TUNE_FLAGS = int(_os.environ.get("PPLIE_LM_FLAGS", "0"))       # tuning knobs of the trial kernel (tools/time_c3_device.py)
@@ -233,6 +258,15 @@ class LazyGroup(dict):
         self._pull()
         return dict(self)
 
+    def __iter__(self):
+        # (also takes CPython's dict(pg) / {**pg} off their raw-storage fast path: they iterate, and every read pulls)
+        self._pull()
+        return dict.__iter__(self)
+
+    def keys(self):
+        self._pull()
+        return dict.keys(self)
+
     def __repr__(self):
         self._pull()
         return dict.__repr__(self)
@@ -288,11 +322,11 @@ class DeviceLM:
 
     # ---- validity of the shortcut that skips the traced forward ------------------------------------------------
     def same_operand(self, X_src):
-        return X_src.data_ptr() == self.x_ptr and X_src.numel() == self.n * 7 and X_src.dtype == self.dtype
+        return X_src.data_ptr() == self.x_ptr and X_src.numel() == self.n * 7 and X_src.dtype == self.dtype \
+            and X_src.device == self.device and X_src.is_contiguous()
 
     def rearm(self, input):
         self.input = input
-        self.budget = (1 << 62) if getattr(self.opt, 'static', False) else _RETRACE
 
     def _wrap_group(self):
         opt = self.opt
@@ -309,17 +343,27 @@ class DeviceLM:
             self.host_dirty = True
         return opt.param_groups[0]
 
-    def try_step(self, input, target, weight):
-        """The whole of ``LM.step`` when nothing the verified program depends on has changed, else None."""
+    def _step_conditions(self, target, weight):
         opt = self.opt
-        if self.budget <= 0 or target is not None or weight is not None or opt.weight is not None \
-                or not _same_input(self.input, input) or self.X_src._version != self.x_version \
-                or self.X_src.data_ptr() != self.x_ptr or self.P.data_ptr() != self.p_ptr \
-                or opt.strategy is not self.strategy or not opt.fused or not getattr(opt, 'structured', True) \
-                or len(opt.param_groups) != 1 or torch.is_inference_mode_enabled():
+        return not (target is not None or weight is not None or opt.weight is not None or self.P.data_ptr() != self.p_ptr
+                    or opt.strategy is not self.strategy or not opt.fused or not getattr(opt, 'structured', True)
+                    or len(opt.param_groups) != 1 or torch.is_inference_mode_enabled())
+
+    def try_step(self, input, target, weight):
+        """LM(static=True) only -- the caller's promise that the residual program does not change: the whole of ``LM.step``
+        without running the model, while the same ``input`` object(s) and operand storage are passed; else None."""
+        if not self._step_conditions(target, weight) or not _same_input(self.input, input) \
+                or self.X_src._version != self.x_version or self.X_src.data_ptr() != self.x_ptr:
             return None
-        self.budget -= 1
-        opt.linearization = Se3InvLinearization.kind
+        self.opt.linearization = Se3InvLinearization.kind
+        return self.step()
+
+    def checked_step(self, m, target, weight):
+        """The default: ``m`` is the program this step's (dry) run of the model was matched to.  If it is the program this
+        state was built on -- same parameter, same constant operand storage -- the step is two launches; else None."""
+        if m[0] != "se3inv" or m[1] is not self.P or not self.same_operand(m[2]) or not self._step_conditions(target, weight):
+            return None
+        self.opt.linearization = Se3InvLinearization.kind
         return self.step()
 
     # ---- one step ----------------------------------------------------------------------------------------------
@@ -438,20 +482,20 @@ def match_pgo(trace, gathers, R, params):
     if not _is_se3_group(P) or P.dim() != 2 or not P.is_contiguous() \
             or any(src is not P for src, _, _ in gathers):
         return None
-    by_out = {o[0].data_ptr(): (n, i) for n, i, o in trace.events}
-    gat = {out.data_ptr(): ix for _, ix, out in gathers}
+    by_out = {_key(o[0]): (n, i) for n, i, o in trace.events}
+    gat = {_key(out): ix for _, ix, out in gathers}
     if len(by_out) != 5 or len(gat) != 2:
         return None
     log = [(n, i, o) for n, i, o in trace.events if n == "se3_log_fwd"]
     if len(log) != 1 or not _same(log[0][2][0], R[0]):
         return None
-    top = by_out.get(log[0][1][0].data_ptr())
+    top = by_out.get(_key(log[0][1][0]))
     if top is None or top[0] != "se3_mul_fwd":
         return None
-    ev = lambda t: by_out.get(t.data_ptr())
+    ev = lambda t: by_out.get(_key(t))
     is_inv_of = lambda e, pred: e is not None and e[0] == "se3_inv_fwd" and pred(e[1][0])
-    gathered = lambda t: t.data_ptr() in gat
-    const = lambda t: not t.requires_grad and not gathered(t) and t.data_ptr() not in by_out
+    gathered = lambda t: _key(t) in gat
+    const = lambda t: not t.requires_grad and not gathered(t) and _key(t) not in by_out and t.device == P.device
     a, b = top[1]
     if gathered(b) and ev(a) is not None and ev(a)[0] == "se3_mul_fwd":
         # (Inv(Z) * Inv(n_i)) * n_j   -- the association of the reference example, pgo.py:24
@@ -465,11 +509,12 @@ def match_pgo(trace, gathers, R, params):
             return None
     else:
         return None
-    if not is_inv_of(zi, const) or not is_inv_of(ni, gathered) or ni[1][0].data_ptr() == n_j.data_ptr():
+    if not is_inv_of(zi, const) or not is_inv_of(ni, gathered) or _key(ni[1][0]) == _key(n_j):
         return None
-    idx0, idx1, Z = gat[ni[1][0].data_ptr()], gat[n_j.data_ptr()], zi[1][0]
+    idx0, idx1, Z = gat[_key(ni[1][0])], gat[_key(n_j)], zi[1][0]
     E = R[0].numel() // 6
-    if idx0.numel() != E or idx1.numel() != E or Z.numel() != E * 7 or Z.dtype != P.dtype:
+    if idx0.numel() != E or idx1.numel() != E or Z.numel() != E * 7 or Z.dtype != P.dtype or idx0.device != P.device \
+            or idx1.device != P.device:
         return None
     return P, idx0.reshape(-1), idx1.reshape(-1), Z
 
@@ -494,6 +539,12 @@ class PgoProgram:
                 cache["pgo_idx"] = ((idx0, idx1), (idx0._version, idx1._version), self.idx)
         self.Z = Z.detach().reshape(-1, 7).contiguous()
         self.E = self.idx.shape[0]
+        self.sources = _sources(idx0, idx1, Z)
+
+    def matches(self, P, idx0, idx1, Z):
+        """the operands of a freshly matched program are the tensors this one was built from, unmodified"""
+        return P is self.P and all(_unchanged(old, new, ver) and old.data_ptr() == ptr
+                                   for (old, ptr, ver), new in zip(self.sources, (idx0, idx1, Z)))
 
     def linearize(self):
         nodes = torch.Tensor.as_subclass(self.P, torch.Tensor).detach()     # (plain: no __torch_function__ round trips below)
@@ -539,35 +590,89 @@ def try_fused(opt, pg, input, target, weight, cache):
     # the device-side decision implements exactly the three built-in damping policies; a user-defined or subclassed
     # strategy sees the real J, D, R of the block linearisation instead
     builtin = _strategy_kind(opt.strategy) is not None
+    static = getattr(opt, 'static', False)
     hit = cache.get("program")
-    if cache.get("fused") is True and hit is not None and _same_input(hit[0], input) and hit[1] is P:
-        # The verified program of the previous step is evaluated directly, without running the model again to re-derive
-        # it, while nothing it was derived from has changed: the same `input` object(s), every operand tensor at the
-        # same address with the same version counter (an in-place edit bumps it).  The model's own code could still
-        # change behaviour without touching a tensor, so the forward is traced again every _RETRACE steps;
-        # LM(static=True) is the caller's promise that it does not (never re-traced).
-        static = getattr(opt, 'static', False)
-        fresh = static or (hit[5][0] > 0 and all(t.data_ptr() == ptr and t._version == ver for t, ptr, ver in hit[4]))
-        if fresh:
-            hit[5][0] -= 1
-            kind, operands = hit[2], hit[3]
-            if kind == "se3inv" and weight is None and trivial and solver_ok and builtin:
-                return Se3InvLinearization(opt, P, operands, None, input)
-            if kind == "pgo" and len(opt.corrector) == 1:
-                return _pgo_linearization(opt, operands, weight, P, trivial)
-    with torch.no_grad(), OpTracer() as tr, _pg.GatherRecorder(params) as rec:
-        R = list(opt.model(input, target))
-    m = match_se3inv(tr, R, params) if not rec.events else None
-    if m is not None and weight is None and trivial and solver_ok and builtin:
-        cache["program"] = (input, P, "se3inv", m[1], _sources(m[1]), [0])     # (DeviceLM.try_step is this program's shortcut)
-        return Se3InvLinearization(opt, *m, input)
-    m = match_pgo(tr, rec.events, R, params)
-    if m is not None and len(opt.corrector) == 1:
-        prog = PgoProgram(*m, cache=cache)
-        cache["program"] = (input, P, "pgo", prog, _sources(*m[1:]), [_RETRACE])
+    if static and cache.get("fused") is True and hit is not None and _same_input(hit[0], input) and hit[1] is P \
+            and all(t.data_ptr() == ptr and t._version == ver for t, ptr, ver in hit[4]):
+        # LM(static=True): the caller's promise that the residual program does not change between steps.  The verified
+        # program of the previous step is evaluated directly, without running the model, while the same `input` object(s)
+        # are passed and every operand tensor sits at the same address with the same version counter.
+        kind, operands = hit[2], hit[3]
+        if kind == "se3inv" and weight is None and trivial and solver_ok and builtin:
+            return Se3InvLinearization(opt, P, operands, None, input)
+        if kind == "pgo" and len(opt.corrector) == 1:
+            return _pgo_linearization(opt, operands, weight, P, trivial)
+    # Default: the model runs EVERY step, as in the reference (optimizer.py:631, 646) -- as a dry trace (DryTracer): its
+    # Python executes, the Lie kernels it would launch are recorded instead of launched, and the program is re-matched
+    # from that trace; the fused kernels below compute the residual themselves.  Only a model a dry run cannot follow
+    # (it looks at values of intermediates) gets a real traced forward.
+    m = opt.__dict__.pop('_dry_hint', None)
+    m = m[1] if m is not None and m[0] is input else None
+    if m is None:
+        m = dry_program(opt, params, input, target) if cache.get("dry") is not False else False
+    if m is False:
+        cache["dry"] = False
+        with torch.no_grad(), OpTracer() as tr, _pg.GatherRecorder(params) as rec:
+            R = list(opt.model(input, target))
+        m = _match(tr, rec, R, params)
+    if m is not None and m[0] == "se3inv" and weight is None and trivial and solver_ok and builtin:
+        cache["program"] = (input, P, "se3inv", m[2], _sources(m[2]), None)     # (DeviceLM is this program's shortcut)
+        return Se3InvLinearization(opt, P, m[2], None, input)
+    if m is not None and m[0] == "pgo" and len(opt.corrector) == 1:
+        prog = hit[3] if hit is not None and hit[2] == "pgo" and hit[3].matches(*m[1:]) else PgoProgram(*m[1:], cache=cache)
+        cache["program"] = (input, P, "pgo", prog, _sources(*m[2:]), None)
         return _pgo_linearization(opt, prog, weight, P, trivial)
     cache["fused"] = False
     return None
+
+
+def _match(tr, rec, R, params):
+    m = match_se3inv(tr, R, params) if not rec.events else None
+    if m is not None:
+        return ("se3inv", m[0], m[1])
+    m = match_pgo(tr, rec.events, R, params)
+    return ("pgo",) + m if m is not None else None
+
+
+def dry_program(opt, params, input, target):
+    """Run the model's Python for this step without launching its kernels and match the recorded chain:
+    ("se3inv", P, X) / ("pgo", P, idx0, idx1, Z), None if it is no recognised program, False if the model cannot be
+    followed dry (it raised: a real forward will say whether that was the dry run's fault)."""
+    from . import posegraph as _pg
+    if len(params) != 1 or not _is_se3_group(params[0]):
+        return None
+    try:
+        with torch.no_grad(), DryTracer() as tr, _pg.GatherRecorder(params) as rec:
+            R = list(opt.model(input, target))
+        if any(r.device.type != "meta" for r in R):
+            return None
+        return _match(tr, rec, R, params)
+    except Exception:
+        return False
+
+
+def checked_shortcut(opt, dev, gs, input, target, weight):
+    """``LM.step`` of the default (non-static) optimizer when a device-resident step exists: the model runs dry, and the
+    shortcut is taken only if THIS step's program is the one it was built on."""
+    pg = opt.param_groups[0]
+    params = [p for p in pg['params'] if p.requires_grad]
+    cache = opt.__dict__.get('_structure_cache') or {}
+    if cache.get("fused") is not True or cache.get("dry") is False or torch.is_inference_mode_enabled():
+        return None
+    m = dry_program(opt, params, input, target)
+    if not m:
+        return None
+    out = None
+    if dev is not None:
+        out = dev.checked_step(m, target, weight)
+    if out is None and gs is not None and m[0] == "pgo" and gs.prog.matches(*m[1:]):
+        w = opt.weight if weight is None else weight
+        if gs.usable(pg, input, target, w, checked=True):
+            with torch.no_grad():
+                return gs.step(pg)
+    if out is None:
+        opt._dry_hint = (input, m)          # the general path re-uses this step's trace
+    return out
 
 
 def _sources(*tensors):

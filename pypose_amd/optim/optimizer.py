@@ -243,7 +243,7 @@ def _linearize(opt, pg, input, target, weight, gauss_newton=False):
     # vector-Jacobian product); negative ones stay (the dense path is always correct).
     # The fused programs' verdict is the expensive one to re-establish (a whole autograd linearisation to compare with: 5 ms
     # on a 10k-pose graph, 8 % of the run if paid every 64 steps) and the least exposed -- a recognised program is re-derived
-    # from a traced forward every fused._RETRACE steps anyway -- so it expires every _REVERIFY linearisations instead.
+    # from a (dry) run of the model every step anyway -- so it expires every _REVERIFY linearisations instead.
     uses = cache['_uses'] = cache.get('_uses', 0) + 1
     if uses % _REPROBE == 0:
         for k in [k for k, v in cache.items() if v is True and (k != "fused" or uses % _REVERIFY == 0)]:
@@ -356,7 +356,8 @@ class LevenbergMarquardt(_Optimizer):
         self.fused = True          # whole-step kernels for recognised residual programs (optim/fused.py)
         # static=True: a promise (like capturing a hipGraph) that the model's residual program and its non-parameter
         # operands do not change between step() calls with the same `input` object; a recognised + verified program
-        # is then evaluated directly instead of being re-derived from a traced forward every step
+        # is then evaluated directly.  The default (False) keeps the reference's semantics: the model's forward runs at
+        # every step (as a dry trace that launches nothing, optim/fused.py DryTracer) and the program is re-derived from it
         self.static = bool(static)
         # torch.distributed process group: independent problems / graph edges are sharded over its
         # ranks (one process per GPU, RCCL); the loss, the gain ratio and -- for pose graphs -- the
@@ -463,29 +464,42 @@ class LevenbergMarquardt(_Optimizer):
         self.__dict__['_last_view'] = value
 
     def step(self, input, target=None, weight=None):
-        dev = self.__dict__.get('_device_lm')
-        if dev is not None and not (self._optimizer_step_pre_hooks or self._optimizer_step_post_hooks or _torch_opt._global_optimizer_pre_hooks
-                                    or _torch_opt._global_optimizer_post_hooks):
-            # a verified fused program whose operands have not changed: the whole step is two kernel launches, the
-            # model is not run (it is traced again every few dozen steps, and whenever anything it was verified on
-            # changes).  Nothing here touches autograd, and torch.optim's per-step profiler range + hook dispatch (a good
-            # 15 us) is only entered when somebody registered a hook.
-            out = dev.try_step(input, target, weight)
-            if out is not None:
-                return out
-        gs = self.__dict__.get('_pgo_graph_step')
-        if gs is not None and not (self._optimizer_step_pre_hooks or self._optimizer_step_post_hooks
-                                   or _torch_opt._global_optimizer_pre_hooks or _torch_opt._global_optimizer_post_hooks):
-            pg = self.param_groups[0]
-            w = self.weight if weight is None else weight
-            if gs.usable(pg, input, target, w):
-                with torch.no_grad():
-                    return gs.step(pg)
-        return self._step_general(input, target, weight)
+        d = self.__dict__
+        dev, gs = d.get('_device_lm'), d.get('_pgo_graph_step')
+        if (dev is not None or gs is not None) and not (self._optimizer_step_pre_hooks or self._optimizer_step_post_hooks
+                                                        or _torch_opt._global_optimizer_pre_hooks or _torch_opt._global_optimizer_post_hooks):
+            # A verified fused program with its loop state on the device: the whole step is one or two launches.  Nothing
+            # here touches autograd, and torch.optim's per-step profiler range + hook dispatch (a good 15 us) is only
+            # entered when somebody registered a hook.
+            if self.static:
+                # the caller's promise that the residual program does not change: the model is not run
+                if dev is not None:
+                    out = dev.try_step(input, target, weight)
+                    if out is not None:
+                        return out
+                if gs is not None:
+                    pg = self.param_groups[0]
+                    if gs.usable(pg, input, target, self.weight if weight is None else weight):
+                        with torch.no_grad():
+                            return gs.step(pg)
+            else:
+                # default, the reference's semantics (optimizer.py:631, 646): the model runs every step -- as a dry trace that
+                # launches nothing -- and the shortcut is taken only if this step's program is the one it was built for
+                from . import fused as _fused
+                out = _fused.checked_shortcut(self, dev, gs, input, target, weight)
+                if out is not None:
+                    return out
+        try:
+            return self._step_general(input, target, weight)
+        finally:
+            d.pop('_dry_hint', None)         # (this step's trace: never carried into another step)
     step.hooked = True              # torch.optim.Optimizer.__init__ must not wrap it again: _step_general carries the wrapper
 
     @torch.no_grad()
     def _step_general(self, input, target=None, weight=None):
+        dev = self.__dict__.get('_device_lm')
+        if dev is not None and dev.pending:          # (a later flush must not overwrite what this step sets: reject_count, damping)
+            dev.flush()
         for pg in self.param_groups:
             weight = self.weight if weight is None else weight
             lin = _linearize(self, pg, input, target, weight)

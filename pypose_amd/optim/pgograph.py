@@ -12,8 +12,9 @@ on buffers that can stay where they are:
 so it is captured once (torch.cuda.CUDAGraph over the very same Python code path the un-captured step runs) and a step
 becomes: write the damping factor, replay, read the vector back, run the strategy / accept test on the host.  A rejected
 trial (rare) continues in the ordinary trial loop on the captured linearisation.  The capture is used only while the
-program, its operands, the weight, the parameter storage and the solver settings are what it was captured on; every
-fused._RETRACE-th step goes through the ordinary path, which re-derives the program from a traced forward.
+program, its operands, the weight, the parameter storage and the solver settings are what it was captured on: by default
+the model's Python is run (dry, no launches) at the top of every step and the program re-matched from that trace
+(fused.checked_shortcut); LM(static=True) takes the program on trust.
 """
 from __future__ import annotations
 
@@ -69,13 +70,15 @@ class PgoGraphStep:
         self.lin, self.D, self.loss, self.J, self.R = lin, D, loss, J, R
 
     # -- per step ------------------------------------------------------------------------------------
-    def usable(self, pg, input, target, weight):
+    def usable(self, pg, input, target, weight, checked=False):
+        """``checked``: the caller has just matched this step's dry run of the model to ``self.prog`` (the default);
+        otherwise (LM(static=True)) the program is taken on trust while the same input objects / operand storage are passed."""
         opt, P = self.opt, self.P
         cache = opt.__dict__.get('_structure_cache')
         if cache is None or cache.get("fused") is not True or target is not None:
             return False
         hit = cache.get("program")
-        if hit is None or hit[3] is not self.prog or hit[1] is not P or not _fused._same_input(hit[0], input):
+        if hit is None or hit[3] is not self.prog or hit[1] is not P or not (checked or _fused._same_input(hit[0], input)):
             return False
         if weight is not self.weight or (isinstance(weight, torch.Tensor) and weight._version != self.weight_version):
             return False
@@ -95,10 +98,8 @@ class PgoGraphStep:
         if uses % _REPROBE == 0:                   # the ordinary path's periodic re-probing keeps its rhythm
             cache['_uses'] = uses - 1
             return False
-        if not getattr(opt, 'static', False):
-            if hit[5][0] <= 0 or not all(t.data_ptr() == ptr and t._version == ver for t, ptr, ver in hit[4]):
-                return False                       # operands changed, or time to re-trace: the ordinary path does that
-            hit[5][0] -= 1
+        if not checked and not all(t.data_ptr() == ptr and t._version == ver for t, ptr, ver in hit[4]):
+            return False                           # operands changed: the ordinary path re-derives the program
         return True
 
     def step(self, pg):
@@ -116,7 +117,16 @@ class PgoGraphStep:
         a, b, loss_h, its, rr, bn2, flag = self.out.tolist()          # the trial's one synchronisation
         opt.linearization = lin.kind
         opt._last_replicated = False
-        if flag == 2.0 or rr != rr:                # a failed solve returned a zero step: the parameters are where they were
+        if flag >= 2.0 or rr != rr:                # a failed solve returned a zero step: the parameters are where they were
+            if flag == 3.0:                        # the persistent launch's workgroups were not all resident: drop the capture,
+                from .posegraph import SolveFailed, _check_persist_flag      # take this step on the two-launch iteration
+                try:
+                    _check_persist_flag(flag, rr)
+                except SolveFailed:
+                    pass
+                opt.__dict__.pop('_pgo_graph_step', None)
+                opt.loss = opt.last
+                return opt._step_general(self.input, None, self.weight)
             print('Linear solve produced NaN (matrix may not be positive-definite)', "\nLinear solver failed. Breaking optimization step...")
             opt.loss = opt.last
             return opt.loss

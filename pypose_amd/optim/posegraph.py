@@ -49,6 +49,7 @@ _PCG2_SPMV_STOP_SIG = [ctypes.c_void_p] * 11 + [ctypes.c_int, ctypes.c_int64, ct
 _PCG2_STEP_SIG = [ctypes.c_void_p] * 9 + [ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]
 _PERSIST_SIG = [ctypes.c_void_p] * 15 + [ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]
 _PERSIST_GRID_MAX = 256     # PPLIE_PCG_PERSIST_GRID
+_PERSIST_SLOTS = 8          # PPLIE_PCG_PERSIST_SLOTS
 import os as _os
 # graphs up to this many nodes run the whole PCG solve in ONE persistent launch (csrc/pcg_persist.hip); larger ones need
 # the whole chip's bandwidth per iteration and keep the two-launch hipGraph iteration
@@ -243,9 +244,21 @@ class _PendingInfo:
 
     def resolve(self, values=None):
         its, rr, bn2, flag = self.info.tolist() if values is None else values
-        if flag == 2.0 or rr != rr:
-            raise SolveFailed('Linear solve produced NaN (matrix may not be positive-definite)')
+        _check_persist_flag(flag, rr)
         return int(its)
+
+
+def _check_persist_flag(flag, rr):
+    """(iterations, rr, bn2, flag) of pplie_pcg_persist: flag 2 = NaN, 3 = a workgroup never arrived at the exchange (the
+    launch's workgroups were not all resident: CU mask, partition, a concurrent kernel) -- both handed back x = 0."""
+    if flag == 3.0:
+        if FusedPCG.persist:
+            FusedPCG.persist = False          # permanently: the two-launch iteration needs no co-residency
+            warnings.warn("pypose_amd: the persistent PCG solve timed out waiting for a workgroup (its workgroups were not all "
+                          "resident on this device); falling back to the two-launch iteration for the rest of the process")
+        raise SolveFailed('persistent PCG: grid exchange timed out; retrying with the two-launch iteration')
+    if flag == 2.0 or rr != rr:
+        raise SolveFailed('Linear solve produced NaN (matrix may not be positive-definite)')
 
 
 class FusedPCG:
@@ -280,14 +293,18 @@ class FusedPCG:
         self.r2 = z(N, m)                                          # the two-launch iteration ping-pongs the residual
         # scal | part | it share ONE allocation: a solve clears them with a single fill instead of three
         esz = 4 if dtype == torch.float32 else 8
-        nb_scal, nb_part, nb_it = _PCG_SCAL_ELEMS * esz, 2 * _PERSIST_GRID_MAX * 8 * 8, 16
-        self._ctl = torch.zeros(nb_scal + nb_part + nb_it, dtype=torch.uint8, device=device)
+        nw = esz // 4
+        nb_scal, nb_part, nb_it = _PCG_SCAL_ELEMS * esz, 2 * _PERSIST_GRID_MAX * _PERSIST_SLOTS * nw * 8, 16
+        # the persistent solve's hand-off table of p (tagged 64-bit words, double-buffered) sits in the same allocation
+        nb_ptag = 2 * N * m * nw * 8 if (N <= PERSIST_NODES and m in (3, 6, 7)) else 0
+        self._ctl = torch.zeros(nb_scal + nb_part + nb_it + nb_ptag, dtype=torch.uint8, device=device)
+        self.ptag = self._ctl[nb_scal + nb_part + nb_it:].view(torch.int64) if nb_ptag else None
+        self.no_persist = nb_ptag == 0                              # (also set when the device cannot hold the solve resident)
         self.scal = self._ctl[:nb_scal].view(dtype)
         self.cap = 1 << 16
         self.rr_hist = z(self.cap)
         self.part = self._ctl[nb_scal:nb_scal + nb_part].view(torch.int64)   # persistent solve: tagged partial sums
-        self.it = self._ctl[nb_scal + nb_part:].view(torch.int32)[:4]     # iterations done, scratch, stop flag, -
-        self.bar = torch.zeros(64 + 32 * 32, dtype=torch.int32, device=device)      # PPLIE_GRID_BAR_WORDS
+        self.it = self._ctl[nb_scal + nb_part:nb_scal + nb_part + nb_it].view(torch.int32)[:4]     # iterations done, scratch, stop flag, -
         self.info = z(4)
         self.sfx = "_f32" if dtype == torch.float32 else "_f64"
         self.graph = None                                          # captured check_every iterations
@@ -295,6 +312,10 @@ class FusedPCG:
         self.sym = False                                           # HB holds one block per edge
         self.stop_tol2 = None                                      # tol^2 when the captured iterations carry the device-side stop
         self._csr_obj = None
+
+    def _persistent(self, plain):
+        """this solve runs as ONE persistent launch (csrc/pcg_persist.hip)"""
+        return self.two_launch and self.persist and not plain and not self.no_persist and self.N <= PERSIST_NODES
 
     def _csr(self, lin):
         """incidence lists sorted by node (shared with the assembly kernel, rebuilt only when the edge list changes)"""
@@ -369,7 +390,7 @@ class FusedPCG:
         if bsr:
             self._csr(lin)
             sym = bool(getattr(lin, "HB_sym", False))
-            if self.two_launch and self.persist and not plain and self.N <= PERSIST_NODES and not sym:
+            if self._persistent(plain) and not sym:
                 self.HB, self.sym = lin.HB, sym                     # the persistent solve reads the linearisation's blocks in place
             else:                                                   # captured iterations point at a buffer of the workspace
                 own = self.__dict__.get('_own_HB')
@@ -406,20 +427,29 @@ class FusedPCG:
                 self.z.copy_(self.r)
                 self.p.copy_(self.r)
                 self.scal[0:1024].copy_(self.scal[3 * 1024:4 * 1024])
-            if bsr and self.two_launch and self.persist and not plain and self.N <= PERSIST_NODES:
+            if bsr and self._persistent(plain) and not self.sym:
                 # the whole solve in one launch: iteration, reductions and the convergence test stay on the device
-                maxit = min(maxiter, self.cap)
+                maxit = min(maxiter, self.cap - 1)
                 code = _C.library().symbol("pplie_pcg_persist" + self.sfx, _PERSIST_SIG)(
                     self.ptr.data_ptr(), self.other.data_ptr(), self.HB.data_ptr(), self.D.data_ptr(), self.Binv.data_ptr(),
                     self.x.data_ptr(), self.r.data_ptr(), self.p.data_ptr(), self.q.data_ptr(), self.z.data_ptr(),
-                    self.part.data_ptr(), self.bar.data_ptr(), self.rr_hist.data_ptr(), self.info.data_ptr(), self.it.data_ptr(),
+                    self.part.data_ptr(), self.ptag.data_ptr(), self.rr_hist.data_ptr(), self.info.data_ptr(), self.it.data_ptr(),
                     float(tol), int(maxit), self.cap, PERSIST_GRID, self.N, self.m, _C.stream_ptr(self.device))
+                if code == _C.ECAPACITY:                            # this device cannot hold the solve resident: stream it instead
+                    self.no_persist = True
+                    return self.solve(lin, s, dmin, dmax, tol, maxiter, group, plain=plain, defer=defer)
                 _C.check(code, "pplie_pcg_persist")
                 if defer:
                     # the caller reads `info` together with the trial's loss and gain terms (ONE read-back per LM trial);
                     # a failed solve returns x = 0, so whatever was queued behind it left the parameters alone
                     return self.x.clone(), _PendingInfo(self.info.clone())
                 its, rr, bn2, flag = self.info.tolist()             # the solve's one read-back
+                if flag == 3.0:                                     # not all workgroups were resident: iterate with two launches
+                    try:
+                        _check_persist_flag(flag, rr)
+                    except SolveFailed:
+                        pass
+                    return self.solve(lin, s, dmin, dmax, tol, maxiter, group, plain=plain, defer=False)
                 assert flag != 2.0 and rr == rr, 'Linear solve produced NaN (matrix may not be positive-definite)'
                 return self.x.clone(), int(its)
             bn2_slots = self.scal[3 * 1024:4 * 1024:32]             # |b|^2: set 0, quantity 3, 32 slots (csrc/graph.hip)

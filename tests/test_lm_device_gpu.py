@@ -261,3 +261,106 @@ def test_failed_factorisation_leaves_the_parameter_untouched(capsys):
     assert "Linear solver failed" in out
     got = net.pose.detach().tensor()
     assert torch.equal(got, P1)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# default semantics: the model's forward runs every step (reference optimizer.py:631, 646); static=True is the opt-out
+# ---------------------------------------------------------------------------------------------------------------------
+class _Switching(InvNet):
+    flip = False
+    other = None
+    calls = 0
+
+    def forward(self, input):
+        self.calls += 1
+        if self.flip:
+            return (self.pose.Inv() @ input).Log().tensor()
+        return (self.pose @ (self.other if self.other is not None else input)).Log().tensor()
+
+
+def _fresh_step_loss(model_cls, pose, inp, **attrs):
+    net = model_cls(pp.SE3(pose.clone()))
+    for k, v in attrs.items():
+        setattr(net, k, v)
+    opt = pp.optim.LM(net, strategy=pp.optim.strategy.Constant(damping=1e-4))
+    return float(opt.step(inp)), opt.linearization
+
+
+def test_default_step_follows_a_rebound_buffer_and_a_flipped_attribute_at_once():
+    torch.manual_seed(5)
+    n = 4096
+    net = _Switching(pp.randn_SE3(n, sigma=0.3, device=DEV))
+    inp, inp2 = pp.randn_SE3(n, sigma=0.3, device=DEV), pp.randn_SE3(n, sigma=0.3, device=DEV)
+    opt = pp.optim.LM(net, strategy=pp.optim.strategy.Constant(damping=1e-4))
+    for _ in range(4):
+        opt.step(inp)
+    assert opt.linearization == "fused:se3inv" and opt.__dict__.get('_device_lm') is not None
+    calls = net.calls
+    opt.step(inp)
+    assert net.calls > calls, "the model's Python must run on every step"
+    # a buffer is REBOUND (no tensor written, same `input` object): the very next step optimises against it
+    pose = net.pose.detach().tensor().clone()
+    net.other = inp2
+    del opt.loss
+    got = float(opt.step(inp))
+    want, kind = _fresh_step_loss(_Switching, pose, inp, other=inp2)
+    assert kind == "fused:se3inv" and abs(got - want) <= 1e-5 * max(want, 1e-12), (got, want)
+    # an attribute flips the residual program itself: the next step runs the other program (generic block path)
+    pose = net.pose.detach().tensor().clone()
+    net.flip = True
+    del opt.loss
+    got = float(opt.step(inp))
+    want, kind = _fresh_step_loss(_Switching, pose, inp, flip=True)
+    assert opt.linearization == kind == "block" and abs(got - want) <= 1e-5 * max(want, 1e-12), (got, want)
+
+
+def test_static_true_is_the_opt_out():
+    torch.manual_seed(6)
+    n = 2048
+    net = _Switching(pp.randn_SE3(n, sigma=0.3, device=DEV))
+    inp = pp.randn_SE3(n, sigma=0.3, device=DEV)
+    opt = pp.optim.LM(net, strategy=pp.optim.strategy.Constant(damping=1e-4), static=True)
+    for _ in range(4):
+        opt.step(inp)
+    calls = net.calls
+    for _ in range(8):
+        opt.step(inp)
+    assert net.calls == calls and opt.linearization == "fused:se3inv"      # the promise: the model is not run
+
+
+def test_default_pose_graph_step_follows_a_model_change_behind_the_captured_graph():
+    from tests.optim_models import PoseGraph
+
+    class Swappable(PoseGraph):
+        swapped = False
+
+        def forward(self, edges, poses):
+            a, b = (1, 0) if self.swapped else (0, 1)
+            return (poses.Inv() @ self.nodes[edges[..., a]].Inv() @ self.nodes[edges[..., b]]).Log().tensor()
+
+    torch.manual_seed(7)
+    N, E = 300, 900
+    gt = pp.cumprod(pp.randn_SE3(N, sigma=0.3, device=DEV), dim=0, left=False)
+    e = torch.cat([torch.stack([torch.arange(N - 1), torch.arange(1, N)], -1), torch.randint(0, N, (E - N + 1, 2))]).to(DEV)
+    e[:, 1] = torch.where(e[:, 0] == e[:, 1], (e[:, 1] + 1) % N, e[:, 1])
+    rel = gt[e[:, 0]].Inv() @ gt[e[:, 1]] @ pp.randn_SE3(E, sigma=0.01, device=DEV)
+    init = gt @ pp.randn_SE3(N, sigma=0.05, device=DEV)
+
+    def make(nodes, **attrs):
+        g = Swappable(pp.SE3(nodes.clone()))
+        for k, v in attrs.items():
+            setattr(g, k, v)
+        return g, pp.optim.LM(g, solver=pp.optim.solver.PCG(tol=1e-6, maxiter=500), strategy=pp.optim.strategy.TrustRegion(radius=1e4))
+    graph, opt = make(init.tensor())
+    for _ in range(6):
+        opt.step((e, rel))
+    assert opt.linearization == "fused:pgo" and opt.__dict__.get('_pgo_graph_step') is not None
+    nodes = graph.nodes.detach().tensor().clone()
+    damping = opt.param_groups[0]['damping']
+    graph.swapped = True                         # residual becomes Log(Z^-1 n_j^-1 n_i): a different problem
+    del opt.loss
+    got = float(opt.step((e, rel)))
+    g2, o2 = make(nodes, swapped=True)
+    o2.param_groups[0]['damping'] = damping
+    want = float(o2.step((e, rel)))
+    assert abs(got - want) <= 1e-4 * want, (got, want)

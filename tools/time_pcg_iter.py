@@ -1,0 +1,59 @@
+"""Per-iteration time of the persistent PCG solve (csrc/pcg_persist.hip) on the metric's 10k / 40k pose graph:
+    python tools/time_pcg_iter.py [N E]
+The linearisation of the first LM step is solved to a tolerance it cannot reach (so every run does exactly `maxiter`
+iterations), for several workgroup counts; HIP events around the solve's launches; the two-launch iteration beside it."""
+import json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import pypose_amd as pp
+from pypose_amd.optim import fused as F, posegraph as G
+from tests.optim_models import PoseGraph
+from tests.test_optim_gpu import _synthetic_graph
+
+N, E = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (10_000, 40_000)
+edges, rel, init = _synthetic_graph(N, E, torch.float32)
+graph = PoseGraph(init.clone())
+solver = pp.optim.solver.PCG(tol=1e-4, maxiter=250)
+opt = pp.optim.LM(graph, solver=solver, strategy=pp.optim.strategy.TrustRegion(radius=1e4))
+opt.step((edges, rel))                                           # establishes the fused program
+cache = opt._structure_cache
+prog = cache["program"][3]
+with torch.no_grad():
+    lin = F._pgo_linearization(opt, prog, None, graph.nodes, True)
+    lin.build_normal_equations(1e-6, 1e32)
+    lin.damp(1e-4)
+    wsp = next(iter(opt._pcg_workspaces.values()))
+    out = {"nodes": N, "edges": E}
+    for iters in (40, 200):
+        for grid in (64, 128, 192, 256):
+            G.PERSIST_GRID = grid
+            ts = []
+            for rep in range(6):
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                x, its = wsp.solve(lin, lin.s, lin.dmin, lin.dmax, 1e-30, iters, None)
+                b.record()
+                torch.cuda.synchronize()
+                ts.append(a.elapsed_time(b) * 1e3)
+            t = sorted(ts[1:])[len(ts[1:]) // 2]
+            out[f"persist_grid{grid}_it{iters}"] = {"us_per_solve": round(t, 1), "iterations": its, "us_per_iteration": round(t / max(its, 1), 2)}
+    # per-iteration cost net of the solve's fixed part (prepare launch, fill, prologue, read-back)
+    for grid in (64, 128, 192, 256):
+        a, b = out[f"persist_grid{grid}_it40"], out[f"persist_grid{grid}_it200"]
+        out[f"persist_grid{grid}_marginal_us_per_iteration"] = round((b["us_per_solve"] - a["us_per_solve"]) / (b["iterations"] - a["iterations"]), 2)
+    G.PERSIST_GRID = 256
+    x1, _ = wsp.solve(lin, lin.s, lin.dmin, lin.dmax, 1e-6, 2000, None)
+    G.FusedPCG.persist = False
+    x2, its2 = wsp.solve(lin, lin.s, lin.dmin, lin.dmax, 1e-6, 2000, None)
+    out["persist_vs_two_launch_max_abs_diff"] = float((x1 - x2).abs().max())
+    out["solution_max_abs"] = float(x2.abs().max())
+    ts = []
+    for rep in range(4):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        x, its = wsp.solve(lin, lin.s, lin.dmin, lin.dmax, 1e-30, 200, None)
+        b.record()
+        torch.cuda.synchronize()
+        ts.append(a.elapsed_time(b) * 1e3)
+    out["two_launch_it200"] = {"us_per_solve": round(sorted(ts[1:])[1], 1), "iterations": its, "us_per_iteration": round(sorted(ts[1:])[1] / max(its, 1), 2)}
+print(json.dumps(out))
