@@ -54,9 +54,10 @@ class _BlockJ:
 # ---------------------------------------------------------------------------------------------------------------------
 # configs[2]: LM on InvNet, B independent SE3 problems (README.md:120-129 through optimizer.py:644-679)
 # ---------------------------------------------------------------------------------------------------------------------
-def invnet_lm(init, inp, steps, strategy="constant", strategy_kw=None, dmin=1e-6, dmax=1e32, reject=16, timing=None):
+def invnet_lm(init, inp, steps, strategy="constant", strategy_kw=None, dmin=1e-6, dmax=1e32, reject=16, sample=None):
     """``steps`` LM steps on ``pose <- argmin |Log(pose @ inp)|^2`` from ``init`` [B,7] / ``inp`` [B,7] (torch CPU tensors).
-    Returns {"loss", "damping", "reject", "final"} like tests/golden/make_lm_golden.py:run."""
+    Returns {"loss", "damping", "reject", "final"} like tests/golden/make_lm_golden.py:run; ``sample`` (an index / slice):
+    also "poses" = the poses ``P[sample]`` after every step."""
     rpp = _rpp()
     op = rpp.lietensor.operation
     strat = _strategy(rpp, strategy, **(strategy_kw or {}))
@@ -64,7 +65,7 @@ def invnet_lm(init, inp, steps, strategy="constant", strategy_kw=None, dmin=1e-6
     P = rpp.SE3(init.clone())
     X = rpp.SE3(inp)
     B = P.shape[0]
-    rec = {"loss": [], "damping": [], "reject": [], "step_seconds": []}
+    rec = {"loss": [], "damping": [], "reject": [], "step_seconds": [], "poses": []}
 
     def residual(P):
         return (P @ X).Log().tensor()
@@ -100,6 +101,8 @@ def invnet_lm(init, inp, steps, strategy="constant", strategy_kw=None, dmin=1e-6
         rec["damping"].append(float(pg["damping"]))
         rec["reject"].append(rejects)
         rec["step_seconds"].append(time.perf_counter() - t0)
+        if sample is not None:
+            rec["poses"].append(P.tensor()[sample].clone())
     rec["final"] = P.tensor().clone()
     return rec
 

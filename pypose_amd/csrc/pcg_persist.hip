@@ -121,13 +121,56 @@ template <class T, int Q> __device__ __forceinline__ bool gather_rows(const u64*
   return ok;
 }
 
+
+// q_i += sum over this lane's incidences of (row i of the off-diagonal block) . (the neighbour's p row).  A lane fetches ONE
+// element of each neighbour row -- its own component -- as a tagged word and the node's M lanes trade them by shuffle.  CH
+// incidences per round: every tagged load of a round is in flight before the first is looked at, so a node of degree <= CH
+// costs ONE memory round trip per iteration (the round-2 kernel walked the list four at a time, each round a chain of two
+// dependent trips: neighbour index, then its row -- that chain, not the grid exchange, was most of its 15 us).  The loop is
+// wave-uniform (runs to the largest degree in the wave, absent incidences masked) so the shuffles sit in uniform control
+// flow.  `hb` / `nb`: this lane's first block / neighbour index -- in LDS when the workgroup's slice was staged there
+// (LDS = true), else in global memory.
+template <class T, int M, int CH, class HP, class NP>
+__device__ __forceinline__ T spmv_rows(HP hb, NP nb, int deg, int maxdeg, int sub, int i, const u64* pin, unsigned own, unsigned tag,
+                                       bool& stale) {
+  constexpr int NW = sizeof(T) / 4;
+  T acc = T(0);
+  for (int c0 = 0; c0 < maxdeg; c0 += CH) {
+    unsigned po[CH];                       // (word index in the table: < 2^32 for every graph the persistent solve takes)
+    T pv[CH];
+    // an absent incidence reads this lane's OWN element of p (always current: no extra wait) against a zeroed block row:
+    // every load is unconditional, no divergent branches around them
+#pragma unroll
+    for (int q = 0; q < CH; ++q) po[q] = c0 + q < deg ? (unsigned)((nb[c0 + q] * M + i) * NW) : own;
+    for (long spin = 0;; ++spin) {
+      bool ok = true;
+#pragma unroll
+      for (int q = 0; q < CH; ++q) pv[q] = get_value<T>(pin + po[q], tag, ok);
+      if (__all(ok)) break;
+      if (spin >= (1L << 20)) { stale = true; break; }
+      __builtin_amdgcn_s_sleep(1);
+    }
+#pragma unroll
+    for (int q = 0; q < CH; ++q) {
+      const bool valid = c0 + q < deg;
+      const T mask = valid ? T(1) : T(0);
+      const int c = valid ? c0 + q : 0;
+#pragma unroll
+      for (int j = 0; j < M; ++j) acc += mask * hb[(size_t)c * M * M + j] * __shfl(pv[q], sub * M + j, 64);
+    }
+  }
+  return acc;
+}
+
 template <class T, int M>
 __global__ void __launch_bounds__(kPersistBlock)
 pcg_persist_kernel(const int* __restrict__ ptr, const int* __restrict__ other, const T* __restrict__ HB, const T* __restrict__ D,
                    const T* __restrict__ Binv, T* __restrict__ x, const T* __restrict__ r, const T* __restrict__ z,
                    u64* part /* [2][kPersistGridMax][kPersistSlots values as tagged words] */,
                    u64* ptag /* [2][N * M values as tagged words] */, T* __restrict__ rr_hist, T* info /* [4] */, int* it_out,
-                   T tol2, int maxiter, int cap, int64_t N) {
+                   T tol2, int maxiter, int cap, int64_t N, int lds_bytes) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
+  constexpr int CH = sizeof(T) == 4 ? 16 : 8;   // incidences per round of tagged loads
   constexpr int NPW = 64 / M;              // nodes per wave: M lanes per node
   constexpr int WV = kPersistBlock / 64;   // waves per workgroup
   constexpr int NW = sizeof(T) / 4, RW = kPersistSlots * NW;
@@ -161,6 +204,21 @@ pcg_persist_kernel(const int* __restrict__ ptr, const int* __restrict__ other, c
     const int o = __shfl_xor(maxdeg, off, 64);
     maxdeg = o > maxdeg ? o : maxdeg;
   }
+  // ---- this workgroup's slice of the matrix -- the off-diagonal blocks of its nodes' incidences (contiguous: incidence
+  // order is node order) and their neighbour indices -- is staged into LDS once and read from there in every iteration;
+  // a slice that does not fit (dense neighbourhoods, few workgroups) stays in global memory (L2)
+  const int c_lo = ptr[n0], c_cnt = ptr[n1] - c_lo;
+  const bool in_lds = (size_t)c_cnt * (M * M * sizeof(T) + 4) <= (size_t)lds_bytes;
+  T* hb_l = reinterpret_cast<T*>(dyn_lds);
+  unsigned* nb_l = reinterpret_cast<unsigned*>(dyn_lds + (size_t)c_cnt * M * M * sizeof(T));
+  if (in_lds) {
+    const T* src = HB + (size_t)c_lo * M * M;
+    for (int e = threadIdx.x; e < c_cnt * M * M; e += kPersistBlock) hb_l[e] = src[e];
+    for (int e = threadIdx.x; e < c_cnt; e += kPersistBlock) nb_l[e] = (unsigned)other[c_lo + e];
+  }
+  __syncthreads();
+  const unsigned own = (unsigned)(((act ? n : n0) * M + (act ? i : 0)) * NW);     // (an idle lane watches the workgroup's first element)
+  const int lbeg = act ? beg - c_lo : 0;
   T bn2 = T(0), rr = T(0);
   int k = 0, flag = 0;                     // flag: 1 converged, 2 NaN, 3 a workgroup never arrived, 0 iteration limit
   for (;; ++k) {
@@ -171,40 +229,10 @@ pcg_persist_kernel(const int* __restrict__ ptr, const int* __restrict__ other, c
     bool stale = false;
 #pragma unroll
     for (int j = 0; j < M; ++j) acc += dr[j] * __shfl(pe, sub * M + j, 64);
-    // Four incidences at a time, every load of a chunk issued before the first use (the gather is a chain of dependent
-    // round trips: neighbour index, then its p row).  A lane fetches ONE element of each neighbour row -- its own component --
-    // and the node's M lanes trade them by shuffle: M times fewer tagged loads than every lane reading whole rows.  The loop
-    // is wave-uniform (runs to the largest degree in the wave, absent incidences masked) so that the shuffles sit in
-    // uniform control flow.
-    for (int c0 = 0; c0 < maxdeg; c0 += 4) {
-      bool valid[4];
-      size_t po[4];
-      T hv[4][M], pv[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        valid[q] = c0 + q < deg;
-        const int c = valid[q] ? beg + c0 + q : 0;
-        po[q] = valid[q] ? ((size_t)other[c] * M + i) * NW : 0;
-        const T* h = HB + ((int64_t)c * M + i) * M;
-#pragma unroll
-        for (int j = 0; j < M; ++j) hv[q][j] = valid[q] ? h[j] : T(0);
-        pv[q] = T(0);
-      }
-      for (long spin = 0;; ++spin) {
-        bool ok = true;
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-          if (valid[q]) pv[q] = get_value<T>(pin + po[q], tag, ok);
-        if (__all(ok)) break;
-        if (spin >= (1L << 20)) { stale = true; break; }
-        __builtin_amdgcn_s_sleep(1);
-      }
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-#pragma unroll
-        for (int j = 0; j < M; ++j) acc += hv[q][j] * __shfl(pv[q], sub * M + j, 64);
-      }
-    }
+    if (in_lds)
+      acc += spmv_rows<T, M, CH>(hb_l + ((size_t)lbeg * M + i) * M, nb_l + lbeg, deg, maxdeg, sub, i, pin, own, tag, stale);
+    else
+      acc += spmv_rows<T, M, CH>(HB + ((size_t)beg * M + i) * M, other + beg, deg, maxdeg, sub, i, pin, own, tag, stale);
     T bq = T(0);
 #pragma unroll
     for (int j = 0; j < M; ++j) bq += br[j] * __shfl(acc, sub * M + j, 64);
@@ -252,17 +280,26 @@ pcg_persist_kernel(const int* __restrict__ ptr, const int* __restrict__ other, c
   }
 }
 
-// the most workgroups of this kernel the device holds at once (they spin on each other: all must be resident)
-template <class T, int M> static int persist_capacity() {
-  static int cap[16] = {0};
+// Dynamic LDS of a workgroup (the staged matrix slice); the most workgroups of this kernel the device holds at once
+// (they spin on each other: all must be resident)
+constexpr int kPersistLds = 128 * 1024;
+template <class T, int M> static int persist_capacity(int& lds_bytes) {
+  static int cap[16] = {0}, lds[16] = {0};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 0;
   if (cap[dev] == 0) {
     int cus = 0, per = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, pcg_persist_kernel<T, M>, kPersistBlock, 0) != hipSuccess) return 0;
+    lds[dev] = kPersistLds;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&pcg_persist_kernel<T, M>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            kPersistLds) != hipSuccess) {
+      (void)hipGetLastError();
+      lds[dev] = 48 * 1024;                                      // (always available without the attribute)
+    }
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, pcg_persist_kernel<T, M>, kPersistBlock, lds[dev]) != hipSuccess) return 0;
     cap[dev] = cus * per > 0 ? cus * per : -1;
   }
+  lds_bytes = lds[dev];
   return cap[dev] > 0 ? cap[dev] : 0;
 }
 
@@ -277,14 +314,16 @@ int pcg_persist(const void* ptr, const void* other, const void* HB, const void* 
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 #define LAUNCH(MM)                                                                                                             \
   {                                                                                                                            \
-    const int resident = persist_capacity<T, MM>();                                                                            \
-    if (resident > 0 && grid > resident) grid = resident;        /* fewer CUs than asked for: every workgroup must be resident */ \
+    int lds_bytes = 0;                                                                                                         \
+    const int resident = persist_capacity<T, MM>(lds_bytes);                                                                   \
+    if (resident <= 0) return PPLIE_ECAPACITY;                                                                                 \
+    if (grid > resident) grid = resident;                         /* fewer CUs than asked for: every workgroup must be resident */ \
     if (grid > N) grid = (int)N;                                                                                               \
     const int64_t per_wg = (kPersistBlock / 64) * (64 / MM);     /* one lane per (node, component): nodes one workgroup holds */ \
     if ((N + grid - 1) / grid > per_wg) return PPLIE_ECAPACITY;  /* too large for this device: use the two-launch iteration */  \
-    hipLaunchKernelGGL((pcg_persist_kernel<T, MM>), dim3(grid), dim3(kPersistBlock), 0, st, (const int*)ptr, (const int*)other, \
+    hipLaunchKernelGGL((pcg_persist_kernel<T, MM>), dim3(grid), dim3(kPersistBlock), lds_bytes, st, (const int*)ptr, (const int*)other, \
                        (const T*)HB, (const T*)D, (const T*)Binv, (T*)x, (const T*)r, (const T*)z, (unsigned long long*)part,     \
-                       (unsigned long long*)ptag, (T*)rr_hist, (T*)info, (int*)it, (T)(tol * tol), maxiter, cap, N);             \
+                       (unsigned long long*)ptag, (T*)rr_hist, (T*)info, (int*)it, (T)(tol * tol), maxiter, cap, N, lds_bytes);  \
   }
   if (m == 6) LAUNCH(6) else if (m == 7) LAUNCH(7) else if (m == 3) LAUNCH(3) else return PPLIE_EBADARG;
 #undef LAUNCH

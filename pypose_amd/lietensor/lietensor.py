@@ -401,12 +401,11 @@ class LieTensor(Tensor):
         kwargs = {} if kwargs is None else kwargs
         plain = tuple(Tensor if issubclass(t, LieTensor) else t for t in types)
         name = getattr(func, '__name__', None)
-        if _gather_recorders and name == '__getitem__' and len(args) == 2 and _C.dry_tracing() \
-                and isinstance(args[1], Tensor) and args[1].dtype == torch.int64 and isinstance(args[0], Tensor) and args[0].dim() == 2 \
-                and any(id(args[0]) in rec.ids for rec in _gather_recorders):
-            # dry trace (optim/fused.py): the row gather on a tracked parameter is noted, not executed
-            data = torch.empty(tuple(args[1].shape) + (args[0].shape[-1],), dtype=args[0].dtype, device="meta")
-        else:
+        data = None
+        if _gather_recorders and name == '__getitem__' and len(args) == 2 and _C.dry_tracing():
+            # dry trace (optim/fused.py): a row gather on a tracked parameter is noted, not executed
+            data = _op._op_tracers[-1].dry_gather(args[0], args[1], _gather_recorders)
+        if data is None:
             data = Tensor.__torch_function__(func, plain, args, kwargs)
         if _gather_recorders and name == '__getitem__' and len(args) == 2:
             for rec in _gather_recorders:        # optim/posegraph.py: which rows feed which residual

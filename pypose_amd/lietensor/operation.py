@@ -77,16 +77,7 @@ def _launch(name, ins, in_widths, out_widths, prm=None):
         # optim/fused.py DryTracer: the model's Python runs, nothing is launched; outputs are `meta` tensors -- shapes and
         # dtypes without storage, so anything that needs a VALUE downstream (a branch on a result, .item(), a copy) raises
         # instead of reading garbage, and the caller falls back to a real forward
-        x0 = ins[0]
-        for t, w in zip(ins, in_widths):
-            if t.shape[-1] != w:
-                raise ValueError(f"expected last dimension {w}, got shape {tuple(t.shape)}")
-            if t.dtype != x0.dtype or (t.device != x0.device and "meta" not in (t.device.type, x0.device.type)):
-                raise ValueError(f"pypose_amd: op {name}: inputs must share dtype / device")
-        outs = tuple(torch.empty(tuple(lead) + (w,), dtype=x0.dtype, device="meta") for w in out_widths)
-        for tr in _op_tracers:
-            tr.note(name, ins, outs)
-        return outs
+        return _op_tracers[-1].dry_launch(name, ins, in_widths, out_widths, lead)
     flat = []
     for t, w in zip(ins, in_widths):
         if t.shape[:-1] != lead:

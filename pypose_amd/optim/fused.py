@@ -52,6 +52,25 @@ class OpTracer:
         self.events.append((name, tuple(ins), tuple(outs)))
 
 
+class _DryState:
+    """What a dry trace keeps from one step to the next (per optimizer): the `meta` outputs by trace position (the same
+    program produces the same shapes every step: no allocation), and the signature + match of the latest trace."""
+    __slots__ = ("pool", "sig", "match", "base")
+
+    def __init__(self):
+        self.pool, self.sig, self.match = {}, None, None
+        # every dry output is a view into ONE storage-less `meta` buffer at its own offset: the offset identifies the
+        # value across as_subclass / view re-wrappings (a storage_offset() read is ~0.1 us; a storage handle ~1 us)
+        self.base = torch.empty((1 << 60,), dtype=torch.uint8, device="meta")
+
+
+def _tok(t):
+    """what a trace signature records of an operand: a dry output's offset, or a real tensor's memory + layout"""
+    if t.device.type == "meta":
+        return -1 - t.storage_offset()
+    return (t.data_ptr(), t.shape, t.dtype, t.requires_grad, t.stride(), t.device.index)
+
+
 class DryTracer(OpTracer):
     """The same recording with NOTHING launched: while it is active on this thread the Lie Functions return `meta` tensors
     (lietensor/operation.py:_launch), row gathers on tracked parameters are noted but not executed (LieTensor.__torch_function__)
@@ -59,6 +78,11 @@ class DryTracer(OpTracer):
     the reference (optimizer.py:631, 646) -- so a change that touches no tensor (an attribute flipped, a buffer rebound, a
     different branch taken) shows up in the trace of the very next step; what a dry run cannot follow (a model that looks at
     VALUES of intermediate results) raises out of it and the caller runs a real forward instead."""
+
+    def __init__(self, state=None):
+        super().__init__()
+        self.state = _DryState() if state is None else state
+        self.pos, self.next_offset, self.sig = 0, 16, []
 
     def __enter__(self):
         _C._tls.dry = getattr(_C._tls, "dry", 0) + 1
@@ -68,11 +92,57 @@ class DryTracer(OpTracer):
         super().__exit__(*exc)
         _C._tls.dry -= 1
 
+    def _out(self, shape, dtype):
+        """the `meta` output of this trace position (kept across steps while shape and dtype stay the same)"""
+        pos = self.pos
+        self.pos = pos + 1
+        hit = self.state.pool.get(pos)
+        if hit is not None and hit[0] == shape and hit[1] is dtype:
+            return hit[2]
+        n = 1
+        for v in shape:
+            n *= v
+        esz = torch.empty((), dtype=dtype, device="meta").element_size()
+        off = (pos + 1) << 44                                        # byte offset: one 16 TB window per trace position
+        t = self.state.base[off:off + max(n, 1) * esz].view(dtype)[:n].view(shape)
+        self.state.pool[pos] = (shape, dtype, t)
+        return t
+
+    def dry_launch(self, name, ins, in_widths, out_widths, lead):
+        x0 = ins[0]
+        for t, w in zip(ins, in_widths):
+            if t.shape[-1] != w:
+                raise ValueError(f"expected last dimension {w}, got shape {tuple(t.shape)}")
+            if t.dtype != x0.dtype or (t.device != x0.device and "meta" not in (t.device.type, x0.device.type)):
+                raise ValueError(f"pypose_amd: op {name}: inputs must share dtype / device")
+        lead = tuple(lead)
+        outs = tuple(self._out(lead + (w,), x0.dtype) for w in out_widths)
+        self.events.append((name, tuple(ins), outs))
+        self.sig.append((name,) + tuple(_tok(t) for t in ins) + tuple(o.storage_offset() for o in outs))
+        return outs
+
+    def dry_gather(self, source, index, recorders):
+        """``source[index]`` of a tracked 2-D parameter with an int64 index tensor: a `meta` result, or None (not ours)"""
+        if not isinstance(index, torch.Tensor) or index.dtype != torch.int64:
+            return None
+        src = None
+        for rec in recorders:
+            src = rec.plain.get(id(source))
+            if src is not None:
+                break
+        if src is None or src.dim() != 2:
+            return None
+        out = self._out(tuple(index.shape) + (src.shape[-1],), src.dtype)
+        self.sig.append(("gather", id(source), _tok(index), out.storage_offset()))
+        return out
+
 
 def _key(t):
-    """identity of a tensor's memory: the address, or (dry-trace outputs have none) storage object + offset"""
+    """identity of a tensor's memory: the address, or (dry-trace outputs have none) the offset in the dry trace's buffer"""
+    if type(t) is not torch.Tensor:
+        t = torch.Tensor.as_subclass(t, torch.Tensor)          # (attribute reads on a LieTensor are __torch_function__ round trips)
     if t.device.type == "meta":
-        return ("meta", t.untyped_storage()._cdata, t.storage_offset())
+        return -1 - t.storage_offset()
     return t.data_ptr()
 
 
@@ -85,6 +155,8 @@ def _is_se3_group(P):
 
 def _same(a, b):
     # (the Lie methods flatten leading dims to rows before launching: same storage, same element count)
+    a = a if type(a) is torch.Tensor else torch.Tensor.as_subclass(a, torch.Tensor)
+    b = b if type(b) is torch.Tensor else torch.Tensor.as_subclass(b, torch.Tensor)
     return a.device == b.device and _key(a) == _key(b) and a.numel() == b.numel() and a.dtype == b.dtype \
         and a.is_contiguous() and b.is_contiguous()
 
@@ -637,16 +709,26 @@ def _match(tr, rec, R, params):
 def dry_program(opt, params, input, target):
     """Run the model's Python for this step without launching its kernels and match the recorded chain:
     ("se3inv", P, X) / ("pgo", P, idx0, idx1, Z), None if it is no recognised program, False if the model cannot be
-    followed dry (it raised: a real forward will say whether that was the dry run's fault)."""
+    followed dry (it raised: a real forward will say whether that was the dry run's fault).  A trace whose signature
+    (kernel names, operand memory / layout, data flow) equals the previous step's is the previous step's program."""
     from . import posegraph as _pg
     if len(params) != 1 or not _is_se3_group(params[0]):
         return None
+    st = opt.__dict__.get('_dry_state')
+    if st is None:
+        st = opt.__dict__['_dry_state'] = _DryState()
     try:
-        with torch.no_grad(), DryTracer() as tr, _pg.GatherRecorder(params) as rec:
+        with torch.no_grad(), DryTracer(st) as tr, _pg.GatherRecorder(params) as rec:
             R = list(opt.model(input, target))
-        if any(r.device.type != "meta" for r in R):
+        plain = [r if type(r) is torch.Tensor else torch.Tensor.as_subclass(r, torch.Tensor) for r in R]
+        if any(r.device.type != "meta" for r in plain):
             return None
-        return _match(tr, rec, R, params)
+        sig = (tuple(tr.sig), tuple(_tok(r) for r in plain), id(params[0]))
+        if st.sig == sig:
+            return st.match
+        m = _match(tr, rec, R, params)
+        st.sig, st.match = sig, m
+        return m
     except Exception:
         return False
 

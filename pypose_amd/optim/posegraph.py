@@ -67,6 +67,8 @@ class GatherRecorder:
 
     def __init__(self, params):
         self.ids = {id(p): p for p in params}
+        # plain aliases of the tracked parameters: attribute reads on a LieTensor are __torch_function__ round trips
+        self.plain = {id(p): torch.Tensor.as_subclass(p, torch.Tensor) for p in params}
         self.events = []      # (param, index LongTensor [E], gathered rows [E, w])
         self.closed = []      # (residual, [(input tensor, d residual / d input blocks)], blockers): ops that know their Jacobian
 
@@ -122,10 +124,13 @@ class GatherRecorder:
     def note(self, source, index, out):
         # gathers on a tracked parameter, or on a tensor derived from one (e.g. ``cat((root, nodes))`` in
         # the reference's chain example, tests/optim/test_sparse_lm.py:26-36)
-        if isinstance(index, torch.Tensor) and index.dtype == torch.int64 and index.dim() >= 1 \
-                and isinstance(out, torch.Tensor) and (out.requires_grad or id(source) in self.ids) \
-                and isinstance(source, torch.Tensor) and source.dim() == 2:
-            self.events.append((source, index, out))
+        if isinstance(index, torch.Tensor) and index.dtype == torch.int64 and index.dim() >= 1 and isinstance(out, torch.Tensor) \
+                and isinstance(source, torch.Tensor):
+            src = self.plain.get(id(source))
+            tracked = src is not None
+            if (tracked or torch.Tensor.as_subclass(out, torch.Tensor).requires_grad) \
+                    and (src if tracked else torch.Tensor.as_subclass(source, torch.Tensor)).dim() == 2:
+                self.events.append((source, index, out))
 
 
 class _PlainGatherMode(torch.overrides.TorchFunctionMode):

@@ -221,11 +221,17 @@ def test_lazy_mirrors_and_user_overrides():
     net.pose.data.copy_(init.tensor())
     l3 = opt.step(inp)
     assert float(l3) == pytest.approx(float(l1), rel=1e-12) and pg['damping'] == pytest.approx(5e-5)
-    # a changed input is seen (version counter): the program is traced again and still matches
-    inp.tensor().mul_(1.0)
-    before = dev.budget
-    opt.step(inp)
-    assert opt._device_lm.budget == fused._RETRACE and before < fused._RETRACE
+    # an input edited in place is read by the very next step (the kernel reads the operand's storage, not a copy)
+    inp2 = inp.tensor().clone()
+    inp.tensor().copy_(pp.randn_SE3(5000, dtype=torch.float64, device=DEV).tensor())
+    net.pose.data.copy_(init.tensor())
+    del opt.loss
+    l4 = float(opt.step(inp))
+    net2 = InvNet(init.clone())
+    opt2 = pp.optim.LM(net2, strategy=pp.optim.strategy.TrustRegion(radius=1e4))
+    opt2.param_groups[0]['damping'] = 5e-5
+    assert l4 == pytest.approx(float(opt2.step(pp.SE3(inp.tensor().clone()))), rel=1e-10) and opt._device_lm is dev
+    inp.tensor().copy_(inp2)
     # the parameter's version counter moves with every in-place step (autograd would notice a stale saved tensor)
     v = net.pose._version
     opt.step(inp)

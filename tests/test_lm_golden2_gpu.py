@@ -76,9 +76,13 @@ def test_pose_graph_fp32_against_the_reference_fp64_trajectory():
     opt = pp.optim.LM(graph, solver=pp.optim.solver.PCG(tol=1e-7, maxiter=4000), strategy=pp.optim.strategy.TrustRegion(radius=1e4), min=1e-6)
     rec = run_steps(opt, ((T(G[f"{tag}/edges"], DEV), pp.SE3(T(G[f"{tag}/poses"], DEV).float())),), {}, 3)
     assert set(rec["kind"]) == {"fused:pgo"}
-    for a, b in zip(rec["loss"], G[f"{tag}/noweight/loss"]):
-        assert abs(a - b) <= 1e-5 * b, (rec["loss"], G[f"{tag}/noweight/loss"])
-    assert rec["damping"] == pytest.approx(list(G[f"{tag}/noweight/damping"][:3]), rel=1e-6)
+    ref = G[f"{tag}/noweight/loss"]
+    for k, (a, b) in enumerate(zip(rec["loss"], ref)):
+        assert abs(a - b) <= 1e-5 * b, (rec["loss"], ref)
+        # the accept / reject decision of a step compares two losses: it is the reference's wherever the reference's own
+        # step moved the loss by more than fp32 can resolve (the third step here changes it by 2e-7 of its value)
+        if k == 0 or abs(ref[k - 1] - b) > 1e-5 * b:
+            assert rec["damping"][k] == pytest.approx(G[f"{tag}/noweight/damping"][k], rel=1e-6), (k, rec["damping"])
 
 
 @pytest.mark.parametrize("structured", [False, True])
