@@ -25,6 +25,8 @@ from __future__ import annotations
 import torch
 
 from .. import _C
+from . import matrices as _mats
+from .matrices import *            # noqa: F401,F403  so3_Jl ... Sim3_Act4_Jacobian (reference operation.py:7-301)
 
 # (algebra width, group width)
 _GROUPS = {"so3": (3, 4), "se3": (6, 7), "sim3": (7, 8), "rxso3": (4, 5)}
@@ -139,8 +141,63 @@ def _fold_vmap(in_dims, args):
     return out
 
 
-def _make_bwd(qualname, kernel, in_widths, out_widths):
-    """Hidden Function running one backward kernel (non-differentiable, vmappable)."""
+def _pad_group(t, dg):
+    """a left-tangent gradient zero-padded to the group's embedding width (operation.py:336-337, 394-395, 849-851)"""
+    return torch.cat([t, t.new_zeros(tuple(t.shape[:-1]) + (dg - t.shape[-1],))], dim=-1)
+
+
+def _rowvec(g, Mx):
+    return (g.unsqueeze(-2) @ Mx).squeeze(-2)
+
+
+def _composed_rule(g, kind):
+    """The backward pass of one Function written as ``cotangent @ matrix(saved)`` with the differentiable helpers of
+    lietensor/matrices.py -- the reference's own formulation of its backward passes (operation.py:366-370, 389-395, 743-748,
+    846-852, 945-949, 1039-1044, 535-543, 646-653).  Only evaluated when the backward ITSELF has to be differentiated
+    (``_Bwd.backward``: create_graph=True, Hessians); first derivatives run the one-kernel backward."""
+    da, dg = _GROUPS[g]
+    G = _CAP[g]
+    H = _mats.__dict__
+    Jl, Jl_inv, little, Adj = H[g + "_Jl"], H[g + "_Jl_inv"], H[g + "_adj"], H[G + "_Adj"]
+    Matrix, Matrix4, ActJ, Act4J = H[G + "_Matrix"], H[G + "_Matrix4x4"], H[G + "_Act_Jacobian"], H[G + "_Act4_Jacobian"]
+    if kind == "exp":
+        return lambda x, c: (_rowvec(c[..., :da], Jl(x)),)
+    if kind == "log":
+        return lambda y, c: (_pad_group(_rowvec(c, Jl_inv(y)), dg),)
+    if kind == "inv":
+        return lambda Y, c: (_pad_group(-_rowvec(c[..., :da], Adj(Y)), dg),)
+    if kind == "mul":
+        return lambda X, c: (_pad_group(c[..., :da], dg), _pad_group(_rowvec(c[..., :da], Adj(X)), dg))
+    if kind == "act":
+        return lambda X, out, c: (_pad_group(_rowvec(c, ActJ(out)), dg), _rowvec(c, Matrix(X)[..., :3, :3]))
+    if kind == "act4":
+        return lambda X, out, c: (_pad_group(_rowvec(c, Act4J(out)), dg), _rowvec(c, Matrix4(X)))
+    if kind == "adj":
+        return lambda X, out, c: (_pad_group(-_rowvec(c, little(out)), dg), _rowvec(c, Adj(X)))
+    if kind == "adjt":
+        def rule(X, a, c):
+            ga = (Adj(X) @ c.unsqueeze(-1)).squeeze(-1)
+            return _pad_group(-_rowvec(a, little(ga)), dg), ga
+        return rule
+    raise KeyError(kind)
+
+
+def _grad_of(forward):
+    """composed backward of an op given as a differentiable torch composition ``forward(*inputs)``: its vector-Jacobian
+    product by autograd, itself differentiable"""
+    def rule(*args):
+        *ins, c = args
+        with torch.enable_grad():
+            ins = [t if t.requires_grad else t.detach().requires_grad_(True) for t in ins]
+            out = forward(*ins)
+            return torch.autograd.grad([out], ins, [c], create_graph=True, allow_unused=True)
+    return rule
+
+
+def _make_bwd(qualname, kernel, in_widths, out_widths, composed=None):
+    """Hidden Function running one backward kernel (vmappable).  Differentiating it -- double backward through the Lie op
+    it belongs to -- re-evaluates the same backward as a differentiable torch composition (``composed``) and takes autograd's
+    vector-Jacobian product of that (the reference's backward passes ARE such compositions: operation.py:366-370 etc.)."""
     single = len(out_widths) == 1
 
     class _Bwd(torch.autograd.Function):
@@ -151,15 +208,21 @@ def _make_bwd(qualname, kernel, in_widths, out_widths):
 
         @staticmethod
         def setup_context(ctx, inputs, output):
-            return
+            ctx.save_for_backward(*inputs)
 
         @staticmethod
         def backward(ctx, *grads):
-            raise NotImplementedError(
-                f"{qualname}: double backward through the HIP Lie-group kernels is not supported (create_graph=True, Hessians, "
-                f"modjac(create_graph=True)): their backward passes are single kernels, not compositions of differentiable "
-                f"torch ops as in the reference (pypose/lietensor/operation.py).  First derivatives, vmap and "
-                f"jacobian(vectorize=True) are.")
+            if composed is None:
+                raise NotImplementedError(f"{qualname}: double backward is not implemented for this op")
+            with torch.enable_grad():
+                ins = [t.detach().requires_grad_(True) for t in ctx.saved_tensors]
+                outs = composed(*ins)
+                pairs = [(o, c) for o, c in zip(outs, grads) if c is not None and o is not None and o.requires_grad]
+                if not pairs:
+                    return tuple(None for _ in ins)
+                got = torch.autograd.grad([o for o, _ in pairs], ins, [c for _, c in pairs], create_graph=torch.is_grad_enabled(),
+                                          allow_unused=True)
+            return tuple(got)
 
         @staticmethod
         def vmap(info, in_dims, *ins):
@@ -185,7 +248,7 @@ def _make_fwd(clsname, g, kind, doc):
     }
     fin, fout, bin_, bout, reads = table[kind]
     fwd_kernel, bwd_kernel = f"{g}_{kind}_fwd", f"{g}_{kind}_bwd"
-    Bwd = _make_bwd(clsname + "_Bwd", bwd_kernel, bin_, bout)
+    Bwd = _make_bwd(clsname + "_Bwd", bwd_kernel, bin_, bout, _composed_rule(g, kind))
 
     class _Fn(torch.autograd.Function):
         __doc__ = doc
@@ -261,7 +324,10 @@ def _make_jinvp(g):
     da, dg = _GROUPS[g]
     kernel = f"{g}_jinvp_fwd"
     # one kernel: forward-mode sweeps through Jl_inv(Log X) p, then <Group>_Log's backward (lie_math.h)
-    Bwd = _make_bwd(_CAP[g] + "_Jinvp_Bwd", f"{g}_jinvp_bwd", (dg, da, da), (dg, da))
+    def composed_forward(X, p):        # Jl_inv(Log X) p (lietensor.py:257-264 ...), through the differentiable Log Function
+        log = globals()[_CAP[g] + "_Log"]
+        return (_mats.__dict__[g + "_Jl_inv"](log.apply(X)) @ p.unsqueeze(-1)).squeeze(-1)
+    Bwd = _make_bwd(_CAP[g] + "_Jinvp_Bwd", f"{g}_jinvp_bwd", (dg, da, da), (dg, da), _grad_of(composed_forward))
 
     class _Jinvp(torch.autograd.Function):
         @staticmethod
@@ -287,7 +353,7 @@ def _make_jinvp(g):
 SO3_Jinvp, SE3_Jinvp, Sim3_Jinvp, RxSO3_Jinvp = (_make_jinvp(g) for g in ("so3", "se3", "sim3", "rxso3"))
 
 
-_so3_Jr_Bwd = _make_bwd("so3_Jr_Bwd", "so3_jr_bwd", (3, 9), (3,))
+_so3_Jr_Bwd = _make_bwd("so3_Jr_Bwd", "so3_jr_bwd", (3, 9), (3,), _grad_of(lambda x: _mats.so3_Jl(-x).flatten(-2)))
 
 
 class so3_Jr(torch.autograd.Function):
@@ -310,6 +376,9 @@ class so3_Jr(torch.autograd.Function):
     @staticmethod
     def vmap(info, in_dims, x):
         return so3_Jr.apply(*_fold_vmap(in_dims, (x,))), 0
+
+
+__all_helpers__ = list(_mats.__all__)
 
 
 def broadcast_inputs(x, y):

@@ -530,7 +530,7 @@ class DeviceLM:
             dict.__setitem__(pg, 'down', st[_ST_DOWN])
         opt.__dict__['_reject_count'] = int(st[_ST_REJECTS])
         opt.__dict__['_trials'] = int(st[_ST_TRIALS])
-        if opt.loss is self.last_loss:
+        if opt.__dict__.get('loss') is self.last_loss and self.last_loss is not None:
             opt._host_loss = (opt.loss, st[_ST_LOSS])
         if st[_ST_FAILED]:
             print('Cholesky decomposition failed. Check your matrix (may not be positive-definite)',

