@@ -43,7 +43,8 @@ class _Dispatch:
 
     def apply(self, *args):
         t = args[0]
-        if self._force or (t.is_cuda and t.dtype in (torch.float32, torch.float64)):
+        if self._force or ((t.is_cuda or t.device.type == "meta") and t.dtype in (torch.float32, torch.float64)):
+            # (`meta`: results of a dry trace of the model, optim/fused.py DryTracer -- the op is recorded, nothing runs)
             return self._ours.apply(*args)
         return self._theirs.apply(*args)
 
@@ -58,6 +59,18 @@ def _to_ours(t):
     if t is None or lt is None or isinstance(t, L.LieTensor):
         return t
     return L._wrap(torch.Tensor.as_subclass(t, torch.Tensor), getattr(L, type(lt).__name__.replace("Type", "_type")))
+
+
+def _ours_cached(module, slot, t):
+    """``_to_ours(t)``, the same object for the same source object (the fused route caches what it derives from the initial
+    state -- r0^-1, broadcast copies -- by object identity + version)"""
+    cache = module.__dict__.setdefault('_pplie_ours', {})
+    hit = cache.get(slot)
+    if hit is not None and hit[0] is t:
+        return hit[1]
+    out = _to_ours(t)
+    cache[slot] = (t, out)
+    return out
 
 
 def _to_theirs(pypose, t):
@@ -146,9 +159,9 @@ def _activate_imu(pypose):
         if not Ours._fused_ok(self, c(dt), c(gyro), c(acc), c(rot) if rot is not None else None, st):
             return orig(self, dt, gyro, acc, rot=rot, gyro_cov=gyro_cov, acc_cov=acc_cov, init_state=init_state)
         mine = dict(st)
-        mine['rot'] = _to_ours(st['rot'])
+        mine['rot'] = _ours_cached(self, 'rot', st['rot'])
         if self.prop_cov:
-            mine['Rij'] = _to_ours(st['Rij'] if 'Rij' in st else self.Rij)
+            mine['Rij'] = _ours_cached(self, 'Rij', st['Rij'] if 'Rij' in st else self.Rij)
         out = Ours.forward(self, dt, gyro, acc, rot=_to_ours(rot), gyro_cov=gyro_cov, acc_cov=acc_cov, init_state=mine)
         if not self.reset:                        # the state the module carries to the next call, in the reference's own types
             self.rot = _to_theirs(pypose, self.rot)

@@ -15,12 +15,20 @@
 //         rho_k = r_k.z_k (exact),  |r_k|^2 (exact; the stop test, BEFORE the update, where the reference's CG tests it:
 //         pypose/optim/solver.py:319),  alpha = rho_k / p.q,  rho_{k+1} = rho_k - 2 alpha q.z + alpha^2 q.Binv q,  beta.
 //     (rho_{k+1} from node-local products is only used for beta; the next exchange replaces it by the exact r.z.)
-//   * each lane owns ONE (node, component) for the whole solve: x, r, z, p, q and its rows of D and Binv live in registers;
-//     per iteration a lane reads its rows of the off-diagonal blocks (L1/L2-resident) and its neighbours' p rows.
+//   * each lane owns ONE (node, component) for the whole solve: x, r, z, p, q and its parts of D and Binv live in registers;
+//     the workgroup's slice of the off-diagonal blocks (the incidences of its nodes: contiguous, incidence order is node
+//     order) and their neighbour indices are staged into LDS once, transposed, and read from there in every iteration.
+//   * the SpMV is organised by COLUMNS: lane (node, j) fetches component j of every neighbour's p -- one tagged load per
+//     incidence, all of a node's (up to 16) in flight together, none for absent incidences -- multiplies it into column j
+//     of the block (six contiguous LDS words) and accumulates the node's whole q row; the M lanes' partial rows are then
+//     summed through a per-wave LDS transpose.  (Measured on MI355X, tools/micro/pingpong.hip: a hand-off between two
+//     workgroups costs 0.3-0.5 us and an all-gather over 256 workgroups 2.4 us -- the 15 us of the round-2 iteration and the
+//     11 us of this file's first version were mostly the walk over the incidence list: dependent round trips four
+//     incidences at a time, then six cross-lane shuffles per incidence.)
 //
-// The exchange itself is the tagged all-gather of gridsync.h (one row of partial sums per workgroup, two tables alternating
-// with the iteration's parity, polled by one wave per quantity); every workgroup adds the rows up in the same order, so all
-// of them hold the same alpha / beta / |r|^2 bits and take the same exit.
+// The exchange itself is a tagged all-gather (one row of partial sums per workgroup, two tables alternating with the
+// iteration's parity, polled by one wave per quantity); every workgroup adds the rows up in the same order, so all of them
+// hold the same alpha / beta / |r|^2 bits and take the same exit.  Two workgroup barriers per iteration.
 #include "rowmap.h"
 #include "gridsync.h"
 
@@ -30,28 +38,6 @@ constexpr int kPersistGridMax = 256;      // = PPLIE_PCG_PERSIST_GRID: rows of t
 constexpr int kPersistBlock = 1024;       // 16 waves per workgroup
 constexpr int kPersistQ = 5;              // quantities per exchange: p.q, q.z, q.Binv q, r.z, r.r
 constexpr int kPersistSlots = 8;          // table row = 8 quantity slots (PPLIE_PCG_PERSIST_SLOTS)
-
-// Q workgroup totals with one pair of barriers (valid in thread 0)
-template <class T, int Q, int BLOCK> __device__ __forceinline__ void wg_totals(T* v) {
-  __shared__ T part[Q][BLOCK / 64];
-#pragma unroll
-  for (int q = 0; q < Q; ++q) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v[q] += __shfl_down(v[q], off, 64);
-    if ((threadIdx.x & 63) == 0) part[q][threadIdx.x >> 6] = v[q];
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-#pragma unroll
-    for (int q = 0; q < Q; ++q) {
-      T s = T(0);
-#pragma unroll
-      for (int w = 0; w < BLOCK / 64; ++w) s += part[q][w];
-      v[q] = s;
-    }
-  }
-  __syncthreads();
-}
 
 // one value as NW tagged words
 template <class T> __device__ __forceinline__ void put_value(u64* dst, T v, unsigned tag) {
@@ -75,92 +61,45 @@ template <class T> __device__ __forceinline__ T get_value(const u64* src, unsign
   return out;
 }
 
-// Sums of Q quantities over `rows` table rows; wave q polls quantity q (4 rows per lane at 256 rows, all loads of a round in
-// flight together), the rows are added in a fixed order.  Every thread must call it; false on a timeout.
-template <class T, int Q> __device__ __forceinline__ bool gather_rows(const u64* tab, int rows, unsigned tag, T out[Q]) {
-  constexpr int NW = sizeof(T) / 4, RW = kPersistSlots * NW;
-  __shared__ T tot_sh[Q];
-  __shared__ int bad_sh;
-  if (threadIdx.x == 0) bad_sh = 0;
-  __syncthreads();
-  const int wq = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  if (wq < Q) {
-    T a = T(0);
-    bool all = true;
-    for (int base = 0; base < rows; base += 256) {
-      T v[4];
-      bool done[4];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) { done[k] = base + lane + 64 * k >= rows; v[k] = T(0); }
-      for (long spin = 0; spin < (1L << 20); ++spin) {
-        bool pending = false;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          if (!done[k]) {
-            bool ok = true;
-            const T t = get_value<T>(tab + (size_t)(base + lane + 64 * k) * RW + wq * NW, tag, ok);
-            if (ok) { v[k] = t; done[k] = true; } else pending = true;
-          }
-        }
-        if (!pending) break;
-        __builtin_amdgcn_s_sleep(1);
-      }
-#pragma unroll
-      for (int k = 0; k < 4; ++k) { all = all && done[k]; a += v[k]; }
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off, 64);
-    if (lane == 0) tot_sh[wq] = a;
-    if (!__all(all) && lane == 0) bad_sh = 1;
-  }
-  __syncthreads();
-#pragma unroll
-  for (int q = 0; q < Q; ++q) out[q] = tot_sh[q];
-  const bool ok = bad_sh == 0;
-  __syncthreads();
-  return ok;
-}
-
-
-// q_i += sum over this lane's incidences of (row i of the off-diagonal block) . (the neighbour's p row).  A lane fetches ONE
-// element of each neighbour row -- its own component -- as a tagged word and the node's M lanes trade them by shuffle.  CH
-// incidences per round: every tagged load of a round is in flight before the first is looked at, so a node of degree <= CH
-// costs ONE memory round trip per iteration (the round-2 kernel walked the list four at a time, each round a chain of two
-// dependent trips: neighbour index, then its row -- that chain, not the grid exchange, was most of its 15 us).  The loop is
-// wave-uniform (runs to the largest degree in the wave, absent incidences masked) so the shuffles sit in uniform control
-// flow.  `hb` / `nb`: this lane's first block / neighbour index -- in LDS when the workgroup's slice was staged there
-// (LDS = true), else in global memory.
+// a[0..M) += sum over this lane's incidences c of (column i of block c) * (component i of the neighbour's p).  `h`: the first
+// block's column i (element j at h[c * cs + j * js]), `nb`: the neighbour indices.  CH incidences per round: every tagged
+// load of a round is in flight before the first is looked at; absent incidences (c >= deg) load nothing (exec-masked).
 template <class T, int M, int CH, class HP, class NP>
-__device__ __forceinline__ T spmv_rows(HP hb, NP nb, int deg, int maxdeg, int sub, int i, const u64* pin, unsigned own, unsigned tag,
-                                       bool& stale) {
+__device__ __forceinline__ void spmv_cols(T* a, HP h, int cs, int js, NP nb, int deg, int maxdeg, int i, const u64* pin, unsigned tag,
+                                          bool& stale) {
   constexpr int NW = sizeof(T) / 4;
-  T acc = T(0);
   for (int c0 = 0; c0 < maxdeg; c0 += CH) {
-    unsigned po[CH];                       // (word index in the table: < 2^32 for every graph the persistent solve takes)
     T pv[CH];
-    // an absent incidence reads this lane's OWN element of p (always current: no extra wait) against a zeroed block row:
-    // every load is unconditional, no divergent branches around them
 #pragma unroll
-    for (int q = 0; q < CH; ++q) po[q] = c0 + q < deg ? (unsigned)((nb[c0 + q] * M + i) * NW) : own;
+    for (int q = 0; q < CH; ++q) pv[q] = T(0);
     for (long spin = 0;; ++spin) {
       bool ok = true;
 #pragma unroll
-      for (int q = 0; q < CH; ++q) pv[q] = get_value<T>(pin + po[q], tag, ok);
+      for (int q = 0; q < CH; ++q)
+        if (c0 + q < deg) pv[q] = get_value<T>(pin + (unsigned)((nb[c0 + q] * M + i) * NW), tag, ok);
       if (__all(ok)) break;
       if (spin >= (1L << 20)) { stale = true; break; }
       __builtin_amdgcn_s_sleep(1);
     }
 #pragma unroll
     for (int q = 0; q < CH; ++q) {
-      const bool valid = c0 + q < deg;
-      const T mask = valid ? T(1) : T(0);
-      const int c = valid ? c0 + q : 0;
+      if (c0 + q < maxdeg) {                                                    // (wave-uniform)
+        const bool valid = c0 + q < deg;
+        const int c = valid ? c0 + q : 0;
 #pragma unroll
-      for (int j = 0; j < M; ++j) acc += mask * hb[(size_t)c * M * M + j] * __shfl(pv[q], sub * M + j, 64);
+        for (int j = 0; j < M; ++j) a[j] += (valid ? h[(size_t)c * cs + j * js] : T(0)) * pv[q];
+      }
     }
   }
-  return acc;
 }
+
+// static LDS of the exchange, double-buffered by the iteration's parity so that one barrier separates "written" from "read"
+// and the next iteration's writes cannot overtake this one's reads
+template <class T> struct PersistShared {
+  T wave_part[2][kPersistQ][kPersistBlock / 64];   // per-wave partial sums
+  T total[2][kPersistQ];                           // the all-gathered sums
+  int bad[2];                                      // a poll timed out / a lane saw a stale p for too long
+};
 
 template <class T, int M>
 __global__ void __launch_bounds__(kPersistBlock)
@@ -170,6 +109,7 @@ pcg_persist_kernel(const int* __restrict__ ptr, const int* __restrict__ other, c
                    u64* ptag /* [2][N * M values as tagged words] */, T* __restrict__ rr_hist, T* info /* [4] */, int* it_out,
                    T tol2, int maxiter, int cap, int64_t N, int lds_bytes) {
   extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
+  __shared__ PersistShared<T> sh;
   constexpr int CH = sizeof(T) == 4 ? 16 : 8;   // incidences per round of tagged loads
   constexpr int NPW = 64 / M;              // nodes per wave: M lanes per node
   constexpr int WV = kPersistBlock / 64;   // waves per workgroup
@@ -182,21 +122,20 @@ pcg_persist_kernel(const int* __restrict__ ptr, const int* __restrict__ other, c
   const size_t NM = (size_t)N * M * NW;
 
   // ---- this lane's (node, component) for the whole solve
-  T dr[M], br[M];                          // rows i of the damped diagonal block and of its inverse
+  T dc[M], br[M];                          // COLUMN i of the damped diagonal block, ROW i of its inverse
   T xe = T(0), re = T(0), ze = T(0), pe = T(0);
   int beg = 0, deg = 0;
+#pragma unroll
+  for (int j = 0; j < M; ++j) { dc[j] = T(0); br[j] = T(0); }
   if (act) {
 #pragma unroll
-    for (int j = 0; j < M; ++j) { dr[j] = D[(n * M + i) * M + j]; br[j] = Binv[(n * M + i) * M + j]; }
+    for (int j = 0; j < M; ++j) { dc[j] = D[(n * M + j) * M + i]; br[j] = Binv[(n * M + i) * M + j]; }
     re = r[n * M + i];                     // pplie_pcg_prepare left r = -g, z = Binv r (= p_0), x = 0
     ze = z[n * M + i];
     pe = ze;
     beg = ptr[n];
     deg = ptr[n + 1] - beg;
     put_value<T>(ptag + (size_t)(n * M + i) * NW, pe, 1u);           // p_k carries tag k + 1, in table k & 1
-  } else {
-#pragma unroll
-    for (int j = 0; j < M; ++j) { dr[j] = T(0); br[j] = T(0); }
   }
   int maxdeg = deg;                        // largest degree among this wave's nodes
 #pragma unroll
@@ -204,54 +143,107 @@ pcg_persist_kernel(const int* __restrict__ ptr, const int* __restrict__ other, c
     const int o = __shfl_xor(maxdeg, off, 64);
     maxdeg = o > maxdeg ? o : maxdeg;
   }
-  // ---- this workgroup's slice of the matrix -- the off-diagonal blocks of its nodes' incidences (contiguous: incidence
-  // order is node order) and their neighbour indices -- is staged into LDS once and read from there in every iteration;
-  // a slice that does not fit (dense neighbourhoods, few workgroups) stays in global memory (L2)
+  // ---- LDS: [ per-wave transpose pads | staged blocks (transposed) | staged neighbour indices ]
+  T* tr_l = reinterpret_cast<T*>(dyn_lds) + (size_t)w * NPW * M * M;          // this wave's pad: [NPW][M (source lane j)][M (row)]
+  constexpr size_t kPadBytes = (size_t)WV * NPW * M * M * sizeof(T);
   const int c_lo = ptr[n0], c_cnt = ptr[n1] - c_lo;
-  const bool in_lds = (size_t)c_cnt * (M * M * sizeof(T) + 4) <= (size_t)lds_bytes;
-  T* hb_l = reinterpret_cast<T*>(dyn_lds);
-  unsigned* nb_l = reinterpret_cast<unsigned*>(dyn_lds + (size_t)c_cnt * M * M * sizeof(T));
+  const bool in_lds = kPadBytes + (size_t)c_cnt * (M * M * sizeof(T) + 4) <= (size_t)lds_bytes;
+  T* hb_l = reinterpret_cast<T*>(dyn_lds + kPadBytes);
+  unsigned* nb_l = reinterpret_cast<unsigned*>(dyn_lds + kPadBytes + (size_t)c_cnt * M * M * sizeof(T));
   if (in_lds) {
     const T* src = HB + (size_t)c_lo * M * M;
-    for (int e = threadIdx.x; e < c_cnt * M * M; e += kPersistBlock) hb_l[e] = src[e];
+    for (int e = threadIdx.x; e < c_cnt * M * M; e += kPersistBlock) {
+      const int c = e / (M * M), ij = e % (M * M);
+      hb_l[c * M * M + (ij % M) * M + ij / M] = src[e];              // transposed: [c][j][i] = H_c[i][j]
+    }
     for (int e = threadIdx.x; e < c_cnt; e += kPersistBlock) nb_l[e] = (unsigned)other[c_lo + e];
   }
+  if (threadIdx.x == 0) { sh.bad[0] = 0; sh.bad[1] = 0; }
   __syncthreads();
-  const unsigned own = (unsigned)(((act ? n : n0) * M + (act ? i : 0)) * NW);     // (an idle lane watches the workgroup's first element)
   const int lbeg = act ? beg - c_lo : 0;
+
   T bn2 = T(0), rr = T(0);
   int k = 0, flag = 0;                     // flag: 1 converged, 2 NaN, 3 a workgroup never arrived, 0 iteration limit
   for (;; ++k) {
     const unsigned tag = (unsigned)k + 1u;
-    const u64* pin = ptag + (size_t)(k & 1) * NM;
-    // ---- q = A p on this lane's row: own block from the node's lanes, neighbours' rows from the tagged table
-    T acc = T(0);
-    bool stale = false;
+    const int par = k & 1;
+    const u64* pin = ptag + (size_t)par * NM;
+    // ---- q = A p.  This lane holds component i of its node's p: it contributes column i of every block.
+    T a[M];
 #pragma unroll
-    for (int j = 0; j < M; ++j) acc += dr[j] * __shfl(pe, sub * M + j, 64);
-    if (in_lds)
-      acc += spmv_rows<T, M, CH>(hb_l + ((size_t)lbeg * M + i) * M, nb_l + lbeg, deg, maxdeg, sub, i, pin, own, tag, stale);
-    else
-      acc += spmv_rows<T, M, CH>(HB + ((size_t)beg * M + i) * M, other + beg, deg, maxdeg, sub, i, pin, own, tag, stale);
+    for (int j = 0; j < M; ++j) a[j] = dc[j] * pe;
+    bool stale = false;
+    if (in_lds) spmv_cols<T, M, CH>(a, hb_l + ((size_t)lbeg * M + i) * M, M * M, 1, nb_l + lbeg, deg, maxdeg, i, pin, tag, stale);
+    else spmv_cols<T, M, CH>(a, HB + (size_t)beg * M * M + i, M * M, M, other + beg, deg, maxdeg, i, pin, tag, stale);
+    // the node's q row = sum of its M lanes' partial rows: through this wave's LDS pad (a wave's LDS accesses execute in order)
+    T acc = T(0);
+    if (sub < NPW) {
+#pragma unroll
+      for (int j = 0; j < M; ++j) tr_l[(sub * M + i) * M + j] = a[j];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (sub < NPW) {
+#pragma unroll
+      for (int j = 0; j < M; ++j) acc += tr_l[(sub * M + j) * M + i];
+    }
     T bq = T(0);
 #pragma unroll
     for (int j = 0; j < M; ++j) bq += br[j] * __shfl(acc, sub * M + j, 64);
+    // ---- partial sums: wave level, then one barrier, then thread 0 publishes the workgroup's row
     T v[kPersistQ] = {acc * pe, acc * ze, acc * bq, re * ze, re * re};
-    if (!act) {
 #pragma unroll
-      for (int q = 0; q < kPersistQ; ++q) v[q] = T(0);
-    }
-    wg_totals<T, kPersistQ, kPersistBlock>(v);
-    u64* row = part + ((size_t)(k & 1) * kPersistGridMax + blockIdx.x) * RW;
-    if (threadIdx.x == 0) {
+    for (int q = 0; q < kPersistQ; ++q) {
+      if (!act) v[q] = T(0);
 #pragma unroll
-      for (int q = 0; q < kPersistQ; ++q) put_value<T>(row + q * NW, v[q], tag);
+      for (int off = 32; off > 0; off >>= 1) v[q] += __shfl_down(v[q], off, 64);
+      if (lane == 0) sh.wave_part[par][q][w] = v[q];
     }
-    T tot[kPersistQ];
-    const bool arrived = gather_rows<T, kPersistQ>(part + (size_t)(k & 1) * kPersistGridMax * RW, gridDim.x, tag, tot);
-    if (__syncthreads_or((int)stale) || !arrived) { flag = 3; break; }
-    const T pq = tot[0], qz = tot[1], qmq = tot[2], rho = tot[3];
-    rr = tot[4];
+    if (stale) sh.bad[par] = 1;
+    __syncthreads();                                                             // barrier 1
+    if (threadIdx.x < kPersistQ) {
+      T sum = T(0);
+#pragma unroll
+      for (int ww = 0; ww < WV; ++ww) sum += sh.wave_part[par][threadIdx.x][ww];
+      put_value<T>(part + ((size_t)par * kPersistGridMax + blockIdx.x) * RW + threadIdx.x * NW, sum, tag);
+    }
+    // ---- all-gather: wave q polls quantity q of every workgroup's row (all loads of a round in flight together) and adds
+    // them up in row order -- the same order, hence the same bits, in every workgroup
+    if (w < kPersistQ) {
+      const u64* tab = part + (size_t)par * kPersistGridMax * RW;
+      T sum = T(0);
+      bool all = true;
+      for (int base = 0; base < (int)gridDim.x; base += 256) {
+        T val[4];
+        bool done[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { done[q] = base + lane + 64 * q >= (int)gridDim.x; val[q] = T(0); }
+        for (long spin = 0; spin < (1L << 20); ++spin) {
+          bool pending = false;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            if (!done[q]) {
+              bool ok = true;
+              const T t = get_value<T>(tab + (size_t)(base + lane + 64 * q) * RW + w * NW, tag, ok);
+              if (ok) { val[q] = t; done[q] = true; } else pending = true;
+            }
+          }
+          if (!pending) break;
+          __builtin_amdgcn_s_sleep(1);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { all = all && done[q]; sum += val[q]; }
+      }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+      if (lane == 0) sh.total[par][w] = sum;
+      if (!__all(all) && lane == 0) sh.bad[par] = 1;
+    }
+    __syncthreads();                                                             // barrier 2
+    const T pq = sh.total[par][0], qz = sh.total[par][1], qmq = sh.total[par][2], rho = sh.total[par][3];
+    rr = sh.total[par][4];
+    if (sh.bad[par]) { flag = 3; break; }
     if (k == 0) bn2 = rr;
     if (blockIdx.x == 0 && threadIdx.x == 0 && k < cap) rr_hist[k] = rr;
     if (!(rr == rr)) { flag = 2; break; }
@@ -316,7 +308,7 @@ int pcg_persist(const void* ptr, const void* other, const void* HB, const void* 
   {                                                                                                                            \
     int lds_bytes = 0;                                                                                                         \
     const int resident = persist_capacity<T, MM>(lds_bytes);                                                                   \
-    if (resident <= 0) return PPLIE_ECAPACITY;                                                                                 \
+    if (resident <= 0 || (size_t)lds_bytes < (size_t)(kPersistBlock / 64) * (64 / MM) * MM * MM * sizeof(T)) return PPLIE_ECAPACITY; \
     if (grid > resident) grid = resident;                         /* fewer CUs than asked for: every workgroup must be resident */ \
     if (grid > N) grid = (int)N;                                                                                               \
     const int64_t per_wg = (kPersistBlock / 64) * (64 / MM);     /* one lane per (node, component): nodes one workgroup holds */ \

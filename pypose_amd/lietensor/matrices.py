@@ -46,12 +46,13 @@ def _kernel_route(*ts):
         and not (torch.is_grad_enabled() and any(t.requires_grad for t in ts)) and not torch._C._are_functorch_transforms_active()
 
 
-def _rows_from(kernel, x, in_widths, width_g, n_rows, take):
-    """[..., n_rows, take]: row i = kernel(x, e_i)[:take] -- the row-vector products the backward kernels compute"""
+def _rows_from(kernel, x, in_widths, out_width, n_rows, take):
+    """[..., n_rows, take]: row i = kernel(x, e_i)[:take] -- the row-vector products the backward kernels compute
+    (``in_widths`` = (saved operand, cotangent), ``out_width`` = what the kernel writes per row)"""
     from . import operation as _op
-    E = torch.zeros((n_rows, width_g), dtype=x.dtype, device=x.device)
+    E = torch.zeros((n_rows, in_widths[1]), dtype=x.dtype, device=x.device)
     E[:, :n_rows] = torch.eye(n_rows, dtype=x.dtype, device=x.device)
-    out = _op._launch(kernel, (x.unsqueeze(-2), E), in_widths, (in_widths[0],))[0]
+    out = _op._launch(kernel, (x.unsqueeze(-2), E), in_widths, (out_width,))[0]
     return out[..., :take]
 
 
@@ -102,7 +103,7 @@ def _th2(phi):
 def so3_Jl(x):
     x = _plain(x)
     if _kernel_route(x):
-        return _rows_from("so3_exp_bwd", x, (3, 4), 4, 3, 3)
+        return _rows_from("so3_exp_bwd", x, (3, 4), 3, 3, 3)
     K = vec2skew(x)
     B, C = _coef_BC(_th2(x))
     return _eye(3, x) + B * K + C * (K @ K)
@@ -111,7 +112,7 @@ def so3_Jl(x):
 def so3_Jl_inv(x):
     x = _plain(x)
     if _kernel_route(x):
-        return _rows_from("so3_log_bwd", x, (3, 3), 3, 3, 3)
+        return _rows_from("so3_log_bwd", x, (3, 3), 4, 3, 3)
     K = vec2skew(x)
     return _eye(3, x) - 0.5 * K + _coef_F(_th2(x)) * (K @ K)
 
@@ -138,7 +139,7 @@ def _blocks(rows):
 def se3_Jl(x):
     x = _plain(x)
     if _kernel_route(x):
-        return _rows_from("se3_exp_bwd", x, (6, 7), 7, 6, 6)
+        return _rows_from("se3_exp_bwd", x, (6, 7), 6, 6, 6)
     J = so3_Jl(x[..., 3:])
     return _blocks([[J, calcQ(x)], [torch.zeros_like(J), J]])
 
@@ -146,7 +147,7 @@ def se3_Jl(x):
 def se3_Jl_inv(x):
     x = _plain(x)
     if _kernel_route(x):
-        return _rows_from("se3_log_bwd", x, (6, 6), 6, 6, 6)
+        return _rows_from("se3_log_bwd", x, (6, 6), 7, 6, 6)
     Ji = so3_Jl_inv(x[..., 3:])
     return _blocks([[Ji, -Ji @ calcQ(x) @ Ji], [torch.zeros_like(Ji), Ji]])
 
@@ -227,7 +228,7 @@ def sim3_Jl(x):
     """the reference's truncated series in the 7x7 adjoint (operation.py:159-165): sum_{k<=5} Xi^k / (k+1)!"""
     x = _plain(x)
     if _kernel_route(x):
-        return _rows_from("sim3_exp_bwd", x, (7, 8), 8, 7, 7)
+        return _rows_from("sim3_exp_bwd", x, (7, 8), 7, 7, 7)
     Xi = sim3_adj(x)
     Xi2 = Xi @ Xi
     Xi4 = Xi2 @ Xi2
@@ -238,7 +239,7 @@ def sim3_Jl_inv(x):
     """I - Xi/2 + Xi^2/12 - Xi^4/720 (operation.py:168-172)"""
     x = _plain(x)
     if _kernel_route(x):
-        return _rows_from("sim3_log_bwd", x, (7, 7), 7, 7, 7)
+        return _rows_from("sim3_log_bwd", x, (7, 7), 8, 7, 7)
     Xi = sim3_adj(x)
     Xi2 = Xi @ Xi
     return _eye(7, x) - Xi / 2 + Xi2 / 12 - (Xi2 @ Xi2) / 720

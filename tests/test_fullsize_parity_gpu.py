@@ -44,9 +44,12 @@ def test_pgo_10k_40k_trajectory_equals_reference_restatement(pgo10k, dtype, ltol
     np.testing.assert_allclose(rec["loss"], ref["loss"], rtol=ltol)
     np.testing.assert_allclose(rec["damping"], ref["damping"], rtol=1e-12)
     assert rec["reject"] == ref["reject"]
-    got = graph.nodes.detach().tensor().double().cpu()
-    # q and -q are the same rotation; compare through the relative transform
-    err = (pp.SE3(got.to(DEV)).Inv() @ pp.SE3(ref["final"].to(DEV))).Log().tensor().abs().max().item()
+    # what the problem determines: the relative pose across every edge (a pose graph without a prior has a free global rigid
+    # motion, held only by the damping; absolute fp32 coordinates of a 10^4-node chain carry ~|t| eps sqrt(N) on top)
+    e = edges.to(DEV)
+    rel_of = lambda nodes: pp.SE3(nodes[e[:, 0]]).Inv() @ pp.SE3(nodes[e[:, 1]])
+    got, want = graph.nodes.detach().tensor().double(), ref["final"].to(DEV)
+    err = (rel_of(got).Inv() @ rel_of(want)).Log().tensor().abs().max().item()
     assert err <= ptol, err
 
 
