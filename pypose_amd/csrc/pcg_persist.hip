@@ -29,6 +29,7 @@
 // The exchange itself is a tagged all-gather (one row of partial sums per workgroup, two tables alternating with the
 // iteration's parity, polled by one wave per quantity); every workgroup adds the rows up in the same order, so all of them
 // hold the same alpha / beta / |r|^2 bits and take the same exit.  Two workgroup barriers per iteration.
+#include <cstdlib>
 #include "rowmap.h"
 #include "gridsync.h"
 
@@ -98,10 +99,123 @@ __device__ __forceinline__ void spmv_cols(T* a, HP h, int cs, int js, NP nb, int
 template <class T> struct PersistShared {
   T wave_part[2][kPersistQ][kPersistBlock / 64];   // per-wave partial sums
   T total[2][kPersistQ];                           // the all-gathered sums
-  int bad[2];                                      // a poll timed out / a lane saw a stale p for too long
+  int bad[2];                                      // a poll timed out / a lane saw a stale vector element for too long
 };
 
-template <class T, int M>
+// per-lane constants of the solve: which (node, component) this lane owns and where its matrix slice sits
+template <class T, int M> struct PersistLane {
+  T dc[M], br[M];            // COLUMN i of the damped diagonal block, ROW i of its inverse
+  int64_t n;                 // node
+  int sub, i, beg, deg, lbeg, maxdeg;
+  bool act, in_lds;
+  T* tr;                     // this wave's transpose pad
+  const T* hb_l;             // staged blocks (transposed), neighbour indices
+  const unsigned* nb_l;
+};
+
+// q_i of this lane's node for the vector whose component i this lane holds (`ve`) and whose other elements are read from
+// the tagged table `pin`:  diagonal block column, neighbour columns (spmv_cols), then the sum over the node's M lanes
+template <class T, int M, int CH>
+__device__ __forceinline__ T node_matvec(const PersistLane<T, M>& L, T ve, const T* HB, const int* other, const u64* pin, unsigned tag,
+                                         bool& stale) {
+  constexpr int NPW = 64 / M;
+  T a[M];
+#pragma unroll
+  for (int j = 0; j < M; ++j) a[j] = L.dc[j] * ve;
+  if (L.in_lds) spmv_cols<T, M, CH>(a, L.hb_l + ((size_t)L.lbeg * M + L.i) * M, M * M, 1, L.nb_l + L.lbeg, L.deg, L.maxdeg, L.i, pin, tag, stale);
+  else spmv_cols<T, M, CH>(a, HB + (size_t)L.beg * M * M + L.i, M * M, M, other + L.beg, L.deg, L.maxdeg, L.i, pin, tag, stale);
+  // the node's row = sum of its M lanes' partial rows: through this wave's LDS pad (a wave's LDS accesses execute in order)
+  T acc = T(0);
+  if (L.sub < NPW) {
+#pragma unroll
+    for (int j = 0; j < M; ++j) L.tr[(L.sub * M + L.i) * M + j] = a[j];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  if (L.sub < NPW) {
+#pragma unroll
+    for (int j = 0; j < M; ++j) acc += L.tr[(L.sub * M + j) * M + L.i];
+  }
+  __builtin_amdgcn_wave_barrier();                               // (the pad is rewritten by the next product)
+  return acc;
+}
+// (Binv v)_i from the node's lanes
+template <class T, int M> __device__ __forceinline__ T node_binv(const PersistLane<T, M>& L, T ve) {
+  T s = T(0);
+#pragma unroll
+  for (int j = 0; j < M; ++j) s += L.br[j] * __shfl(ve, L.sub * M + j, 64);
+  return s;
+}
+// wave-level sums of NQ quantities into the exchange's LDS (every lane calls; then ONE __syncthreads, then publish_row)
+template <class T, int NQ> __device__ __forceinline__ void post_wave_sums(PersistShared<T>& sh, int par, T* v, bool act, bool stale) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    if (!act) v[q] = T(0);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v[q] += __shfl_down(v[q], off, 64);
+    if (lane == 0) sh.wave_part[par][q][w] = v[q];
+  }
+  if (stale) sh.bad[par] = 1;
+}
+template <class T, int NQ> __device__ __forceinline__ void publish_row(PersistShared<T>& sh, int par, u64* part, unsigned tag) {
+  constexpr int NW = sizeof(T) / 4, RW = kPersistSlots * NW, WV = kPersistBlock / 64;
+  if (threadIdx.x < NQ) {
+    T sum = T(0);
+#pragma unroll
+    for (int ww = 0; ww < WV; ++ww) sum += sh.wave_part[par][threadIdx.x][ww];
+    put_value<T>(part + ((size_t)par * kPersistGridMax + blockIdx.x) * RW + threadIdx.x * NW, sum, tag);
+  }
+}
+// all-gather: wave q polls quantity q of every workgroup's row (all loads of a round in flight together) and adds them up in
+// row order -- the same order, hence the same bits, in every workgroup.  Then ONE __syncthreads; totals in sh.total[par].
+template <class T, int NQ> __device__ __forceinline__ void gather_rows(PersistShared<T>& sh, int par, const u64* part, unsigned tag) {
+  constexpr int NW = sizeof(T) / 4, RW = kPersistSlots * NW;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (w < NQ) {
+    const u64* tab = part + (size_t)par * kPersistGridMax * RW;
+    T sum = T(0);
+    bool all = true;
+    for (int base = 0; base < (int)gridDim.x; base += 256) {
+      T val[4];
+      bool done[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { done[q] = base + lane + 64 * q >= (int)gridDim.x; val[q] = T(0); }
+      for (long spin = 0; spin < (1L << 20); ++spin) {
+        bool pending = false;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          if (!done[q]) {
+            bool ok = true;
+            const T t = get_value<T>(tab + (size_t)(base + lane + 64 * q) * RW + w * NW, tag, ok);
+            if (ok) { val[q] = t; done[q] = true; } else pending = true;
+          }
+        }
+        if (!pending) break;
+        __builtin_amdgcn_s_sleep(1);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { all = all && done[q]; sum += val[q]; }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+    if (lane == 0) sh.total[par][w] = sum;
+    if (!__all(all) && lane == 0) sh.bad[par] = 1;
+  }
+}
+
+// PIPE = false: preconditioned CG as the reference writes it, one exchange per iteration (header comment).
+// PIPE = true:  the PIPELINED form of the same recurrence (Ghysels & Vanroose 2014, Alg. 4) -- identical iterates in exact
+//   arithmetic.  With  u = Binv r,  w = A u,  m = Binv w,  n = A m  and the auxiliary recurrences
+//       z = n + beta z,  q = m + beta q,  s = w + beta s,  p = u + beta p;   x += alpha p,  r -= alpha s,  u -= alpha q,  w -= alpha z
+//   the dot products of an iteration, gamma = r.u and delta = w.u (and |r|^2 for the stop test), depend only on vectors that
+//   exist BEFORE its matrix product: the partial sums are posted first and collected after the product, so the all-gather
+//   travels while the workgroup waits for its neighbours' vector elements and multiplies -- the two grid-wide dependencies
+//   of an iteration (measured 4 - 5 us each under load, tools/time_pcg_iter.py) overlap instead of adding up.  Its
+//   recurrences for u and w drift from Binv r and A u by O(eps * iterations): used for tolerances an fp32 / fp64 residual
+//   reaches with room to spare (the host selects it for tol >= 1e-5), the plain form otherwise.
+template <class T, int M, bool PIPE>
 __global__ void __launch_bounds__(kPersistBlock)
 pcg_persist_kernel(const int* __restrict__ ptr, const int* __restrict__ other, const T* __restrict__ HB, const T* __restrict__ D,
                    const T* __restrict__ Binv, T* __restrict__ x, const T* __restrict__ r, const T* __restrict__ z,
@@ -113,44 +227,48 @@ pcg_persist_kernel(const int* __restrict__ ptr, const int* __restrict__ other, c
   constexpr int CH = sizeof(T) == 4 ? 16 : 8;   // incidences per round of tagged loads
   constexpr int NPW = 64 / M;              // nodes per wave: M lanes per node
   constexpr int WV = kPersistBlock / 64;   // waves per workgroup
-  constexpr int NW = sizeof(T) / 4, RW = kPersistSlots * NW;
+  constexpr int NW = sizeof(T) / 4;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int sub = lane / M, i = lane % M;
   const int64_t n0 = N * blockIdx.x / gridDim.x, n1 = N * (blockIdx.x + 1) / gridDim.x;     // (host: n1 - n0 <= WV * NPW)
-  const int64_t n = n0 + w * NPW + sub;
-  const bool act = sub < NPW && n < n1;
   const size_t NM = (size_t)N * M * NW;
+  PersistLane<T, M> L;
+  L.sub = lane / M;
+  L.i = lane % M;
+  L.n = n0 + w * NPW + L.sub;
+  L.act = L.sub < NPW && L.n < n1;
+  const int64_t n = L.n;
+  const int i = L.i;
+  const bool act = L.act;
 
   // ---- this lane's (node, component) for the whole solve
-  T dc[M], br[M];                          // COLUMN i of the damped diagonal block, ROW i of its inverse
-  T xe = T(0), re = T(0), ze = T(0), pe = T(0);
-  int beg = 0, deg = 0;
+  T xe = T(0), re = T(0), ze = T(0);
+  L.beg = 0;
+  L.deg = 0;
 #pragma unroll
-  for (int j = 0; j < M; ++j) { dc[j] = T(0); br[j] = T(0); }
+  for (int j = 0; j < M; ++j) { L.dc[j] = T(0); L.br[j] = T(0); }
   if (act) {
 #pragma unroll
-    for (int j = 0; j < M; ++j) { dc[j] = D[(n * M + j) * M + i]; br[j] = Binv[(n * M + i) * M + j]; }
-    re = r[n * M + i];                     // pplie_pcg_prepare left r = -g, z = Binv r (= p_0), x = 0
+    for (int j = 0; j < M; ++j) { L.dc[j] = D[(n * M + j) * M + i]; L.br[j] = Binv[(n * M + i) * M + j]; }
+    re = r[n * M + i];                     // pplie_pcg_prepare left r = -g, z = Binv r, x = 0
     ze = z[n * M + i];
-    pe = ze;
-    beg = ptr[n];
-    deg = ptr[n + 1] - beg;
-    put_value<T>(ptag + (size_t)(n * M + i) * NW, pe, 1u);           // p_k carries tag k + 1, in table k & 1
+    L.beg = ptr[n];
+    L.deg = ptr[n + 1] - L.beg;
+    put_value<T>(ptag + (size_t)(n * M + i) * NW, ze, 1u);           // hand-off h carries tag h + 1, in table h & 1
   }
-  int maxdeg = deg;                        // largest degree among this wave's nodes
+  L.maxdeg = L.deg;                        // largest degree among this wave's nodes
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
-    const int o = __shfl_xor(maxdeg, off, 64);
-    maxdeg = o > maxdeg ? o : maxdeg;
+    const int o = __shfl_xor(L.maxdeg, off, 64);
+    L.maxdeg = o > L.maxdeg ? o : L.maxdeg;
   }
   // ---- LDS: [ per-wave transpose pads | staged blocks (transposed) | staged neighbour indices ]
-  T* tr_l = reinterpret_cast<T*>(dyn_lds) + (size_t)w * NPW * M * M;          // this wave's pad: [NPW][M (source lane j)][M (row)]
+  L.tr = reinterpret_cast<T*>(dyn_lds) + (size_t)w * NPW * M * M;             // this wave's pad: [NPW][M (source lane j)][M (row)]
   constexpr size_t kPadBytes = (size_t)WV * NPW * M * M * sizeof(T);
   const int c_lo = ptr[n0], c_cnt = ptr[n1] - c_lo;
-  const bool in_lds = kPadBytes + (size_t)c_cnt * (M * M * sizeof(T) + 4) <= (size_t)lds_bytes;
+  L.in_lds = kPadBytes + (size_t)c_cnt * (M * M * sizeof(T) + 4) <= (size_t)lds_bytes;
   T* hb_l = reinterpret_cast<T*>(dyn_lds + kPadBytes);
   unsigned* nb_l = reinterpret_cast<unsigned*>(dyn_lds + kPadBytes + (size_t)c_cnt * M * M * sizeof(T));
-  if (in_lds) {
+  if (L.in_lds) {
     const T* src = HB + (size_t)c_lo * M * M;
     for (int e = threadIdx.x; e < c_cnt * M * M; e += kPersistBlock) {
       const int c = e / (M * M), ij = e % (M * M);
@@ -158,110 +276,127 @@ pcg_persist_kernel(const int* __restrict__ ptr, const int* __restrict__ other, c
     }
     for (int e = threadIdx.x; e < c_cnt; e += kPersistBlock) nb_l[e] = (unsigned)other[c_lo + e];
   }
+  L.hb_l = hb_l;
+  L.nb_l = nb_l;
   if (threadIdx.x == 0) { sh.bad[0] = 0; sh.bad[1] = 0; }
   __syncthreads();
-  const int lbeg = act ? beg - c_lo : 0;
+  L.lbeg = act ? L.beg - c_lo : 0;
 
   T bn2 = T(0), rr = T(0);
   int k = 0, flag = 0;                     // flag: 1 converged, 2 NaN, 3 a workgroup never arrived, 0 iteration limit
-  for (;; ++k) {
-    const unsigned tag = (unsigned)k + 1u;
-    const int par = k & 1;
-    const u64* pin = ptag + (size_t)par * NM;
-    // ---- q = A p.  This lane holds component i of its node's p: it contributes column i of every block.
-    T a[M];
-#pragma unroll
-    for (int j = 0; j < M; ++j) a[j] = dc[j] * pe;
-    bool stale = false;
-    if (in_lds) spmv_cols<T, M, CH>(a, hb_l + ((size_t)lbeg * M + i) * M, M * M, 1, nb_l + lbeg, deg, maxdeg, i, pin, tag, stale);
-    else spmv_cols<T, M, CH>(a, HB + (size_t)beg * M * M + i, M * M, M, other + beg, deg, maxdeg, i, pin, tag, stale);
-    // the node's q row = sum of its M lanes' partial rows: through this wave's LDS pad (a wave's LDS accesses execute in order)
-    T acc = T(0);
-    if (sub < NPW) {
-#pragma unroll
-      for (int j = 0; j < M; ++j) tr_l[(sub * M + i) * M + j] = a[j];
+  // cap < 0 (tools/time_pcg_iter.py): thread 0 of the middle workgroup accumulates the wall-clock ticks (10 ns) of every
+  // phase of the iteration and leaves them in the last 8 entries of rr_hist
+  const bool prof = cap < 0;
+  if (prof) cap = -cap;
+  const bool clocked = prof && blockIdx.x == gridDim.x / 2 && threadIdx.x == 0;
+  unsigned long long tk[6] = {0, 0, 0, 0, 0, 0}, t_prev = clocked ? wall_clock64() : 0;
+#define PPLIE_TICK(slot)                                       \
+  if (clocked) {                                               \
+    const unsigned long long t_now = wall_clock64();           \
+    tk[slot] += t_now - t_prev;                                \
+    t_prev = t_now;                                            \
+  }
+  if (!PIPE) {
+    T pe = ze;                             // p_0 = z_0 (published above as hand-off 0)
+    for (;; ++k) {
+      const unsigned tag = (unsigned)k + 1u;
+      const int par = k & 1;
+      bool stale = false;
+      const T acc = node_matvec<T, M, CH>(L, pe, HB, other, ptag + (size_t)par * NM, tag, stale);      // q = A p
+      PPLIE_TICK(0)
+      const T bq = node_binv<T, M>(L, acc);
+      T v[kPersistQ] = {acc * pe, acc * ze, acc * bq, re * ze, re * re};
+      post_wave_sums<T, kPersistQ>(sh, par, v, act, stale);
+      PPLIE_TICK(1)
+      __syncthreads();                                                           // barrier 1
+      PPLIE_TICK(2)
+      publish_row<T, kPersistQ>(sh, par, part, tag);
+      gather_rows<T, kPersistQ>(sh, par, part, tag);
+      PPLIE_TICK(3)
+      __syncthreads();                                                           // barrier 2
+      PPLIE_TICK(4)
+      const T pq = sh.total[par][0], qz = sh.total[par][1], qmq = sh.total[par][2], rho = sh.total[par][3];
+      rr = sh.total[par][4];
+      if (sh.bad[par]) { flag = 3; break; }
+      if (k == 0) bn2 = rr;
+      if (blockIdx.x == 0 && threadIdx.x == 0 && k < cap) rr_hist[k] = rr;
+      if (!(rr == rr)) { flag = 2; break; }
+      if (rr <= tol2 * bn2) { flag = 1; break; }                     // (also |b| = 0: x = 0 is the answer)
+      if (k >= maxiter) break;
+      const T alpha = pq != T(0) ? rho / pq : T(0);                 // p.q = 0 only once r = 0: stay put, no NaN
+      T rho_next = rho - T(2) * alpha * qz + alpha * alpha * qmq;
+      if (rho_next < T(0)) rho_next = T(0);
+      const T beta = rho != T(0) ? rho_next / rho : T(0);
+      xe += alpha * pe;
+      re -= alpha * acc;
+      ze = node_binv<T, M>(L, re);
+      pe = ze + beta * pe;
+      if (act) put_value<T>(ptag + (size_t)((k + 1) & 1) * NM + (size_t)(n * M + i) * NW, pe, tag + 1u);
+      PPLIE_TICK(5)
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    if (sub < NPW) {
-#pragma unroll
-      for (int j = 0; j < M; ++j) acc += tr_l[(sub * M + j) * M + i];
+  } else {
+    // u_0 = z (hand-off 0, published above);  w_0 = A u_0;  m_0 = Binv w_0 (hand-off 1)
+    T ue = ze, we, me, pe = T(0), se = T(0), qe = T(0), zz = T(0);
+    {
+      bool stale = false;
+      we = node_matvec<T, M, CH>(L, ue, HB, other, ptag, 1u, stale);
+      if (stale) sh.bad[0] = 1;
+      me = node_binv<T, M>(L, we);
+      if (act) put_value<T>(ptag + NM + (size_t)(n * M + i) * NW, me, 2u);
     }
-    T bq = T(0);
-#pragma unroll
-    for (int j = 0; j < M; ++j) bq += br[j] * __shfl(acc, sub * M + j, 64);
-    // ---- partial sums: wave level, then one barrier, then thread 0 publishes the workgroup's row
-    T v[kPersistQ] = {acc * pe, acc * ze, acc * bq, re * ze, re * re};
-#pragma unroll
-    for (int q = 0; q < kPersistQ; ++q) {
-      if (!act) v[q] = T(0);
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) v[q] += __shfl_down(v[q], off, 64);
-      if (lane == 0) sh.wave_part[par][q][w] = v[q];
-    }
-    if (stale) sh.bad[par] = 1;
-    __syncthreads();                                                             // barrier 1
-    if (threadIdx.x < kPersistQ) {
-      T sum = T(0);
-#pragma unroll
-      for (int ww = 0; ww < WV; ++ww) sum += sh.wave_part[par][threadIdx.x][ww];
-      put_value<T>(part + ((size_t)par * kPersistGridMax + blockIdx.x) * RW + threadIdx.x * NW, sum, tag);
-    }
-    // ---- all-gather: wave q polls quantity q of every workgroup's row (all loads of a round in flight together) and adds
-    // them up in row order -- the same order, hence the same bits, in every workgroup
-    if (w < kPersistQ) {
-      const u64* tab = part + (size_t)par * kPersistGridMax * RW;
-      T sum = T(0);
-      bool all = true;
-      for (int base = 0; base < (int)gridDim.x; base += 256) {
-        T val[4];
-        bool done[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { done[q] = base + lane + 64 * q >= (int)gridDim.x; val[q] = T(0); }
-        for (long spin = 0; spin < (1L << 20); ++spin) {
-          bool pending = false;
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            if (!done[q]) {
-              bool ok = true;
-              const T t = get_value<T>(tab + (size_t)(base + lane + 64 * q) * RW + w * NW, tag, ok);
-              if (ok) { val[q] = t; done[q] = true; } else pending = true;
-            }
-          }
-          if (!pending) break;
-          __builtin_amdgcn_s_sleep(1);
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { all = all && done[q]; sum += val[q]; }
+    T gamma_prev = T(1), alpha_prev = T(1);
+    for (;; ++k) {
+      const unsigned tag = (unsigned)k + 1u;                         // of this iteration's partial sums
+      const int par = k & 1;
+      // ---- post gamma = r.u, delta = w.u, |r|^2  (they only involve vectors that exist before this iteration's product)
+      T v[3] = {re * ue, we * ue, re * re};
+      post_wave_sums<T, 3>(sh, par, v, act, false);
+      PPLIE_TICK(1)
+      __syncthreads();                                                           // barrier 1
+      PPLIE_TICK(2)
+      publish_row<T, 3>(sh, par, part, tag);
+      // ---- n = A m while the partial sums travel (m_k is hand-off k + 1: tag k + 2, table (k + 1) & 1)
+      bool stale = false;
+      const T ne = node_matvec<T, M, CH>(L, me, HB, other, ptag + (size_t)((k + 1) & 1) * NM, tag + 1u, stale);
+      if (stale) sh.bad[par] = 1;
+      PPLIE_TICK(0)
+      gather_rows<T, 3>(sh, par, part, tag);
+      PPLIE_TICK(3)
+      __syncthreads();                                                           // barrier 2
+      PPLIE_TICK(4)
+      const T gamma = sh.total[par][0], delta = sh.total[par][1];
+      rr = sh.total[par][2];
+      if (sh.bad[par]) { flag = 3; break; }
+      if (k == 0) bn2 = rr;
+      if (blockIdx.x == 0 && threadIdx.x == 0 && k < cap) rr_hist[k] = rr;
+      if (!(rr == rr)) { flag = 2; break; }
+      if (rr <= tol2 * bn2) { flag = 1; break; }
+      if (k >= maxiter) break;
+      T beta = T(0), den = delta;
+      if (k > 0) {
+        beta = gamma_prev != T(0) ? gamma / gamma_prev : T(0);
+        den = delta - beta * gamma / alpha_prev;
       }
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
-      if (lane == 0) sh.total[par][w] = sum;
-      if (!__all(all) && lane == 0) sh.bad[par] = 1;
+      const T alpha = den != T(0) ? gamma / den : T(0);
+      gamma_prev = gamma;
+      alpha_prev = alpha != T(0) ? alpha : T(1);
+      zz = ne + beta * zz;
+      qe = me + beta * qe;
+      se = we + beta * se;
+      pe = ue + beta * pe;
+      xe += alpha * pe;
+      re -= alpha * se;
+      ue -= alpha * qe;
+      we -= alpha * zz;
+      me = node_binv<T, M>(L, we);
+      if (act) put_value<T>(ptag + (size_t)(k & 1) * NM + (size_t)(n * M + i) * NW, me, tag + 2u);   // hand-off k + 2
+      PPLIE_TICK(5)
     }
-    __syncthreads();                                                             // barrier 2
-    const T pq = sh.total[par][0], qz = sh.total[par][1], qmq = sh.total[par][2], rho = sh.total[par][3];
-    rr = sh.total[par][4];
-    if (sh.bad[par]) { flag = 3; break; }
-    if (k == 0) bn2 = rr;
-    if (blockIdx.x == 0 && threadIdx.x == 0 && k < cap) rr_hist[k] = rr;
-    if (!(rr == rr)) { flag = 2; break; }
-    if (rr <= tol2 * bn2) { flag = 1; break; }                       // (also |b| = 0: x = 0 is the answer)
-    if (k >= maxiter) break;
-    const T alpha = pq != T(0) ? rho / pq : T(0);                   // p.q = 0 only once r = 0: stay put, no NaN
-    T rho_next = rho - T(2) * alpha * qz + alpha * alpha * qmq;
-    if (rho_next < T(0)) rho_next = T(0);
-    const T beta = rho != T(0) ? rho_next / rho : T(0);
-    // ---- vector update on this lane's element
-    xe += alpha * pe;
-    re -= alpha * acc;
-    T zn = T(0);
+  }
+#undef PPLIE_TICK
+  if (clocked) {
 #pragma unroll
-    for (int j = 0; j < M; ++j) zn += br[j] * __shfl(re, sub * M + j, 64);
-    ze = zn;
-    pe = ze + beta * pe;
-    if (act) put_value<T>(ptag + (size_t)((k + 1) & 1) * NM + (size_t)(n * M + i) * NW, pe, tag + 1u);
+    for (int q = 0; q < 6; ++q) rr_hist[cap - 8 + q] = (T)tk[q];
   }
   // a failed solve (NaN, or a workgroup that never arrived) hands back x = 0: the caller may have queued the parameter
   // update behind this launch and look at `info` only afterwards (one read-back per LM trial) -- Exp(0) p = p
@@ -275,7 +410,7 @@ pcg_persist_kernel(const int* __restrict__ ptr, const int* __restrict__ other, c
 // Dynamic LDS of a workgroup (the staged matrix slice); the most workgroups of this kernel the device holds at once
 // (they spin on each other: all must be resident)
 constexpr int kPersistLds = 128 * 1024;
-template <class T, int M> static int persist_capacity(int& lds_bytes) {
+template <class T, int M, bool PIPE> static int persist_capacity(int& lds_bytes) {
   static int cap[16] = {0}, lds[16] = {0};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 0;
@@ -283,12 +418,12 @@ template <class T, int M> static int persist_capacity(int& lds_bytes) {
     int cus = 0, per = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
     lds[dev] = kPersistLds;
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&pcg_persist_kernel<T, M>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&pcg_persist_kernel<T, M, PIPE>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             kPersistLds) != hipSuccess) {
       (void)hipGetLastError();
       lds[dev] = 48 * 1024;                                      // (always available without the attribute)
     }
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, pcg_persist_kernel<T, M>, kPersistBlock, lds[dev]) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, pcg_persist_kernel<T, M, PIPE>, kPersistBlock, lds[dev]) != hipSuccess) return 0;
     cap[dev] = cus * per > 0 ? cus * per : -1;
   }
   lds_bytes = lds[dev];
@@ -304,21 +439,27 @@ int pcg_persist(const void* ptr, const void* other, const void* HB, const void* 
   if (grid < 1 || grid > kPersistGridMax || maxiter < 0) return PPLIE_EBADARG;
   (void)p; (void)q;                                              // (round-2 signature: p and q now live in registers)
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-#define LAUNCH(MM)                                                                                                             \
+  // pipelined recurrence for tolerances a residual reaches with room to spare (see the kernel); PPLIE_PCG_PIPELINE=0/1 forces
+  static const int forced = [] { const char* e = getenv("PPLIE_PCG_PIPELINE"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
+  const bool pipe = forced >= 0 ? forced == 1 : tol >= 1e-5;
+#define LAUNCH2(MM, PP)                                                                                                        \
   {                                                                                                                            \
     int lds_bytes = 0;                                                                                                         \
-    const int resident = persist_capacity<T, MM>(lds_bytes);                                                                   \
+    const int resident = persist_capacity<T, MM, PP>(lds_bytes);                                                               \
     if (resident <= 0 || (size_t)lds_bytes < (size_t)(kPersistBlock / 64) * (64 / MM) * MM * MM * sizeof(T)) return PPLIE_ECAPACITY; \
     if (grid > resident) grid = resident;                         /* fewer CUs than asked for: every workgroup must be resident */ \
     if (grid > N) grid = (int)N;                                                                                               \
     const int64_t per_wg = (kPersistBlock / 64) * (64 / MM);     /* one lane per (node, component): nodes one workgroup holds */ \
     if ((N + grid - 1) / grid > per_wg) return PPLIE_ECAPACITY;  /* too large for this device: use the two-launch iteration */  \
-    hipLaunchKernelGGL((pcg_persist_kernel<T, MM>), dim3(grid), dim3(kPersistBlock), lds_bytes, st, (const int*)ptr, (const int*)other, \
-                       (const T*)HB, (const T*)D, (const T*)Binv, (T*)x, (const T*)r, (const T*)z, (unsigned long long*)part,     \
-                       (unsigned long long*)ptag, (T*)rr_hist, (T*)info, (int*)it, (T)(tol * tol), maxiter, cap, N, lds_bytes);  \
+    hipLaunchKernelGGL((pcg_persist_kernel<T, MM, PP>), dim3(grid), dim3(kPersistBlock), lds_bytes, st, (const int*)ptr,       \
+                       (const int*)other, (const T*)HB, (const T*)D, (const T*)Binv, (T*)x, (const T*)r, (const T*)z,            \
+                       (unsigned long long*)part, (unsigned long long*)ptag, (T*)rr_hist, (T*)info, (int*)it, (T)(tol * tol),    \
+                       maxiter, cap, N, lds_bytes);                                                                            \
   }
+#define LAUNCH(MM) { if (pipe) LAUNCH2(MM, true) else LAUNCH2(MM, false) }
   if (m == 6) LAUNCH(6) else if (m == 7) LAUNCH(7) else if (m == 3) LAUNCH(3) else return PPLIE_EBADARG;
 #undef LAUNCH
+#undef LAUNCH2
   return hipGetLastError() == hipSuccess ? PPLIE_OK : PPLIE_ELAUNCH;
 }
 }  // namespace pplie

@@ -285,6 +285,7 @@ class FusedPCG:
     two_launch = True        # class-level switches (tools/ and tests compare the three-launch / graph-less variants)
     use_graph = True
     persist = True           # one persistent launch per solve on small graphs (csrc/pcg_persist.hip)
+    profile = False          # tools/time_pcg_iter.py: the persistent kernel leaves per-phase clock ticks in rr_hist[cap - 8:]
 
     def __init__(self, E, K, dr, m, N, dtype, device, has_w, check_every):
         z = lambda *s: torch.zeros(s, dtype=dtype, device=device)
@@ -439,7 +440,8 @@ class FusedPCG:
                     self.ptr.data_ptr(), self.other.data_ptr(), self.HB.data_ptr(), self.D.data_ptr(), self.Binv.data_ptr(),
                     self.x.data_ptr(), self.r.data_ptr(), self.p.data_ptr(), self.q.data_ptr(), self.z.data_ptr(),
                     self.part.data_ptr(), self.ptag.data_ptr(), self.rr_hist.data_ptr(), self.info.data_ptr(), self.it.data_ptr(),
-                    float(tol), int(maxit), self.cap, PERSIST_GRID, self.N, self.m, _C.stream_ptr(self.device))
+                    float(tol), int(maxit), -self.cap if FusedPCG.profile else self.cap, PERSIST_GRID, self.N, self.m,
+                    _C.stream_ptr(self.device))
                 if code == _C.ECAPACITY:                            # this device cannot hold the solve resident: stream it instead
                     self.no_persist = True
                     return self.solve(lin, s, dmin, dmax, tol, maxiter, group, plain=plain, defer=defer)

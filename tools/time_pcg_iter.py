@@ -41,6 +41,19 @@ with torch.no_grad():
     for grid in (64, 128, 192, 256):
         a, b = out[f"persist_grid{grid}_it40"], out[f"persist_grid{grid}_it200"]
         out[f"persist_grid{grid}_marginal_us_per_iteration"] = round((b["us_per_solve"] - a["us_per_solve"]) / (b["iterations"] - a["iterations"]), 2)
+    # phase breakdown of the persistent iteration (wall-clock ticks of 10 ns, thread 0 of the middle workgroup)
+    for grid in (64, 128, 256):
+        G.PERSIST_GRID = grid
+        cap = wsp.cap
+        G.FusedPCG.profile = True
+        try:
+            x, its = wsp.solve(lin, lin.s, lin.dmin, lin.dmax, 1e-30, 200, None)
+        finally:
+            G.FusedPCG.profile = False
+        torch.cuda.synchronize()
+        tk = wsp.rr_hist[cap - 8:cap - 2].tolist()
+        names = ("spmv", "transpose+wave_sums", "barrier1", "publish+allgather", "barrier2", "update+handoff")
+        out[f"persist_grid{grid}_phase_us_per_iteration"] = {n: round(t * 0.01 / max(its, 1), 3) for n, t in zip(names, tk)}
     G.PERSIST_GRID = 256
     x1, _ = wsp.solve(lin, lin.s, lin.dmin, lin.dmax, 1e-6, 2000, None)
     G.FusedPCG.persist = False
