@@ -205,17 +205,11 @@ template <class T, int NQ> __device__ __forceinline__ void gather_rows(PersistSh
   }
 }
 
-// PIPE = false: preconditioned CG as the reference writes it, one exchange per iteration (header comment).
-// PIPE = true:  the PIPELINED form of the same recurrence (Ghysels & Vanroose 2014, Alg. 4) -- identical iterates in exact
-//   arithmetic.  With  u = Binv r,  w = A u,  m = Binv w,  n = A m  and the auxiliary recurrences
-//       z = n + beta z,  q = m + beta q,  s = w + beta s,  p = u + beta p;   x += alpha p,  r -= alpha s,  u -= alpha q,  w -= alpha z
-//   the dot products of an iteration, gamma = r.u and delta = w.u (and |r|^2 for the stop test), depend only on vectors that
-//   exist BEFORE its matrix product: the partial sums are posted first and collected after the product, so the all-gather
-//   travels while the workgroup waits for its neighbours' vector elements and multiplies -- the two grid-wide dependencies
-//   of an iteration (measured 4 - 5 us each under load, tools/time_pcg_iter.py) overlap instead of adding up.  Its
-//   recurrences for u and w drift from Binv r and A u by O(eps * iterations): used for tolerances an fp32 / fp64 residual
-//   reaches with room to spare (the host selects it for tol >= 1e-5), the plain form otherwise.
-template <class T, int M, bool PIPE>
+// (A PIPELINED recurrence -- Ghysels & Vanroose 2014: post the dot products before the matrix product, collect them after, so
+// that the all-gather overlaps the neighbour exchange -- was built and measured in round 3: 10.5 us per iteration instead of
+// 12.2, but its recurrences for Binv r and A Binv r lose the residual in fp32: it stalls above 1e-4 already at condition
+// number 100, cf. profiles/r03/SUMMARY.md.  Not kept.)
+template <class T, int M>
 __global__ void __launch_bounds__(kPersistBlock)
 pcg_persist_kernel(const int* __restrict__ ptr, const int* __restrict__ other, const T* __restrict__ HB, const T* __restrict__ D,
                    const T* __restrict__ Binv, T* __restrict__ x, const T* __restrict__ r, const T* __restrict__ z,
@@ -296,7 +290,7 @@ pcg_persist_kernel(const int* __restrict__ ptr, const int* __restrict__ other, c
     tk[slot] += t_now - t_prev;                                \
     t_prev = t_now;                                            \
   }
-  if (!PIPE) {
+  {
     T pe = ze;                             // p_0 = z_0 (published above as hand-off 0)
     for (;; ++k) {
       const unsigned tag = (unsigned)k + 1u;
@@ -334,64 +328,6 @@ pcg_persist_kernel(const int* __restrict__ ptr, const int* __restrict__ other, c
       if (act) put_value<T>(ptag + (size_t)((k + 1) & 1) * NM + (size_t)(n * M + i) * NW, pe, tag + 1u);
       PPLIE_TICK(5)
     }
-  } else {
-    // u_0 = z (hand-off 0, published above);  w_0 = A u_0;  m_0 = Binv w_0 (hand-off 1)
-    T ue = ze, we, me, pe = T(0), se = T(0), qe = T(0), zz = T(0);
-    {
-      bool stale = false;
-      we = node_matvec<T, M, CH>(L, ue, HB, other, ptag, 1u, stale);
-      if (stale) sh.bad[0] = 1;
-      me = node_binv<T, M>(L, we);
-      if (act) put_value<T>(ptag + NM + (size_t)(n * M + i) * NW, me, 2u);
-    }
-    T gamma_prev = T(1), alpha_prev = T(1);
-    for (;; ++k) {
-      const unsigned tag = (unsigned)k + 1u;                         // of this iteration's partial sums
-      const int par = k & 1;
-      // ---- post gamma = r.u, delta = w.u, |r|^2  (they only involve vectors that exist before this iteration's product)
-      T v[3] = {re * ue, we * ue, re * re};
-      post_wave_sums<T, 3>(sh, par, v, act, false);
-      PPLIE_TICK(1)
-      __syncthreads();                                                           // barrier 1
-      PPLIE_TICK(2)
-      publish_row<T, 3>(sh, par, part, tag);
-      // ---- n = A m while the partial sums travel (m_k is hand-off k + 1: tag k + 2, table (k + 1) & 1)
-      bool stale = false;
-      const T ne = node_matvec<T, M, CH>(L, me, HB, other, ptag + (size_t)((k + 1) & 1) * NM, tag + 1u, stale);
-      if (stale) sh.bad[par] = 1;
-      PPLIE_TICK(0)
-      gather_rows<T, 3>(sh, par, part, tag);
-      PPLIE_TICK(3)
-      __syncthreads();                                                           // barrier 2
-      PPLIE_TICK(4)
-      const T gamma = sh.total[par][0], delta = sh.total[par][1];
-      rr = sh.total[par][2];
-      if (sh.bad[par]) { flag = 3; break; }
-      if (k == 0) bn2 = rr;
-      if (blockIdx.x == 0 && threadIdx.x == 0 && k < cap) rr_hist[k] = rr;
-      if (!(rr == rr)) { flag = 2; break; }
-      if (rr <= tol2 * bn2) { flag = 1; break; }
-      if (k >= maxiter) break;
-      T beta = T(0), den = delta;
-      if (k > 0) {
-        beta = gamma_prev != T(0) ? gamma / gamma_prev : T(0);
-        den = delta - beta * gamma / alpha_prev;
-      }
-      const T alpha = den != T(0) ? gamma / den : T(0);
-      gamma_prev = gamma;
-      alpha_prev = alpha != T(0) ? alpha : T(1);
-      zz = ne + beta * zz;
-      qe = me + beta * qe;
-      se = we + beta * se;
-      pe = ue + beta * pe;
-      xe += alpha * pe;
-      re -= alpha * se;
-      ue -= alpha * qe;
-      we -= alpha * zz;
-      me = node_binv<T, M>(L, we);
-      if (act) put_value<T>(ptag + (size_t)(k & 1) * NM + (size_t)(n * M + i) * NW, me, tag + 2u);   // hand-off k + 2
-      PPLIE_TICK(5)
-    }
   }
 #undef PPLIE_TICK
   if (clocked) {
@@ -410,7 +346,7 @@ pcg_persist_kernel(const int* __restrict__ ptr, const int* __restrict__ other, c
 // Dynamic LDS of a workgroup (the staged matrix slice); the most workgroups of this kernel the device holds at once
 // (they spin on each other: all must be resident)
 constexpr int kPersistLds = 128 * 1024;
-template <class T, int M, bool PIPE> static int persist_capacity(int& lds_bytes) {
+template <class T, int M> static int persist_capacity(int& lds_bytes) {
   static int cap[16] = {0}, lds[16] = {0};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 0;
@@ -418,12 +354,12 @@ template <class T, int M, bool PIPE> static int persist_capacity(int& lds_bytes)
     int cus = 0, per = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
     lds[dev] = kPersistLds;
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&pcg_persist_kernel<T, M, PIPE>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&pcg_persist_kernel<T, M>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             kPersistLds) != hipSuccess) {
       (void)hipGetLastError();
       lds[dev] = 48 * 1024;                                      // (always available without the attribute)
     }
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, pcg_persist_kernel<T, M, PIPE>, kPersistBlock, lds[dev]) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, pcg_persist_kernel<T, M>, kPersistBlock, lds[dev]) != hipSuccess) return 0;
     cap[dev] = cus * per > 0 ? cus * per : -1;
   }
   lds_bytes = lds[dev];
@@ -439,27 +375,22 @@ int pcg_persist(const void* ptr, const void* other, const void* HB, const void* 
   if (grid < 1 || grid > kPersistGridMax || maxiter < 0) return PPLIE_EBADARG;
   (void)p; (void)q;                                              // (round-2 signature: p and q now live in registers)
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  // pipelined recurrence for tolerances a residual reaches with room to spare (see the kernel); PPLIE_PCG_PIPELINE=0/1 forces
-  static const int forced = [] { const char* e = getenv("PPLIE_PCG_PIPELINE"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
-  const bool pipe = forced >= 0 ? forced == 1 : tol >= 1e-5;
-#define LAUNCH2(MM, PP)                                                                                                        \
+#define LAUNCH(MM)                                                                                                             \
   {                                                                                                                            \
     int lds_bytes = 0;                                                                                                         \
-    const int resident = persist_capacity<T, MM, PP>(lds_bytes);                                                               \
+    const int resident = persist_capacity<T, MM>(lds_bytes);                                                                   \
     if (resident <= 0 || (size_t)lds_bytes < (size_t)(kPersistBlock / 64) * (64 / MM) * MM * MM * sizeof(T)) return PPLIE_ECAPACITY; \
     if (grid > resident) grid = resident;                         /* fewer CUs than asked for: every workgroup must be resident */ \
     if (grid > N) grid = (int)N;                                                                                               \
     const int64_t per_wg = (kPersistBlock / 64) * (64 / MM);     /* one lane per (node, component): nodes one workgroup holds */ \
     if ((N + grid - 1) / grid > per_wg) return PPLIE_ECAPACITY;  /* too large for this device: use the two-launch iteration */  \
-    hipLaunchKernelGGL((pcg_persist_kernel<T, MM, PP>), dim3(grid), dim3(kPersistBlock), lds_bytes, st, (const int*)ptr,       \
+    hipLaunchKernelGGL((pcg_persist_kernel<T, MM>), dim3(grid), dim3(kPersistBlock), lds_bytes, st, (const int*)ptr,           \
                        (const int*)other, (const T*)HB, (const T*)D, (const T*)Binv, (T*)x, (const T*)r, (const T*)z,            \
                        (unsigned long long*)part, (unsigned long long*)ptag, (T*)rr_hist, (T*)info, (int*)it, (T)(tol * tol),    \
                        maxiter, cap, N, lds_bytes);                                                                            \
   }
-#define LAUNCH(MM) { if (pipe) LAUNCH2(MM, true) else LAUNCH2(MM, false) }
   if (m == 6) LAUNCH(6) else if (m == 7) LAUNCH(7) else if (m == 3) LAUNCH(3) else return PPLIE_EBADARG;
 #undef LAUNCH
-#undef LAUNCH2
   return hipGetLastError() == hipSuccess ? PPLIE_OK : PPLIE_ELAUNCH;
 }
 }  // namespace pplie

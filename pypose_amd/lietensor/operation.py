@@ -387,6 +387,11 @@ def broadcast_inputs(x, y):
         return (x.reshape(-1, x.shape[-1]).contiguous(),), tuple(x.shape[:-1])
     if x.dim() == 2 and y.dim() == 2 and x.shape[0] == y.shape[0] and x.is_contiguous() and y.is_contiguous():
         return (x, y), (x.shape[0],)                 # already rows: nothing to broadcast, flatten or copy
+    if _C.dry_tracing():
+        # a dry trace (optim/fused.py) records which tensors meet in which op: nothing is expanded or copied, the operands
+        # stay the caller's own tensors (the recorded launch broadcasts the leading dimensions itself)
+        shp = x.shape[:-1] if x.shape[:-1] == y.shape[:-1] else torch.broadcast_shapes(x.shape[:-1], y.shape[:-1])
+        return (x, y), tuple(shp)
     # (equal shapes are the common case; torch.broadcast_shapes costs ~10 us of Python)
     out_shape = x.shape[:-1] if x.shape[:-1] == y.shape[:-1] else torch.broadcast_shapes(x.shape[:-1], y.shape[:-1])
     shape = out_shape if out_shape != torch.Size([]) else (1,)

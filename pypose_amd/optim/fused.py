@@ -380,6 +380,7 @@ class DeviceLM:
         self.cfg = _LmCfg()
         sfx = _blocks._suffix(pt)
         self.fn = _C.library().symbol("pplie_lm_se3inv_step" + sfx, _STEP_SIG)
+        self.kind_name = Se3InvLinearization.kind
         self.fn_sums = _C.library().symbol("pplie_lm_se3inv_trial_sums" + sfx, _SUMS_SIG)
         self.fn_decide = _C.library().symbol("pplie_lm_decide" + sfx, _DECIDE_SIG)
         sp = self.state.data_ptr()
@@ -415,9 +416,11 @@ class DeviceLM:
             self.host_dirty = True
         return opt.param_groups[0]
 
-    def _step_conditions(self, target, weight):
+    def _step_conditions(self, target, weight, m=None):
         opt = self.opt
-        return not (target is not None or weight is not None or opt.weight is not None or self.P.data_ptr() != self.p_ptr
+        if target is not None and (m is None or m[0] != "lpr" or m[1].b is None or not _same(m[1].b, target)):
+            return False
+        return not (weight is not None or opt.weight is not None or self.P.data_ptr() != self.p_ptr
                     or opt.strategy is not self.strategy or not opt.fused or not getattr(opt, 'structured', True)
                     or len(opt.param_groups) != 1 or torch.is_inference_mode_enabled())
 
@@ -433,9 +436,9 @@ class DeviceLM:
     def checked_step(self, m, target, weight):
         """The default: ``m`` is the program this step's (dry) run of the model was matched to.  If it is the program this
         state was built on -- same parameter, same constant operand storage -- the step is two launches; else None."""
-        if m[0] != "se3inv" or m[1] is not self.P or not self.same_operand(m[2]) or not self._step_conditions(target, weight):
+        if not self.matches(m) or not self._step_conditions(target, weight, m):
             return None
-        self.opt.linearization = Se3InvLinearization.kind
+        self.opt.linearization = self.kind_name
         return self.step()
 
     # ---- one step ----------------------------------------------------------------------------------------------
@@ -480,9 +483,9 @@ class DeviceLM:
         stream = _C.stream_ptr(self.device)
         if opt.group is None:
             with _C._on_device(self.device):
-                code = self.fn(self.p_ptr, self.x_ptr, save, partials, st_in, st_out, sync, self.cfg, self.n, loss_ptr, last_ptr, stream)
+                code = self._launch(save, partials, st_in, st_out, sync, loss_ptr, last_ptr, stream)
             if code:
-                _C.check(code, "pplie_lm_se3inv_step")
+                _C.check(code, "pplie_lm_*_step")
             self.cur = 1 - self.cur
         else:
             self._sharded(st_in, st_out, loss_ptr, last_ptr, stream)
@@ -492,6 +495,13 @@ class DeviceLM:
         opt._last_view = self.last_views[k]
         opt.__dict__.pop('_host_loss', None)
         return opt.loss
+
+    def _launch(self, save, partials, st_in, st_out, sync, loss_ptr, last_ptr, stream):
+        return self.fn(self.p_ptr, self.x_ptr, save, partials, st_in, st_out, sync, self.cfg, self.n, loss_ptr, last_ptr, stream)
+
+    def matches(self, m):
+        """``m`` (a freshly matched program) is the program this state was built on"""
+        return m[0] == "se3inv" and m[1] is self.P and self.same_operand(m[2])
 
     def _sharded(self, st_in, st_out, loss_ptr, last_ptr, stream):
         """LM(group=...): every rank runs the trial on its problems; the four sums are all-reduced so that all ranks
@@ -535,6 +545,240 @@ class DeviceLM:
         if st[_ST_FAILED]:
             print('Cholesky decomposition failed. Check your matrix (may not be positive-definite)',
                   "\nLinear solver failed. Breaking optimization step...")
+
+
+# ---------------------------------------------------------------------------------------------
+# the normal form  r = Log(L * P^s * R) [- b]  /  r = (L * P^s * R) . a [- b]   (csrc/lm_generic.hip)
+# ---------------------------------------------------------------------------------------------
+_GROUP_OF = {"SO3Type": ("so3", 0, 3, 4), "SE3Type": ("se3", 1, 6, 7), "Sim3Type": ("sim3", 2, 7, 8), "RxSO3Type": ("rxso3", 3, 4, 5)}
+_LPR_SIG = [ctypes.c_int] * 3 + [ctypes.c_void_p] * 10 + [ctypes.POINTER(_LmCfg), ctypes.c_int64] + [ctypes.c_void_p] * 3
+
+
+class LprProgram:
+    """One residual program in normal form: the parameter ``P`` (a group LieTensor, one element per problem), ``sign`` (+1: P,
+    -1: P^-1), the constant factors to its left and right in the product (``(tensor, inverted)`` pairs, folded into one
+    L / R tensor each by real kernel launches -- once, and again only when one of them is written to), ``kind`` 0 (Log)
+    or 1 (Act on points ``a``) and the target ``b`` (or None)."""
+
+    def __init__(self, P, gkey, kind, sign, left, right, a, b):
+        self.P, self.kind, self.sign, self.left, self.right, self.a, self.b = P, kind, sign, left, right, a, b
+        self.g, self.gid, self.da, self.dg = gkey
+        self.n = P.numel() // self.dg
+        self._folded = None
+
+    def key(self):
+        t = lambda x: None if x is None else (x.data_ptr(), tuple(x.shape), x.dtype)
+        return (id(self.P), self.kind, self.sign, tuple((t(c), inv) for c, inv in self.left), tuple((t(c), inv) for c, inv in self.right),
+                t(self.a), t(self.b))
+
+    def _versions(self):
+        return tuple(c._version for c, _ in self.left + self.right)
+
+    def _fold(self, factors):
+        if not factors:
+            return None
+        g, dg, n = self.g, self.dg, self.n
+        out = None
+        for c, inv in factors:
+            c = c.detach().reshape(-1, dg)
+            if c.shape[0] != n:
+                c = c.expand(n, dg)
+            c = c.contiguous()
+            if inv:
+                c = _C.row_op(g + "_inv_fwd", [c], (dg,))[0]
+            out = c if out is None else _C.row_op(g + "_mul_fwd", [out, c], (dg,))[0]
+        return out
+
+    def operands(self):
+        """(L, R, a, b) as contiguous [n, w] tensors (None where absent); the folds are redone only when a factor was edited"""
+        ver = self._versions()
+        if self._folded is None or self._folded[0] != ver:
+            row = lambda t, w: None if t is None else (t.detach().reshape(-1, w).expand(self.n, w).contiguous())
+            dr = self.da if self.kind == 0 else 3
+            self._folded = (ver, self._fold(self.left), self._fold(self.right), row(self.a, 3), row(self.b, dr),
+                            (None if self.a is None else self.a._version, None if self.b is None else self.b._version))
+        elif self._folded[5] != (None if self.a is None else self.a._version, None if self.b is None else self.b._version):
+            self._folded = None
+            return self.operands()
+        return self._folded[1:5]
+
+
+def match_lpr(trace, outputs, params, target, gathers):
+    """An :class:`LprProgram` if the traced forward is  Log / Act  of a product chain (Mul / Inv) over exactly one occurrence
+    of the parameter and any number of constant group elements, its output the model's only output; else None."""
+    if gathers or len(outputs) != 1 or len(params) != 1 or not trace.events:
+        return None
+    P = params[0]
+    gkey = _GROUP_OF.get(type(getattr(P, "ltype", None)).__name__)
+    if gkey is None or P.dim() < 2 or tuple(getattr(P.ltype, "dimension", ())) != (gkey[3],):
+        return None
+    g, dg = gkey[0], gkey[3]
+    Pp = torch.Tensor.as_subclass(P, torch.Tensor)
+    if not Pp.is_contiguous():
+        return None
+    n = Pp.numel() // dg
+    by_out = {_key(o[0]): (name, ins) for name, ins, o in trace.events}
+    top = by_out.get(_key(outputs[0]))
+    if top is None or len(by_out) != len(trace.events):
+        return None
+    used = [0]
+
+    def const_ok(t, w):
+        return (not t.requires_grad and t.device == Pp.device and t.dtype == Pp.dtype and t.shape[-1] == w and t.numel() in (w, n * w)
+                and t.device.type != "meta")
+
+    def factors(t, inverted):
+        ev = by_out.get(_key(t)) if t.device.type == "meta" else None
+        if ev is not None:
+            used[0] += 1
+            name, ins = ev
+            if name == g + "_mul_fwd":
+                a, b = factors(ins[0], inverted), factors(ins[1], inverted)
+                if a is None or b is None:
+                    return None
+                return b + a if inverted else a + b
+            if name == g + "_inv_fwd":
+                return factors(ins[0], not inverted)
+            return None
+        if t.device.type == "meta":
+            return None
+        if _same(t, Pp):
+            return [("P", inverted)]
+        return [(t, inverted)] if const_ok(t, dg) else None
+    name, ins = top
+    a = None
+    if name == g + "_log_fwd":
+        kind = 0
+    elif name == g + "_act_fwd":
+        kind, a = 1, ins[1]
+        if not const_ok(a, 3):
+            return None
+    else:
+        return None
+    chain = factors(ins[0], False)
+    if chain is None or used[0] + 1 != len(trace.events):
+        return None
+    where = [k for k, f in enumerate(chain) if f[0] == "P" if isinstance(f[0], str)]
+    if len(where) != 1:
+        return None
+    k = where[0]
+    b = None
+    if target is not None:
+        b = target
+        dr = gkey[2] if kind == 0 else 3
+        if not isinstance(b, torch.Tensor) or not const_ok(torch.Tensor.as_subclass(b, torch.Tensor), dr):
+            return None
+        b = torch.Tensor.as_subclass(b, torch.Tensor)
+    return LprProgram(P, gkey, kind, -1 if chain[k][1] else 1, chain[:k], chain[k + 1:], a, b)
+
+
+class DeviceLMLpr(DeviceLM):
+    """:class:`DeviceLM` for an :class:`LprProgram` (``pplie_lm_lpr_step``): same loop state, decisions and lazy mirrors."""
+
+    def __init__(self, opt, prog, input):
+        self.prog = prog
+        self.opt, self.P, self.X_src = opt, prog.P, prog.P
+        self.kind = _strategy_kind(opt.strategy)
+        self.strategy = opt.strategy
+        pt = prog.P.detach()
+        self.n, dg = prog.n, prog.dg
+        self.dtype, self.device = pt.dtype, pt.device
+        self.p_ptr = pt.data_ptr()
+        self.x_ptr, self.x_version = 0, 0
+        z = dict(dtype=self.dtype, device=self.device)
+        self.save = torch.empty((self.n, dg), **z)
+        self.partials = torch.empty((_PARTIALS, 4), **z)
+        self.sums = torch.zeros(4, **z)
+        self.state = torch.zeros((2, _LM_STATE), dtype=torch.float64, device=self.device)
+        self.cur = 0
+        self.sync = torch.zeros(8, dtype=torch.int32, device=self.device)
+        self.cfg = _LmCfg()
+        self.fn = _C.library().symbol("pplie_lm_lpr_step" + _blocks._suffix(pt), _LPR_SIG)
+        self.kind_name = LprLinearization.kind
+        sp = self.state.data_ptr()
+        self.ptrs = (self.save.data_ptr(), self.partials.data_ptr(), (sp, sp + 8 * _LM_STATE), self.sync.data_ptr())
+        self.item = pt.element_size()
+        self.k = _LOSS_BLOCK
+        self.pending = False
+        self.host_dirty = True
+        self.last_loss = None
+        self.rearm(input)
+        self._wrap_group()
+
+    def _launch(self, save, partials, st_in, st_out, sync, loss_ptr, last_ptr, stream):
+        pr = self.prog
+        L, R, a, b = self._ops = pr.operands()                       # (held until the next step: the launch reads them)
+        p = lambda t: None if t is None else t.data_ptr()
+        return self.fn(pr.gid, pr.kind, pr.sign, self.p_ptr, p(L), p(R), p(a), p(b), save, partials, st_in, st_out, sync, self.cfg,
+                       self.n, loss_ptr, last_ptr, stream)
+
+    def matches(self, m):
+        return m[0] == "lpr" and m[1].key() == self.prog.key()
+
+    def try_step(self, input, target, weight):
+        """LM(static=True): the program is taken on trust while the same input object(s) are passed"""
+        if not self._step_conditions(None if (self.prog.b is not None and target is not None and _same(self.prog.b, target)) else target,
+                                     weight) or not _same_input(self.input, input):
+            return None
+        self.opt.linearization = self.kind_name
+        return self.step()
+
+    def _sharded(self, *a):
+        raise RuntimeError("LM(group=...) is not available for this residual program; use the block path (opt.fused = False)")
+
+
+class LprLinearization:
+    """LM trial steps of an :class:`LprProgram` on the device (csrc/lm_generic.hip)."""
+
+    kind = "fused:lpr"
+    reference_kind = "block"
+
+    def __init__(self, opt, prog, input):
+        self.opt, self.prog, self.input, self.P = opt, prog, input, prog.P
+
+    def build_normal_equations(self, dmin, dmax):
+        self.dmin, self.dmax = float(dmin), float(dmax)
+
+    def verify(self, ref, dmin, dmax, rtol=1e-3):
+        """One undamped device step on a COPY of the parameter against the generic block linearisation ``ref`` of the same
+        model: the candidate poses Exp(d) P and the residual norm."""
+        from .solver import Cholesky
+        pr = self.prog
+        pt = pr.P.detach().reshape(pr.n, pr.dg)
+        scratch = pt.clone()
+        z = dict(dtype=pt.dtype, device=pt.device)
+        save, partials = torch.empty_like(scratch), torch.empty((_PARTIALS, 4), **z)
+        state = torch.zeros((2, _LM_STATE), dtype=torch.float64, device=pt.device)
+        sync = torch.zeros(8, dtype=torch.int32, device=pt.device)
+        out = torch.zeros(2, **z)
+        cfg = _LmCfg()
+        cfg.high, cfg.low, cfg.up, cfg.factor, cfg.smin, cfg.smax, cfg.sdown = 0.5, 1e-3, 2.0, 0.5, 1e-6, 1e16, 0.5
+        cfg.dmin, cfg.dmax, cfg.host_damping, cfg.host_down = float(dmin), float(dmax), 0.0, 0.5
+        cfg.strategy, cfg.reject, cfg.flags, cfg.grid_cap = 0, 0, 3, 0
+        L, R, a, b = pr.operands()
+        p = lambda t: None if t is None else t.data_ptr()
+        fn = _C.library().symbol("pplie_lm_lpr_step" + _blocks._suffix(pt), _LPR_SIG)
+        with _C._on_device(pt.device):
+            code = fn(pr.gid, pr.kind, pr.sign, scratch.data_ptr(), p(L), p(R), p(a), p(b), save.data_ptr(), partials.data_ptr(),
+                      state[0].data_ptr(), state[1].data_ptr(), sync.data_ptr(), cfg, pr.n, out.data_ptr(),
+                      out.data_ptr() + pt.element_size(), _C.stream_ptr(pt.device))
+        _C.check(code, "pplie_lm_lpr_step")
+        ref.build_normal_equations(dmin, dmax)
+        Dr = ref.solve(Cholesky()).view(pr.n, pr.dg).contiguous()
+        want = _C.row_op(pr.g + "_retract", [Dr, pt.contiguous()], (pr.dg,))[0]
+        moved = (want - pt).abs().max().clamp_min(1e-30)
+        ok = bool((scratch - want).abs().max() <= rtol * moved + 1e-6 * want.abs().max())
+        old = ref.Rb.square().sum()
+        return ok and bool((state[1, _ST_LAST] - old.double()).abs() <= rtol * old.double().clamp_min(1e-30))
+
+    def run_trials(self, opt, pg):
+        dev = opt.__dict__.get('_device_lm')
+        if not isinstance(dev, DeviceLMLpr) or dev.prog.key() != self.prog.key():
+            dev = opt._device_lm = DeviceLMLpr(opt, self.prog, self.input)
+        else:
+            dev.prog = self.prog if dev.prog._folded is None else dev.prog
+            dev.rearm(self.input)
+        return dev.step()
 
 
 _PGO_SIG = [ctypes.c_void_p] * 5 + [ctypes.c_int64, ctypes.c_void_p]
@@ -655,7 +899,7 @@ def try_fused(opt, pg, input, target, weight, cache):
     if cache.get("fused") is False or len(params) != 1 or _C._test_backend is not None:
         return None
     P = params[0]
-    if not (P.is_cuda and _blocks._suffix(P) and target is None and len(opt.param_groups) == 1):
+    if not (P.is_cuda and _blocks._suffix(P) and len(opt.param_groups) == 1):
         return None
     trivial = all(isinstance(c, Trivial) for c in opt.corrector) and all(isinstance(k, Trivial) for k in opt.model.kernel)
     solver_ok = (isinstance(opt.solver, Cholesky) and not opt.solver.upper) or isinstance(opt.solver, _pg.PCG)
@@ -670,10 +914,13 @@ def try_fused(opt, pg, input, target, weight, cache):
         # program of the previous step is evaluated directly, without running the model, while the same `input` object(s)
         # are passed and every operand tensor sits at the same address with the same version counter.
         kind, operands = hit[2], hit[3]
-        if kind == "se3inv" and weight is None and trivial and solver_ok and builtin:
+        if kind == "se3inv" and weight is None and trivial and solver_ok and builtin and target is None:
             return Se3InvLinearization(opt, P, operands, None, input)
-        if kind == "pgo" and len(opt.corrector) == 1:
+        if kind == "pgo" and len(opt.corrector) == 1 and target is None:
             return _pgo_linearization(opt, operands, weight, P, trivial)
+        if kind == "lpr" and weight is None and trivial and solver_ok and builtin \
+                and ((operands.b is None) if target is None else (operands.b is not None and _same(operands.b, target))):
+            return LprLinearization(opt, operands, input)
     # Default: the model runs EVERY step, as in the reference (optimizer.py:631, 646) -- as a dry trace (DryTracer): its
     # Python executes, the Lie kernels it would launch are recorded instead of launched, and the program is re-matched
     # from that trace; the fused kernels below compute the residual themselves.  Only a model a dry run cannot follow
@@ -685,8 +932,11 @@ def try_fused(opt, pg, input, target, weight, cache):
     if m is False:
         cache["dry"] = False
         with torch.no_grad(), OpTracer() as tr, _pg.GatherRecorder(params) as rec:
-            R = list(opt.model(input, target))
-        m = _match(tr, rec, R, params)
+            R = _outputs(opt, input)
+        m = _match(tr, rec, R, params, target)
+    if m is not None and m[0] == "lpr" and weight is None and trivial and solver_ok and builtin:
+        cache["program"] = (input, P, "lpr", m[1], [], None)
+        return LprLinearization(opt, m[1], input)
     if m is not None and m[0] == "se3inv" and weight is None and trivial and solver_ok and builtin:
         cache["program"] = (input, P, "se3inv", m[2], _sources(m[2]), None)     # (DeviceLM is this program's shortcut)
         return Se3InvLinearization(opt, P, m[2], None, input)
@@ -698,12 +948,23 @@ def try_fused(opt, pg, input, target, weight, cache):
     return None
 
 
-def _match(tr, rec, R, params):
-    m = match_se3inv(tr, R, params) if not rec.events else None
-    if m is not None:
-        return ("se3inv", m[0], m[1])
-    m = match_pgo(tr, rec.events, R, params)
-    return ("pgo",) + m if m is not None else None
+def _outputs(opt, input):
+    """the model's raw outputs (RobustModel subtracts the target afterwards, optimizer.py:94-101), as a list"""
+    out = opt.model.model_forward(input)
+    return list(out) if isinstance(out, (tuple, list)) else [out]
+
+
+def _match(tr, rec, R, params, target=None):
+    """``R``: the model's raw outputs (before ``- target``)"""
+    if target is None:
+        m = match_se3inv(tr, R, params) if not rec.events else None
+        if m is not None:
+            return ("se3inv", m[0], m[1])
+        m = match_pgo(tr, rec.events, R, params)
+        if m is not None:
+            return ("pgo",) + m
+    m = match_lpr(tr, R, params, target, rec.events)
+    return ("lpr", m) if m is not None else None
 
 
 def dry_program(opt, params, input, target):
@@ -712,21 +973,22 @@ def dry_program(opt, params, input, target):
     followed dry (it raised: a real forward will say whether that was the dry run's fault).  A trace whose signature
     (kernel names, operand memory / layout, data flow) equals the previous step's is the previous step's program."""
     from . import posegraph as _pg
-    if len(params) != 1 or not _is_se3_group(params[0]):
+    if len(params) != 1 or type(getattr(params[0], "ltype", None)).__name__ not in _GROUP_OF:
         return None
     st = opt.__dict__.get('_dry_state')
     if st is None:
         st = opt.__dict__['_dry_state'] = _DryState()
     try:
         with torch.no_grad(), DryTracer(st) as tr, _pg.GatherRecorder(params) as rec:
-            R = list(opt.model(input, target))
+            R = _outputs(opt, input)
         plain = [r if type(r) is torch.Tensor else torch.Tensor.as_subclass(r, torch.Tensor) for r in R]
         if any(r.device.type != "meta" for r in plain):
             return None
-        sig = (tuple(tr.sig), tuple(_tok(r) for r in plain), id(params[0]))
+        tt = None if target is None else (_tok(torch.Tensor.as_subclass(target, torch.Tensor)) if isinstance(target, torch.Tensor) else id(target))
+        sig = (tuple(tr.sig), tuple(_tok(r) for r in plain), id(params[0]), tt)
         if st.sig == sig:
             return st.match
-        m = _match(tr, rec, R, params)
+        m = _match(tr, rec, plain, params, target)
         st.sig, st.match = sig, m
         return m
     except Exception:

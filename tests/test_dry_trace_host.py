@@ -54,8 +54,9 @@ def test_python_side_changes_show_in_the_next_trace():
     assert fused.dry_program(opt, [net.pose], inp, None)[2].data_ptr() == inp.data_ptr()
     net.other = inp2                                                  # a rebound buffer: no tensor was written to
     assert fused.dry_program(opt, [net.pose], inp, None)[2].data_ptr() == inp2.data_ptr()
-    net.flip = True                                                   # a different program altogether
-    assert fused.dry_program(opt, [net.pose], inp, None) is None
+    net.flip = True                                                   # a different program altogether: Log(P^-1 X)
+    m = fused.dry_program(opt, [net.pose], inp, None)
+    assert m[0] == "lpr" and m[1].sign == -1 and m[1].kind == 0 and not m[1].left and len(m[1].right) == 1
 
 
 def test_value_dependent_models_escape_the_dry_run():
@@ -72,6 +73,38 @@ def test_value_dependent_models_escape_the_dry_run():
             return 2.0 * (self.pose @ input).Log().tensor()           # not the recognised chain
     net = Scaled(_se3(5, 0))
     assert not fused.dry_program(_Opt(net), [net.pose], _se3(5, 1), None)
+
+
+def test_product_chains_reduce_to_the_normal_form():
+    """r = Log(A^-1 * (P^-1 * B) * C^-1): constants to the left and right of the one occurrence of the parameter"""
+    class Chain(InvNet):
+        def __init__(self, init, A, B, C):
+            super().__init__(init)
+            self.A, self.B, self.C = A, B, C
+
+        def forward(self, input):
+            return (self.A.Inv() @ (self.pose.Inv() @ self.B) @ self.C.Inv()).Log().tensor()
+    A, B, C = _se3(5, 2), _se3(5, 3), _se3(1, 4)
+    net = Chain(_se3(5, 0), A, B, C)
+    m = fused.dry_program(_Opt(net), [net.pose], None, None)
+    assert m[0] == "lpr"
+    pr = m[1]
+    assert pr.sign == -1 and [(c.data_ptr(), inv) for c, inv in pr.left] == [(A.data_ptr(), True)]
+    assert [(c.data_ptr(), inv) for c, inv in pr.right] == [(B.data_ptr(), False), (C.data_ptr(), True)]
+
+    class ActNet(InvNet):
+        def forward(self, pts):
+            return self.pose.Inv().Act(pts)
+    net = ActNet(_se3(5, 0))
+    pts, tgt = torch.randn(5, 3), torch.randn(5, 3)
+    m = fused.dry_program(_Opt(net), [net.pose], pts, tgt)
+    assert m[0] == "lpr" and m[1].kind == 1 and m[1].sign == -1 and m[1].a.data_ptr() == pts.data_ptr() and m[1].b.data_ptr() == tgt.data_ptr()
+
+    class TwoP(InvNet):                                                # the parameter twice: not the normal form
+        def forward(self, input):
+            return (self.pose @ input @ self.pose).Log().tensor()
+    net = TwoP(_se3(5, 0))
+    assert fused.dry_program(_Opt(net), [net.pose], _se3(5, 1), None) is None
 
 
 def test_other_launches_are_refused_during_a_dry_trace():

@@ -311,13 +311,13 @@ def test_default_step_follows_a_rebound_buffer_and_a_flipped_attribute_at_once()
     got = float(opt.step(inp))
     want, kind = _fresh_step_loss(_Switching, pose, inp, other=inp2)
     assert kind == "fused:se3inv" and abs(got - want) <= 1e-5 * max(want, 1e-12), (got, want)
-    # an attribute flips the residual program itself: the next step runs the other program (generic block path)
+    # an attribute flips the residual program itself: the next step runs the other program (Log(P^-1 X): the normal-form kernel)
     pose = net.pose.detach().tensor().clone()
     net.flip = True
     del opt.loss
     got = float(opt.step(inp))
     want, kind = _fresh_step_loss(_Switching, pose, inp, flip=True)
-    assert opt.linearization == kind == "block" and abs(got - want) <= 1e-5 * max(want, 1e-12), (got, want)
+    assert opt.linearization == kind == "fused:lpr" and abs(got - want) <= 1e-5 * max(want, 1e-12), (got, want)
 
 
 def test_static_true_is_the_opt_out():
