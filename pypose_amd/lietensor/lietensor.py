@@ -104,21 +104,36 @@ class LieType:
                 "act4": cap + "_Act4", "adj": cap + "_AdjXa", "adjt": cap + "_AdjTXa", "jinvp": cap + "_Jinvp"}
         return getattr(_op, names[kind])   # resolved at call time (rebinding-friendly)
 
+    def _dry(self, kind, xs, out_ltype):
+        """During a dry trace (optim/fused.py DryTracer: the model's Python runs, nothing is launched) an op is a note in the
+        trace and a storage-less result that the tracer keeps per trace position -- none of the Function / autograd /
+        broadcasting machinery below is needed to produce it.  None unless a dry trace is active on this thread and the
+        Function this op would call is still this package's own (someone who rebinds it gets the ordinary path)."""
+        if not getattr(_C._tls, "dry", 0):
+            return None
+        fn = self._fn(kind)
+        if getattr(fn, "_dry_kernel", None) is None:
+            return None
+        return _op._op_tracers[-1].dry_lie(fn, xs, out_ltype)
+
     # -- Exp / Log -----------------------------------------------------------------------
     def Exp(self, x):
         if self._is_group:
             raise AttributeError("Lie Group has no Exp attribute")
-        return _wrap(self._fn("exp").apply(_raw(x)), self._group)
+        out = self._dry("exp", (x,), self._group)
+        return out if out is not None else _wrap(self._fn("exp").apply(_raw(x)), self._group)
 
     def Log(self, X):
         if not self._is_group:
             raise AttributeError("Lie Algebra has no Log attribute")
-        return _wrap(self._fn("log").apply(_raw(X)), self._algebra)
+        out = self._dry("log", (X,), self._algebra)
+        return out if out is not None else _wrap(self._fn("log").apply(_raw(X)), self._algebra)
 
     def Inv(self, X):
         if not self._is_group:
             return LieTensor(-X, ltype=self)
-        return _wrap(self._fn("inv").apply(_raw(X)), self)
+        out = self._dry("inv", (X,), self)
+        return out if out is not None else _wrap(self._fn("inv").apply(_raw(X)), self)
 
     # -- binary ops ------------------------------------------------------------------------
     def _binary(self, kind, X, other, out_ltype):
@@ -138,6 +153,9 @@ class LieType:
     def Mul(self, X, Y):
         if self._is_group:
             if isinstance(Y, LieTensor) and not Y.ltype.on_manifold:      # transform o transform
+                out = self._dry("mul", (X, Y), self)
+                if out is not None:
+                    return out
                 (x, y), out_shape = broadcast_inputs(_raw(X), _raw(Y))
                 out = self._fn("mul").apply(x, y)
                 width = -1 if out.nelement() != 0 else x.shape[-1]
@@ -443,7 +461,8 @@ class LieTensor(Tensor):
         return self.view(*shape + self.ltype.dimension)
 
     def tensor(self) -> Tensor:
-        return Tensor.as_subclass(self, Tensor)
+        pl = self.__dict__.get("_pl")          # (results of a dry trace carry their plain alias: optim/fused.py dry_lie)
+        return pl if pl is not None else Tensor.as_subclass(self, Tensor)
 
     # arithmetic: all forwarded to the type
     def Exp(self):

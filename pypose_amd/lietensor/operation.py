@@ -293,6 +293,7 @@ def _make_fwd(clsname, g, kind, doc):
 
     _Fn.__name__ = _Fn.__qualname__ = clsname
     _Fn._bwd = Bwd
+    _Fn._dry_kernel = (fwd_kernel, fin, fout)       # what a dry trace notes for this op (lietensor.LieType._dry)
     return _Fn
 
 

@@ -55,10 +55,10 @@ class OpTracer:
 class _DryState:
     """What a dry trace keeps from one step to the next (per optimizer): the `meta` outputs by trace position (the same
     program produces the same shapes every step: no allocation), and the signature + match of the latest trace."""
-    __slots__ = ("pool", "sig", "match", "base")
+    __slots__ = ("pool", "wrapped", "sig", "match", "base")
 
     def __init__(self):
-        self.pool, self.sig, self.match = {}, None, None
+        self.pool, self.wrapped, self.sig, self.match = {}, {}, None, None
         # every dry output is a view into ONE storage-less `meta` buffer at its own offset: the offset identifies the
         # value across as_subclass / view re-wrappings (a storage_offset() read is ~0.1 us; a storage handle ~1 us)
         self.base = torch.empty((1 << 60,), dtype=torch.uint8, device="meta")
@@ -120,6 +120,35 @@ class DryTracer(OpTracer):
         self.events.append((name, tuple(ins), outs))
         self.sig.append((name,) + tuple(_tok(t) for t in ins) + tuple(o.storage_offset() for o in outs))
         return outs
+
+    def dry_lie(self, fn, xs, out_ltype):
+        """the LieTensor-level entry (lietensor.LieType._dry): operands may be LieTensors; the wrapped result of this trace
+        position is kept across steps together with its plain alias"""
+        name, in_widths, out_width = fn._dry_kernel
+        ins = []
+        for x in xs:
+            pl = x.__dict__.get("_pl") if type(x) is not torch.Tensor else x
+            ins.append(pl if pl is not None else torch.Tensor.as_subclass(x, torch.Tensor))
+        x0 = ins[0]
+        lead = x0.shape[:-1]
+        for t, w in zip(ins, in_widths):
+            if t.shape[-1] != w:
+                raise ValueError(f"expected last dimension {w}, got shape {tuple(t.shape)}")
+            if t.dtype != x0.dtype or (t.device != x0.device and "meta" not in (t.device.type, x0.device.type)):
+                raise ValueError(f"pypose_amd: op {name}: inputs must share dtype / device")
+            if t.shape[:-1] != lead:
+                lead = torch.broadcast_shapes(lead, t.shape[:-1])
+        pos = self.pos
+        out = self._out(tuple(lead) + (out_width,), x0.dtype)
+        ins = tuple(ins)
+        self.events.append((name, ins, (out,)))
+        self.sig.append((name,) + tuple(_tok(t) for t in ins) + (out.storage_offset(),))
+        wrapped = self.state.wrapped.get(pos)
+        if wrapped is None or wrapped._pl is not out or wrapped.ltype is not out_ltype:
+            wrapped = _lt._wrap(out, out_ltype)
+            wrapped._pl = out
+            self.state.wrapped[pos] = wrapped
+        return wrapped
 
     def dry_gather(self, source, index, recorders):
         """``source[index]`` of a tracked 2-D parameter with an int64 index tensor: a `meta` result, or None (not ours)"""
@@ -740,8 +769,9 @@ class LprLinearization:
         self.dmin, self.dmax = float(dmin), float(dmax)
 
     def verify(self, ref, dmin, dmax, rtol=1e-3):
-        """One undamped device step on a COPY of the parameter against the generic block linearisation ``ref`` of the same
-        model: the candidate poses Exp(d) P and the residual norm."""
+        """One device step (damping 1e-2: fp32 normal equations of far-from-converged problems can be singular to rounding
+        without it) on a COPY of the parameter against the generic block linearisation ``ref`` of the same model: the
+        candidate poses Exp(d) P and the residual norm."""
         from .solver import Cholesky
         pr = self.prog
         pt = pr.P.detach().reshape(pr.n, pr.dg)
@@ -753,7 +783,7 @@ class LprLinearization:
         out = torch.zeros(2, **z)
         cfg = _LmCfg()
         cfg.high, cfg.low, cfg.up, cfg.factor, cfg.smin, cfg.smax, cfg.sdown = 0.5, 1e-3, 2.0, 0.5, 1e-6, 1e16, 0.5
-        cfg.dmin, cfg.dmax, cfg.host_damping, cfg.host_down = float(dmin), float(dmax), 0.0, 0.5
+        cfg.dmin, cfg.dmax, cfg.host_damping, cfg.host_down = float(dmin), float(dmax), 1e-2, 0.5
         cfg.strategy, cfg.reject, cfg.flags, cfg.grid_cap = 0, 0, 3, 0
         L, R, a, b = pr.operands()
         p = lambda t: None if t is None else t.data_ptr()
@@ -764,6 +794,7 @@ class LprLinearization:
                       out.data_ptr() + pt.element_size(), _C.stream_ptr(pt.device))
         _C.check(code, "pplie_lm_lpr_step")
         ref.build_normal_equations(dmin, dmax)
+        ref.damp(1e-2)
         Dr = ref.solve(Cholesky()).view(pr.n, pr.dg).contiguous()
         want = _C.row_op(pr.g + "_retract", [Dr, pt.contiguous()], (pr.dg,))[0]
         moved = (want - pt).abs().max().clamp_min(1e-30)

@@ -62,6 +62,18 @@ _DIVERGED = 100.0           # or as soon as the residual norm is this far above 
 DENSE_LIMIT = 4096          # assemble a dense A for the user's solver up to this many unknowns
 
 
+_geo_mod = None
+
+
+def _geometry():
+    """pypose_amd.function.geometry, imported on first use (it imports this package's optimizers back)"""
+    global _geo_mod
+    if _geo_mod is None:
+        from ..function import geometry as g
+        _geo_mod = g
+    return _geo_mod
+
+
 class GatherRecorder:
     """Context manager recording ``param[index_tensor]`` gathers on the tracked parameters."""
 
@@ -104,7 +116,7 @@ class GatherRecorder:
         return None
 
     def __enter__(self):
-        from ..function import geometry as _geo
+        _geo = _geometry()
         _geo._closed_recorders.append(self)
         _lt._gather_recorders.append(self)
         # plain nn.Parameters (e.g. intrinsics / 3-D points of a bundle-adjustment model) do not pass through
@@ -118,8 +130,7 @@ class GatherRecorder:
         if self._mode is not None:
             self._mode.__exit__(*exc)
         _lt._gather_recorders.remove(self)
-        from ..function import geometry as _geo
-        _geo._closed_recorders.remove(self)
+        _geometry()._closed_recorders.remove(self)
 
     def note(self, source, index, out):
         # gathers on a tracked parameter, or on a tensor derived from one (e.g. ``cat((root, nodes))`` in

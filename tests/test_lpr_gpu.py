@@ -68,7 +68,7 @@ def test_normal_form_steps_equal_the_block_path(name, group, strategy):
     assert set(rec[False][0]["kind"]) == {"block"}
     a, b = rec[True][0], rec[False][0]
     for k in range(4):
-        if b["loss"][k] > 1e-18:
+        if b["loss"][k] > 1e-12 * b["loss"][0]:
             assert abs(a["loss"][k] - b["loss"][k]) <= 1e-8 * b["loss"][k], (k, a["loss"], b["loss"])
             assert a["reject"][k] == b["reject"][k] and a["damping"][k] == pytest.approx(b["damping"][k], rel=1e-12)
     assert float((rec[True][1] - rec[False][1]).abs().max()) <= 1e-7
