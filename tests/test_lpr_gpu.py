@@ -43,8 +43,14 @@ def _problem(P, group, name, n, dtype, dev, seed=0):
     consts = {"init": mk(n), "X": mk(n), "A": mk(n), "B": mk(n), "C": mk(1)}
     args, target = (), None
     if name.startswith("act"):
-        args = (torch.randn(n, 3, dtype=dtype).to(dev),)
-        target = torch.randn(n, 3, dtype=dtype).to(dev)
+        # a well-posed fit: the targets are the points moved by a nearby transform (free targets let the scale of Sim3 / RxSO3
+        # run away to 0 or infinity on either path)
+        pts = torch.randn(n, 3, dtype=dtype).to(dev)
+        with torch.no_grad():
+            truth = mk(n)
+            moved = PROGRAMS[name](truth, consts, pts)
+        args, target = (pts,), (moved + 0.01 * torch.randn(n, 3, dtype=dtype).to(dev)).detach()
+        consts["init"] = getattr(P, "randn_" + group.lower())(n, sigma=0.05, dtype=dtype).to(dev).Exp() @ truth
     return consts, args, target
 
 
@@ -88,7 +94,8 @@ def test_normal_form_steps_equal_the_reference_optimizer(name):
     opt = pp.optim.LM(net, strategy=pp.optim.strategy.TrustRegion(radius=1e3))
     got = [float(opt.step(args[0].to(DEV) if args else (), target=None if target is None else target.to(DEV))) for _ in range(4)]
     assert opt.linearization == "fused:lpr"
-    np.testing.assert_allclose(got, want, rtol=1e-7)
+    for a, b in zip(got, want):
+        assert abs(a - b) <= 1e-7 * b + 1e-20, (got, want)
     np.testing.assert_allclose(net.pose.detach().tensor().cpu().numpy(), ref_net.pose.detach().tensor().numpy(), atol=1e-8)
 
 
@@ -99,7 +106,7 @@ def test_normal_form_fp32_million_problems_and_constant_edits():
     X = pp.randn_SE3(n, device=DEV)
     net = Prog(pp, PROGRAMS["log_pinv_x"], init=pp.randn_SE3(n, device=DEV), X=X)
     opt = pp.optim.LM(net, strategy=pp.optim.strategy.Constant(damping=1e-4))
-    l0 = float(net(()).square().sum())
+    l0 = float(net().square().sum())
     losses = [float(opt.step(())) for _ in range(3)]
     assert opt.linearization == "fused:lpr" and losses[-1] < 1e-6 * l0, (l0, losses)
     resid = (net.pose.detach().Inv() @ X).Log().tensor().abs().max().item()

@@ -41,3 +41,29 @@ for _ in range(N):
 pr.disable()
 torch.cuda.synchronize()
 pstats.Stats(pr).sort_stats("tottime").print_stats(18)
+
+# ---- the default (static=False): the model's Python runs (dry) at every step
+net2 = InvNet(init.clone())
+opt2 = pp.optim.LM(net2, strategy=pp.optim.strategy.Constant(damping=1.0))
+for _ in range(5):
+    opt2.step(inp)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(N):
+    opt2.step(inp)
+t1 = time.perf_counter()
+torch.cuda.synchronize()
+print(f"DEFAULT (dry trace every step): host enqueue {(t1 - t0) / N * 1e6:.2f} us/step")
+from pypose_amd.optim import fused as F
+params = [net2.pose]
+t0 = time.perf_counter()
+for _ in range(N):
+    F.dry_program(opt2, params, inp, None)
+print(f"  dry_program alone: {(time.perf_counter() - t0) / N * 1e6:.2f} us")
+pr = cProfile.Profile()
+pr.enable()
+for _ in range(N):
+    opt2.step(inp)
+pr.disable()
+torch.cuda.synchronize()
+pstats.Stats(pr).sort_stats("tottime").print_stats(22)
