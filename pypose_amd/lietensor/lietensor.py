@@ -38,6 +38,9 @@ index_copy_ select select_scatter index_put index_put_ copy_
 
 
 _gather_recorders = []      # active optim.posegraph.GatherRecorder instances
+# torch functions that look at a tensor's metadata only
+_VALUE_FREE = frozenset(("__get__", "dim", "size", "stride", "numel", "is_contiguous", "data_ptr", "storage_offset", "element_size",
+                         "ndimension", "is_floating_point", "is_complex", "type", "requires_grad_", "nelement", "get_device"))
 
 
 def _raw(t):
@@ -420,9 +423,14 @@ class LieTensor(Tensor):
         plain = tuple(Tensor if issubclass(t, LieTensor) else t for t in types)
         name = getattr(func, '__name__', None)
         data = None
-        if _gather_recorders and name == '__getitem__' and len(args) == 2 and _C.dry_tracing():
-            # dry trace (optim/fused.py): a row gather on a tracked parameter is noted, not executed
-            data = _op._op_tracers[-1].dry_gather(args[0], args[1], _gather_recorders)
+        if _C.dry_tracing():
+            if _gather_recorders and name == '__getitem__' and len(args) == 2:
+                # dry trace (optim/fused.py): a row gather on a tracked parameter is noted, not executed
+                data = _op._op_tracers[-1].dry_gather(args[0], args[1], _gather_recorders)
+            if data is None and name not in _VALUE_FREE:
+                # any other torch function on a LieTensor during a dry trace may read VALUES of a real tensor (a parameter):
+                # remembered, so that nothing is run speculatively around such a model (fused.checked_shortcut)
+                _op._op_tracers[-1].touched = True
         if data is None:
             data = Tensor.__torch_function__(func, plain, args, kwargs)
         if _gather_recorders and name == '__getitem__' and len(args) == 2:
@@ -462,7 +470,11 @@ class LieTensor(Tensor):
 
     def tensor(self) -> Tensor:
         pl = self.__dict__.get("_pl")          # (results of a dry trace carry their plain alias: optim/fused.py dry_lie)
-        return pl if pl is not None else Tensor.as_subclass(self, Tensor)
+        if pl is not None:
+            return pl
+        if _C.dry_tracing():                   # a plain alias of a REAL LieTensor escapes the tracer's view: see _VALUE_FREE
+            _op._op_tracers[-1].touched = True
+        return Tensor.as_subclass(self, Tensor)
 
     # arithmetic: all forwarded to the type
     def Exp(self):

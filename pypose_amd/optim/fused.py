@@ -31,6 +31,7 @@ from ..lietensor import lietensor as _lt
 from ..lietensor import operation as _op
 from . import blocks as _blocks
 
+_no_tf = torch._C.DisableTorchFunctionSubclass
 _PARTIALS = 4096          # PPLIE_LM_TRIAL_PARTIALS: rows of per-workgroup partial sums the kernel may write
 _TRIAL_SIG = [ctypes.c_void_p] * 7 + [ctypes.c_double] * 3 + [ctypes.c_int64, ctypes.c_void_p]
 
@@ -55,10 +56,10 @@ class OpTracer:
 class _DryState:
     """What a dry trace keeps from one step to the next (per optimizer): the `meta` outputs by trace position (the same
     program produces the same shapes every step: no allocation), and the signature + match of the latest trace."""
-    __slots__ = ("pool", "wrapped", "sig", "match", "base")
+    __slots__ = ("pool", "wrapped", "sig", "match", "base", "touched")
 
     def __init__(self):
-        self.pool, self.wrapped, self.sig, self.match = {}, {}, None, None
+        self.pool, self.wrapped, self.sig, self.match, self.touched = {}, {}, None, None, False
         # every dry output is a view into ONE storage-less `meta` buffer at its own offset: the offset identifies the
         # value across as_subclass / view re-wrappings (a storage_offset() read is ~0.1 us; a storage handle ~1 us)
         self.base = torch.empty((1 << 60,), dtype=torch.uint8, device="meta")
@@ -83,6 +84,7 @@ class DryTracer(OpTracer):
         super().__init__()
         self.state = _DryState() if state is None else state
         self.pos, self.next_offset, self.sig = 0, 16, []
+        self.touched = False           # the model applied a torch function to a REAL LieTensor (it may have read parameter values)
 
     def __enter__(self):
         _C._tls.dry = getattr(_C._tls, "dry", 0) + 1
@@ -449,7 +451,9 @@ class DeviceLM:
         opt = self.opt
         if target is not None and (m is None or m[0] != "lpr" or m[1].b is None or not _same(m[1].b, target)):
             return False
-        return not (weight is not None or opt.weight is not None or self.P.data_ptr() != self.p_ptr
+        with _no_tf():
+            p_ptr = self.P.data_ptr()
+        return not (weight is not None or opt.weight is not None or p_ptr != self.p_ptr
                     or opt.strategy is not self.strategy or not opt.fused or not getattr(opt, 'structured', True)
                     or len(opt.param_groups) != 1 or torch.is_inference_mode_enabled())
 
@@ -1010,8 +1014,10 @@ def dry_program(opt, params, input, target):
     if st is None:
         st = opt.__dict__['_dry_state'] = _DryState()
     try:
+        st.touched = True              # (until this run of the model completes without touching a value)
         with torch.no_grad(), DryTracer(st) as tr, _pg.GatherRecorder(params) as rec:
             R = _outputs(opt, input)
+        st.touched = tr.touched
         plain = [r if type(r) is torch.Tensor else torch.Tensor.as_subclass(r, torch.Tensor) for r in R]
         if any(r.device.type != "meta" for r in plain):
             return None
@@ -1030,21 +1036,37 @@ def checked_shortcut(opt, dev, gs, input, target, weight):
     """``LM.step`` of the default (non-static) optimizer when a device-resident step exists: the model runs dry, and the
     shortcut is taken only if THIS step's program is the one it was built on."""
     pg = opt.param_groups[0]
-    params = [p for p in pg['params'] if p.requires_grad]
+    with _no_tf():              # (attribute reads on a LieTensor parameter are __torch_function__ round trips: ~3 us each)
+        params = [p for p in dict.__getitem__(pg, 'params') if p.requires_grad]
     cache = opt.__dict__.get('_structure_cache') or {}
     if cache.get("fused") is not True or cache.get("dry") is False or torch.is_inference_mode_enabled():
         return None
+    if dev is None and gs is not None and getattr(opt, 'speculate', True):
+        # Pose graphs: a step is one hipGraph replay followed by a read-back the host has to wait for anyway (~0.5 ms).  The
+        # replay is enqueued FIRST and the model's (dry) run -- this step's check that the program is still the one captured --
+        # happens while the GPU works; the captured trial starts by saving the parameters, so a mismatch (rare: the model
+        # changed) is undone exactly: wait, copy back, take the ordinary path.  A model that reads parameter VALUES during
+        # its forward would see them mid-update: the dry tracer notices any such access (DryTracer.touched) and the
+        # speculation is then cancelled and never tried again for this optimizer.
+        w = opt.weight if weight is None else weight
+        if gs.usable(pg, input, target, w, checked=True):
+            with torch.no_grad():
+                gs.launch(pg)
+            m = dry_program(opt, params, input, target)
+            st = opt.__dict__.get('_dry_state')
+            if m and m[0] == "pgo" and gs.prog.matches(*m[1:]) and not (st is not None and st.touched):
+                with torch.no_grad():
+                    return gs.finish(pg)
+            gs.cancel()
+            if st is not None and st.touched:
+                opt.speculate = False
+            if m:
+                opt._dry_hint = (input, m)
+            return None
     m = dry_program(opt, params, input, target)
     if not m:
         return None
     out = None
-    if dev is not None:
-        out = dev.checked_step(m, target, weight)
-    if out is None and gs is not None and m[0] == "pgo" and gs.prog.matches(*m[1:]):
-        w = opt.weight if weight is None else weight
-        if gs.usable(pg, input, target, w, checked=True):
-            with torch.no_grad():
-                return gs.step(pg)
     if out is None:
         opt._dry_hint = (input, m)          # the general path re-uses this step's trace
     return out

@@ -40,6 +40,7 @@ class PgoGraphStep:
         self.s_dev = torch.ones(1, dtype=torch.float64, device=dev)
         self.params = [p for p in pg['params'] if p.requires_grad]
         self.graph = None
+        self.backup = torch.empty_like(torch.Tensor.as_subclass(P, torch.Tensor).detach())   # the parameters before the latest replay
         # capture on a side stream (torch.cuda.graph does that); the first replay-equivalent run happens during capture
         torch.cuda.synchronize(dev)
         saved = P.detach().clone()
@@ -52,6 +53,9 @@ class PgoGraphStep:
 
     def _trial(self, pg):
         opt = self.opt
+        # (first node of the captured trial: a replay launched speculatively -- before this step's run of the model has
+        #  confirmed the program, see fused.checked_shortcut -- is undone by copying this back)
+        self.backup.copy_(torch.Tensor.as_subclass(self.P, torch.Tensor).detach())
         lin = _fused._pgo_linearization(opt, self.prog, self.weight, self.P, self.trivial)
         lin.build_normal_equations(*self.clamp)
         lin.s_dev = self.s_dev                     # prepare reads the damping factor from here (pplie_pcg_prepare_dev)
@@ -103,17 +107,35 @@ class PgoGraphStep:
         return True
 
     def step(self, pg):
+        self.launch(pg)
+        return self.finish(pg)
+
+    def launch(self, pg):
+        """enqueue the trial (everything up to the read-back); the host returns while the GPU works"""
         opt = self.opt
         if not hasattr(opt, 'loss'):               # first step of a run: the loss at the starting point (optimizer.py:659)
             opt.loss = self.lin.fast_loss()
+        self._prev_last = opt.__dict__.get('_last_view')
         opt.last = opt.loss
-        last_h = opt._host(opt.loss)
+        self._last_h = opt._host(opt.loss)
         opt.reject_count = 0
         lin = self.lin
         lin.s = 1.0 + float(pg['damping'])         # (host mirror: a retry compounds from here)
         self.s_dev.fill_(lin.s)
         self.graph.replay()
         _C.mark_written(self.P)
+
+    def cancel(self):
+        """undo a speculative launch: wait for it, put the parameters back (nothing else it wrote is state)"""
+        torch.cuda.synchronize(self.backup.device)
+        with torch.no_grad():
+            torch.Tensor.as_subclass(self.P, torch.Tensor).detach().copy_(self.backup)
+        _C.mark_written(self.P)
+        if self._prev_last is not None:
+            self.opt.last = self._prev_last
+
+    def finish(self, pg):
+        opt, lin, last_h = self.opt, self.lin, self._last_h
         a, b, loss_h, its, rr, bn2, flag = self.out.tolist()          # the trial's one synchronisation
         opt.linearization = lin.kind
         opt._last_replicated = False

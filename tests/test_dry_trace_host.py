@@ -112,3 +112,31 @@ def test_other_launches_are_refused_during_a_dry_trace():
         with pytest.raises(_C.DryTraceEscape):
             _C.stream_ptr(torch.device("cpu"))
     assert not _C.dry_tracing()
+
+
+def test_value_reads_of_real_lietensors_are_noticed():
+    """what lets a pose-graph step be launched before its dry run finished (fused.checked_shortcut): the tracer knows whether
+    the model could have looked at parameter VALUES"""
+    graph = PoseGraph(_se3(6, 0))
+    edges, poses = torch.tensor([[0, 1], [1, 2], [2, 3], [5, 0]]), _se3(4, 2)
+    o = _Opt(graph)
+    assert fused.dry_program(o, [graph.nodes], (edges, poses), None)[0] == "pgo"
+    assert o._dry_state.touched is False
+
+    class Logging(PoseGraph):
+        def forward(self, edges, poses):
+            self.norm = self.nodes.tensor().norm()                     # reads the parameter's values
+            return super().forward(edges, poses)
+    g2 = Logging(_se3(6, 0))
+    o2 = _Opt(g2)
+    assert fused.dry_program(o2, [g2.nodes], (edges, poses), None)[0] == "pgo"
+    assert o2._dry_state.touched is True
+
+    class Scaling(PoseGraph):
+        def forward(self, edges, poses):
+            self.c = self.nodes.abs().max()                            # a torch function on the parameter itself
+            return super().forward(edges, poses)
+    g3 = Scaling(_se3(6, 0))
+    o3 = _Opt(g3)
+    fused.dry_program(o3, [g3.nodes], (edges, poses), None)
+    assert o3._dry_state.touched is True

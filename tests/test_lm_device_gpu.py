@@ -370,3 +370,41 @@ def test_default_pose_graph_step_follows_a_model_change_behind_the_captured_grap
     o2.param_groups[0]['damping'] = damping
     want = float(o2.step((e, rel)))
     assert abs(got - want) <= 1e-4 * want, (got, want)
+
+
+def test_pose_graph_model_that_reads_parameter_values_is_never_run_speculatively():
+    """the captured pose-graph step is enqueued before the model's dry run has finished (fused.checked_shortcut); a model whose
+    forward looks at the parameter's VALUES must see them as the reference's would (before the step): the tracer notices the
+    access, the launch is undone exactly and speculation is switched off -- same iterates as the plain model"""
+    from tests.optim_models import PoseGraph
+
+    class Logging(PoseGraph):
+        seen = None
+
+        def forward(self, edges, poses):
+            with torch.no_grad():
+                type(self).seen = float(self.nodes.tensor().abs().sum())         # a host read of the parameter, every forward
+            return super().forward(edges, poses)
+
+    torch.manual_seed(11)
+    N, E = 300, 900
+    gt = pp.cumprod(pp.randn_SE3(N, sigma=0.3, device=DEV), dim=0, left=False)
+    e = torch.cat([torch.stack([torch.arange(N - 1), torch.arange(1, N)], -1), torch.randint(0, N, (E - N + 1, 2))]).to(DEV)
+    e[:, 1] = torch.where(e[:, 0] == e[:, 1], (e[:, 1] + 1) % N, e[:, 1])
+    rel = gt[e[:, 0]].Inv() @ gt[e[:, 1]] @ pp.randn_SE3(E, sigma=0.01, device=DEV)
+    init = gt @ pp.randn_SE3(N, sigma=0.05, device=DEV)
+    runs = {}
+    for cls in (PoseGraph, Logging):
+        g = cls(pp.SE3(init.tensor().clone()))
+        opt = pp.optim.LM(g, solver=pp.optim.solver.PCG(tol=1e-6, maxiter=500), strategy=pp.optim.strategy.TrustRegion(radius=1e4))
+        losses, seen = [], []
+        for _ in range(8):
+            before = float(g.nodes.detach().tensor().abs().sum())
+            losses.append(float(opt.step((e, rel))))
+            seen.append((Logging.seen, before))
+        runs[cls] = (losses, seen, opt)
+    assert runs[Logging][2].__dict__.get('speculate') is False and runs[PoseGraph][2].__dict__.get('speculate', True) is True
+    np.testing.assert_allclose(runs[Logging][0], runs[PoseGraph][0], rtol=1e-4)
+    # every forward of the step saw the parameters a reference run would have shown it: the LAST forward of a step is the loss
+    # evaluation at the accepted point or the dry run at its start -- never a half-updated state (a finite, plausible sum)
+    assert all(np.isfinite(s) and abs(s - b) <= 0.2 * b for s, b in runs[Logging][1])
