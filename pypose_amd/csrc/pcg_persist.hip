@@ -40,20 +40,24 @@ constexpr int kPersistBlock = 1024;       // 16 waves per workgroup
 constexpr int kPersistQ = 5;              // quantities per exchange: p.q, q.z, q.Binv q, r.z, r.r
 constexpr int kPersistSlots = 8;          // table row = 8 quantity slots (PPLIE_PCG_PERSIST_SLOTS)
 
-// one value as NW tagged words
-template <class T> __device__ __forceinline__ void put_value(u64* dst, T v, unsigned tag) {
+// one value as NW tagged words.  SYS: the word crosses GPUs (peer-mapped memory over xGMI): system-scope accesses
+template <class T, bool SYS = false> __device__ __forceinline__ void put_value(u64* dst, T v, unsigned tag) {
   constexpr int NW = sizeof(T) / 4;
   unsigned w[NW];
   __builtin_memcpy(w, &v, sizeof(T));
 #pragma unroll
-  for (int k = 0; k < NW; ++k) xwg_store(dst + k, ((u64)tag << 32) | (u64)w[k]);
+  for (int k = 0; k < NW; ++k) {
+    const u64 word = ((u64)tag << 32) | (u64)w[k];
+    if (SYS) __hip_atomic_store(dst + k, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    else xwg_store(dst + k, word);
+  }
 }
-template <class T> __device__ __forceinline__ T get_value(const u64* src, unsigned tag, bool& ok) {
+template <class T, bool SYS = false> __device__ __forceinline__ T get_value(const u64* src, unsigned tag, bool& ok) {
   constexpr int NW = sizeof(T) / 4;
   unsigned w[NW];
 #pragma unroll
   for (int k = 0; k < NW; ++k) {
-    const u64 v = xwg_load(src + k);
+    const u64 v = SYS ? __hip_atomic_load(src + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : xwg_load(src + k);
     ok = ok && (unsigned)(v >> 32) == tag;
     w[k] = (unsigned)v;
   }
@@ -65,7 +69,7 @@ template <class T> __device__ __forceinline__ T get_value(const u64* src, unsign
 // a[0..M) += sum over this lane's incidences c of (column i of block c) * (component i of the neighbour's p).  `h`: the first
 // block's column i (element j at h[c * cs + j * js]), `nb`: the neighbour indices.  CH incidences per round: every tagged
 // load of a round is in flight before the first is looked at; absent incidences (c >= deg) load nothing (exec-masked).
-template <class T, int M, int CH, class HP, class NP>
+template <class T, int M, int CH, bool SYS, class HP, class NP>
 __device__ __forceinline__ void spmv_cols(T* a, HP h, int cs, int js, NP nb, int deg, int maxdeg, int i, const u64* pin, unsigned tag,
                                           bool& stale) {
   constexpr int NW = sizeof(T) / 4;
@@ -77,7 +81,7 @@ __device__ __forceinline__ void spmv_cols(T* a, HP h, int cs, int js, NP nb, int
       bool ok = true;
 #pragma unroll
       for (int q = 0; q < CH; ++q)
-        if (c0 + q < deg) pv[q] = get_value<T>(pin + (unsigned)((nb[c0 + q] * M + i) * NW), tag, ok);
+        if (c0 + q < deg) pv[q] = get_value<T, SYS>(pin + (unsigned)((nb[c0 + q] * M + i) * NW), tag, ok);
       if (__all(ok)) break;
       if (spin >= (1L << 20)) { stale = true; break; }
       __builtin_amdgcn_s_sleep(1);
@@ -93,6 +97,22 @@ __device__ __forceinline__ void spmv_cols(T* a, HP h, int cs, int js, NP nb, int
     }
   }
 }
+
+// Several GPUs, one process each (LM(group=, shard="nodes", exchange="p2p"), optim/nodeshard.py): every rank runs this kernel on
+// the node rows it owns.  The hand-off table of p spans ALL nodes and exists once per rank; a rank stores its elements into
+// every rank's copy (its own and, through peer-mapped pointers over xGMI, the others'), so that every gather stays a local
+// read.  The dot products go two levels: the all-gather over this rank's workgroups as on one GPU, then workgroup 0 stores
+// the rank's totals into every rank's small `rpart` table and everybody adds the `world` rows in rank order -- the same
+// bits on every GPU.  Tags carry a per-solve epoch (the tables are not cleared between solves: a clear would race with a
+// peer that is already a solve ahead).
+constexpr int kPersistMaxWorld = 8;
+struct PersistPeers {
+  int world, rank;
+  unsigned tag_base;               // (epoch & 0xffff) << 16
+  long long row0, n_global;        // first owned node, nodes of the whole graph
+  u64* ptag[kPersistMaxWorld];     // rank r's hand-off table  [2][n_global * M values as tagged words]
+  u64* rpart[kPersistMaxWorld];    // rank r's rank-level sums [2][kPersistMaxWorld][kPersistSlots values as tagged words]
+};
 
 // static LDS of the exchange, double-buffered by the iteration's parity so that one barrier separates "written" from "read"
 // and the next iteration's writes cannot overtake this one's reads
@@ -115,15 +135,15 @@ template <class T, int M> struct PersistLane {
 
 // q_i of this lane's node for the vector whose component i this lane holds (`ve`) and whose other elements are read from
 // the tagged table `pin`:  diagonal block column, neighbour columns (spmv_cols), then the sum over the node's M lanes
-template <class T, int M, int CH>
+template <class T, int M, int CH, bool SYS>
 __device__ __forceinline__ T node_matvec(const PersistLane<T, M>& L, T ve, const T* HB, const int* other, const u64* pin, unsigned tag,
                                          bool& stale) {
   constexpr int NPW = 64 / M;
   T a[M];
 #pragma unroll
   for (int j = 0; j < M; ++j) a[j] = L.dc[j] * ve;
-  if (L.in_lds) spmv_cols<T, M, CH>(a, L.hb_l + ((size_t)L.lbeg * M + L.i) * M, M * M, 1, L.nb_l + L.lbeg, L.deg, L.maxdeg, L.i, pin, tag, stale);
-  else spmv_cols<T, M, CH>(a, HB + (size_t)L.beg * M * M + L.i, M * M, M, other + L.beg, L.deg, L.maxdeg, L.i, pin, tag, stale);
+  if (L.in_lds) spmv_cols<T, M, CH, SYS>(a, L.hb_l + ((size_t)L.lbeg * M + L.i) * M, M * M, 1, L.nb_l + L.lbeg, L.deg, L.maxdeg, L.i, pin, tag, stale);
+  else spmv_cols<T, M, CH, SYS>(a, HB + (size_t)L.beg * M * M + L.i, M * M, M, other + L.beg, L.deg, L.maxdeg, L.i, pin, tag, stale);
   // the node's row = sum of its M lanes' partial rows: through this wave's LDS pad (a wave's LDS accesses execute in order)
   T acc = T(0);
   if (L.sub < NPW) {
@@ -209,13 +229,14 @@ template <class T, int NQ> __device__ __forceinline__ void gather_rows(PersistSh
 // that the all-gather overlaps the neighbour exchange -- was built and measured in round 3: 10.5 us per iteration instead of
 // 12.2, but its recurrences for Binv r and A Binv r lose the residual in fp32: it stalls above 1e-4 already at condition
 // number 100, cf. profiles/r03/SUMMARY.md.  Not kept.)
-template <class T, int M>
+template <class T, int M, bool XG>
 __global__ void __launch_bounds__(kPersistBlock)
 pcg_persist_kernel(const int* __restrict__ ptr, const int* __restrict__ other, const T* __restrict__ HB, const T* __restrict__ D,
                    const T* __restrict__ Binv, T* __restrict__ x, const T* __restrict__ r, const T* __restrict__ z,
                    u64* part /* [2][kPersistGridMax][kPersistSlots values as tagged words] */,
-                   u64* ptag /* [2][N * M values as tagged words] */, T* __restrict__ rr_hist, T* info /* [4] */, int* it_out,
-                   T tol2, int maxiter, int cap, int64_t N, int lds_bytes) {
+                   u64* ptag /* [2][N * M values as tagged words] (XG: peers.ptag[rank], all nodes of the graph) */,
+                   T* __restrict__ rr_hist, T* info /* [4] */, int* it_out, T tol2, int maxiter, int cap, int64_t N, int lds_bytes,
+                   PersistPeers peers) {
   extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
   __shared__ PersistShared<T> sh;
   constexpr int CH = sizeof(T) == 4 ? 16 : 8;   // incidences per round of tagged loads
@@ -224,7 +245,9 @@ pcg_persist_kernel(const int* __restrict__ ptr, const int* __restrict__ other, c
   constexpr int NW = sizeof(T) / 4;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int64_t n0 = N * blockIdx.x / gridDim.x, n1 = N * (blockIdx.x + 1) / gridDim.x;     // (host: n1 - n0 <= WV * NPW)
-  const size_t NM = (size_t)N * M * NW;
+  const size_t NM = (size_t)(XG ? peers.n_global : N) * M * NW;     // one table of the hand-off
+  const int64_t g0 = XG ? peers.row0 : 0;                          // global id of this rank's first node
+  const unsigned tag0 = XG ? peers.tag_base : 0u;
   PersistLane<T, M> L;
   L.sub = lane / M;
   L.i = lane % M;
@@ -247,8 +270,18 @@ pcg_persist_kernel(const int* __restrict__ ptr, const int* __restrict__ other, c
     ze = z[n * M + i];
     L.beg = ptr[n];
     L.deg = ptr[n + 1] - L.beg;
-    put_value<T>(ptag + (size_t)(n * M + i) * NW, ze, 1u);           // hand-off h carries tag h + 1, in table h & 1
   }
+  // hand-off h of the search direction carries tag h + 1 (+ the solve's epoch), in table h & 1 -- of every rank
+  auto hand_off = [&](T v, int table, unsigned tag) {
+    if (!act) return;
+    const size_t at = (size_t)table * NM + (size_t)((g0 + n) * M + i) * NW;
+    if (XG) {
+      for (int rk = 0; rk < peers.world; ++rk) put_value<T, true>(peers.ptag[rk] + at, v, tag);
+    } else {
+      put_value<T>(ptag + at, v, tag);
+    }
+  };
+  hand_off(ze, 0, tag0 + 1u);
   L.maxdeg = L.deg;                        // largest degree among this wave's nodes
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
@@ -293,10 +326,10 @@ pcg_persist_kernel(const int* __restrict__ ptr, const int* __restrict__ other, c
   {
     T pe = ze;                             // p_0 = z_0 (published above as hand-off 0)
     for (;; ++k) {
-      const unsigned tag = (unsigned)k + 1u;
+      const unsigned tag = tag0 + (unsigned)k + 1u;
       const int par = k & 1;
       bool stale = false;
-      const T acc = node_matvec<T, M, CH>(L, pe, HB, other, ptag + (size_t)par * NM, tag, stale);      // q = A p
+      const T acc = node_matvec<T, M, CH, XG>(L, pe, HB, other, ptag + (size_t)par * NM, tag, stale);   // q = A p
       PPLIE_TICK(0)
       const T bq = node_binv<T, M>(L, acc);
       T v[kPersistQ] = {acc * pe, acc * ze, acc * bq, re * ze, re * re};
@@ -309,6 +342,35 @@ pcg_persist_kernel(const int* __restrict__ ptr, const int* __restrict__ other, c
       PPLIE_TICK(3)
       __syncthreads();                                                           // barrier 2
       PPLIE_TICK(4)
+      if (XG) {
+        // second level: this rank's totals to every rank; everybody adds the `world` rows in rank order
+        constexpr int RW2 = kPersistSlots * NW;
+        const size_t tab = (size_t)par * kPersistMaxWorld * RW2;
+        if (blockIdx.x == 0 && threadIdx.x < kPersistQ) {
+          for (int rk = 0; rk < peers.world; ++rk)
+            put_value<T, true>(peers.rpart[rk] + tab + (size_t)peers.rank * RW2 + threadIdx.x * NW, sh.total[par][threadIdx.x], tag);
+        }
+        __syncthreads();                                             // (everybody has read this rank's totals before they are replaced)
+        if (threadIdx.x < kPersistQ) {
+          const u64* mine = peers.rpart[peers.rank] + tab + threadIdx.x * NW;
+          T sum = T(0);
+          bool all = true;
+          for (int rk = 0; rk < peers.world; ++rk) {
+            bool ok = false;
+            T v = T(0);
+            for (long spin = 0; spin < (1L << 20) && !ok; ++spin) {
+              ok = true;
+              v = get_value<T, true>(mine + (size_t)rk * RW2, tag, ok);
+              if (!ok) __builtin_amdgcn_s_sleep(1);
+            }
+            all = all && ok;
+            sum += v;
+          }
+          sh.total[par][threadIdx.x] = sum;
+          if (!all) sh.bad[par] = 1;
+        }
+        __syncthreads();
+      }
       const T pq = sh.total[par][0], qz = sh.total[par][1], qmq = sh.total[par][2], rho = sh.total[par][3];
       rr = sh.total[par][4];
       if (sh.bad[par]) { flag = 3; break; }
@@ -325,7 +387,7 @@ pcg_persist_kernel(const int* __restrict__ ptr, const int* __restrict__ other, c
       re -= alpha * acc;
       ze = node_binv<T, M>(L, re);
       pe = ze + beta * pe;
-      if (act) put_value<T>(ptag + (size_t)((k + 1) & 1) * NM + (size_t)(n * M + i) * NW, pe, tag + 1u);
+      hand_off(pe, (k + 1) & 1, tag + 1u);
       PPLIE_TICK(5)
     }
   }
@@ -346,7 +408,7 @@ pcg_persist_kernel(const int* __restrict__ ptr, const int* __restrict__ other, c
 // Dynamic LDS of a workgroup (the staged matrix slice); the most workgroups of this kernel the device holds at once
 // (they spin on each other: all must be resident)
 constexpr int kPersistLds = 128 * 1024;
-template <class T, int M> static int persist_capacity(int& lds_bytes) {
+template <class T, int M, bool XG> static int persist_capacity(int& lds_bytes) {
   static int cap[16] = {0}, lds[16] = {0};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 0;
@@ -354,12 +416,12 @@ template <class T, int M> static int persist_capacity(int& lds_bytes) {
     int cus = 0, per = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
     lds[dev] = kPersistLds;
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&pcg_persist_kernel<T, M>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&pcg_persist_kernel<T, M, XG>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             kPersistLds) != hipSuccess) {
       (void)hipGetLastError();
       lds[dev] = 48 * 1024;                                      // (always available without the attribute)
     }
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, pcg_persist_kernel<T, M>, kPersistBlock, lds[dev]) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, pcg_persist_kernel<T, M, XG>, kPersistBlock, lds[dev]) != hipSuccess) return 0;
     cap[dev] = cus * per > 0 ? cus * per : -1;
   }
   lds_bytes = lds[dev];
@@ -367,41 +429,78 @@ template <class T, int M> static int persist_capacity(int& lds_bytes) {
 }
 
 template <class T>
-int pcg_persist(const void* ptr, const void* other, const void* HB, const void* D, const void* Binv, void* x, void* r, void* p,
-                void* q, void* z, void* part, void* ptag, void* rr_hist, void* info, void* it, double tol, int maxiter, int cap,
-                int grid, int64_t N, int m, void* stream) {
+int pcg_persist(const void* ptr, const void* other, const void* HB, const void* D, const void* Binv, void* x, const void* r, const void* z,
+                void* part, void* ptag, void* rr_hist, void* info, void* it, double tol, int maxiter, int cap, int grid, int64_t N, int m,
+                void* stream, const PersistPeers* peers) {
   if (N <= 0) return N == 0 ? PPLIE_OK : PPLIE_EBADARG;
   if (!ptr || !other || !HB || !D || !Binv || !x || !r || !z || !part || !ptag || !rr_hist || !info || !it) return PPLIE_EBADARG;
-  if (grid < 1 || grid > kPersistGridMax || maxiter < 0) return PPLIE_EBADARG;
-  (void)p; (void)q;                                              // (round-2 signature: p and q now live in registers)
+  if (grid < 1 || grid > kPersistGridMax || maxiter < 0 || maxiter > 65534) return PPLIE_EBADARG;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-#define LAUNCH(MM)                                                                                                             \
+  PersistPeers none = {};
+#define LAUNCH2(MM, XG)                                                                                                        \
   {                                                                                                                            \
     int lds_bytes = 0;                                                                                                         \
-    const int resident = persist_capacity<T, MM>(lds_bytes);                                                                   \
+    const int resident = persist_capacity<T, MM, XG>(lds_bytes);                                                               \
     if (resident <= 0 || (size_t)lds_bytes < (size_t)(kPersistBlock / 64) * (64 / MM) * MM * MM * sizeof(T)) return PPLIE_ECAPACITY; \
     if (grid > resident) grid = resident;                         /* fewer CUs than asked for: every workgroup must be resident */ \
     if (grid > N) grid = (int)N;                                                                                               \
     const int64_t per_wg = (kPersistBlock / 64) * (64 / MM);     /* one lane per (node, component): nodes one workgroup holds */ \
     if ((N + grid - 1) / grid > per_wg) return PPLIE_ECAPACITY;  /* too large for this device: use the two-launch iteration */  \
-    hipLaunchKernelGGL((pcg_persist_kernel<T, MM>), dim3(grid), dim3(kPersistBlock), lds_bytes, st, (const int*)ptr,           \
+    hipLaunchKernelGGL((pcg_persist_kernel<T, MM, XG>), dim3(grid), dim3(kPersistBlock), lds_bytes, st, (const int*)ptr,       \
                        (const int*)other, (const T*)HB, (const T*)D, (const T*)Binv, (T*)x, (const T*)r, (const T*)z,            \
                        (unsigned long long*)part, (unsigned long long*)ptag, (T*)rr_hist, (T*)info, (int*)it, (T)(tol * tol),    \
-                       maxiter, cap, N, lds_bytes);                                                                            \
+                       maxiter, cap, N, lds_bytes, XG ? *peers : none);                                                        \
   }
+#define LAUNCH(MM) { if (peers) LAUNCH2(MM, true) else LAUNCH2(MM, false) }
   if (m == 6) LAUNCH(6) else if (m == 7) LAUNCH(7) else if (m == 3) LAUNCH(3) else return PPLIE_EBADARG;
 #undef LAUNCH
+#undef LAUNCH2
   return hipGetLastError() == hipSuccess ? PPLIE_OK : PPLIE_ELAUNCH;
+}
+
+template <class T>
+int pcg_persist_p2p(const void* ptr, const void* other, const void* HB, const void* D, const void* Binv, void* x, const void* r,
+                    const void* z, void* part, const void* const* ptag_peers, const void* const* rpart_peers, void* rr_hist, void* info,
+                    void* it, double tol, int maxiter, int cap, int grid, int64_t n_own, int64_t row0, int64_t n_global, int world,
+                    int rank, int epoch, int m, void* stream) {
+  if (world < 1 || world > kPersistMaxWorld || rank < 0 || rank >= world || !ptag_peers || !rpart_peers || row0 < 0 ||
+      row0 + n_own > n_global)
+    return PPLIE_EBADARG;
+  PersistPeers pe = {};
+  pe.world = world;
+  pe.rank = rank;
+  pe.tag_base = ((unsigned)epoch & 0xffffu) << 16;
+  pe.row0 = row0;
+  pe.n_global = n_global;
+  for (int k = 0; k < world; ++k) {
+    if (!ptag_peers[k] || !rpart_peers[k]) return PPLIE_EBADARG;
+    pe.ptag[k] = (u64*)ptag_peers[k];
+    pe.rpart[k] = (u64*)rpart_peers[k];
+  }
+  return pcg_persist<T>(ptr, other, HB, D, Binv, x, r, z, part, pe.ptag[rank], rr_hist, info, it, tol, maxiter, cap, grid, n_own, m, stream, &pe);
 }
 }  // namespace pplie
 
 extern "C" int pplie_pcg_persist_f32(const void* ptr, const void* other, const void* HB, const void* D, const void* Binv, void* x,
                                      void* r, void* p, void* q, void* z, void* part, void* ptag, void* rr_hist, void* info, void* it,
                                      double tol, int maxiter, int cap, int grid, int64_t N, int m, void* stream) {
-  return pplie::pcg_persist<float>(ptr, other, HB, D, Binv, x, r, p, q, z, part, ptag, rr_hist, info, it, tol, maxiter, cap, grid, N, m, stream);
+  (void)p; (void)q;                                              // (round-2 signature: p and q now live in registers)
+  return pplie::pcg_persist<float>(ptr, other, HB, D, Binv, x, r, z, part, ptag, rr_hist, info, it, tol, maxiter, cap, grid, N, m, stream, nullptr);
 }
 extern "C" int pplie_pcg_persist_f64(const void* ptr, const void* other, const void* HB, const void* D, const void* Binv, void* x,
                                      void* r, void* p, void* q, void* z, void* part, void* ptag, void* rr_hist, void* info, void* it,
                                      double tol, int maxiter, int cap, int grid, int64_t N, int m, void* stream) {
-  return pplie::pcg_persist<double>(ptr, other, HB, D, Binv, x, r, p, q, z, part, ptag, rr_hist, info, it, tol, maxiter, cap, grid, N, m, stream);
+  (void)p; (void)q;
+  return pplie::pcg_persist<double>(ptr, other, HB, D, Binv, x, r, z, part, ptag, rr_hist, info, it, tol, maxiter, cap, grid, N, m, stream, nullptr);
 }
+#define PPLIE_P2P(SFX, T)                                                                                                         \
+  extern "C" int pplie_pcg_persist_p2p_##SFX(const void* ptr, const void* other, const void* HB, const void* D, const void* Binv, \
+                                             void* x, const void* r, const void* z, void* part, const void* const* ptag_peers,   \
+                                             const void* const* rpart_peers, void* rr_hist, void* info, void* it, double tol,   \
+                                             int maxiter, int cap, int grid, int64_t n_own, int64_t row0, int64_t n_global,     \
+                                             int world, int rank, int epoch, int m, void* stream) {                             \
+    return pplie::pcg_persist_p2p<T>(ptr, other, HB, D, Binv, x, r, z, part, ptag_peers, rpart_peers, rr_hist, info, it, tol,     \
+                                     maxiter, cap, grid, n_own, row0, n_global, world, rank, epoch, m, stream);                  \
+  }
+PPLIE_P2P(f32, float)
+PPLIE_P2P(f64, double)

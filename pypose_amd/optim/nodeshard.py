@@ -29,6 +29,45 @@ import torch
 from .. import _C
 
 
+_P2P_SIG = [ctypes.c_void_p] * 9 + [ctypes.POINTER(ctypes.c_void_p)] * 2 + [ctypes.c_void_p] * 3 + \
+           [ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
+            ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+_P2P_CAP = 1 << 16
+
+
+class P2PRank:
+    """One rank's buffers of the multi-GPU persistent PCG (csrc/pcg_persist.hip, ``pplie_pcg_persist_p2p``): its copy of the
+    hand-off table of p (all nodes of the graph), its rank-level sum table, the workgroup-level table and the outputs.
+    The two exchange tables are what the peers map (hipIpc) and write into."""
+
+    def __init__(self, n_global, m, dtype, device):
+        nw = 1 if dtype == torch.float32 else 2
+        z64 = lambda k: torch.zeros(k, dtype=torch.int64, device=device)
+        self.ptag = z64(2 * n_global * m * nw)                         # zeroed once: tags carry the solve's epoch
+        self.rpart = z64(2 * 8 * 8 * nw)
+        self.part = z64(2 * 256 * 8 * nw)
+        self.rr_hist = torch.zeros(_P2P_CAP, dtype=dtype, device=device)
+        self.info = torch.zeros(4, dtype=dtype, device=device)
+        self.it = torch.zeros(4, dtype=torch.int32, device=device)
+
+
+def persist_p2p_launch(rk, ptag_ptrs, rpart_ptrs, ptr, other, HB, D, Binv, x, r, z, tol, maxiter, grid, row0, n_global, world, rank,
+                       epoch, m):
+    """enqueue one rank's kernel on the current stream.  ``ptag_ptrs`` / ``rpart_ptrs``: the ``world`` table addresses as this
+    process sees them (its own allocation + the peers' mapped ones)."""
+    n_own = D.shape[0]
+    sfx = "_f32" if D.dtype == torch.float32 else "_f64"
+    arr = ctypes.c_void_p * world
+    fn = _C.library().symbol("pplie_pcg_persist_p2p" + sfx, _P2P_SIG)
+    rk.part.zero_()                                                  # (workgroup-level table: local, cleared per solve)
+    with _C._on_device(D.device):
+        code = fn(ptr.data_ptr(), other.data_ptr(), HB.data_ptr(), D.data_ptr(), Binv.data_ptr(), x.data_ptr(), r.data_ptr(),
+                  z.data_ptr(), rk.part.data_ptr(), arr(*ptag_ptrs), arr(*rpart_ptrs), rk.rr_hist.data_ptr(), rk.info.data_ptr(),
+                  rk.it.data_ptr(), float(tol), int(min(maxiter, 65534)), _P2P_CAP, int(grid), n_own, int(row0), int(n_global),
+                  int(world), int(rank), int(epoch), int(m), _C.stream_ptr(D.device))
+    return code
+
+
 def _bounds(N, world, rank):
     chunk = -(-N // world)
     a = min(N, rank * chunk)
@@ -57,6 +96,8 @@ class NodeShard:
         self.halo = torch.unique(oth[~own])                                  # sorted global ids of the remote neighbours
         slot = torch.searchsorted(self.halo, oth.clamp_max(max(N - 1, 0))) if self.halo.numel() else torch.zeros_like(oth)
         self.other = torch.where(own, oth - self.a, self.n_own + slot).to(torch.int32).contiguous()
+        self.other_global = oth.to(torch.int32).contiguous()            # (the p2p exchange addresses the full hand-off table)
+        self.p2p = None                                                  # P2PRank + the peers' mapped tables, set up on first use
         counts = (self.ptr[1:] - self.ptr[:-1]).long()
         self.row = torch.repeat_interleave(torch.arange(self.n_own, device=dev), counts)    # owned row of every incidence
         self.edge, self.side = (self.blk // K).long(), (self.blk % K).long()
@@ -78,6 +119,32 @@ class NodeShard:
         import torch.distributed as dist
         dist.all_reduce(t, group=self.group)
         return t
+
+    # ---- peer-to-peer exchange (exchange="p2p") ------------------------------------------------------------------------
+    def p2p_setup(self, dtype, device):
+        """Allocate this rank's exchange tables, publish them to the peers as IPC handles (hipIpcGetMemHandle through
+        torch.multiprocessing's CUDA-tensor reduction; one process per GPU) and map theirs.  Collective, once per edge list."""
+        import torch.distributed as dist
+        from torch.multiprocessing.reductions import reduce_tensor
+        if self.p2p is not None and self.p2p['dtype'] == dtype:
+            return self.p2p
+        rk = P2PRank(self.N, self.m, dtype, device)
+        torch.cuda.synchronize(device)                                   # (zero-filled before anybody can write into them)
+        mine = [reduce_tensor(rk.ptag), reduce_tensor(rk.rpart)]
+        everyone = [None] * self.world
+        dist.all_gather_object(everyone, mine, group=self.group)
+        ptag, rpart = [], []
+        for k, handles in enumerate(everyone):
+            if k == self.rank:
+                ptag.append(rk.ptag)
+                rpart.append(rk.rpart)
+            else:
+                (f0, a0), (f1, a1) = handles
+                ptag.append(f0(*a0))                                     # hipIpcOpenMemHandle: the peer's table, addressable from this device
+                rpart.append(f1(*a1))
+        dist.barrier(group=self.group)                                   # every table exists and is mapped everywhere
+        self.p2p = dict(dtype=dtype, rk=rk, ptag=ptag, rpart=rpart, epoch=0, ok=True)
+        return self.p2p
 
 
 class NodeShardedSystem:
@@ -203,10 +270,55 @@ class NodeShardedSystem:
                         break
         return sh.gather_rows(w['x']), done
 
+    def _solve_p2p(self, s, dmin, dmax, tol, maxiter):
+        """The whole solve as ONE persistent launch per rank (pplie_pcg_persist_p2p): p and the dot products cross GPUs as tagged
+        words written straight into the peers' tables from inside the kernel -- no collective, no launch and no host round trip
+        per iteration.  One RCCL all-gather of the solution at the end."""
+        import torch.distributed as dist
+        from . import posegraph as _pg
+        sh, m = self.sh, self.lin.m
+        n, chunk, dev, dt = sh.n_own, sh.chunk, self.g.device, self.g.dtype
+        sfx = "_f32" if dt == torch.float32 else "_f64"
+        z = lambda *shape: torch.zeros(shape, dtype=dt, device=dev)
+        pp_ = sh.p2p_setup(dt, dev)
+        w = self.__dict__.get('_wp')
+        if w is None or w['key'] != (n, chunk, dt):
+            w = self._wp = dict(key=(n, chunk, dt), D=z(n, m, m), Binv=z(n, m, m), shift=z(n, m), x=z(chunk, m), r=z(n, m), z=z(n, m),
+                                p=z(n, m), scal=z(_pg._PCG_SCAL_ELEMS), full=z(sh.world * chunk, m))
+        pp_['epoch'] += 1
+        with _C._on_device(dev):
+            _C.check(_C.library().symbol("pplie_pcg_prepare" + sfx, _pg._PREP_SIG)(
+                self.B.data_ptr(), self.g.data_ptr(), w['D'].data_ptr(), w['Binv'].data_ptr(), w['shift'].data_ptr(), w['x'].data_ptr(),
+                w['r'].data_ptr(), w['z'].data_ptr(), w['p'].data_ptr(), w['scal'].data_ptr(), float(s), float(dmin), float(dmax), n, m,
+                _C.stream_ptr(dev)), "pplie_pcg_prepare")
+            code = persist_p2p_launch(pp_['rk'], [t.data_ptr() for t in pp_['ptag']], [t.data_ptr() for t in pp_['rpart']], sh.ptr,
+                                      sh.other_global, self.HB, w['D'], w['Binv'], w['x'][:n], w['r'], w['z'], tol, maxiter,
+                                      _pg.PERSIST_GRID, sh.a, sh.N, sh.world, sh.rank, pp_['epoch'], m)
+        _C.check(code, "pplie_pcg_persist_p2p")
+        dist.all_gather_into_tensor(w['full'], w['x'], group=sh.group)
+        its, rr, bn2, flag = pp_['rk'].info.tolist()
+        if flag == 3.0:
+            pp_['ok'] = False
+            raise _pg.SolveFailed('p2p persistent PCG: a peer never arrived (kernels not co-resident / peer memory not visible)')
+        assert flag != 2.0 and rr == rr, 'Linear solve produced NaN (matrix may not be positive-definite)'
+        full = w['full'].view(sh.world, chunk, m)
+        return torch.cat([full[k, :(_bounds(sh.N, sh.world, k)[2] - _bounds(sh.N, sh.world, k)[1])] for k in range(sh.world)], 0), int(its)
+
+    def p2p_applicable(self):
+        """group-uniform facts only (every rank must take the same path): device backend, HIP shapes, rows per rank within what
+        one persistent launch holds"""
+        sh, m = self.sh, self.lin.m
+        per_wg = 16 * (64 // m)
+        return (getattr(self.lin.opt, 'exchange', 'rccl') == 'p2p' and self.lin._hip() and m in (3, 6, 7) and self.group_is_device()
+                and sh.world <= 8 and sh.chunk <= 256 * per_wg and sh.chunk > 0 and sh.N % 1 == 0
+                and (sh.p2p is None or sh.p2p.get('ok', True)))
+
     def solve(self, s, dmin, dmax, tol, maxiter, check_every=8):
         """(H + damping) d = -g over all ranks; returns the FULL step [N, m] (all-gathered) and the iteration count."""
         sh, m = self.sh, self.lin.m
         n = sh.n_own
+        if self.p2p_applicable() and (sh.world - 1) * sh.chunk < sh.N:       # (every rank owns at least one row)
+            return self._solve_p2p(s, dmin, dmax, tol, maxiter)
         if self._hip() and n > 0 and self.group_is_device():
             return self._solve_hip(s, dmin, dmax, tol, maxiter, check_every)
         diag = self.B.diagonal(dim1=-2, dim2=-1)

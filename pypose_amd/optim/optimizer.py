@@ -343,7 +343,8 @@ class LevenbergMarquardt(_Optimizer):
     """
 
     def __init__(self, model, solver=None, strategy=None, kernel=None, corrector=None,
-                 weight=None, reject=16, min=1e-6, max=1e32, vectorize=True, sparse=False, *, group=None, static=False, shard="edges"):
+                 weight=None, reject=16, min=1e-6, max=1e32, vectorize=True, sparse=False, *, group=None, static=False, shard="edges",
+                 exchange="rccl"):
         assert min > 0, ValueError("min value has to be positive: {}".format(min))
         assert max > 0, ValueError("max value has to be positive: {}".format(max))
         self.strategy = TrustRegion() if strategy is None else strategy
@@ -368,6 +369,11 @@ class LevenbergMarquardt(_Optimizer):
         # "edges" (default): edge shards with the solve replicated / all-reduced (optim/posegraph.py)
         assert shard in ("edges", "nodes"), ValueError("shard has to be 'edges' or 'nodes': {}".format(shard))
         self.shard = shard
+        # exchange="p2p" (with shard="nodes"): the node-sharded solve runs as one persistent kernel per GPU that writes its p
+        # slices and partial sums straight into the peers' memory (hipIpc-mapped, xGMI) -- no collective per PCG iteration;
+        # "rccl" (default): one all-gather + one all-reduce per iteration (optim/nodeshard.py)
+        assert exchange in ("rccl", "p2p"), ValueError("exchange has to be 'rccl' or 'p2p': {}".format(exchange))
+        self.exchange = exchange
         self.jackwargs = {'vectorize': vectorize}
         self.solver = Cholesky() if solver is None else solver
         self.reject, self.reject_count = reject, 0

@@ -113,7 +113,8 @@ class PgoGraphStep:
     def launch(self, pg):
         """enqueue the trial (everything up to the read-back); the host returns while the GPU works"""
         opt = self.opt
-        if not hasattr(opt, 'loss'):               # first step of a run: the loss at the starting point (optimizer.py:659)
+        self._had_loss = hasattr(opt, 'loss')
+        if not self._had_loss:                     # first step of a run: the loss at the starting point (optimizer.py:659)
             opt.loss = self.lin.fast_loss()
         self._prev_last = opt.__dict__.get('_last_view')
         opt.last = opt.loss
@@ -131,8 +132,14 @@ class PgoGraphStep:
         with torch.no_grad():
             torch.Tensor.as_subclass(self.P, torch.Tensor).detach().copy_(self.backup)
         _C.mark_written(self.P)
+        opt = self.opt
+        if not self._had_loss:                     # (that starting loss was the CAPTURED program's: the ordinary path computes its own)
+            del opt.loss
+        opt.__dict__.pop('_host_loss', None)
         if self._prev_last is not None:
-            self.opt.last = self._prev_last
+            opt.last = self._prev_last
+        else:
+            opt.__dict__.pop('_last_view', None)
 
     def finish(self, pg):
         opt, lin, last_h = self.opt, self.lin, self._last_h

@@ -130,7 +130,8 @@ def test_fused_pgo_is_recognised_only_when_exact(G):
 
 
 def test_fused_program_is_recognised_only_when_exact(G):
-    """Anything but  Log(P @ X)  with a Trivial kernel / no weight / no target stays on the generic paths."""
+    """Log(P @ X) takes the hand-derived program, other product chains over one P the normal-form kernel (fused:lpr); a robust
+    kernel, a non-Cholesky solver or a residual that is not such a chain stays on the generic paths."""
     torch.manual_seed(0)
     inp = pp.randn_SE3(64, device=DEV)
 
@@ -142,7 +143,7 @@ def test_fused_program_is_recognised_only_when_exact(G):
         def forward(self, input):
             return (input @ self.pose).Log().tensor()
 
-    for cls, kw, want in ((InvNet, {}, "fused:se3inv"), (Scaled, {}, "block"), (Swapped, {}, "block"),
+    for cls, kw, want in ((InvNet, {}, "fused:se3inv"), (Scaled, {}, "block"), (Swapped, {}, "fused:lpr"),
                           (InvNet, {"kernel": pp.optim.kernel.Huber()}, "block"),
                           (InvNet, {"solver": pp.optim.solver.PINV()}, "block")):
         net = cls(pp.randn_SE3(64, device=DEV))
@@ -153,7 +154,7 @@ def test_fused_program_is_recognised_only_when_exact(G):
     net = InvNet(pp.randn_SE3(64, device=DEV))
     opt = pp.optim.LM(net, strategy=pp.optim.strategy.Constant(1e-6))
     opt.step(inp, target=torch.zeros(64, 6, device=DEV))
-    assert opt.linearization == "block"
+    assert opt.linearization == "fused:lpr"          # (a target is part of the normal form: r = Log(P X) - b)
 
 
 @pytest.mark.parametrize("mode", ["dense", "graph", "fused:pgo"])
