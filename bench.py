@@ -524,7 +524,7 @@ def imu_sharded_rate(dev, rank, world, B=4096, F=1024):
             "ms_max_over_ranks": {"with_covariance": ms_cov, "states_only": ms_plain}}
 
 
-def pgo_sharded_lm_rate(dev, rank, world, nodes=100_000, edges=400_000, steps=3, reps=3, shard="edges"):
+def pgo_sharded_lm_rate(dev, rank, world, nodes=100_000, edges=400_000, steps=3, reps=3, shard="edges", exchange="rccl"):
     """BASELINE configs[3]: pose-graph LM, 100k SE3 nodes / 400k relative-pose edges, sharded over the ranks --
     `LM(group=...)`, SURVEY.md section 8(e).  Same generator, solver and strategy as `pgo_lm_rate`.  Collective: every rank
     calls this; rank 0's figures are reported.  Not part of `value`."""
@@ -538,7 +538,8 @@ def pgo_sharded_lm_rate(dev, rank, world, nodes=100_000, edges=400_000, steps=3,
     e_mine, rel_mine = e[rank::world].contiguous(), pp.SE3(rel[rank::world].contiguous())
     graph = _pose_graph_model(pp.SE3(init.clone()))
     solver = pp.optim.solver.PCG(tol=1e-4, maxiter=250)
-    opt = pp.optim.LM(graph, solver=solver, strategy=pp.optim.strategy.TrustRegion(radius=1e4), group=dist.group.WORLD, shard=shard)
+    opt = pp.optim.LM(graph, solver=solver, strategy=pp.optim.strategy.TrustRegion(radius=1e4), group=dist.group.WORLD, shard=shard,
+                      exchange=exchange)
     times, losses, its = [], [], []
     for rep in range(reps + 1):                   # repetition 0 (structure probe, kernel verification) is untimed
         graph.nodes.data.copy_(init)
@@ -558,8 +559,12 @@ def pgo_sharded_lm_rate(dev, rank, world, nodes=100_000, edges=400_000, steps=3,
     dt = sorted(times)[len(times) // 2]
     return {"metric": "LM iters/sec, pose graph 100k nodes / 400k edges sharded over the ranks (BASELINE configs[3])",
             "value": 1.0 / dt, "unit": "LM steps/s", "n_gpus": world, "nodes": nodes, "edges": edges,
-            "edges_per_rank": int(e_mine.shape[0]), "path": opt.linearization, "losses": losses, "pcg_iterations": its,
+            "edges_per_rank": int(e_mine.shape[0]), "path": opt.linearization, "losses": losses, "pcg_iterations": its, "ranks": world,
             "mode": getattr(opt, "_last_shard_mode", "replicated" if getattr(opt, "_last_replicated", False) else "edge-sharded"),
+            "exchange": ("in-kernel peer stores over xGMI (hipIpc-mapped tables, csrc/pcg_persist.hip): no collective per PCG iteration"
+                         if exchange == "p2p" and shard == "nodes" else f"{dist.get_backend()} collectives (RCCL over xGMI on GPUs)"),
+            "scales": ("no: every rank runs the whole solve (the blocks are all-gathered once per LM step)" if shard == "edges" else
+                       "the solve is sharded by node rows"),
             "repetitions_ms_per_step": [round(t * 1e3, 3) for t in times]}
 
 
@@ -777,7 +782,9 @@ def main():
                 ("lm_pgo_sharded", lambda: pgo_sharded_lm_rate(dev, rank, world, *((80, 200) if small else (100_000, 400_000)),
                                                                reps=1 if small else 3)),
                 ("lm_pgo_node_sharded", lambda: pgo_sharded_lm_rate(dev, rank, world, *((80, 200) if small else (100_000, 400_000)),
-                                                                    reps=1 if small else 2, shard="nodes")))
+                                                                    reps=1 if small else 2, shard="nodes")),
+                ("lm_pgo_node_sharded_p2p", lambda: pgo_sharded_lm_rate(dev, rank, world, *((80, 200) if small else (100_000, 400_000)),
+                                                                        reps=1 if small else 2, shard="nodes", exchange="p2p")))
         for key, fn in legs:
             try:
                 res = fn()

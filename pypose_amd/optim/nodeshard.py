@@ -122,29 +122,37 @@ class NodeShard:
 
     # ---- peer-to-peer exchange (exchange="p2p") ------------------------------------------------------------------------
     def p2p_setup(self, dtype, device):
-        """Allocate this rank's exchange tables, publish them to the peers as IPC handles (hipIpcGetMemHandle through
-        torch.multiprocessing's CUDA-tensor reduction; one process per GPU) and map theirs.  Collective, once per edge list."""
-        import torch.distributed as dist
-        from torch.multiprocessing.reductions import reduce_tensor
+        """this rank's exchange tables + the peers' mapped ones (collective, once per edge list and dtype)"""
         if self.p2p is not None and self.p2p['dtype'] == dtype:
             return self.p2p
         rk = P2PRank(self.N, self.m, dtype, device)
-        torch.cuda.synchronize(device)                                   # (zero-filled before anybody can write into them)
-        mine = [reduce_tensor(rk.ptag), reduce_tensor(rk.rpart)]
-        everyone = [None] * self.world
-        dist.all_gather_object(everyone, mine, group=self.group)
-        ptag, rpart = [], []
-        for k, handles in enumerate(everyone):
-            if k == self.rank:
-                ptag.append(rk.ptag)
-                rpart.append(rk.rpart)
-            else:
-                (f0, a0), (f1, a1) = handles
-                ptag.append(f0(*a0))                                     # hipIpcOpenMemHandle: the peer's table, addressable from this device
-                rpart.append(f1(*a1))
-        dist.barrier(group=self.group)                                   # every table exists and is mapped everywhere
+        ptag, rpart = p2p_exchange_tables(rk, self.group)
         self.p2p = dict(dtype=dtype, rk=rk, ptag=ptag, rpart=rpart, epoch=0, ok=True)
         return self.p2p
+
+
+def p2p_exchange_tables(rk, group):
+    """Publish this rank's two exchange tables to the peers as IPC handles (hipIpcGetMemHandle through torch.multiprocessing's
+    CUDA-tensor reduction; one process per GPU) and map theirs (hipIpcOpenMemHandle).  Collective over ``group``; returns the
+    ``world`` hand-off tables and the ``world`` rank-sum tables as tensors addressable from this process (own ones included)."""
+    import torch.distributed as dist
+    from torch.multiprocessing.reductions import reduce_tensor
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    torch.cuda.synchronize(rk.ptag.device)                               # (zero-filled before anybody can write into them)
+    mine = [reduce_tensor(rk.ptag), reduce_tensor(rk.rpart)]
+    everyone = [None] * world
+    dist.all_gather_object(everyone, mine, group=group)
+    ptag, rpart = [], []
+    for k, handles in enumerate(everyone):
+        if k == rank:
+            ptag.append(rk.ptag)
+            rpart.append(rk.rpart)
+        else:
+            (f0, a0), (f1, a1) = handles
+            ptag.append(f0(*a0))                                         # the peer's table, addressable from this device
+            rpart.append(f1(*a1))
+    dist.barrier(group=group)                                            # every table exists and is mapped everywhere
+    return ptag, rpart
 
 
 class NodeShardedSystem:

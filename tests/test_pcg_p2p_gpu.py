@@ -1,8 +1,8 @@
 """The multi-GPU persistent PCG (pplie_pcg_persist_p2p, csrc/pcg_persist.hip; LM(group=, shard="nodes", exchange="p2p")) with its
-`world` ranks emulated on ONE device: every "rank" is a launch on its own stream over its own node rows, the peers' tables are
-plain pointers of the same process -- the kernel protocol (p stored into every rank's hand-off table, two-level tagged sums,
-epoch-tagged tables that are never cleared) is exactly what runs over xGMI with peer-mapped pointers.  Against the one-rank
-solve of the same system."""
+`world` ranks as separate PROCESSES on the one GPU of the test box: each rank launches the kernel over its own node rows, the
+peers' tables are hipIpc-mapped exactly as across GPUs (optim/nodeshard.p2p_exchange_tables) -- the kernel protocol (p stored
+into every rank's hand-off table, two-level tagged sums, epoch-tagged tables that are never cleared) and the IPC plumbing are
+what runs over xGMI with one process per GPU; only the link is different.  Against the one-rank solve of the same system."""
 import pytest
 import torch
 
@@ -31,43 +31,75 @@ def _system(N, E, dtype):
     return lin, wsp
 
 
+def _rank_operands(lin, D, Binv, r, z, world, rank, dtype, m):
+    N = D.shape[0]
+    ptr, blk, other = lin.csr()
+    chunk, a, b = NS._bounds(N, world, rank)
+    lo, hi = int(ptr[a]), int(ptr[b])
+    return a, dict(ptr=(ptr[a:b + 1] - lo).to(torch.int32).contiguous(), other=other[lo:hi].contiguous(), HB=lin.HB[lo:hi].contiguous(),
+                   D=D[a:b].contiguous(), Binv=Binv[a:b].contiguous(), x=torch.zeros(b - a, m, dtype=dtype, device=DEV),
+                   r=r[a:b].contiguous(), z=z[a:b].contiguous())
+
+
+def _worker(rank, world, port, dtype, tol, out):
+    """one process = one rank (all on this box's one GPU: separate processes have separate hardware queues, so their persistent
+    kernels run side by side as they would on separate GPUs); the tables cross processes through hipIpc exactly as in production"""
+    import torch.distributed as dist
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        N, E, m = 3000, 12000, 6
+        lin, wsp = _system(N, E, dtype)
+        with torch.no_grad():
+            x_ref, its_ref = wsp.solve(lin, lin.s, lin.dmin, lin.dmax, tol, 2000, None)
+            D, Binv = wsp.D.clone(), wsp.Binv.clone()
+            r = (-lin.g).contiguous()
+            z = (Binv @ r.unsqueeze(-1)).squeeze(-1).contiguous()
+        rk = NS.P2PRank(N, m, dtype, torch.device(DEV))
+        ptag, rpart = NS.p2p_exchange_tables(rk, dist.group.WORLD)
+        res = []
+        for epoch in (1, 2):                                         # twice: the tables are not cleared between solves
+            a, ops = _rank_operands(lin, D, Binv, r, z, world, rank, dtype, m)
+            dist.barrier()
+            code = NS.persist_p2p_launch(rk, [t.data_ptr() for t in ptag], [t.data_ptr() for t in rpart], tol=tol, maxiter=2000,
+                                         grid=96 // world, row0=a, n_global=N, world=world, rank=rank, epoch=epoch, m=m, **ops)
+            torch.cuda.synchronize()
+            info = rk.info.tolist()
+            xs = [None] * world
+            dist.all_gather_object(xs, ops["x"].cpu())
+            res.append((code, info, float((torch.cat(xs, 0) - x_ref.cpu()).abs().max()), float(x_ref.abs().max()), int(its_ref)))
+        out.put((rank, res))
+    finally:
+        dist.destroy_process_group()
+
+
 @pytest.mark.parametrize("dtype,tol,atol", [(torch.float32, 1e-5, 2e-4), (torch.float64, 1e-10, 1e-8)])
-@pytest.mark.parametrize("world", [2, 4])
-def test_emulated_ranks_reproduce_the_one_rank_solve(world, dtype, tol, atol):
-    N, E, m = 3000, 12000, 6
-    lin, wsp = _system(N, E, dtype)
-    with torch.no_grad():
-        x_ref, its_ref = wsp.solve(lin, lin.s, lin.dmin, lin.dmax, tol, 2000, None)          # one rank (prepare + persistent solve)
-        D, Binv = wsp.D.clone(), wsp.Binv.clone()
-        # the right-hand side as pplie_pcg_prepare leaves it: r = -g, z = Binv r
-        r = (-lin.g).contiguous()
-        z = (Binv @ r.unsqueeze(-1)).squeeze(-1).contiguous()
-        ptr, blk, other = lin.csr()
-        HB = lin.HB
-    ranks = [NS.P2PRank(N, m, dtype, torch.device(DEV)) for _ in range(world)]
-    ptag_ptrs = [rk.ptag.data_ptr() for rk in ranks]
-    rpart_ptrs = [rk.rpart.data_ptr() for rk in ranks]
-    xs, keep = [], []
-    for epoch in (1, 2):                                             # twice: the tables are not cleared between solves
-        streams = [torch.cuda.Stream() for _ in range(world)]
-        torch.cuda.synchronize()
-        xs = []
-        for rank in range(world):
-            chunk, a, b = NS._bounds(N, world, rank)
-            lo, hi = int(ptr[a]), int(ptr[b])
-            ops = dict(ptr=(ptr[a:b + 1] - lo).to(torch.int32).contiguous(), other=other[lo:hi].contiguous(), HB=HB[lo:hi].contiguous(),
-                       D=D[a:b].contiguous(), Binv=Binv[a:b].contiguous(), x=torch.zeros(b - a, m, dtype=dtype, device=DEV),
-                       r=r[a:b].contiguous(), z=z[a:b].contiguous())
-            keep.append(ops)
-            with torch.cuda.stream(streams[rank]):
-                code = NS.persist_p2p_launch(ranks[rank], ptag_ptrs, rpart_ptrs, tol=tol, maxiter=2000, grid=128 // world,
-                                             row0=a, n_global=N, world=world, rank=rank, epoch=epoch, m=m, **ops)
-            assert code == 0
-            xs.append(ops["x"])
-        torch.cuda.synchronize()
-        infos = [rk.info.tolist() for rk in ranks]
-        assert all(i[3] == 1.0 for i in infos), infos                # converged everywhere
-        assert len({i[0] for i in infos}) == 1                       # ... in the same iteration
-        assert abs(infos[0][0] - its_ref) <= 2, (infos[0][0], its_ref)
-        x = torch.cat(xs, 0)
-        assert float((x - x_ref).abs().max()) <= atol * max(1.0, float(x_ref.abs().max())), float((x - x_ref).abs().max())
+@pytest.mark.parametrize("world", [2, 3])
+def test_ranks_in_separate_processes_reproduce_the_one_rank_solve(world, dtype, tol, atol):
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(k, world, port, dtype, tol, out)) for k in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    try:
+        for _ in range(world):
+            rank, res = out.get(timeout=240)
+            got[rank] = res
+    finally:
+        for p in procs:
+            p.join(timeout=30)
+            if p.is_alive():
+                p.kill()
+    assert len(got) == world
+    for rank, res in got.items():
+        for code, info, err, scale, its_ref in res:
+            assert code == 0 and info[3] == 1.0, (rank, code, info)               # converged
+            assert abs(info[0] - its_ref) <= 2, (info[0], its_ref)
+            assert err <= atol * max(1.0, scale), (rank, err)
+    assert len({tuple(r[1][0] for r in res) for res in got.values()}) == 1     # every rank stopped in the same iteration
