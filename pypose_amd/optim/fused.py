@@ -1067,6 +1067,13 @@ def checked_shortcut(opt, dev, gs, input, target, weight):
     if not m:
         return None
     out = None
+    if dev is not None:
+        out = dev.checked_step(m, target, weight)
+    if out is None and gs is not None and m[0] == "pgo" and gs.prog.matches(*m[1:]):
+        w = opt.weight if weight is None else weight
+        if gs.usable(pg, input, target, w, checked=True):
+            with torch.no_grad():
+                return gs.step(pg)
     if out is None:
         opt._dry_hint = (input, m)          # the general path re-uses this step's trace
     return out
