@@ -40,6 +40,9 @@ def _suffix(t):
     return {torch.float32: "_f32", torch.float64: "_f64"}.get(t.dtype)
 
 
+_GRAM_SIG = [ctypes.c_void_p] * 5 + [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+
+
 def normal_equations(J, R, W=None):
     """J [n,dr,dp], R [n,dr], W [n,dr,dr] | None  ->  A [n,dp,dp] = J^T W J,  g [n,dp] = J^T W R."""
     n, dr, dp = J.shape
@@ -56,7 +59,18 @@ def normal_equations(J, R, W=None):
                       n, dr, dp, _C.stream_ptr(J.device))
         _C.check(code, "pplie_block_normal_eq")
         return A, g
-    # sizes outside the HIP kernel table: batched torch ops on the same device
+    if J.is_cuda and _suffix(J) and dp <= 15 and n > 0 and W is None:
+        # large residual stacks: the Gram product [J | R]^T [J | R] of every problem on the matrix cores, one wavefront per
+        # problem (csrc/gram_mfma.hip)
+        J, R = J.contiguous(), R.contiguous()
+        A = torch.empty((n, dp, dp), dtype=J.dtype, device=J.device)
+        g = torch.empty((n, dp), dtype=J.dtype, device=J.device)
+        fn = _C.library().symbol("pplie_block_gram_mfma" + _suffix(J), _GRAM_SIG)
+        with _C._on_device(J.device):
+            code = fn(J.data_ptr(), R.data_ptr(), A.data_ptr(), g.data_ptr(), None, n, dr, dp, _C.stream_ptr(J.device))
+        _C.check(code, "pplie_block_gram_mfma")
+        return A, g
+    # anything else (a weight W: J^T W J is not the Gram product of one matrix; host tensors): batched torch ops
     JtW = J.mT if W is None else J.mT @ W
     return JtW @ J, (JtW @ R.unsqueeze(-1)).squeeze(-1)
 

@@ -60,20 +60,26 @@ def test_posegraph_group_equals_single_process(group, fused, replicate):
     torch.testing.assert_close(a[2][0], b[2][0], rtol=0, atol=1e-7)
 
 
+@pytest.mark.parametrize("exchange", ["rccl", "p2p"])
 @pytest.mark.parametrize("fused", [False, True])
-def test_node_sharded_solve_on_rccl_equals_single_process(group, fused):
+def test_node_sharded_solve_on_rccl_equals_single_process(group, fused, exchange):
     """LM(group=, shard="nodes") over RCCL (one rank): the all-gather of the blocks, the owned-row assembly and SpMV
-    kernels on the local incidence lists, the per-iteration all-gather / all-reduces -- same steps as one process."""
+    kernels on the local incidence lists, the per-iteration all-gather / all-reduces -- same steps as one process.
+    exchange="p2p": the solve is one persistent launch per rank (pplie_pcg_persist_p2p; with one rank its peer tables are its
+    own -- the multi-rank protocol itself runs in tests/test_pcg_p2p_gpu.py)."""
     G = load_lm_golden()
     edges, poses = T(G["pgo40/edges"], DEV), pp.SE3(T(G["pgo40/poses"], DEV))
     kw = {"solver": pp.optim.solver.PCG(tol=1e-12, maxiter=2000), "strategy": pp.optim.strategy.TrustRegion(radius=1e4)}
     make = lambda: (PoseGraph(pp.SE3(T(G["pgo40/init"], DEV))), dict(kw))
     a = _run(make, ((edges, poses),), None, fused)
     model = PoseGraph(pp.SE3(T(G["pgo40/init"], DEV)))
-    opt = pp.optim.LM(model, group=group, shard="nodes", **kw)
+    opt = pp.optim.LM(model, group=group, shard="nodes", exchange=exchange, **kw)
     opt.fused = fused
     losses = [float(opt.step((edges, poses))) for _ in range(4)]
     assert opt._last_shard_mode == "node-sharded solve" and opt.linearization == a[1]
+    if exchange == "p2p":
+        shard = opt._node_shards['shard'][1]
+        assert shard.p2p is not None and shard.p2p['epoch'] >= 4 and shard.p2p['ok']
     for x, y in zip(a[0], losses):
         assert abs(x - y) <= 1e-7 * abs(x)
     torch.testing.assert_close(a[2][0], model.nodes.detach(), rtol=0, atol=1e-7)

@@ -304,6 +304,13 @@ def test_default_step_follows_a_rebound_buffer_and_a_flipped_attribute_at_once()
     calls = net.calls
     opt.step(inp)
     assert net.calls > calls, "the model's Python must run on every step"
+    # ... and yet the step stays the two-launch device step: the general path (linearise, verify, host decisions) is not entered
+    general, orig = [], opt._step_general
+    opt._step_general = lambda *a, **k: (general.append(1), orig(*a, **k))[1]
+    for _ in range(5):
+        opt.step(inp)
+    opt._step_general = orig
+    assert not general and opt._device_lm.pending
     # a buffer is REBOUND (no tensor written, same `input` object): the very next step optimises against it
     pose = net.pose.detach().tensor().clone()
     net.other = inp2
