@@ -405,6 +405,204 @@ pcg_persist_kernel(const int* __restrict__ ptr, const int* __restrict__ other, c
   }
 }
 
+// =====================================================================================================================
+// GHOST-ZONE form: ONE grid-wide dependency per iteration.
+//
+// In the kernel above an iteration waits twice for the whole grid: for the all-gather of the dot products, and -- because with
+// loop closures every workgroup borders on nearly every other -- for the neighbours' new search direction before the next
+// product (measured: 5.7 + 4.2 of 11.9 us, tools/time_pcg_iter.py).  Here a workgroup also keeps r and p of its GHOST nodes
+// (the neighbours it does not own) and advances them itself: what an owner publishes per iteration is q = A p of its nodes,
+// at the same moment as its partial sums; a reader fetches its ghosts' q while it polls the all-gather, and then applies the
+// very recurrence the owner applies --  r -= alpha q,  z = Binv r,  p = z + beta p  -- to its ghosts, same operands, same
+// order, same bits.  The matrix product reads every p from LDS and never waits; the only grid-wide wait left is the
+// all-gather, with the q exchange riding in its shadow.
+//   lanes: a lane owns (node, component) of one OWNED node and of up to kGhostLayers ghost nodes (layer l, position as the
+//   owned one); p of all local nodes (owned, then ghosts) sits in LDS, indexed by the local slot the host precomputed for every
+//   incidence (optim/posegraph.py FusedPCG._ghost_map).
+constexpr int kGhostLayers = 3;
+
+template <class T, int M>
+__global__ void __launch_bounds__(kPersistBlock)
+pcg_ghost_kernel(const int* __restrict__ ptr, const int* __restrict__ slot, const T* __restrict__ HB, const T* __restrict__ D,
+                 const T* __restrict__ Binv, T* __restrict__ x, const T* __restrict__ r, const T* __restrict__ z,
+                 const int* __restrict__ gptr, const int* __restrict__ gids, u64* part, u64* qtag /* [2][N * M tagged values] */,
+                 T* __restrict__ rr_hist, T* info, int* it_out, T tol2, int maxiter, int cap, int64_t N, int lds_bytes) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
+  __shared__ PersistShared<T> sh;
+  constexpr int NPW = 64 / M, WV = kPersistBlock / 64, NW = sizeof(T) / 4, POS = WV * NPW;      // POS: node positions per layer
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int sub = lane / M, i = lane % M;
+  const int64_t n0 = N * blockIdx.x / gridDim.x, n1 = N * (blockIdx.x + 1) / gridDim.x;
+  const int n_own = (int)(n1 - n0);
+  const int pos = w * NPW + sub;                                   // this lane's node position in every layer
+  const int64_t n = n0 + pos;
+  const bool act = sub < NPW && pos < n_own;
+  const size_t NM = (size_t)N * M * NW;
+  const int g_lo = gptr[blockIdx.x], n_ghost = gptr[blockIdx.x + 1] - g_lo;
+
+  // ---- owned element
+  T dc[M], br[M], xe = T(0), re = T(0), ze = T(0), pe = T(0);
+  int beg = 0, deg = 0;
+#pragma unroll
+  for (int j = 0; j < M; ++j) { dc[j] = T(0); br[j] = T(0); }
+  if (act) {
+#pragma unroll
+    for (int j = 0; j < M; ++j) { dc[j] = D[(n * M + j) * M + i]; br[j] = Binv[(n * M + i) * M + j]; }
+    re = r[n * M + i];
+    ze = z[n * M + i];
+    pe = ze;
+    beg = ptr[n];
+    deg = ptr[n + 1] - beg;
+  }
+  // ---- ghost elements: layer l holds ghost g_lo + l * POS + pos
+  T gbr[kGhostLayers][M], gr[kGhostLayers], gp[kGhostLayers];
+  int gnode[kGhostLayers];
+  bool gact[kGhostLayers];
+#pragma unroll
+  for (int l = 0; l < kGhostLayers; ++l) {
+    const int gi = l * POS + pos;
+    gact[l] = sub < NPW && gi < n_ghost;
+    gnode[l] = gact[l] ? gids[g_lo + gi] : 0;
+    gr[l] = T(0);
+    gp[l] = T(0);
+#pragma unroll
+    for (int j = 0; j < M; ++j) gbr[l][j] = gact[l] ? Binv[((size_t)gnode[l] * M + i) * M + j] : T(0);
+    if (gact[l]) {
+      gr[l] = r[(size_t)gnode[l] * M + i];
+      gp[l] = z[(size_t)gnode[l] * M + i];                         // p_0 = z_0
+    }
+  }
+  int maxdeg = deg;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const int o = __shfl_xor(maxdeg, off, 64);
+    maxdeg = o > maxdeg ? o : maxdeg;
+  }
+  // ---- LDS: [ per-wave transpose pads | p of the local nodes | staged blocks (transposed) | staged local slots ]
+  T* tr = reinterpret_cast<T*>(dyn_lds) + (size_t)w * NPW * M * M;
+  constexpr size_t kPadBytes = (size_t)WV * NPW * M * M * sizeof(T);
+  constexpr size_t kPBytes = (size_t)(1 + kGhostLayers) * POS * M * sizeof(T);
+  T* p_l = reinterpret_cast<T*>(dyn_lds + kPadBytes);
+  const int c_lo = ptr[n0], c_cnt = ptr[n1] - c_lo;
+  T* hb_l = reinterpret_cast<T*>(dyn_lds + kPadBytes + kPBytes);
+  int* sl_l = reinterpret_cast<int*>(dyn_lds + kPadBytes + kPBytes + (size_t)c_cnt * M * M * sizeof(T));
+  {                                                                // (host guarantees the slice fits: see pcg_ghost())
+    const T* src = HB + (size_t)c_lo * M * M;
+    for (int e = threadIdx.x; e < c_cnt * M * M; e += kPersistBlock) {
+      const int c = e / (M * M), ij = e % (M * M);
+      hb_l[c * M * M + (ij % M) * M + ij / M] = src[e];
+    }
+    for (int e = threadIdx.x; e < c_cnt; e += kPersistBlock) sl_l[e] = slot[c_lo + e];
+  }
+  if (act) p_l[pos * M + i] = pe;
+#pragma unroll
+  for (int l = 0; l < kGhostLayers; ++l)
+    if (gact[l]) p_l[(n_own + l * POS + pos) * M + i] = gp[l];
+  if (threadIdx.x == 0) { sh.bad[0] = 0; sh.bad[1] = 0; }
+  __syncthreads();
+  const int lbeg = act ? beg - c_lo : 0;
+
+  T bn2 = T(0), rr = T(0);
+  int k = 0, flag = 0;
+  for (;; ++k) {
+    const unsigned tag = (unsigned)k + 1u;
+    const int par = k & 1;
+    // ---- q = A p from LDS: this lane contributes column i of every block of its node
+    T a[M];
+#pragma unroll
+    for (int j = 0; j < M; ++j) a[j] = dc[j] * pe;
+#pragma unroll 4
+    for (int c = 0; c < maxdeg; ++c) {                             // (wave-uniform trip count, absent incidences masked)
+      const bool valid = c < deg;
+      const int cc = valid ? lbeg + c : 0;
+      const T pv = valid ? p_l[sl_l[cc] * M + i] : T(0);
+      const T* h = hb_l + ((size_t)cc * M + i) * M;
+#pragma unroll
+      for (int j = 0; j < M; ++j) a[j] += h[j] * pv;
+    }
+    T acc = T(0);
+    if (sub < NPW) {
+#pragma unroll
+      for (int j = 0; j < M; ++j) tr[(sub * M + i) * M + j] = a[j];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (sub < NPW) {
+#pragma unroll
+      for (int j = 0; j < M; ++j) acc += tr[(sub * M + j) * M + i];
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (act) put_value<T>(qtag + (size_t)par * NM + (size_t)(n * M + i) * NW, acc, tag);      // q of the owned nodes, for their readers
+    T bq = T(0);
+#pragma unroll
+    for (int j = 0; j < M; ++j) bq += br[j] * __shfl(acc, sub * M + j, 64);
+    T v[kPersistQ] = {acc * pe, acc * ze, acc * bq, re * ze, re * re};
+    post_wave_sums<T, kPersistQ>(sh, par, v, act, false);
+    __syncthreads();                                                             // barrier 1
+    publish_row<T, kPersistQ>(sh, par, part, tag);
+    // ---- the ghosts' q: issued now, needed after the all-gather
+    T gq[kGhostLayers];
+    bool gok[kGhostLayers];
+#pragma unroll
+    for (int l = 0; l < kGhostLayers; ++l) {
+      gok[l] = true;
+      gq[l] = gact[l] ? get_value<T>(qtag + (size_t)par * NM + ((size_t)gnode[l] * M + i) * NW, tag, gok[l]) : T(0);
+    }
+    gather_rows<T, kPersistQ>(sh, par, part, tag);
+    bool stale = false;
+#pragma unroll
+    for (int l = 0; l < kGhostLayers; ++l) {
+      for (long spin = 0; gact[l] && !gok[l]; ++spin) {
+        if (spin >= (1L << 20)) { stale = true; break; }
+        __builtin_amdgcn_s_sleep(1);
+        gok[l] = true;
+        gq[l] = get_value<T>(qtag + (size_t)par * NM + ((size_t)gnode[l] * M + i) * NW, tag, gok[l]);
+      }
+    }
+    if (stale) sh.bad[par] = 1;
+    __syncthreads();                                                             // barrier 2
+    const T pq = sh.total[par][0], qz = sh.total[par][1], qmq = sh.total[par][2], rho = sh.total[par][3];
+    rr = sh.total[par][4];
+    if (sh.bad[par]) { flag = 3; break; }
+    if (k == 0) bn2 = rr;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && k < cap) rr_hist[k] = rr;
+    if (!(rr == rr)) { flag = 2; break; }
+    if (rr <= tol2 * bn2) { flag = 1; break; }
+    if (k >= maxiter) break;
+    const T alpha = pq != T(0) ? rho / pq : T(0);
+    T rho_next = rho - T(2) * alpha * qz + alpha * alpha * qmq;
+    if (rho_next < T(0)) rho_next = T(0);
+    const T beta = rho != T(0) ? rho_next / rho : T(0);
+    // ---- the same update for the owned element and for the ghosts (identical operands, order and contraction: identical bits)
+    xe += alpha * pe;
+    re -= alpha * acc;
+    {
+      T zn = T(0);
+#pragma unroll
+      for (int j = 0; j < M; ++j) zn += br[j] * __shfl(re, sub * M + j, 64);
+      ze = zn;
+      pe = ze + beta * pe;
+    }
+    if (act) p_l[pos * M + i] = pe;
+#pragma unroll
+    for (int l = 0; l < kGhostLayers; ++l) {
+      gr[l] -= alpha * gq[l];
+      T zn = T(0);
+#pragma unroll
+      for (int j = 0; j < M; ++j) zn += gbr[l][j] * __shfl(gr[l], sub * M + j, 64);
+      gp[l] = zn + beta * gp[l];
+      if (gact[l]) p_l[(n_own + l * POS + pos) * M + i] = gp[l];
+    }
+    __syncthreads();                                                             // barrier 3: every local p is in place
+  }
+  if (act) x[n * M + i] = flag >= 2 ? T(0) : xe;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    info[0] = (T)k; info[1] = rr; info[2] = bn2; info[3] = (T)flag;
+    it_out[0] = k;
+  }
+}
+
 // Dynamic LDS of a workgroup (the staged matrix slice); the most workgroups of this kernel the device holds at once
 // (they spin on each other: all must be resident)
 constexpr int kPersistLds = 128 * 1024;
@@ -479,6 +677,55 @@ int pcg_persist_p2p(const void* ptr, const void* other, const void* HB, const vo
   }
   return pcg_persist<T>(ptr, other, HB, D, Binv, x, r, z, part, pe.ptag[rank], rr_hist, info, it, tol, maxiter, cap, grid, n_own, m, stream, &pe);
 }
+
+// ghost-zone solve: PPLIE_ECAPACITY (nothing launched) when a workgroup's slice or ghost set does not fit -- the caller then uses
+// pplie_pcg_persist.  max_cnt / max_ghost: the largest incidence count and ghost count of any workgroup for THIS grid.
+template <class T, int M> static int ghost_capacity(int& lds_bytes) {
+  static int cap[16] = {0}, lds[16] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 0;
+  if (cap[dev] == 0) {
+    int cus = 0, per = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    lds[dev] = kPersistLds;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&pcg_ghost_kernel<T, M>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            kPersistLds) != hipSuccess) {
+      (void)hipGetLastError();
+      lds[dev] = 48 * 1024;
+    }
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, pcg_ghost_kernel<T, M>, kPersistBlock, lds[dev]) != hipSuccess) return 0;
+    cap[dev] = cus * per > 0 ? cus * per : -1;
+  }
+  lds_bytes = lds[dev];
+  return cap[dev] > 0 ? cap[dev] : 0;
+}
+
+template <class T>
+int pcg_ghost(const void* ptr, const void* slot, const void* HB, const void* D, const void* Binv, void* x, const void* r, const void* z,
+              const void* gptr, const void* gids, void* part, void* qtag, void* rr_hist, void* info, void* it, double tol, int maxiter,
+              int cap, int grid, int max_cnt, int max_ghost, int64_t N, int m, void* stream) {
+  if (N <= 0) return N == 0 ? PPLIE_OK : PPLIE_EBADARG;
+  if (!ptr || !slot || !HB || !D || !Binv || !x || !r || !z || !gptr || !gids || !part || !qtag || !rr_hist || !info || !it) return PPLIE_EBADARG;
+  if (grid < 1 || grid > kPersistGridMax || maxiter < 0 || max_cnt < 0 || max_ghost < 0) return PPLIE_EBADARG;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+#define LAUNCH(MM)                                                                                                             \
+  {                                                                                                                            \
+    int lds_bytes = 0;                                                                                                         \
+    const int resident = ghost_capacity<T, MM>(lds_bytes);                                                                     \
+    constexpr int POS = (kPersistBlock / 64) * (64 / MM);                                                                      \
+    const size_t need = (size_t)POS * MM * MM * sizeof(T) + (size_t)(1 + kGhostLayers) * POS * MM * sizeof(T) +                 \
+                        (size_t)max_cnt * (MM * MM * sizeof(T) + 4);                                                           \
+    if (resident < grid || need > (size_t)lds_bytes || max_ghost > kGhostLayers * POS || (N + grid - 1) / grid > POS)           \
+      return PPLIE_ECAPACITY;             /* (the grid is part of the host's ghost map: it cannot be shrunk here) */             \
+    hipLaunchKernelGGL((pcg_ghost_kernel<T, MM>), dim3(grid), dim3(kPersistBlock), lds_bytes, st, (const int*)ptr, (const int*)slot, \
+                       (const T*)HB, (const T*)D, (const T*)Binv, (T*)x, (const T*)r, (const T*)z, (const int*)gptr,             \
+                       (const int*)gids, (unsigned long long*)part, (unsigned long long*)qtag, (T*)rr_hist, (T*)info, (int*)it,   \
+                       (T)(tol * tol), maxiter, cap, N, lds_bytes);                                                            \
+  }
+  if (m == 6) LAUNCH(6) else if (m == 7) LAUNCH(7) else if (m == 3) LAUNCH(3) else return PPLIE_EBADARG;
+#undef LAUNCH
+  return hipGetLastError() == hipSuccess ? PPLIE_OK : PPLIE_ELAUNCH;
+}
 }  // namespace pplie
 
 extern "C" int pplie_pcg_persist_f32(const void* ptr, const void* other, const void* HB, const void* D, const void* Binv, void* x,
@@ -504,3 +751,13 @@ extern "C" int pplie_pcg_persist_f64(const void* ptr, const void* other, const v
   }
 PPLIE_P2P(f32, float)
 PPLIE_P2P(f64, double)
+#define PPLIE_GHOST(SFX, T)                                                                                                       \
+  extern "C" int pplie_pcg_ghost_##SFX(const void* ptr, const void* slot, const void* HB, const void* D, const void* Binv, void* x,  \
+                                       const void* r, const void* z, const void* gptr, const void* gids, void* part, void* qtag,     \
+                                       void* rr_hist, void* info, void* it, double tol, int maxiter, int cap, int grid, int max_cnt, \
+                                       int max_ghost, int64_t N, int m, void* stream) {                                             \
+    return pplie::pcg_ghost<T>(ptr, slot, HB, D, Binv, x, r, z, gptr, gids, part, qtag, rr_hist, info, it, tol, maxiter, cap, grid,    \
+                               max_cnt, max_ghost, N, m, stream);                                                                   \
+  }
+PPLIE_GHOST(f32, float)
+PPLIE_GHOST(f64, double)

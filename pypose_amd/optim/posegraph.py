@@ -48,6 +48,7 @@ _PCG2_SPMV_SIG = [ctypes.c_void_p] * 11 + [ctypes.c_int, ctypes.c_int64, ctypes.
 _PCG2_SPMV_STOP_SIG = [ctypes.c_void_p] * 11 + [ctypes.c_int, ctypes.c_int64, ctypes.c_int, ctypes.c_double, ctypes.c_void_p]
 _PCG2_STEP_SIG = [ctypes.c_void_p] * 9 + [ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]
 _PERSIST_SIG = [ctypes.c_void_p] * 15 + [ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]
+_GHOST_SIG = [ctypes.c_void_p] * 15 + [ctypes.c_double] + [ctypes.c_int] * 5 + [ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]
 _PERSIST_GRID_MAX = 256     # PPLIE_PCG_PERSIST_GRID
 _PERSIST_SLOTS = 8          # PPLIE_PCG_PERSIST_SLOTS
 import os as _os
@@ -296,6 +297,7 @@ class FusedPCG:
     two_launch = True        # class-level switches (tools/ and tests compare the three-launch / graph-less variants)
     use_graph = True
     persist = True           # one persistent launch per solve on small graphs (csrc/pcg_persist.hip)
+    ghost = True             # the ghost-zone form of the persistent solve (one grid-wide dependency per iteration)
     profile = False          # tools/time_pcg_iter.py: the persistent kernel leaves per-phase clock ticks in rr_hist[cap - 8:]
 
     def __init__(self, E, K, dr, m, N, dtype, device, has_w, check_every):
@@ -329,6 +331,38 @@ class FusedPCG:
         self.sym = False                                           # HB holds one block per edge
         self.stop_tol2 = None                                      # tol^2 when the captured iterations carry the device-side stop
         self._csr_obj = None
+
+    def _ghost_map(self, lin, grid):
+        """What pplie_pcg_ghost needs of the incidence lists for `grid` workgroups: slot[c] = local index of incidence c's
+        neighbour inside the workgroup that owns the incidence's node (its owned nodes first, then its ghosts = the neighbours it
+        does not own, sorted), gptr / gids = the ghost lists, and the largest incidence / ghost count of any workgroup.  Cached
+        with the incidence lists (rebuilt only when the edge list changes)."""
+        hit = self.__dict__.get('_ghost')
+        if hit is not None and hit[0] is self._csr_obj and hit[1] == grid:
+            return hit[2]
+        N, dev = self.N, self.ptr.device
+        ptr, other = self.ptr.long(), self.other.long()
+        wg = torch.arange(grid + 1, device=dev)
+        bounds = (N * wg) // grid                                  # n0 of every workgroup (the kernel's own partition)
+        deg = ptr[1:] - ptr[:-1]
+        node = torch.repeat_interleave(torch.arange(N, device=dev), deg)
+        w_node = torch.searchsorted(bounds, node, right=True) - 1
+        w_other = torch.searchsorted(bounds, other, right=True) - 1
+        ghost = w_node != w_other
+        key = w_node[ghost] * N + other[ghost]
+        uniq, inv = torch.unique(key, sorted=True, return_inverse=True)
+        g_wg, gids = uniq // N, (uniq % N).to(torch.int32)
+        gcount = torch.bincount(g_wg, minlength=grid)
+        gptr = torch.zeros(grid + 1, dtype=torch.int64, device=dev)
+        gptr[1:] = torch.cumsum(gcount, 0)
+        n_own = bounds[1:] - bounds[:-1]
+        slot = other - bounds[w_node]                              # owned neighbours: their local node index
+        slot[ghost] = n_own[w_node[ghost]] + (inv - gptr[w_node[ghost]])
+        cnt = ptr[bounds[1:]] - ptr[bounds[:-1]]
+        stats = torch.stack([cnt.max(), gcount.max()]).tolist()    # (one read-back per edge list)
+        out = (slot.to(torch.int32).contiguous(), gptr.to(torch.int32).contiguous(), gids.contiguous(), int(stats[0]), int(stats[1]))
+        self._ghost = (self._csr_obj, grid, out)
+        return out
 
     def _persistent(self, plain):
         """this solve runs as ONE persistent launch (csrc/pcg_persist.hip)"""
@@ -447,12 +481,26 @@ class FusedPCG:
             if bsr and self._persistent(plain) and not self.sym:
                 # the whole solve in one launch: iteration, reductions and the convergence test stay on the device
                 maxit = min(maxiter, self.cap - 1)
-                code = _C.library().symbol("pplie_pcg_persist" + self.sfx, _PERSIST_SIG)(
+                code = _C.ECAPACITY
+                if FusedPCG.ghost and not self.__dict__.get('_no_ghost') and not FusedPCG.profile:
+                    # ghost-zone form: ONE grid-wide dependency per iteration (csrc/pcg_persist.hip); falls through to the
+                    # two-dependency kernel when a workgroup's slice / ghost set does not fit
+                    grid = min(PERSIST_GRID, self.N)
+                    slot, gptr, gids, max_cnt, max_ghost = self._ghost_map(lin, grid)
+                    code = _C.library().symbol("pplie_pcg_ghost" + self.sfx, _GHOST_SIG)(
+                        self.ptr.data_ptr(), slot.data_ptr(), self.HB.data_ptr(), self.D.data_ptr(), self.Binv.data_ptr(),
+                        self.x.data_ptr(), self.r.data_ptr(), self.z.data_ptr(), gptr.data_ptr(), gids.data_ptr(), self.part.data_ptr(),
+                        self.ptag.data_ptr(), self.rr_hist.data_ptr(), self.info.data_ptr(), self.it.data_ptr(), float(tol), int(maxit),
+                        self.cap, grid, max_cnt, max_ghost, self.N, self.m, _C.stream_ptr(self.device))
+                    if code == _C.ECAPACITY:
+                        self._no_ghost = True
+                if code == _C.ECAPACITY:
+                    code = _C.library().symbol("pplie_pcg_persist" + self.sfx, _PERSIST_SIG)(
                     self.ptr.data_ptr(), self.other.data_ptr(), self.HB.data_ptr(), self.D.data_ptr(), self.Binv.data_ptr(),
                     self.x.data_ptr(), self.r.data_ptr(), self.p.data_ptr(), self.q.data_ptr(), self.z.data_ptr(),
                     self.part.data_ptr(), self.ptag.data_ptr(), self.rr_hist.data_ptr(), self.info.data_ptr(), self.it.data_ptr(),
-                    float(tol), int(maxit), -self.cap if FusedPCG.profile else self.cap, PERSIST_GRID, self.N, self.m,
-                    _C.stream_ptr(self.device))
+                        float(tol), int(maxit), -self.cap if FusedPCG.profile else self.cap, PERSIST_GRID, self.N, self.m,
+                        _C.stream_ptr(self.device))
                 if code == _C.ECAPACITY:                            # this device cannot hold the solve resident: stream it instead
                     self.no_persist = True
                     return self.solve(lin, s, dmin, dmax, tol, maxiter, group, plain=plain, defer=defer)

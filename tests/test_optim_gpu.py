@@ -631,3 +631,29 @@ def test_negative_edge_indices_on_the_fused_pose_graph_path(G):
         out.append((losses, graph.nodes.detach().tensor().clone()))
     assert out[0][0] == pytest.approx(out[1][0], rel=1e-12)
     torch.testing.assert_close(out[0][1], out[1][1], rtol=0, atol=1e-12)
+
+
+@pytest.mark.parametrize("dtype,tol,atol", [(torch.float32, 1e-5, 1e-4), (torch.float64, 1e-11, 1e-9)])
+def test_ghost_zone_solve_equals_the_two_dependency_kernel(dtype, tol, atol, monkeypatch):
+    """pplie_pcg_ghost (one grid-wide dependency per iteration: ghosts advanced locally) against pplie_pcg_persist: same
+    iteration count, same solution, on a graph large enough for every workgroup to have ghosts in several layers"""
+    from pypose_amd.optim import fused as F, posegraph
+    edges, rel, init = _synthetic_graph(9000, 36000, dtype)
+    graph = PoseGraph(init.clone())
+    solver = pp.optim.solver.PCG(tol=1e-4, maxiter=250)
+    opt = pp.optim.LM(graph, solver=solver, strategy=pp.optim.strategy.TrustRegion(radius=1e4))
+    opt.step((edges, rel))
+    prog = opt._structure_cache["program"][3]
+    with torch.no_grad():
+        lin = F._pgo_linearization(opt, prog, None, graph.nodes, True)
+        lin.build_normal_equations(1e-6, 1e32)
+        lin.damp(1e-4)
+        wsp = next(iter(opt._pcg_workspaces.values()))
+        res = {}
+        for ghost in (True, False):
+            monkeypatch.setattr(posegraph.FusedPCG, "ghost", ghost, raising=False)
+            res[ghost] = wsp.solve(lin, lin.s, lin.dmin, lin.dmax, tol, 3000, None)
+    assert not wsp.__dict__.get("_no_ghost", False), "the ghost-zone kernel did not take this graph"
+    assert abs(res[True][1] - res[False][1]) <= 2, (res[True][1], res[False][1])
+    scale = float(res[False][0].abs().max())
+    assert float((res[True][0] - res[False][0]).abs().max()) <= atol * max(1.0, scale)

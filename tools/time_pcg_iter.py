@@ -24,6 +24,28 @@ with torch.no_grad():
     lin.damp(1e-4)
     wsp = next(iter(opt._pcg_workspaces.values()))
     out = {"nodes": N, "edges": E}
+    # the ghost-zone form (default) first: marginal cost per iteration and agreement with the two-dependency kernel
+    for grid in (128, 256):
+        G.PERSIST_GRID = grid
+        res = {}
+        for iters in (40, 200):
+            ts = []
+            for rep in range(6):
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                x, its = wsp.solve(lin, lin.s, lin.dmin, lin.dmax, 1e-30, iters, None)
+                b.record()
+                torch.cuda.synchronize()
+                ts.append(a.elapsed_time(b) * 1e3)
+            res[iters] = (sorted(ts[1:])[len(ts[1:]) // 2], its)
+        out[f"ghost_grid{grid}"] = {"us_per_solve_40": round(res[40][0], 1), "us_per_solve_200": round(res[200][0], 1),
+                                    "marginal_us_per_iteration": round((res[200][0] - res[40][0]) / (res[200][1] - res[40][1]), 2),
+                                    "used": not wsp.__dict__.get("_no_ghost", False)}
+    G.PERSIST_GRID = 256
+    xg, itg = wsp.solve(lin, lin.s, lin.dmin, lin.dmax, 1e-6, 2000, None)
+    G.FusedPCG.ghost = False
+    xp, itp = wsp.solve(lin, lin.s, lin.dmin, lin.dmax, 1e-6, 2000, None)
+    out["ghost_vs_persist"] = {"max_abs_diff": float((xg - xp).abs().max()), "iterations": [itg, itp]}
     for iters in (40, 200):
         for grid in (64, 128, 192, 256):
             G.PERSIST_GRID = grid
