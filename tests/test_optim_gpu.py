@@ -638,7 +638,8 @@ def test_ghost_zone_solve_equals_the_two_dependency_kernel(dtype, tol, atol, mon
     """pplie_pcg_ghost (one grid-wide dependency per iteration: ghosts advanced locally) against pplie_pcg_persist: same
     iteration count, same solution, on a graph large enough for every workgroup to have ghosts in several layers"""
     from pypose_amd.optim import fused as F, posegraph
-    edges, rel, init = _synthetic_graph(9000, 36000, dtype)
+    # (fp64 blocks are twice the size: fewer nodes per workgroup so that the slice + ghost state still fit in LDS)
+    edges, rel, init = _synthetic_graph(*((9000, 36000) if dtype == torch.float32 else (5000, 20000)), dtype)
     graph = PoseGraph(init.clone())
     solver = pp.optim.solver.PCG(tol=1e-4, maxiter=250)
     opt = pp.optim.LM(graph, solver=solver, strategy=pp.optim.strategy.TrustRegion(radius=1e4))

@@ -25,8 +25,9 @@ with torch.no_grad():
     wsp = next(iter(opt._pcg_workspaces.values()))
     out = {"nodes": N, "edges": E}
     # the ghost-zone form (default) first: marginal cost per iteration and agreement with the two-dependency kernel
-    for grid in (128, 256):
+    for grid in (192, 256):
         G.PERSIST_GRID = grid
+        wsp.__dict__.pop('_no_ghost', None)
         res = {}
         for iters in (40, 200):
             ts = []
@@ -42,6 +43,7 @@ with torch.no_grad():
                                     "marginal_us_per_iteration": round((res[200][0] - res[40][0]) / (res[200][1] - res[40][1]), 2),
                                     "used": not wsp.__dict__.get("_no_ghost", False)}
     G.PERSIST_GRID = 256
+    wsp.__dict__.pop('_no_ghost', None)
     xg, itg = wsp.solve(lin, lin.s, lin.dmin, lin.dmax, 1e-6, 2000, None)
     G.FusedPCG.ghost = False
     xp, itp = wsp.solve(lin, lin.s, lin.dmin, lin.dmax, 1e-6, 2000, None)
