@@ -605,7 +605,7 @@ pcg_ghost_kernel(const int* __restrict__ ptr, const int* __restrict__ slot, cons
 
 // Dynamic LDS of a workgroup (the staged matrix slice); the most workgroups of this kernel the device holds at once
 // (they spin on each other: all must be resident)
-constexpr int kPersistLds = 128 * 1024;
+constexpr int kPersistLds = 152 * 1024;      // of the 160 KB a CU has (one 1024-lane workgroup per CU; ~1.5 KB are static)
 template <class T, int M, bool XG> static int persist_capacity(int& lds_bytes) {
   static int cap[16] = {0}, lds[16] = {0};
   int dev = 0;

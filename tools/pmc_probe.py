@@ -95,3 +95,23 @@ camr = torch.cat([Kr.reshape(1, 9).expand(E, 9), torch.randn(E, 2, device=dev)],
 for _ in range(3):
     _C.row_op("se3_reproj_lin", [Xr, pr, camr], (2, 18))
 torch.cuda.synchronize()
+
+# round 3: the normal-form LM kernel, Log(P^-1 X) at 1M problems (P 28 r + X 28 r + P' 28 w + save 28 w per problem), and the MFMA
+# Gram kernel on [200k, 64, 7] blocks
+from torch import nn
+class _Lpr(nn.Module):
+    def __init__(s, init, X):
+        super().__init__()
+        s.pose, s.X = pp.Parameter(init), X
+    def forward(s):
+        return (s.pose.Inv() @ s.X).Log().tensor()
+netl = _Lpr(pp.randn_SE3(B, device=dev), pp.randn_SE3(B, device=dev))
+optl = pp.optim.LM(netl, strategy=pp.optim.strategy.Constant(damping=1e-4))
+for _ in range(4):
+    optl.step(())
+torch.cuda.synchronize()
+from pypose_amd.optim import blocks as _bl
+Jg, Rg = torch.randn(200_000, 64, 7, device=dev), torch.randn(200_000, 64, device=dev)
+for _ in range(3):
+    _bl.normal_equations(Jg, Rg)
+torch.cuda.synchronize()
