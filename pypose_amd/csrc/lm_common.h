@@ -44,17 +44,21 @@ __device__ __forceinline__ void lm_decide(const double* in, double* o, const LmC
   double loss = v_new;
   const bool failed = !(v_new == v_new);           // NaN: a non-positive pivot in some problem's Cholesky (solver.py:214)
   const double quality = (last - loss) / -(v_jj + 2.0 * v_jr);
-  if (cfg.strategy == LM_ADAPTIVE) {
-    if (quality > cfg.high) damping *= down;
-    else if (!(quality > cfg.low)) damping *= cfg.up;
-    damping = fmax(cfg.smin, fmin(damping, cfg.smax));
-  } else if (cfg.strategy == LM_TRUSTREGION) {
-    if (quality > cfg.high) { radius *= cfg.up; down = cfg.sdown; }
-    else if (quality > cfg.low) { down = cfg.sdown; }
-    else { radius *= down; down *= cfg.factor; }
-    down = fmax(cfg.smin, fmin(down, cfg.smax));
-    radius = fmax(cfg.smin, fmin(radius, cfg.smax));
-    damping = 1.0 / radius;
+  // a failed factorisation: the reference's solver raises and the step is abandoned BEFORE strategy.update
+  // (optimizer.py:667-670) -- damping, radius and down stay what they were
+  if (!failed) {
+    if (cfg.strategy == LM_ADAPTIVE) {
+      if (quality > cfg.high) damping *= down;
+      else if (!(quality > cfg.low)) damping *= cfg.up;
+      damping = fmax(cfg.smin, fmin(damping, cfg.smax));
+    } else if (cfg.strategy == LM_TRUSTREGION) {
+      if (quality > cfg.high) { radius *= cfg.up; down = cfg.sdown; }
+      else if (quality > cfg.low) { down = cfg.sdown; }
+      else { radius *= down; down *= cfg.factor; }
+      down = fmax(cfg.smin, fmin(down, cfg.smax));
+      radius = fmax(cfg.smin, fmin(radius, cfg.smax));
+      damping = 1.0 / radius;
+    }
   }
   double done = 1.0;
   if (!failed && last < loss && rejects < (double)cfg.reject) {     // reject the step

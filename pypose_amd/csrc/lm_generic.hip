@@ -62,8 +62,10 @@ template <int W, class T> __device__ __forceinline__ void st_row(T* p, int64_t r
 }
 
 // forward chain at the pose `P`: Y = P^s, Z = L Y R, and the residual (y = Log Z for kind 0, q = Z . a for kind 1)
+// (hasL / hasR / hasB instead of null pointers: a local array whose ADDRESS is selected at run time cannot stay in registers)
 template <class T, int GID, int KIND>
-PP_HD void lpr_forward(const T* P, const T* Lr, const T* Rr, int sign, const T* av, const T* bv, T* Y, T* Z, T* y, T* r) {
+PP_HD void lpr_forward(const T* P, const T* Lr, bool hasL, const T* Rr, bool hasR, int sign, const T* av, const T* bv, bool hasB, T* Y,
+                       T* Z, T* y, T* r) {
   typedef Grp<T, GID> G;
   constexpr int DG = G::DG, DR = KIND == 0 ? (int)G::DA : 3;
   if (sign > 0) {
@@ -73,12 +75,12 @@ PP_HD void lpr_forward(const T* P, const T* Lr, const T* Rr, int sign, const T* 
     G::inv(P, Y);
   }
   T W[DG];
-  if (Lr) G::mul(Lr, Y, W);
+  if (hasL) G::mul(Lr, Y, W);
   else {
 #pragma unroll
     for (int k = 0; k < DG; ++k) W[k] = Y[k];
   }
-  if (Rr) G::mul(W, Rr, Z);
+  if (hasR) G::mul(W, Rr, Z);
   else {
 #pragma unroll
     for (int k = 0; k < DG; ++k) Z[k] = W[k];
@@ -86,17 +88,17 @@ PP_HD void lpr_forward(const T* P, const T* Lr, const T* Rr, int sign, const T* 
   if (KIND == 0) G::log(Z, y);
   else G::act(Z, av, y);
 #pragma unroll
-  for (int k = 0; k < DR; ++k) r[k] = bv ? y[k] - bv[k] : y[k];
+  for (int k = 0; k < DR; ++k) r[k] = hasB ? y[k] - bv[k] : y[k];
 }
 
 // one LM trial of one problem: candidate pose `pn` and the four summands
 template <class T, int GID, int KIND>
-PP_HD void lm_lpr_row(const T* plin, const T* Lr, const T* Rr, int sign, const T* av, const T* bv, T s, T dmin, T dmax, T* pn,
-                      T& a_new, T& a_old, T& a_jj, T& a_jr) {
+PP_HD void lm_lpr_row(const T* plin, const T* Lr, bool hasL, const T* Rr, bool hasR, int sign, const T* av, const T* bv, bool hasB, T s,
+                      T dmin, T dmax, T* pn, T& a_new, T& a_old, T& a_jj, T& a_jr) {
   typedef Grp<T, GID> G;
   constexpr int DA = G::DA, DG = G::DG, DR = KIND == 0 ? (int)G::DA : 3;
   T Y[DG], Z[DG], y[DR > 3 ? DR : 3], r[DR];
-  lpr_forward<T, GID, KIND>(plin, Lr, Rr, sign, av, bv, Y, Z, y, r);
+  lpr_forward<T, GID, KIND>(plin, Lr, hasL, Rr, hasR, sign, av, bv, hasB, Y, Z, y, r);
   // Jacobian rows: the reference's backward rules on unit cotangents
   T J[DR][DA];
 #pragma unroll
@@ -113,7 +115,7 @@ PP_HD void lm_lpr_row(const T* plin, const T* Lr, const T* Rr, int sign, const T
       for (int k = 0; k < 3; ++k) e[k] = k == i ? T(1) : T(0);
       G::act_bwd(Z, y, e, g1, gp);                       // [e_i @ J_act(q), 0]
     }
-    if (Lr) {
+    if (hasL) {
       T gx[DG], gy[DG];
       G::mul_bwd(Lr, g1, gx, gy);                        // through Z = L (Y R): . @ Adj(L)
 #pragma unroll
@@ -160,7 +162,7 @@ PP_HD void lm_lpr_row(const T* plin, const T* Lr, const T* Rr, int sign, const T
   G::mul(E, plin, pn);
   // the new loss at the candidate as stored
   T Y2[DG], Z2[DG], y2[DR > 3 ? DR : 3], r2[DR];
-  lpr_forward<T, GID, KIND>(pn, Lr, Rr, sign, av, bv, Y2, Z2, y2, r2);
+  lpr_forward<T, GID, KIND>(pn, Lr, hasL, Rr, hasR, sign, av, bv, hasB, Y2, Z2, y2, r2);
   T nn = T(0), oo = T(0), jr = T(0), ld = T(0);
 #pragma unroll
   for (int i = 0; i < DR; ++i) { nn += r2[i] * r2[i]; oo += r[i] * r[i]; }
@@ -185,13 +187,17 @@ __device__ __forceinline__ void lm_lpr_rows(const T* Plin, T* Pout, T* save, con
   for (int64_t row = (int64_t)blockIdx.x * BLOCK + threadIdx.x; row < n; row += (int64_t)gridDim.x * BLOCK) {
     T p[DG], l[DG], rr[DG], a3[3], b[DW], pn[DG];
     ld_row<DG>(Plin, row, p);
+#pragma unroll
+    for (int k = 0; k < DG; ++k) { l[k] = T(0); rr[k] = T(0); }
+#pragma unroll
+    for (int k = 0; k < DW; ++k) b[k] = T(0);
+    a3[0] = a3[1] = a3[2] = T(0);
     if (L) ld_row<DG>(L, row, l);
     if (R) ld_row<DG>(R, row, rr);
     if (KIND == 1) ld_row<3>(av, row, a3);
     if (bv) ld_row<DW>(bv, row, b);
     if (save) st_row<DG>(save, row, p);
-    lm_lpr_row<T, GID, KIND>(p, L ? l : nullptr, R ? rr : nullptr, ar.sign, a3, bv ? b : nullptr, s, dmin, dmax, pn, a_new, a_old, a_jj,
-                             a_jr);
+    lm_lpr_row<T, GID, KIND>(p, l, L != nullptr, rr, R != nullptr, ar.sign, a3, b, bv != nullptr, s, dmin, dmax, pn, a_new, a_old, a_jj, a_jr);
     st_row<DG>(Pout, row, pn);
   }
   T v0 = wg_sum<T, BLOCK>(a_new), v1 = wg_sum<T, BLOCK>(a_old), v2 = wg_sum<T, BLOCK>(a_jj), v3_ = wg_sum<T, BLOCK>(a_jr);

@@ -327,7 +327,9 @@ class NodeShardedSystem:
         n = sh.n_own
         if self.p2p_applicable() and (sh.world - 1) * sh.chunk < sh.N:       # (every rank owns at least one row)
             return self._solve_p2p(s, dmin, dmax, tol, maxiter)
-        if self._hip() and n > 0 and self.group_is_device():
+        # the HIP and the torch formulation issue different collective sequences: the choice is made from facts every rank
+        # agrees on (backend, shapes, every rank owning at least one row), never from this rank's own row count
+        if self._hip() and self.group_is_device() and (sh.world - 1) * sh.chunk < sh.N:
             return self._solve_hip(s, dmin, dmax, tol, maxiter, check_every)
         diag = self.B.diagonal(dim1=-2, dim2=-1)
         D = self.B.clone()

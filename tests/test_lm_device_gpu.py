@@ -249,14 +249,19 @@ def test_custom_strategy_keeps_the_block_path():
     assert opt.linearization == "block"
 
 
-def test_failed_factorisation_leaves_the_parameter_untouched(capsys):
+@pytest.mark.parametrize("kind", ["constant", "adaptive", "trustregion"])
+def test_failed_factorisation_leaves_the_parameter_untouched(capsys, kind):
     """A non-positive pivot (here: a NaN input row) makes the reference's solver raise before any update
-    (solver.py:214, optimizer.py:667-671): the step is abandoned, P is unchanged, the loss stays."""
+    (solver.py:214, optimizer.py:667-671): the step is abandoned, P is unchanged, the loss stays -- and so do damping /
+    radius / down: strategy.update is never reached (:672)."""
     init, inp = _far_problem(1000, torch.float64)
     net = InvNet(init)
-    opt = pp.optim.LM(net, strategy=pp.optim.strategy.Constant(damping=1e-4))
+    S = pp.optim.strategy
+    st = {"constant": lambda: S.Constant(damping=1e-4), "adaptive": lambda: S.Adaptive(damping=1e-4), "trustregion": lambda: S.TrustRegion(radius=1e4)}[kind]()
+    opt = pp.optim.LM(net, strategy=st)
     l0 = float(opt.step(inp))
     P1 = net.pose.detach().tensor().clone()
+    before = {k: opt.param_groups[0].get(k) for k in ("damping", "radius", "down")}
     bad = inp.tensor().clone()
     bad[17] = float('nan')
     # same storage, new values: keeps the program, the version counter re-triggers the trace
@@ -267,6 +272,10 @@ def test_failed_factorisation_leaves_the_parameter_untouched(capsys):
     assert "Linear solver failed" in out
     got = net.pose.detach().tensor()
     assert torch.equal(got, P1)
+    after = {k: opt.param_groups[0].get(k) for k in ("damping", "radius", "down")}
+    for k in before:
+        if before[k] is not None and not (kind == "trustregion" and k == "radius"):      # (radius is re-derived as 1 / damping)
+            assert after[k] == pytest.approx(before[k], rel=1e-12), (k, before, after)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
