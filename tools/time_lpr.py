@@ -48,7 +48,9 @@ out = {}
 for group, rnd in (("SE3", pp.randn_SE3), ("SO3", pp.randn_SO3), ("Sim3", pp.randn_Sim3)):
     torch.manual_seed(0)
     init, X, A = rnd(n, device=dev), rnd(n, device=dev), rnd(n, device=dev)
-    pts, tgt = torch.randn(n, 3, device=dev), torch.randn(n, 3, device=dev)
+    pts = torch.randn(n, 3, device=dev)
+    with torch.no_grad():                          # targets = the points under a transform NEAR the start (a solvable problem)
+        tgt = (rnd(n, sigma=0.05, device=dev) @ init).Act(pts).contiguous()
     progs = {"Log(P X)": (lambda p, c: (p @ c["X"]).Log().tensor(), (X,), None, ()),
              "Log(P^-1 X)": (lambda p, c: (p.Inv() @ c["X"]).Log().tensor(), (X,), None, ()),
              "Log(A P^-1 X)": (lambda p, c: (c["A"] @ p.Inv() @ c["X"]).Log().tensor(), (X,), None, ()),
