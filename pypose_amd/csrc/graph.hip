@@ -642,7 +642,14 @@ pcg_prepare_kernel(const T* __restrict__ B, const T* __restrict__ g, T* __restri
                    T* scal, T s_host, T dmin, T dmax, int64_t N, const double* __restrict__ s_dev) {
   // the compounded damping factor: a launch argument, or (s_dev) a device scalar -- a captured hipGraph of the whole LM trial
   // is replayed with the factor of the day written there
-  const T s = s_dev ? (T)s_dev[0] : s_host;
+  // (system scope, one lane per workgroup: the scalar may sit in host-pinned memory that the host rewrites between replays of a
+  //  captured graph -- a read is a round trip over the host link, and 10^4 lanes reading it took 14 us)
+  __shared__ T s_sh;
+  if (s_dev) {
+    if (threadIdx.x == 0) s_sh = (T)__hip_atomic_load(s_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __syncthreads();
+  }
+  const T s = s_dev ? s_sh : s_host;
   T a_rho = T(0), a_bn = T(0);
   for (int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x; n < N; n += (int64_t)gridDim.x * 256) {
     T A[M * M], X[M * M], rv[M];

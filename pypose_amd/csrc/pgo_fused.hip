@@ -12,6 +12,11 @@
 // 24 residual + 2 * 144 Jacobian written = 412 B; the autograd route makes 6 backward sweeps through five ops.
 #include "rowmap.h"
 
+extern "C" int pplie_graph_gain_terms_f32(const void* J, const void* idx, const void* d, int ld, const void* R, void* partial,
+                                          int64_t E, int dr, int m, int k, void* stream);      // csrc/graph.hip
+extern "C" int pplie_graph_gain_terms_f64(const void* J, const void* idx, const void* d, int ld, const void* R, void* partial,
+                                          int64_t E, int dr, int m, int k, void* stream);
+
 namespace pplie {
 
 // r = Log(Z^-1 n1^-1 n2);  T = Z^-1 n1^-1
@@ -123,6 +128,92 @@ pgo_residual_kernel(const T* __restrict__ nodes, const int64_t* __restrict__ idx
 
 constexpr int kPgoPartials = 1024;     // = PPLIE_PGO_PARTIALS in include/pplie.h
 
+// ---------------------------------------------------------------------------------------------
+// The tail of one captured LM trial (optim/pgograph.py): everything between the linear solve and the host's decision,
+// four launches and no tensor ops --
+//   retract   nodes <- Exp(x_n) nodes_n   (lietensor.py:60-65, optimizer.py update_parameter); the old rows go to `backup` if given
+//   residual  per edge at the candidate: per-workgroup partials of |r|^2, the trial's loss (optimizer.py:672; pgo_residual_kernel)
+//   gain      JD_e = J_e0 x_i + J_e1 x_j: partials of sum JD.JD, sum JD.R  (strategy.py:144, :261; graph_gain_kernel, csrc/graph.hip)
+//   pack      one wavefront: the partials summed in index order (double), the solve's (iterations, |r|^2, |b|^2, flag) appended,
+//             the loss stored into the caller's ring of loss scalars, and the 8 doubles {a, b, loss, its, rr, bn2, flag, seq}
+//             stored with SYSTEM scope -- `out` may be host-pinned memory the host polls for `seq`, the last word written.
+// `state` (device memory, three 64-bit words): {seq: incremented by every execution, address of the loss ring (T*) or 0, its length}.
+// ---------------------------------------------------------------------------------------------
+template <class T>
+__global__ void __launch_bounds__(256)
+pgo_retract_kernel(T* __restrict__ nodes, const T* __restrict__ x, T* __restrict__ backup /* or null */, int64_t N) {
+  const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (n >= N) return;
+  T d[7], X[7], E[7], out[7];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) d[k] = x[n * 6 + k];
+  d[6] = T(0);
+#pragma unroll
+  for (int k = 0; k < 7; ++k) X[k] = nodes[n * 7 + k];
+  if (backup) {
+#pragma unroll
+    for (int k = 0; k < 7; ++k) backup[n * 7 + k] = X[k];
+  }
+  se3_exp<T>(d, E);
+  se3_mul<T>(E, X, out);
+#pragma unroll
+  for (int k = 0; k < 7; ++k) nodes[n * 7 + k] = out[k];
+}
+
+template <class T>
+__global__ void __launch_bounds__(64)
+pgo_trial_pack_kernel(const T* __restrict__ partial, int nparts, const T* __restrict__ pcg_info, unsigned long long* state,
+                      double* out) {
+  // every lane sums the partials i = q, q + 64, ... and a shuffle tree adds the lanes: a fixed order, the same bits every replay
+  const int q = threadIdx.x;
+  double loss = 0.0, a = 0.0, b = 0.0;
+  for (int i = q; i < nparts; i += 64) {
+    loss += (double)partial[i];                                   // pgo_residual_kernel
+    a += (double)partial[kPgoPartials + 2 * i];                   // graph_gain_kernel: sum JD.JD
+    b += (double)partial[kPgoPartials + 2 * i + 1];               //                    sum JD.R
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    loss += __shfl_down(loss, off, 64);
+    a += __shfl_down(a, off, 64);
+    b += __shfl_down(b, off, 64);
+  }
+  loss = __shfl(loss, 0, 64); a = __shfl(a, 0, 64); b = __shfl(b, 0, 64);
+  const unsigned long long seq = state[0] + 1, ring = state[1], len = state[2];
+  const T lossT = (T)loss;
+  if (q == 0) {
+    state[0] = seq;
+    if (ring && len) reinterpret_cast<T*>(ring)[seq % len] = lossT;
+  }
+  // seven lanes store one word each (the stores overlap: `out` may be host memory, a round trip per store), then the
+  // sequence number behind a system-scope fence
+  const double v = q == 0 ? a : q == 1 ? b : q == 2 ? (double)lossT : q < 7 ? (double)pcg_info[q - 3] : 0.0;
+  if (q < 7) __hip_atomic_store(out + q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __threadfence_system();
+  if (q == 0) __hip_atomic_store(out + 7, (double)seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+template <class T>
+int pgo_trial_tail(void* nodes, void* backup, const void* idx, const void* Z, const void* J, const void* R, const void* x, const void* pcg_info,
+                   void* partial, void* state, void* out, int64_t N, int64_t E, void* stream) {
+  if (N <= 0 || E <= 0) return PPLIE_EBADARG;
+  if (!nodes || !idx || !Z || !J || !R || !x || !pcg_info || !partial || !state || !out || !aligned16(Z)) return PPLIE_EBADARG;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL((pgo_retract_kernel<T>), dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, (T*)nodes, (const T*)x, (T*)backup, N);
+  constexpr int BLOCK = 256;
+  const int64_t nt = (E + BLOCK - 1) / BLOCK;
+  const int grid = (int)(nt < kPgoPartials ? nt : kPgoPartials);             // (= the grid of both kernels below)
+  T* part = (T*)partial;
+  hipLaunchKernelGGL((pgo_residual_kernel<T, BLOCK>), dim3(grid), dim3(BLOCK), 0, st, (const T*)nodes, (const int64_t*)idx,
+                     (const T*)Z, (T*)nullptr, part, E);
+  const int code = sizeof(T) == 4 ? pplie_graph_gain_terms_f32(J, idx, x, 6, R, part + kPgoPartials, E, 6, 6, 2, stream)
+                                  : pplie_graph_gain_terms_f64(J, idx, x, 6, R, part + kPgoPartials, E, 6, 6, 2, stream);
+  if (code != PPLIE_OK) return code;
+  hipLaunchKernelGGL((pgo_trial_pack_kernel<T>), dim3(1), dim3(64), 0, st, (const T*)part, grid, (const T*)pcg_info,
+                     (unsigned long long*)state, (double*)out);
+  return hipGetLastError() == hipSuccess ? PPLIE_OK : PPLIE_ELAUNCH;
+}
+
 template <class T>
 int pgo_linearize(const void* nodes, const void* idx, const void* Z, void* R, void* J, int64_t E, void* stream) {
   if (E < 0) return PPLIE_EBADARG;
@@ -159,4 +250,14 @@ extern "C" int pplie_pgo_residual_f32(const void* nodes, const void* idx, const 
 }
 extern "C" int pplie_pgo_residual_f64(const void* nodes, const void* idx, const void* Z, void* R, void* partial, int64_t E, void* stream) {
   return pplie::pgo_residual_launch<double>(nodes, idx, Z, R, partial, E, stream);
+}
+extern "C" int pplie_pgo_trial_tail_f32(void* nodes, void* backup, const void* idx, const void* Z, const void* J, const void* R, const void* x,
+                                        const void* pcg_info, void* partial, void* state, void* out, int64_t N, int64_t E,
+                                        void* stream) {
+  return pplie::pgo_trial_tail<float>(nodes, backup, idx, Z, J, R, x, pcg_info, partial, state, out, N, E, stream);
+}
+extern "C" int pplie_pgo_trial_tail_f64(void* nodes, void* backup, const void* idx, const void* Z, const void* J, const void* R, const void* x,
+                                        const void* pcg_info, void* partial, void* state, void* out, int64_t N, int64_t E,
+                                        void* stream) {
+  return pplie::pgo_trial_tail<double>(nodes, backup, idx, Z, J, R, x, pcg_info, partial, state, out, N, E, stream);
 }

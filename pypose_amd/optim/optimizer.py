@@ -33,6 +33,7 @@ from .corrector import FastTriggs
 from .functional import modjac
 from .solver import PINV, Cholesky
 from .strategy import Adaptive, Constant, TrustRegion
+from . import strategy as _strategy
 
 
 class Trivial(nn.Module):
@@ -427,9 +428,7 @@ class LevenbergMarquardt(_Optimizer):
             if pend is not None:
                 lin.pending_info = None
                 lin._pending_solver.iterations = pend.resolve(vals[3:7])     # raises like an eager solve would have
-            x = max(a, 1e-300) ** 0.5
-            one = torch.ones((1, 1), dtype=torch.float64)
-            self.strategy.update(pg, last=last_h, loss=loss_h, J=one, D=x * one, R=(b / x) * one)
+            _strategy.update_from_terms(self.strategy, pg, last_h, loss_h, a, b)
             return loss_h
         if self.group is None or getattr(J, 'replicated', False):
             self.strategy.update(pg, last=self.last, loss=self.loss, J=J, D=D, R=R)

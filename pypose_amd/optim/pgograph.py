@@ -9,8 +9,14 @@ on buffers that can stay where they are:
     prepare (clamp + damp + block inverses; the damping factor is read from a DEVICE scalar)  ->  persistent PCG  ->
     retract the parameters  ->  loss at the candidate  ->  gain-ratio terms  ->  [gain, loss, solver info] in one vector
 
-so it is captured once (torch.cuda.CUDAGraph over the very same Python code path the un-captured step runs) and a step
-becomes: write the damping factor, replay, read the vector back, run the strategy / accept test on the host.  A rejected
+so it is captured once and a step becomes: write the damping factor, replay, wait for the verdict, run the strategy / accept
+test on the host.  Host and device talk through two small blocks of HOST-PINNED memory instead of copies and fills: the
+prepare kernel reads the damping factor from one (system-scope load), the last kernel of the trial stores
+{gain terms, loss, solver info, sequence number} into the other (system-scope stores, the sequence number last) and the host
+polls that word -- no stream synchronisation, no device-to-host copy, no fill kernel on the critical path between two trials
+(measured with rocprofv3: the step had ~105 us of host round trips and 15 small tensor kernels behind a 145-500 us solve).
+Everything after the solve is four launches of one C entry point (`pplie_pgo_trial_tail`: retract, candidate loss, gain
+terms, pack).  A rejected
 trial (rare) continues in the ordinary trial loop on the captured linearisation.  The capture is used only while the
 program, its operands, the weight, the parameter storage and the solver settings are what it was captured on: by default
 the model's Python is run (dry, no launches) at the top of every step and the program re-matched from that trace
@@ -18,10 +24,16 @@ the model's Python is run (dry, no launches) at the top of every step and the pr
 """
 from __future__ import annotations
 
+import ctypes
+
 import torch
 
 from .. import _C
 from . import fused as _fused
+from . import strategy as _strategy
+
+_TAIL_SIG = [ctypes.c_void_p] * 11 + [ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p]
+_PARTIALS = 1024          # PPLIE_PGO_PARTIALS
 
 
 class PgoGraphStep:
@@ -37,10 +49,21 @@ class PgoGraphStep:
         assert isinstance(solver, PCG)
         self.solver_key = (solver, solver.tol, solver.maxiter, solver.check_every)
         dev = P.device
-        self.s_dev = torch.ones(1, dtype=torch.float64, device=dev)
+        pt = torch.Tensor.as_subclass(P, torch.Tensor).detach()
+        # host-pinned blocks the kernels address directly: ctl = {damping factor}, out = {a, b, loss, iterations, |r|^2, |b|^2,
+        # flag, seq}; device state of the pack kernel: {seq (counts executions), loss ring address, its length}
+        self.ctl = torch.ones(2, dtype=torch.float64).pin_memory()
+        self.ctl_f = self.ctl.numpy()
+        self.out = torch.zeros(8, dtype=torch.float64).pin_memory()
+        self.out_np = self.out.numpy()
+        self.seq = 0
+        self.state = torch.zeros(3, dtype=torch.int64, device=dev)
+        self.partial = torch.empty(3 * _PARTIALS, dtype=pt.dtype, device=dev)
+        self._new_ring(pt.dtype, dev)
+        self.tail = _C.library().symbol("pplie_pgo_trial_tail" + ("_f32" if pt.dtype == torch.float32 else "_f64"), _TAIL_SIG)
         self.params = [p for p in pg['params'] if p.requires_grad]
         self.graph = None
-        self.backup = torch.empty_like(torch.Tensor.as_subclass(P, torch.Tensor).detach())   # the parameters before the latest replay
+        self.backup = torch.empty_like(pt)      # the parameters before the latest replay
         # capture on a side stream (torch.cuda.graph does that); the first replay-equivalent run happens during capture
         torch.cuda.synchronize(dev)
         saved = P.detach().clone()
@@ -51,32 +74,49 @@ class PgoGraphStep:
         with torch.no_grad():           # capture does not execute: nothing moved, but be explicit about the state we hand back
             torch.Tensor.as_subclass(P, torch.Tensor).detach().copy_(torch.Tensor.as_subclass(saved, torch.Tensor))
 
+    RING = 1024
+
+    def _new_ring(self, dtype, dev):
+        """the trial's loss lands in a ring of device scalars (``opt.loss`` is a view of one): a fresh ring when this one has
+        gone round, so a loss handed out earlier is never overwritten"""
+        self.ring = torch.zeros(self.RING, dtype=dtype, device=dev)
+        self.loss_views = self.ring.unbind(0)
+        self.state[1:].copy_(torch.tensor([self.ring.data_ptr(), self.RING], dtype=torch.int64))     # (once per RING trials)
+
     def _trial(self, pg):
         opt = self.opt
-        # (first node of the captured trial: a replay launched speculatively -- before this step's run of the model has
-        #  confirmed the program, see fused.checked_shortcut -- is undone by copying this back)
-        self.backup.copy_(torch.Tensor.as_subclass(self.P, torch.Tensor).detach())
+        pt = torch.Tensor.as_subclass(self.P, torch.Tensor).detach()
+        # (a replay launched speculatively -- before this step's run of the model has confirmed the program, see
+        #  fused.checked_shortcut -- is undone by copying `backup` back: the retraction kernel, the only writer of the
+        #  parameters in the trial, saves the rows it overwrites)
         lin = _fused._pgo_linearization(opt, self.prog, self.weight, self.P, self.trivial)
         lin.build_normal_equations(*self.clamp)
-        lin.s_dev = self.s_dev                     # prepare reads the damping factor from here (pplie_pcg_prepare_dev)
-        opt._defer_solver_info = True
+        lin.s_dev = self.ctl                       # prepare reads the damping factor from here (pplie_pcg_prepare_dev)
+        opt._defer_solver_info = 'inplace'
         try:
-            D = lin.solve(opt.solver)
+            Dn = lin._pcg(opt.solver, lin.s, lin.dmin, lin.dmax, plain=False)       # [N, 6]: the solver workspace's x itself
         finally:
             opt._defer_solver_info = False
         lin.s_dev = None                           # retries after a rejection run un-captured, with the host value
-        opt.update_parameter(pg['params'], D)
-        loss = lin.fast_loss()
-        J, R = lin.strategy_args()
-        ab = J.gain_terms(D)
         pend, lin.pending_info = lin.pending_info, None
-        self.out = torch.cat([ab.reshape(-1).double(), loss.detach().reshape(1).double(), pend.info.double()])
-        self.lin, self.D, self.loss, self.J, self.R = lin, D, loss, J, R
+        prog = self.prog
+        assert pend is not None and Dn.is_contiguous() and pt.is_contiguous() and lin.m == 6 and lin.K == 2 and lin.dr == 6 \
+            and lin.idx.data_ptr() == prog.idx.data_ptr() and lin.E == prog.E
+        with _C._on_device(pt.device):
+            code = self.tail(pt.data_ptr(), self.backup.data_ptr(), prog.idx.data_ptr(), prog.Z.data_ptr(), lin.J.data_ptr(), lin.R.data_ptr(), Dn.data_ptr(),
+                             pend.info.data_ptr(), self.partial.data_ptr(), self.state.data_ptr(), self.out.data_ptr(), lin.N, lin.E,
+                             _C.stream_ptr(pt.device))
+        _C.check(code, "pplie_pgo_trial_tail")
+        self.lin, self.Dn = lin, Dn
 
     # -- per step ------------------------------------------------------------------------------------
     def usable(self, pg, input, target, weight, checked=False):
         """``checked``: the caller has just matched this step's dry run of the model to ``self.prog`` (the default);
         otherwise (LM(static=True)) the program is taken on trust while the same input objects / operand storage are passed."""
+        with _fused._no_tf():      # (attribute reads on a LieTensor parameter are __torch_function__ round trips: ~3 us each)
+            return self._usable(pg, input, target, weight, checked)
+
+    def _usable(self, pg, input, target, weight, checked):
         opt, P = self.opt, self.P
         cache = opt.__dict__.get('_structure_cache')
         if cache is None or cache.get("fused") is not True or target is not None:
@@ -116,15 +156,33 @@ class PgoGraphStep:
         self._had_loss = hasattr(opt, 'loss')
         if not self._had_loss:                     # first step of a run: the loss at the starting point (optimizer.py:659)
             opt.loss = self.lin.fast_loss()
+        lin = self.lin
+        lin.s = 1.0 + float(pg['damping'])         # (host mirror: a retry compounds from here)
+        self.ctl_f[0] = lin.s
+        self.seq = seq = self.seq + 1
+        self.slot = seq % self.RING
+        if self.slot == 0:
+            self._new_ring(self.ring.dtype, self.ring.device)
+        self.graph.replay()
+        # (the GPU is working: the step's host-side bookkeeping happens behind the launch)
         self._prev_last = opt.__dict__.get('_last_view')
         opt.last = opt.loss
         self._last_h = opt._host(opt.loss)
         opt.reject_count = 0
-        lin = self.lin
-        lin.s = 1.0 + float(pg['damping'])         # (host mirror: a retry compounds from here)
-        self.s_dev.fill_(lin.s)
-        self.graph.replay()
         _C.mark_written(self.P)
+
+    def _wait(self):
+        """the trial's verdict: poll the pinned word the last kernel stores; a solve that takes unusually long is waited for
+        with a stream synchronisation instead"""
+        out, seq = self.out_np, float(self.seq)
+        n = 0
+        while out[7] != seq:
+            n += 1
+            if n > 200_000:
+                torch.cuda.synchronize(self.backup.device)
+                if out[7] != seq:
+                    raise RuntimeError("pypose_amd: the captured pose-graph trial finished without reporting its result")
+        return out[:7].tolist()
 
     def cancel(self):
         """undo a speculative launch: wait for it, put the parameters back (nothing else it wrote is state)"""
@@ -143,7 +201,7 @@ class PgoGraphStep:
 
     def finish(self, pg):
         opt, lin, last_h = self.opt, self.lin, self._last_h
-        a, b, loss_h, its, rr, bn2, flag = self.out.tolist()          # the trial's one synchronisation
+        a, b, loss_h, its, rr, bn2, flag = self._wait()               # the trial's one wait (no stream synchronisation)
         opt.linearization = lin.kind
         opt._last_replicated = False
         if flag >= 2.0 or rr != rr:                # a failed solve returned a zero step: the parameters are where they were
@@ -160,14 +218,13 @@ class PgoGraphStep:
             opt.loss = opt.last
             return opt.loss
         opt.solver.iterations = int(its)
-        x = max(a, 1e-300) ** 0.5
-        one = torch.ones((1, 1), dtype=torch.float64)
-        opt.strategy.update(pg, last=last_h, loss=loss_h, J=one, D=x * one, R=(b / x) * one)
+        _strategy.update_from_terms(opt.strategy, pg, last_h, loss_h, a, b)
         if last_h < loss_h and opt.reject_count < opt.reject:        # rejected: back, then the ordinary trial loop
-            opt.update_parameter(params=pg['params'], step=-self.D)
+            opt.update_parameter(params=pg['params'], step=-lin.nodes_to_step(self.Dn))
             opt.loss, opt.reject_count, loss_h = opt.last, 1, last_h
-            loss_h = opt._trial_loop(pg, lin, self.J, self.R, None, None, last_h, loss_h, defer=False)
+            J, R = lin.strategy_args()
+            loss_h = opt._trial_loop(pg, lin, J, R, None, None, last_h, loss_h, defer=False)
         else:
-            opt.loss = self.loss.clone()           # (the captured buffer is overwritten by the next replay)
+            opt.loss = self.loss_views[self.slot]  # (a ring of device scalars: never overwritten while the view is alive)
         opt._host_loss = (opt.loss, loss_h)
         return opt.loss

@@ -505,6 +505,8 @@ class FusedPCG:
                     self.no_persist = True
                     return self.solve(lin, s, dmin, dmax, tol, maxiter, group, plain=plain, defer=defer)
                 _C.check(code, "pplie_pcg_persist")
+                if defer == 'inplace':                              # (a captured trial: the tail kernels read the workspace itself)
+                    return self.x, _PendingInfo(self.info)
                 if defer:
                     # the caller reads `info` together with the trial's loss and gain terms (ONE read-back per LM trial);
                     # a failed solve returns x = 0, so whatever was queued behind it left the parameters alone
@@ -826,7 +828,8 @@ class GraphLinearization:
             wsp = cache.get(key)
             if wsp is None:
                 wsp = cache[key] = FusedPCG(*key)
-            defer = bool(getattr(self.opt, '_defer_solver_info', False)) and not plain
+            defer = getattr(self.opt, '_defer_solver_info', False)
+            defer = False if plain else (defer if defer == 'inplace' else bool(defer))
             Dn, its = wsp.solve(self, s, dmin, dmax, solver.tol, maxiter, self.group, plain=plain, defer=defer)
             if isinstance(its, _PendingInfo):
                 self.pending_info, self._pending_solver = its, solver

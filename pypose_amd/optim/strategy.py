@@ -34,9 +34,23 @@ def _bounded(x, lo, hi):
     return lo if x < lo else (hi if x > hi else x)
 
 
-def _grade(pg, last, loss, J, D, R):
-    quality = gain_ratio(last, loss, J, D, R)
+def _grade(pg, quality):
     return GOOD if quality > pg['high'] else (FAIR if quality > pg['low'] else POOR)
+
+
+def update_from_terms(strategy, pg, last, loss, a, b):
+    """``strategy.update`` from the two dot products ``a = (J D).(J D)``, ``b = (J D).R`` a fused linearisation reads back with
+    the loss: the equivalent 1 x 1 problem ``x^2 = a``, ``x r = b``.  The policies of this module take it as host floats (the same
+    IEEE double operations the 1 x 1 tensors went through, without seven tensor ops on the step's critical path); any other
+    strategy object -- the reference's own, a user's -- gets the 1 x 1 tensors its ``update`` expects."""
+    x = max(a, 1e-300) ** 0.5
+    if type(strategy) in (Constant, Adaptive, TrustRegion):
+        r = b / x
+        strategy.update_quality(pg, (last - loss) / -(x * (2 * r + x)))
+        return
+    import torch
+    one = torch.ones((1, 1), dtype=torch.float64)
+    strategy.update(pg, last=last, loss=loss, J=one, D=x * one, R=(b / x) * one)
 
 
 class Constant(object):
@@ -47,6 +61,9 @@ class Constant(object):
         self.defaults = {'damping': damping}
 
     def update(self, pg, *args, **kwargs):
+        pg['damping'] = pg['damping']
+
+    def update_quality(self, pg, quality):
         pg['damping'] = pg['damping']
 
 
@@ -60,7 +77,10 @@ class Adaptive(object):
         self.min, self.max = min, max
 
     def update(self, pg, last, loss, J, D, R, *args, **kwargs):
-        factor = {GOOD: pg['down'], FAIR: 1, POOR: pg['up']}[_grade(pg, last, loss, J, D, R)]
+        self.update_quality(pg, gain_ratio(last, loss, J, D, R))
+
+    def update_quality(self, pg, quality):
+        factor = {GOOD: pg['down'], FAIR: 1, POOR: pg['up']}[_grade(pg, quality)]
         pg['damping'] = _bounded(pg['damping'] * factor, self.min, self.max)
 
 
@@ -78,7 +98,10 @@ class TrustRegion(object):
                          'up': up, 'down': down, 'factor': factor}
 
     def update(self, pg, last, loss, J, D, R, *args, **kwargs):
-        grade = _grade(pg, last, loss, J, D, R)
+        self.update_quality(pg, gain_ratio(last, loss, J, D, R))
+
+    def update_quality(self, pg, quality):
+        grade = _grade(pg, quality)
         radius = 1. / pg['damping']
         if grade == POOR:
             radius, shrink = radius * pg['down'], pg['down'] * pg['factor']
