@@ -32,6 +32,7 @@
 #include <cstdlib>
 #include "rowmap.h"
 #include "gridsync.h"
+#include "dpp.h"
 
 namespace pplie {
 
@@ -170,12 +171,12 @@ template <class T, int M> __device__ __forceinline__ T node_binv(const PersistLa
 // wave-level sums of NQ quantities into the exchange's LDS (every lane calls; then ONE __syncthreads, then publish_row)
 template <class T, int NQ> __device__ __forceinline__ void post_wave_sums(PersistShared<T>& sh, int par, T* v, bool act, bool stale) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  // (DPP adds on the VALU: the 30 ds_bpermute of a shuffle tree queue behind the SpMV's reads on the one LDS pipe the 16 waves share)
 #pragma unroll
   for (int q = 0; q < NQ; ++q) {
     if (!act) v[q] = T(0);
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v[q] += __shfl_down(v[q], off, 64);
-    if (lane == 0) sh.wave_part[par][q][w] = v[q];
+    v[q] = wave_total63<T>(v[q]);
+    if (lane == 63) sh.wave_part[par][q][w] = v[q];
   }
   if (stale) sh.bad[par] = 1;
 }
@@ -441,13 +442,13 @@ pcg_ghost_kernel(const int* __restrict__ ptr, const int* __restrict__ slot, cons
   const int g_lo = gptr[blockIdx.x], n_ghost = gptr[blockIdx.x + 1] - g_lo;
 
   // ---- owned element
-  T dc[M], br[M], xe = T(0), re = T(0), ze = T(0), pe = T(0);
+  T dr[M], br[M], xe = T(0), re = T(0), ze = T(0), pe = T(0);
   int beg = 0, deg = 0;
 #pragma unroll
-  for (int j = 0; j < M; ++j) { dc[j] = T(0); br[j] = T(0); }
+  for (int j = 0; j < M; ++j) { dr[j] = T(0); br[j] = T(0); }
   if (act) {
 #pragma unroll
-    for (int j = 0; j < M; ++j) { dc[j] = D[(n * M + j) * M + i]; br[j] = Binv[(n * M + i) * M + j]; }
+    for (int j = 0; j < M; ++j) { dr[j] = D[(n * M + i) * M + j]; br[j] = Binv[(n * M + i) * M + j]; }
     re = r[n * M + i];
     ze = z[n * M + i];
     pe = ze;
@@ -472,26 +473,16 @@ pcg_ghost_kernel(const int* __restrict__ ptr, const int* __restrict__ slot, cons
       gp[l] = z[(size_t)gnode[l] * M + i];                         // p_0 = z_0
     }
   }
-  int maxdeg = deg;
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    const int o = __shfl_xor(maxdeg, off, 64);
-    maxdeg = o > maxdeg ? o : maxdeg;
-  }
-  // ---- LDS: [ per-wave transpose pads | p of the local nodes | staged blocks (transposed) | staged local slots ]
-  T* tr = reinterpret_cast<T*>(dyn_lds) + (size_t)w * NPW * M * M;
-  constexpr size_t kPadBytes = (size_t)WV * NPW * M * M * sizeof(T);
+  // ---- LDS: [ p of the local nodes (owned, then ghost layers) | staged blocks, row-major | y = H_c p per incidence | local slots ]
   constexpr size_t kPBytes = (size_t)(1 + kGhostLayers) * POS * M * sizeof(T);
-  T* p_l = reinterpret_cast<T*>(dyn_lds + kPadBytes);
+  T* p_l = reinterpret_cast<T*>(dyn_lds);
   const int c_lo = ptr[n0], c_cnt = ptr[n1] - c_lo;
-  T* hb_l = reinterpret_cast<T*>(dyn_lds + kPadBytes + kPBytes);
-  int* sl_l = reinterpret_cast<int*>(dyn_lds + kPadBytes + kPBytes + (size_t)c_cnt * M * M * sizeof(T));
+  T* hb_l = reinterpret_cast<T*>(dyn_lds + kPBytes);
+  T* yb = hb_l + (size_t)c_cnt * M * M;
+  int* sl_l = reinterpret_cast<int*>(yb + (size_t)c_cnt * M);
   {                                                                // (host guarantees the slice fits: see pcg_ghost())
     const T* src = HB + (size_t)c_lo * M * M;
-    for (int e = threadIdx.x; e < c_cnt * M * M; e += kPersistBlock) {
-      const int c = e / (M * M), ij = e % (M * M);
-      hb_l[c * M * M + (ij % M) * M + ij / M] = src[e];
-    }
+    for (int e = threadIdx.x; e < c_cnt * M * M; e += kPersistBlock) hb_l[e] = src[e];
     for (int e = threadIdx.x; e < c_cnt; e += kPersistBlock) sl_l[e] = slot[c_lo + e];
   }
   if (act) p_l[pos * M + i] = pe;
@@ -504,42 +495,53 @@ pcg_ghost_kernel(const int* __restrict__ ptr, const int* __restrict__ slot, cons
 
   T bn2 = T(0), rr = T(0);
   int k = 0, flag = 0;
+  // cap < 0 (tools/time_pcg_iter.py): thread 0 of the middle workgroup accumulates the wall-clock ticks (10 ns) of the phases
+  const bool prof = cap < 0;
+  if (prof) cap = -cap;
+  const bool clocked = prof && blockIdx.x == gridDim.x / 2 && threadIdx.x == 0;
+  unsigned long long tk[5] = {0, 0, 0, 0, 0}, t_prev = clocked ? wall_clock64() : 0;
+#define PPLIE_TICK(slot)                                       \
+  if (clocked) {                                               \
+    const unsigned long long t_now = wall_clock64();           \
+    tk[slot] += t_now - t_prev;                                \
+    t_prev = t_now;                                            \
+  }
   for (;; ++k) {
     const unsigned tag = (unsigned)k + 1u;
     const int par = k & 1;
-    // ---- q = A p from LDS: this lane contributes column i of every block of its node
-    T a[M];
+    // ---- q = A p from LDS in two passes.  (1) INCIDENCE-parallel over all 16 waves: lane group g takes incidences g, g + POS, ...
+    // and lane i of it forms component i of y_c = H_c p_far(c) (row i of the block, the neighbour's p: both contiguous);
+    // (2) the node's lanes add the diagonal term and their node's y in incidence order.  (Was: the node's own 6 lanes walked its
+    // incidences -- a chain of dependent LDS reads as long as the largest degree in the wave, on 4 of the 16 waves -- and a
+    // transpose through LDS: 1.65 us of the 7.1 us iteration.)
+    if (sub < NPW) {
+      for (int c = pos; c < c_cnt; c += POS) {
+        const T* h = hb_l + ((size_t)c * M + i) * M;
+        const T* pp = p_l + (size_t)sl_l[c] * M;
+        T y = T(0);
 #pragma unroll
-    for (int j = 0; j < M; ++j) a[j] = dc[j] * pe;
-#pragma unroll 4
-    for (int c = 0; c < maxdeg; ++c) {                             // (wave-uniform trip count, absent incidences masked)
-      const bool valid = c < deg;
-      const int cc = valid ? lbeg + c : 0;
-      const T pv = valid ? p_l[sl_l[cc] * M + i] : T(0);
-      const T* h = hb_l + ((size_t)cc * M + i) * M;
-#pragma unroll
-      for (int j = 0; j < M; ++j) a[j] += h[j] * pv;
+        for (int j = 0; j < M; ++j) y += h[j] * pp[j];
+        yb[c * M + i] = y;
+      }
     }
+    __syncthreads();                                                             // barrier 0: every y is in place
     T acc = T(0);
-    if (sub < NPW) {
+    if (act) {
+      const T* pp = p_l + (size_t)pos * M;
 #pragma unroll
-      for (int j = 0; j < M; ++j) tr[(sub * M + i) * M + j] = a[j];
+      for (int j = 0; j < M; ++j) acc += dr[j] * pp[j];
+#pragma unroll 4
+      for (int c = 0; c < deg; ++c) acc += yb[(lbeg + c) * M + i];
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    if (sub < NPW) {
-#pragma unroll
-      for (int j = 0; j < M; ++j) acc += tr[(sub * M + j) * M + i];
-    }
-    __builtin_amdgcn_wave_barrier();
     if (act) put_value<T>(qtag + (size_t)par * NM + (size_t)(n * M + i) * NW, acc, tag);      // q of the owned nodes, for their readers
+    PPLIE_TICK(0)
     T bq = T(0);
 #pragma unroll
     for (int j = 0; j < M; ++j) bq += br[j] * __shfl(acc, sub * M + j, 64);
     T v[kPersistQ] = {acc * pe, acc * ze, acc * bq, re * ze, re * re};
     post_wave_sums<T, kPersistQ>(sh, par, v, act, false);
     __syncthreads();                                                             // barrier 1
+    PPLIE_TICK(1)
     publish_row<T, kPersistQ>(sh, par, part, tag);
     // ---- the ghosts' q: issued now, needed after the all-gather
     T gq[kGhostLayers];
@@ -550,6 +552,7 @@ pcg_ghost_kernel(const int* __restrict__ ptr, const int* __restrict__ slot, cons
       gq[l] = gact[l] ? get_value<T>(qtag + (size_t)par * NM + ((size_t)gnode[l] * M + i) * NW, tag, gok[l]) : T(0);
     }
     gather_rows<T, kPersistQ>(sh, par, part, tag);
+    PPLIE_TICK(2)
     bool stale = false;
 #pragma unroll
     for (int l = 0; l < kGhostLayers; ++l) {
@@ -562,6 +565,7 @@ pcg_ghost_kernel(const int* __restrict__ ptr, const int* __restrict__ slot, cons
     }
     if (stale) sh.bad[par] = 1;
     __syncthreads();                                                             // barrier 2
+    PPLIE_TICK(3)
     const T pq = sh.total[par][0], qz = sh.total[par][1], qmq = sh.total[par][2], rho = sh.total[par][3];
     rr = sh.total[par][4];
     if (sh.bad[par]) { flag = 3; break; }
@@ -595,7 +599,11 @@ pcg_ghost_kernel(const int* __restrict__ ptr, const int* __restrict__ slot, cons
       if (gact[l]) p_l[(n_own + l * POS + pos) * M + i] = gp[l];
     }
     __syncthreads();                                                             // barrier 3: every local p is in place
+    PPLIE_TICK(4)
   }
+#undef PPLIE_TICK
+  if (clocked)
+    for (int q = 0; q < 5; ++q) rr_hist[cap - 8 + q] = (T)tk[q];
   if (act) x[n * M + i] = flag >= 2 ? T(0) : xe;
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     info[0] = (T)k; info[1] = rr; info[2] = bn2; info[3] = (T)flag;
@@ -713,8 +721,8 @@ int pcg_ghost(const void* ptr, const void* slot, const void* HB, const void* D, 
     int lds_bytes = 0;                                                                                                         \
     const int resident = ghost_capacity<T, MM>(lds_bytes);                                                                     \
     constexpr int POS = (kPersistBlock / 64) * (64 / MM);                                                                      \
-    const size_t need = (size_t)POS * MM * MM * sizeof(T) + (size_t)(1 + kGhostLayers) * POS * MM * sizeof(T) +                 \
-                        (size_t)max_cnt * (MM * MM * sizeof(T) + 4);                                                           \
+    const size_t need = (size_t)(1 + kGhostLayers) * POS * MM * sizeof(T) +                                                    \
+                        (size_t)max_cnt * (MM * MM * sizeof(T) + MM * sizeof(T) + 4);                                          \
     if (resident < grid || need > (size_t)lds_bytes || max_ghost > kGhostLayers * POS || (N + grid - 1) / grid > POS)           \
       return PPLIE_ECAPACITY;             /* (the grid is part of the host's ghost map: it cannot be shrunk here) */             \
     hipLaunchKernelGGL((pcg_ghost_kernel<T, MM>), dim3(grid), dim3(kPersistBlock), lds_bytes, st, (const int*)ptr, (const int*)slot, \

@@ -55,6 +55,7 @@ import os as _os
 # graphs up to this many nodes run the whole PCG solve in ONE persistent launch (csrc/pcg_persist.hip); larger ones need
 # the whole chip's bandwidth per iteration and keep the two-launch hipGraph iteration
 PERSIST_NODES = int(_os.environ.get("PPLIE_PCG_PERSIST_NODES", "32768"))
+GHOST_GRIDS = (160, 192)    # grids the ghost-zone solve tries below PERSIST_GRID (tools/time_pcg_iter.py sweeps them)
 PERSIST_GRID = int(_os.environ.get("PPLIE_PCG_PERSIST_GRID", "256"))   # one 1024-lane workgroup per CU: 64 -> 675, 128 -> 788, 256 -> 850 LM steps/s at 10 k nodes
 _INV_SIG = [ctypes.c_void_p] * 2 + [ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]
 _HIP_SHAPES = {(6, 6, 2), (7, 7, 2), (3, 3, 2), (6, 6, 1), (3, 3, 1)}
@@ -482,16 +483,26 @@ class FusedPCG:
                 # the whole solve in one launch: iteration, reductions and the convergence test stay on the device
                 maxit = min(maxiter, self.cap - 1)
                 code = _C.ECAPACITY
-                if FusedPCG.ghost and not self.__dict__.get('_no_ghost') and not FusedPCG.profile:
+                if FusedPCG.ghost and not self.__dict__.get('_no_ghost'):
                     # ghost-zone form: ONE grid-wide dependency per iteration (csrc/pcg_persist.hip); falls through to the
-                    # two-dependency kernel when a workgroup's slice / ghost set does not fit
-                    grid = min(PERSIST_GRID, self.N)
-                    slot, gptr, gids, max_cnt, max_ghost = self._ghost_map(lin, grid)
-                    code = _C.library().symbol("pplie_pcg_ghost" + self.sfx, _GHOST_SIG)(
-                        self.ptr.data_ptr(), slot.data_ptr(), self.HB.data_ptr(), self.D.data_ptr(), self.Binv.data_ptr(),
-                        self.x.data_ptr(), self.r.data_ptr(), self.z.data_ptr(), gptr.data_ptr(), gids.data_ptr(), self.part.data_ptr(),
-                        self.ptag.data_ptr(), self.rr_hist.data_ptr(), self.info.data_ptr(), self.it.data_ptr(), float(tol), int(maxit),
-                        self.cap, grid, max_cnt, max_ghost, self.N, self.m, _C.stream_ptr(self.device))
+                    # two-dependency kernel when a workgroup's slice / ghost set does not fit.  Fewer, larger workgroups make the
+                    # all-gather of the partial sums cheaper (5.6 us per iteration at 160-176 workgroups, 6.4 at 256, 10 k nodes):
+                    # the smallest grid whose slices and ghost sets fit is kept for this workspace.
+                    hit = self.__dict__.get('_ghost_grids')
+                    if hit is None or hit[0] != (PERSIST_GRID, GHOST_GRIDS) or hit[2] is not self._csr_obj:
+                        cands = sorted({min(g, self.N) for g in GHOST_GRIDS if g < PERSIST_GRID} | {min(PERSIST_GRID, self.N)})
+                        hit = self._ghost_grids = ((PERSIST_GRID, GHOST_GRIDS), cands, self._csr_obj)
+                    while hit[1]:
+                        grid = hit[1][0]
+                        slot, gptr, gids, max_cnt, max_ghost = self._ghost_map(lin, grid)
+                        code = _C.library().symbol("pplie_pcg_ghost" + self.sfx, _GHOST_SIG)(
+                            self.ptr.data_ptr(), slot.data_ptr(), self.HB.data_ptr(), self.D.data_ptr(), self.Binv.data_ptr(),
+                            self.x.data_ptr(), self.r.data_ptr(), self.z.data_ptr(), gptr.data_ptr(), gids.data_ptr(), self.part.data_ptr(),
+                            self.ptag.data_ptr(), self.rr_hist.data_ptr(), self.info.data_ptr(), self.it.data_ptr(), float(tol), int(maxit),
+                            -self.cap if FusedPCG.profile else self.cap, grid, max_cnt, max_ghost, self.N, self.m, _C.stream_ptr(self.device))
+                        if code != _C.ECAPACITY:
+                            break
+                        hit[1].pop(0)
                     if code == _C.ECAPACITY:
                         self._no_ghost = True
                 if code == _C.ECAPACITY:

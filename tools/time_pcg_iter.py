@@ -25,7 +25,8 @@ with torch.no_grad():
     wsp = next(iter(opt._pcg_workspaces.values()))
     out = {"nodes": N, "edges": E}
     # the ghost-zone form (default) first: marginal cost per iteration and agreement with the two-dependency kernel
-    for grid in (192, 256):
+    G.GHOST_GRIDS = ()                           # (exactly the grid asked for)
+    for grid in (128, 160, 176, 192, 208, 224, 256):
         G.PERSIST_GRID = grid
         wsp.__dict__.pop('_no_ghost', None)
         res = {}
@@ -44,6 +45,15 @@ with torch.no_grad():
                                     "used": not wsp.__dict__.get("_no_ghost", False)}
     G.PERSIST_GRID = 256
     wsp.__dict__.pop('_no_ghost', None)
+    G.FusedPCG.profile = True                    # phases of the ghost-zone iteration (ticks of 10 ns, thread 0 of the middle workgroup)
+    try:
+        x, its = wsp.solve(lin, lin.s, lin.dmin, lin.dmax, 1e-30, 200, None)
+    finally:
+        G.FusedPCG.profile = False
+    torch.cuda.synchronize()
+    tk = wsp.rr_hist[wsp.cap - 8:wsp.cap - 3].tolist()
+    out["ghost_grid256_phase_us_per_iteration"] = {n: round(t * 0.01 / max(its, 1), 3) for n, t in zip(
+        ("spmv(2 passes, barrier0)+put_q", "wave_sums+barrier1", "publish+issue_ghost_q+allgather", "ghost_q_wait+barrier2", "update+barrier3"), tk)}
     xg, itg = wsp.solve(lin, lin.s, lin.dmin, lin.dmax, 1e-6, 2000, None)
     G.FusedPCG.ghost = False
     xp, itp = wsp.solve(lin, lin.s, lin.dmin, lin.dmax, 1e-6, 2000, None)
