@@ -457,7 +457,11 @@ extern "C" int pplie_graph_bsr_spmv_f64(const void* ptr, const void* other, cons
 namespace pplie {
 //   SYM: HB is [E, M, M], one block per EDGE (the side-0 incidence writes H_e = J_0^T W J_1; the side-1 incidence of the
 //   same edge needs H_e^T, which the SpMV reads transposed) -- valid for symmetric W; halves the off-diagonal bytes.
-template <class T, int DR, int M, int K, bool HAS_W, bool SYM = false>
+//   PACK: every off-diagonal block is SYMMETRIC and the same for both incidences of an edge (J_0 = -J_1, W symmetric: H_ij = H_ji =
+//   -J_1^T W J_1 -- the relative-pose program of csrc/pgo_fused.hip): HB is [nnz, M (M + 1) / 2], the upper triangle row by row, in
+//   incidence order -- 84 instead of 144 bytes per incidence for every SpMV to stream (pplie_pcg2_spmv_pack).
+template <int M> __host__ __device__ constexpr int tri_index(int i, int j) { return i * M - (i * (i - 1)) / 2 + (j - i); }   // i <= j
+template <class T, int DR, int M, int K, bool HAS_W, bool SYM = false, bool PACK = false>
 __global__ void __launch_bounds__(256)
 graph_assemble_csr_kernel(const int* __restrict__ ptr, const int* __restrict__ blk, const T* __restrict__ J,
                           const T* __restrict__ W, const T* __restrict__ R, T* __restrict__ Bdiag, T* __restrict__ grad,
@@ -474,8 +478,10 @@ graph_assemble_csr_kernel(const int* __restrict__ ptr, const int* __restrict__ b
 #pragma unroll
       for (int b = 0; b < M; ++b) row[b] = T(0);
       const int beg = ptr[n], end = ptr[n + 1];
+      int bk_next = beg < end ? blk[beg] : 0;                      // (the index runs one incidence ahead of the blocks it addresses)
       for (int c = beg; c < end; ++c) {
-        const int64_t bk = blk[c];
+        const int64_t bk = bk_next;
+        bk_next = c + 1 < end ? blk[c + 1] : 0;
         const int64_t e = bk / K;
         const T* Jc = J + bk * (DR * M);
         T v[DR];                                  // row i of J_c^T W
@@ -508,8 +514,14 @@ graph_assemble_csr_kernel(const int* __restrict__ ptr, const int* __restrict__ b
             for (int l = 0; l < DR; ++l)
 #pragma unroll
               for (int b = 0; b < M; ++b) hb[b] += v[l] * Jo[l * M + b];
+            if constexpr (PACK) {
 #pragma unroll
-            for (int b = 0; b < M; ++b) HB[((SYM ? e : (int64_t)c) * M + i) * M + b] = hb[b];
+              for (int b = 0; b < M; ++b)
+                if (b >= i) HB[(int64_t)c * (M * (M + 1) / 2) + (i * M - (i * (i - 1)) / 2 + (b - i))] = hb[b];
+            } else {
+#pragma unroll
+              for (int b = 0; b < M; ++b) HB[((SYM ? e : (int64_t)c) * M + i) * M + b] = hb[b];
+            }
           }
         }
       }
@@ -522,13 +534,26 @@ graph_assemble_csr_kernel(const int* __restrict__ ptr, const int* __restrict__ b
 
 template <class T, int DR, int M, int K>
 int graph_assemble_csr_launch(const void* ptr, const void* blk, const void* J, const void* W, const void* R, void* B, void* g,
-                              void* HB, int64_t N, void* stream, bool sym = false) {
+                              void* HB, int64_t N, void* stream, int sym = 0 /* 1: one block per edge, 2: packed symmetric per incidence */) {
   if (N <= 0) return N == 0 ? PPLIE_OK : PPLIE_EBADARG;
   if (!ptr || !blk || !J || !R || !B || !g) return PPLIE_EBADARG;
   constexpr int NPW = 64 / M;
   int64_t blocks = ((N + NPW - 1) / NPW + 3) / 4;
   int grid = (int)(blocks < (1 << 20) ? blocks : (1 << 20));
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (sym == 2) {
+    if constexpr (K == 2) {
+      if (!HB) return PPLIE_EBADARG;
+      if (W)
+        hipLaunchKernelGGL((graph_assemble_csr_kernel<T, DR, M, K, true, false, true>), dim3(grid), dim3(256), 0, st, (const int*)ptr,
+                           (const int*)blk, (const T*)J, (const T*)W, (const T*)R, (T*)B, (T*)g, (T*)HB, N);
+      else
+        hipLaunchKernelGGL((graph_assemble_csr_kernel<T, DR, M, K, false, false, true>), dim3(grid), dim3(256), 0, st, (const int*)ptr,
+                           (const int*)blk, (const T*)J, (const T*)nullptr, (const T*)R, (T*)B, (T*)g, (T*)HB, N);
+      return hipGetLastError() == hipSuccess ? PPLIE_OK : PPLIE_ELAUNCH;
+    }
+    return PPLIE_EBADARG;
+  }
   if (sym && K == 2 && HB) {
     if (W)
       hipLaunchKernelGGL((graph_assemble_csr_kernel<T, DR, M, K, true, true>), dim3(grid), dim3(256), 0, st, (const int*)ptr,
@@ -548,7 +573,7 @@ int graph_assemble_csr_launch(const void* ptr, const void* blk, const void* J, c
 }
 template <class T>
 int graph_assemble_csr_dispatch(int dr, int m, int k, const void* ptr, const void* blk, const void* J, const void* W,
-                                const void* R, void* B, void* g, void* HB, int64_t N, void* stream, bool sym = false) {
+                                const void* R, void* B, void* g, void* HB, int64_t N, void* stream, int sym = 0) {
 #define X(A, B_, C) \
   if (dr == A && m == B_ && k == C) return graph_assemble_csr_launch<T, A, B_, C>(ptr, blk, J, W, R, B, g, HB, N, stream, sym);
   PPLIE_GRAPH_SHAPES(X)
@@ -569,11 +594,22 @@ extern "C" int pplie_graph_assemble_csr_f64(const void* ptr, const void* blk, co
 // the same with ONE off-diagonal block per edge: HB [E, M, M] = J_0^T W J_1 (W symmetric; pplie_pcg2_spmv_sym reads it)
 extern "C" int pplie_graph_assemble_csr_sym_f32(const void* ptr, const void* blk, const void* J, const void* W, const void* R,
                                                 void* Bdiag, void* grad, void* HB, int64_t N, int dr, int m, int k, void* stream) {
-  return pplie::graph_assemble_csr_dispatch<float>(dr, m, k, ptr, blk, J, W, R, Bdiag, grad, HB, N, stream, true);
+  return pplie::graph_assemble_csr_dispatch<float>(dr, m, k, ptr, blk, J, W, R, Bdiag, grad, HB, N, stream, 1);
 }
 extern "C" int pplie_graph_assemble_csr_sym_f64(const void* ptr, const void* blk, const void* J, const void* W, const void* R,
                                                 void* Bdiag, void* grad, void* HB, int64_t N, int dr, int m, int k, void* stream) {
-  return pplie::graph_assemble_csr_dispatch<double>(dr, m, k, ptr, blk, J, W, R, Bdiag, grad, HB, N, stream, true);
+  return pplie::graph_assemble_csr_dispatch<double>(dr, m, k, ptr, blk, J, W, R, Bdiag, grad, HB, N, stream, 1);
+}
+
+// the same for problems whose off-diagonal blocks are symmetric and equal for both incidences of an edge (J[e,0] = -J[e,1], W
+// symmetric): HB [nnz, m (m + 1) / 2] = the upper triangle of J_c^T W J_far(c), row by row, in incidence order
+extern "C" int pplie_graph_assemble_csr_pack_f32(const void* ptr, const void* blk, const void* J, const void* W, const void* R,
+                                                 void* Bdiag, void* grad, void* HB, int64_t N, int dr, int m, int k, void* stream) {
+  return pplie::graph_assemble_csr_dispatch<float>(dr, m, k, ptr, blk, J, W, R, Bdiag, grad, HB, N, stream, 2);
+}
+extern "C" int pplie_graph_assemble_csr_pack_f64(const void* ptr, const void* blk, const void* J, const void* W, const void* R,
+                                                 void* Bdiag, void* grad, void* HB, int64_t N, int dr, int m, int k, void* stream) {
+  return pplie::graph_assemble_csr_dispatch<double>(dr, m, k, ptr, blk, J, W, R, Bdiag, grad, HB, N, stream, 2);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -812,7 +848,8 @@ template <class T> __device__ __forceinline__ T* squant2(T* scal, int set, int q
 // every iteration, solver.py:276-340); every later launch of either kernel returns at once, so the host may queue several
 // captured chunks of iterations per read-back and the solve still ends in the iteration that converged.  it[0] then holds
 // the iteration count.  (it must be 4 ints, zeroed by the caller.)
-template <class T, int M, bool SYM = false, bool STOP = false>
+// PACK: HB is [nnz, M (M + 1) / 2]: symmetric blocks, upper triangle row by row (pplie_graph_assemble_csr_pack)
+template <class T, int M, bool SYM = false, bool STOP = false, bool PACK = false>
 __global__ void __launch_bounds__(256)
 pcg2_spmv_kernel(const int* __restrict__ ptr, const int* __restrict__ other, const T* __restrict__ HB, const T* __restrict__ D,
                  const T* __restrict__ Binv, const T* __restrict__ p, const T* __restrict__ z, T* __restrict__ q, T* scal,
@@ -852,6 +889,9 @@ pcg2_spmv_kernel(const int* __restrict__ ptr, const int* __restrict__ other, con
     const int64_t n = base + sub;
     const bool act = active_lane && n < N;
     T acc = T(0), pi = T(0);
+    T uk[M];                                                      // PACK: see below
+#pragma unroll
+    for (int k = 0; k < M; ++k) uk[k] = T(0);
     if (act) {
       T pv[M];
 #pragma unroll
@@ -860,9 +900,14 @@ pcg2_spmv_kernel(const int* __restrict__ ptr, const int* __restrict__ other, con
 #pragma unroll
       for (int j = 0; j < M; ++j) acc += D[(n * M + i) * M + j] * pv[j];
       const int beg = ptr[n], end = ptr[n + 1];
+      // The neighbour indices run one pair ahead of the gathers they address: index -> p[index] is a chain of two memory round
+      // trips per pair, and with ~4 pairs per node on 6 waves per SIMD that chain, not bandwidth, set the kernel's time.
+      int nx0 = beg < end ? other[beg] : 0, nx1 = beg + 1 < end ? other[beg + 1] : nx0;
       for (int c = beg; c < end; c += 2) {
         const bool two = c + 1 < end;
-        const int64_t o0 = other[c], o1 = two ? other[c + 1] : o0;
+        const int64_t o0 = nx0, o1 = nx1;
+        nx0 = c + 2 < end ? other[c + 2] : 0;
+        nx1 = c + 3 < end ? other[c + 3] : nx0;
         const T* p0 = p + o0 * M;
         const T* p1 = p + o1 * M;
         T s0 = T(0), s1 = T(0);
@@ -874,6 +919,30 @@ pcg2_spmv_kernel(const int* __restrict__ ptr, const int* __restrict__ other, con
           const int r1 = (b1 & 1) ? 1 : M, c1 = (b1 & 1) ? M : 1;
 #pragma unroll
           for (int j = 0; j < M; ++j) { s0 += h0[i * r0 + j * c0] * p0[j]; s1 += h1[i * r1 + j * c1] * p1[j]; }
+        } else if constexpr (PACK) {
+          // Lane i holds row i of the UPPER triangle, S(i, i..M-1): contiguous, so it is two merged loads like a full row (a
+          // gather of the six scattered S(i, j) is six load instructions per incidence and made this kernel issue-bound: 43 us
+          // instead of 38).  It adds the upper part S(i, j >= i) p_j to its own row and keeps S(i, i + k) p_i, what row i + k is
+          // owed by symmetry, in uk[k]; the node's lanes exchange those once per node, after the loop.  Loads run up to M - 1
+          // elements past the triangle's row / the neighbour's p: masked out below; HB and p carry M elements of padding.
+          constexpr int NP = M * (M + 1) / 2;
+          const int tii = i * M - (i * (i - 1)) / 2;
+          const T* h0 = HB + (int64_t)c * NP + tii;
+          const T* h1 = two ? h0 + NP : h0;
+          const T* q0 = p0 + i;
+          const T* q1 = p1 + i;
+          T l0[M], l1[M], r0[M], r1[M];
+#pragma unroll
+          for (int k = 0; k < M; ++k) { l0[k] = h0[k]; l1[k] = h1[k]; r0[k] = q0[k]; r1[k] = q1[k]; }     // (unconditional: merged loads)
+#pragma unroll
+          for (int k = 0; k < M; ++k) {
+            const bool in = k < M - i;                               // (what lies beyond the row is somebody else's data: never multiplied)
+            const T a0 = in ? l0[k] : T(0), a1 = (in && two) ? l1[k] : T(0);
+            const T b0 = in ? r0[k] : T(0), b1 = in ? r1[k] : T(0);
+            s0 += a0 * b0;
+            s1 += a1 * b1;
+            if (k > 0) uk[k] += a0 * r0[0] + a1 * r1[0];
+          }
         } else {
           const T* h0 = HB + ((int64_t)c * M + i) * M;
           const T* h1 = two ? h0 + M * M : h0;
@@ -882,7 +951,15 @@ pcg2_spmv_kernel(const int* __restrict__ ptr, const int* __restrict__ other, con
         }
         acc += two ? s0 + s1 : s0;
       }
-      q[n * M + i] = acc;
+      if constexpr (!PACK) q[n * M + i] = acc;
+    }
+    if constexpr (PACK) {                                          // the lower triangle's share: row i collects uk[d] of lane i - d
+#pragma unroll
+      for (int d = 1; d < M; ++d) {
+        const T t = __shfl_up(uk[d], d, 64);
+        if (i >= d) acc += t;
+      }
+      if (act) q[n * M + i] = acc;
     }
     // (Binv q)_i needs the node's whole q: the M lanes of the node exchange their rows (all lanes take part)
     T bq = T(0);
@@ -994,7 +1071,7 @@ pcg2_step_kernel(T* __restrict__ x, T* r0, T* r1, T* __restrict__ p, const T* __
 template <class T>
 int pcg2_spmv(const void* ptr, const void* other, const void* HB, const void* D, const void* Binv, const void* p, const void* z,
               void* q, void* scal, void* rr_hist, void* it, int cap, int64_t N, int m, void* stream, const void* blk = nullptr,
-              bool stop = false, double tol2 = 0.0) {
+              bool stop = false, double tol2 = 0.0, bool pack = false) {
   if (N <= 0) return N == 0 ? PPLIE_OK : PPLIE_EBADARG;
   if (!ptr || !other || !HB || !D || !Binv || !p || !z || !q || !scal || !rr_hist || !it) return PPLIE_EBADARG;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -1003,7 +1080,15 @@ int pcg2_spmv(const void* ptr, const void* other, const void* HB, const void* D,
     int64_t waves = (N + (64 / MM) - 1) / (64 / MM);                                                                  \
     int64_t blocks = (waves + 3) / 4;                                                                                 \
     int grid = (int)(blocks < 4096 ? blocks : 4096);                                                                  \
-    if (stop && !blk)                                                                                                 \
+    if (pack && stop)                                                                                                 \
+      hipLaunchKernelGGL((pcg2_spmv_kernel<T, MM, false, true, true>), dim3(grid), dim3(256), 0, st, (const int*)ptr,   \
+                         (const int*)other, (const T*)HB, (const T*)D, (const T*)Binv, (const T*)p, (const T*)z, (T*)q, \
+                         (T*)scal, (T*)rr_hist, (int*)it, cap, N, (const int*)nullptr, (T)tol2);                        \
+    else if (pack)                                                                                                    \
+      hipLaunchKernelGGL((pcg2_spmv_kernel<T, MM, false, false, true>), dim3(grid), dim3(256), 0, st, (const int*)ptr,  \
+                         (const int*)other, (const T*)HB, (const T*)D, (const T*)Binv, (const T*)p, (const T*)z, (T*)q, \
+                         (T*)scal, (T*)rr_hist, (int*)it, cap, N, (const int*)nullptr);                                 \
+    else if (stop && !blk)                                                                                            \
       hipLaunchKernelGGL((pcg2_spmv_kernel<T, MM, false, true>), dim3(grid), dim3(256), 0, st, (const int*)ptr,         \
                          (const int*)other, (const T*)HB, (const T*)D, (const T*)Binv, (const T*)p, (const T*)z, (T*)q, \
                          (T*)scal, (T*)rr_hist, (int*)it, cap, N, (const int*)nullptr, (T)tol2);                        \
@@ -1064,6 +1149,17 @@ extern "C" int pplie_pcg2_spmv_stop_f64(const void* ptr, const void* other, cons
                                         const void* p, const void* z, void* q, void* scal, void* rr_hist, void* it, int cap,
                                         int64_t N, int m, double tol2, void* stream) {
   return pplie::pcg2_spmv<double>(ptr, other, HB, D, Binv, p, z, q, scal, rr_hist, it, cap, N, m, stream, nullptr, true, tol2);
+}
+// symmetric blocks in packed form (pplie_graph_assemble_csr_pack): HB [nnz, m (m + 1) / 2]; tol2 < 0: no device-side stop test
+extern "C" int pplie_pcg2_spmv_pack_f32(const void* ptr, const void* other, const void* HB, const void* D, const void* Binv,
+                                        const void* p, const void* z, void* q, void* scal, void* rr_hist, void* it, int cap,
+                                        int64_t N, int m, double tol2, void* stream) {
+  return pplie::pcg2_spmv<float>(ptr, other, HB, D, Binv, p, z, q, scal, rr_hist, it, cap, N, m, stream, nullptr, tol2 >= 0.0, tol2, true);
+}
+extern "C" int pplie_pcg2_spmv_pack_f64(const void* ptr, const void* other, const void* HB, const void* D, const void* Binv,
+                                        const void* p, const void* z, void* q, void* scal, void* rr_hist, void* it, int cap,
+                                        int64_t N, int m, double tol2, void* stream) {
+  return pplie::pcg2_spmv<double>(ptr, other, HB, D, Binv, p, z, q, scal, rr_hist, it, cap, N, m, stream, nullptr, tol2 >= 0.0, tol2, true);
 }
 extern "C" int pplie_pcg2_step_stop_f32(void* x, void* r, void* r_alt, void* p, const void* q, void* z, const void* Binv, void* scal,
                                         void* it, int64_t N, int m, void* stream) {

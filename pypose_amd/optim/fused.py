@@ -1099,6 +1099,8 @@ def _pgo_linearization(opt, prog, weight, P, trivial):
     r, J = prog.linearize()
     lin = _pg.build_graph_linearization(opt, weight, r, J, prog.idx, P, 7, 6)
     lin.kind = "fused:pgo"
+    # r = Log(Z^-1 n_i^-1 n_j): d r / d n_i = -d r / d n_j (csrc/pgo_fused.hip), and a corrector scales both blocks of an edge alike
+    lin.antisym = True
 
     def verify(ref, dmin, dmax, rtol=1e-3):
         """residuals and blocks against the autograd-derived pose-graph linearisation (whose edge ends are in

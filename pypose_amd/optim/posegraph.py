@@ -294,6 +294,9 @@ class FusedPCG:
     # blocks are one sequential stream per node, the per-edge blocks are 144-byte gathers (two 128-byte lines each) and the
     # second touch of a random closure's block is never a cache hit; it pays only on graphs whose edges are local in node order
     sym_blocks = False
+    # symmetric off-diagonal blocks in packed form on graphs beyond the persistent solve, for linearisations that declare
+    # J[e, 0] = -J[e, 1] (the relative-pose program): 84 instead of 144 bytes of matrix per incidence and iteration
+    pack_blocks = True
     device_stop = True       # large graphs: the two-launch iteration tests convergence on the device (pplie_pcg2_*_stop)
     two_launch = True        # class-level switches (tools/ and tests compare the three-launch / graph-less variants)
     use_graph = True
@@ -309,7 +312,8 @@ class FusedPCG:
         self.J = self.W = self.idx = None                          # per-edge copies: only the matrix-free (sharded) path
         self.D, self.HB = z(N, m, m), None                         # damped diagonal blocks; off-diagonal blocks (bsr path)
         self.Binv, self.shift = z(N, m, m), z(N, m)
-        self.x, self.r, self.p, self.q, self.z = (z(N, m) for _ in range(5))
+        self.x, self.r, self.q, self.z = (z(N, m) for _ in range(4))
+        self.p = z(N + 2, m)[:N]                                   # (pplie_pcg2_spmv_pack reads up to m - 1 elements past a row)
         self.r2 = z(N, m)                                          # the two-launch iteration ping-pongs the residual
         # scal | part | it share ONE allocation: a solve clears them with a single fill instead of three
         esz = 4 if dtype == torch.float32 else 8
@@ -381,19 +385,19 @@ class FusedPCG:
         st = _C.stream_ptr(self.device)
         if self.bsr and self.two_launch:
             # q = A p with p.q, q.z, q.Binv q ; then every vector update in one launch (csrc/graph.hip, pcg2)
-            if self.stop_tol2 is not None and not self.sym:
-                # convergence test on the device: a launch after the converging iteration returns at once (csrc/graph.hip)
+            # (stop: convergence test on the device -- a launch after the converging iteration returns at once)
+            stop = self.stop_tol2 is not None and self.sym in (False, 'pack')
+            if self.sym == 'pack':
+                code = lib.symbol("pplie_pcg2_spmv_pack" + self.sfx, _PCG2_SPMV_STOP_SIG)(
+                    self.ptr.data_ptr(), self.other.data_ptr(), self.HB.data_ptr(), self.D.data_ptr(), self.Binv.data_ptr(),
+                    self.p.data_ptr(), self.z.data_ptr(), self.q.data_ptr(), self.scal.data_ptr(), self.rr_hist.data_ptr(),
+                    self.it.data_ptr(), self.cap, self.N, self.m, self.stop_tol2 if stop else -1.0, st)
+            elif stop:
                 code = lib.symbol("pplie_pcg2_spmv_stop" + self.sfx, _PCG2_SPMV_STOP_SIG)(
                     self.ptr.data_ptr(), self.other.data_ptr(), self.HB.data_ptr(), self.D.data_ptr(), self.Binv.data_ptr(),
                     self.p.data_ptr(), self.z.data_ptr(), self.q.data_ptr(), self.scal.data_ptr(), self.rr_hist.data_ptr(),
                     self.it.data_ptr(), self.cap, self.N, self.m, self.stop_tol2, st)
-                _C.check(code, "pplie_pcg2_spmv_stop")
-                code = lib.symbol("pplie_pcg2_step_stop" + self.sfx, _PCG2_STEP_SIG)(
-                    self.x.data_ptr(), self.r.data_ptr(), self.r2.data_ptr(), self.p.data_ptr(), self.q.data_ptr(),
-                    self.z.data_ptr(), self.Binv.data_ptr(), self.scal.data_ptr(), self.it.data_ptr(), self.N, self.m, st)
-                _C.check(code, "pplie_pcg2_step_stop")
-                return
-            if self.sym:
+            elif self.sym:
                 code = lib.symbol("pplie_pcg2_spmv_sym" + self.sfx, [ctypes.c_void_p] + _PCG2_SPMV_SIG)(
                     self.ptr.data_ptr(), self.other.data_ptr(), self.blk.data_ptr(), self.HB.data_ptr(), self.D.data_ptr(),
                     self.Binv.data_ptr(), self.p.data_ptr(), self.z.data_ptr(), self.q.data_ptr(), self.scal.data_ptr(),
@@ -404,7 +408,7 @@ class FusedPCG:
                     self.p.data_ptr(), self.z.data_ptr(), self.q.data_ptr(), self.scal.data_ptr(), self.rr_hist.data_ptr(),
                     self.it.data_ptr(), self.cap, self.N, self.m, st)
             _C.check(code, "pplie_pcg2_spmv")
-            code = lib.symbol("pplie_pcg2_step" + self.sfx, _PCG2_STEP_SIG)(
+            code = lib.symbol("pplie_pcg2_step" + ("_stop" if stop else "") + self.sfx, _PCG2_STEP_SIG)(
                 self.x.data_ptr(), self.r.data_ptr(), self.r2.data_ptr(), self.p.data_ptr(), self.q.data_ptr(),
                 self.z.data_ptr(), self.Binv.data_ptr(), self.scal.data_ptr(), self.it.data_ptr(), self.N, self.m, st)
             _C.check(code, "pplie_pcg2_step")
@@ -441,13 +445,14 @@ class FusedPCG:
         self.bsr = bsr
         if bsr:
             self._csr(lin)
-            sym = bool(getattr(lin, "HB_sym", False))
+            sym = 'pack' if getattr(lin, "HB_pack", False) else bool(getattr(lin, "HB_sym", False))      # storage of the off-diagonal blocks
             if self._persistent(plain) and not sym:
                 self.HB, self.sym = lin.HB, sym                     # the persistent solve reads the linearisation's blocks in place
             else:                                                   # captured iterations point at a buffer of the workspace
                 own = self.__dict__.get('_own_HB')
                 if own is None or own.shape != lin.HB.shape or own.dtype != lin.HB.dtype or sym != self.sym or self.HB is not own:
-                    own = self._own_HB = torch.empty_like(lin.HB) if own is None or own.shape != lin.HB.shape else own
+                    own = self._own_HB = (torch.empty((lin.HB.shape[0] + 1,) + tuple(lin.HB.shape[1:]), dtype=lin.HB.dtype, device=lin.HB.device)[:lin.HB.shape[0]]
+                                             if own is None or own.shape != lin.HB.shape else own)      # (+1 record: see pplie_pcg2_spmv_pack)
                     self.HB, self.sym, self.graph = own, sym, None
                 if lin.HB is not self.HB:                           # (assembled in place when the workspace already existed)
                     self.HB.copy_(lin.HB)                           # off-diagonal blocks in incidence (or edge) order
@@ -535,7 +540,7 @@ class FusedPCG:
             bn2 = None
             maxiter = min(maxiter, self.cap - self.check_every)
             done, best, stalled, xbest = 0, float('inf'), 0, None
-            if bsr and self.two_launch and not plain and group is None and not self.sym and self.device_stop:
+            if bsr and self.two_launch and not plain and group is None and self.sym in (False, 'pack') and self.device_stop:
                 # The two-launch iteration with the convergence test ON THE DEVICE: chunks of `check_every` captured iterations
                 # are queued `ahead` at a time per read-back of the 4-int control word; the launch that finds
                 # |r|^2 <= tol^2 |b|^2 raises a flag and every later one returns at once, so the solve ends in the iteration
@@ -652,6 +657,8 @@ class GraphLinearization:
         self.HB = None
         self.pending_info = None  # a deferred read-back of the persistent PCG's (iterations, rr, bn2, flag)
         self.HB_sym = False     # True: HB holds one block per EDGE (symmetric weights, large graphs)
+        self.HB_pack = False    # True: HB holds packed symmetric blocks per incidence (antisym linearisations, large graphs)
+        self.antisym = False    # the builder's promise that J[e, 0] == -J[e, 1] (relative-pose residuals: optim/fused.py)
         self.node_group = None  # process group over which the SOLVE is sharded by node rows (optim/nodeshard.py)
 
     # -- index helpers -------------------------------------------------------------------------
@@ -719,21 +726,26 @@ class GraphLinearization:
                     # off-diagonal blocks in incidence order feed the streaming node-parallel SpMV of the PCG; graphs too
                     # large for the persistent solve keep ONE block per edge (H_ji = H_ij^T for symmetric weights):
                     # half the bytes every SpMV streams
-                    self.HB_sym = (self.K == 2 and FusedPCG.two_launch and not (FusedPCG.persist and N <= PERSIST_NODES)
-                                   and FusedPCG.sym_blocks and self._weights_symmetric())
+                    large = self.K == 2 and FusedPCG.two_launch and not (FusedPCG.persist and N <= PERSIST_NODES)
+                    # J_0 = -J_1 and W symmetric: every off-diagonal block is -J_1^T W J_1, symmetric, the same for both incidences
+                    self.HB_pack = (large and self.antisym and FusedPCG.pack_blocks and self.dr == self.m
+                                    and self._weights_symmetric())
+                    self.HB_sym = large and not self.HB_pack and FusedPCG.sym_blocks and self._weights_symmetric()
+                    mode = 'pack' if self.HB_pack else self.HB_sym
                     self.HB = None
                     if self.K == 2:
-                        shape = (self.E * (1 if self.HB_sym else 2), m, m)
+                        shape = (self.E * 2, m * (m + 1) // 2) if self.HB_pack else (self.E * (1 if self.HB_sym else 2), m, m)
+                        pad = 1 if self.HB_pack else 0      # (the packed SpMV reads up to m - 1 elements past a triangle's row)
                         # large graphs: assemble straight into the PCG workspace's block buffer (the captured iterations point
                         # at it) instead of into a fresh tensor that is then copied there -- 115 MB per LM step at 4e5 edges
                         for w in (self.opt.__dict__.get('_pcg_workspaces') or {}).values():
                             own = w.__dict__.get('_own_HB')
-                            if own is not None and own.shape == shape and own.dtype == dt and own.device == dev and w.sym == self.HB_sym:
+                            if own is not None and own.shape == shape and own.dtype == dt and own.device == dev and w.sym == mode:
                                 self.HB = own
                                 break
                         if self.HB is None:
-                            self.HB = torch.empty(shape, dtype=dt, device=dev)
-                    code = lib.symbol("pplie_graph_assemble_csr" + ("_sym" if self.HB_sym else "") + sfx, _ASMC_SIG)(
+                            self.HB = torch.empty((shape[0] + pad,) + tuple(shape[1:]), dtype=dt, device=dev)[:shape[0]]
+                    code = lib.symbol("pplie_graph_assemble_csr" + ("_pack" if self.HB_pack else "_sym" if self.HB_sym else "") + sfx, _ASMC_SIG)(
                         ptr.data_ptr(), blk.data_ptr(), self.J.data_ptr(), wptr, self.R.data_ptr(), B.data_ptr(),
                         g.data_ptr(), self.HB.data_ptr() if self.HB is not None else None, N, self.dr, self.m, self.K, st)
                     _C.check(code, "pplie_graph_assemble_csr")

@@ -1,0 +1,86 @@
+"""Packed symmetric off-diagonal blocks (csrc/graph.hip: pplie_graph_assemble_csr_pack / pplie_pcg2_spmv_pack).
+
+For the relative-pose program the two Jacobian blocks of an edge are opposite, so every off-diagonal block of the normal equations is
+-J_1^T W J_1: symmetric, and the same for both incidences of the edge.  Graphs beyond the persistent solve store the upper triangle
+only.  Checked here: the linearisation really has J[e, 0] == -J[e, 1]; the packed blocks are the upper triangles of the full ones;
+and LM runs with and without the packed storage agree (two-launch PCG forced on a small graph), unweighted and weighted, fp32 / fp64.
+"""
+import pytest
+import torch
+
+import pypose_amd as pp
+from pypose_amd.optim import posegraph
+from tests.optim_models import PoseGraph, run_steps
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0") if torch.cuda.is_available() else torch.device("cpu")
+
+
+def _graph(N, E, dtype, seed=1):
+    g = torch.Generator().manual_seed(seed)
+    torch.manual_seed(seed)
+    truth = pp.cumprod(pp.randn_SE3(N, sigma=0.3, dtype=dtype, device=DEV), dim=0)
+    i = torch.cat([torch.arange(N - 1), torch.randint(0, N, (E - N + 1,), generator=g)])
+    j = torch.cat([torch.arange(1, N), torch.randint(0, N, (E - N + 1,), generator=g)])
+    keep = i != j
+    i, j = i[keep].to(DEV), j[keep].to(DEV)
+    rel = truth[i].Inv() @ truth[j] @ pp.randn_SE3(len(i), sigma=0.01, dtype=dtype, device=DEV)
+    init = truth @ pp.randn_SE3(N, sigma=0.05, dtype=dtype, device=DEV)
+    A = torch.randn(len(i), 6, 6, dtype=dtype, device=DEV, generator=None)
+    W = A @ A.mT / 6 + torch.eye(6, dtype=dtype, device=DEV)          # symmetric positive definite information matrices
+    return torch.stack([i, j], 1), rel.tensor(), init.tensor(), W
+
+
+def _run(edges, rel, init, W, pack, monkeypatch, steps=2, tol=1e-8):      # (two steps reach the noise floor of this graph)
+    monkeypatch.setattr(posegraph, "PERSIST_NODES", 64, raising=False)          # the two-launch iteration, as beyond 32 k nodes
+    monkeypatch.setattr(posegraph.FusedPCG, "pack_blocks", pack, raising=False)
+    graph = PoseGraph(pp.SE3(init.clone()))
+    opt = pp.optim.LM(graph, solver=pp.optim.solver.PCG(tol=tol, maxiter=2000), strategy=pp.optim.strategy.TrustRegion(radius=1e4))
+    rec = run_steps(opt, ((edges, pp.SE3(rel)),), {"weight": W}, steps)
+    modes = {w.sym for w in opt._pcg_workspaces.values()}
+    return rec, graph.nodes.detach().tensor().clone(), modes, opt
+
+
+@pytest.mark.parametrize("dtype,rtol", [(torch.float64, 1e-9), (torch.float32, 2e-4)])
+@pytest.mark.parametrize("weighted", [False, True])
+def test_lm_with_packed_blocks_equals_full_blocks(dtype, rtol, weighted, monkeypatch):
+    edges, rel, init, W = _graph(1200, 4800, dtype)
+    W = W if weighted else None
+    tol = 1e-10 if dtype == torch.float64 else 1e-5
+    a, pa, ma, opt = _run(edges, rel, init, W, True, monkeypatch, tol=tol)
+    b, pb, mb, _ = _run(edges, rel, init, W, False, monkeypatch, tol=tol)
+    assert ma == {"pack"} and mb == {False}, (ma, mb)
+    assert a["kind"][-1] == "fused:pgo"
+    torch.testing.assert_close(torch.tensor(a["loss"]), torch.tensor(b["loss"]), rtol=rtol, atol=0)
+    assert a["damping"] == b["damping"] and a["reject"] == b["reject"]
+    err = (pp.SE3(pa).Inv() @ pp.SE3(pb)).Log().tensor().abs().max().item()
+    assert err <= 50 * rtol, err
+
+
+def test_jacobian_blocks_are_opposite_and_packed_blocks_are_the_upper_triangles(monkeypatch):
+    from pypose_amd.optim import fused
+    dtype = torch.float64
+    edges, rel, init, W = _graph(300, 1100, dtype)
+    graph = PoseGraph(pp.SE3(init.clone()))
+    opt = pp.optim.LM(graph, solver=pp.optim.solver.PCG(tol=1e-8, maxiter=500), strategy=pp.optim.strategy.TrustRegion(radius=1e4))
+    opt.step((edges, pp.SE3(rel)), weight=W)
+    prog = opt._structure_cache["program"][3]
+    monkeypatch.setattr(posegraph, "PERSIST_NODES", 64, raising=False)
+    out = {}
+    for pack in (True, False):
+        monkeypatch.setattr(posegraph.FusedPCG, "pack_blocks", pack, raising=False)
+        with torch.no_grad():
+            lin = fused._pgo_linearization(opt, prog, W, graph.nodes, True)
+            lin.build_normal_equations(1e-6, 1e32)
+        assert lin.antisym and torch.equal(lin.J[:, 0], -lin.J[:, 1])
+        assert bool(lin.HB_pack) == pack
+        out[pack] = (lin.HB.clone(), lin.B.clone(), lin.g.clone())
+    iu = torch.triu_indices(6, 6)
+    full = out[False][0]
+    torch.testing.assert_close(out[True][0], full[:, iu[0], iu[1]], rtol=1e-12, atol=1e-12)
+    torch.testing.assert_close(full, full.mT, rtol=1e-12, atol=1e-12)                 # symmetric ...
+    ptr, blk, other = lin.csr()
+    pos = torch.empty_like(blk); pos[blk.long()] = torch.arange(len(blk), device=blk.device, dtype=blk.dtype)
+    twin = pos[(blk ^ 1).long()].long()                                               # ... and equal to the twin incidence's block
+    torch.testing.assert_close(full, full[twin], rtol=1e-12, atol=1e-12)
+    torch.testing.assert_close(out[True][1], out[False][1]); torch.testing.assert_close(out[True][2], out[False][2])
