@@ -167,7 +167,10 @@ class PgoGraphStep:
         # (the GPU is working: the step's host-side bookkeeping happens behind the launch)
         self._prev_last = opt.__dict__.get('_last_view')
         opt.last = opt.loss
-        self._last_h = opt._host(opt.loss)
+        # (the starting loss of a run is not on the host yet: reading it here would wait for the replay and keep the caller's
+        #  check of the program -- the dry run -- from overlapping with it; finish() reads it after the trial's verdict)
+        hit = opt.__dict__.get('_host_loss')
+        self._last_h = hit[1] if hit is not None and hit[0] is opt.loss else None
         opt.reject_count = 0
         _C.mark_written(self.P)
 
@@ -202,6 +205,8 @@ class PgoGraphStep:
     def finish(self, pg):
         opt, lin, last_h = self.opt, self.lin, self._last_h
         a, b, loss_h, its, rr, bn2, flag = self._wait()               # the trial's one wait (no stream synchronisation)
+        if last_h is None:
+            last_h = opt._host(opt.last)
         opt.linearization = lin.kind
         opt._last_replicated = False
         if flag >= 2.0 or rr != rr:                # a failed solve returned a zero step: the parameters are where they were

@@ -38,6 +38,7 @@ from . import blocks as _blocks
 _SPMV_SIG = [ctypes.c_void_p] * 5 + [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
 _ASM_SIG = [ctypes.c_void_p] * 7 + [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
 _ASMC_SIG = [ctypes.c_void_p] * 8 + [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+_ASML_SIG = [ctypes.c_void_p] * 9 + [ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
 _PREP_SIG = [ctypes.c_void_p] * 10 + [ctypes.c_double] * 3 + [ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]
 _PREP_DEV_SIG = [ctypes.c_void_p] * 11 + [ctypes.c_double] * 2 + [ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]
 _GAIN_SIG = [ctypes.c_void_p] * 3 + [ctypes.c_int] + [ctypes.c_void_p] * 2 + [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
@@ -297,6 +298,7 @@ class FusedPCG:
     # symmetric off-diagonal blocks in packed form on graphs beyond the persistent solve, for linearisations that declare
     # J[e, 0] = -J[e, 1] (the relative-pose program): 84 instead of 144 bytes of matrix per incidence and iteration
     pack_blocks = True
+    lap_assembly = True      # ... and their assembly in two launches without dependent chains (pplie_graph_assemble_lap)
     device_stop = True       # large graphs: the two-launch iteration tests convergence on the device (pplie_pcg2_*_stop)
     two_launch = True        # class-level switches (tools/ and tests compare the three-launch / graph-less variants)
     use_graph = True
@@ -700,9 +702,18 @@ class GraphLinearization:
         if self.W is None:
             return True
         cache = self.opt.__dict__.setdefault('_w_sym', {})
+        src = getattr(self.W, '_pplie_src', None)
+        if src is not None and isinstance(src[0], torch.Tensor):
+            if src[2]:
+                return True                                            # (Gauss-Newton: W^T W)
+            if cache.get('src') is src[0] and cache.get('key') == (src[1], tuple(self.W.shape)):
+                return cache['ok']
+            cache['src'], cache['key'] = src[0], (src[1], tuple(self.W.shape))
+            cache['ok'] = bool(torch.equal(self.W, self.W.mT))
+            return cache['ok']
         key = (self.W.data_ptr(), self.W._version, tuple(self.W.shape))
-        if cache.get('key') != key:
-            cache['key'], cache['ok'] = key, bool(torch.equal(self.W, self.W.mT))
+        if cache.get('key') != key or cache.get('src') is not None:
+            cache['src'], cache['key'], cache['ok'] = None, key, bool(torch.equal(self.W, self.W.mT))
         return cache['ok']
 
     # -- kernels ---------------------------------------------------------------------------------
@@ -745,10 +756,19 @@ class GraphLinearization:
                                 break
                         if self.HB is None:
                             self.HB = torch.empty((shape[0] + pad,) + tuple(shape[1:]), dtype=dt, device=dev)[:shape[0]]
-                    code = lib.symbol("pplie_graph_assemble_csr" + ("_pack" if self.HB_pack else "_sym" if self.HB_sym else "") + sfx, _ASMC_SIG)(
-                        ptr.data_ptr(), blk.data_ptr(), self.J.data_ptr(), wptr, self.R.data_ptr(), B.data_ptr(),
-                        g.data_ptr(), self.HB.data_ptr() if self.HB is not None else None, N, self.dr, self.m, self.K, st)
-                    _C.check(code, "pplie_graph_assemble_csr")
+                    if (self.K == 2 and self.antisym and self.dr == self.m and not self.HB_sym and FusedPCG.lap_assembly
+                            and self.m in (3, 6, 7) and self._weights_symmetric()):
+                        # J_0 = -J_1: incidence-parallel blocks, then per-node sums (csrc/graph.hip, pplie_graph_assemble_lap)
+                        gg = torch.empty((self.E * 2, m), dtype=dt, device=dev)
+                        code = lib.symbol("pplie_graph_assemble_lap" + sfx, _ASML_SIG)(
+                            ptr.data_ptr(), blk.data_ptr(), self.J.data_ptr(), wptr, self.R.data_ptr(), B.data_ptr(), g.data_ptr(),
+                            self.HB.data_ptr(), gg.data_ptr(), N, self.E * 2, self.m, 1 if self.HB_pack else 0, st)
+                        _C.check(code, "pplie_graph_assemble_lap")
+                    else:
+                        code = lib.symbol("pplie_graph_assemble_csr" + ("_pack" if self.HB_pack else "_sym" if self.HB_sym else "") + sfx, _ASMC_SIG)(
+                            ptr.data_ptr(), blk.data_ptr(), self.J.data_ptr(), wptr, self.R.data_ptr(), B.data_ptr(),
+                            g.data_ptr(), self.HB.data_ptr() if self.HB is not None else None, N, self.dr, self.m, self.K, st)
+                        _C.check(code, "pplie_graph_assemble_csr")
                 else:           # edge shards (group=): scatter-add, then all-reduce
                     B = torch.zeros((N, m, m), dtype=dt, device=dev)
                     g = torch.zeros((N, m), dtype=dt, device=dev)
@@ -1040,6 +1060,8 @@ def _edge_terms(opt, corrector, weight, r, J, gauss_newton=False):
         Wb = ws.repeat(ni, 1, 1).contiguous()
         if gauss_newton:
             Wb = (Wb.mT @ Wb).contiguous()
+        # (what the symmetry check of GraphLinearization._weights_symmetric is remembered by: Wb is a new tensor every step)
+        Wb._pplie_src = (weight, weight._version if isinstance(weight, torch.Tensor) else None, bool(gauss_newton))
     return Rc, Jc, Wb
 
 
