@@ -40,6 +40,7 @@ _ASM_SIG = [ctypes.c_void_p] * 7 + [ctypes.c_int64, ctypes.c_int, ctypes.c_int, 
 _ASMC_SIG = [ctypes.c_void_p] * 8 + [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
 _ASML_SIG = [ctypes.c_void_p] * 9 + [ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
 _PREP_SIG = [ctypes.c_void_p] * 10 + [ctypes.c_double] * 3 + [ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]
+_BEGIN_SIG = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
 _PREP_DEV_SIG = [ctypes.c_void_p] * 11 + [ctypes.c_double] * 2 + [ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]
 _GAIN_SIG = [ctypes.c_void_p] * 3 + [ctypes.c_int] + [ctypes.c_void_p] * 2 + [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
 _GAIN_PARTIALS = 1024       # PPLIE_GAIN_PARTIALS
@@ -466,15 +467,23 @@ class FusedPCG:
             self.idx.copy_(lin.idx)
             if self.W is not None:
                 self.W.copy_(lin.W)
-        self._ctl.zero_()                                           # scal, part (sequence tags restart at 1), it
+        s_dev = getattr(lin, 's_dev', None)
+        if s_dev is None:
+            self._ctl.zero_()                                       # scal, part (sequence tags restart at 1), it
         with _C._on_device(self.device):
             # one launch: D = clamped + damped block diagonal, Binv = D^-1, shift, x = 0, r = -g, z = Binv r, p = z, r.z, |g|^2
-            s_dev = getattr(lin, 's_dev', None)
-            if s_dev is not None:       # (a captured trial: the damping factor of the day is written to a device scalar)
+            if s_dev is not None:
+                # a captured trial: the damping factor of the day sits in a host-pinned scalar; the launch that clears the
+                # control block also brings it into device memory (pplie_pcg_begin)
+                if self.__dict__.get('s_device') is None:
+                    self.s_device = torch.ones(1, dtype=torch.float64, device=self.device)
+                code = _C.library().symbol("pplie_pcg_begin", _BEGIN_SIG)(
+                    self._ctl.data_ptr(), self._ctl.numel(), s_dev.data_ptr(), self.s_device.data_ptr(), _C.stream_ptr(self.device))
+                _C.check(code, "pplie_pcg_begin")
                 code = _C.library().symbol("pplie_pcg_prepare_dev" + self.sfx, _PREP_DEV_SIG)(
                     lin.B.data_ptr(), lin.g.data_ptr(), self.D.data_ptr(), self.Binv.data_ptr(), self.shift.data_ptr(),
                     self.x.data_ptr(), self.r.data_ptr(), self.z.data_ptr(), self.p.data_ptr(), self.scal.data_ptr(),
-                    s_dev.data_ptr(), float(dmin), float(dmax), self.N, self.m, _C.stream_ptr(self.device))
+                    self.s_device.data_ptr(), float(dmin), float(dmax), self.N, self.m, _C.stream_ptr(self.device))
             else:
                 code = _C.library().symbol("pplie_pcg_prepare" + self.sfx, _PREP_SIG)(
                     lin.B.data_ptr(), lin.g.data_ptr(), self.D.data_ptr(), self.Binv.data_ptr(), self.shift.data_ptr(),
