@@ -333,6 +333,7 @@ class FusedPCG:
         self.part = self._ctl[nb_scal:nb_scal + nb_part].view(torch.int64)   # persistent solve: tagged partial sums
         self.it = self._ctl[nb_scal + nb_part:nb_scal + nb_part + nb_it].view(torch.int32)[:4]     # iterations done, scratch, stop flag, -
         self.info = z(4)
+        self.s_device = torch.ones(1, dtype=torch.float64, device=device)      # the damping factor of a captured trial (pplie_pcg_begin)
         self.sfx = "_f32" if dtype == torch.float32 else "_f64"
         self.graph = None                                          # captured check_every iterations
         self.bsr = None                                            # which iteration the graph holds
@@ -475,8 +476,6 @@ class FusedPCG:
             if s_dev is not None:
                 # a captured trial: the damping factor of the day sits in a host-pinned scalar; the launch that clears the
                 # control block also brings it into device memory (pplie_pcg_begin)
-                if self.__dict__.get('s_device') is None:
-                    self.s_device = torch.ones(1, dtype=torch.float64, device=self.device)
                 code = _C.library().symbol("pplie_pcg_begin", _BEGIN_SIG)(
                     self._ctl.data_ptr(), self._ctl.numel(), s_dev.data_ptr(), self.s_device.data_ptr(), _C.stream_ptr(self.device))
                 _C.check(code, "pplie_pcg_begin")
