@@ -1119,4 +1119,27 @@ def _pgo_linearization(opt, prog, weight, P, trivial):
     lin.reference_kind = "graph"
     if trivial:
         lin.fast_loss = lambda: prog.loss(opt.group)
+        if opt.group is None and lin._hip():
+            def trial_tail():
+                """What the trial loop does between the solve and its decision (optimizer.py:669-673) as one C call and one wait on
+                pinned memory (optim/pgograph.py TrialTail): the parameters retracted by the step the solve just returned, then
+                (a, b, loss) as host floats and the loss as a device scalar; None if this trial cannot take the route."""
+                from .pgograph import TrialTail
+                Dn = lin.__dict__.pop('_last_Dn', None)
+                pt = torch.Tensor.as_subclass(P, torch.Tensor).detach()
+                if Dn is None or Dn.shape != (lin.N, 6) or not pt.is_contiguous() or lin.idx.data_ptr() != prog.idx.data_ptr() \
+                        or lin.J.shape != (prog.E, 2, 6, 6) or Dn.dtype != pt.dtype:
+                    return None
+                tt = opt.__dict__.get('_trial_tail')
+                if tt is None or tt.dtype != pt.dtype or tt.dev != pt.device:
+                    tt = opt._trial_tail = TrialTail(pt.dtype, pt.device)
+                pend, lin.pending_info = lin.pending_info, None
+                slot = tt.advance()
+                tt.enqueue(pt, None, prog, lin, Dn.contiguous(), None if pend is None else pend.info)
+                _C.mark_written(P)
+                a, b, loss_h, its, rr, bn2, flag = tt.wait()
+                if pend is not None:             # the persistent solve's (iterations, flag) rode along: raises like an eager solve
+                    lin._pending_solver.iterations = pend.resolve([its, rr, bn2, flag])
+                return a, b, loss_h, tt.loss_views[slot]
+            lin.trial_tail = trial_tail
     return lin

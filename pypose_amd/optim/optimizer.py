@@ -548,10 +548,17 @@ class LevenbergMarquardt(_Optimizer):
                 break
             finally:
                 self._defer_solver_info = False
-            self.update_parameter(pg['params'], D)
-            self.loss = lin.fast_loss() if hasattr(lin, 'fast_loss') else self._loss(input, target)
             try:
-                loss_h = self._strategy_update(pg, J, D, R, last_h)
+                # the recognised pose-graph program: update, candidate loss, gain terms and their read-back are one C call and one
+                # wait on pinned memory (optim/pgograph.py TrialTail)
+                fused_tail = lin.trial_tail() if defer and getattr(lin, 'trial_tail', None) is not None else None
+                if fused_tail is not None:
+                    a, b, loss_h, self.loss = fused_tail
+                    _strategy.update_from_terms(self.strategy, pg, last_h, loss_h, a, b)
+                else:
+                    self.update_parameter(pg['params'], D)
+                    self.loss = lin.fast_loss() if hasattr(lin, 'fast_loss') else self._loss(input, target)
+                    loss_h = self._strategy_update(pg, J, D, R, last_h)
             except _SolveFailed as e:       # noticed after the fact; the step was zero, the parameters are where they were
                 print(e, "\nLinear solver failed. Breaking optimization step...")
                 self.loss = self.last

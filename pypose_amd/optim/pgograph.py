@@ -36,6 +36,63 @@ _TAIL_SIG = [ctypes.c_void_p] * 11 + [ctypes.c_int64, ctypes.c_int64, ctypes.c_v
 _PARTIALS = 1024          # PPLIE_PGO_PARTIALS
 
 
+class TrialTail:
+    """``pplie_pgo_trial_tail`` with its buffers: everything between the linear solve and the host's decision in four launches of one
+    C entry point, the result block in HOST-PINNED memory that :meth:`wait` polls, the loss in a ring of device scalars.  Used by the
+    captured trial below (the launches are part of the graph) and by the ordinary trial loop of the optimizer (graphs the
+    persistent solve does not hold, and the steps before a capture exists)."""
+
+    RING = 1024
+
+    def __init__(self, dtype, dev):
+        self.dtype, self.dev = dtype, dev
+        self.out = torch.zeros(8, dtype=torch.float64).pin_memory()       # {a, b, loss, iterations, |r|^2, |b|^2, flag, seq}
+        self.out_np = self.out.numpy()
+        self.seq = 0
+        self.state = torch.zeros(3, dtype=torch.int64, device=dev)         # {seq (counts executions), loss ring address, its length}
+        self.partial = torch.empty(3 * _PARTIALS, dtype=dtype, device=dev)
+        self.no_info = torch.zeros(4, dtype=dtype, device=dev)             # (a solve that reported to the host already)
+        self.new_ring()
+        self.fn = _C.library().symbol("pplie_pgo_trial_tail" + ("_f32" if dtype == torch.float32 else "_f64"), _TAIL_SIG)
+
+    def new_ring(self):
+        """a fresh ring when this one has gone round, so a loss handed out earlier is never overwritten"""
+        self.ring = torch.zeros(self.RING, dtype=self.dtype, device=self.dev)
+        self.loss_views = self.ring.unbind(0)
+        self.state[1:].copy_(torch.tensor([self.ring.data_ptr(), self.RING], dtype=torch.int64))     # (once per RING trials)
+
+    def enqueue(self, pt, backup, prog, lin, Dn, info):
+        """the four launches (nothing else: callable inside a stream capture)"""
+        assert Dn.is_contiguous() and pt.is_contiguous() and lin.m == 6 and lin.K == 2 and lin.dr == 6 \
+            and lin.idx.data_ptr() == prog.idx.data_ptr() and lin.E == prog.E and Dn.shape == (lin.N, 6)
+        with _C._on_device(pt.device):
+            code = self.fn(pt.data_ptr(), None if backup is None else backup.data_ptr(), prog.idx.data_ptr(), prog.Z.data_ptr(),
+                           lin.J.data_ptr(), lin.R.data_ptr(), Dn.data_ptr(), (self.no_info if info is None else info).data_ptr(),
+                           self.partial.data_ptr(), self.state.data_ptr(), self.out.data_ptr(), lin.N, lin.E, _C.stream_ptr(pt.device))
+        _C.check(code, "pplie_pgo_trial_tail")
+
+    def advance(self):
+        """host mirror of the execution the device is about to count; returns the slot of the loss ring it will write"""
+        self.seq += 1
+        slot = self.seq % self.RING
+        if slot == 0:
+            self.new_ring()
+        return slot
+
+    def wait(self):
+        """the trial's verdict: poll the pinned word the last kernel stores; a solve that takes unusually long is waited for
+        with a stream synchronisation instead"""
+        out, seq = self.out_np, float(self.seq)
+        n = 0
+        while out[7] != seq:
+            n += 1
+            if n > 200_000:
+                torch.cuda.synchronize(self.dev)
+                if out[7] != seq:
+                    raise RuntimeError("pypose_amd: the pose-graph trial finished without reporting its result")
+        return out[:7].tolist()
+
+
 class PgoGraphStep:
     MIN_STREAK = 3          # ordinary steps on the same program before the capture is made
 
@@ -50,17 +107,10 @@ class PgoGraphStep:
         self.solver_key = (solver, solver.tol, solver.maxiter, solver.check_every)
         dev = P.device
         pt = torch.Tensor.as_subclass(P, torch.Tensor).detach()
-        # host-pinned blocks the kernels address directly: ctl = {damping factor}, out = {a, b, loss, iterations, |r|^2, |b|^2,
-        # flag, seq}; device state of the pack kernel: {seq (counts executions), loss ring address, its length}
+        # host-pinned scalar the solve's first launch reads the damping factor from; the trial's tail and its result block
         self.ctl = torch.ones(2, dtype=torch.float64).pin_memory()
         self.ctl_f = self.ctl.numpy()
-        self.out = torch.zeros(8, dtype=torch.float64).pin_memory()
-        self.out_np = self.out.numpy()
-        self.seq = 0
-        self.state = torch.zeros(3, dtype=torch.int64, device=dev)
-        self.partial = torch.empty(3 * _PARTIALS, dtype=pt.dtype, device=dev)
-        self._new_ring(pt.dtype, dev)
-        self.tail = _C.library().symbol("pplie_pgo_trial_tail" + ("_f32" if pt.dtype == torch.float32 else "_f64"), _TAIL_SIG)
+        self.tt = TrialTail(pt.dtype, dev)
         self.params = [p for p in pg['params'] if p.requires_grad]
         self.graph = None
         self.backup = torch.empty_like(pt)      # the parameters before the latest replay
@@ -73,15 +123,6 @@ class PgoGraphStep:
         self.graph = g
         with torch.no_grad():           # capture does not execute: nothing moved, but be explicit about the state we hand back
             torch.Tensor.as_subclass(P, torch.Tensor).detach().copy_(torch.Tensor.as_subclass(saved, torch.Tensor))
-
-    RING = 1024
-
-    def _new_ring(self, dtype, dev):
-        """the trial's loss lands in a ring of device scalars (``opt.loss`` is a view of one): a fresh ring when this one has
-        gone round, so a loss handed out earlier is never overwritten"""
-        self.ring = torch.zeros(self.RING, dtype=dtype, device=dev)
-        self.loss_views = self.ring.unbind(0)
-        self.state[1:].copy_(torch.tensor([self.ring.data_ptr(), self.RING], dtype=torch.int64))     # (once per RING trials)
 
     def _trial(self, pg):
         opt = self.opt
@@ -99,14 +140,8 @@ class PgoGraphStep:
             opt._defer_solver_info = False
         lin.s_dev = None                           # retries after a rejection run un-captured, with the host value
         pend, lin.pending_info = lin.pending_info, None
-        prog = self.prog
-        assert pend is not None and Dn.is_contiguous() and pt.is_contiguous() and lin.m == 6 and lin.K == 2 and lin.dr == 6 \
-            and lin.idx.data_ptr() == prog.idx.data_ptr() and lin.E == prog.E
-        with _C._on_device(pt.device):
-            code = self.tail(pt.data_ptr(), self.backup.data_ptr(), prog.idx.data_ptr(), prog.Z.data_ptr(), lin.J.data_ptr(), lin.R.data_ptr(), Dn.data_ptr(),
-                             pend.info.data_ptr(), self.partial.data_ptr(), self.state.data_ptr(), self.out.data_ptr(), lin.N, lin.E,
-                             _C.stream_ptr(pt.device))
-        _C.check(code, "pplie_pgo_trial_tail")
+        assert pend is not None
+        self.tt.enqueue(pt, self.backup, self.prog, lin, Dn, pend.info)
         self.lin, self.Dn = lin, Dn
 
     # -- per step ------------------------------------------------------------------------------------
@@ -159,10 +194,7 @@ class PgoGraphStep:
         lin = self.lin
         lin.s = 1.0 + float(pg['damping'])         # (host mirror: a retry compounds from here)
         self.ctl_f[0] = lin.s
-        self.seq = seq = self.seq + 1
-        self.slot = seq % self.RING
-        if self.slot == 0:
-            self._new_ring(self.ring.dtype, self.ring.device)
+        self.slot = self.tt.advance()
         self.graph.replay()
         # (the GPU is working: the step's host-side bookkeeping happens behind the launch)
         self._prev_last = opt.__dict__.get('_last_view')
@@ -173,19 +205,6 @@ class PgoGraphStep:
         self._last_h = hit[1] if hit is not None and hit[0] is opt.loss else None
         opt.reject_count = 0
         _C.mark_written(self.P)
-
-    def _wait(self):
-        """the trial's verdict: poll the pinned word the last kernel stores; a solve that takes unusually long is waited for
-        with a stream synchronisation instead"""
-        out, seq = self.out_np, float(self.seq)
-        n = 0
-        while out[7] != seq:
-            n += 1
-            if n > 200_000:
-                torch.cuda.synchronize(self.backup.device)
-                if out[7] != seq:
-                    raise RuntimeError("pypose_amd: the captured pose-graph trial finished without reporting its result")
-        return out[:7].tolist()
 
     def cancel(self):
         """undo a speculative launch: wait for it, put the parameters back (nothing else it wrote is state)"""
@@ -204,7 +223,7 @@ class PgoGraphStep:
 
     def finish(self, pg):
         opt, lin, last_h = self.opt, self.lin, self._last_h
-        a, b, loss_h, its, rr, bn2, flag = self._wait()               # the trial's one wait (no stream synchronisation)
+        a, b, loss_h, its, rr, bn2, flag = self.tt.wait()             # the trial's one wait (no stream synchronisation)
         if last_h is None:
             last_h = opt._host(opt.last)
         opt.linearization = lin.kind
@@ -230,6 +249,6 @@ class PgoGraphStep:
             J, R = lin.strategy_args()
             loss_h = opt._trial_loop(pg, lin, J, R, None, None, last_h, loss_h, defer=False)
         else:
-            opt.loss = self.loss_views[self.slot]  # (a ring of device scalars: never overwritten while the view is alive)
+            opt.loss = self.tt.loss_views[self.slot]  # (a ring of device scalars: never overwritten while the view is alive)
         opt._host_loss = (opt.loss, loss_h)
         return opt.loss

@@ -860,6 +860,7 @@ class GraphLinearization:
             assert not torch.any(torch.isnan(Dn)), 'Linear solve produced NaN (matrix may not be positive-definite)'
         else:
             Dn = self._pcg(solver, self.s, self.dmin, self.dmax, plain=False)     # (checks its residual norm for NaN)
+        self._last_Dn = Dn                         # (the step per node, un-padded: what a fused trial tail takes)
         return self.nodes_to_step(Dn)
 
     def _pcg(self, solver, s, dmin, dmax, plain):

@@ -14,18 +14,19 @@ graph = bench._pose_graph_model(init.clone())
 solver = pp.optim.solver.PCG(tol=1e-4, maxiter=250)
 opt = pp.optim.LM(graph, solver=solver, strategy=pp.optim.strategy.TrustRegion(radius=1e4), static=static)
 pp.optim.freeze_gc()
-T = {"wait": 0.0, "finish_rest": 0.0, "launch": 0.0, "replay": 0.0, "n": 0}
+T = {"wait": 0.0, "finish_rest": 0.0, "launch": 0.0, "replay": 0.0, "n": 0, "_w": 0.0}
 pc = time.perf_counter
 G = pgograph.PgoGraphStep
-_wait, _finish, _launch = G._wait, G.finish, G.launch
+TT = pgograph.TrialTail
+_wait, _finish, _launch = TT.wait, G.finish, G.launch
 
 
 def wait(self):
-    t0 = pc(); r = _wait(self); self._t_wait = pc() - t0; return r
+    t0 = pc(); r = _wait(self); T['_w'] = pc() - t0; return r
 
 
 def finish(self, pg):
-    t0 = pc(); r = _finish(self, pg); T["wait"] += self._t_wait; T["finish_rest"] += pc() - t0 - self._t_wait; T["n"] += 1; return r
+    t0 = pc(); r = _finish(self, pg); T["wait"] += T['_w']; T["finish_rest"] += pc() - t0 - T['_w']; T["n"] += 1; return r
 
 
 def launch(self, pg):
@@ -44,7 +45,7 @@ def launch(self, pg):
     T["launch"] += pc() - t0
 
 
-G._wait, G.finish, G.launch = wait, finish, launch
+TT.wait, G.finish, G.launch = wait, finish, launch
 for rep in range(13):
     graph.nodes.data.copy_(init.tensor())
     if hasattr(opt, "loss"):
