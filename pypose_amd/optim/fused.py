@@ -1135,7 +1135,11 @@ def _pgo_linearization(opt, prog, weight, P, trivial):
                     tt = opt._trial_tail = TrialTail(pt.dtype, pt.device)
                 pend, lin.pending_info = lin.pending_info, None
                 slot = tt.advance()
-                tt.enqueue(pt, None, prog, lin, Dn.contiguous(), None if pend is None else pend.info)
+                try:
+                    tt.enqueue(pt, None, prog, lin, Dn.contiguous(), None if pend is None else pend.info)
+                except BaseException:
+                    tt.seq -= 1                  # (nothing ran: the device's execution count did not move)
+                    raise
                 _C.mark_written(P)
                 a, b, loss_h, its, rr, bn2, flag = tt.wait()
                 if pend is not None:             # the persistent solve's (iterations, flag) rode along: raises like an eager solve

@@ -538,11 +538,16 @@ class LevenbergMarquardt(_Optimizer):
     def _trial_loop(self, pg, lin, J, R, input, target, last_h, loss_h, defer):
         """damp / solve / update / loss / strategy / accept-or-reject until a trial is accepted (optimizer.py:662-678);
         returns the accepted loss as a host float"""
+        use_tail = defer and getattr(lin, 'trial_tail', None) is not None and hasattr(lin, 'solve_nodes')
         while last_h <= loss_h:
             lin.damp(pg['damping'])
             self._defer_solver_info = defer
+            D = Dn = None
             try:
-                D = lin.solve(self.solver)
+                if use_tail:
+                    Dn = lin.solve_nodes(self.solver)          # (the padded step only if somebody needs it)
+                else:
+                    D = lin.solve(self.solver)
             except Exception as e:
                 print(e, "\nLinear solver failed. Breaking optimization step...")
                 break
@@ -551,11 +556,12 @@ class LevenbergMarquardt(_Optimizer):
             try:
                 # the recognised pose-graph program: update, candidate loss, gain terms and their read-back are one C call and one
                 # wait on pinned memory (optim/pgograph.py TrialTail)
-                fused_tail = lin.trial_tail() if defer and getattr(lin, 'trial_tail', None) is not None else None
+                fused_tail = lin.trial_tail() if use_tail else None
                 if fused_tail is not None:
                     a, b, loss_h, self.loss = fused_tail
                     _strategy.update_from_terms(self.strategy, pg, last_h, loss_h, a, b)
                 else:
+                    D = lin.nodes_to_step(Dn) if D is None else D
                     self.update_parameter(pg['params'], D)
                     self.loss = lin.fast_loss() if hasattr(lin, 'fast_loss') else self._loss(input, target)
                     loss_h = self._strategy_update(pg, J, D, R, last_h)
@@ -567,7 +573,7 @@ class LevenbergMarquardt(_Optimizer):
                 pend, lin.pending_info = lin.pending_info, None
                 lin._pending_solver.iterations = pend.resolve()
             if last_h < loss_h and self.reject_count < self.reject:           # reject the step
-                self.update_parameter(params=pg['params'], step=-D)
+                self.update_parameter(params=pg['params'], step=-(lin.nodes_to_step(Dn) if D is None else D))
                 self.loss, self.reject_count, loss_h = self.last, self.reject_count + 1, last_h
             else:
                 break

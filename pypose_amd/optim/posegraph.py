@@ -845,13 +845,18 @@ class GraphLinearization:
         self.s = self.s * (1.0 + damping)
 
     def solve(self, solver):
+        return self.nodes_to_step(self.solve_nodes(solver))
+
+    def solve_nodes(self, solver):
+        """the step per node, [N, m] (``solve`` pads it to the parameter's width: a fill and a concatenation that only the
+        generic update and a rejected trial's way back need)"""
         N, m = self.N, self.m
         if self.node_group is not None:
             pcg = solver if isinstance(solver, PCG) else PCG(tol=1e-10, maxiter=max(1000, 2 * N))
             maxiter = N * m * 10 if pcg.maxiter is None else pcg.maxiter
             Dn, its = self.ns.solve(self.s, self.dmin, self.dmax, pcg.tol, maxiter, pcg.check_every)
             solver.iterations = its
-            return self.nodes_to_step(Dn)
+            return Dn
         if not isinstance(solver, PCG) and N * m <= DENSE_LIMIT and self.group is None:
             shift = self.s * self.diag_clamped - self.diag_raw       # A = H + diag(shift)
             A = self.dense_matrix()
@@ -860,8 +865,8 @@ class GraphLinearization:
             assert not torch.any(torch.isnan(Dn)), 'Linear solve produced NaN (matrix may not be positive-definite)'
         else:
             Dn = self._pcg(solver, self.s, self.dmin, self.dmax, plain=False)     # (checks its residual norm for NaN)
-        self._last_Dn = Dn                         # (the step per node, un-padded: what a fused trial tail takes)
-        return self.nodes_to_step(Dn)
+        self._last_Dn = Dn                         # (what a fused trial tail takes)
+        return Dn
 
     def _pcg(self, solver, s, dmin, dmax, plain):
         """(H + damping) d = -g by the matrix-free conjugate gradient (block-Jacobi preconditioned unless ``plain``)."""
