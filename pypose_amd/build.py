@@ -80,6 +80,42 @@ def build(force: bool = False, jobs: int | None = None, verbose: bool = True) ->
     return out
 
 
+TORCH_EXT = "pplie_torch_ext"
+
+
+def build_torch_ext(force: bool = False, verbose: bool = True):
+    """Compile csrc_torch/pplie_autograd.cpp (native autograd nodes for the row operators: the dispatch layer between torch's
+    autograd engine and libpplie.so, no kernels of its own) against the installed torch into lib/pplie_torch_ext.so.  Needs no
+    GPU.  Returns the path, or None if this torch cannot build extensions (the Python Functions then carry the autograd)."""
+    src = PKG / "csrc_torch" / "pplie_autograd.cpp"
+    out = LIBDIR / (TORCH_EXT + ".so")
+    stamp = OBJDIR / (TORCH_EXT + ".sha1")
+    try:
+        import torch
+        from torch.utils import cpp_extension
+    except Exception as e:                          # pragma: no cover
+        print(f"[pypose_amd.build] torch extension not built: {e}", file=sys.stderr)
+        return None
+    h = hashlib.sha1()
+    h.update(src.read_bytes())
+    h.update(torch.__version__.encode())
+    dig = h.hexdigest()
+    OBJDIR.mkdir(exist_ok=True)
+    LIBDIR.mkdir(exist_ok=True)
+    if not force and out.exists() and stamp.exists() and stamp.read_text() == dig:
+        return out
+    bdir = OBJDIR / "torch_ext"
+    bdir.mkdir(exist_ok=True)
+    cpp_extension.load(name=TORCH_EXT, sources=[str(src)], build_directory=str(bdir), extra_cflags=["-O2"], with_cuda=True,
+                       is_python_module=False, verbose=False)
+    built = bdir / (TORCH_EXT + ".so")
+    out.write_bytes(built.read_bytes())
+    stamp.write_text(dig)
+    if verbose:
+        print(f"[pypose_amd.build] {out} ({out.stat().st_size >> 10} KiB)")
+    return out
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--force", action="store_true")
@@ -87,6 +123,7 @@ if __name__ == "__main__":
     a = ap.parse_args()
     try:
         build(force=a.force, jobs=a.j)
+        build_torch_ext(force=a.force)
     except RuntimeError as e:
         print(e, file=sys.stderr)
         sys.exit(1)

@@ -28,6 +28,56 @@ from .. import _C
 from . import matrices as _mats
 from .matrices import *            # noqa: F401,F403  so3_Jl ... Sim3_Act4_Jacobian (reference operation.py:7-301)
 
+
+# ---- native autograd nodes (csrc_torch/pplie_autograd.cpp): the plain eager case of the 32 Functions below recorded as a C++
+# node -- a Python Function costs ~35 us per backward node on the autograd engine's device thread (GIL, Python context), which is
+# most of BASELINE configs[0]'s latency; everything else (transforms, tracers, broadcasting, host tensors) stays on the Python path
+_native_state = {"mod": None, "tried": False, "ptr": {}, "rules": 0}
+_ROW_OP = _C.row_op            # (a launcher somebody replaced -- tests that record launches, a stand-in backend -- is honoured)
+
+
+def _native():
+    st = _native_state
+    if not st["tried"]:
+        st["tried"] = True
+        import importlib.util
+        import os
+        path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "lib", "pplie_torch_ext.so")
+        if os.environ.get("PPLIE_NATIVE_AUTOGRAD", "1") != "0" and os.path.exists(path) and _C._test_backend is None:
+            try:
+                spec = importlib.util.spec_from_file_location("pplie_torch_ext", path)
+                mod = importlib.util.module_from_spec(spec)
+                spec.loader.exec_module(mod)
+                st["mod"] = mod
+            except Exception as e:             # (built against another torch: the Python Functions carry the autograd)
+                import warnings
+                warnings.warn(f"pypose_amd: native autograd nodes unavailable ({e}); using the Python Functions")
+    return st["mod"]
+
+
+def _kernel_address(name, dtype):
+    key = (name, dtype)
+    hit = _native_state["ptr"].get(key)
+    if hit is None:
+        import ctypes
+        fn = _C.library().symbol("pplie_" + name + ("_f32" if dtype == torch.float32 else "_f64"))
+        hit = _native_state["ptr"][key] = ctypes.cast(fn, ctypes.c_void_p).value
+    return hit
+
+
+def _native_ok(ins, widths):
+    x0 = ins[0]
+    if type(x0) is not torch.Tensor and type(x0) is not torch.nn.Parameter:
+        return False
+    if not x0.is_cuda or x0.dtype not in (torch.float32, torch.float64) or not x0.is_contiguous() or x0.dim() < 1 \
+            or x0.shape[-1] != widths[0]:
+        return False
+    for t, w in zip(ins[1:], widths[1:]):
+        if (type(t) is not torch.Tensor and type(t) is not torch.nn.Parameter) or t.dtype != x0.dtype or t.device != x0.device \
+                or not t.is_contiguous() or t.shape[:-1] != x0.shape[:-1] or t.shape[-1] != w:
+            return False
+    return True
+
 # (algebra width, group width)
 _GROUPS = {"so3": (3, 4), "se3": (6, 7), "sim3": (7, 8), "rxso3": (4, 5)}
 _CAP = {"so3": "SO3", "se3": "SE3", "sim3": "Sim3", "rxso3": "RxSO3"}
@@ -248,6 +298,7 @@ def _make_fwd(clsname, g, kind, doc):
     }
     fin, fout, bin_, bout, reads = table[kind]
     fwd_kernel, bwd_kernel = f"{g}_{kind}_fwd", f"{g}_{kind}_bwd"
+    saved_spec = [-1 if key == "out" else int(key[2:]) for key in reads.split(",")]     # (what the backward kernel reads, in its order)
     Bwd = _make_bwd(clsname + "_Bwd", bwd_kernel, bin_, bout, _composed_rule(g, kind))
 
     class _Fn(torch.autograd.Function):
@@ -261,10 +312,27 @@ def _make_fwd(clsname, g, kind, doc):
             if not _transforms_active():
                 if not (torch.is_grad_enabled() and any(t.requires_grad for t in ins)):
                     return _launch(fwd_kernel, ins, fin, (fout,))[0]
+                nat = _native()
+                if nat is not None and len(ins) <= 2 and not _op_tracers and _C.row_op is _ROW_OP and not _C.dry_tracing() \
+                        and _native_ok(ins, fin):
+                    # the plain eager case: a native autograd node around the same two kernels (csrc_torch/pplie_autograd.cpp)
+                    dt = ins[0].dtype
+                    return nat.row_op(ins[0], ins[1] if len(ins) == 2 else None, _kernel_address(fwd_kernel, dt),
+                                      _kernel_address(bwd_kernel, dt), fout, saved_spec, list(bout), cls._native_rule(nat))
                 # recorded, but no functorch transform: the engine's own apply, past Function.apply's per-call
                 # inspect.signature binding of forward()'s defaults (~15 us; there are none)
                 return super(torch.autograd.Function, cls).apply(*ins)
             return super().apply(*ins)
+
+        @classmethod
+        def _native_rule(cls, nat):
+            """key of this operator's differentiable backward rule in the extension (registered on first use)"""
+            key = cls.__dict__.get('_rule_key')
+            if key is None:
+                _native_state["rules"] += 1
+                key = cls._rule_key = _native_state["rules"]
+                nat.set_rule(key, Bwd.apply)
+            return key
 
         @staticmethod
         def forward(*ins):

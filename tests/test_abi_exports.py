@@ -46,3 +46,17 @@ def test_product_has_no_cpu_path():
         pytest.skip("GPU present")
     with pytest.raises(RuntimeError, match="no CPU compute path"):
         pp.randn_so3(2).Exp()
+
+
+def test_torch_extension_builds_and_imports():
+    """pypose_amd/csrc_torch/pplie_autograd.cpp (native autograd nodes around the row kernels) compiles against the installed torch
+    without a GPU and exposes its two entry points; the product uses it only on HIP tensors (tests/test_native_autograd_gpu.py)."""
+    import importlib.util
+    from pypose_amd.build import build_torch_ext
+    path = build_torch_ext(verbose=False)
+    assert path is not None and path.exists()
+    import torch  # noqa: F401  (the extension links against libtorch)
+    spec = importlib.util.spec_from_file_location("pplie_torch_ext", str(path))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert callable(mod.row_op) and callable(mod.set_rule)
