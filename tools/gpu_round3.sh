@@ -16,3 +16,7 @@ echo "== rocprof all legs"; timeout 900 rocprofv3 --kernel-trace --stats --outpu
 cd $R; find gpurun_out/r03 -name "*kernel_trace.csv" -delete; find gpurun_out/r03 -name "*.db" -delete
 for d in prof_headline prof_all; do f=$(find gpurun_out/r03/$d -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" gpurun_out/r03/${d}_kernel_stats.csv && head -8 "$f" | cut -c1-160; done
 echo "== pmc"; bash tools/gpu_pmc.sh > gpurun_out/r03/pmc.log 2>&1; cp gpurun_out/pmc/pmc_raw.json gpurun_out/r03/pmc_raw.json 2>/dev/null; tail -5 gpurun_out/r03/pmc.log | cut -c1-200
+echo "== timelines / latency split"; bash tools/gpu_timeline.sh > gpurun_out/r03/timeline.log 2>&1; bash tools/gpu_timeline100k.sh > gpurun_out/r03/timeline100k.log 2>&1
+cp gpurun_out/tl/timeline_0.txt gpurun_out/r03/pgo_step_timeline_default.txt; cp gpurun_out/tl/timeline_1.txt gpurun_out/r03/pgo_step_timeline_static.txt; cp gpurun_out/tl/timeline_100k.txt gpurun_out/r03/pgo100k_step_timeline.txt
+timeout 200 python tools/time_c1_parts.py > gpurun_out/r03/c1_parts.log 2>&1; tail -7 gpurun_out/r03/c1_parts.log
+timeout 300 python tools/time_pgo_host.py 2>&1 | tail -1 > gpurun_out/r03/pgo_host_split.log; timeout 300 python tools/time_pgo_host.py static 2>&1 | tail -1 >> gpurun_out/r03/pgo_host_split.log; cat gpurun_out/r03/pgo_host_split.log
