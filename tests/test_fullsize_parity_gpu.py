@@ -67,6 +67,25 @@ def test_pgo_10k_40k_default_solver_settings_follow_the_reference_loss():
     assert rec["reject"] == ref["reject"]
 
 
+def test_pgo_100k_400k_follows_the_reference_loss():
+    """BASELINE configs[3] at full size (the two-launch PCG on packed symmetric blocks, the Laplacian assembly, the fused trial
+    tail): fp32 at bench.py's solver settings against the restatement running the reference's CG at the same tolerance -- the
+    inexact solves differ in their last iterations, the loss sequence agrees to 2e-3, the decisions are the same"""
+    from oracle import ref_restate
+    # (generated in fp64 and rounded once: 10^5 sequential fp32 products on the host leave the chain's quaternions 2e-5 off the unit
+    #  sphere, where the fused kernel and the traced chain are no longer the same function -- see the fixture above)
+    edges, rel, init = (t if t.dtype == torch.int64 else t.float() for t in ref_restate.pose_graph_problem(100_000, 400_000, seed=0, dtype=torch.float64))
+    ref = ref_restate.pgo_lm(init, edges, rel, 3, radius=1e4, tol=1e-4, maxiter=250)
+    graph = PoseGraph(pp.SE3(init.to(DEV)))
+    opt = pp.optim.LM(graph, solver=pp.optim.solver.PCG(tol=1e-4, maxiter=250), strategy=pp.optim.strategy.TrustRegion(radius=1e4))
+    rec = run_steps(opt, ((edges.to(DEV), pp.SE3(rel.to(DEV))),), {}, 3)
+    assert rec["kind"][-1] == "fused:pgo", rec["kind"]
+    assert {w.sym for w in opt._pcg_workspaces.values()} == {"pack"}
+    np.testing.assert_allclose(rec["loss"], ref["loss"], rtol=2e-3)
+    np.testing.assert_allclose(rec["damping"], ref["damping"], rtol=1e-12)
+    assert rec["reject"] == ref["reject"]
+
+
 @pytest.fixture(scope="module")
 def invnet1m():
     from oracle import ref_restate
