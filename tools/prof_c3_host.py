@@ -9,7 +9,7 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 torch.manual_seed(0)
 init = pp.randn_SE3(B, device="cuda"); inp = pp.randn_SE3(B, device="cuda")
 net = InvNet(init.clone())
-opt = pp.optim.LM(net, strategy=pp.optim.strategy.Constant(damping=1.0), static=True)
+opt = pp.optim.LM(net, strategy=pp.optim.strategy.Constant(damping=1e-4), static=True)
 for _ in range(5):
     opt.step(inp)
 torch.cuda.synchronize()
@@ -44,7 +44,7 @@ pstats.Stats(pr).sort_stats("tottime").print_stats(18)
 
 # ---- the default (static=False): the model's Python runs (dry) at every step
 net2 = InvNet(init.clone())
-opt2 = pp.optim.LM(net2, strategy=pp.optim.strategy.Constant(damping=1.0))
+opt2 = pp.optim.LM(net2, strategy=pp.optim.strategy.Constant(damping=1e-4))
 for _ in range(5):
     opt2.step(inp)
 torch.cuda.synchronize()
