@@ -34,6 +34,7 @@ from .functional import modjac
 from .solver import PINV, Cholesky
 from .strategy import Adaptive, Constant, TrustRegion
 from . import strategy as _strategy
+from . import fused as _fused
 
 
 class Trivial(nn.Module):
@@ -490,7 +491,6 @@ class LevenbergMarquardt(_Optimizer):
             else:
                 # default, the reference's semantics (optimizer.py:631, 646): the model runs every step -- as a dry trace that
                 # launches nothing -- and the shortcut is taken only if this step's program is the one it was built for
-                from . import fused as _fused
                 out = _fused.checked_shortcut(self, dev, gs, input, target, weight)
                 if out is not None:
                     return out

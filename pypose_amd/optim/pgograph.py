@@ -36,6 +36,19 @@ _TAIL_SIG = [ctypes.c_void_p] * 11 + [ctypes.c_int64, ctypes.c_int64, ctypes.c_v
 _PARTIALS = 1024          # PPLIE_PGO_PARTIALS
 
 
+_OPT_NAMES = None
+
+
+def _optimizer_names():
+    """(Trivial, _REPROBE) of optim/optimizer.py, which imports this module: resolved once (an import statement inside the
+    per-step check costs a microsecond or two each)"""
+    global _OPT_NAMES
+    if _OPT_NAMES is None:
+        from .optimizer import Trivial, _REPROBE
+        _OPT_NAMES = (Trivial, _REPROBE)
+    return _OPT_NAMES
+
+
 class TrialTail:
     """``pplie_pgo_trial_tail`` with its buffers: everything between the linear solve and the host's decision in four launches of one
     C entry point, the result block in HOST-PINNED memory that :meth:`wait` polls, the loss in a ring of device scalars.  Used by the
@@ -168,11 +181,10 @@ class PgoGraphStep:
             return False
         if _fused._strategy_kind(opt.strategy) is None or opt.group is not None or len(opt.param_groups) != 1:
             return False
-        from .optimizer import Trivial
+        Trivial, _REPROBE = _optimizer_names()
         if (all(isinstance(c, Trivial) for c in opt.corrector) and all(isinstance(k, Trivial) for k in opt.model.kernel)) != self.trivial \
                 or len(opt.corrector) != 1:
             return False
-        from .optimizer import _REPROBE
         uses = cache['_uses'] = cache.get('_uses', 0) + 1
         if uses % _REPROBE == 0:                   # the ordinary path's periodic re-probing keeps its rhythm
             cache['_uses'] = uses - 1
