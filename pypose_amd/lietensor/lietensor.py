@@ -585,11 +585,29 @@ class Parameter(LieTensor, nn.Parameter):
             param.ltype = data.ltype
             param._is_param = True
             return param
+        if sjac and type(data) is Tensor:
+            # the reference hands back nn.Parameter(TrackingTensor(data)), whose ``.tensor()`` its callers (and its own
+            # tests/optim/test_sparse_lm.py:86) use to get at the plain values
+            return Tensor._make_subclass(_TrackedParameter, data, requires_grad)
         return nn.Parameter(data, requires_grad)
 
     def __deepcopy__(self, memo):
         if id(self) not in memo:
             memo[id(self)] = type(self)(self.clone(memory_format=torch.preserve_format))
+        return memo[id(self)]
+
+
+class _TrackedParameter(nn.Parameter):
+    """what ``Parameter(plain_tensor, sjac=True)`` returns: an ``nn.Parameter`` with the ``tensor()`` accessor of the
+    reference's tracking wrapper (reference lietensor.py:1308-1323)"""
+
+    def tensor(self):
+        return Tensor.as_subclass(self, Tensor)
+
+    def __deepcopy__(self, memo):
+        if id(self) not in memo:
+            memo[id(self)] = Tensor._make_subclass(type(self), self.data.clone(memory_format=torch.preserve_format),
+                                                   self.requires_grad)
         return memo[id(self)]
 
 
