@@ -1,6 +1,8 @@
-"""Dispatch of ``cumprod_`` / ``cummul_`` on group LieTensors to the single-pass HIP scan
-(csrc/scan.hip: one wavefront per sequence, O(L) work, one launch) -- replaces the
-Hillis-Steele formulation of pypose/basics/ops.py:27-36 when no gradient is required."""
+"""Dispatch of ``cumprod_`` / ``cummul_`` on group LieTensors to the single-pass HIP scan (csrc/scan.hip: one wavefront
+per sequence, O(L) work, one launch) -- replaces the Hillis-Steele formulation of pypose/basics/ops.py:27-36, WITH or
+WITHOUT a gradient: the differentiable route is one autograd node whose backward is the one-pass kernel
+``pplie_scan_<g>_bwd`` (a reverse sum of adjoint-transported cotangents read off the scan's output), instead of the
+reference's log2(L) rounds of index_select / Mul / index_copy_ nodes."""
 import ctypes
 
 import torch
@@ -8,7 +10,89 @@ import torch
 from .. import _C
 
 _SIG = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]
+_BSIG = [ctypes.c_void_p] * 4 + [ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]
 _KEY = {"SO3Type": "so3", "SE3Type": "se3", "Sim3Type": "sim3", "RxSO3Type": "rxso3"}
+_ADJ = {"so3": "SO3_Adj", "se3": "SE3_Adj", "sim3": "Sim3_Adj", "rxso3": "RxSO3_Adj"}
+_plain = lambda t: torch.Tensor.as_subclass(t, torch.Tensor)
+DIFFERENTIABLE_SCAN = True       # False: gradients go through the reference's Hillis-Steele rounds (tests compare the two routes)
+
+
+def _geometry(shape, dim):
+    L = shape[dim]
+    outer = 1
+    for s in shape[:dim]:
+        outer *= s
+    inner = 1
+    for s in shape[dim + 1:-1]:
+        inner *= s
+    return outer, L, inner
+
+
+def _launch_fwd(t, key, dim, left):
+    outer, L, inner = _geometry(t.shape, dim)
+    fn = _C.library().symbol(f"pplie_scan_{key}" + ("_f32" if t.dtype == torch.float32 else "_f64"), _SIG)
+    with _C._on_device(t.device):
+        code = fn(t.data_ptr(), outer * inner, L, inner, 1 if left else 0, _C.stream_ptr(t.device))
+    _C.check(code, f"pplie_scan_{key}")
+
+
+def _launch_bwd(xy, g, key, dim, left):
+    """xy: the scan's input (left products) or output (right products) -- what the kernel reads, csrc/scan.hip"""
+    outer, L, inner = _geometry(xy.shape, dim)
+    gx = torch.empty_like(xy)
+    fn = _C.library().symbol(f"pplie_scan_{key}_bwd" + ("_f32" if xy.dtype == torch.float32 else "_f64"), _BSIG)
+    with _C._on_device(xy.device):
+        code = fn(xy.data_ptr() if left else None, None if left else xy.data_ptr(), g.data_ptr(), gx.data_ptr(), outer * inner,
+                  L, inner, 1 if left else 0, _C.stream_ptr(xy.device))
+    _C.check(code, f"pplie_scan_{key}_bwd")
+    return gx
+
+
+def _composed_bwd(y, g, key, dim, left):
+    """the same closed form from differentiable torch ops -- only when the backward itself is being recorded
+    (``create_graph=True``): double backward through a scan"""
+    from ..lietensor import matrices
+    adj = getattr(matrices, _ADJ[key])
+    D = y.shape[-1] - 1
+    rowvec = lambda v, Y: (v.unsqueeze(-2) @ adj(Y)).squeeze(-2)            # v @ Adj(Y) = Adj(Y)^T v
+    rsum = lambda v: v.flip(dim).cumsum(dim).flip(dim)
+    gt = g[..., :D]
+    if left:
+        from ..lietensor import lietensor as lt
+        Y = lt._wrap(y, getattr(lt, {"so3": "SO3_type", "se3": "SE3_type", "sim3": "Sim3_type", "rxso3": "RxSO3_type"}[key]))
+        out = rowvec(rsum(rowvec(gt, y)), _plain(Y.Inv()))
+    else:
+        ident = torch.zeros_like(y.narrow(dim, 0, 1))
+        ident[..., [3] if key in ("so3", "rxso3") else [6]] = 1
+        if key in ("sim3", "rxso3"):
+            ident[..., -1] = 1
+        yprev = torch.cat([ident, y.narrow(dim, 0, y.shape[dim] - 1)], dim=dim)
+        out = rowvec(rsum(gt), yprev)
+    return torch.cat([out, torch.zeros_like(out[..., :1])], dim=-1)
+
+
+class _GroupScan(torch.autograd.Function):
+    """in-place product scan of a non-leaf group tensor as ONE autograd node"""
+
+    @staticmethod
+    def forward(ctx, x, key, dim, left):
+        ctx.mark_dirty(x)
+        # left products: the backward transports cotangents through the scan's own FACTORS (kept: the scan overwrites them);
+        # right products: through the output
+        x_in = _plain(x).clone() if left else None
+        _launch_fwd(_plain(x), key, dim, left)
+        ctx.key, ctx.dim, ctx.left = key, dim, left
+        ctx.save_for_backward(x, x_in)
+        return x
+
+    @staticmethod
+    def backward(ctx, g):
+        y, x_in = ctx.saved_tensors
+        y = _plain(y)
+        g = _plain(g)
+        if torch.is_grad_enabled():
+            return _composed_bwd(y, g, ctx.key, ctx.dim, ctx.left), None, None, None
+        return _launch_bwd(x_in if ctx.left else y, g.contiguous(), ctx.key, ctx.dim, ctx.left), None, None, None
 
 
 def try_scan_(input, dim, left):
@@ -19,22 +103,14 @@ def try_scan_(input, dim, left):
         return None
     if input.dtype not in (torch.float32, torch.float64) or not input.is_contiguous():
         return None
-    if torch.is_grad_enabled() and input.requires_grad:
-        return None          # the differentiable route goes through the Mul Functions
     nd = input.dim()
     dim = dim % nd
     if dim == nd - 1:
         return None
-    L = input.shape[dim]
-    outer = 1
-    for s in input.shape[:dim]:
-        outer *= s
-    inner = 1
-    for s in input.shape[dim + 1:-1]:
-        inner *= s
-    fn = _C.library().symbol(f"pplie_scan_{key}" + ("_f32" if input.dtype == torch.float32 else "_f64"), _SIG)
-    with _C._on_device(input.device):
-        code = fn(input.data_ptr(), outer * inner, L, inner, 1 if left else 0, _C.stream_ptr(input.device))
-    _C.check(code, f"pplie_scan_{key}")
+    if torch.is_grad_enabled() and input.requires_grad:
+        if not DIFFERENTIABLE_SCAN or torch._C._are_functorch_transforms_active() or input.is_leaf:
+            return None       # transforms trace the composed route; a leaf raises there exactly as in the reference
+        return _GroupScan.apply(input, key, dim, left)
+    _launch_fwd(input, key, dim, left)
     _C.mark_written(input)                # the scan wrote through the raw pointer
     return input

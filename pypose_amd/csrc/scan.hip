@@ -31,14 +31,23 @@ template <class T, int W> __device__ __forceinline__ void bcast_vec(const T* v, 
 
 // group products: c = a * b
 // (ident(k): component k of the group identity)
+// (inv(a, o): o = a^-1;  adjT(X, g, o): o = [Adj(X)^T g[:W-1], 0] -- the Y-gradient of Mul, operation.py:846-852)
 template <class T> struct MulSO3 { enum { W = 4 }; static __device__ __forceinline__ void mul(const T* a, const T* b, T* c) { so3_mul<T>(a, b, c); }
-  static __device__ __forceinline__ T ident(int k) { return k == 3 ? T(1) : T(0); } };
+  static __device__ __forceinline__ T ident(int k) { return k == 3 ? T(1) : T(0); }
+  static __device__ __forceinline__ void inv(const T* a, T* o) { so3_inv<T>(a, o); }
+  static __device__ __forceinline__ void adjT(const T* X, const T* g, T* o) { T gx[W]; so3_mul_bwd<T>(X, g, gx, o); } };
 template <class T> struct MulSE3 { enum { W = 7 }; static __device__ __forceinline__ void mul(const T* a, const T* b, T* c) { se3_mul<T>(a, b, c); }
-  static __device__ __forceinline__ T ident(int k) { return k == 6 ? T(1) : T(0); } };
+  static __device__ __forceinline__ T ident(int k) { return k == 6 ? T(1) : T(0); }
+  static __device__ __forceinline__ void inv(const T* a, T* o) { se3_inv<T>(a, o); }
+  static __device__ __forceinline__ void adjT(const T* X, const T* g, T* o) { T gx[W]; se3_mul_bwd<T>(X, g, gx, o); } };
 template <class T> struct MulSim3 { enum { W = 8 }; static __device__ __forceinline__ void mul(const T* a, const T* b, T* c) { sim3_mul<T>(a, b, c); }
-  static __device__ __forceinline__ T ident(int k) { return (k == 6 || k == 7) ? T(1) : T(0); } };
+  static __device__ __forceinline__ T ident(int k) { return (k == 6 || k == 7) ? T(1) : T(0); }
+  static __device__ __forceinline__ void inv(const T* a, T* o) { sim3_inv<T>(a, o); }
+  static __device__ __forceinline__ void adjT(const T* X, const T* g, T* o) { T gx[W]; sim3_mul_bwd<T>(X, g, gx, o); } };
 template <class T> struct MulRxSO3 { enum { W = 5 }; static __device__ __forceinline__ void mul(const T* a, const T* b, T* c) { rxso3_mul<T>(a, b, c); }
-  static __device__ __forceinline__ T ident(int k) { return (k == 3 || k == 4) ? T(1) : T(0); } };
+  static __device__ __forceinline__ T ident(int k) { return (k == 3 || k == 4) ? T(1) : T(0); }
+  static __device__ __forceinline__ void inv(const T* a, T* o) { rxso3_inv<T>(a, o); }
+  static __device__ __forceinline__ void adjT(const T* X, const T* g, T* o) { T gx[W]; rxso3_mul_bwd<T>(X, g, gx, o); } };
 
 // acc (+) x  with acc the earlier prefix: left ? x * acc : acc * x   (basics/ops.py:49-56)
 template <class T, class G> __device__ __forceinline__ void combine(const T* acc, const T* x, T* out, bool left) {
@@ -159,6 +168,145 @@ template <class T, class G> int scan_launch(void* data, int64_t nseq, int64_t L,
 }
 
 // ---------------------------------------------------------------------------------------------
+// Backward of the product scan (the cotangent of  y = cumprod(x)  in the reference's gradient convention: gradients of
+// group elements are left-tangent vectors zero-padded to the embedding width, operation.py:846-852).  The reference gets
+// it by differentiating the log2(L) Hillis-Steele rounds (basics/ops.py:27-36: index_select / Mul / index_copy_ per round
+// plus their backward nodes); composing the Mul rules gives closed forms that are REVERSE PLAIN SUMS of transported tangent
+// vectors -- no group product of cotangents, no tree:
+//   right products  y_i = x_1 ... x_i :  gx_k = Adj(y_{k-1})^T  sum_{i>=k} g_i                                 (y_0 = 1)
+//       (read: the scan's OUTPUT y, shifted by one, and g)
+//   left products   y_i = x_i ... x_1 :  gx_k = sum_{i>=k} Adj(x_i ... x_{k+1})^T g_i
+//                                             = Adj(z_k)^T [ sum_{i>=k, i<=e} Adj(z_i^-1)^T g_i  +  Adj(x_{e+1})^T gx_{e+1} ],
+//       z_i = x_e ... x_{i+1}  the product of the LATER elements of the 64 K-element chunk [.., e] the wave is working on
+//       (read: the scan's INPUT x and g).  The transports are relative to the chunk's own end, built from the chunk's own
+//       factors by one wave product scan -- absolute poses y never enter, so fp32 does not lose the digits that the
+//       differences of far-away translations would cost (measured: 10x the error of the reference's tree on a 1000-pose SE3
+//       random walk when the same sums were transported through y_i y_a^-1).
+// One wavefront per sequence, chunks walked from the END of the sequence, lanes in reverse order (a prefix over the lanes
+// is a suffix over positions), K consecutive elements per lane; 3 W scalars of traffic per element.
+// Element 0 is never the OUTPUT of a product in the reference's rounds (ops.py:34-35 overwrites indices >= step only): y_0 IS
+// x_0 and its cotangent passes through whole, last embedding component included.
+// ---------------------------------------------------------------------------------------------
+template <class T, class G, int WAVES, int K, bool LEFT>
+__global__ void __launch_bounds__(WAVES * 64)
+scan_bwd_kernel(const T* __restrict__ xy, const T* __restrict__ g, T* __restrict__ gx, int64_t nseq, int64_t L, int64_t inner) {
+  constexpr int W = G::W, D = W - 1;
+  const int lane = threadIdx.x & 63, rl = 63 - lane;
+  const int64_t seq = (int64_t)blockIdx.x * WAVES + (threadIdx.x >> 6);
+  if (seq >= nseq) return;
+  const int64_t o = seq / inner, in = seq % inner;
+  auto row = [&](int64_t i) { return ((o * L + i) * inner + in) * W; };
+  T C[W];                 // the sum over everything behind this chunk (LEFT: gx of the later chunk's first element)
+  T xn[W], idn[W];        // LEFT: the later chunk's first factor x_{e+1}
+#pragma unroll
+  for (int k = 0; k < W; ++k) { C[k] = T(0); xn[k] = idn[k] = G::ident(k); }
+  const int64_t CH = 64 * K, nch = (L + CH - 1) / CH;
+  for (int64_t c = nch - 1; c >= 0; --c) {
+    const int64_t c0 = c * CH;
+    T yv[K][W], u[K][W];
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      const int64_t i = c0 + (int64_t)rl * K + j;
+      const bool valid = i < L;
+      const T* pg = g + row(valid ? i : 0);
+#pragma unroll
+      for (int k = 0; k < D; ++k) u[j][k] = valid ? pg[k] : T(0);
+      u[j][D] = T(0);
+      const bool has = LEFT ? valid : (valid && i > 0);           // right products read y_{i-1}, left products x_i
+      const T* py = xy + row(has ? (LEFT ? i : i - 1) : 0);
+#pragma unroll
+      for (int k = 0; k < W; ++k) yv[j][k] = has ? py[k] : G::ident(k);
+    }
+    T z[K][W];
+    if (LEFT) {
+      if (c < nch - 1) {                                          // the carried sum enters this chunk through x_{e+1}
+        T Cn[W];
+        G::adjT(xn, C, Cn);
+#pragma unroll
+        for (int k = 0; k < W; ++k) C[k] = Cn[k];
+      }
+      bcast_vec<T, W>(yv[0], xn, 63);                             // this chunk's first factor, for the next (earlier) chunk
+      // z_i = x_e ... x_{i+1}: inside the lane (later positions first), then over the lanes (lane 0 holds the chunk's end)
+#pragma unroll
+      for (int k = 0; k < W; ++k) z[K - 1][k] = idn[k];
+#pragma unroll
+      for (int j = K - 2; j >= 0; --j) G::mul(z[j + 1], yv[j + 1], z[j]);
+      T tot[W], ex[W];
+      G::mul(z[0], yv[0], tot);
+      wave_scan<T, G>(tot, idn, false, false, lane);              // P_l = tot_0 tot_1 ... tot_l
+#pragma unroll
+      for (int k = 0; k < W; ++k) ex[k] = lane_shift_up1(tot[k], idn[k]);
+#pragma unroll
+      for (int j = 0; j < K; ++j) {
+        T zz[W], zi[W], t[W];
+        G::mul(ex, z[j], zz);
+        G::inv(zz, zi);
+        G::adjT(zi, u[j], t);
+#pragma unroll
+        for (int k = 0; k < W; ++k) { z[j][k] = zz[k]; u[j][k] = t[k]; }
+      }
+    }
+    // suffix sums over positions: inside the lane, then over the (reversed) lanes
+#pragma unroll
+    for (int j = K - 2; j >= 0; --j)
+#pragma unroll
+      for (int k = 0; k < D; ++k) u[j][k] += u[j + 1][k];
+    T ex[W];
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+      const T tot = wave_prefix_add<T>(u[0][k]);
+      ex[k] = lane_shift_up1(tot, T(0)) + C[k];                   // everything behind this lane's K elements
+    }
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+#pragma unroll
+      for (int k = 0; k < D; ++k) u[j][k] += ex[k];
+      u[j][D] = T(0);
+    }
+    T first[W];                                                   // the value at position c0 (lane 63, j = 0)
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      const int64_t i = c0 + (int64_t)rl * K + j;
+      T out[W];
+      if (LEFT) G::adjT(z[j], u[j], out); else G::adjT(yv[j], u[j], out);
+      if (j == 0) {
+#pragma unroll
+        for (int k = 0; k < W; ++k) first[k] = LEFT ? out[k] : u[0][k];
+      }
+      if (i < L) {
+        T* p = gx + row(i);
+#pragma unroll
+        for (int k = 0; k < D; ++k) p[k] = out[k];
+        p[D] = i == 0 ? g[row(0) + D] : T(0);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < D; ++k) C[k] = lane_bcast63(first[k]);
+  }
+}
+
+template <class T, class G> int scan_bwd_launch(const void* x, const void* y, const void* g, void* gx, int64_t nseq, int64_t L,
+                                                int64_t inner, int left, void* stream) {
+  if (nseq < 0 || L < 0 || inner <= 0) return SC_EBADARG;
+  if (nseq == 0 || L == 0) return SC_OK;
+  if (!g || !gx || (left ? !x : !y)) return SC_EBADARG;
+  const void* xy = left ? x : y;
+  constexpr int WAVES = 4;
+  int64_t blocks = (nseq + WAVES - 1) / WAVES;
+#define PPLIE_SCANB(KK, LF)                                                                                          \
+  hipLaunchKernelGGL((scan_bwd_kernel<T, G, WAVES, KK, LF>), dim3((unsigned)blocks), dim3(WAVES * 64), 0,              \
+                     reinterpret_cast<hipStream_t>(stream), static_cast<const T*>(xy), static_cast<const T*>(g),         \
+                     static_cast<T*>(gx), nseq, L, inner)
+  if (L >= 256) {
+    if (left) PPLIE_SCANB(2, true); else PPLIE_SCANB(2, false);
+  } else {
+    if (left) PPLIE_SCANB(1, true); else PPLIE_SCANB(1, false);
+  }
+#undef PPLIE_SCANB
+  return hipGetLastError() == hipSuccess ? SC_OK : SC_ELAUNCH;
+}
+
+// ---------------------------------------------------------------------------------------------
 // IMU pre-integration (imu_preintegrator.py:314-426): one wavefront per sequence.
 //   dr_f   = Exp(gyro_f dt_f)                                  (:360)
 //   P_f    = dr_0 ... dr_f  (incre_r[f+1]);  Pex_f = incre_r[f] (:361-362)
@@ -275,6 +423,117 @@ imu_integrate_kernel(const T* __restrict__ dt, const T* __restrict__ gyro, const
     for (int k = 0; k < 3; ++k) { cV[k] = lane_bcast63(Dv[k]); cP[k] = lane_bcast63(Dp[k]); }
     cT = lane_bcast63(Dt);
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Backward of imu_integrate (training THROUGH the pre-integrator: examples/module/imu/imu_corrector.py:97 back-propagates a
+// position / rotation loss to corrected gyro / acc).  The reference differentiates the composed graph of :359-384 and
+// :422-426 -- two cumsum nodes, Act / Inv / Mul / Exp nodes and the log2(F) rounds of the product scan.  In world-frame
+// quantities (Q_f = rot_f = r0 dr_0 ... dr_f, Q_{-1} = r0, U_f = R(Q_{f-1}) a_f, a_f = acc_f - R(Qw_f)^T g) the whole
+// backward is three reverse plain sums per sequence and element-wise algebra:
+//   Sp_j = sum_{f>=j} Gp_f                                   (cotangent reaching the position increments)
+//   Sv_j = sum_{m>=j} (Gv_m + h_{m+1} Sp_{m+1})              = suffix(Gv + h Sp)_j - h_j Sp_j
+//   gU_j = h_j Sv_j + h_j^2/2 Sp_j ;  g_acc_j = R(Q_{j-1})^T gU_j
+//   gQ_j = Gr_j + U_{j+1} x gU_{j+1} + [rot not given] g x (R(Q_j) g_acc_j)      (left-tangent cotangent of Q_j)
+//   SQ_k = sum_{i>=k} gQ_i                                   = suffix(A + c)_k - c_k,  c_j = U_j x gU_j
+//   g_dr_k = R(Q_{k-1})^T SQ_k ;  g_phi_k = g_dr_k @ Jl(phi_k) ;  g_gyro_k = h_k g_phi_k
+//   g_dt_k = Sp_k . vel_k + Sv_k . U_k + gyro_k . g_phi_k
+// Reads per step: dt, gyro, acc, rot_f, rot_{f-1} (saved outputs), the three cotangents [, vel_f for g_dt]; writes g_gyro,
+// g_acc [, g_dt].  One wavefront per sequence, chunks of 64 steps from the END, lanes reversed (prefix over lanes = suffix
+// over steps).  Gradients of the initial state are sums of these outputs (host side, module/imu_preintegrator.py).
+// ---------------------------------------------------------------------------------------------
+template <class T, int WAVES, bool KNOWN>
+__global__ void __launch_bounds__(WAVES * 64)
+imu_integrate_bwd_kernel(const T* __restrict__ dt, const T* __restrict__ gyro, const T* __restrict__ acc,
+                         const T* __restrict__ rot_known, const T* __restrict__ rot_out, const T* __restrict__ vel_out,
+                         const T* __restrict__ init_rot, T gx, T gy, T gz,
+                         const T* __restrict__ g_rot, const T* __restrict__ g_vel, const T* __restrict__ g_pos,
+                         T* __restrict__ o_gyro, T* __restrict__ o_acc, T* __restrict__ o_dt, int64_t B, int64_t F) {
+  const int lane = threadIdx.x & 63, rl = 63 - lane;
+  const int64_t b = (int64_t)blockIdx.x * WAVES + (threadIdx.x >> 6);
+  if (b >= B) return;
+  const V3<T> g = v3<T>(gx, gy, gz);
+  T cSp[3] = {T(0), T(0), T(0)}, cT2[3] = {T(0), T(0), T(0)}, cS3[3] = {T(0), T(0), T(0)};
+  const int64_t nch = (F + 63) / 64;
+  for (int64_t c = nch - 1; c >= 0; --c) {
+    const int64_t f = c * 64 + rl;
+    const bool valid = f < F;
+    const int64_t row = b * F + (valid ? f : 0);
+    const T h = valid ? dt[row] : T(0);
+    T gyv[3], w[3], am[3], Q[4], Qm[4], Rw[4], Gp[3], Gv[3], Gr[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      gyv[k] = valid ? gyro[row * 3 + k] : T(0);
+      w[k] = gyv[k] * h;
+      am[k] = valid ? acc[row * 3 + k] : T(0);
+      Gp[k] = (g_pos && valid) ? g_pos[row * 3 + k] : T(0);
+      Gv[k] = (g_vel && valid) ? g_vel[row * 3 + k] : T(0);
+      Gr[k] = (g_rot && valid) ? g_rot[row * 4 + k] : T(0);
+    }
+    const T* pm = (valid && f > 0) ? rot_out + (row - 1) * 4 : init_rot + b * 4;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      Q[k] = valid ? rot_out[row * 4 + k] : (k == 3 ? T(1) : T(0));
+      Qm[k] = valid ? pm[k] : (k == 3 ? T(1) : T(0));
+      Rw[k] = KNOWN ? (valid ? rot_known[row * 4 + k] : (k == 3 ? T(1) : T(0))) : Q[k];
+    }
+    T Sp[3], T2[3], Sv[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) Sp[k] = wave_prefix_add<T>(Gp[k]) + cSp[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      T2[k] = wave_prefix_add<T>(Gv[k] + h * Sp[k]) + cT2[k];
+      Sv[k] = T2[k] - h * Sp[k];
+    }
+    const T hh = T(0.5) * h * h;
+    const V3<T> gU = v3<T>(h * Sv[0] + hh * Sp[0], h * Sv[1] + hh * Sp[1], h * Sv[2] + hh * Sp[2]);
+    const V3<T> a = v3(am) - quat_rotate(-v3(Rw), Rw[3], g);
+    const V3<T> U = quat_rotate(v3(Qm), Qm[3], a);
+    const V3<T> ga = adj_rotate_T(v3(Qm), Qm[3], gU);
+    const V3<T> cc = cross(U, gU);
+    V3<T> A = v3(Gr);
+    if (!KNOWN) A = A + cross(g, adj_rotate(v3(Q), Q[3], ga));
+    T s3[3] = {A.x + cc.x, A.y + cc.y, A.z + cc.z}, S3[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) S3[k] = wave_prefix_add<T>(s3[k]) + cS3[k];
+    const V3<T> SQ = v3<T>(S3[0] - cc.x, S3[1] - cc.y, S3[2] - cc.z);
+    const V3<T> gdr = adj_rotate_T(v3(Qm), Qm[3], SQ);
+    T gdr3[3] = {gdr.x, gdr.y, gdr.z}, gphi[3];
+    so3_exp_bwd<T>(w, gdr3, gphi);
+    if (valid) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) o_gyro[row * 3 + k] = h * gphi[k];
+      put(ga, o_acc + row * 3);
+      if (o_dt) {
+        T acc_dt = Sv[0] * U.x + Sv[1] * U.y + Sv[2] * U.z;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) acc_dt += Sp[k] * vel_out[row * 3 + k] + gyv[k] * gphi[k];
+        o_dt[row] = acc_dt;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { cSp[k] = lane_bcast63(Sp[k]); cT2[k] = lane_bcast63(T2[k]); cS3[k] = lane_bcast63(S3[k]); }
+  }
+}
+
+template <class T>
+int imu_integrate_bwd_launch(const void* dt, const void* gyro, const void* acc, const void* rot_known, const void* rot_out,
+                             const void* vel_out, const void* init_rot, const double* gravity, const void* g_rot,
+                             const void* g_vel, const void* g_pos, void* o_gyro, void* o_acc, void* o_dt, int64_t B, int64_t F,
+                             void* stream) {
+  if (B < 0 || F < 0) return SC_EBADARG;
+  if (B == 0 || F == 0) return SC_OK;
+  if (!dt || !gyro || !acc || !rot_out || !init_rot || !gravity || !o_gyro || !o_acc || (o_dt && !vel_out)) return SC_EBADARG;
+  constexpr int WAVES = 4;
+  int64_t blocks = (B + WAVES - 1) / WAVES;
+#define PPLIE_IMUB(KN)                                                                                                   \
+  hipLaunchKernelGGL((imu_integrate_bwd_kernel<T, WAVES, KN>), dim3((unsigned)blocks), dim3(WAVES * 64), 0,                \
+                     reinterpret_cast<hipStream_t>(stream), (const T*)dt, (const T*)gyro, (const T*)acc, (const T*)rot_known, \
+                     (const T*)rot_out, (const T*)vel_out, (const T*)init_rot, (T)gravity[0], (T)gravity[1], (T)gravity[2],  \
+                     (const T*)g_rot, (const T*)g_vel, (const T*)g_pos, (T*)o_gyro, (T*)o_acc, (T*)o_dt, B, F)
+  if (rot_known) PPLIE_IMUB(true); else PPLIE_IMUB(false);
+#undef PPLIE_IMUB
+  return hipGetLastError() == hipSuccess ? SC_OK : SC_ELAUNCH;
 }
 
 // K consecutive steps per lane (chunks of 64 K steps): the local products / sums of a lane's K steps are formed
@@ -980,6 +1239,19 @@ int imu_cov_launch(const void* dt, const void* rk, const void* rij, const void* 
   extern "C" int pplie_scan_##g##_f64(void* data, int64_t nseq, int64_t L, int64_t inner, int left, void* stream) { \
     return pplie::scan_launch<double, pplie::G<double>>(data, nseq, L, inner, left, stream);                        \
   }
+#define PPLIE_SCAN_BWD_EXPORT(g, G)                                                                                 \
+  extern "C" int pplie_scan_##g##_bwd_f32(const void* x, const void* y, const void* gy, void* gx, int64_t nseq, int64_t L,  \
+                                          int64_t inner, int left, void* stream) {                                  \
+    return pplie::scan_bwd_launch<float, pplie::G<float>>(x, y, gy, gx, nseq, L, inner, left, stream);              \
+  }                                                                                                                 \
+  extern "C" int pplie_scan_##g##_bwd_f64(const void* x, const void* y, const void* gy, void* gx, int64_t nseq, int64_t L,  \
+                                          int64_t inner, int left, void* stream) {                                  \
+    return pplie::scan_bwd_launch<double, pplie::G<double>>(x, y, gy, gx, nseq, L, inner, left, stream);            \
+  }
+PPLIE_SCAN_BWD_EXPORT(so3, MulSO3)
+PPLIE_SCAN_BWD_EXPORT(se3, MulSE3)
+PPLIE_SCAN_BWD_EXPORT(sim3, MulSim3)
+PPLIE_SCAN_BWD_EXPORT(rxso3, MulRxSO3)
 PPLIE_SCAN_EXPORT(so3, MulSO3)
 PPLIE_SCAN_EXPORT(se3, MulSE3)
 PPLIE_SCAN_EXPORT(sim3, MulSim3)
@@ -999,6 +1271,16 @@ extern "C" int pplie_imu_integrate_f64(const void* dt, const void* gyro, const v
   return pplie::imu_integrate_launch<double>(dt, gyro, acc, rot, init_rot, init_vel, init_pos, rij0, gravity, out_rot, out_vel,
                                              out_pos, aux_rk, aux_rij, aux_a, B, F, stream);
 }
+#define PPLIE_IMU_BWD_EXPORT(sfx, T)                                                                                    \
+  extern "C" int pplie_imu_integrate_bwd_##sfx(const void* dt, const void* gyro, const void* acc, const void* rot,            \
+                                               const void* rot_out, const void* vel_out, const void* init_rot,                \
+                                               const double* gravity, const void* g_rot, const void* g_vel, const void* g_pos,  \
+                                               void* g_gyro, void* g_acc, void* g_dt, int64_t B, int64_t F, void* stream) {   \
+    return pplie::imu_integrate_bwd_launch<T>(dt, gyro, acc, rot, rot_out, vel_out, init_rot, gravity, g_rot, g_vel, g_pos,   \
+                                              g_gyro, g_acc, g_dt, B, F, stream);                                           \
+  }
+PPLIE_IMU_BWD_EXPORT(f32, float)
+PPLIE_IMU_BWD_EXPORT(f64, double)
 extern "C" int pplie_imu_cov2_f32(const void* dt, const void* gyro, const void* acc, const void* rot_out, const void* rot_world,
                                   const void* C, const void* init_cov, const void* gyro_cov, int64_t gc_sb, int64_t gc_sf,
                                   const void* acc_cov, int64_t ac_sb, int64_t ac_sf, const double* gravity, void* cov, int64_t B,

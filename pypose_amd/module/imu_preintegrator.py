@@ -27,6 +27,8 @@ from ..lietensor import lietensor as _lt
 
 _INT_SIG = [ctypes.c_void_p] * 8 + [ctypes.POINTER(ctypes.c_double)] + [ctypes.c_void_p] * 6 + \
            [ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p]
+_INTB_SIG = [ctypes.c_void_p] * 7 + [ctypes.POINTER(ctypes.c_double)] + [ctypes.c_void_p] * 6 + \
+            [ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p]
 _COV2_SIG = [ctypes.c_void_p] * 8 + [ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
              ctypes.POINTER(ctypes.c_double), ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p]
 _COV_SIG = [ctypes.c_void_p] * 6 + [ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
@@ -35,6 +37,68 @@ _COV_SIG = [ctypes.c_void_p] * 6 + [ctypes.c_int64, ctypes.c_int64, ctypes.c_voi
 
 def _sfx(t):
     return "_f32" if t.dtype == torch.float32 else "_f64"
+
+
+def _qrot(q, p):
+    """rotate p by the quaternion q (xyzw), plain torch (host-side sums of the initial-state gradients only)"""
+    v, w = q[..., :3], q[..., 3:]
+    uv = 2 * torch.linalg.cross(v, p.expand(v.shape))
+    return p + w * uv + torch.linalg.cross(v, uv)
+
+
+class _ImuIntegrate(torch.autograd.Function):
+    """``integrate`` + ``predict`` (reference :314-426) as ONE autograd node: forward ``pplie_imu_integrate``, backward
+    ``pplie_imu_integrate_bwd`` (one reverse pass per sequence) -- the reference's graph for the same thing is two cumsum
+    nodes, Exp / Act / Inv / Mul nodes and the log2(F) rounds of its product scan."""
+
+    @staticmethod
+    def forward(ctx, mod, dt, gyro, acc, rot, r0, v0, p0):
+        B, F = dt.shape[:2]
+        orot, ovel, opos, held = mod._launch_integrate(dt, gyro, acc, rot, r0, v0, p0, None, None)
+        ctx.mod, ctx.has_rot = mod, rot is not None
+        ctx.save_for_backward(*held[:3], held[3] if rot is not None else dt, held[4], orot, ovel, opos, r0, v0, p0)
+        return orot, ovel, opos
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_rot, g_vel, g_pos):
+        dtc, gy, ac, rk, r0b, orot, ovel, opos, r0, v0, p0 = ctx.saved_tensors
+        mod = ctx.mod
+        B, F = dtc.shape[:2]
+        need = ctx.needs_input_grad          # (mod, dt, gyro, acc, rot, r0, v0, p0)
+        c = lambda t: None if t is None else t.contiguous()
+        g_rot, g_vel, g_pos = c(g_rot), c(g_vel), c(g_pos)
+        o_gyro, o_acc = torch.empty_like(gy), torch.empty_like(ac)
+        o_dt = torch.empty_like(dtc) if need[1] else None
+        P = lambda t: t.data_ptr() if t is not None else None
+        fn = _C.library().symbol("pplie_imu_integrate_bwd" + _sfx(dtc), _INTB_SIG)
+        with _C._on_device(dtc.device):
+            code = fn(P(dtc), P(gy), P(ac), P(rk) if ctx.has_rot else None, P(orot), P(ovel), P(r0b), mod._gravity_host(),
+                      P(g_rot), P(g_vel), P(g_pos), P(o_gyro), P(o_acc), P(o_dt), B, F, _C.stream_ptr(dtc.device))
+        _C.check(code, "pplie_imu_integrate_bwd")
+        g_r0 = g_v0 = g_p0 = None
+        if need[5] or need[6] or need[7]:
+            # the initial state enters linearly (vel, pos) or as the first factor of the rotation products: its gradients are
+            # sums over the steps of quantities already at hand
+            zero3 = lambda: torch.zeros((B, F, 3), dtype=dtc.dtype, device=dtc.device)
+            Gr = g_rot[..., :3] if g_rot is not None else zero3()
+            Gv = g_vel if g_vel is not None else zero3()
+            Gp = g_pos if g_pos is not None else zero3()
+            Dt = torch.cumsum(dtc, dim=1)
+            v0b, p0b = v0.reshape(-1, 1, 3), p0.reshape(-1, 1, 3)
+            if need[7]:
+                g_p0 = Gp.sum(1, keepdim=True).sum_to_size(p0b.shape).reshape(p0.shape)
+            if need[6]:
+                g_v0 = (Gv + Dt * Gp).sum(1, keepdim=True).sum_to_size(v0b.shape).reshape(v0.shape)
+            if need[5]:
+                t = Gr + torch.linalg.cross(ovel - v0b, Gv) + torch.linalg.cross(opos - p0b - v0b * Dt, Gp)
+                if not ctx.has_rot:
+                    gvec = mod.gravity.to(dtc.dtype).reshape(1, 1, 3).expand(B, F, 3)
+                    t = t + torch.linalg.cross(gvec, _qrot(orot, o_acc))
+                t = t.sum(1, keepdim=True)
+                t = torch.cat([t, torch.zeros_like(t[..., :1])], dim=-1)
+                g_r0 = t.sum_to_size(r0.reshape(-1, 1, 4).shape).reshape(r0.shape)
+        return None, o_dt, o_gyro, o_acc, None, g_r0, g_v0, g_p0
 
 
 class IMUPreintegrator(nn.Module):
@@ -57,6 +121,7 @@ class IMUPreintegrator(nn.Module):
         self.register_buffer('gyro_cov', gyro_cov, persistent=False)
         self.register_buffer('acc_cov', acc_cov, persistent=False)
         self.Rij = None      # rotation corresponding to the "zero-state" covariance
+        self.fused_backward = True     # False: gradients through the composed LieTensor graph (tests compare the two routes)
 
     def _check(self, obj):
         if obj is not None:
@@ -85,6 +150,9 @@ class IMUPreintegrator(nn.Module):
             Rij0 = init_state['Rij'] if 'Rij' in init_state else self.Rij
 
         fused = self._fused_ok(dt, gyro, acc, rot, init_state)
+        if fused and self.prop_cov and torch.is_grad_enabled() and \
+                any(t is not None and t.requires_grad for t in (gyro_cov, acc_cov, init_cov)):
+            fused = False        # a learnt noise model: the covariance itself carries a gradient (composed route)
         if fused:
             # states: one kernel writing rot / vel / pos only; covariance: a second kernel that re-derives what it needs per
             # step (increment, gravity-free acceleration, Rij) from the raw inputs and the integrated rotations -- no
@@ -96,7 +164,9 @@ class IMUPreintegrator(nn.Module):
                 last = SO3(Cq.unsqueeze(1)) * SO3(torch.Tensor.as_subclass(predict['rot'], torch.Tensor)[:, -1:, :])
                 Rij = LieTensor(torch.Tensor.as_subclass(last, torch.Tensor), ltype=init_state['rot'].ltype) \
                     if isinstance(init_state['rot'], LieTensor) else last
-                cov = {'cov': self._fused_cov2(dt, gyro, acc, rot, predict['rot'], Cq, init_cov, gyro_cov, acc_cov), 'Rij': Rij}
+                # (the covariance is a function of DETACHED states, reference :288-291; the kernel reads raw pointers)
+                cov = {'cov': self._fused_cov2(dt, gyro, acc, rot, predict['rot'], Cq, init_cov, gyro_cov, acc_cov),
+                       'Rij': Rij.detach()}
             else:
                 cov = {'cov': None}
         else:
@@ -132,7 +202,10 @@ class IMUPreintegrator(nn.Module):
         if _C._test_backend is not None or not all(t.is_cuda for t in ts):
             return False
         if torch.is_grad_enabled() and any(t.requires_grad for t in ts):
-            return False
+            # differentiable fused route (one node, pplie_imu_integrate_bwd): dt / gyro / acc / initial state may require a
+            # gradient; a known-orientation input that does, or a functorch transform, takes the composed route
+            if (rot is not None and rot.requires_grad) or torch._C._are_functorch_transforms_active() or not self.fused_backward:
+                return False
         return dt.dtype in (torch.float32, torch.float64) and all(t.dtype == dt.dtype for t in ts)
 
     def _rij_offset(self, rot0, Rij0, B):
@@ -199,24 +272,21 @@ class IMUPreintegrator(nn.Module):
         _C.check(code, "pplie_imu_cov2")
         return cov
 
-    def _fused_integrate(self, dt, gyro, acc, rot, init_state, Rij0, aux=None):
+    def _launch_integrate(self, dt, gyro, acc, rot, r0, v0, p0, Rij0, aux):
+        """pplie_imu_integrate on plain tensors; returns (rot, vel, pos, contiguous inputs it read [dt, gyro, acc, rot, r0])"""
         B, F = dt.shape[:2]
         dev, dty = dt.device, dt.dtype
         c = lambda t: t.contiguous()
-        r0 = self._bcast('r0', init_state['rot'], B, 4)
-        v0 = self._bcast('v0', init_state['vel'], B, 3)
-        p0 = self._bcast('p0', init_state['pos'], B, 3)
+        r0 = self._bcast('r0', r0, B, 4)
+        v0 = self._bcast('v0', v0, B, 3)
+        p0 = self._bcast('p0', p0, B, 3)
         dtc, gy, ac = c(dt), c(gyro), c(acc)
         rk = c(torch.Tensor.as_subclass(rot, torch.Tensor).expand(B, F, 4)) if rot is not None else None
         q0 = c(torch.Tensor.as_subclass(Rij0, torch.Tensor).expand(B, 1, 4).reshape(B, 4)) if Rij0 is not None else None
         orot = torch.empty((B, F, 4), dtype=dty, device=dev)
         ovel = torch.empty((B, F, 3), dtype=dty, device=dev)
         opos = torch.empty((B, F, 3), dtype=dty, device=dev)
-        want_aux = self.prop_cov if aux is None else aux
-        aux = {}
-        if want_aux:
-            aux = {'Rk': torch.empty((B, F, 4), dtype=dty, device=dev), 'Rij': torch.empty((B, F, 4), dtype=dty, device=dev),
-                   'a': torch.empty((B, F, 3), dtype=dty, device=dev)}
+        aux = aux or {}
         g = self._gravity_host()
         P = lambda t: t.data_ptr() if t is not None else None
         fn = _C.library().symbol("pplie_imu_integrate" + _sfx(dt), _INT_SIG)
@@ -224,7 +294,26 @@ class IMUPreintegrator(nn.Module):
             code = fn(P(dtc), P(gy), P(ac), P(rk), P(r0), P(v0), P(p0), P(q0), g, P(orot), P(ovel), P(opos),
                       P(aux.get('Rk')), P(aux.get('Rij')), P(aux.get('a')), B, F, _C.stream_ptr(dev))
         _C.check(code, "pplie_imu_integrate")
+        return orot, ovel, opos, (dtc, gy, ac, rk, r0)
+
+    def _fused_integrate(self, dt, gyro, acc, rot, init_state, Rij0, aux=None):
+        B, F = dt.shape[:2]
+        dev, dty = dt.device, dt.dtype
+        want_aux = self.prop_cov if aux is None else aux
+        aux = {}
+        if want_aux:
+            aux = {'Rk': torch.empty((B, F, 4), dtype=dty, device=dev), 'Rij': torch.empty((B, F, 4), dtype=dty, device=dev),
+                   'a': torch.empty((B, F, 3), dtype=dty, device=dev)}
         r_in = init_state['rot']
+        plain = torch.Tensor.as_subclass
+        ins = (dt, gyro, acc, plain(r_in, torch.Tensor), init_state['vel'], init_state['pos'])
+        if torch.is_grad_enabled() and any(t.requires_grad for t in ins):
+            # training through the pre-integrator: one autograd node, backward = pplie_imu_integrate_bwd
+            assert not want_aux
+            orot, ovel, opos = _ImuIntegrate.apply(self, dt, gyro, acc, None if rot is None else plain(rot, torch.Tensor).detach(),
+                                                   ins[3], ins[4], ins[5])
+        else:
+            orot, ovel, opos, _ = self._launch_integrate(dt, gyro, acc, rot, ins[3], ins[4], ins[5], Rij0, aux)
         rot_out = _lt._wrap(orot, r_in.ltype if isinstance(r_in, LieTensor) else _lt.SO3_type)
         return {'rot': rot_out, 'vel': ovel, 'pos': opos}, aux
 
