@@ -134,8 +134,11 @@ def cpu_baseline(budget_s: float = 12.0):
 # per-leg cpu_baseline (BASELINE.md section 3 / SURVEY.md 8(c)-(d)): the reference itself at the largest size it can run,
 # and the reference-function restatement of its LM loop (oracle/ref_restate.py) at the leg's full size
 # ---------------------------------------------------------------------------------------------------------------
-def leg_cpu_baselines(threads):
-    """{leg: cpu_baseline block}; `threads` intra-op threads (the count the headline's probe found fastest on this host)."""
+def leg_cpu_baselines(threads, instances=None, gpu=None):
+    """{leg: cpu_baseline block}; `threads` intra-op threads (the count the headline's probe found fastest on this host).
+    `instances`: the host-generated LM instances the GPU legs ran on (same tensors here); `gpu`: the GPU legs' blocks, whose
+    recorded trajectories are compared with the restatement's in a `parity` entry per leg."""
+    instances, gpu = instances or {}, gpu or {}
     import torch
     from oracle import ref_loader, ref_restate
     if not ref_loader.available():
@@ -172,10 +175,18 @@ def leg_cpu_baselines(threads):
             n1, n2 = self.nodes[e[..., 0]], self.nodes[e[..., 1]]
             return (poses.Inv() @ n1.Inv() @ n2).Log().tensor()
 
+    def parity_of(key, rec):
+        tr = (gpu.get(key) or {}).get("trajectory")
+        return _parity(tr, rec) if tr and key in instances and "error" not in tr else None
+
     def invnet():
         B = 1_000_000
-        torch.manual_seed(0)
-        init, inp = rpp.randn_SE3(B).tensor(), rpp.randn_SE3(B).tensor()
+        if "lm_invnet" in instances:
+            init, inp = instances["lm_invnet"]
+            B = init.shape[0]
+        else:
+            torch.manual_seed(0)
+            init, inp = rpp.randn_SE3(B).tensor(), rpp.randn_SE3(B).tensor()
         rec = ref_restate.invnet_lm(init, inp, 3, strategy="constant", strategy_kw=dict(damping=1e-4))
         t = sum(rec["step_seconds"]) / 3
         Br = 1024
@@ -189,13 +200,16 @@ def leg_cpu_baselines(threads):
         tr = time.perf_counter() - t0
         return block(1.0 / t, "LM steps/s", "port", f"3 LM steps at B = {B} fp32: oracle/ref_restate.invnet_lm -- the reference's loop "
                      "(optimizer.py:644-679) on [B,7,7] blocks, every formula a reference function (se3_Jl_inv, SE3 ops, cholesky_ex, "
-                     "its own strategy object)", problem_steps_per_s=B / t, losses=rec["loss"],
+                     "its own strategy object)", problem_steps_per_s=B / t, losses=rec["loss"], parity=parity_of("lm_invnet", rec),
                      reference_at_largest_runnable_size=block(1.0 / tr, "LM steps/s", "reference", f"one pp.optim.LM step of the reference "
                                                                  f"package itself (dense modjac J [6B,7B]) at B = {Br}", problem_steps_per_s=Br / tr))
 
-    def pgo(N, E, steps):
+    def pgo(N, E, steps, key):
         def f():
-            e, rel, init = ref_restate.pose_graph_problem(N, E, dtype=torch.float32)
+            if key in instances:
+                e, rel, init = instances[key]
+            else:
+                e, rel, init = ref_restate.pose_graph_problem(N, E, dtype=torch.float32)
             rec = ref_restate.pgo_lm(init, e, rel, steps, radius=1e4, tol=1e-4, maxiter=250)
             t = sum(rec["step_seconds"]) / steps
             Nr, Er = 200, 560
@@ -209,7 +223,7 @@ def leg_cpu_baselines(threads):
             return block(1.0 / t, "LM steps/s", "port", f"{steps} LM step(s) at {N} nodes / {E} edges fp32: oracle/ref_restate.pgo_lm -- "
                          "per-edge blocks from the reference's se3_Jl_inv / SE3_Adj, J as torch.sparse_csr, A = J^T J in CSR (the reference's "
                          "sparse branch, optimizer.py:640-643), the reference's CG (solver.py:276-340, tol 1e-4, maxiter 250) with a "
-                         "block-Jacobi M, TrustRegion(radius=1e4)", losses=rec["loss"], solve_seconds_per_step=sum(rec["solve_seconds"]) / steps,
+                         "block-Jacobi M, TrustRegion(radius=1e4)", losses=rec["loss"], parity=parity_of(key, rec), solve_seconds_per_step=sum(rec["solve_seconds"]) / steps,
                          reference_at_largest_runnable_size=block(1.0 / tr, "LM steps/s", "reference", "one pp.optim.LM step of the reference "
                                                                      f"package itself (dense J, Cholesky) at {Nr} nodes / {Er} edges"))
         return f
@@ -229,12 +243,58 @@ def leg_cpu_baselines(threads):
         return block(B * F / res[True], "steps/s", "reference", f"one forward of the reference's IMUPreintegrator(prop_cov=True) at "
                      f"{B} sequences x {F} steps fp32 (its largest size here: SURVEY 8d 'C5: B <= 512')", states_only_value=B * F / res[False])
 
+    def imu_train():
+        # the reference itself, forward + backward of the example's training loss (examples/module/imu/imu_corrector.py:69-74, 97)
+        B, F = 64, 1024
+        torch.manual_seed(0)
+        dt = torch.full((B, F, 1), 0.005)
+        gyro = (0.1 * torch.randn(B, F, 3)).requires_grad_(True)
+        acc = (torch.randn(B, F, 3) + torch.tensor([0., 0., 9.81])).requires_grad_(True)
+        gt_pos, gt_rot = torch.randn(B, F, 3), rpp.randn_SO3(B, F)
+        integ = rpp.module.IMUPreintegrator(prop_cov=False, reset=True)
+
+        def step():
+            gyro.grad = acc.grad = None
+            o = integ(dt=dt, gyro=gyro, acc=acc)
+            loss = torch.nn.functional.mse_loss(o["pos"], gt_pos) + 5e2 * (gt_rot * o["rot"].Inv()).Log().norm(dim=-1).mean()
+            loss.backward()
+        step()
+        t0 = time.perf_counter()
+        n = 0
+        while time.perf_counter() - t0 < 6.0:
+            step()
+            n += 1
+        t = (time.perf_counter() - t0) / n
+        return block(B * F / t, "steps/s", "reference", f"{n} training steps (forward + loss + backward) of the reference's IMUPreintegrator("
+                     f"prop_cov=False) at {B} sequences x {F} steps fp32, loss of examples/module/imu/imu_corrector.py:69-74")
+
+    def ops_chain():
+        # "fwd+bwd at 1 M" is the largest the reference runs comfortably on the host
+        B = 1_000_000
+        torch.manual_seed(0)
+        x = rpp.randn_se3(B, dtype=torch.float32, requires_grad=True)
+
+        def step():
+            x.grad = None
+            x.Exp().Log().sum().backward()
+        step()
+        t0 = time.perf_counter()
+        n = 0
+        while time.perf_counter() - t0 < 6.0:
+            step()
+            n += 1
+        t = (time.perf_counter() - t0) / n
+        return block(B / t, "SE3 Exp+Log pairs/s forward + backward", "reference", f"{n} passes of randn_se3({B}).Exp().Log().sum().backward() "
+                     "(fp32) through the reference package itself")
+
     try:
         with torch.no_grad():
             guarded("lm_invnet", invnet)
-            guarded("lm_pgo", pgo(10_000, 40_000, 3))
-            guarded("lm_pgo_100k", pgo(100_000, 400_000, 1))
+            guarded("lm_pgo", pgo(10_000, 40_000, 3, "lm_pgo"))
+            guarded("lm_pgo_100k", pgo(100_000, 400_000, 1, "lm_pgo_100k"))
             guarded("imu", imu)
+        guarded("imu_train", imu_train)
+        guarded("ops_10m", ops_chain)
     finally:
         torch.set_num_threads(old)
     return out
@@ -244,7 +304,10 @@ def leg_cpu_baselines(threads):
 # secondary workloads
 # ---------------------------------------------------------------------------------------------------------------
 def _pose_graph_problem(dev, nodes, edges):
-    """SURVEY.md section 8d C4 generator: chain + random loop closures, sigma 0.01 edge noise, sigma 0.05 initial error."""
+    """SURVEY.md section 8d C4 generator: chain + random loop closures, sigma 0.01 edge noise, sigma 0.05 initial error.
+    With `dev` = cpu the random numbers come from the HOST generator (the group arithmetic is still staged through the HIP
+    kernels): bench.py builds each LM instance once this way and hands the SAME tensors to the GPU leg and to the CPU
+    baseline's restatement of the reference's loop, so that their loss / damping / reject sequences can be compared."""
     import torch
     import pypose_amd as pp
     g = torch.Generator().manual_seed(0)
@@ -280,13 +343,48 @@ def _sync(dev):
         torch.cuda.synchronize()
 
 
-def pgo_lm_rate(dev, nodes=10_000, edges=40_000, steps=3, reps=5, with_static=True):
+def _host_instances(small, standin):
+    """the LM instances of the secondary legs, generated ONCE on the host (host RNG; plain tensors)"""
+    import torch
+    import pypose_amd as pp
+    import warnings
+    cpu = torch.device("cpu")
+    inst = {}
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")            # (host tensors staged through the kernels: that is the point here)
+        for key, (n, e) in (("lm_pgo", (60, 150) if small else (10_000, 40_000)), ("lm_pgo_100k", (80, 200) if small else (100_000, 400_000))):
+            ed, rel, init = _pose_graph_problem(cpu, n, e)
+            inst[key] = (ed, rel.tensor().contiguous(), init.tensor().contiguous())
+        B = 2000 if small else 1_000_000
+        torch.manual_seed(0)
+        inst["lm_invnet"] = (pp.randn_SE3(B).tensor().contiguous(), pp.randn_SE3(B).tensor().contiguous())
+    return inst
+
+
+def _parity(gpu, ref):
+    """same instance, same settings: the GPU leg's recorded trajectory beside the CPU restatement of the reference's loop"""
+    n = min(len(gpu["loss"]), len(ref["loss"]))
+    if n == 0:
+        return None
+    rel = [abs(a - b) / max(abs(b), 1e-300) for a, b in zip(gpu["loss"][:n], ref["loss"][:n])]
+    return {"steps_compared": n, "loss_rel": max(rel), "loss_rel_per_step": rel,
+            "damping_equal": all(abs(a - b) <= 1e-6 * abs(b) for a, b in zip(gpu["damping"][:n], ref["damping"][:n])),
+            "reject_equal": list(gpu["reject"][:n]) == list(ref["reject"][:n]),
+            "gpu": {k: gpu[k][:n] for k in ("loss", "damping", "reject")}, "cpu": {k: ref[k][:n] for k in ("loss", "damping", "reject")},
+            "note": "fp32 on both sides; the inexact PCG solves (tol 1e-4) may end in different iterations, see DESIGN.md section 4"}
+
+
+def pgo_lm_rate(dev, nodes=10_000, edges=40_000, steps=3, reps=5, with_static=True, problem=None):
     """Second half of BASELINE.json's metric: LM iterations/s on a synthetic pose graph (PCG tol 1e-4 / maxiter 250 as
     examples/module/ba, TrustRegion(radius=1e4) as pgo.py:67).  Every repetition restarts from the same initial estimate
     and takes the `steps` LM steps that do the actual descent (this problem reaches its noise floor in 3-4); repetition 0
     (structure probe, kernel verification, hipGraph capture) is untimed; the rate is the median repetition."""
     import pypose_amd as pp
-    e, rel, init = _pose_graph_problem(dev, nodes, edges)
+    if problem is None:
+        e, rel, init = _pose_graph_problem(dev, nodes, edges)
+    else:
+        e, rel, init = problem[0].to(dev), pp.SE3(problem[1].to(dev)), pp.SE3(problem[2].to(dev))
+        nodes, edges = init.shape[0], e.shape[0]
 
     def run(static):
         graph = _pose_graph_model(init.clone())
@@ -327,10 +425,25 @@ def pgo_lm_rate(dev, nodes=10_000, edges=40_000, steps=3, reps=5, with_static=Tr
         opt2, dt2, _, losses2, _ = run(True)
         out["static_model_value"] = 1.0 / dt2
         out["static_model_final_loss"] = losses2[-1]
+    # untimed: the trajectory of one repetition, read step by step, for the parity block against the CPU restatement
+    graph = opt.model.model if hasattr(opt.model, "model") else None
+    traj = {"loss": [], "damping": [], "reject": []}
+    try:
+        opt.model.model.nodes.data.copy_(init.tensor())
+        if hasattr(opt, "loss"):
+            del opt.loss
+        opt.param_groups[0].update(opt.strategy.defaults)
+        for _ in range(steps):
+            traj["loss"].append(float(opt.step((e, rel))))
+            traj["damping"].append(float(opt.param_groups[0]["damping"]))
+            traj["reject"].append(int(opt.reject_count))
+    except Exception as ex:                     # never lose the leg over its parity record
+        traj["error"] = repr(ex)
+    out["trajectory"] = traj
     return out
 
 
-def invnet_lm_rate(dev, B=1_000_000, steps=3, reps=40, group=None):
+def invnet_lm_rate(dev, B=1_000_000, steps=3, reps=40, group=None, problem=None):
     """BASELINE configs[2]: LM on the reference's README InvNet, B independent SE3 problems (per rank), fp32
     (SURVEY.md section 8d C3).  A repetition restarts from the same random poses and takes `steps` LM steps (the problem
     converges in 2-3; later steps sit at the rounding floor where every trial is a coin-flip rejection).  The step is
@@ -348,8 +461,12 @@ def invnet_lm_rate(dev, B=1_000_000, steps=3, reps=40, group=None):
             return (self.pose @ input).Log().tensor()
 
     torch.manual_seed(0 if group is None else 1 + torch.distributed.get_rank())
-    init = pp.randn_SE3(B, device=dev)
-    inp = pp.randn_SE3(B, device=dev)
+    if problem is None:
+        init = pp.randn_SE3(B, device=dev)
+        inp = pp.randn_SE3(B, device=dev)
+    else:
+        init, inp = pp.SE3(problem[0].to(dev)), pp.SE3(problem[1].to(dev))
+        B = init.shape[0]
     l0 = float(InvNet(init)(inp).detach().square().sum())
 
     def measure(static):
@@ -395,7 +512,19 @@ def invnet_lm_rate(dev, B=1_000_000, steps=3, reps=40, group=None):
     best_static, _, loss_static, _ = measure(True)
     world = 1 if group is None else torch.distributed.get_world_size(group)
     ach = 84.0 * B / best / 1e9
-    return {"metric": "LM iters/sec (InvNet SE3, 1M independent problems per GPU)", "value": 1.0 / best, "unit": "LM steps/s",
+    traj = {"loss": [], "damping": [], "reject": []}
+    if group is None:                       # untimed: one repetition read step by step (parity block against the CPU restatement)
+        try:
+            net = InvNet(init.clone())
+            opt = pp.optim.LM(net, strategy=pp.optim.strategy.Constant(damping=1e-4))
+            for _ in range(steps):
+                traj["loss"].append(float(opt.step(inp)))
+                traj["damping"].append(float(opt.param_groups[0]["damping"]))
+                traj["reject"].append(int(opt.reject_count))
+        except Exception as ex:
+            traj["error"] = repr(ex)
+    return {"trajectory": traj,
+            "metric": "LM iters/sec (InvNet SE3, 1M independent problems per GPU)", "value": 1.0 / best, "unit": "LM steps/s",
             "static_model_value": 1.0 / best_static, "static_model_final_loss": loss_static,
             "problems_per_gpu": B, "n_gpus": world, "problem_steps_per_s": world * B / best, "path": path,
             "initial_loss": l0, "final_loss": loss, "steps_per_repetition": steps, "repetitions_in_flight": reps,
@@ -438,6 +567,111 @@ def imu_rate(dev, B=4096, F=1024, reps=20, inner=16):
                          "frac": nbytes / t / 1e9 / HBM_PEAK_GBPS, "algorithmic_bytes_per_launch": nbytes,
                          "per": "module forward (68 B / step" + (" + 324 B / sequence)" if cov else ")")}}
     out["value"] = out["with_covariance"]["value"]
+    return out
+
+
+def _event_ms(dev, f, reps, warm=3):
+    """median HIP-event time of `f` (on torch's current stream: the stream every launch of the library uses)"""
+    import torch
+    for _ in range(warm):
+        f()
+    _sync(dev)
+    ts = []
+    if dev.type != "cuda":                     # (--standin dry run: plumbing only)
+        for _ in range(reps):
+            t0 = time.perf_counter(); f(); ts.append((time.perf_counter() - t0) * 1e3)
+        return sorted(ts)[len(ts) // 2]
+    for _ in range(reps):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); f(); b.record(); _sync(dev)
+        ts.append(a.elapsed_time(b))
+    return sorted(ts)[len(ts) // 2]
+
+
+def ops_10m_rates(dev, B=10_000_000, reps=20):
+    """BASELINE configs[1] in full ("Batched SE3 Exp/Log/Adj, B = 10 M, fp32") as SURVEY 8(d) C2 lists it: Exp, Log, Adj forward,
+    the two custom backwards, Jinvp, and the autograd chain x.Exp().Log().sum().backward(), each HIP-event timed at B rows with
+    its algorithmic bytes per row (Exp / Log 52, Adj / Exp-bwd / Log-bwd / Jinvp 76, forward + backward pair 256)."""
+    import torch
+    import pypose_amd as pp
+    from pypose_amd import _C
+    torch.manual_seed(0)
+    x = pp.randn_se3(B, device=dev).tensor().contiguous()
+    torch.manual_seed(1)
+    a = pp.randn_se3(B, device=dev).tensor().contiguous()
+    X = _C.row_op("se3_exp_fwd", [x], (7,))[0]
+    y = _C.row_op("se3_log_fwd", [X], (6,))[0]
+    g7 = torch.randn(B, 7, device=dev)
+    o6, o7 = torch.empty(B, 6, device=dev), torch.empty(B, 7, device=dev)
+    kern = {"se3_exp_fwd": ([x], o7, 52), "se3_log_fwd": ([X], o6, 52), "se3_adj_fwd": ([X, a], o6, 76),
+            "se3_exp_bwd": ([x, g7], o6, 76), "se3_log_bwd": ([y, a], o7, 76), "se3_jinvp_fwd": ([X, a], o6, 76)}
+    out = {"metric": "BASELINE configs[1]: SE3 row operators at B = 10 M fp32, one launch each", "rows": B, "unit": "GB/s", "kernels": {}}
+    for name, (ins, o, bpr) in kern.items():
+        ms = _event_ms(dev, lambda: _C.row_op(name, ins, (o.shape[1],), out=[o]), reps)
+        ach = B * bpr / ms / 1e6
+        out["kernels"][name] = {"ms": ms, "bytes_per_row": bpr, "rows_per_s": B / ms * 1e3,
+                                "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBPS, "achieved": ach, "frac": ach / HBM_PEAK_GBPS}}
+    del g7, o6, o7, y, X, a
+    xg = pp.LieTensor(x, ltype=pp.se3_type).requires_grad_(True)
+
+    def chain():
+        xg.grad = None
+        xg.Exp().Log().sum().backward()
+    ms = _event_ms(dev, chain, max(5, reps // 2))
+    ach = B * 256.0 / ms / 1e6
+    out["fwd_bwd_chain"] = {"ms": ms, "pairs_per_s": B / ms * 1e3, "bytes_per_row": 256,
+                            "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBPS, "achieved": ach, "frac": ach / HBM_PEAK_GBPS,
+                                         "per": "x.Exp().Log().sum().backward(): Exp 52 + Log 52 + Log-bwd 76 + Exp-bwd 76 B/row (SURVEY 8d C2); "
+                                                "torch's own sum (24 B/row read) and the materialised ones cotangent (24 B/row written, "
+                                                "24 read) ride on top and are NOT in the 256"}}
+    fr = [k["roofline"]["frac"] for k in out["kernels"].values()]
+    out["value"] = min(fr)
+    out["slowest_kernel"] = min(out["kernels"], key=lambda k: out["kernels"][k]["roofline"]["frac"])
+    return out
+
+
+def imu_train_rate(dev, B=4096, F=1024, reps=10):
+    """Training THROUGH the pre-integrator (examples/module/imu/imu_corrector.py:97) at BASELINE configs[4]'s shape: forward +
+    backward of IMUPreintegrator(prop_cov=False) w.r.t. gyro and acc.  `integrator` times the integrator pair alone
+    (torch.autograd.grad with given cotangents: pplie_imu_integrate + pplie_imu_integrate_bwd); `training_step` adds the
+    example's loss (mse on pos + 5e2 x geodesic rotation error) and its own backward.  Beside each: the composed route -- the
+    reference's formulation (Exp, log2(F) Hillis-Steele rounds of Mul, Act, Inv, two cumsums and their backward nodes) on the
+    same HIP row kernels.  Algorithmic bytes per step: forward 28 r + 40 w, backward 28 (inputs) + 16 (rot) + 40 (cotangents)
+    r + 24 w = 176 B."""
+    import torch
+    import pypose_amd as pp
+    torch.manual_seed(0)
+    dt = torch.full((B, F, 1), 0.005, device=dev)
+    gyro = (0.1 * torch.randn(B, F, 3, device=dev)).requires_grad_(True)
+    acc = (torch.randn(B, F, 3, device=dev) + torch.tensor([0., 0., 9.81], device=dev)).requires_grad_(True)
+    gt_pos, gt_rot = torch.randn(B, F, 3, device=dev), pp.randn_SO3(B, F, device=dev)
+    Wr, Wv, Wp = torch.randn(B, F, 4, device=dev), torch.randn(B, F, 3, device=dev), torch.randn(B, F, 3, device=dev)
+    out = {"metric": "IMU pre-integration forward + backward, steps/s", "sequences": B, "steps": F, "unit": "steps/s"}
+    nbytes = 176.0 * B * F
+    grads = {}
+    for route in ("fused", "composed"):
+        integ = pp.module.IMUPreintegrator(prop_cov=False, reset=True).to(dev)
+        integ.fused_backward = route == "fused"
+
+        def pair():
+            o = integ(dt=dt, gyro=gyro, acc=acc)
+            return torch.autograd.grad([o["rot"].tensor(), o["vel"], o["pos"]], [gyro, acc], [Wr, Wv, Wp])
+
+        def train():
+            gyro.grad = acc.grad = None
+            o = integ(dt=dt, gyro=gyro, acc=acc)
+            loss = torch.nn.functional.mse_loss(o["pos"], gt_pos) + 5e2 * (gt_rot * o["rot"].Inv()).Log().norm(dim=-1).mean()
+            loss.backward()
+        n = reps if route == "fused" else max(3, reps // 3)
+        ms_pair, ms_train = _event_ms(dev, pair, n), _event_ms(dev, train, n)
+        grads[route] = [g.double() for g in pair()]
+        out[route] = {"integrator": {"ms": ms_pair, "value": B * F / ms_pair * 1e3,
+                                     "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBPS, "achieved": nbytes / ms_pair / 1e6,
+                                                  "frac": nbytes / ms_pair / 1e6 / HBM_PEAK_GBPS, "algorithmic_bytes_per_launch_pair": nbytes}},
+                      "training_step": {"ms": ms_train, "value": B * F / ms_train * 1e3}}
+    out["value"] = out["fused"]["integrator"]["value"]
+    out["speedup_over_composed"] = {k: out["composed"][k]["ms"] / out["fused"][k]["ms"] for k in ("integrator", "training_step")}
+    out["routes_agree_rel"] = max(float((a - b).abs().max() / b.abs().max()) for a, b in zip(grads["fused"], grads["composed"]))
     return out
 
 
@@ -733,13 +967,23 @@ def main():
     gc.collect()
     gc.freeze()                   # (a gen-2 collection with torch loaded is a 40-70 ms pause)
     small = standin                # the dry run shrinks every leg: it checks plumbing, not speed
+    instances = {}
     if world == 1 and not a.no_secondary and rank == 0:
+        x = y = X = None                       # (the headline's 0.8 GB go back to the allocator before the 10 M-row legs)
+        try:
+            instances = _host_instances(small, standin)
+        except Exception as e:
+            out["instances_error"] = repr(e)
         legs = (("c1", lambda: c1_latency(dev)),
-                ("lm_invnet", lambda: invnet_lm_rate(dev, B=2000 if small else 1_000_000, reps=2 if small else 40)),
-                ("lm_pgo", lambda: pgo_lm_rate(dev, *((60, 150) if small else (10_000, 40_000)), reps=1 if small else 5)),
+                ("ops_10m", lambda: ops_10m_rates(dev, 4000 if small else 10_000_000, reps=2 if small else 20)),
+                ("lm_invnet", lambda: invnet_lm_rate(dev, B=2000 if small else 1_000_000, reps=2 if small else 40,
+                                                     problem=instances.get("lm_invnet"))),
+                ("lm_pgo", lambda: pgo_lm_rate(dev, *((60, 150) if small else (10_000, 40_000)), reps=1 if small else 5,
+                                               problem=instances.get("lm_pgo"))),
                 ("lm_pgo_100k", lambda: pgo_lm_rate(dev, *((80, 200) if small else (100_000, 400_000)), reps=1 if small else 5,
-                                                    with_static=False)),
+                                                    with_static=False, problem=instances.get("lm_pgo_100k"))),
                 ("imu", lambda: imu_rate(dev, *((8, 64) if small else (4096, 1024)), reps=2 if small else 20)),
+                ("imu_train", lambda: imu_train_rate(dev, *((8, 64) if small else (4096, 1024)), reps=2 if small else 10)),
                 ("ba_reproj", lambda: reproj_rate(dev, 2000 if small else 4_000_000, reps=2 if small else 10)))
         for key, fn in legs:
             try:
@@ -750,7 +994,8 @@ def main():
         out["cpu_baseline"] = cpu_baseline()
         if not a.no_secondary:
             try:
-                per_leg = leg_cpu_baselines(int(out["cpu_baseline"].get("cores") or 8) if out["cpu_baseline"].get("kind") == "reference" else 8)
+                per_leg = leg_cpu_baselines(int(out["cpu_baseline"].get("cores") or 8) if out["cpu_baseline"].get("kind") == "reference" else 8,
+                                            instances, out)
             except Exception as e:
                 per_leg = {"error": repr(e)}
             for key, blk in per_leg.items():

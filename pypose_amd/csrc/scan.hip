@@ -171,35 +171,34 @@ template <class T, class G> int scan_launch(void* data, int64_t nseq, int64_t L,
 // Backward of the product scan (the cotangent of  y = cumprod(x)  in the reference's gradient convention: gradients of
 // group elements are left-tangent vectors zero-padded to the embedding width, operation.py:846-852).  The reference gets
 // it by differentiating the log2(L) Hillis-Steele rounds (basics/ops.py:27-36: index_select / Mul / index_copy_ per round
-// plus their backward nodes); composing the Mul rules gives closed forms that are REVERSE PLAIN SUMS of transported tangent
-// vectors -- no group product of cotangents, no tree:
+// plus their backward nodes); composing the Mul rules gives one reverse pass:
 //   right products  y_i = x_1 ... x_i :  gx_k = Adj(y_{k-1})^T  sum_{i>=k} g_i                                 (y_0 = 1)
-//       (read: the scan's OUTPUT y, shifted by one, and g)
-//   left products   y_i = x_i ... x_1 :  gx_k = sum_{i>=k} Adj(x_i ... x_{k+1})^T g_i
-//                                             = Adj(z_k)^T [ sum_{i>=k, i<=e} Adj(z_i^-1)^T g_i  +  Adj(x_{e+1})^T gx_{e+1} ],
-//       z_i = x_e ... x_{i+1}  the product of the LATER elements of the 64 K-element chunk [.., e] the wave is working on
-//       (read: the scan's INPUT x and g).  The transports are relative to the chunk's own end, built from the chunk's own
-//       factors by one wave product scan -- absolute poses y never enter, so fp32 does not lose the digits that the
-//       differences of far-away translations would cost (measured: 10x the error of the reference's tree on a 1000-pose SE3
-//       random walk when the same sums were transported through y_i y_a^-1).
+//       a reverse PLAIN sum of the cotangents (they all live in the same left frame), then one transport.
+//       Reads the scan's OUTPUT y (shifted by one) and g.
+//   left products   y_i = x_i ... x_1 :  gx_k = g_k + Adj(x_{k+1})^T gx_{k+1}
+//       a reverse scan of the affine maps  s -> c + Adj(M)^T s  (pairs (M, c); composition (M_A, c_A) o (M_B, c_B) =
+//       (M_B M_A, c_A + Adj(M_A)^T c_B) for a range A followed by the later range B): inside a lane sequentially, across the
+//       lanes by the 7-step DPP tree, across chunks by a carried cotangent.  Every transport is by a product of the factors
+//       BETWEEN the two elements -- what the reference's tree does, at O(L) work; transporting through absolute poses
+//       (y_i y_a^-1) or through a chunk-wide anchor instead was measured 10x (SE3 random walk) to 70x (Sim3 with compounding
+//       scales) less accurate than the reference's formulation in fp32.  Reads the scan's INPUT x (shifted by one) and g.
 // One wavefront per sequence, chunks walked from the END of the sequence, lanes in reverse order (a prefix over the lanes
 // is a suffix over positions), K consecutive elements per lane; 3 W scalars of traffic per element.
 // Element 0 is never the OUTPUT of a product in the reference's rounds (ops.py:34-35 overwrites indices >= step only): y_0 IS
 // x_0 and its cotangent passes through whole, last embedding component included.
 // ---------------------------------------------------------------------------------------------
-template <class T, class G, int WAVES, int K, bool LEFT>
+template <class T, class G, int WAVES, int K>
 __global__ void __launch_bounds__(WAVES * 64)
-scan_bwd_kernel(const T* __restrict__ xy, const T* __restrict__ g, T* __restrict__ gx, int64_t nseq, int64_t L, int64_t inner) {
+scan_bwd_right_kernel(const T* __restrict__ y, const T* __restrict__ g, T* __restrict__ gx, int64_t nseq, int64_t L, int64_t inner) {
   constexpr int W = G::W, D = W - 1;
   const int lane = threadIdx.x & 63, rl = 63 - lane;
   const int64_t seq = (int64_t)blockIdx.x * WAVES + (threadIdx.x >> 6);
   if (seq >= nseq) return;
   const int64_t o = seq / inner, in = seq % inner;
   auto row = [&](int64_t i) { return ((o * L + i) * inner + in) * W; };
-  T C[W];                 // the sum over everything behind this chunk (LEFT: gx of the later chunk's first element)
-  T xn[W], idn[W];        // LEFT: the later chunk's first factor x_{e+1}
+  T C[W];                 // the sum over everything behind this chunk
 #pragma unroll
-  for (int k = 0; k < W; ++k) { C[k] = T(0); xn[k] = idn[k] = G::ident(k); }
+  for (int k = 0; k < W; ++k) C[k] = T(0);
   const int64_t CH = 64 * K, nch = (L + CH - 1) / CH;
   for (int64_t c = nch - 1; c >= 0; --c) {
     const int64_t c0 = c * CH;
@@ -212,39 +211,10 @@ scan_bwd_kernel(const T* __restrict__ xy, const T* __restrict__ g, T* __restrict
 #pragma unroll
       for (int k = 0; k < D; ++k) u[j][k] = valid ? pg[k] : T(0);
       u[j][D] = T(0);
-      const bool has = LEFT ? valid : (valid && i > 0);           // right products read y_{i-1}, left products x_i
-      const T* py = xy + row(has ? (LEFT ? i : i - 1) : 0);
+      const bool has = valid && i > 0;                            // y_{i-1}
+      const T* py = y + row(has ? i - 1 : 0);
 #pragma unroll
       for (int k = 0; k < W; ++k) yv[j][k] = has ? py[k] : G::ident(k);
-    }
-    T z[K][W];
-    if (LEFT) {
-      if (c < nch - 1) {                                          // the carried sum enters this chunk through x_{e+1}
-        T Cn[W];
-        G::adjT(xn, C, Cn);
-#pragma unroll
-        for (int k = 0; k < W; ++k) C[k] = Cn[k];
-      }
-      bcast_vec<T, W>(yv[0], xn, 63);                             // this chunk's first factor, for the next (earlier) chunk
-      // z_i = x_e ... x_{i+1}: inside the lane (later positions first), then over the lanes (lane 0 holds the chunk's end)
-#pragma unroll
-      for (int k = 0; k < W; ++k) z[K - 1][k] = idn[k];
-#pragma unroll
-      for (int j = K - 2; j >= 0; --j) G::mul(z[j + 1], yv[j + 1], z[j]);
-      T tot[W], ex[W];
-      G::mul(z[0], yv[0], tot);
-      wave_scan<T, G>(tot, idn, false, false, lane);              // P_l = tot_0 tot_1 ... tot_l
-#pragma unroll
-      for (int k = 0; k < W; ++k) ex[k] = lane_shift_up1(tot[k], idn[k]);
-#pragma unroll
-      for (int j = 0; j < K; ++j) {
-        T zz[W], zi[W], t[W];
-        G::mul(ex, z[j], zz);
-        G::inv(zz, zi);
-        G::adjT(zi, u[j], t);
-#pragma unroll
-        for (int k = 0; k < W; ++k) { z[j][k] = zz[k]; u[j][k] = t[k]; }
-      }
     }
     // suffix sums over positions: inside the lane, then over the (reversed) lanes
 #pragma unroll
@@ -263,15 +233,101 @@ scan_bwd_kernel(const T* __restrict__ xy, const T* __restrict__ g, T* __restrict
       for (int k = 0; k < D; ++k) u[j][k] += ex[k];
       u[j][D] = T(0);
     }
-    T first[W];                                                   // the value at position c0 (lane 63, j = 0)
+#pragma unroll
+    for (int k = 0; k < D; ++k) C[k] = lane_bcast63(u[0][k]);     // the sum from position c0 on
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      const int64_t i = c0 + (int64_t)rl * K + j;
+      if (i < L) {
+        T out[W];
+        G::adjT(yv[j], u[j], out);
+        T* p = gx + row(i);
+#pragma unroll
+        for (int k = 0; k < D; ++k) p[k] = out[k];
+        p[D] = i == 0 ? g[row(0) + D] : T(0);
+      }
+    }
+  }
+}
+
+// (M, c) <- (M, c) o (Ma, ca):  the range held by this lane followed by the LATER range (Ma, ca) of the lower lanes
+template <class T, class G> __device__ __forceinline__ void affine_after(T* M, T* c, const T* Ma, const T* ca) {
+  constexpr int W = G::W;
+  T t[W], Mn[W];
+  G::adjT(M, ca, t);
+  G::mul(Ma, M, Mn);
+#pragma unroll
+  for (int k = 0; k < W; ++k) { M[k] = Mn[k]; c[k] += t[k]; }
+}
+template <class T, class G, int CTRL, int RM, int BM>
+__device__ __forceinline__ void affine_scan_step(const T* srcM, const T* srcc, T* M, T* c) {
+  constexpr int W = G::W;
+  T Ma[W], ca[W];
+#pragma unroll
+  for (int k = 0; k < W; ++k) { Ma[k] = dpp_mov<CTRL, RM, BM>(G::ident(k), srcM[k]); ca[k] = dpp_mov<CTRL, RM, BM>(T(0), srcc[k]); }
+  affine_after<T, G>(M, c, Ma, ca);
+}
+
+template <class T, class G, int WAVES, int K>
+__global__ void __launch_bounds__(WAVES * 64)
+scan_bwd_left_kernel(const T* __restrict__ x, const T* __restrict__ g, T* __restrict__ gx, int64_t nseq, int64_t L, int64_t inner) {
+  constexpr int W = G::W, D = W - 1;
+  const int lane = threadIdx.x & 63, rl = 63 - lane;
+  const int64_t seq = (int64_t)blockIdx.x * WAVES + (threadIdx.x >> 6);
+  if (seq >= nseq) return;
+  const int64_t o = seq / inner, in = seq % inner;
+  auto row = [&](int64_t i) { return ((o * L + i) * inner + in) * W; };
+  T C[W];                 // gx of the later chunk's first element (zero behind the end of the sequence)
+#pragma unroll
+  for (int k = 0; k < W; ++k) C[k] = T(0);
+  const int64_t CH = 64 * K, nch = (L + CH - 1) / CH;
+  for (int64_t ch = nch - 1; ch >= 0; --ch) {
+    const int64_t c0 = ch * CH;
+    // element i carries the map  s -> g_i + Adj(x_{i+1})^T s ; M[j], c[j] become the lane-local composites of [j .. K-1]
+    T M[K][W], c[K][W];
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      const int64_t i = c0 + (int64_t)rl * K + j;
+      const bool valid = i < L, nxt = i + 1 < L;
+      const T* pg = g + row(valid ? i : 0);
+      const T* px = x + row(nxt ? i + 1 : 0);
+#pragma unroll
+      for (int k = 0; k < D; ++k) c[j][k] = valid ? pg[k] : T(0);
+      c[j][D] = T(0);
+#pragma unroll
+      for (int k = 0; k < W; ++k) M[j][k] = nxt ? px[k] : G::ident(k);
+    }
+#pragma unroll
+    for (int j = K - 2; j >= 0; --j) affine_after<T, G>(M[j], c[j], M[j + 1], c[j + 1]);
+    // inclusive scan of the lane totals over the lanes (lower lanes = later positions)
+    T Mt[W], ct[W], M0[W], c0v[W];
+#pragma unroll
+    for (int k = 0; k < W; ++k) { Mt[k] = M0[k] = M[0][k]; ct[k] = c0v[k] = c[0][k]; }
+    affine_scan_step<T, G, DPP_ROW_SHR1, 0xf, 0xf>(M0, c0v, Mt, ct);
+    affine_scan_step<T, G, DPP_ROW_SHR2, 0xf, 0xf>(M0, c0v, Mt, ct);
+    affine_scan_step<T, G, DPP_ROW_SHR3, 0xf, 0xf>(M0, c0v, Mt, ct);
+    affine_scan_step<T, G, DPP_ROW_SHR4, 0xf, 0xe>(Mt, ct, Mt, ct);
+    affine_scan_step<T, G, DPP_ROW_SHR8, 0xf, 0xc>(Mt, ct, Mt, ct);
+    affine_scan_step<T, G, DPP_ROW_BCAST15, 0xa, 0xf>(Mt, ct, Mt, ct);
+    affine_scan_step<T, G, DPP_ROW_BCAST31, 0xc, 0xf>(Mt, ct, Mt, ct);
+    // what follows this lane's K elements: the exclusive composite applied to the carried cotangent
+    T Me[W], ce[W], S[W], t[W];
+#pragma unroll
+    for (int k = 0; k < W; ++k) { Me[k] = lane_shift_up1(Mt[k], G::ident(k)); ce[k] = lane_shift_up1(ct[k], T(0)); }
+    G::adjT(Me, C, t);
+#pragma unroll
+    for (int k = 0; k < W; ++k) S[k] = ce[k] + t[k];
+    T first[W];
 #pragma unroll
     for (int j = 0; j < K; ++j) {
       const int64_t i = c0 + (int64_t)rl * K + j;
       T out[W];
-      if (LEFT) G::adjT(z[j], u[j], out); else G::adjT(yv[j], u[j], out);
+      G::adjT(M[j], S, out);
+#pragma unroll
+      for (int k = 0; k < D; ++k) out[k] += c[j][k];
       if (j == 0) {
 #pragma unroll
-        for (int k = 0; k < W; ++k) first[k] = LEFT ? out[k] : u[0][k];
+        for (int k = 0; k < W; ++k) first[k] = out[k];
       }
       if (i < L) {
         T* p = gx + row(i);
@@ -293,14 +349,14 @@ template <class T, class G> int scan_bwd_launch(const void* x, const void* y, co
   const void* xy = left ? x : y;
   constexpr int WAVES = 4;
   int64_t blocks = (nseq + WAVES - 1) / WAVES;
-#define PPLIE_SCANB(KK, LF)                                                                                          \
-  hipLaunchKernelGGL((scan_bwd_kernel<T, G, WAVES, KK, LF>), dim3((unsigned)blocks), dim3(WAVES * 64), 0,              \
+#define PPLIE_SCANB(KERNEL, KK)                                                                                       \
+  hipLaunchKernelGGL((KERNEL<T, G, WAVES, KK>), dim3((unsigned)blocks), dim3(WAVES * 64), 0,                           \
                      reinterpret_cast<hipStream_t>(stream), static_cast<const T*>(xy), static_cast<const T*>(g),         \
                      static_cast<T*>(gx), nseq, L, inner)
   if (L >= 256) {
-    if (left) PPLIE_SCANB(2, true); else PPLIE_SCANB(2, false);
+    if (left) PPLIE_SCANB(scan_bwd_left_kernel, 2); else PPLIE_SCANB(scan_bwd_right_kernel, 2);
   } else {
-    if (left) PPLIE_SCANB(1, true); else PPLIE_SCANB(1, false);
+    if (left) PPLIE_SCANB(scan_bwd_left_kernel, 1); else PPLIE_SCANB(scan_bwd_right_kernel, 1);
   }
 #undef PPLIE_SCANB
   return hipGetLastError() == hipSuccess ? SC_OK : SC_ELAUNCH;

@@ -151,7 +151,7 @@ def _imu_grads(tag, dtype, fused=True):
     loss = (o["rot"].tensor() * T("imu/Wr")).sum() + (o["vel"] * T("imu/Wv")).sum() + (o["pos"] * T("imu/Wp")).sum()
     loss.backward()
     out = {k: (v.grad.tensor() if hasattr(v.grad, "tensor") else v.grad).double().cpu().numpy() for k, v in leaves.items()}
-    return float(loss), out, o
+    return float(loss.detach()), out, o
 
 
 @pytest.mark.parametrize("tag", ["plain", "init", "known", "cov"])
