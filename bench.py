@@ -570,8 +570,9 @@ def imu_rate(dev, B=4096, F=1024, reps=20, inner=16):
     return out
 
 
-def _event_ms(dev, f, reps, warm=3):
-    """median HIP-event time of `f` (on torch's current stream: the stream every launch of the library uses)"""
+def _event_ms(dev, f, reps, warm=3, inner=1):
+    """median HIP-event time of `f` (on torch's current stream: the stream every launch of the library uses); `inner` calls are
+    enqueued back to back per event pair (a synchronisation per call exposes ~40 us of launch + wake-up latency)"""
     import torch
     for _ in range(warm):
         f()
@@ -583,8 +584,11 @@ def _event_ms(dev, f, reps, warm=3):
         return sorted(ts)[len(ts) // 2]
     for _ in range(reps):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record(); f(); b.record(); _sync(dev)
-        ts.append(a.elapsed_time(b))
+        a.record()
+        for _ in range(inner):
+            f()
+        b.record(); _sync(dev)
+        ts.append(a.elapsed_time(b) / inner)
     return sorted(ts)[len(ts) // 2]
 
 
@@ -663,7 +667,7 @@ def imu_train_rate(dev, B=4096, F=1024, reps=10):
             loss = torch.nn.functional.mse_loss(o["pos"], gt_pos) + 5e2 * (gt_rot * o["rot"].Inv()).Log().norm(dim=-1).mean()
             loss.backward()
         n = reps if route == "fused" else max(3, reps // 3)
-        ms_pair, ms_train = _event_ms(dev, pair, n), _event_ms(dev, train, n)
+        ms_pair, ms_train = _event_ms(dev, pair, n, inner=4), _event_ms(dev, train, n, inner=4)
         grads[route] = [g.double() for g in pair()]
         out[route] = {"integrator": {"ms": ms_pair, "value": B * F / ms_pair * 1e3,
                                      "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBPS, "achieved": nbytes / ms_pair / 1e6,

@@ -200,22 +200,33 @@ scan_bwd_right_kernel(const T* __restrict__ y, const T* __restrict__ g, T* __res
 #pragma unroll
   for (int k = 0; k < W; ++k) C[k] = T(0);
   const int64_t CH = 64 * K, nch = (L + CH - 1) / CH;
-  for (int64_t c = nch - 1; c >= 0; --c) {
-    const int64_t c0 = c * CH;
-    T yv[K][W], u[K][W];
+  // software pipeline: the next (earlier) chunk's rows are requested before this chunk's sums run -- one wave owns the whole
+  // sequence, so every chunk would otherwise pay the full HBM latency on its critical path
+  T ny[K][W], nu[K][W];
+  auto fetch = [&](int64_t c0) {
 #pragma unroll
     for (int j = 0; j < K; ++j) {
       const int64_t i = c0 + (int64_t)rl * K + j;
       const bool valid = i < L;
       const T* pg = g + row(valid ? i : 0);
 #pragma unroll
-      for (int k = 0; k < D; ++k) u[j][k] = valid ? pg[k] : T(0);
-      u[j][D] = T(0);
+      for (int k = 0; k < D; ++k) nu[j][k] = valid ? pg[k] : T(0);
+      nu[j][D] = T(0);
       const bool has = valid && i > 0;                            // y_{i-1}
       const T* py = y + row(has ? i - 1 : 0);
 #pragma unroll
-      for (int k = 0; k < W; ++k) yv[j][k] = has ? py[k] : G::ident(k);
+      for (int k = 0; k < W; ++k) ny[j][k] = has ? py[k] : G::ident(k);
     }
+  };
+  fetch((nch - 1) * CH);
+  for (int64_t c = nch - 1; c >= 0; --c) {
+    const int64_t c0 = c * CH;
+    T yv[K][W], u[K][W];
+#pragma unroll
+    for (int j = 0; j < K; ++j)
+#pragma unroll
+      for (int k = 0; k < W; ++k) { yv[j][k] = ny[j][k]; u[j][k] = nu[j][k]; }
+    if (c > 0) fetch(c0 - CH);
     // suffix sums over positions: inside the lane, then over the (reversed) lanes
 #pragma unroll
     for (int j = K - 2; j >= 0; --j)
@@ -281,10 +292,8 @@ scan_bwd_left_kernel(const T* __restrict__ x, const T* __restrict__ g, T* __rest
 #pragma unroll
   for (int k = 0; k < W; ++k) C[k] = T(0);
   const int64_t CH = 64 * K, nch = (L + CH - 1) / CH;
-  for (int64_t ch = nch - 1; ch >= 0; --ch) {
-    const int64_t c0 = ch * CH;
-    // element i carries the map  s -> g_i + Adj(x_{i+1})^T s ; M[j], c[j] become the lane-local composites of [j .. K-1]
-    T M[K][W], c[K][W];
+  T nM[K][W], nc[K][W];   // software pipeline as in the right-product kernel
+  auto fetch = [&](int64_t c0) {
 #pragma unroll
     for (int j = 0; j < K; ++j) {
       const int64_t i = c0 + (int64_t)rl * K + j;
@@ -292,11 +301,22 @@ scan_bwd_left_kernel(const T* __restrict__ x, const T* __restrict__ g, T* __rest
       const T* pg = g + row(valid ? i : 0);
       const T* px = x + row(nxt ? i + 1 : 0);
 #pragma unroll
-      for (int k = 0; k < D; ++k) c[j][k] = valid ? pg[k] : T(0);
-      c[j][D] = T(0);
+      for (int k = 0; k < D; ++k) nc[j][k] = valid ? pg[k] : T(0);
+      nc[j][D] = T(0);
 #pragma unroll
-      for (int k = 0; k < W; ++k) M[j][k] = nxt ? px[k] : G::ident(k);
+      for (int k = 0; k < W; ++k) nM[j][k] = nxt ? px[k] : G::ident(k);
     }
+  };
+  fetch((nch - 1) * CH);
+  for (int64_t ch = nch - 1; ch >= 0; --ch) {
+    const int64_t c0 = ch * CH;
+    // element i carries the map  s -> g_i + Adj(x_{i+1})^T s ; M[j], c[j] become the lane-local composites of [j .. K-1]
+    T M[K][W], c[K][W];
+#pragma unroll
+    for (int j = 0; j < K; ++j)
+#pragma unroll
+      for (int k = 0; k < W; ++k) { M[j][k] = nM[j][k]; c[j][k] = nc[j][k]; }
+    if (ch > 0) fetch(c0 - CH);
 #pragma unroll
     for (int j = K - 2; j >= 0; --j) affine_after<T, G>(M[j], c[j], M[j + 1], c[j + 1]);
     // inclusive scan of the lane totals over the lanes (lower lanes = later positions)
@@ -511,28 +531,44 @@ imu_integrate_bwd_kernel(const T* __restrict__ dt, const T* __restrict__ gyro, c
   const V3<T> g = v3<T>(gx, gy, gz);
   T cSp[3] = {T(0), T(0), T(0)}, cT2[3] = {T(0), T(0), T(0)}, cS3[3] = {T(0), T(0), T(0)};
   const int64_t nch = (F + 63) / 64;
-  for (int64_t c = nch - 1; c >= 0; --c) {
+  // software pipeline: the next (earlier) chunk's 24 scalars per step are in flight while this chunk's sums run
+  T n_h, n_gy[3], n_am[3], n_Q[4], n_Qm[4], n_Rw[4], n_Gp[3], n_Gv[3], n_Gr[3], n_vel[3];
+  auto fetch = [&](int64_t c) {
     const int64_t f = c * 64 + rl;
     const bool valid = f < F;
     const int64_t row = b * F + (valid ? f : 0);
-    const T h = valid ? dt[row] : T(0);
-    T gyv[3], w[3], am[3], Q[4], Qm[4], Rw[4], Gp[3], Gv[3], Gr[3];
+    n_h = valid ? dt[row] : T(0);
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-      gyv[k] = valid ? gyro[row * 3 + k] : T(0);
-      w[k] = gyv[k] * h;
-      am[k] = valid ? acc[row * 3 + k] : T(0);
-      Gp[k] = (g_pos && valid) ? g_pos[row * 3 + k] : T(0);
-      Gv[k] = (g_vel && valid) ? g_vel[row * 3 + k] : T(0);
-      Gr[k] = (g_rot && valid) ? g_rot[row * 4 + k] : T(0);
+      n_gy[k] = valid ? gyro[row * 3 + k] : T(0);
+      n_am[k] = valid ? acc[row * 3 + k] : T(0);
+      n_Gp[k] = (g_pos && valid) ? g_pos[row * 3 + k] : T(0);
+      n_Gv[k] = (g_vel && valid) ? g_vel[row * 3 + k] : T(0);
+      n_Gr[k] = (g_rot && valid) ? g_rot[row * 4 + k] : T(0);
+      n_vel[k] = (o_dt && valid) ? vel_out[row * 3 + k] : T(0);
     }
     const T* pm = (valid && f > 0) ? rot_out + (row - 1) * 4 : init_rot + b * 4;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      Q[k] = valid ? rot_out[row * 4 + k] : (k == 3 ? T(1) : T(0));
-      Qm[k] = valid ? pm[k] : (k == 3 ? T(1) : T(0));
-      Rw[k] = KNOWN ? (valid ? rot_known[row * 4 + k] : (k == 3 ? T(1) : T(0))) : Q[k];
+      n_Q[k] = valid ? rot_out[row * 4 + k] : (k == 3 ? T(1) : T(0));
+      n_Qm[k] = valid ? pm[k] : (k == 3 ? T(1) : T(0));
+      n_Rw[k] = KNOWN ? (valid ? rot_known[row * 4 + k] : (k == 3 ? T(1) : T(0))) : n_Q[k];
     }
+  };
+  fetch(nch - 1);
+  for (int64_t c = nch - 1; c >= 0; --c) {
+    const int64_t f = c * 64 + rl;
+    const bool valid = f < F;
+    const int64_t row = b * F + (valid ? f : 0);
+    const T h = n_h;
+    T gyv[3], w[3], am[3], Q[4], Qm[4], Rw[4], Gp[3], Gv[3], Gr[3], velv[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      gyv[k] = n_gy[k]; w[k] = gyv[k] * h; am[k] = n_am[k]; Gp[k] = n_Gp[k]; Gv[k] = n_Gv[k]; Gr[k] = n_Gr[k]; velv[k] = n_vel[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { Q[k] = n_Q[k]; Qm[k] = n_Qm[k]; Rw[k] = n_Rw[k]; }
+    if (c > 0) fetch(c - 1);
     T Sp[3], T2[3], Sv[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) Sp[k] = wave_prefix_add<T>(Gp[k]) + cSp[k];
@@ -563,7 +599,7 @@ imu_integrate_bwd_kernel(const T* __restrict__ dt, const T* __restrict__ gyro, c
       if (o_dt) {
         T acc_dt = Sv[0] * U.x + Sv[1] * U.y + Sv[2] * U.z;
 #pragma unroll
-        for (int k = 0; k < 3; ++k) acc_dt += Sp[k] * vel_out[row * 3 + k] + gyv[k] * gphi[k];
+        for (int k = 0; k < 3; ++k) acc_dt += Sp[k] * velv[k] + gyv[k] * gphi[k];
         o_dt[row] = acc_dt;
       }
     }
