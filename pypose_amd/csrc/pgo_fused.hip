@@ -11,6 +11,7 @@
 // Algorithmic bytes per edge: 16 idx + 28 Z + 2 * 28 gathered nodes read,
 // 24 residual + 2 * 144 Jacobian written = 412 B; the autograd route makes 6 backward sweeps through five ops.
 #include "rowmap.h"
+#include "robust.h"
 
 extern "C" int pplie_graph_gain_terms_f32(const void* J, const void* idx, const void* d, int ld, const void* R, void* partial,
                                           int64_t E, int dr, int m, int k, void* stream);      // csrc/graph.hip
@@ -32,7 +33,7 @@ template <class T> __device__ __forceinline__ void pgo_residual(const T* z, cons
 template <class T, int BLOCK>
 __global__ void __launch_bounds__(BLOCK)
 pgo_linearize_kernel(const T* __restrict__ nodes, const int64_t* __restrict__ idx, const T* __restrict__ Z,
-                     T* __restrict__ R, T* __restrict__ J, int64_t E) {
+                     T* __restrict__ R, T* __restrict__ J, int64_t E, RobustParam<T> rk) {
   __shared__ __attribute__((aligned(16))) T lds[BLOCK * 72];
   const int64_t ntiles = (E + BLOCK - 1) / BLOCK;
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -70,6 +71,14 @@ pgo_linearize_kernel(const T* __restrict__ nodes, const int64_t* __restrict__ id
         Jm[0 * 6 + 3 + c] = b.x; Jm[1 * 6 + 3 + c] = b.y; Jm[2 * 6 + 3 + c] = b.z;
         Jm[3 * 6 + 3 + c] = a.x; Jm[4 * 6 + 3 + c] = a.y; Jm[5 * 6 + 3 + c] = a.z;
       }
+      if (rk.kind != RK_NONE) {
+        // robust kernel on the edge: residual and both blocks scaled by sqrt(rho'(|r|^2)) in registers (corrector.py:91-96)
+        const T sc = robust_row_scale<T, 6>(rk, r);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) r[k] *= sc;
+#pragma unroll
+        for (int k = 0; k < 36; ++k) Jm[k] *= sc;
+      }
     }
     __syncthreads();                                              // every lane has read its Z row
     if (t < rows) row_st<6>(lds + t * 6, r);
@@ -90,7 +99,7 @@ pgo_linearize_kernel(const T* __restrict__ nodes, const int64_t* __restrict__ id
 template <class T, int BLOCK>
 __global__ void __launch_bounds__(BLOCK)
 pgo_residual_kernel(const T* __restrict__ nodes, const int64_t* __restrict__ idx, const T* __restrict__ Z,
-                    T* __restrict__ R /* or null */, T* __restrict__ partial /* [gridDim.x] */, int64_t E) {
+                    T* __restrict__ R /* or null */, T* __restrict__ partial /* [gridDim.x] */, int64_t E, RobustParam<T> rk) {
   __shared__ __attribute__((aligned(16))) T lds[BLOCK * 7];
   T acc = T(0);
   const int64_t ntiles = (E + BLOCK - 1) / BLOCK;
@@ -111,8 +120,10 @@ pgo_residual_kernel(const T* __restrict__ nodes, const int64_t* __restrict__ idx
 #pragma unroll
       for (int k = 0; k < 7; ++k) { n1[k] = nodes[i0 * 7 + k]; n2[k] = nodes[i1 * 7 + k]; }
       pgo_residual<T>(z, n1, n2, Tm, r);
+      T x = T(0);
 #pragma unroll
-      for (int k = 0; k < 6; ++k) acc += r[k] * r[k];
+      for (int k = 0; k < 6; ++k) x += r[k] * r[k];
+      acc += rk.kind != RK_NONE ? robust_rho<T>(rk, x) : x;        // the model's loss sum_e rho(|r_e|^2) (optimizer.py:118-125)
     }
     __syncthreads();
     if (R) {
@@ -205,7 +216,7 @@ int pgo_trial_tail(void* nodes, void* backup, const void* idx, const void* Z, co
   const int grid = (int)(nt < kPgoPartials ? nt : kPgoPartials);             // (= the grid of both kernels below)
   T* part = (T*)partial;
   hipLaunchKernelGGL((pgo_residual_kernel<T, BLOCK>), dim3(grid), dim3(BLOCK), 0, st, (const T*)nodes, (const int64_t*)idx,
-                     (const T*)Z, (T*)nullptr, part, E);
+                     (const T*)Z, (T*)nullptr, part, E, RobustParam<T>{RK_NONE, T(0), T(0)});
   const int code = sizeof(T) == 4 ? pplie_graph_gain_terms_f32(J, idx, x, 6, R, part + kPgoPartials, E, 6, 6, 2, stream)
                                   : pplie_graph_gain_terms_f64(J, idx, x, 6, R, part + kPgoPartials, E, 6, 6, 2, stream);
   if (code != PPLIE_OK) return code;
@@ -215,29 +226,52 @@ int pgo_trial_tail(void* nodes, void* backup, const void* idx, const void* Z, co
 }
 
 template <class T>
-int pgo_linearize(const void* nodes, const void* idx, const void* Z, void* R, void* J, int64_t E, void* stream) {
-  if (E < 0) return PPLIE_EBADARG;
+int pgo_linearize(const void* nodes, const void* idx, const void* Z, void* R, void* J, int64_t E, void* stream, int kind = 0,
+                  double p0 = 0, double p1 = 0) {
+  if (E < 0 || kind < 0 || kind > RK_TOLERANT) return PPLIE_EBADARG;
   if (E == 0) return PPLIE_OK;
   if (!nodes || !idx || !Z || !R || !J || !aligned16(Z) || !aligned16(R) || !aligned16(J)) return PPLIE_EBADARG;
   constexpr int BLOCK = 64;
   int64_t nt = (E + BLOCK - 1) / BLOCK;
   int grid = (int)(nt < (1 << 20) ? nt : (1 << 20));
   hipLaunchKernelGGL((pgo_linearize_kernel<T, BLOCK>), dim3(grid), dim3(BLOCK), 0, reinterpret_cast<hipStream_t>(stream),
-                     (const T*)nodes, (const int64_t*)idx, (const T*)Z, (T*)R, (T*)J, E);
+                     (const T*)nodes, (const int64_t*)idx, (const T*)Z, (T*)R, (T*)J, E, RobustParam<T>{kind, (T)p0, (T)p1});
   return hipGetLastError() == hipSuccess ? PPLIE_OK : PPLIE_ELAUNCH;
 }
 template <class T>
-int pgo_residual_launch(const void* nodes, const void* idx, const void* Z, void* R, void* partial, int64_t E, void* stream) {
+int pgo_residual_launch(const void* nodes, const void* idx, const void* Z, void* R, void* partial, int64_t E, void* stream,
+                        int kind = 0, double p0 = 0, double p1 = 0) {
+  if (kind < 0 || kind > RK_TOLERANT) return PPLIE_EBADARG;
   if (E <= 0) return E == 0 ? PPLIE_OK : PPLIE_EBADARG;
   if (!nodes || !idx || !Z || !partial || !aligned16(Z) || (R && !aligned16(R))) return PPLIE_EBADARG;
   constexpr int BLOCK = 256;
   int64_t nt = (E + BLOCK - 1) / BLOCK;
   int grid = (int)(nt < kPgoPartials ? nt : kPgoPartials);
   hipLaunchKernelGGL((pgo_residual_kernel<T, BLOCK>), dim3(grid), dim3(BLOCK), 0, reinterpret_cast<hipStream_t>(stream),
-                     (const T*)nodes, (const int64_t*)idx, (const T*)Z, (T*)R, (T*)partial, E);
+                     (const T*)nodes, (const int64_t*)idx, (const T*)Z, (T*)R, (T*)partial, E, RobustParam<T>{kind, (T)p0, (T)p1});
   return hipGetLastError() == hipSuccess ? PPLIE_OK : PPLIE_ELAUNCH;
 }
 }  // namespace pplie
+
+// the same two entries with a robust kernel (kind: PPLIE_ROBUST_* of include/pplie.h; p0 = delta, Tolerant: p0 = a, p1 = b):
+// the linearisation returns the CORRECTED residuals and blocks sqrt(rho'(|r|^2)) (r, J) of corrector.py:91-96, the residual
+// entry the partial sums of rho(|r_e|^2)
+extern "C" int pplie_pgo_linearize_robust_f32(const void* nodes, const void* idx, const void* Z, void* R, void* J, int64_t E, int kind,
+                                              double p0, double p1, void* stream) {
+  return pplie::pgo_linearize<float>(nodes, idx, Z, R, J, E, stream, kind, p0, p1);
+}
+extern "C" int pplie_pgo_linearize_robust_f64(const void* nodes, const void* idx, const void* Z, void* R, void* J, int64_t E, int kind,
+                                              double p0, double p1, void* stream) {
+  return pplie::pgo_linearize<double>(nodes, idx, Z, R, J, E, stream, kind, p0, p1);
+}
+extern "C" int pplie_pgo_residual_robust_f32(const void* nodes, const void* idx, const void* Z, void* R, void* partial, int64_t E, int kind,
+                                             double p0, double p1, void* stream) {
+  return pplie::pgo_residual_launch<float>(nodes, idx, Z, R, partial, E, stream, kind, p0, p1);
+}
+extern "C" int pplie_pgo_residual_robust_f64(const void* nodes, const void* idx, const void* Z, void* R, void* partial, int64_t E, int kind,
+                                             double p0, double p1, void* stream) {
+  return pplie::pgo_residual_launch<double>(nodes, idx, Z, R, partial, E, stream, kind, p0, p1);
+}
 
 extern "C" int pplie_pgo_linearize_f32(const void* nodes, const void* idx, const void* Z, void* R, void* J, int64_t E, void* stream) {
   return pplie::pgo_linearize<float>(nodes, idx, Z, R, J, E, stream);

@@ -817,6 +817,7 @@ class LprLinearization:
 
 
 _PGO_SIG = [ctypes.c_void_p] * 5 + [ctypes.c_int64, ctypes.c_void_p]
+_PGO_ROBUST_SIG = [ctypes.c_void_p] * 5 + [ctypes.c_int64, ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_void_p]
 _PGO_PARTIALS = 1024      # PPLIE_PGO_PARTIALS
 
 
@@ -897,26 +898,38 @@ class PgoProgram:
         return P is self.P and all(_unchanged(old, new, ver) and old.data_ptr() == ptr
                                    for (old, ptr, ver), new in zip(self.sources, (idx0, idx1, Z)))
 
-    def linearize(self):
+    def linearize(self, robust=None):
+        """residuals [E, 6] and blocks [E, 2, 6, 6]; with ``robust`` = (kind, p0, p1) of a built-in kernel (optim/kernel.py
+        robust_code) they come out already corrected -- sqrt(rho'(|r_e|^2)) applied to r_e and J_e in the kernel's registers"""
         nodes = torch.Tensor.as_subclass(self.P, torch.Tensor).detach()     # (plain: no __torch_function__ round trips below)
         assert nodes.is_contiguous()
         R = torch.empty((self.E, 6), dtype=nodes.dtype, device=nodes.device)
         J = torch.empty((self.E, 2, 6, 6), dtype=nodes.dtype, device=nodes.device)
-        fn = _C.library().symbol("pplie_pgo_linearize" + _blocks._suffix(nodes), _PGO_SIG)
         with _C._on_device(nodes.device):
-            code = fn(nodes.data_ptr(), self.idx.data_ptr(), self.Z.data_ptr(), R.data_ptr(), J.data_ptr(), self.E,
-                      _C.stream_ptr(nodes.device))
+            if robust is None:
+                fn = _C.library().symbol("pplie_pgo_linearize" + _blocks._suffix(nodes), _PGO_SIG)
+                code = fn(nodes.data_ptr(), self.idx.data_ptr(), self.Z.data_ptr(), R.data_ptr(), J.data_ptr(), self.E,
+                          _C.stream_ptr(nodes.device))
+            else:
+                fn = _C.library().symbol("pplie_pgo_linearize_robust" + _blocks._suffix(nodes), _PGO_ROBUST_SIG)
+                code = fn(nodes.data_ptr(), self.idx.data_ptr(), self.Z.data_ptr(), R.data_ptr(), J.data_ptr(), self.E,
+                          robust[0], robust[1], robust[2], _C.stream_ptr(nodes.device))
         _C.check(code, "pplie_pgo_linearize")
         return R, J
 
-    def loss(self, group=None):
-        """sum |r|^2 at the current parameter values (the Trivial-kernel loss of optimizer.py:118-125)."""
+    def loss(self, group=None, robust=None):
+        """sum_e rho(|r_e|^2) at the current parameter values (optimizer.py:118-125; rho = identity without ``robust``)."""
         nodes = torch.Tensor.as_subclass(self.P, torch.Tensor).detach()     # (plain: no __torch_function__ round trips below)
         part = torch.zeros(_PGO_PARTIALS, dtype=nodes.dtype, device=nodes.device)
-        fn = _C.library().symbol("pplie_pgo_residual" + _blocks._suffix(nodes), _PGO_SIG)
         with _C._on_device(nodes.device):
-            code = fn(nodes.data_ptr(), self.idx.data_ptr(), self.Z.data_ptr(), None, part.data_ptr(), self.E,
-                      _C.stream_ptr(nodes.device))
+            if robust is None:
+                fn = _C.library().symbol("pplie_pgo_residual" + _blocks._suffix(nodes), _PGO_SIG)
+                code = fn(nodes.data_ptr(), self.idx.data_ptr(), self.Z.data_ptr(), None, part.data_ptr(), self.E,
+                          _C.stream_ptr(nodes.device))
+            else:
+                fn = _C.library().symbol("pplie_pgo_residual_robust" + _blocks._suffix(nodes), _PGO_ROBUST_SIG)
+                code = fn(nodes.data_ptr(), self.idx.data_ptr(), self.Z.data_ptr(), None, part.data_ptr(), self.E,
+                          robust[0], robust[1], robust[2], _C.stream_ptr(nodes.device))
         _C.check(code, "pplie_pgo_residual")
         loss = part.sum()
         if group is not None:
@@ -1096,9 +1109,16 @@ def _same_input(a, b):
 
 def _pgo_linearization(opt, prog, weight, P, trivial):
     from . import posegraph as _pg
-    r, J = prog.linearize()
-    lin = _pg.build_graph_linearization(opt, weight, r, J, prog.idx, P, 7, 6)
+    from .corrector import FastTriggs, Triggs
+    from .kernel import robust_code
+    from .optimizer import Trivial
+    # a built-in robust kernel rides inside the linearisation kernel (csrc/robust.h): no corrector pass, no autograd graph
+    c = opt.corrector[0]
+    robust = robust_code(c.kernel) if (not trivial and type(c) in (FastTriggs, Triggs) and opt.group is None) else None
+    r, J = prog.linearize(robust)
+    lin = _pg.build_graph_linearization(opt, weight, r, J, prog.idx, P, 7, 6, corrector=Trivial() if robust is not None else None)
     lin.kind = "fused:pgo"
+    lin.robust = robust
     # r = Log(Z^-1 n_i^-1 n_j): d r / d n_i = -d r / d n_j (csrc/pgo_fused.hip), and a corrector scales both blocks of an edge alike
     lin.antisym = True
 
@@ -1117,6 +1137,9 @@ def _pgo_linearization(opt, prog, weight, P, trivial):
             and bool((Jr - lin.J).abs().max() <= rtol * Jr.abs().max().clamp_min(1e-30))
     lin.verify = verify
     lin.reference_kind = "graph"
+    loss_code = None if trivial else robust_code(opt.model.kernel[0]) if len(opt.model.kernel) == 1 else None
+    if not trivial and loss_code is not None:
+        lin.fast_loss = lambda: prog.loss(opt.group, loss_code)          # sum_e rho(|r_e|^2) in the residual kernel
     if trivial:
         lin.fast_loss = lambda: prog.loss(opt.group)
         if opt.group is None and lin._hip():

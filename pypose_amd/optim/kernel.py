@@ -3,11 +3,43 @@
 Every kernel is a ``RobustKernel``: the scale parameter is validated once in the base class and ``forward`` checks the
 argument's sign before handing it to the subclass's ``rho``.  The correctors differentiate ``rho`` by autograd
 (optim/corrector.py), so each ``rho`` must have a finite derivative wherever it can be evaluated.
+
+On the GPU with no gradient being recorded, ``forward`` is ONE element-wise HIP kernel (``pplie_robust_rho``, csrc/robust.hip)
+-- the torch formulas below are 3-6 launches each, Huber's two boolean-mask writes a host synchronisation -- and
+``robust_code`` hands the linearisation kernels the (kind, p0, p1) triple of csrc/robust.h (include/pplie.h PPLIE_ROBUST_*).
 """
+import ctypes
 import math
 
 import torch
 from torch import nn
+
+from .. import _C
+
+_RHO_SIG = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_void_p]
+
+
+def robust_code(kernel):
+    """(kind, p0, p1) of a built-in kernel for the HIP kernels, None for anything else (subclasses and user kernels keep the
+    torch / autograd route: their ``rho`` may differ)"""
+    return getattr(kernel, "_code", lambda: None)() if type(kernel) in _BUILTIN else None
+
+
+def _fused_rho(kernel, x):
+    """rho(x) by pplie_robust_rho, or None if this call is not a plain GPU evaluation"""
+    code = robust_code(kernel)
+    if code is None or not isinstance(x, torch.Tensor) or not x.is_cuda or _C._test_backend is not None \
+            or x.dtype not in (torch.float32, torch.float64) or (torch.is_grad_enabled() and x.requires_grad) \
+            or torch._C._are_functorch_transforms_active():
+        return None
+    xc = torch.Tensor.as_subclass(x, torch.Tensor).contiguous()
+    out = torch.empty_like(xc)
+    if xc.numel():
+        fn = _C.library().symbol("pplie_robust_rho" + ("_f32" if xc.dtype == torch.float32 else "_f64"), _RHO_SIG)
+        with _C._on_device(xc.device):
+            rc = fn(xc.data_ptr(), out.data_ptr(), xc.numel(), code[0], code[1], code[2], _C.stream_ptr(xc.device))
+        _C.check(rc, "pplie_robust_rho")
+    return out
 
 
 class RobustKernel(nn.Module):
@@ -23,6 +55,9 @@ class RobustKernel(nn.Module):
         return delta > 0
 
     def forward(self, input):
+        out = _fused_rho(self, input)          # (x = |r|^2 >= 0 by construction on this route's callers; the assert below
+        if out is not None:                    #  costs a device round trip per evaluation)
+            return out
         assert torch.all(input >= 0), 'input has to be non-negative.'
         return self.rho(input)
 
@@ -33,19 +68,24 @@ class RobustKernel(nn.Module):
 class Huber(RobustKernel):
     """x inside sqrt(x) < delta, the tangent line in sqrt(x) outside: 2 delta sqrt(x) - delta^2 (kernel.py:37-55)."""
 
+    def _code(self):
+        return (1, float(self.delta), 0.0)
+
     def rho(self, x):
-        root = x.sqrt()
-        inside = root < self.delta
-        # masked writes, not torch.where: the outer branch has an infinite slope at x = 0, and where() would feed
-        # 0 * inf = NaN into rho'(0) when the correctors differentiate through it
+        inside = x.detach().sqrt() < self.delta
+        # masked writes, not torch.where, and the root taken of the OUTSIDE elements only: the outer branch has an infinite slope
+        # at x = 0, and a root over all of x would feed 0 * inf = NaN into rho'(0) when the correctors differentiate through it
         out = torch.zeros_like(x)
         out[inside] = x[inside]
-        out[~inside] = 2 * self.delta * root[~inside] - self.delta2
+        out[~inside] = 2 * self.delta * x[~inside].sqrt() - self.delta2
         return out
 
 
 class PseudoHuber(RobustKernel):
     """2 delta^2 (sqrt(1 + x / delta^2) - 1) (kernel.py:83-95)."""
+
+    def _code(self):
+        return (2, float(self.delta), 0.0)
 
     def rho(self, x):
         return 2 * self.delta2 * ((x / self.delta2 + 1).sqrt() - 1)
@@ -54,12 +94,18 @@ class PseudoHuber(RobustKernel):
 class Cauchy(RobustKernel):
     """delta^2 log(1 + x / delta^2) (kernel.py:123-135)."""
 
+    def _code(self):
+        return (3, float(self.delta), 0.0)
+
     def rho(self, x):
         return self.delta2 * (x / self.delta2 + 1).log()
 
 
 class SoftLOne(RobustKernel):
     """2 (delta sqrt(x + 1 / delta^2) - 1) (kernel.py:163-176)."""
+
+    def _code(self):
+        return (4, float(self.delta), 0.0)
 
     def rho(self, x):
         return 2 * (self.delta * (1 / self.delta2 + x).sqrt() - 1)
@@ -72,6 +118,9 @@ class Arctan(RobustKernel):
     def valid_scale(delta):
         return True
 
+    def _code(self):
+        return (5, float(self.delta), 0.0)
+
     def rho(self, x):
         return self.delta2 * (x / self.delta2).arctan()
 
@@ -83,6 +132,9 @@ class Scale(RobustKernel):
     @staticmethod
     def valid_scale(delta):
         return 0 < delta <= 1
+
+    def _code(self):
+        return (6, float(self.delta), 0.0)
 
     def forward(self, input):
         return self.delta * input
@@ -98,5 +150,11 @@ class Tolerant(RobustKernel):
         self.a, self.b = a, b
         self.at_zero = b * math.log(1 + math.exp(-a / b))
 
+    def _code(self):
+        return (7, float(self.a), float(self.b))
+
     def rho(self, x):
         return self.b * (1 + ((x - self.a) / self.b).exp()).log() - self.at_zero
+
+
+_BUILTIN = (Huber, PseudoHuber, Cauchy, SoftLOne, Arctan, Scale, Tolerant)

@@ -624,7 +624,10 @@ def try_multigraph_linearization(opt, pg, input, target, weight, R, params, rec,
             cols.append(Jcat[:, :, off:off + m])
             off += src.shape[-1]
         corrector = opt.corrector[0] if len(opt.corrector) == 1 else opt.corrector[i]
-        Rc, Jc = corrector(R=r.detach().reshape(E, dr), J=torch.cat(cols, -1))   # row-local on the concatenated tangent blocks
+        from .posegraph import Trivial_type, _fused_rows
+        rr, Jc0 = r.detach().reshape(E, dr), torch.cat(cols, -1)             # row-local on the concatenated tangent blocks
+        fused = None if isinstance(corrector, Trivial_type()) else _fused_rows(corrector, rr, Jc0)   # built-in kernel: one launch
+        Rc, Jc = fused if fused is not None else corrector(R=rr, J=Jc0)
         Rp = torch.zeros((E, dr_max), dtype=dt, device=dev)
         Rp[:, :dr] = Rc
         Rs.append(Rp)

@@ -161,6 +161,7 @@ class BlockLinearization:
         Rs, Js, off = [], [], 0
         for i, r in enumerate(R):
             c = opt.corrector[0] if len(opt.corrector) == 1 else opt.corrector[i]
+            # (FastTriggs / Triggs with a built-in kernel: one HIP launch, closed-form rho' -- optim/corrector.py)
             ri, ji = c(R=r.detach().reshape(n, dims[i]), J=Jb[:, off:off + dims[i], :])
             Rs.append(ri)
             Js.append(ji)
@@ -585,7 +586,8 @@ class LevenbergMarquardt(_Optimizer):
         from .pgograph import PgoGraphStep
         from .posegraph import PCG, PERSIST_NODES, FusedPCG
         d = self.__dict__
-        ok = (defer and lin.kind == "fused:pgo" and hasattr(lin, 'fast_loss') and target is None and len(self.param_groups) == 1
+        ok = (defer and lin.kind == "fused:pgo" and hasattr(lin, 'fast_loss') and getattr(lin, 'robust', None) is None
+              and target is None and len(self.param_groups) == 1
               and isinstance(self.solver, PCG) and getattr(self.solver, 'fused', True) and lin.N <= PERSIST_NODES
               and FusedPCG.persist and FusedPCG.two_launch and getattr(self, 'graph_step', True)
               and not isinstance(weight, (tuple, list)))

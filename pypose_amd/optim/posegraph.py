@@ -1057,6 +1057,20 @@ def _gather_edge_shards(group, tensors, limit):
     return out
 
 
+def Trivial_type():
+    from .optimizer import Trivial
+    return Trivial
+
+
+def _fused_rows(corrector, r, J):
+    """FastTriggs / Triggs with a built-in kernel: sqrt(rho') is one scalar per edge, so the blocks are scaled where they lie
+    (pplie_robust_scale_rows, csrc/robust.hip); None -> the corrector's own formulation"""
+    from .corrector import FastTriggs, Triggs, fused_scale_rows
+    if type(corrector) not in (FastTriggs, Triggs) or not J.is_contiguous() or J.requires_grad:
+        return None
+    return fused_scale_rows(corrector.kernel, r, J, inplace=True)
+
+
 def _edge_terms(opt, corrector, weight, r, J, gauss_newton=False):
     """Corrector and weight of ONE residual applied to its per-edge residuals r [E,dr] and blocks J [E,K,dr,m]:
     (Rc, Jc, Wb or None).  Gauss-Newton weights both sides of its rectangular system with W (optimizer.py:318-322),
@@ -1065,6 +1079,8 @@ def _edge_terms(opt, corrector, weight, r, J, gauss_newton=False):
     from .optimizer import Trivial
     if isinstance(corrector, Trivial):          # no kernel: skip the [E, dr, K*m] round trip (two copies of J)
         Rc, Jc = r, J
+    elif (fused := _fused_rows(corrector, r, J)) is not None:
+        Rc, Jc = fused                          # built-in kernel: one launch, J scaled in place in its own layout
     else:
         Rc, Jc = corrector(R=r, J=J.permute(0, 2, 1, 3).reshape(E, dr, K * m))       # row-local: acts on [E, dr, K*m]
         Jc = Jc.reshape(E, dr, K, m).permute(0, 2, 1, 3)
@@ -1079,10 +1095,11 @@ def _edge_terms(opt, corrector, weight, r, J, gauss_newton=False):
     return Rc, Jc, Wb
 
 
-def build_graph_linearization(opt, weight, r, J, idx, param, wfull, m, gauss_newton=False):
-    """Single-residual entry (also used by the fused pose-graph program): r [E,dr], J [E,K,dr,m] -> GraphLinearization."""
+def build_graph_linearization(opt, weight, r, J, idx, param, wfull, m, gauss_newton=False, corrector=None):
+    """Single-residual entry (also used by the fused pose-graph program): r [E,dr], J [E,K,dr,m] -> GraphLinearization.
+    ``corrector``: overrides opt.corrector[0] (the fused program passes Trivial when its kernel already applied the weighting)."""
     w = weight[0] if isinstance(weight, (tuple, list)) else weight
-    Rc, Jc, Wb = _edge_terms(opt, opt.corrector[0], w, r, J, gauss_newton)
+    Rc, Jc, Wb = _edge_terms(opt, opt.corrector[0] if corrector is None else corrector, w, r, J, gauss_newton)
     return _finish_graph_linearization(opt, Rc, Jc, idx, Wb, param, wfull, m)
 
 

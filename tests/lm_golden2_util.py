@@ -55,12 +55,13 @@ def robust_case(G, name, device="cpu"):
     return net, pp.optim.LM(net, strategy=pp.optim.strategy.Adaptive(damping=1e-6), **kw), inp, 5
 
 
-def compare2(rec, G, prefix, floor=1e-16, rtol=1e-6, damping=True):
-    """loss sequence equal to the reference's while above the noise floor; damping / reject sequence over that range"""
+def compare2(rec, G, prefix, floor=1e-16, rtol=1e-6, damping=True, atol=0.0):
+    """loss sequence equal to the reference's while above the noise floor; damping / reject sequence over that range.
+    ``atol``: absolute rounding noise of the loss itself (kernels written as a difference of nearly equal numbers)"""
     ref = G[prefix + "/loss"]
     for k, (a, b) in enumerate(zip(rec["loss"], ref)):
         if b > floor:
-            assert abs(a - b) <= rtol * b, (prefix, k, a, b, rec["loss"], ref)
+            assert abs(a - b) <= rtol * b + atol, (prefix, k, a, b, rec["loss"], ref)
             prev = ref[k - 1] if k else None
             if damping and (prev is None or abs(prev - b) > 1e-7 * b):
                 assert np.isclose(rec["damping"][k], G[prefix + "/damping"][k], rtol=1e-12), (prefix, k, rec["damping"], G[prefix + "/damping"])

@@ -92,5 +92,7 @@ def test_robust_kernels_correctors_and_lstsq_on_device(name, structured):
     net, opt, inp, n = robust_case(G, name, DEV)
     opt.structured = structured
     rec = run_steps(opt, (inp,), {}, n)
-    compare2(rec, G, f"robust/{name}", floor=1e-18)
+    # SoftLOne / PseudoHuber are 2 (d sqrt(1/d^2 + x) - 1)-shaped: at a loss of 1e-10 the reference's own fp64 value carries ~1e-16
+    # of cancellation noise per row (2e-6 of the loss), and so does anything that follows the same formula in another op order
+    compare2(rec, G, f"robust/{name}", floor=1e-18, atol=2e-15 if name in ("softlone", "pseudohuber") else 0.0)
     np.testing.assert_allclose(net.pose.detach().tensor().cpu().numpy(), G[f"robust/{name}/final"], atol=1e-8)
