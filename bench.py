@@ -762,10 +762,11 @@ def imu_sharded_rate(dev, rank, world, B=4096, F=1024):
             "ms_max_over_ranks": {"with_covariance": ms_cov, "states_only": ms_plain}}
 
 
-def pgo_sharded_lm_rate(dev, rank, world, nodes=100_000, edges=400_000, steps=3, reps=3, shard="edges", exchange="rccl"):
+def pgo_sharded_lm_rate(dev, rank, world, nodes=100_000, edges=400_000, steps=3, reps=3, shard=None, exchange=None):
     """BASELINE configs[3]: pose-graph LM, 100k SE3 nodes / 400k relative-pose edges, sharded over the ranks --
     `LM(group=...)`, SURVEY.md section 8(e).  Same generator, solver and strategy as `pgo_lm_rate`.  Collective: every rank
-    calls this; rank 0's figures are reported.  Not part of `value`."""
+    calls this; rank 0's figures are reported.  Not part of `value`.  shard / exchange None = the library's own choice
+    (optim/posegraph.py resolve_shard_mode: node rows sharded with in-kernel peer stores for a graph of this size on GPUs)."""
     import torch
     import torch.distributed as dist
     import pypose_amd as pp
@@ -795,13 +796,24 @@ def pgo_sharded_lm_rate(dev, rank, world, nodes=100_000, edges=400_000, steps=3,
         if rep:
             times.append((time.perf_counter() - t0) / steps)
     dt = sorted(times)[len(times) // 2]
+    seen = torch.ones(1, device=dev)
+    dist.all_reduce(seen)
+    shard_eff, exch_eff = getattr(opt, "_shard_eff", shard), getattr(opt, "_exchange_eff", exchange)
+    ns = getattr(opt, "_node_shards", {}).get("shard", (None, None))[1]
+    p2p_state = getattr(ns, "p2p", None)
+    its_mean = sum(its) / max(1, len(its))
     return {"metric": "LM iters/sec, pose graph 100k nodes / 400k edges sharded over the ranks (BASELINE configs[3])",
-            "value": 1.0 / dt, "unit": "LM steps/s", "n_gpus": world, "nodes": nodes, "edges": edges,
+            "value": 1.0 / dt, "unit": "LM steps/s", "n_gpus": world, "ranks_seen": int(seen.item()), "nodes": nodes, "edges": edges,
             "edges_per_rank": int(e_mine.shape[0]), "path": opt.linearization, "losses": losses, "pcg_iterations": its, "ranks": world,
+            "requested": {"shard": shard, "exchange": exchange}, "effective": {"shard": shard_eff, "exchange": exch_eff},
             "mode": getattr(opt, "_last_shard_mode", "replicated" if getattr(opt, "_last_replicated", False) else "edge-sharded"),
+            "p2p_tables": (None if p2p_state is None else {"ok": bool(p2p_state.get("ok")), "epochs": int(p2p_state.get("epoch", 0)),
+                                                             "error": repr(p2p_state.get("error")) if p2p_state.get("error") else None}),
+            "us_per_pcg_iteration_incl_step_overheads": dt * 1e6 / max(1.0, its_mean),
             "exchange": ("in-kernel peer stores over xGMI (hipIpc-mapped tables, csrc/pcg_persist.hip): no collective per PCG iteration"
-                         if exchange == "p2p" and shard == "nodes" else f"{dist.get_backend()} collectives (RCCL over xGMI on GPUs)"),
-            "scales": ("no: every rank runs the whole solve (the blocks are all-gathered once per LM step)" if shard == "edges" else
+                         if exch_eff == "p2p" and shard_eff == "nodes" and (p2p_state or {}).get("ok", False)
+                         else f"{dist.get_backend()} collectives (RCCL over xGMI on GPUs)"),
+            "scales": ("no: every rank runs the whole solve (the blocks are all-gathered once per LM step)" if shard_eff == "edges" else
                        "the solve is sharded by node rows"),
             "repetitions_ms_per_step": [round(t * 1e3, 3) for t in times]}
 
@@ -935,6 +947,10 @@ def main():
         import torch.distributed as dist
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = t.item()
+    seen = torch.ones(1, dtype=torch.float64, device=dev)        # every rank that took part in the timed region adds one
+    if launched:
+        dist.all_reduce(seen)
+    ranks_seen = int(seen.item())
 
     out = None
     if rank == 0:
@@ -955,6 +971,7 @@ def main():
             "unit": "SE3 Exp+Log pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic" if not standin else "DRY RUN on the CPU stand-in: not a measurement",
+            "ranks_seen": ranks_seen,
             "config": {"workload": "se3_explog_b10m (BASELINE configs[1]: batched SE3 Exp then Log, fp32, forward)",
                        "rows_per_gpu": B, "parallelism": f"rows sharded x{world}, no collective",
                        "ranks": world, "collective_backend": (a.backend if launched else None),
@@ -1028,12 +1045,14 @@ def main():
         legs = (("lm_invnet_sharded", lambda: invnet_lm_rate(dev, B=2000 if small else 1_000_000, reps=2 if small else 40,
                                                              group=dist.group.WORLD)),
                 ("imu_sharded", lambda: imu_sharded_rate(dev, rank, world, *((8, 64) if small else (4096, 1024)))),
+                # the library's default for this graph (node rows sharded, peer stores where they apply), then the two explicit
+                # alternatives: the replicated solve (the fallback) and node shards over RCCL collectives
                 ("lm_pgo_sharded", lambda: pgo_sharded_lm_rate(dev, rank, world, *((80, 200) if small else (100_000, 400_000)),
                                                                reps=1 if small else 3)),
+                ("lm_pgo_replicated", lambda: pgo_sharded_lm_rate(dev, rank, world, *((80, 200) if small else (100_000, 400_000)),
+                                                                  reps=1 if small else 2, shard="edges", exchange="rccl")),
                 ("lm_pgo_node_sharded", lambda: pgo_sharded_lm_rate(dev, rank, world, *((80, 200) if small else (100_000, 400_000)),
-                                                                    reps=1 if small else 2, shard="nodes")),
-                ("lm_pgo_node_sharded_p2p", lambda: pgo_sharded_lm_rate(dev, rank, world, *((80, 200) if small else (100_000, 400_000)),
-                                                                        reps=1 if small else 2, shard="nodes", exchange="p2p")))
+                                                                    reps=1 if small else 2, shard="nodes", exchange="rccl")))
         for key, fn in legs:
             try:
                 res = fn()

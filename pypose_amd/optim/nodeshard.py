@@ -125,9 +125,25 @@ class NodeShard:
         """this rank's exchange tables + the peers' mapped ones (collective, once per edge list and dtype)"""
         if self.p2p is not None and self.p2p['dtype'] == dtype:
             return self.p2p
-        rk = P2PRank(self.N, self.m, dtype, device)
-        ptag, rpart = p2p_exchange_tables(rk, self.group)
-        self.p2p = dict(dtype=dtype, rk=rk, ptag=ptag, rpart=rpart, epoch=0, ok=True)
+        import torch.distributed as dist
+        rk, ptag, rpart, err = None, None, None, None
+        try:
+            rk = P2PRank(self.N, self.m, dtype, device)
+        except Exception as e:                          # (allocation failure on this rank only)
+            err = e
+        # the table exchange is a sequence of collectives: whether to enter it is agreed first, and so is its outcome -- a rank
+        # that failed alone would leave the others waiting inside a collective it never joins
+        bad = torch.tensor([0 if err is None else 1], dtype=torch.int32, device=device)
+        dist.all_reduce(bad, op=dist.ReduceOp.MAX, group=self.group)
+        if int(bad) == 0:
+            try:
+                ptag, rpart = p2p_exchange_tables(rk, self.group)
+            except Exception as e:
+                err = e
+            bad = torch.tensor([0 if err is None else 1], dtype=torch.int32, device=device)
+            dist.all_reduce(bad, op=dist.ReduceOp.MAX, group=self.group)
+        ok = int(bad) == 0
+        self.p2p = dict(dtype=dtype, rk=rk, ptag=ptag, rpart=rpart, epoch=0, ok=ok, error=err)
         return self.p2p
 
 
@@ -142,16 +158,21 @@ def p2p_exchange_tables(rk, group):
     mine = [reduce_tensor(rk.ptag), reduce_tensor(rk.rpart)]
     everyone = [None] * world
     dist.all_gather_object(everyone, mine, group=group)
-    ptag, rpart = [], []
+    ptag, rpart, err = [], [], None
     for k, handles in enumerate(everyone):
         if k == rank:
             ptag.append(rk.ptag)
             rpart.append(rk.rpart)
         else:
-            (f0, a0), (f1, a1) = handles
-            ptag.append(f0(*a0))                                         # the peer's table, addressable from this device
-            rpart.append(f1(*a1))
+            try:
+                (f0, a0), (f1, a1) = handles
+                ptag.append(f0(*a0))                                     # the peer's table, addressable from this device
+                rpart.append(f1(*a1))
+            except Exception as e:                                       # (peer memory not mappable from this process)
+                err = err or e
     dist.barrier(group=group)                                            # every table exists and is mapped everywhere
+    if err is not None:
+        raise err
     return ptag, rpart
 
 
@@ -289,35 +310,51 @@ class NodeShardedSystem:
         sfx = "_f32" if dt == torch.float32 else "_f64"
         z = lambda *shape: torch.zeros(shape, dtype=dt, device=dev)
         pp_ = sh.p2p_setup(dt, dev)
+        if not pp_['ok']:                               # (agreed by all ranks inside p2p_setup)
+            raise _pg.SolveFailed(f"p2p exchange tables could not be set up on every rank ({pp_.get('error')}); using RCCL collectives")
         w = self.__dict__.get('_wp')
         if w is None or w['key'] != (n, chunk, dt):
             w = self._wp = dict(key=(n, chunk, dt), D=z(n, m, m), Binv=z(n, m, m), shift=z(n, m), x=z(chunk, m), r=z(n, m), z=z(n, m),
                                 p=z(n, m), scal=z(_pg._PCG_SCAL_ELEMS), full=z(sh.world * chunk, m))
-        pp_['epoch'] += 1
-        with _C._on_device(dev):
-            _C.check(_C.library().symbol("pplie_pcg_prepare" + sfx, _pg._PREP_SIG)(
-                self.B.data_ptr(), self.g.data_ptr(), w['D'].data_ptr(), w['Binv'].data_ptr(), w['shift'].data_ptr(), w['x'].data_ptr(),
-                w['r'].data_ptr(), w['z'].data_ptr(), w['p'].data_ptr(), w['scal'].data_ptr(), float(s), float(dmin), float(dmax), n, m,
-                _C.stream_ptr(dev)), "pplie_pcg_prepare")
-            code = persist_p2p_launch(pp_['rk'], [t.data_ptr() for t in pp_['ptag']], [t.data_ptr() for t in pp_['rpart']], sh.ptr,
-                                      sh.other_global, self.HB, w['D'], w['Binv'], w['x'][:n], w['r'], w['z'], tol, maxiter,
-                                      _pg.PERSIST_GRID, sh.a, sh.N, sh.world, sh.rank, pp_['epoch'], m)
-        _C.check(code, "pplie_pcg_persist_p2p")
+        pp_['epoch'] += 1                               # (every rank makes this call for every solve: the epochs stay in step)
+        local_err = None
+        try:
+            with _C._on_device(dev):
+                _C.check(_C.library().symbol("pplie_pcg_prepare" + sfx, _pg._PREP_SIG)(
+                    self.B.data_ptr(), self.g.data_ptr(), w['D'].data_ptr(), w['Binv'].data_ptr(), w['shift'].data_ptr(), w['x'].data_ptr(),
+                    w['r'].data_ptr(), w['z'].data_ptr(), w['p'].data_ptr(), w['scal'].data_ptr(), float(s), float(dmin), float(dmax), n, m,
+                    _C.stream_ptr(dev)), "pplie_pcg_prepare")
+                code = persist_p2p_launch(pp_['rk'], [t.data_ptr() for t in pp_['ptag']], [t.data_ptr() for t in pp_['rpart']], sh.ptr,
+                                          sh.other_global, self.HB, w['D'], w['Binv'], w['x'][:n], w['r'], w['z'], tol, maxiter,
+                                          _pg.PERSIST_GRID, sh.a, sh.N, sh.world, sh.rank, pp_['epoch'], m)
+            _C.check(code, "pplie_pcg_persist_p2p")
+        except Exception as e:                          # this rank could not launch: the peers will time out at the exchange
+            local_err = e
+        # The verdict of the solve is COLLECTIVE: a spin time-out (flag 3) is local to the rank that hit it -- a peer may have finished
+        # its last iteration normally -- and the next solve must take the same route (peer stores or RCCL collectives) on every
+        # rank, or the ranks wait for each other in different collectives for ever.  MAX over {flag, 4 if the launch itself failed}.
+        verdict = pp_['rk'].info[3:4].clone() if local_err is None else torch.full((1,), 4.0, dtype=dt, device=dev)
+        dist.all_reduce(verdict, op=dist.ReduceOp.MAX, group=sh.group)
         dist.all_gather_into_tensor(w['full'], w['x'], group=sh.group)
         its, rr, bn2, flag = pp_['rk'].info.tolist()
-        if flag == 3.0:
-            pp_['ok'] = False
-            raise _pg.SolveFailed('p2p persistent PCG: a peer never arrived (kernels not co-resident / peer memory not visible)')
+        worst = float(verdict)
+        if worst >= 3.0:
+            pp_['ok'] = False                           # on every rank: from here on the RCCL iteration
+            raise _pg.SolveFailed('p2p persistent PCG: ' + ('a rank could not launch its kernel' if worst >= 4.0 else
+                                  'a peer never arrived at an exchange (kernels not co-resident / peer memory not visible)')
+                                  + '; every rank falls back to RCCL collectives') from local_err
         assert flag != 2.0 and rr == rr, 'Linear solve produced NaN (matrix may not be positive-definite)'
         full = w['full'].view(sh.world, chunk, m)
         return torch.cat([full[k, :(_bounds(sh.N, sh.world, k)[2] - _bounds(sh.N, sh.world, k)[1])] for k in range(sh.world)], 0), int(its)
 
     def p2p_applicable(self):
         """group-uniform facts only (every rank must take the same path): device backend, HIP shapes, rows per rank within what
-        one persistent launch holds"""
+        one persistent launch holds, and the `ok` flag -- which is only ever cleared by the collective verdicts of p2p_setup /
+        _solve_p2p, i.e. on all ranks at once"""
         sh, m = self.sh, self.lin.m
         per_wg = 16 * (64 // m)
-        return (getattr(self.lin.opt, 'exchange', 'rccl') == 'p2p' and self.lin._hip() and m in (3, 6, 7) and self.group_is_device()
+        return (getattr(self.lin.opt, '_exchange_eff', getattr(self.lin.opt, 'exchange', None) or 'rccl') == 'p2p' and self.lin._hip()
+                and m in (3, 6, 7) and self.group_is_device()
                 and sh.world <= 8 and sh.chunk <= 256 * per_wg and sh.chunk > 0 and sh.N % 1 == 0
                 and (sh.p2p is None or sh.p2p.get('ok', True)))
 
@@ -326,7 +363,14 @@ class NodeShardedSystem:
         sh, m = self.sh, self.lin.m
         n = sh.n_own
         if self.p2p_applicable() and (sh.world - 1) * sh.chunk < sh.N:       # (every rank owns at least one row)
-            return self._solve_p2p(s, dmin, dmax, tol, maxiter)
+            from . import posegraph as _pg
+            try:
+                return self._solve_p2p(s, dmin, dmax, tol, maxiter)
+            except _pg.SolveFailed as e:
+                # the verdict behind this exception was agreed by all ranks (see _solve_p2p): every rank is here, and every rank
+                # now runs the same RCCL iteration for this solve and the following ones
+                import warnings
+                warnings.warn(f"pypose_amd: {e}")
         # the HIP and the torch formulation issue different collective sequences: the choice is made from facts every rank
         # agrees on (backend, shapes, every rank owning at least one row), never from this rank's own row count
         if self._hip() and self.group_is_device() and (sh.world - 1) * sh.chunk < sh.N:

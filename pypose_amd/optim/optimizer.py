@@ -346,8 +346,8 @@ class LevenbergMarquardt(_Optimizer):
     """
 
     def __init__(self, model, solver=None, strategy=None, kernel=None, corrector=None,
-                 weight=None, reject=16, min=1e-6, max=1e32, vectorize=True, sparse=False, *, group=None, static=False, shard="edges",
-                 exchange="rccl"):
+                 weight=None, reject=16, min=1e-6, max=1e32, vectorize=True, sparse=False, *, group=None, static=False, shard=None,
+                 exchange=None):
         assert min > 0, ValueError("min value has to be positive: {}".format(min))
         assert max > 0, ValueError("max value has to be positive: {}".format(max))
         self.strategy = TrustRegion() if strategy is None else strategy
@@ -368,14 +368,17 @@ class LevenbergMarquardt(_Optimizer):
         # normal-equation pieces are all-reduced so that every rank takes the same decisions.
         self.group = group
         # shard="nodes" (pose graphs, with group=): the linear solve is sharded by node rows -- each rank assembles and
-        # iterates on the rows it owns, one all-gather of p + one scalar all-reduce per PCG iteration (optim/nodeshard.py);
-        # "edges" (default): edge shards with the solve replicated / all-reduced (optim/posegraph.py)
-        assert shard in ("edges", "nodes"), ValueError("shard has to be 'edges' or 'nodes': {}".format(shard))
+        # iterates on the rows it owns (optim/nodeshard.py); "edges": edge shards with the solve replicated / all-reduced
+        # (optim/posegraph.py).  None (default) decides per graph from facts every rank shares (posegraph.resolve_shard_mode):
+        # one process per GPU over RCCL and a graph beyond what ONE GPU solves in a single persistent launch -> "nodes", the
+        # mode built to scale; smaller graphs (latency-bound, already one launch per solve) and host groups -> "edges"
+        assert shard in (None, "edges", "nodes"), ValueError("shard has to be 'edges', 'nodes' or None: {}".format(shard))
         self.shard = shard
-        # exchange="p2p" (with shard="nodes"): the node-sharded solve runs as one persistent kernel per GPU that writes its p
-        # slices and partial sums straight into the peers' memory (hipIpc-mapped, xGMI) -- no collective per PCG iteration;
-        # "rccl" (default): one all-gather + one all-reduce per iteration (optim/nodeshard.py)
-        assert exchange in ("rccl", "p2p"), ValueError("exchange has to be 'rccl' or 'p2p': {}".format(exchange))
+        # exchange="p2p" (node shards): the solve runs as one persistent kernel per GPU that writes its p slices and partial sums
+        # straight into the peers' memory (hipIpc-mapped, xGMI) -- no collective per PCG iteration; "rccl": one all-gather + one
+        # all-reduce per iteration.  None (default): "p2p" where it applies (device group, <= 8 ranks, slice fits one launch),
+        # else "rccl"; a failed peer exchange falls back to "rccl" on EVERY rank together (optim/nodeshard.py)
+        assert exchange in (None, "rccl", "p2p"), ValueError("exchange has to be 'rccl', 'p2p' or None: {}".format(exchange))
         self.exchange = exchange
         self.jackwargs = {'vectorize': vectorize}
         self.solver = Cholesky() if solver is None else solver

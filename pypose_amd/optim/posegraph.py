@@ -1103,6 +1103,23 @@ def build_graph_linearization(opt, weight, r, J, idx, param, wfull, m, gauss_new
     return _finish_graph_linearization(opt, Rc, Jc, idx, Wb, param, wfull, m)
 
 
+def resolve_shard_mode(opt, group, n_nodes, pairwise):
+    """("edges" | "nodes", "rccl" | "p2p") for one pose graph under LM(group=...): the caller's explicit choice, or -- the default --
+    a decision from group-uniform facts only (backend, world size, node count), so that every rank issues the same collectives.
+    Node rows are sharded when the ranks are GPUs (RCCL) and the graph is beyond the capacity of ONE GPU's persistent solve
+    (PERSIST_NODES: measured, 5.6 us / iteration up to there; 32 us two-launch iterations beyond): each rank's slice then fits a
+    persistent launch again.  Below that size a solve is one launch on every rank already and sharding it only adds exchanges."""
+    import torch.distributed as dist
+    shard, exchange = getattr(opt, 'shard', None), getattr(opt, 'exchange', None)
+    device_group = dist.get_backend(group) == "nccl"
+    if shard is None:
+        shard = "nodes" if (device_group and pairwise and dist.get_world_size(group) > 1 and n_nodes > PERSIST_NODES) else "edges"
+    if exchange is None:
+        exchange = "p2p" if (shard == "nodes" and device_group) else "rccl"
+    opt._shard_eff, opt._exchange_eff = shard, exchange
+    return shard, exchange
+
+
 def _finish_graph_linearization(opt, Rc, Jc, idx, Wb, param, wfull, m):
     # Edge shards (LM(group=...)).  The linear solve dominates a pose-graph step and is latency-bound when every PCG
     # iteration carries an all-reduce, so while the blocks of all shards fit on one GPU they are gathered ONCE per
@@ -1110,7 +1127,7 @@ def _finish_graph_linearization(opt, Rc, Jc, idx, Wb, param, wfull, m):
     # runs the un-sharded solve (streaming SpMV, graph-captured iterations, no collective).  Larger problems keep
     # the blocks distributed and all-reduce diag / gradient once per step and H p once per iteration.
     group = getattr(opt, 'group', None)
-    nodes = group is not None and getattr(opt, 'shard', 'edges') == 'nodes' and Jc.shape[1] == 2
+    nodes = group is not None and resolve_shard_mode(opt, group, param.shape[0], Jc.shape[1] == 2)[0] == 'nodes' and Jc.shape[1] == 2
     if group is not None and (getattr(opt, 'replicate_solve', True) or nodes):
         gathered = _gather_edge_shards(group, [Rc.contiguous(), Jc.contiguous(), idx.contiguous(), Wb], REPLICATE_LIMIT)
         if gathered is not None:
@@ -1119,7 +1136,7 @@ def _finish_graph_linearization(opt, Rc, Jc, idx, Wb, param, wfull, m):
             # shard="nodes": every rank holds the blocks of all edges (gathered once per LM step, above) but assembles
             # and solves only the node rows it owns -- optim/nodeshard.py
             lin.node_group = group if nodes else None
-            opt._last_shard_mode = "node-sharded solve" if nodes else "replicated solve"
+            opt._last_shard_mode = f"node-sharded solve ({opt._exchange_eff} exchange)" if nodes else "replicated solve"
             return lin
     if group is not None:
         opt._last_shard_mode = "edge-sharded (all-reduce per PCG iteration)"

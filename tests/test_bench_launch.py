@@ -28,18 +28,19 @@ def test_two_ranks_self_launched_dry_run():
     assert out["n_gpus"] == 2 and out["config"]["ranks"] == 2 and out["config"]["collective_backend"] == "gloo"
     assert out["config"]["launch"].startswith("self-launched")
     assert out["value"] > 0 and out["scaling"] == "weak"
-    for leg in ("lm_invnet_sharded", "imu_sharded", "lm_pgo_sharded", "lm_pgo_node_sharded"):
+    assert out["ranks_seen"] == 2
+    for leg in ("lm_invnet_sharded", "imu_sharded", "lm_pgo_sharded", "lm_pgo_replicated", "lm_pgo_node_sharded"):
         assert "error" not in out[leg], (leg, out[leg])
         assert out[leg]["n_gpus"] == 2 and out[leg]["value"] > 0
     assert out["lm_pgo_sharded"]["losses"][-1] < out["lm_pgo_sharded"]["losses"][0]
-    assert out["lm_pgo_node_sharded"]["mode"] == "node-sharded solve"
+    assert out["lm_pgo_node_sharded"]["mode"].startswith("node-sharded solve")
     assert out["lm_pgo_node_sharded"]["losses"] == pytest.approx(out["lm_pgo_sharded"]["losses"], rel=1e-4)
 
 
 def test_single_process_dry_run_has_every_config():
     out = _run(["--gpus", "1", "--steps", "2", "--warmup", "1", "--rows", "1000", "--backend", "gloo", "--standin"])
     assert out["n_gpus"] == 1 and out["config"]["launch"] == "single process"
-    for leg in ("c1", "lm_invnet", "lm_pgo", "lm_pgo_100k", "imu"):
+    for leg in ("c1", "ops_10m", "lm_invnet", "lm_pgo", "lm_pgo_100k", "imu", "imu_train"):
         assert "error" not in out[leg], (leg, out[leg])
     assert out["lm_invnet"]["roofline"]["algorithmic_bytes_per_step"] == 84 * out["lm_invnet"]["problems_per_gpu"]
     assert set(out["imu"]) >= {"states_only", "with_covariance"}

@@ -129,7 +129,7 @@ def test_node_sharded_solve_matches_reference_trajectory(world):
     out = _run("graph_nodes", world)
     G = load_lm_golden()
     for r in range(world):
-        assert out[r]["kind"] == ["graph"] * 4 and out[r]["mode"] == "node-sharded solve"
+        assert out[r]["kind"] == ["graph"] * 4 and out[r]["mode"] == "node-sharded solve (rccl exchange)"
         assert out[r]["pcg_iterations"] > 0
         np.testing.assert_allclose(out[r]["loss"][:3], G["pgo40/infos/loss"][:3], rtol=1e-7)
         np.testing.assert_allclose(out[r]["damping"][:3], G["pgo40/infos/damping"][:3], rtol=1e-12)

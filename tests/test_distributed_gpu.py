@@ -76,10 +76,54 @@ def test_node_sharded_solve_on_rccl_equals_single_process(group, fused, exchange
     opt = pp.optim.LM(model, group=group, shard="nodes", exchange=exchange, **kw)
     opt.fused = fused
     losses = [float(opt.step((edges, poses))) for _ in range(4)]
-    assert opt._last_shard_mode == "node-sharded solve" and opt.linearization == a[1]
+    assert opt._last_shard_mode.startswith("node-sharded solve") and opt.linearization == a[1]
     if exchange == "p2p":
         shard = opt._node_shards['shard'][1]
         assert shard.p2p is not None and shard.p2p['epoch'] >= 4 and shard.p2p['ok']
     for x, y in zip(a[0], losses):
         assert abs(x - y) <= 1e-7 * abs(x)
     torch.testing.assert_close(a[2][0], model.nodes.detach(), rtol=0, atol=1e-7)
+
+
+def test_p2p_failure_is_agreed_and_falls_back_to_rccl(group, monkeypatch):
+    """a peer-exchange failure seen by ONE rank must move EVERY rank to the RCCL iteration, in the same
+    solve.  A launch failure is injected into this rank's second p2p solve: the verdict all-reduce turns it into the group's
+    decision, the solve is redone over RCCL collectives (same numbers), and the following steps stay there."""
+    from pypose_amd.optim import nodeshard as NS
+    G = load_lm_golden()
+    edges, poses = T(G["pgo40/edges"], DEV), pp.SE3(T(G["pgo40/poses"], DEV))
+    kw = {"solver": pp.optim.solver.PCG(tol=1e-12, maxiter=2000), "strategy": pp.optim.strategy.TrustRegion(radius=1e4)}
+    ref = pp.optim.LM(PoseGraph(pp.SE3(T(G["pgo40/init"], DEV))), **kw)
+    want = [float(ref.step((edges, poses))) for _ in range(4)]
+    model = PoseGraph(pp.SE3(T(G["pgo40/init"], DEV)))
+    opt = pp.optim.LM(model, group=group, shard="nodes", exchange="p2p", **kw)
+    calls = {"n": 0}
+    real = NS.persist_p2p_launch
+
+    def flaky(*a, **k):
+        calls["n"] += 1
+        return -2 if calls["n"] == 2 else real(*a, **k)
+    monkeypatch.setattr(NS, "persist_p2p_launch", flaky)
+    with pytest.warns(UserWarning, match="falls back to RCCL"):
+        got = [float(opt.step((edges, poses))) for _ in range(4)]
+    shard = opt._node_shards['shard'][1]
+    assert shard.p2p['ok'] is False and calls["n"] == 2            # no p2p launch after the agreed failure
+    for x, y in zip(want, got):
+        assert abs(x - y) <= 1e-7 * abs(x)
+
+
+def test_default_shard_mode_is_decided_from_group_uniform_facts(monkeypatch):
+    from pypose_amd.optim import posegraph as PG
+
+    class Opt:
+        shard = exchange = None
+    for backend, world, n, want in (("nccl", 8, 100_000, ("nodes", "p2p")), ("nccl", 8, 10_000, ("edges", "rccl")),
+                                    ("nccl", 1, 100_000, ("edges", "rccl")), ("gloo", 8, 100_000, ("edges", "rccl"))):
+        monkeypatch.setattr(dist, "get_backend", lambda g=None, b=backend: b)
+        monkeypatch.setattr(dist, "get_world_size", lambda g=None, w=world: w)
+        assert PG.resolve_shard_mode(Opt(), object(), n, True) == want, (backend, world, n)
+    o = Opt(); o.shard, o.exchange = "nodes", "rccl"
+    assert PG.resolve_shard_mode(o, object(), 50, True) == ("nodes", "rccl")
+    o = Opt(); o.shard = "nodes"
+    monkeypatch.setattr(dist, "get_backend", lambda g=None: "gloo")
+    assert PG.resolve_shard_mode(o, object(), 50, True) == ("nodes", "rccl")
