@@ -25,6 +25,7 @@ from . import io
 from . import function
 from . import testing
 from . import func
-from .function import cart2homo, homo2cart, point2pixel, pixel2point, reprojerr, is_lietensor, is_SE3, hasnan, chspline, bspline, svdtf, svdstf
+from .function import cart2homo, homo2cart, point2pixel, pixel2point, reprojerr, is_lietensor, is_SE3, hasnan, chspline, bspline, svdtf, svdstf, \
+    bvv, bmv, bvmv
 from . import metric
 from .module.loss import geodesic_loss

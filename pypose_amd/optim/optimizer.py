@@ -49,6 +49,36 @@ class Trivial(nn.Module):
         return out[0] if len(out) == 1 else out
 
 
+class RowWeights:
+    """Block-diagonal weight of a stacked row system, kept as its blocks: per residual a [k, d, d] tensor tiled ``ni`` times.
+    ``W @ M`` and ``M^T W`` (what LM / GN need, reference optimizer.py:318-322, 653-655) are batched d x d products."""
+
+    def __init__(self, parts):
+        self.parts = parts                                # [(blocks [k, d, d], ni)]
+
+    def _each(self, M):
+        off = 0
+        for ws, ni in self.parts:
+            k, d = ws.shape[0] * ni, ws.shape[-1]
+            blk = ws.repeat(ni, 1, 1) if ni > 1 else ws
+            yield blk, M[off:off + k * d].reshape(k, d, -1)
+            off += k * d
+
+    def matmul(self, M):
+        """W @ M for M [N_res] or [N_res, c]"""
+        vec = M.dim() == 1
+        M2 = M.unsqueeze(-1) if vec else M
+        out = torch.cat([(blk @ rows).reshape(-1, M2.shape[-1]) for blk, rows in self._each(M2)])
+        return out.squeeze(-1) if vec else out
+
+    def rmatmul_T(self, M):
+        """M^T @ W for M [N_res, c]: ([W^T M])^T"""
+        return torch.cat([(blk.mT @ rows).reshape(-1, M.shape[-1]) for blk, rows in self._each(M)]).T
+
+    def dense(self):
+        return torch.block_diag(*[b for ws, ni in self.parts for b in list(ws.unbind(0)) * ni])
+
+
 class RobustModel(nn.Module):
     """Standardises a model into residual(s) and a robust loss (reference optimizer.py:64-125)."""
 
@@ -57,31 +87,32 @@ class RobustModel(nn.Module):
         self.model = model
         self.kernel = [Trivial()] if kernel is None else kernel
 
-    def flatten_row_jacobian(self, J, params_values):
-        if isinstance(J, (tuple, list)):
-            J = torch.cat([j.reshape(-1, p.numel()) for j, p in zip(J, params_values)], 1)
-        return J
-
     @staticmethod
     def _weight_blocks(w, r):
-        """per-row weight matrices [k, d, d] and the tiling factor covering all rows of r"""
+        """per-row weight matrices [k, d, d] and the tiling factor covering all rows of r (a weight given for fewer rows than
+        the residual has is repeated, a scalar-residual weight is a 1x1 block: the reference's conventions, optimizer.py:88-97)"""
         ni = r.numel() * w.shape[-1] / w.numel()
         w = w.view(*w.shape, 1, 1) if r.shape[-1] == 1 else w
         return w.reshape(-1, w.shape[-2], w.shape[-1]), int(ni)
 
-    def normalize_RWJ(self, R, weight, J):
-        weight_diag = None
+    def stack_rows(self, R, weight, J, params):
+        """All residuals of a model as ONE row system: (r [N_res], W or None, J [N_res, N_par]).
+
+        J arrives per residual as a tuple over parameters of [*r.shape, *p.shape] derivatives; the parameters become the columns.
+        W stays in its block-diagonal FORM (``RowWeights`` below): the reference materialises torch.block_diag of every row's
+        d x d block -- an [N_res, N_res] matrix with d / N_res of its entries non-zero -- although everything
+        that follows only ever multiplies by it."""
+        rows = []
+        for Jr in J:
+            if isinstance(Jr, (tuple, list)):
+                Jr = torch.cat([j.reshape(-1, p.numel()) for j, p in zip(Jr, params)], dim=1)
+            rows.append(Jr)
+        W = None
         if weight is not None:
             weight = weight if isinstance(weight, (tuple, list)) else [weight]
             assert len(R) == len(weight)
-            mats = []
-            for w, r in zip(weight, R):
-                ws, ni = self._weight_blocks(w, r)
-                mats += list(ws.unbind(0)) * ni
-            weight_diag = torch.block_diag(*mats)
-        R = [r.reshape(-1) for r in R]
-        J = torch.cat(J) if isinstance(J, (tuple, list)) else J
-        return torch.cat(R), weight_diag, J
+            W = RowWeights([self._weight_blocks(w, r) for w, r in zip(weight, R)])
+        return torch.cat([r.reshape(-1) for r in R]), W, torch.cat(rows)
 
     def forward(self, input, target=None):
         return self.residuals(self.model_forward(input), target)
@@ -121,15 +152,16 @@ class DenseLinearization:
         R = list(model(input, target))
         J = modjac(model, input=(input, target), flatten=False, **opt.jackwargs)
         values = tuple(dict(model.named_parameters()).values())
-        J = [model.flatten_row_jacobian(Jr, values) for Jr in J]
+        J = [torch.cat([j.reshape(-1, p.numel()) for j, p in zip(Jr, values)], dim=1) if isinstance(Jr, (tuple, list)) else Jr
+             for Jr in J]
         for i in range(len(R)):
             c = opt.corrector[0] if len(opt.corrector) == 1 else opt.corrector[i]
             R[i], J[i] = c(R=R[i], J=J[i])
-        self.R, self.W, self.J = model.normalize_RWJ(R, weight, J)
+        self.R, self.W, self.J = model.stack_rows(R, weight, J, values)
 
     # LM
     def build_normal_equations(self, dmin, dmax):
-        self.J_T = self.J.T @ self.W if self.W is not None else self.J.T
+        self.J_T = self.W.rmatmul_T(self.J) if self.W is not None else self.J.T
         self.A = self.J_T @ self.J
         self.A.diagonal().clamp_(dmin, dmax)
 
@@ -141,7 +173,7 @@ class DenseLinearization:
 
     # GN
     def solve_gauss_newton(self, solver):
-        A, b = (self.J, -self.R) if self.W is None else (self.W @ self.J, -self.W @ self.R)
+        A, b = (self.J, -self.R) if self.W is None else (self.W.matmul(self.J), -self.W.matmul(self.R))
         return solver(A=A, b=b.view(-1, 1))
 
     def strategy_args(self):
