@@ -148,13 +148,16 @@ constexpr int kPgoPartials = 1024;     // = PPLIE_PGO_PARTIALS in include/pplie.
 //   pack      one wavefront: the partials summed in index order (double), the solve's (iterations, |r|^2, |b|^2, flag) appended,
 //             the loss stored into the caller's ring of loss scalars, and the 8 doubles {a, b, loss, its, rr, bn2, flag, seq}
 //             stored with SYSTEM scope -- `out` may be host-pinned memory the host polls for `seq`, the last word written.
-// `state` (device memory, three 64-bit words): {seq: incremented by every execution, address of the loss ring (T*) or 0, its length}.
+// `state` (device memory, four 64-bit words): {seq: incremented by every execution's last kernel, address of the loss ring (T*) or 0,
+// its length, retractions: incremented by every execution's FIRST kernel}.
 // ---------------------------------------------------------------------------------------------
 template <class T>
 __global__ void __launch_bounds__(256)
-pgo_retract_kernel(T* __restrict__ nodes, const T* __restrict__ x, T* __restrict__ backup /* or null */, int64_t N) {
+pgo_retract_kernel(T* __restrict__ nodes, const T* __restrict__ x, T* __restrict__ backup /* or null */, int64_t N,
+                   unsigned long long* state) {
   const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (n >= N) return;
+  if (n == 0) state[3] += 1;             // "the parameters were moved": what an error path needs to know before it restores them
   T d[7], X[7], E[7], out[7];
 #pragma unroll
   for (int k = 0; k < 6; ++k) d[k] = x[n * 6 + k];
@@ -210,7 +213,8 @@ int pgo_trial_tail(void* nodes, void* backup, const void* idx, const void* Z, co
   if (N <= 0 || E <= 0) return PPLIE_EBADARG;
   if (!nodes || !idx || !Z || !J || !R || !x || !pcg_info || !partial || !state || !out || !aligned16(Z)) return PPLIE_EBADARG;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL((pgo_retract_kernel<T>), dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, (T*)nodes, (const T*)x, (T*)backup, N);
+  hipLaunchKernelGGL((pgo_retract_kernel<T>), dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, (T*)nodes, (const T*)x, (T*)backup, N,
+                     (unsigned long long*)state);
   constexpr int BLOCK = 256;
   const int64_t nt = (E + BLOCK - 1) / BLOCK;
   const int grid = (int)(nt < kPgoPartials ? nt : kPgoPartials);             // (= the grid of both kernels below)

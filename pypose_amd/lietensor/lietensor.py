@@ -39,8 +39,19 @@ index_copy_ select select_scatter index_put index_put_ copy_
 
 _gather_recorders = []      # active optim.posegraph.GatherRecorder instances
 # torch functions that look at a tensor's metadata only
-_VALUE_FREE = frozenset(("__get__", "dim", "size", "stride", "numel", "is_contiguous", "data_ptr", "storage_offset", "element_size",
+_VALUE_FREE = frozenset(("dim", "size", "stride", "numel", "is_contiguous", "data_ptr", "storage_offset", "element_size",
                          "ndimension", "is_floating_point", "is_complex", "type", "requires_grad_", "nelement", "get_device"))
+# property getters reach __torch_function__ as the generic ``__get__`` of a getset descriptor: only the ones NAMED here read
+# metadata; .data, .grad, .T, .mT, .H, .real, .imag ... hand out value-carrying aliases the tracer no longer sees
+_VALUE_FREE_PROPERTIES = frozenset(("shape", "dtype", "device", "requires_grad", "ndim", "is_cuda", "is_cpu", "is_leaf", "layout",
+                                    "is_sparse", "is_quantized", "is_meta", "names", "itemsize", "nbytes", "grad_fn", "output_nr",
+                                    "_version", "is_mkldnn", "is_xpu", "is_mps", "is_nested", "is_sparse_csr", "retains_grad"))
+
+
+def _value_free(func, name):
+    if name == "__get__":
+        return getattr(getattr(func, "__self__", None), "__name__", None) in _VALUE_FREE_PROPERTIES
+    return name in _VALUE_FREE
 
 
 def _raw(t):
@@ -427,7 +438,7 @@ class LieTensor(Tensor):
             if _gather_recorders and name == '__getitem__' and len(args) == 2:
                 # dry trace (optim/fused.py): a row gather on a tracked parameter is noted, not executed
                 data = _op._op_tracers[-1].dry_gather(args[0], args[1], _gather_recorders)
-            if data is None and name not in _VALUE_FREE:
+            if data is None and not _value_free(func, name):
                 # any other torch function on a LieTensor during a dry trace may read VALUES of a real tensor (a parameter):
                 # remembered, so that nothing is run speculatively around such a model (fused.checked_shortcut)
                 _op._op_tracers[-1].touched = True

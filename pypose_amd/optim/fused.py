@@ -65,10 +65,17 @@ class _DryState:
         self.base = torch.empty((1 << 60,), dtype=torch.uint8, device="meta")
 
 
+def _meta_id(t):
+    """identity of a dry-trace value: its BYTE offset in the tracer's buffer (one window per trace position; element offsets of
+    different dtypes can coincide: an fp32 value at position 1 and an fp64 one at position 3)"""
+    return -1 - t.storage_offset() * t.element_size()
+
+
 def _tok(t):
-    """what a trace signature records of an operand: a dry output's offset, or a real tensor's memory + layout"""
+    """what a trace signature records of an operand: a dry value's identity AND view (shape / stride / dtype: a model that
+    returns r[..., :3] of the same value one step and r the next must not look unchanged), or a real tensor's memory + layout"""
     if t.device.type == "meta":
-        return -1 - t.storage_offset()
+        return (_meta_id(t), t.shape, t.stride(), t.dtype)
     return (t.data_ptr(), t.shape, t.dtype, t.requires_grad, t.stride(), t.device.index)
 
 
@@ -120,7 +127,7 @@ class DryTracer(OpTracer):
         lead = tuple(lead)
         outs = tuple(self._out(lead + (w,), x0.dtype) for w in out_widths)
         self.events.append((name, tuple(ins), outs))
-        self.sig.append((name,) + tuple(_tok(t) for t in ins) + tuple(o.storage_offset() for o in outs))
+        self.sig.append((name,) + tuple(_tok(t) for t in ins) + tuple(_tok(o) for o in outs))
         return outs
 
     def dry_lie(self, fn, xs, out_ltype):
@@ -144,7 +151,7 @@ class DryTracer(OpTracer):
         out = self._out(tuple(lead) + (out_width,), x0.dtype)
         ins = tuple(ins)
         self.events.append((name, ins, (out,)))
-        self.sig.append((name,) + tuple(_tok(t) for t in ins) + (out.storage_offset(),))
+        self.sig.append((name,) + tuple(_tok(t) for t in ins) + (_tok(out),))
         wrapped = self.state.wrapped.get(pos)
         if wrapped is None or wrapped._pl is not out or wrapped.ltype is not out_ltype:
             wrapped = _lt._wrap(out, out_ltype)
@@ -164,7 +171,7 @@ class DryTracer(OpTracer):
         if src is None or src.dim() != 2:
             return None
         out = self._out(tuple(index.shape) + (src.shape[-1],), src.dtype)
-        self.sig.append(("gather", id(source), _tok(index), out.storage_offset()))
+        self.sig.append(("gather", id(source), _tok(index), _tok(out)))
         return out
 
 
@@ -173,7 +180,7 @@ def _key(t):
     if type(t) is not torch.Tensor:
         t = torch.Tensor.as_subclass(t, torch.Tensor)          # (attribute reads on a LieTensor are __torch_function__ round trips)
     if t.device.type == "meta":
-        return -1 - t.storage_offset()
+        return _meta_id(t)
     return t.data_ptr()
 
 
@@ -651,8 +658,11 @@ def match_lpr(trace, outputs, params, target, gathers):
         return None
     n = Pp.numel() // dg
     by_out = {_key(o[0]): (name, ins) for name, ins, o in trace.events}
+    top_out = {_key(o[0]): o[0] for name, ins, o in trace.events}.get(_key(outputs[0]))
     top = by_out.get(_key(outputs[0]))
-    if top is None or len(by_out) != len(trace.events):
+    # the model's output has to BE the top event's result -- same element count, contiguous: not a slice or a strided view of it
+    # (r[..., :3] starts at the same offset), as match_se3inv / match_pgo require of theirs
+    if top is None or len(by_out) != len(trace.events) or not _same(top_out, outputs[0]):
         return None
     used = [0]
 
@@ -1157,11 +1167,24 @@ def _pgo_linearization(opt, prog, weight, P, trivial):
                 if tt is None or tt.dtype != pt.dtype or tt.dev != pt.device:
                     tt = opt._trial_tail = TrialTail(pt.dtype, pt.device)
                 pend, lin.pending_info = lin.pending_info, None
+                bk = tt.__dict__.get('_backup')
+                if bk is None or bk.shape != pt.shape or bk.dtype != pt.dtype or bk.device != pt.device:
+                    bk = tt._backup = torch.empty_like(pt)
+                before = tt.seq
                 slot = tt.advance()
                 try:
-                    tt.enqueue(pt, None, prog, lin, Dn.contiguous(), None if pend is None else pend.info)
+                    # (the retraction keeps the old rows in `bk`: 28 B per node, against a trial that overwrites the parameters
+                    #  with nothing to go back to if one of the later launches of the same C call fails)
+                    tt.enqueue(pt, bk, prog, lin, Dn.contiguous(), None if pend is None else pend.info)
                 except BaseException:
-                    tt.seq -= 1                  # (nothing ran: the device's execution count did not move)
+                    # some of the call's launches may have run (the retraction comes first): the device's own execution count says
+                    # whether the result block was written; the parameters go back to what the retraction saved
+                    torch.cuda.synchronize(pt.device)
+                    tt.seq = before
+                    tt.resync()
+                    if tt.unfinished > 0:        # the retraction ran, the report did not: bk holds this trial's starting point
+                        pt.copy_(bk)
+                        tt.state[3] = tt.state[0]
                     raise
                 _C.mark_written(P)
                 a, b, loss_h, its, rr, bn2, flag = tt.wait()

@@ -62,7 +62,8 @@ class TrialTail:
         self.out = torch.zeros(8, dtype=torch.float64).pin_memory()       # {a, b, loss, iterations, |r|^2, |b|^2, flag, seq}
         self.out_np = self.out.numpy()
         self.seq = 0
-        self.state = torch.zeros(3, dtype=torch.int64, device=dev)         # {seq (counts executions), loss ring address, its length}
+        self.state = torch.zeros(4, dtype=torch.int64, device=dev)         # {seq (counts executions), loss ring address, its length,
+                                                                           #  retractions (counts moved parameters)}
         self.partial = torch.empty(3 * _PARTIALS, dtype=dtype, device=dev)
         self.no_info = torch.zeros(4, dtype=dtype, device=dev)             # (a solve that reported to the host already)
         self.new_ring()
@@ -72,7 +73,7 @@ class TrialTail:
         """a fresh ring when this one has gone round, so a loss handed out earlier is never overwritten"""
         self.ring = torch.zeros(self.RING, dtype=self.dtype, device=self.dev)
         self.loss_views = self.ring.unbind(0)
-        self.state[1:].copy_(torch.tensor([self.ring.data_ptr(), self.RING], dtype=torch.int64))     # (once per RING trials)
+        self.state[1:3].copy_(torch.tensor([self.ring.data_ptr(), self.RING], dtype=torch.int64))    # (once per RING trials)
 
     def enqueue(self, pt, backup, prog, lin, Dn, info):
         """the four launches (nothing else: callable inside a stream capture)"""
@@ -92,18 +93,45 @@ class TrialTail:
             self.new_ring()
         return slot
 
-    def wait(self):
-        """the trial's verdict: poll the pinned word the last kernel stores; a solve that takes unusually long is waited for
-        with a stream synchronisation instead"""
+    SPIN_SECONDS = 0.05          # busy polling (the usual trial answers in well under a millisecond) before yielding the GIL
+    WAIT_SECONDS = 30.0          # a trial that has not reported by then is given up on
+
+    def wait(self, stream=None):
+        """the trial's verdict: poll the pinned word the last kernel stores.  Bounded by WALL TIME, not by a poll count: after
+        SPIN_SECONDS the loop yields the GIL between polls and asks the stream whether it is still working (an asynchronous HIP
+        error on the stream surfaces there as an exception instead of an endless wait); a stream that went idle without the
+        word arriving, or WAIT_SECONDS, ends it."""
+        import time
         out, seq = self.out_np, float(self.seq)
-        n = 0
+        if out[7] == seq:
+            return out[:7].tolist()
+        t0 = time.perf_counter()
+        st = torch.cuda.current_stream(self.dev) if stream is None else stream
         while out[7] != seq:
-            n += 1
-            if n > 200_000:
+            dt = time.perf_counter() - t0
+            if dt < self.SPIN_SECONDS:
+                continue
+            time.sleep(0)                                    # (other Python threads -- the autograd engine's among them -- get to run)
+            idle = st.query()                                # raises on a sticky error of the device
+            if out[7] == seq:
+                break
+            if idle or dt > self.WAIT_SECONDS:
                 torch.cuda.synchronize(self.dev)
                 if out[7] != seq:
-                    raise RuntimeError("pypose_amd: the pose-graph trial finished without reporting its result")
+                    self.resync()
+                    raise RuntimeError("pypose_amd: the pose-graph trial finished without reporting its result"
+                                       if idle else "pypose_amd: the pose-graph trial did not report within "
+                                       f"{self.WAIT_SECONDS:.0f} s")
         return out[:7].tolist()
+
+    def resync(self):
+        """after a failed launch / an exception: the host's execution count is read back from the device's (a read-back, so a
+        synchronisation -- error paths only).  Returns how many executions the device counted beyond the host's mirror."""
+        dev_seq, moved = (int(v) for v in self.state[[0, 3]].tolist())
+        ahead = dev_seq - self.seq
+        self.seq = dev_seq
+        self.unfinished = moved - dev_seq            # retractions whose trial never reported (0 or 1)
+        return ahead
 
 
 class PgoGraphStep:

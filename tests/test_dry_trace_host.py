@@ -140,3 +140,32 @@ def test_value_reads_of_real_lietensors_are_noticed():
     o3 = _Opt(g3)
     fused.dry_program(o3, [g3.nodes], (edges, poses), None)
     assert o3._dry_state.touched is True
+
+
+def test_a_view_of_the_result_is_not_the_result():
+    """a model that returns a SLICE of the Log result (same storage offset) is not the full program, and a model
+    that changes the view it returns between steps must not keep the previous step's match"""
+    class Sliced(InvNet):
+        cut = False
+
+        def forward(self, input):
+            r = (self.pose.Inv() @ input).Log().tensor()
+            return r[..., :3] if self.cut else r
+    net = Sliced(_se3(5, 0))
+    inp = _se3(5, 1)
+    opt = _Opt(net)
+    m = fused.dry_program(opt, [net.pose], inp, None)
+    assert m is not None and m[0] == "lpr"
+    net.cut = True                                                    # same kernels, same operands, same offset: another view
+    m2 = fused.dry_program(opt, [net.pose], inp, None)
+    assert m2 is None or m2 is False
+    net.cut = False
+    assert fused.dry_program(opt, [net.pose], inp, None)[0] == "lpr"
+
+
+def test_trace_positions_of_different_dtypes_do_not_collide():
+    st = fused._DryState()
+    with fused.DryTracer(st) as tr:
+        outs = [tr._out((4, 6), torch.float32), tr._out((4, 6), torch.float32), tr._out((4, 6), torch.float64),
+                tr._out((4, 6), torch.float64)]
+    assert len({fused._key(o) for o in outs}) == 4 and len({fused._tok(o) for o in outs}) == 4

@@ -32,7 +32,7 @@ def test_trial_tail_equals_the_unfused_ops(dtype, tol, N, E):
     info = torch.tensor([5.0, 1e-3, 1.0, 1.0], dtype=dtype, device=DEV)
     partial = torch.empty(3 * 1024, dtype=dtype, device=DEV)
     ring = torch.zeros(16, dtype=dtype, device=DEV)
-    state = torch.tensor([6, ring.data_ptr(), 16], dtype=torch.int64, device=DEV)       # (six executions so far)
+    state = torch.tensor([6, ring.data_ptr(), 16, 6], dtype=torch.int64, device=DEV)    # (six executions so far, six retractions)
     out = torch.zeros(8, dtype=torch.float64).pin_memory()
     backup = torch.empty_like(nodes)
     want_nodes = (pp.se3(x).Exp() @ pp.SE3(nodes)).tensor()
@@ -48,7 +48,7 @@ def test_trial_tail_equals_the_unfused_ops(dtype, tol, N, E):
     assert code == 0
     torch.cuda.synchronize()
     got = out.tolist()
-    assert got[7] == 7.0 and state.tolist()[0] == 7                     # the sequence number counts executions
+    assert got[7] == 7.0 and state.tolist()[0] == 7 and state.tolist()[3] == 7     # executions and retractions are counted
     assert got[3:7] == [5.0, pytest.approx(1e-3, rel=1e-6), 1.0, 1.0]
     assert got[0] == pytest.approx(want_a, rel=tol) and got[1] == pytest.approx(want_b, rel=tol, abs=tol * want_a)
     assert got[2] == pytest.approx(want_loss, rel=tol)
@@ -67,3 +67,54 @@ def test_pcg_begin_clears_and_fetches_from_pinned_memory():
         assert fn(ctl.data_ptr(), 12, None, None, _C.stream_ptr(DEV)) != 0            # (not a multiple of 8)
     torch.cuda.synchronize()
     assert ctl.count_nonzero().item() == 0 and dst.item() == 1.0 + 2.5e-5
+
+
+def test_a_failed_tail_in_the_ordinary_loop_restores_the_parameters_and_resyncs():
+    """the un-captured trial's tail overwrites the parameters in its first launch; a failure reported by the same C
+    call afterwards must leave the parameters where the trial started and the host's execution count equal to the device's.
+    The failure is injected AFTER a real execution's retraction (the call runs, then reports an error), and as a call that
+    never ran."""
+    from pypose_amd.optim import pgograph as PG
+    from tests.optim_models import PoseGraph
+    from tests.test_optim_gpu import _synthetic_graph
+    edges, rel, init = _synthetic_graph(40_000, 120_000, torch.float32)     # beyond the persistent solve: the ordinary trial loop
+    graph = PoseGraph(init.clone())
+    opt = pp.optim.LM(graph, solver=pp.optim.solver.PCG(tol=1e-4, maxiter=100), strategy=pp.optim.strategy.TrustRegion(radius=1e4))
+    opt.graph_step = False
+    l0 = float(opt.step((edges, rel)))
+    tt = opt.__dict__.get("_trial_tail")
+    assert tt is not None, "the fused tail was not used on this path"
+    real_enqueue = PG.TrialTail.enqueue
+    before = graph.nodes.detach().clone()
+    mode = {"k": "after"}
+
+    def failing(self, pt, backup, prog, lin, Dn, info):
+        if mode["k"] == "after":
+            real_enqueue(self, pt, backup, prog, lin, Dn, info)
+            torch.cuda.synchronize()
+            self.state[0] -= 1                     # as if the last kernel (pack) had never run: retracted, not reported
+        raise RuntimeError("injected")
+    PG.TrialTail.enqueue = failing
+    try:
+        for k in ("after", "never"):
+            mode["k"] = k
+            seq_dev = int(tt.state[0])
+            with pytest.raises(RuntimeError, match="injected"):
+                opt.step((edges, rel))
+            torch.cuda.synchronize()
+            assert torch.equal(graph.nodes.detach(), before), k          # back at the trial's starting point
+            assert tt.seq == int(tt.state[0]) == seq_dev, k              # host mirror = device count
+            assert int(tt.state[3]) == int(tt.state[0]), k
+    finally:
+        PG.TrialTail.enqueue = real_enqueue
+    l1 = float(opt.step((edges, rel)))                                    # and the loop carries on
+    assert l1 < l0
+
+
+def test_wait_is_bounded_by_time_and_reports_an_idle_stream():
+    from pypose_amd.optim import pgograph as PG
+    tt = PG.TrialTail(torch.float32, torch.device(DEV))
+    tt.advance()                                                          # a result is expected, nothing was enqueued
+    with pytest.raises(RuntimeError, match="without reporting"):
+        tt.wait()
+    assert tt.seq == 0                                                    # resynchronised with the device's count
