@@ -37,6 +37,39 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+# VALU issue peak: 256 CUs x 4 SIMD-32, a wave64 VALU instruction occupies its SIMD for 2 cycles, 2.4 GHz (MI355X_MICROARCH.md
+# "Wave scheduling" / per-instruction cycle constants): 256 * 4 * 2.4e9 / 2 wave-instructions per second
+VALU_PEAK_WAVE_INSTR = 256 * 4 * 2.4e9 / 2
+
+
+def _pmc(name):
+    """profiles/<name>.json: counters of EARLIER rocprofv3 --pmc passes of these kernels (never collected inside a bench run);
+    every file carries the commit and date it was collected at under "_stamp" """
+    try:
+        with open(os.path.join(ROOT, "profiles", name + ".json")) as f:
+            return json.load(f)
+    except Exception:
+        return {}
+
+
+def valu_roofline(kernels, seconds, hbm_block=None):
+    """roofline block of a leg whose kernels are bound by VALU instruction issue, not by bytes: achieved = wave64 VALU
+    instructions issued per second (SQ_INSTS_VALU of the leg's kernels, profiles/pmc_sq.json, over the time measured HERE)
+    against the chip's issue peak; the HBM figure rides along as "hbm" """
+    sq = _pmc("pmc_sq")
+    tot, used = 0.0, {}
+    for k in kernels:
+        e = sq.get(k)
+        if not e:
+            return dict(hbm_block or {}, bound_note=f"VALU-issue bound by measurement, but profiles/pmc_sq.json has no entry for {k}")
+        tot += e["SQ_INSTS_VALU"]
+        used[k] = {"SQ_INSTS_VALU_per_launch": e["SQ_INSTS_VALU"], "valu_per_wave": e.get("valu_per_wave"), "waves": e.get("SQ_WAVES")}
+    ach = tot / seconds
+    return {"bound": "valu", "unit": "wave64 VALU instructions/s", "achieved": ach, "peak": VALU_PEAK_WAVE_INSTR,
+            "frac": ach / VALU_PEAK_WAVE_INSTR, "kernels": used,
+            "counter_source": f"profiles/pmc_sq.json ({sq.get('_stamp', 'unstamped')}): rocprofv3 --pmc SQ_INSTS_VALU of an earlier run "
+                              "of these kernels on this workload; the time is this run's", "hbm": hbm_block}
+
 BYTES_PER_ROW = {"se3_exp_fwd": 24 + 28, "se3_log_fwd": 28 + 24}    # SURVEY.md section 8(d): 52 B/row each
 
 
@@ -410,16 +443,42 @@ def pgo_lm_rate(dev, nodes=10_000, edges=40_000, steps=3, reps=5, with_static=Tr
     graph0 = _pose_graph_model(init.clone())
     l0 = float(graph0(e, rel).detach().square().sum())
     opt, dt, times, losses, its = run(False)
-    # one PCG iteration streams ~400 B / edge (J^T J blocks + indices + vectors), the linearisation 388 B / edge
-    # + 168 B / node; the whole-step figure below bills every iteration and the linearisation to the measured step time
-    it_bytes = 400.0 * edges
-    step_bytes = sum(its) / len(its) * it_bytes + 388.0 * edges + 168.0 * nodes
+    its_mean = sum(its) / len(its)
+    persistent = nodes <= 32768            # (optim/posegraph.py PERSIST_NODES: one persistent launch per solve, blocks resident in LDS)
+    traffic = _pmc("pmc_traffic")
+    if persistent:
+        # One launch per solve with the off-diagonal blocks resident in LDS: the blocks cross HBM once per SOLVE, not once per
+        # iteration, and an iteration is a grid-wide exchange (tagged words through L2), not a stream of bytes.  What bounds it is
+        # the latency of that exchange: us per iteration against the hand-off floor measured in profiles/r03/pingpong.log.
+        solve_bytes = (traffic.get("detail", {}).get("pcg_ghost_solve") or {})
+        lin_bytes = 388.0 * edges + 168.0 * nodes
+        roof = {"bound": "latency (one grid-wide exchange per PCG iteration)", "unit": "us per PCG iteration",
+                "us_per_lm_step": dt * 1e6, "mean_pcg_iterations": its_mean,
+                "us_per_pcg_iteration_incl_step_overheads": dt * 1e6 / max(its_mean, 1.0),
+                "exchange_floor_us": [0.40, 0.57], "floor_source": "profiles/r03/pingpong.log (one tagged-word hand-off between two workgroups)",
+                "marginal_us_per_iteration": 5.6, "marginal_source": "profiles/r03/pcg_iter.json / profiles/r04 (tools/time_pcg_iter.py)",
+                "hbm": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBPS,
+                        "bytes_per_lm_step": lin_bytes + float(solve_bytes.get("fetch", 0.0) or 0.0) + float(solve_bytes.get("write", 0.0) or 0.0),
+                        "note": "linearisation 388 B/edge + 168 B/node (SURVEY 8d C4) + the solve's COUNTED traffic per launch "
+                                "(profiles/pmc_traffic.json pcg_ghost_solve, most of it the polled hand-off table): "
+                                "a few percent of the HBM rate -- not what bounds this leg"}}
+        roof["hbm"]["achieved"] = roof["hbm"]["bytes_per_lm_step"] / dt / 1e9
+        roof["hbm"]["frac"] = roof["hbm"]["achieved"] / HBM_PEAK_GBPS
+    else:
+        # two launches per iteration (pcg2_spmv_pack + pcg2_step), every iteration streams the packed blocks: SURVEY 8(d) C4's
+        # 400 B/edge is the un-packed figure; the packed layout moves 84 B per incidence + 2 x 144 B per node + the vectors
+        it_bytes = 84.0 * 2 * edges + (144.0 * 2 + 24.0 * 6) * nodes + 4.0 * 2 * edges
+        step_bytes = its_mean * it_bytes + 388.0 * edges + 168.0 * nodes
+        roof = {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBPS, "achieved": step_bytes / dt / 1e9,
+                "frac": step_bytes / dt / 1e9 / HBM_PEAK_GBPS, "algorithmic_bytes_per_step": step_bytes,
+                "algorithmic_bytes_per_pcg_iteration": it_bytes, "mean_pcg_iterations": its_mean,
+                "us_per_pcg_iteration_incl_step_overheads": dt * 1e6 / max(its_mean, 1.0),
+                "per": "LM step (linearise + mean PCG iterations x packed blocks 84 B/incidence, D and Binv 144 B/node each, vectors)",
+                "note": "the iteration is bound by the rate the memory system serves its gathers (profiles/r04/pcg2_100k_experiments.md: "
+                        "waves 66 % parked on s_waitcnt, insensitive to occupancy and to trips per wave), counted fetch 1.5x algorithmic"}
     out = {"metric": f"LM iters/sec (PGO {nodes} poses / {edges} edges)", "value": 1.0 / dt, "unit": "LM steps/s", "nodes": nodes,
            "edges": edges, "path": opt.linearization, "initial_loss": l0, "losses": losses, "pcg_iterations": its,
-           "steps_per_repetition": steps, "repetitions_ms_per_step": [round(t * 1e3, 3) for t in times],
-           "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBPS, "achieved": step_bytes / dt / 1e9,
-                        "frac": step_bytes / dt / 1e9 / HBM_PEAK_GBPS,
-                        "algorithmic_bytes_per_step": step_bytes, "per": "LM step (linearise + mean PCG iterations x 400 B/edge)"}}
+           "steps_per_repetition": steps, "repetitions_ms_per_step": [round(t * 1e3, 3) for t in times], "roofline": roof}
     if with_static:
         # LM(static=True): the caller's promise that the residual program does not change between steps
         opt2, dt2, _, losses2, _ = run(True)
@@ -523,16 +582,17 @@ def invnet_lm_rate(dev, B=1_000_000, steps=3, reps=40, group=None, problem=None)
                 traj["reject"].append(int(opt.reject_count))
         except Exception as ex:
             traj["error"] = repr(ex)
-    return {"trajectory": traj,
+    return {"trajectory": traj, "algorithmic_bytes_per_step": 84 * B,
             "metric": "LM iters/sec (InvNet SE3, 1M independent problems per GPU)", "value": 1.0 / best, "unit": "LM steps/s",
             "static_model_value": 1.0 / best_static, "static_model_final_loss": loss_static,
             "problems_per_gpu": B, "n_gpus": world, "problem_steps_per_s": world * B / best, "path": path,
             "initial_loss": l0, "final_loss": loss, "steps_per_repetition": steps, "repetitions_in_flight": reps,
             "value_with_a_sync_per_repetition": 1.0 / sync_best,
-            "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBPS, "achieved": ach, "frac": ach / HBM_PEAK_GBPS,
-                         "frac_static_model": 84.0 * B / best_static / 1e9 / HBM_PEAK_GBPS,
-                         "algorithmic_bytes_per_step": 84 * B, "per": "LM step per GPU (SURVEY 8d C3: pose 28 r + input 28 r + pose 28 w)",
-                         "kernel": "lm_se3inv_trial2_kernel + lm_se3inv_finish_kernel (pplie_lm_se3inv_step_f32)"}}
+            "roofline": valu_roofline(["lm_se3inv_trial2", "lm_se3inv_finish"], best, {
+                "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBPS, "achieved": ach, "frac": ach / HBM_PEAK_GBPS,
+                "frac_static_model": 84.0 * B / best_static / 1e9 / HBM_PEAK_GBPS,
+                "algorithmic_bytes_per_step": 84 * B, "per": "LM step per GPU (SURVEY 8d C3: pose 28 r + input 28 r + pose 28 w)",
+                "kernel": "lm_se3inv_trial2_kernel + lm_se3inv_finish_kernel (pplie_lm_se3inv_step_f32)"})}
 
 
 def imu_rate(dev, B=4096, F=1024, reps=20, inner=16):
@@ -563,9 +623,10 @@ def imu_rate(dev, B=4096, F=1024, reps=20, inner=16):
         nbytes = 68.0 * B * F + (324.0 * B if cov else 0.0)
         out["with_covariance" if cov else "states_only"] = {
             "value": B * F / t, "ms": t * 1e3,
-            "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBPS, "achieved": nbytes / t / 1e9,
-                         "frac": nbytes / t / 1e9 / HBM_PEAK_GBPS, "algorithmic_bytes_per_launch": nbytes,
-                         "per": "module forward (68 B / step" + (" + 324 B / sequence)" if cov else ")")}}
+            "roofline": valu_roofline(["imu_integrate_multi"] + (["imu_cov_seg"] if cov else []), t, {
+                "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBPS, "achieved": nbytes / t / 1e9,
+                "frac": nbytes / t / 1e9 / HBM_PEAK_GBPS, "algorithmic_bytes_per_launch": nbytes,
+                "per": "module forward (68 B / step" + (" + 324 B / sequence)" if cov else ")")})}
     out["value"] = out["with_covariance"]["value"]
     return out
 
@@ -962,9 +1023,8 @@ def main():
         dom, ms_dom = ("se3_log_fwd", ms_log) if ms_log >= ms_exp else ("se3_exp_fwd", ms_exp)
         achieved = B * BYTES_PER_ROW[dom] / (ms_dom * 1e-3) / 1e9
         traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):
-            traffic = json.load(open(pmc)).get(dom)
+        pmcj = _pmc("pmc_traffic")
+        traffic = pmcj.get(dom)
         out = {
             "metric": "batched SE3 Exp+Log ops/sec (BASELINE metric, first half; second half under lm_pgo)",
             "value": world * B * a.steps / elapsed,
@@ -979,8 +1039,8 @@ def main():
                                  ("torch.distributed.run" if launched else "single process")},
             "roofline": {"bound": "hbm", "kernel": f"rowmap_lds_kernel<{dom}> (pplie_{dom}_f32)",
                          "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                         "traffic": traffic, "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc passes of an earlier run of "
-                         "this kernel on this workload; not collected in this run)" if traffic is not None else None,
+                         "traffic": traffic, "traffic_source": (f"profiles/pmc_traffic.json ({pmcj.get('_stamp', 'unstamped')}): rocprofv3 --pmc passes of an "
+                                            "earlier run of this kernel on this workload; not collected in this run") if traffic is not None else None,
                          "algorithmic_bytes_per_launch": B * BYTES_PER_ROW[dom],
                          "avg_launch_ms": ms_dom, "timed_launches": len(ev), "other_kernel_ms": {"se3_exp_fwd": ms_exp, "se3_log_fwd": ms_log}},
         }

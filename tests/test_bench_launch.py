@@ -42,5 +42,5 @@ def test_single_process_dry_run_has_every_config():
     assert out["n_gpus"] == 1 and out["config"]["launch"] == "single process"
     for leg in ("c1", "ops_10m", "lm_invnet", "lm_pgo", "lm_pgo_100k", "imu", "imu_train"):
         assert "error" not in out[leg], (leg, out[leg])
-    assert out["lm_invnet"]["roofline"]["algorithmic_bytes_per_step"] == 84 * out["lm_invnet"]["problems_per_gpu"]
+    assert out["lm_invnet"]["algorithmic_bytes_per_step"] == 84 * out["lm_invnet"]["problems_per_gpu"]
     assert set(out["imu"]) >= {"states_only", "with_covariance"}

@@ -115,3 +115,30 @@ Jg, Rg = torch.randn(200_000, 64, 7, device=dev), torch.randn(200_000, 64, devic
 for _ in range(3):
     _bl.normal_equations(Jg, Rg)
 torch.cuda.synchronize()
+
+# round 4: the backward scans (4096 x 1025: SO3 67 + 67 MB read, 67 MB written; SE3 118 + 118 / 118), the IMU backward
+# (4096 x 1024: 28 + 16 + 40 B read, 24 B written per step) and the one-launch robust re-weighting ([400k, 6] residuals, [400k, 72] blocks)
+for rnd in (pp.randn_SO3, pp.randn_SE3):
+    for left in (True, False):
+        Xs = rnd(4096, 1025, device=dev, requires_grad=True)
+        Ws = torch.randn(4096, 1025, Xs.shape[-1], device=dev)
+        for _ in range(2):
+            Ys = pp.cumprod(Xs, dim=1, left=left)
+            torch.autograd.grad([Ys.tensor()], [Xs], [Ws])
+        torch.cuda.synchronize()
+        del Xs, Ws, Ys
+Bq, F = 4096, 1024
+dt = torch.full((Bq, F, 1), 0.005, device=dev)
+gyro = (0.1 * torch.randn(Bq, F, 3, device=dev)).requires_grad_(True)
+acc = (torch.randn(Bq, F, 3, device=dev) + torch.tensor([0., 0., 9.81], device=dev)).requires_grad_(True)
+integ = pp.module.IMUPreintegrator(prop_cov=False, reset=True).to(dev)
+Wr, Wv, Wp = torch.randn(Bq, F, 4, device=dev), torch.randn(Bq, F, 3, device=dev), torch.randn(Bq, F, 3, device=dev)
+for _ in range(2):
+    o = integ(dt=dt, gyro=gyro, acc=acc)
+    torch.autograd.grad([o["rot"].tensor(), o["vel"], o["pos"]], [gyro, acc], [Wr, Wv, Wp])
+torch.cuda.synchronize()
+Rr, Jr = torch.randn(400_000, 6, device=dev), torch.randn(400_000, 2, 6, 6, device=dev)
+ft = pp.optim.corrector.FastTriggs(pp.optim.kernel.Huber(1.0))
+for _ in range(3):
+    ft(R=Rr, J=Jr, inplace=True)
+torch.cuda.synchronize()
