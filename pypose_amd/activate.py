@@ -106,7 +106,7 @@ def _activate_scans(pypose, force):
             return done if done is not None else _orig(input, dim, left)
 
         def outofplace(input, dim, left=True, _ip=inplace, _orig=orig):
-            if _on_device(input, False) and not (torch.is_grad_enabled() and input.requires_grad):
+            if _on_device(input, False):          # (with a gradient: one autograd node, backward = pplie_scan_<g>_bwd)
                 return _ip(input.clone(), dim, left)
             return _orig(input, dim, left)
         inplace.__name__, outofplace.__name__ = base + "_", base
@@ -142,7 +142,7 @@ def _activate_jinvp_jr(pypose, force):
     cls.Jr = Jr
 
 
-_IMU_HELPERS = ("_fused_ok", "_rij_offset", "_bcast", "_gravity_host", "_fused_cov2", "_fused_integrate")
+_IMU_HELPERS = ("_fused_ok", "_rij_offset", "_bcast", "_gravity_host", "_fused_cov2", "_fused_integrate", "_launch_integrate")
 
 
 def _activate_imu(pypose):
@@ -152,8 +152,9 @@ def _activate_imu(pypose):
     orig = cls.__dict__["forward"]
 
     def forward(self, dt, gyro, acc, rot=None, gyro_cov=None, acc_cov=None, init_state=None):
-        """the fused route of pypose_amd's module on THIS module's buffers when everything lives on the GPU and nothing
-        needs a gradient; the reference's own forward otherwise"""
+        """the fused route of pypose_amd's module on THIS module's buffers when everything lives on the GPU (with gradients
+        w.r.t. dt / gyro / acc / the initial state: one autograd node, backward = pplie_imu_integrate_bwd); the reference's
+        own forward otherwise"""
         st = init_state if init_state is not None else {'pos': self.pos, 'rot': self.rot, 'vel': self.vel}
         c = self._check
         if not Ours._fused_ok(self, c(dt), c(gyro), c(acc), c(rot) if rot is not None else None, st):

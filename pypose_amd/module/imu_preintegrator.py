@@ -204,7 +204,8 @@ class IMUPreintegrator(nn.Module):
         if torch.is_grad_enabled() and any(t.requires_grad for t in ts):
             # differentiable fused route (one node, pplie_imu_integrate_bwd): dt / gyro / acc / initial state may require a
             # gradient; a known-orientation input that does, or a functorch transform, takes the composed route
-            if (rot is not None and rot.requires_grad) or torch._C._are_functorch_transforms_active() or not self.fused_backward:
+            if (rot is not None and rot.requires_grad) or torch._C._are_functorch_transforms_active() \
+                    or not getattr(self, 'fused_backward', True):
                 return False
         return dt.dtype in (torch.float32, torch.float64) and all(t.dtype == dt.dtype for t in ts)
 

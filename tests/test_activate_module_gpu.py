@@ -91,15 +91,45 @@ def test_activated_scans_jinvp_and_jr(rpp, dtype, tol):
     b = rpp.randn_so3(257, dtype=dtype)
     want = [rpp.cumprod(X, dim=1, left=False).tensor(), rpp.cummul(X, dim=1).tensor(), X.cumprod(dim=1).tensor(),
             Y.Jinvp(a).tensor(), S.Jinvp(b).tensor(), w.Jr()]
+    Xc = X.clone().requires_grad_(True)                    # the reference's own gradient through its Hillis-Steele rounds (CPU)
+    Wc = torch.randn(X.shape, dtype=dtype)
+    (rpp.cumprod(Xc, dim=1).tensor() * Wc).sum().backward()
+    want_grad = Xc.grad.tensor() if hasattr(Xc.grad, "tensor") else Xc.grad
     activate.activate(rpp, module=True)
     try:
         Xg, Sg, ag, Yg, wg = X.to(DEV), S.to(DEV), a.to(DEV), Y.to(DEV), w.to(DEV)
         got = [rpp.cumprod(Xg, dim=1, left=False).tensor(), rpp.cummul(Xg, dim=1).tensor(), Xg.cumprod(dim=1).tensor(),
                Yg.Jinvp(ag).tensor(), Sg.Jinvp(b.to(DEV)).tensor(), wg.Jr()]
-        Xr = Xg.clone().requires_grad_(True)               # gradients: the reference's own scan on the activated Mul Functions
-        rpp.cumprod(Xr, dim=1).tensor().sum().backward()
-        assert Xr.grad is not None and bool(torch.isfinite(Xr.grad).all())
+        Xr = Xg.clone().requires_grad_(True)               # gradients: one node, backward = pplie_scan_se3_bwd
+        (rpp.cumprod(Xr, dim=1).tensor() * Wc.to(DEV)).sum().backward()
+        got_grad = (Xr.grad.tensor() if hasattr(Xr.grad, "tensor") else Xr.grad).double().cpu()
+        assert float((got_grad - want_grad.double()).abs().max()) <= tol * float(want_grad.abs().max())
     finally:
         activate.deactivate()
     for g, wv in zip(got, want):
         assert float((g.double().cpu() - wv.double()).abs().max()) <= tol * max(1.0, float(wv.abs().max()))
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-9), (torch.float32, 3e-5)])
+def test_training_through_the_activated_reference_imu(rpp, dtype, tol):
+    """gradients w.r.t. gyro / acc through the ACTIVATED reference module (fused forward + pplie_imu_integrate_bwd) against the
+    reference's own autograd on the CPU in fp64"""
+    from pypose_amd import activate
+    dt, gyro, acc = _imu_inputs(6, 200, torch.float64, "cpu")
+    Wp, Wr = torch.randn(6, 200, 3, dtype=torch.float64), torch.randn(6, 200, 4, dtype=torch.float64)
+
+    def grads(dev, D):
+        g, a = gyro.detach().clone().to(D).to(dev).requires_grad_(True), acc.detach().clone().to(D).to(dev).requires_grad_(True)
+        integ = rpp.module.IMUPreintegrator(pos=torch.zeros(3, dtype=D), rot=rpp.identity_SO3(dtype=D),
+                                            vel=torch.zeros(3, dtype=D), prop_cov=False, reset=True).to(D).to(dev)
+        o = integ(dt=dt.to(D).to(dev), gyro=g, acc=a)
+        ((o["pos"] * Wp.to(D).to(dev)).sum() + (o["rot"].tensor() * Wr.to(D).to(dev)).sum()).backward()
+        return g.grad.double().cpu(), a.grad.double().cpu()
+    want = grads("cpu", torch.float64)
+    activate.activate(rpp, module=True)
+    try:
+        got = grads(DEV, dtype)
+    finally:
+        activate.deactivate()
+    for x, y in zip(got, want):
+        assert float((x - y).abs().max()) <= tol * float(y.abs().max())
