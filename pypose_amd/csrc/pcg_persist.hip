@@ -769,3 +769,25 @@ PPLIE_P2P(f64, double)
   }
 PPLIE_GHOST(f32, float)
 PPLIE_GHOST(f64, double)
+
+// Peer access for the hand-off tables of the multi-GPU solve: the kernel of GPU `device` stores into (and polls) tables that
+// live in the memory of GPU `peer` (hipIpc-mapped by the caller).  Returns 0 when `device` can reach `peer`'s memory after the
+// call (already enabled counts), PPLIE_ECAPACITY (-3) when the hardware offers no peer path -- the caller then keeps the
+// RCCL exchange --, PPLIE_ELAUNCH (-2) on any other runtime error.  The calling thread's current device is left as it was.
+extern "C" int pplie_enable_peer_access(int device, int peer) {
+  using namespace pplie;
+  if (device < 0 || peer < 0) return PPLIE_EBADARG;
+  if (device == peer) return PPLIE_OK;
+  int can = 0;
+  if (hipDeviceCanAccessPeer(&can, device, peer) != hipSuccess) { (void)hipGetLastError(); return PPLIE_ELAUNCH; }
+  if (!can) return PPLIE_ECAPACITY;
+  int cur = -1;
+  if (hipGetDevice(&cur) != hipSuccess) { (void)hipGetLastError(); return PPLIE_ELAUNCH; }
+  int rc = PPLIE_OK;
+  if (hipSetDevice(device) != hipSuccess) { (void)hipGetLastError(); return PPLIE_ELAUNCH; }
+  const hipError_t e = hipDeviceEnablePeerAccess(peer, 0);
+  if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) rc = PPLIE_ELAUNCH;
+  (void)hipGetLastError();
+  if (cur >= 0) (void)hipSetDevice(cur);
+  return rc;
+}

@@ -170,6 +170,14 @@ def p2p_exchange_tables(rk, group):
                 rpart.append(f1(*a1))
             except Exception as e:                                       # (peer memory not mappable from this process)
                 err = err or e
+    # the kernel of THIS rank's GPU stores into the peers' tables: peer access from our device to every device that owns one
+    mine_dev = rk.ptag.device.index
+    fn = _C.library().symbol("pplie_enable_peer_access", [ctypes.c_int, ctypes.c_int])
+    for t in ptag:
+        if err is None and t.device.index != mine_dev:
+            code = fn(mine_dev, t.device.index)
+            if code != 0:
+                err = RuntimeError(f"no peer access from cuda:{mine_dev} to cuda:{t.device.index} (status {code})")
     dist.barrier(group=group)                                            # every table exists and is mapped everywhere
     if err is not None:
         raise err

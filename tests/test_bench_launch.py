@@ -20,7 +20,9 @@ def _run(args, env_extra=None, timeout=600):
                        cwd=ROOT)
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert r.returncode == 0 and len(lines) == 1, (r.returncode, r.stdout[-2000:], r.stderr[-3000:])
-    return json.loads(lines[0])
+    out = json.loads(lines[0])
+    out["_stderr"] = r.stderr
+    return out
 
 
 def test_two_ranks_self_launched_dry_run():
@@ -29,12 +31,17 @@ def test_two_ranks_self_launched_dry_run():
     assert out["config"]["launch"].startswith("self-launched")
     assert out["value"] > 0 and out["scaling"] == "weak"
     assert out["ranks_seen"] == 2
-    for leg in ("lm_invnet_sharded", "imu_sharded", "lm_pgo_sharded", "lm_pgo_replicated", "lm_pgo_node_sharded"):
+    for leg in ("lm_invnet_sharded", "imu_sharded", "lm_pgo_replicated", "lm_pgo_node_sharded"):
         assert "error" not in out[leg], (leg, out[leg])
         assert out[leg]["n_gpus"] == 2 and out[leg]["value"] > 0
-    assert out["lm_pgo_sharded"]["losses"][-1] < out["lm_pgo_sharded"]["losses"][0]
+    assert out["lm_pgo_replicated"]["losses"][-1] < out["lm_pgo_replicated"]["losses"][0]
     assert out["lm_pgo_node_sharded"]["mode"].startswith("node-sharded solve")
-    assert out["lm_pgo_node_sharded"]["losses"] == pytest.approx(out["lm_pgo_sharded"]["losses"], rel=1e-4)
+    assert out["lm_pgo_node_sharded"]["losses"] == pytest.approx(out["lm_pgo_replicated"]["losses"], rel=1e-4)
+    assert "deferred" in out["lm_pgo_sharded"]                     # the library-default leg runs after the line is out
+    post = [l for l in out["_stderr"].splitlines() if l.startswith("PPLIE_BENCH_POSTLINE ")]
+    assert len(post) == 1
+    leg = json.loads(post[0].split(" ", 1)[1])["lm_pgo_sharded"]
+    assert "error" not in leg and leg["ranks_seen"] == 2 and leg["effective"]["shard"] == "edges"      # (gloo group: no node shards)
 
 
 def test_single_process_dry_run_has_every_config():
