@@ -142,7 +142,7 @@ def _activate_jinvp_jr(pypose, force):
     cls.Jr = Jr
 
 
-_IMU_HELPERS = ("_fused_ok", "_rij_offset", "_bcast", "_gravity_host", "_fused_cov2", "_fused_integrate", "_launch_integrate")
+_IMU_HELPERS = ("_fused_ok", "_rij_offset", "_bcast", "_gravity_host", "_fused_cov2", "_fused_integrate", "_launch_integrate", "_isotropic")
 
 
 def _activate_imu(pypose):

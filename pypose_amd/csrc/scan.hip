@@ -1039,8 +1039,12 @@ template <class T> struct MulImuP {
 
 // one step of the backward recurrence  P <- A_j P  on the structured state (S, X, Y, t); optionally (ACC) first adds the
 // step's noise term  P Bc_j P^T  to the accumulators
-template <class T, bool ACC>
-__device__ __forceinline__ void imu_cov_step(T* P, T h, const T* gy, const T* av, const T* qij, const T* dg, const T* da, T* acc) {
+// ISO (with ACC): the accelerometer noise is isotropic and the same for every step (the module's default: one scalar), so
+// Rij Ca Rij^T = ca I and the U-term of a step is ca h [0; I; tu I][..]^T: three SCALAR sums (h, h tu, h tu^2 in uacc) instead of
+// a 3x3 congruence and 39 accumulator updates per step
+template <class T, bool ACC, bool ISO = false>
+__device__ __forceinline__ void imu_cov_step(T* P, T h, const T* gy, const T* av, const T* qij, const T* dg, const T* da, T* acc,
+                                             T* uacc = nullptr) {
   T S[9], Rj[9], M1[9], G[9];
   quat_matrix<T>(P, S);
   quat_matrix<T>(qij, Rj);
@@ -1062,21 +1066,27 @@ __device__ __forceinline__ void imu_cov_step(T* P, T h, const T* gy, const T* av
 #pragma unroll
       for (int k = 0; k < 3; ++k) Vd[r * 3 + k] = V[r * 3 + k] * (h * dg[k]);
     T Wa[9];
+    if (ISO) {
+      uacc[0] += h;
+      uacc[1] += h * tu;
+      uacc[2] += h * tu * tu;
+    } else {
 #pragma unroll
-    for (int rr = 0; rr < 3; ++rr)
+      for (int rr = 0; rr < 3; ++rr)
 #pragma unroll
-      for (int cc = rr; cc < 3; ++cc) {
-        const T ww = h * (Rj[rr * 3] * da[0] * Rj[cc * 3] + Rj[rr * 3 + 1] * da[1] * Rj[cc * 3 + 1] + Rj[rr * 3 + 2] * da[2] * Rj[cc * 3 + 2]);
-        Wa[rr * 3 + cc] = ww;
-        Wa[cc * 3 + rr] = ww;
-      }
+        for (int cc = rr; cc < 3; ++cc) {
+          const T ww = h * (Rj[rr * 3] * da[0] * Rj[cc * 3] + Rj[rr * 3 + 1] * da[1] * Rj[cc * 3 + 1] + Rj[rr * 3 + 2] * da[2] * Rj[cc * 3 + 2]);
+          Wa[rr * 3 + cc] = ww;
+          Wa[cc * 3 + rr] = ww;
+        }
+    }
 #pragma unroll
     for (int r = 0; r < 9; ++r)
 #pragma unroll
       for (int c = r; c < 9; ++c) {
         const int e = r * 9 - (r * (r - 1)) / 2 + (c - r);
         T sacc = Vd[r * 3] * V[c * 3] + Vd[r * 3 + 1] * V[c * 3 + 1] + Vd[r * 3 + 2] * V[c * 3 + 2];
-        if (r >= 3) {
+        if (!ISO && r >= 3) {
           const T f = (r < 6 ? T(1) : tu) * (c < 6 ? T(1) : tu);
           sacc += f * Wa[(r % 3) * 3 + (c % 3)];
         }
@@ -1106,7 +1116,7 @@ __device__ __forceinline__ void imu_cov_step(T* P, T h, const T* gy, const T* av
   P[22] += h;
 }
 
-template <class T, int WAVES, int LS>
+template <class T, int WAVES, int LS, bool ISO>
 __global__ void __launch_bounds__(WAVES * 64, 3)
 imu_cov_seg_kernel(const T* __restrict__ dt, const T* __restrict__ gyro, const T* __restrict__ accel, const T* __restrict__ rout,
                    const T* __restrict__ rw, const T* __restrict__ C, const T* __restrict__ init_cov, const T* __restrict__ gyro_cov,
@@ -1131,14 +1141,19 @@ imu_cov_seg_kernel(const T* __restrict__ dt, const T* __restrict__ gyro, const T
   T dg0[3], da0[3];
 #pragma unroll
   for (int i = 0; i < 3; ++i) { dg0[i] = gyro_cov[b * gc_sb + i]; da0[i] = acc_cov[b * ac_sb + i]; }
+  // ISO: the caller vouches for ONE isotropic accelerometer variance for every sequence and step (launcher below)
+  constexpr bool iso = ISO;
+  T uacc[3] = {T(0), T(0), T(0)};
   const int64_t CH = 64 * LS;
   const int64_t nchunks = (F + CH - 1) / CH;
   const int seg = 63 - lane;                      // lanes walk a chunk's segments backwards: a suffix over steps is a prefix over lanes
   for (int64_t ch = nchunks - 1; ch >= 0; --ch) {
     const int64_t j0 = ch * CH + (int64_t)seg * LS;
     // ---- this segment's steps: raw inputs -> (h, gyro, a, Rij), parked in lane-private LDS slots for the two walks
-    // (11 values per step; held in registers the unrolled walks need > 256 VGPRs)
-#pragma unroll 1
+    // (11 values per step; held in registers the unrolled walks need > 256 VGPRs).  Unrolled: the raw loads of all LS steps are
+    // independent and go out together -- rolled up, every step of the segment paid its own HBM round trip, LS of them per chunk
+    // on the critical path of a wave that has only two others on its SIMD to hide behind.
+#pragma unroll
     for (int s = 0; s < LS; ++s) {
       const int64_t j = j0 + s;
       const bool ok = j < F;
@@ -1174,13 +1189,39 @@ imu_cov_seg_kernel(const T* __restrict__ dt, const T* __restrict__ gyro, const T
       const T qij[4] = {slot[448], slot[512], slot[576], slot[640]};
       imu_cov_step<T, false>(P, slot[0], gy, av, qij, nullptr, nullptr, nullptr);
     }
-    // ---- scan over the lanes (later segments sit in lower lanes) and the later chunks' carry
-    wave_scan<T, MulImuP<T>>(P, carry, true, true, lane);
+    // ---- scan over the lanes (later segments sit in lower lanes) and the later chunks' carry.
+    // Incl(l) = L_l Incl(l-1), Incl(-1) = carry, in the structured form (S, X, Y, t) with  c = a b:  S_c = S_a S_b,
+    // X_c = X_a R(S_b) + X_b,  Y_c = Y_a R(S_b) + t_a X_b + Y_b,  t_c = t_a + t_b.  Unrolled over the lanes, only the rotation
+    // part is a PRODUCT scan; with E(l) = Incl(l-1) the rest are plain prefix sums of transported terms:
+    //   X_incl = carry.X + prefix( X_l R(S_E(l)) ),   Y_incl = carry.Y + prefix( Y_l R(S_E(l)) + t_l X_E(l) ),   t_incl = carry.t + prefix(t_l)
+    // -- 7 DPP steps of a quaternion product and 19 scalar prefix sums instead of 7 steps of the 23-value structured product
+    // (two 3x3 matrix products each): ~400 instead of ~1390 VALU instructions per chunk.
     T Q[23];                                     // exclusive: everything behind this segment
+    {
+      T Sq[4] = {P[0], P[1], P[2], P[3]}, cS[4] = {carry[0], carry[1], carry[2], carry[3]};
+      wave_scan<T, MulSO3<T>>(Sq, cS, true, true, lane);
 #pragma unroll
-    for (int i = 0; i < 23; ++i) Q[i] = lane_shift_up1(P[i], carry[i]);
+      for (int i = 0; i < 4; ++i) Q[i] = lane_shift_up1(Sq[i], cS[i]);
+      T Re[9], Xh[9], Yh[9];
+      quat_matrix<T>(Q, Re);
+      mat3_mul<T>(P + 4, Re, Xh);
+      mat3_mul<T>(P + 13, Re, Yh);
+      const T tl = P[22];
 #pragma unroll
-    for (int i = 0; i < 23; ++i) carry[i] = lane_bcast63(P[i]);
+      for (int i = 0; i < 9; ++i) {
+        const T xi = wave_prefix_add<T>(Xh[i]) + carry[4 + i];
+        Q[4 + i] = lane_shift_up1(xi, carry[4 + i]);
+        const T yi = wave_prefix_add<T>(Yh[i] + tl * Q[4 + i]) + carry[13 + i];
+        Q[13 + i] = lane_shift_up1(yi, carry[13 + i]);
+        carry[4 + i] = lane_bcast63(xi);
+        carry[13 + i] = lane_bcast63(yi);
+      }
+      const T ti = wave_prefix_add<T>(tl) + carry[22];
+      Q[22] = lane_shift_up1(ti, carry[22]);
+      carry[22] = lane_bcast63(ti);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) carry[i] = lane_bcast63(Sq[i]);
+    }
     // ---- walk 2: the true suffix products and the noise terms
 #pragma unroll 1
     for (int s = LS - 1; s >= 0; --s) {
@@ -1196,7 +1237,15 @@ imu_cov_seg_kernel(const T* __restrict__ dt, const T* __restrict__ gyro, const T
       const T* slot = sd + ((size_t)(wv * LS + s) * 11) * 64 + lane;
       const T gy[3] = {slot[64], slot[128], slot[192]}, av[3] = {slot[256], slot[320], slot[384]};
       const T qij[4] = {slot[448], slot[512], slot[576], slot[640]};
-      imu_cov_step<T, true>(Q, slot[0], gy, av, qij, dg, da, acc);
+      imu_cov_step<T, true, ISO>(Q, slot[0], gy, av, qij, dg, da, acc, uacc);
+    }
+  }
+  if (iso) {                                      // ca (sum h) I, ca (sum h tu) I, ca (sum h tu^2) I on the diagonals of the U blocks
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      acc[(3 + i) * 9 - ((3 + i) * (2 + i)) / 2] += da0[0] * uacc[0];                    // (3+i, 3+i)
+      acc[(3 + i) * 9 - ((3 + i) * (2 + i)) / 2 + 3] += da0[0] * uacc[1];                // (3+i, 6+i)
+      acc[(6 + i) * 9 - ((6 + i) * (5 + i)) / 2] += da0[0] * uacc[2];                    // (6+i, 6+i)
     }
   }
 #pragma unroll
@@ -1259,17 +1308,24 @@ int imu_cov2_launch(const void* dt, const void* gyro, const void* acc, const voi
   }
   constexpr int WAVES = 2;
   const int64_t blocks = (B + WAVES - 1) / WAVES;
-#define PPLIE_COV2(LSN)                                                                                                        \
-  hipLaunchKernelGGL((imu_cov_seg_kernel<T, WAVES, LSN>), dim3((unsigned)blocks), dim3(WAVES * 64), 0,                          \
+  // ac_sb == 0 && ac_sf == -1: the caller states that acc_cov is ONE isotropic variance (acc_cov[0] == [1] == [2]) shared by every
+  // sequence and step -- the module's default noise model -- which turns the accelerometer part of every step's noise term into
+  // three scalar sums (imu_cov_step ISO)
+  const bool iso = ac_sb == 0 && ac_sf == -1;
+  if (iso) ac_sf = 0;
+#define PPLIE_COV2K(LSN, ISOV)                                                                                                  \
+  hipLaunchKernelGGL((imu_cov_seg_kernel<T, WAVES, LSN, ISOV>), dim3((unsigned)blocks), dim3(WAVES * 64), 0,                    \
                      reinterpret_cast<hipStream_t>(stream), (const T*)dt, (const T*)gyro, (const T*)acc, (const T*)rout,        \
                      (const T*)rw, (const T*)C, (const T*)init_cov, (const T*)gc, gc_sb, gc_sf, (const T*)ac, ac_sb, ac_sf, (T)g[0], \
                      (T)g[1], (T)g[2], (T*)cov, B, F)
+#define PPLIE_COV2(LSN) { if (iso) PPLIE_COV2K(LSN, true); else PPLIE_COV2K(LSN, false); }
   const char* env = getenv("PPLIE_IMU_COV_LS");                   // tuning switch: steps per lane
   const int ls = env ? atoi(env) : 4;
-  if (F <= 128 || ls == 2) PPLIE_COV2(2);
-  else if (ls == 8) PPLIE_COV2(8);
-  else PPLIE_COV2(4);
+  if (F <= 128 || ls == 2) PPLIE_COV2(2)
+  else if (ls == 8) PPLIE_COV2(8)
+  else PPLIE_COV2(4)
 #undef PPLIE_COV2
+#undef PPLIE_COV2K
   return hipGetLastError() == hipSuccess ? SC_OK : SC_ELAUNCH;
 }
 

@@ -240,6 +240,14 @@ class IMUPreintegrator(nn.Module):
         cache[slot] = (t, raw._version, out)
         return out
 
+    def _isotropic(self, cv):
+        """is this (single-row) covariance one value three times?  Read back once per tensor object and version."""
+        hit = self.__dict__.get('_iso_cache')
+        if hit is None or hit[0] is not cv or hit[1] != cv._version:
+            v = cv.reshape(-1).tolist()
+            hit = self.__dict__['_iso_cache'] = (cv, cv._version, len(v) == 3 and v[0] == v[1] == v[2])
+        return hit[2]
+
     def _gravity_host(self):
         """the gravity vector as a C array (read back once per value: the buffer lives on the device)"""
         gt = self.gravity
@@ -260,6 +268,8 @@ class IMUPreintegrator(nn.Module):
             return cv, (cv.stride(0) if cv.shape[0] > 1 else 0), (cv.stride(1) if cv.shape[1] > 1 else 0)
         gc, gsb, gsf = strided(gyro_cov)
         ac, asb, asf = strided(acc_cov)
+        if asb == 0 and asf == 0 and self._isotropic(acc_cov):
+            asf = -1          # one isotropic variance for every sequence and step (the default noise model): scalar sums in the kernel
         ic = self._bcast('cov0', init_cov if init_cov.dtype == dt.dtype else init_cov.to(dt.dtype), B, 81)
         ro = torch.Tensor.as_subclass(rot_out, torch.Tensor).contiguous()
         rw = torch.Tensor.as_subclass(rot, torch.Tensor).expand(B, F, 4).contiguous() if rot is not None else ro
