@@ -474,7 +474,7 @@ def pgo_lm_rate(dev, nodes=10_000, edges=40_000, steps=3, reps=5, with_static=Tr
                 "algorithmic_bytes_per_pcg_iteration": it_bytes, "mean_pcg_iterations": its_mean,
                 "us_per_pcg_iteration_incl_step_overheads": dt * 1e6 / max(its_mean, 1.0),
                 "per": "LM step (linearise + mean PCG iterations x packed blocks 84 B/incidence, D and Binv 144 B/node each, vectors)",
-                "note": "the iteration is bound by the rate the memory system serves its gathers (profiles/r04/pcg2_100k_experiments.md: "
+                "note": "the iteration is bound by the rate the memory system serves its gathers (profiles/r04/EXPERIMENTS.md: "
                         "waves 66 % parked on s_waitcnt, insensitive to occupancy and to trips per wave), counted fetch 1.5x algorithmic"}
     out = {"metric": f"LM iters/sec (PGO {nodes} poses / {edges} edges)", "value": 1.0 / dt, "unit": "LM steps/s", "nodes": nodes,
            "edges": edges, "path": opt.linearization, "initial_loss": l0, "losses": losses, "pcg_iterations": its,
