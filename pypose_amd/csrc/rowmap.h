@@ -287,15 +287,23 @@ template <class Op> struct TileOf {
   static constexpr int sumw = Op::IW0 + Op::IW1 + Op::IW2 + Op::OW0 + Op::OW1;
   static constexpr int rpt32 = sumw <= 14 ? 2 : 1;
   static constexpr int rpt64 = 1;
+  static constexpr int block32 = 256;          // workgroup size of the fp32 build
+  static constexpr bool roll32 = false;        // rows of a lane one after the other (register footprint of a single row)
 };
 #define PPLIE_TILE(OP, RPT32) \
-  template <> struct TileOf<OP<float>> { static constexpr int rpt32 = RPT32; static constexpr int rpt64 = 1; };
+  template <> struct TileOf<OP<float>> { static constexpr int rpt32 = RPT32; static constexpr int rpt64 = 1; \
+                                         static constexpr int block32 = 256; static constexpr bool roll32 = false; };
+// full shape: rows per lane, workgroup size, rolled rows (tools/tune_general.py measures the candidates at 10 M rows)
+#define PPLIE_TILE_EX(OP, RPT32, BLOCK32, ROLL32) \
+  template <> struct TileOf<OP<float>> { static constexpr int rpt32 = RPT32; static constexpr int rpt64 = 1; \
+                                         static constexpr int block32 = BLOCK32; static constexpr bool roll32 = ROLL32; };
 
 // C-ABI export of one op in both precisions (uniform signature, see include/pplie.h).
 #define PPLIE_EXPORT(SYM, OP)                                                                                    \
   extern "C" int SYM##_f32(const void* i0, const void* i1, const void* i2, void* o0, void* o1, int64_t n,        \
                            void* stream) {                                                                       \
-    return pplie::launch_rowmap<float, OP<float>, pplie::TileOf<OP<float>>::rpt32>(i0, i1, i2, o0, o1, n, stream); \
+    return pplie::launch_rowmap<float, OP<float>, pplie::TileOf<OP<float>>::rpt32, pplie::TileOf<OP<float>>::block32,  \
+                                pplie::TileOf<OP<float>>::roll32>(i0, i1, i2, o0, o1, n, stream);                    \
   }                                                                                                              \
   extern "C" int SYM##_f64(const void* i0, const void* i1, const void* i2, void* o0, void* o1, int64_t n,        \
                            void* stream) {                                                                       \

@@ -9,7 +9,9 @@ lib = _C.library()
 SIG = [ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 5 + [ctypes.c_int64, ctypes.c_void_p]
 st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 ops = {"se3_exp_bwd": ((6, 7), (6,)), "se3_log_bwd": ((6, 6), (7,)), "se3_mul_fwd": ((7, 7), (7,)),
-       "se3_mul_bwd": ((7, 7), (7, 7)), "se3_act_bwd": ((7, 3, 3), (7, 3))}
+       "se3_mul_bwd": ((7, 7), (7, 7)), "se3_act_bwd": ((7, 3, 3), (7, 3)), "se3_jinvp_fwd": ((7, 6), (6,)), "se3_adj_fwd": ((7, 6), (6,))}
+if len(sys.argv) > 1:
+    ops = {k: v for k, v in ops.items() if k in sys.argv[1:]}
 
 def med_ms(f, reps=30):
     for _ in range(5): f()
@@ -28,6 +30,8 @@ for name, (iw, ow) in ops.items():
     ins = [torch.randn(N, w, device=dev) for w in iw]
     if name in ("se3_exp_bwd", "se3_log_bwd"):
         ins[0] = pp.randn_se3(N, device=dev).tensor().contiguous()      # realistic angle distribution (both coefficient branches)
+    if name in ("se3_jinvp_fwd", "se3_adj_fwd"):
+        ins[0] = pp.randn_SE3(N, device=dev).tensor().contiguous()
     outs = [torch.empty(N, w, device=dev) for w in ow]
     P = lambda l, k: l[k].data_ptr() if k < len(l) else None
     for block in (128, 256, 1128, 1256):
