@@ -59,6 +59,9 @@ template <class T> struct Op_se3_reproj_fwd {
 };
 PPLIE_OP_3_2(Op_se3_reproj_lin, se3_reproj_lin, 7, 3, 11, 2, 18)
 PPLIE_OP_2_2(Op_reproj_vjp, reproj_vjp, 18, 2, 7, 3)
+// 41 scalars per row: a 256-row tile is 42 KB of LDS (3 workgroups per CU); 128 x 1 measured 141.8 -> 128.6 us at 4 M observations
+// (round 4; 64 x 1: 130.8; two rows per lane, rolled or not: 190-245)
+PPLIE_TILE_EX(Op_se3_reproj_lin, 1, 128, false)
 
 }  // namespace pplie
 
