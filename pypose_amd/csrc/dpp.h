@@ -20,7 +20,7 @@ template <int CTRL, int RM, int BM> __device__ __forceinline__ double dpp_mov(do
   return __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo);
 }
 enum { DPP_ROW_SHR1 = 0x111, DPP_ROW_SHR2 = 0x112, DPP_ROW_SHR3 = 0x113, DPP_ROW_SHR4 = 0x114, DPP_ROW_SHR8 = 0x118,
-       DPP_WAVE_SHR1 = 0x138, DPP_ROW_BCAST15 = 0x142, DPP_ROW_BCAST31 = 0x143 };
+       DPP_WAVE_SHL1 = 0x130, DPP_WAVE_SHR1 = 0x138, DPP_ROW_BCAST15 = 0x142, DPP_ROW_BCAST31 = 0x143 };
 
 // value of lane-1 (lane 0 receives `first`)
 template <class T> __device__ __forceinline__ T lane_shift_up1(T v, T first) { return dpp_mov<DPP_WAVE_SHR1, 0xf, 0xf>(first, v); }

@@ -15,6 +15,7 @@
 // node vectors [N][M].  Scatter uses hardware fp atomics (-munsafe-fp-atomics).
 #include "rowmap.h"
 #include "chol.h"
+#include "dpp.h"
 
 namespace pplie {
 
@@ -1091,11 +1092,21 @@ pcg2_spmv_kernel(const int* __restrict__ ptr, const int* __restrict__ other, con
           const int tii = i * M - (i * (i - 1)) / 2;
           const T* h0 = HB + (int64_t)c * NP + tii;
           const T* h1 = two ? h0 + NP : h0;
-          const T* q0 = p0 + i;
-          const T* q1 = p1 + i;
+          // The neighbour's p: lane i needs p_j for j >= i.  It loads p_i alone -- the node's M lanes read the row once, M dwords
+          // side by side -- and takes p_{i+k} from lane i + k by k wave-wide DPP shifts (VALU moves; the lanes of a node enter and
+          // leave this loop together, so the lanes a row looks at are live; what a shift brings in from the NEXT node's lanes is
+          // masked out below like the loads past a triangle row).  Reading the window p[i .. i + M - 1] per lane instead asked
+          // the memory pipeline for M times the bytes through M differently misaligned windows: ~30 % of this kernel's time.
           T l0[M], l1[M], r0[M], r1[M];
+          r0[0] = p0[i];
+          r1[0] = p1[i];
 #pragma unroll
-          for (int k = 0; k < M; ++k) { l0[k] = h0[k]; l1[k] = h1[k]; r0[k] = q0[k]; r1[k] = q1[k]; }     // (unconditional: merged loads)
+          for (int k = 0; k < M; ++k) { l0[k] = h0[k]; l1[k] = h1[k]; }                                   // (unconditional: merged loads)
+#pragma unroll
+          for (int k = 1; k < M; ++k) {
+            r0[k] = dpp_mov<DPP_WAVE_SHL1, 0xf, 0xf>(T(0), r0[k - 1]);
+            r1[k] = dpp_mov<DPP_WAVE_SHL1, 0xf, 0xf>(T(0), r1[k - 1]);
+          }
 #pragma unroll
           for (int k = 0; k < M; ++k) {
             const bool in = k < M - i;                               // (what lies beyond the row is somebody else's data: never multiplied)

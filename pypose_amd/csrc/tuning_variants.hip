@@ -41,6 +41,15 @@ PPLIE_OP_2_2(Var_se3_mul_bwd, se3_mul_bwd, 7, 7, 7, 7)
 PPLIE_OP_3_2(Var_se3_act_bwd, se3_act_bwd, 7, 3, 3, 7, 3)
 PPLIE_OP_2_1(Var_se3_jinvp_fwd, se3_jinvp, 7, 6, 6)
 PPLIE_OP_2_1(Var_se3_adj_fwd, se3_adj, 7, 6, 6)
+PPLIE_OP_3_2(Var_se3_jinvp_bwd, se3_jinvp_bwd, 7, 6, 6, 7, 6)
+PPLIE_OP_1_1(Var_sim3_exp_fwd, sim3_exp, 7, 8)
+PPLIE_OP_1_1(Var_sim3_log_fwd, sim3_log, 8, 7)
+PPLIE_OP_2_1(Var_sim3_exp_bwd, sim3_exp_bwd, 7, 8, 7)
+PPLIE_OP_2_1(Var_sim3_log_bwd, sim3_log_bwd, 7, 7, 8)
+PPLIE_OP_1_1(Var_se3_exp_fwd, se3_exp, 6, 7)
+PPLIE_OP_1_1(Var_se3_log_fwd, se3_log, 7, 6)
+PPLIE_OP_2_1(Var_se3_act_fwd, se3_act, 7, 3, 3)
+PPLIE_OP_2_1(Var_se3_inv_bwd, se3_inv_bwd, 7, 7, 7)
 template <class Op>
 int var_general(int rpt, int block, const void* a, const void* b, const void* c, void* o, void* p, int64_t n, void* st) {
   // block: 256 / 128 = unrolled rows ; 1256 / 1128 = rolled rows (one row's registers at a time)
@@ -74,6 +83,15 @@ PPLIE_VAR_GENERAL(se3_mul_bwd)
 PPLIE_VAR_GENERAL(se3_act_bwd)
 PPLIE_VAR_GENERAL(se3_jinvp_fwd)
 PPLIE_VAR_GENERAL(se3_adj_fwd)
+PPLIE_VAR_GENERAL(se3_jinvp_bwd)
+PPLIE_VAR_GENERAL(sim3_exp_fwd)
+PPLIE_VAR_GENERAL(sim3_log_fwd)
+PPLIE_VAR_GENERAL(sim3_exp_bwd)
+PPLIE_VAR_GENERAL(sim3_log_bwd)
+PPLIE_VAR_GENERAL(se3_exp_fwd)
+PPLIE_VAR_GENERAL(se3_log_fwd)
+PPLIE_VAR_GENERAL(se3_act_fwd)
+PPLIE_VAR_GENERAL(se3_inv_bwd)
 
 // device-copy ceiling: nbytes must be a multiple of 16
 extern "C" int pplie_var_copy(const void* src, void* dst, int64_t nbytes, int grid, void* stream) {

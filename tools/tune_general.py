@@ -9,7 +9,10 @@ lib = _C.library()
 SIG = [ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 5 + [ctypes.c_int64, ctypes.c_void_p]
 st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 ops = {"se3_exp_bwd": ((6, 7), (6,)), "se3_log_bwd": ((6, 6), (7,)), "se3_mul_fwd": ((7, 7), (7,)),
-       "se3_mul_bwd": ((7, 7), (7, 7)), "se3_act_bwd": ((7, 3, 3), (7, 3)), "se3_jinvp_fwd": ((7, 6), (6,)), "se3_adj_fwd": ((7, 6), (6,))}
+       "se3_mul_bwd": ((7, 7), (7, 7)), "se3_act_bwd": ((7, 3, 3), (7, 3)), "se3_jinvp_fwd": ((7, 6), (6,)), "se3_adj_fwd": ((7, 6), (6,)),
+       "se3_jinvp_bwd": ((7, 6, 6), (7, 6)), "sim3_exp_fwd": ((7,), (8,)), "sim3_log_fwd": ((8,), (7,)), "sim3_exp_bwd": ((7, 8), (7,)),
+       "sim3_log_bwd": ((7, 7), (8,)), "se3_exp_fwd": ((6,), (7,)), "se3_log_fwd": ((7,), (6,)), "se3_act_fwd": ((7, 3), (3,)),
+       "se3_inv_bwd": ((7, 7), (7,))}
 if len(sys.argv) > 1:
     ops = {k: v for k, v in ops.items() if k in sys.argv[1:]}
 
@@ -28,10 +31,14 @@ for name, (iw, ow) in ops.items():
     fn = lib.symbol(f"pplie_var_{name}_f32", SIG)
     import pypose_amd as pp
     ins = [torch.randn(N, w, device=dev) for w in iw]
-    if name in ("se3_exp_bwd", "se3_log_bwd"):
+    if name in ("se3_exp_bwd", "se3_log_bwd", "se3_exp_fwd"):
         ins[0] = pp.randn_se3(N, device=dev).tensor().contiguous()      # realistic angle distribution (both coefficient branches)
-    if name in ("se3_jinvp_fwd", "se3_adj_fwd"):
+    if name in ("se3_jinvp_fwd", "se3_adj_fwd", "se3_jinvp_bwd", "se3_log_fwd", "se3_act_fwd", "se3_inv_bwd"):
         ins[0] = pp.randn_SE3(N, device=dev).tensor().contiguous()
+    if name in ("sim3_exp_fwd", "sim3_exp_bwd", "sim3_log_bwd"):
+        ins[0] = pp.randn_sim3(N, device=dev).tensor().contiguous()
+    if name == "sim3_log_fwd":
+        ins[0] = pp.randn_Sim3(N, device=dev).tensor().contiguous()
     outs = [torch.empty(N, w, device=dev) for w in ow]
     P = lambda l, k: l[k].data_ptr() if k < len(l) else None
     for block in (128, 256, 1128, 1256):
@@ -42,4 +49,5 @@ for name, (iw, ow) in ops.items():
             nb = 4 * N * (sum(iw) + sum(ow))
             rec = {"op": name, "block": block, "rpt": rpt, "ms": ms, "GBps": nb / ms / 1e6}
             res.append(rec); print(rec, flush=True)
+os.makedirs("gpurun_out", exist_ok=True)
 json.dump(res, open("gpurun_out/tune_general.json", "w"), indent=1)
