@@ -40,6 +40,9 @@ HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 # VALU issue peak: 256 CUs x 4 SIMD-32, a wave64 VALU instruction occupies its SIMD for 2 cycles, 2.4 GHz (MI355X_MICROARCH.md
 # "Wave scheduling" / per-instruction cycle constants): 256 * 4 * 2.4e9 / 2 wave-instructions per second
 VALU_PEAK_WAVE_INSTR = 256 * 4 * 2.4e9 / 2
+# what tools/micro/valu_rate.hip reaches of that peak with nothing but independent v_fma_f32 on 8 waves per SIMD (2.45 nominal cycles
+# per instruction; a DPP move costs 4.7, a reciprocal 8.4): profiles/r04/valu_rate.json -- the ceiling of a `bound: "valu"` fraction
+VALU_MEASURED_CEILING = 2.0 / 2.445
 
 
 def _pmc(name):
@@ -66,7 +69,8 @@ def valu_roofline(kernels, seconds, hbm_block=None):
         used[k] = {"SQ_INSTS_VALU_per_launch": e["SQ_INSTS_VALU"], "valu_per_wave": e.get("valu_per_wave"), "waves": e.get("SQ_WAVES")}
     ach = tot / seconds
     return {"bound": "valu", "unit": "wave64 VALU instructions/s", "achieved": ach, "peak": VALU_PEAK_WAVE_INSTR,
-            "frac": ach / VALU_PEAK_WAVE_INSTR, "kernels": used,
+            "frac": ach / VALU_PEAK_WAVE_INSTR, "frac_ceiling_measured": VALU_MEASURED_CEILING,
+            "ceiling_source": "profiles/r04/valu_rate.json (tools/micro/valu_rate.hip: plain v_fma_f32, 8 waves per SIMD)", "kernels": used,
             "counter_source": f"profiles/pmc_sq.json ({sq.get('_stamp', 'unstamped')}): rocprofv3 --pmc SQ_INSTS_VALU of an earlier run "
                               "of these kernels on this workload; the time is this run's", "hbm": hbm_block}
 

@@ -68,7 +68,12 @@ def _composed_bwd(y, g, key, dim, left):
             ident[..., -1] = 1
         yprev = torch.cat([ident, y.narrow(dim, 0, y.shape[dim] - 1)], dim=dim)
         out = rowvec(rsum(gt), yprev)
-    return torch.cat([out, torch.zeros_like(out[..., :1])], dim=-1)
+    # last (padding) component: zero, except the first element's, which passes through (its factor enters no Mul node on the
+    # reference's route either: basics/ops.py:27-36 never touches element 0) -- same values as the kernel
+    L = y.shape[dim]
+    last = torch.cat([g.narrow(dim, 0, 1)[..., D:], torch.zeros_like(out.narrow(dim, 1, L - 1)[..., :1])], dim=dim) if L > 1 \
+        else g[..., D:]
+    return torch.cat([out, last], dim=-1)
 
 
 class _GroupScan(torch.autograd.Function):

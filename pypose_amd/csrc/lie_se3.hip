@@ -13,5 +13,7 @@ PPLIE_TILE(Op_se3_adj_fwd, 2)
 PPLIE_TILE_EX(Op_se3_jinvp_bwd, 1, 128, false)
 PPLIE_TILE_EX(Op_se3_mul_fwd, 4, 128, false)
 PPLIE_TILE_EX(Op_se3_inv_bwd, 4, 128, false)
+PPLIE_TILE(Op_se3_adjt_fwd, 2)
+PPLIE_TILE(Op_se3_act_fwd, 1)
 }
 PPLIE_EXPORT_GROUP(se3)

@@ -115,6 +115,14 @@ def test_scan_autograd_contract():
     g1, = torch.autograd.grad((Y.tensor() * W).sum(), X, create_graph=True)
     g1 = g1.tensor() if hasattr(g1, "tensor") else g1
     assert g1.requires_grad
+    g0, = torch.autograd.grad((Y.tensor() * W).sum(), X)                       # the kernel's values
+    torch.testing.assert_close(g1.detach(), g0.tensor() if hasattr(g0, "tensor") else g0, rtol=1e-9, atol=1e-9)
+    for left in (True, False):                                                 # (and for left products)
+        Yl = pp.cumprod(X, dim=1, left=left)
+        a, = torch.autograd.grad((Yl.tensor() * W).sum(), X, create_graph=True)
+        b, = torch.autograd.grad((Yl.tensor() * W).sum(), X)
+        tt = lambda t: t.tensor() if hasattr(t, "tensor") else t
+        torch.testing.assert_close(tt(a).detach(), tt(b), rtol=1e-9, atol=1e-9)
     g1.square().sum().backward()
     assert torch.isfinite(X.grad.tensor() if hasattr(X.grad, "tensor") else X.grad).all()
     # a non-contiguous cotangent and a scan along dim 0 with trailing batch dims
