@@ -56,7 +56,17 @@ class HipLibrary:
             fn.argtypes = _ROW_SIG if argtypes is None else argtypes
             fn.restype = ctypes.c_int
             self._fns[name] = fn
+        elif argtypes is not None and len(fn.argtypes) != len(argtypes):
+            fn.argtypes = argtypes          # (first resolved without a prototype: the caller that knows the signature wins)
         return fn
+
+    def address(self, name: str) -> int:
+        """entry address of an export (for the native autograd nodes, which call through function pointers); leaves the
+        ctypes prototype cache of ``symbol`` alone -- an entry first seen here must not get the row-operator signature"""
+        try:
+            return ctypes.cast(getattr(self.cdll, name), ctypes.c_void_p).value
+        except AttributeError as e:
+            raise AttributeError(f"pypose_amd: symbol {name} missing from {self.path}") from e
 
     def has(self, name: str) -> bool:
         try:

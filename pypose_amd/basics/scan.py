@@ -100,6 +100,30 @@ class _GroupScan(torch.autograd.Function):
         return _launch_bwd(x_in if ctx.left else y, g.contiguous(), ctx.key, ctx.dim, ctx.left), None, None, None
 
 
+NATIVE_NODE = True               # False: the Python autograd.Function instead of the C++ node (same kernels; tests compare)
+_rules, _addr = {}, {}
+
+
+def _native_scan(input, key, dim, left):
+    """_GroupScan as a C++ autograd node (csrc_torch/pplie_autograd.cpp ScanOp): a Python Function's backward costs ~100 us of host
+    time on the autograd engine's thread, more than the backward kernel of most scans.  None when the extension is not there."""
+    from ..lietensor import operation as _op
+    nat = _op._native() if NATIVE_NODE else None
+    if nat is None or not hasattr(nat, "scan_op"):
+        return None
+    rule = _rules.get(key)
+    if rule is None:
+        _op._native_state["rules"] += 1
+        rule = _rules[key] = _op._native_state["rules"]
+        nat.set_rule(rule, lambda y, g, d, lf, _k=key: _composed_bwd(_plain(y), _plain(g), _k, d, lf))
+    outer, L, inner = _geometry(input.shape, dim)
+    fns = _addr.get((key, input.dtype))
+    if fns is None:
+        sfx, lib = "_f32" if input.dtype == torch.float32 else "_f64", _C.library()
+        fns = _addr[(key, input.dtype)] = (lib.address(f"pplie_scan_{key}{sfx}"), lib.address(f"pplie_scan_{key}_bwd{sfx}"))
+    return nat.scan_op(input, fns[0], fns[1], outer * inner, L, inner, bool(left), rule, dim)
+
+
 def try_scan_(input, dim, left):
     """Scan ``input`` (a group LieTensor) in place along ``dim`` on the GPU; None if not applicable."""
     ltype = getattr(input, "ltype", None)
@@ -115,7 +139,8 @@ def try_scan_(input, dim, left):
     if torch.is_grad_enabled() and input.requires_grad:
         if not DIFFERENTIABLE_SCAN or torch._C._are_functorch_transforms_active() or input.is_leaf:
             return None       # transforms trace the composed route; a leaf raises there exactly as in the reference
-        return _GroupScan.apply(input, key, dim, left)
+        nat = _native_scan(input, key, dim, left)
+        return nat if nat is not None else _GroupScan.apply(input, key, dim, left)
     _launch_fwd(input, key, dim, left)
     _C.mark_written(input)                # the scan wrote through the raw pointer
     return input

@@ -124,10 +124,132 @@ at::Tensor row_op(const at::Tensor& a, const c10::optional<at::Tensor>& b, int64
 }
 
 void set_rule(int64_t key, py::object fn) { py_rules()[key] = std::move(fn); }
+
+// ---- IMU pre-integration (module/imu_preintegrator.py): pplie_imu_integrate / pplie_imu_integrate_bwd as ONE native node ----------
+// Training through the pre-integrator is two kernels (64 + 108 us at 4096 x 1024); as a Python Function the pair cost ~190 us of
+// host time per step (the backward runs on the engine's device thread behind the GIL) -- more than the kernels.  Same contract as
+// _ImuIntegrate in Python, for the case it is used in training: gradients w.r.t. dt / gyro / acc (the initial state's and a double
+// backward stay on the Python node).  C ABI: include/pplie.h.
+typedef int (*imufwd_t)(const void*, const void*, const void*, const void*, const void*, const void*, const void*, const void*,
+                        const double*, void*, void*, void*, void*, void*, void*, int64_t, int64_t, void*);
+typedef int (*imubwd_t)(const void*, const void*, const void*, const void*, const void*, const void*, const void*, const double*,
+                        const void*, const void*, const void*, void*, void*, void*, int64_t, int64_t, void*);
+
+struct ImuOp : public torch::autograd::Function<ImuOp> {
+  static variable_list forward(AutogradContext* ctx, const at::Tensor& dt, const at::Tensor& gyro, const at::Tensor& acc,
+                               const c10::optional<at::Tensor>& rot, const at::Tensor& r0, const at::Tensor& v0, const at::Tensor& p0,
+                               std::vector<double> gravity, int64_t fwd_fn, int64_t bwd_fn) {
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(dt.device());
+    const int64_t B = dt.size(0), F = dt.size(1);
+    at::Tensor orot = at::empty({B, F, 4}, dt.options()), ovel = at::empty({B, F, 3}, dt.options()), opos = at::empty({B, F, 3}, dt.options());
+    const int code = reinterpret_cast<imufwd_t>(fwd_fn)(
+        dt.data_ptr(), gyro.data_ptr(), acc.data_ptr(), rot.has_value() ? rot->data_ptr() : nullptr, r0.data_ptr(), v0.data_ptr(),
+        p0.data_ptr(), nullptr, gravity.data(), orot.data_ptr(), ovel.data_ptr(), opos.data_ptr(), nullptr, nullptr, nullptr, B, F,
+        (void*)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(dt.device().index()).stream());
+    TORCH_CHECK(code == 0, "pplie_imu_integrate failed with status ", code);
+    ctx->save_for_backward({dt, gyro, acc, rot.has_value() ? *rot : at::Tensor(), r0, orot, ovel});
+    ctx->saved_data["bwd_fn"] = bwd_fn;
+    ctx->saved_data["gravity"] = gravity;
+    return {orot, ovel, opos};
+  }
+
+  static variable_list backward(AutogradContext* ctx, variable_list grads) {
+    TORCH_CHECK(!at::GradMode::is_enabled(), "pplie: the fused IMU backward is not differentiable a second time "
+                                             "(IMUPreintegrator.fused_backward = False takes the composed route)");
+    variable_list s = ctx->get_saved_variables();
+    const at::Tensor &dt = s[0], &gyro = s[1], &acc = s[2], &rot = s[3], &r0 = s[4], &orot = s[5], &ovel = s[6];
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(dt.device());
+    const int64_t B = dt.size(0), F = dt.size(1);
+    at::Tensor g[3];
+    const int64_t w[3] = {4, 3, 3};
+    for (int k = 0; k < 3; ++k)
+      if (grads[(size_t)k].defined()) g[k] = grads[(size_t)k].expand({B, F, w[k]}).to(dt.options()).contiguous();
+    at::Tensor o_gyro = at::empty_like(gyro), o_acc = at::empty_like(acc), o_dt;
+    if (ctx->needs_input_grad(0)) o_dt = at::empty_like(dt);
+    std::vector<double> gravity = ctx->saved_data["gravity"].toDoubleVector();
+    auto P = [](const at::Tensor& t) -> void* { return t.defined() ? t.data_ptr() : nullptr; };
+    const int code = reinterpret_cast<imubwd_t>(ctx->saved_data["bwd_fn"].toInt())(
+        dt.data_ptr(), gyro.data_ptr(), acc.data_ptr(), P(rot), orot.data_ptr(), ovel.data_ptr(), r0.data_ptr(), gravity.data(), P(g[0]),
+        P(g[1]), P(g[2]), o_gyro.data_ptr(), o_acc.data_ptr(), P(o_dt), B, F,
+        (void*)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(dt.device().index()).stream());
+    TORCH_CHECK(code == 0, "pplie_imu_integrate_bwd failed with status ", code);
+    variable_list res(10);
+    res[0] = o_dt;
+    res[1] = o_gyro;
+    res[2] = o_acc;
+    return res;
+  }
+};
+
+variable_list imu_integrate(const at::Tensor& dt, const at::Tensor& gyro, const at::Tensor& acc, const c10::optional<at::Tensor>& rot,
+                            const at::Tensor& r0, const at::Tensor& v0, const at::Tensor& p0, std::vector<double> gravity, int64_t fwd_fn,
+                            int64_t bwd_fn) {
+  TORCH_CHECK(dt.dim() == 3 && dt.size(2) == 1 && plain(dt, dt) && plain(gyro, dt) && plain(acc, dt) && plain(r0, dt) && plain(v0, dt) &&
+                  plain(p0, dt) && (!rot.has_value() || plain(*rot, dt)) && gravity.size() == 3,
+              "pplie native IMU node: contiguous device tensors of one dtype");
+  const int64_t B = dt.size(0), F = dt.size(1);
+  TORCH_CHECK(gyro.numel() == B * F * 3 && acc.numel() == B * F * 3 && r0.numel() == B * 4 && v0.numel() == B * 3 && p0.numel() == B * 3 &&
+                  (!rot.has_value() || rot->numel() == B * F * 4),
+              "pplie native IMU node: [B, F, 1 / 3 / 3 (/ 4)] inputs and [B, 4 / 3 / 3] initial states");
+  return ImuOp::apply(dt, gyro, acc, rot, r0, v0, p0, gravity, fwd_fn, bwd_fn);
+}
+
+// ---- product scans (basics/scan.py): pplie_scan_<g> in place + pplie_scan_<g>_bwd as one native node ----------------------------
+typedef int (*scanfwd_t)(void*, int64_t, int64_t, int64_t, int, void*);
+typedef int (*scanbwd_t)(const void*, const void*, const void*, void*, int64_t, int64_t, int64_t, int, void*);
+
+struct ScanOp : public torch::autograd::Function<ScanOp> {
+  static at::Tensor forward(AutogradContext* ctx, at::Tensor x, int64_t fwd_fn, int64_t bwd_fn, int64_t nseq, int64_t L, int64_t inner,
+                            bool left, int64_t rule, int64_t dim) {
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(x.device());
+    ctx->mark_dirty({x});
+    // left products: the backward transports cotangents through the scan's own FACTORS (kept: the scan overwrites them)
+    at::Tensor x_in = left ? x.clone() : at::Tensor();
+    const int code = reinterpret_cast<scanfwd_t>(fwd_fn)(x.data_ptr(), nseq, L, inner, left ? 1 : 0,
+                                                         (void*)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(x.device().index()).stream());
+    TORCH_CHECK(code == 0, "pplie_scan failed with status ", code);
+    ctx->save_for_backward({x, x_in});
+    ctx->saved_data["bwd_fn"] = bwd_fn;
+    ctx->saved_data["geom"] = std::vector<int64_t>{nseq, L, inner, left ? 1 : 0, rule, dim};
+    return x;
+  }
+
+  static variable_list backward(AutogradContext* ctx, variable_list grads) {
+    variable_list s = ctx->get_saved_variables();
+    const std::vector<int64_t> geom = ctx->saved_data["geom"].toIntVector();
+    const bool left = geom[3] != 0;
+    variable_list res(9);
+    at::Tensor g = grads[0];
+    if (at::GradMode::is_enabled() || !g.has_storage()) {            // create_graph=True / batched cotangents: the Python rule
+      py::gil_scoped_acquire gil;
+      py::object rule = py_rules().at(geom[4]);
+      res[0] = rule(s[0], g, geom[5], left).cast<at::Tensor>();
+      return res;
+    }
+    const at::Tensor& ref = s[0];
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(ref.device());
+    if (!plain(g, ref) || g.sizes() != ref.sizes()) g = g.expand(ref.sizes()).to(ref.options()).contiguous();
+    at::Tensor gx = at::empty_like(ref);
+    const int code = reinterpret_cast<scanbwd_t>(ctx->saved_data["bwd_fn"].toInt())(
+        left ? s[1].data_ptr() : nullptr, left ? nullptr : ref.data_ptr(), g.data_ptr(), gx.data_ptr(), geom[0], geom[1], geom[2],
+        left ? 1 : 0, (void*)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(ref.device().index()).stream());
+    TORCH_CHECK(code == 0, "pplie_scan_bwd failed with status ", code);
+    res[0] = gx;
+    return res;
+  }
+};
+
+at::Tensor scan_op(at::Tensor x, int64_t fwd_fn, int64_t bwd_fn, int64_t nseq, int64_t L, int64_t inner, bool left, int64_t rule,
+                   int64_t dim) {
+  TORCH_CHECK(plain(x, x) && x.numel() == nseq * L * x.size(-1), "pplie native scan node: a contiguous device tensor");
+  return ScanOp::apply(x, fwd_fn, bwd_fn, nseq, L, inner, left, rule, dim);
+}
 }  // namespace
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.doc() = "native autograd nodes for the row operators of libpplie (pypose_amd/csrc_torch/pplie_autograd.cpp)";
   m.def("row_op", &row_op, "forward of one row operator recorded as a native autograd node");
   m.def("set_rule", &set_rule, "register the differentiable Python rule of an operator's backward (double backward)");
+  m.def("scan_op", &scan_op, "pplie_scan_<group> in place, recorded as a native autograd node (backward: pplie_scan_<group>_bwd)");
+  m.def("imu_integrate", &imu_integrate, "pplie_imu_integrate recorded as a native autograd node (backward: pplie_imu_integrate_bwd)");
 }

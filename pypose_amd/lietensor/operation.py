@@ -59,9 +59,7 @@ def _kernel_address(name, dtype):
     key = (name, dtype)
     hit = _native_state["ptr"].get(key)
     if hit is None:
-        import ctypes
-        fn = _C.library().symbol("pplie_" + name + ("_f32" if dtype == torch.float32 else "_f64"))
-        hit = _native_state["ptr"][key] = ctypes.cast(fn, ctypes.c_void_p).value
+        hit = _native_state["ptr"][key] = _C.library().address("pplie_" + name + ("_f32" if dtype == torch.float32 else "_f64"))
     return hit
 
 

@@ -46,6 +46,30 @@ def _qrot(q, p):
     return p + w * uv + torch.linalg.cross(v, uv)
 
 
+def _native_node(mod, dt, gyro, acc, rot, r0, v0, p0):
+    """The same node as _ImuIntegrate in C++ (csrc_torch/pplie_autograd.cpp ImuOp: a Python Function's backward runs on the autograd
+    engine's device thread behind the GIL, ~190 us of host time per training step around 172 us of kernels) for the training case:
+    gradients w.r.t. dt / gyro / acc.  None (-> the Python node) when the initial state needs a gradient, the extension is not
+    built, or the operands are not plain contiguous device tensors."""
+    from ..lietensor import operation as _op
+    nat = _op._native()
+    if nat is None or not hasattr(nat, "imu_integrate") or r0.requires_grad or v0.requires_grad or p0.requires_grad \
+            or not getattr(mod, 'native_backward', True):
+        return None
+    ts = (dt, gyro, acc) if rot is None else (dt, gyro, acc, rot)
+    if any(type(t) is not torch.Tensor or not t.is_contiguous() for t in ts) or dt.dim() != 3:
+        return None
+    B, F = dt.shape[:2]
+    if rot is not None and rot.shape != (B, F, 4):
+        return None
+    r0b, v0b, p0b = mod._bcast('r0', r0, B, 4), mod._bcast('v0', v0, B, 3), mod._bcast('p0', p0, B, 3)
+    g = mod.__dict__.get('_g_list')
+    if g is None or g[0] is not mod.gravity or g[1] != mod.gravity._version:
+        g = mod.__dict__['_g_list'] = (mod.gravity, mod.gravity._version, [float(x) for x in mod.gravity.tolist()])
+    return nat.imu_integrate(dt, gyro, acc, rot, r0b.detach(), v0b.detach(), p0b.detach(), g[2],
+                             _op._kernel_address("imu_integrate", dt.dtype), _op._kernel_address("imu_integrate_bwd", dt.dtype))
+
+
 class _ImuIntegrate(torch.autograd.Function):
     """``integrate`` + ``predict`` (reference :314-426) as ONE autograd node: forward ``pplie_imu_integrate``, backward
     ``pplie_imu_integrate_bwd`` (one reverse pass per sequence) -- the reference's graph for the same thing is two cumsum
@@ -122,6 +146,7 @@ class IMUPreintegrator(nn.Module):
         self.register_buffer('acc_cov', acc_cov, persistent=False)
         self.Rij = None      # rotation corresponding to the "zero-state" covariance
         self.fused_backward = True     # False: gradients through the composed LieTensor graph (tests compare the two routes)
+        self.native_backward = True    # False: the fused node as a Python autograd.Function instead of the C++ one (same kernels)
 
     def _check(self, obj):
         if obj is not None:
@@ -321,8 +346,9 @@ class IMUPreintegrator(nn.Module):
         if torch.is_grad_enabled() and any(t.requires_grad for t in ins):
             # training through the pre-integrator: one autograd node, backward = pplie_imu_integrate_bwd
             assert not want_aux
-            orot, ovel, opos = _ImuIntegrate.apply(self, dt, gyro, acc, None if rot is None else plain(rot, torch.Tensor).detach(),
-                                                   ins[3], ins[4], ins[5])
+            rk = None if rot is None else plain(rot, torch.Tensor).detach()
+            nat = _native_node(self, dt, gyro, acc, rk, ins[3], ins[4], ins[5])
+            orot, ovel, opos = nat if nat is not None else _ImuIntegrate.apply(self, dt, gyro, acc, rk, ins[3], ins[4], ins[5])
         else:
             orot, ovel, opos, _ = self._launch_integrate(dt, gyro, acc, rot, ins[3], ins[4], ins[5], Rij0, aux)
         rot_out = _lt._wrap(orot, r_in.ltype if isinstance(r_in, LieTensor) else _lt.SO3_type)

@@ -60,3 +60,21 @@ def test_torch_extension_builds_and_imports():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     assert callable(mod.row_op) and callable(mod.set_rule)
+
+
+def test_prototype_cache_is_not_poisoned_by_address_lookups():
+    """The native autograd nodes resolve entry ADDRESSES (HipLibrary.address); a later ctypes caller of the same entry must still get
+    its own prototype, also when someone resolved it without one first (18-argument entries called through the 7-argument row
+    prototype pass truncated pointers)."""
+    import ctypes
+    from pypose_amd import _C
+    from pypose_amd.module import imu_preintegrator as im
+    lib = _C.HipLibrary()
+    addr = lib.address("pplie_imu_integrate_f32")
+    assert isinstance(addr, int) and addr != 0 and "pplie_imu_integrate_f32" not in lib._fns
+    fn = lib.symbol("pplie_imu_integrate_f32", im._INT_SIG)
+    assert len(fn.argtypes) == len(im._INT_SIG) == 18
+    lib2 = _C.HipLibrary()
+    assert len(lib2.symbol("pplie_imu_integrate_bwd_f64").argtypes) == 7                  # (resolved blind: the row prototype)
+    assert len(lib2.symbol("pplie_imu_integrate_bwd_f64", im._INTB_SIG).argtypes) == len(im._INTB_SIG) == 17
+    assert ctypes.cast(fn, ctypes.c_void_p).value == addr

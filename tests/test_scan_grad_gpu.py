@@ -45,8 +45,12 @@ def test_scan_backward_kernel_matches_reference_gradients(gname, tag, side, monk
     monkeypatch.setattr(scan_mod, "_launch_bwd", lambda *a: (launches.append(a[2]), real(*a))[1])
     Xn, Wn, ref = G[f"scan/{gname}/{tag}/X"], G[f"scan/{gname}/{tag}/W"], G[f"scan/{gname}/{tag}/{side}/gX"]
     scale = np.abs(ref).max() + 1e-300
+    monkeypatch.setattr(scan_mod, "NATIVE_NODE", False)               # the Python autograd.Function around the kernel pair
     Y, gX = _scan_grad(gname, Xn, Wn, DIMS[tag], side == "L", torch.float64)
     assert launches == [KEY[gname]], "the backward did not run on pplie_scan_*_bwd"
+    monkeypatch.setattr(scan_mod, "NATIVE_NODE", True)                # the same pair as a C++ node: same kernels, same bits
+    Yn, gXn = _scan_grad(gname, Xn, Wn, DIMS[tag], side == "L", torch.float64)
+    assert launches == [KEY[gname]] and np.array_equal(Yn, Y) and np.array_equal(gXn, gX)
     assert np.abs(Y - G[f"scan/{gname}/{tag}/{side}/Y"]).max() < 1e-9 * max(1.0, np.abs(Y).max())
     assert np.abs(gX - ref).max() <= 1e-9 * scale, (np.abs(gX - ref).max(), scale)
     _, gX32 = _scan_grad(gname, Xn, Wn, DIMS[tag], side == "L", torch.float32)
@@ -115,7 +119,7 @@ def test_scan_autograd_contract():
     g1, = torch.autograd.grad((Y.tensor() * W).sum(), X, create_graph=True)
     g1 = g1.tensor() if hasattr(g1, "tensor") else g1
     assert g1.requires_grad
-    g0, = torch.autograd.grad((Y.tensor() * W).sum(), X)                       # the kernel's values
+    g0, = torch.autograd.grad((Y.tensor() * W).sum(), X, retain_graph=True)    # the kernel's values
     torch.testing.assert_close(g1.detach(), g0.tensor() if hasattr(g0, "tensor") else g0, rtol=1e-9, atol=1e-9)
     for left in (True, False):                                                 # (and for left products)
         Yl = pp.cumprod(X, dim=1, left=left)
@@ -143,7 +147,7 @@ def _imu(dtype, **kw):
                                       vel=torch.zeros(3, dtype=dtype), **kw).to(dtype).to(DEV)
 
 
-def _imu_grads(tag, dtype, fused=True):
+def _imu_grads(tag, dtype, fused=True, native=True):
     T = lambda k: torch.from_numpy(G[k].copy()).to(dtype).to(DEV)
     dt, gyro, acc = (T(k).requires_grad_(True) for k in ("imu/dt", "imu/gyro", "imu/acc"))
     leaves, kw = {"dt": dt, "gyro": gyro, "acc": acc}, {}
@@ -154,7 +158,7 @@ def _imu_grads(tag, dtype, fused=True):
     if tag == "known":
         kw["rot"] = pp.SO3(T("imu/rotk"))
     m = _imu(dtype, reset=True, prop_cov=(tag == "cov"))
-    m.fused_backward = fused
+    m.fused_backward, m.native_backward = fused, native
     o = m(dt, gyro, acc, **kw)
     loss = (o["rot"].tensor() * T("imu/Wr")).sum() + (o["vel"] * T("imu/Wv")).sum() + (o["pos"] * T("imu/Wp")).sum()
     loss.backward()
@@ -168,8 +172,14 @@ def test_imu_backward_kernel_matches_reference_gradients(tag, monkeypatch):
     used = []
     real = im._ImuIntegrate.backward
     monkeypatch.setattr(im._ImuIntegrate, "backward", staticmethod(lambda ctx, *g: (used.append(1), real(ctx, *g))[1]))
-    loss, got, o = _imu_grads(tag, torch.float64)
+    loss, got, o = _imu_grads(tag, torch.float64, native=False)
     assert used, "the gradient did not flow through pplie_imu_integrate_bwd"
+    # the same node in C++ (csrc_torch/pplie_autograd.cpp ImuOp) whenever the initial state needs no gradient: same kernels, same bits
+    del used[:]
+    loss_n, got_n, o_n = _imu_grads(tag, torch.float64)
+    if tag == "plain":                                   # (the other cases ask for the initial state's gradients: Python node)
+        assert not used and "ImuOp" in o_n["pos"].grad_fn.name(), (used, o_n["pos"].grad_fn.name())
+    assert loss_n == loss and all(np.array_equal(got_n[k], got[k]) for k in got)
     assert abs(loss - float(G[f"imu/{tag}/loss"])) <= 1e-9 * abs(float(G[f"imu/{tag}/loss"]))
     for k, v in got.items():
         ref = G[f"imu/{tag}/g_{k}"]
@@ -227,3 +237,33 @@ def test_imu_backward_at_configs4_shape_follows_the_composed_route():
     for x, xc, x64 in ((gf, gc, g64), (af, ac, a64)):
         ef, ec = float((x - x64).abs().max() / x64.abs().max()), float((xc - x64).abs().max() / x64.abs().max())
         assert ef <= 2e-5 or ef <= 2 * ec, (ef, ec)
+
+
+def test_native_imu_node_equals_the_python_node_on_partial_losses():
+    """known rotations, a loss on ONE output (the other cotangents arrive undefined), dt with and without a gradient, an expanded
+    (stride-0) cotangent out of sum(): C++ node vs Python node, same kernels -> same bits"""
+    torch.manual_seed(3)
+    B, F = 7, 300
+    for dtype in (torch.float32, torch.float64):
+        dt0 = torch.full((B, F, 1), 0.01, dtype=dtype, device=DEV)
+        gy0 = 0.2 * torch.randn(B, F, 3, dtype=dtype, device=DEV)
+        ac0 = torch.randn(B, F, 3, dtype=dtype, device=DEV)
+        rk = pp.randn_SO3(B, F, dtype=dtype, device=DEV)
+        for known in (False, True):
+            for which in ("pos", "vel", "rot"):
+                for dt_grad in (False, True):
+                    res = []
+                    for native in (True, False):
+                        dt, gy, ac = dt0.clone().requires_grad_(dt_grad), gy0.clone().requires_grad_(True), ac0.clone().requires_grad_(True)
+                        m = _imu(dtype, reset=True, prop_cov=False)
+                        m.native_backward = native
+                        o = m(dt, gy, ac, rot=rk if known else None)
+                        assert ("ImuOp" in o["pos"].grad_fn.name()) == native, o["pos"].grad_fn.name()
+                        (o[which].tensor() if which == "rot" else o[which]).sum().backward()
+                        res.append([t.grad.clone() for t in ((dt, gy, ac) if dt_grad else (gy, ac))])
+                    for a, b in zip(*res):
+                        assert torch.equal(a, b), (dtype, known, which, dt_grad)
+    with pytest.raises(RuntimeError, match="not differentiable a second time"):
+        gy = gy0.clone().requires_grad_(True)
+        o = _imu(torch.float64, reset=True, prop_cov=False)(dt0.double(), gy.double(), ac0.double())
+        torch.autograd.grad(o["pos"].sum(), gy, create_graph=True)
