@@ -99,7 +99,9 @@ scan_kernel(T* __restrict__ data, int64_t nseq, int64_t L, int64_t inner) {
 #pragma unroll
   for (int k = 0; k < W; ++k) carry[k] = G::ident(k);
   // software pipeline: the next chunk's elements are requested before this chunk's scan runs (one wave owns the whole
-  // sequence, so every chunk would otherwise pay the full HBM latency on its critical path)
+  // sequence, so every chunk would otherwise pay the full HBM latency on its critical path).  The fetch is nothing but loads from
+  // clamped addresses: a predicate on the load (`ok ? p[k] : d`) or a select right behind it puts an s_waitcnt INSIDE the fetch
+  // and the "prefetch" completes before the scan starts (how these kernels ran until round 4; the same holds for all fetches below).
   T nxt[K][W];
   auto fetch = [&](int64_t c0) {
 #pragma unroll
@@ -108,16 +110,18 @@ scan_kernel(T* __restrict__ data, int64_t nseq, int64_t L, int64_t inner) {
       const bool valid = i < L;
       const T* p = data + ((o * L + (valid ? i : 0)) * inner + in) * W;
 #pragma unroll
-      for (int k = 0; k < W; ++k) nxt[j][k] = valid ? p[k] : G::ident(k);   // padding: the identity changes nothing
+      for (int k = 0; k < W; ++k) nxt[j][k] = p[k];          // raw (the address is clamped); the padding is selected at the consumer
     }
   };
   fetch(0);
   for (int64_t c0 = 0; c0 < L; c0 += 64 * K) {
     T v[K][W];
 #pragma unroll
-    for (int j = 0; j < K; ++j)
+    for (int j = 0; j < K; ++j) {
+      const bool valid = c0 + (int64_t)lane * K + j < L;
 #pragma unroll
-      for (int k = 0; k < W; ++k) v[j][k] = nxt[j][k];
+      for (int k = 0; k < W; ++k) v[j][k] = valid ? nxt[j][k] : G::ident(k);     // padding: the identity changes nothing
+    }
     if (c0 + 64 * K < L) fetch(c0 + 64 * K);      // (reads rows this iteration does not write: the scan is in place)
 #pragma unroll
     for (int j = 1; j < K; ++j) combine<T, G>(v[j - 1], v[j], v[j], lf);     // running products inside the lane
@@ -196,6 +200,7 @@ scan_bwd_right_kernel(const T* __restrict__ y, const T* __restrict__ g, T* __res
   if (seq >= nseq) return;
   const int64_t o = seq / inner, in = seq % inner;
   auto row = [&](int64_t i) { return ((o * L + i) * inner + in) * W; };
+  const T g0D = g[row(0) + D];     // (element 0's padding component passes through: read once, not under a branch in the loop)
   T C[W];                 // the sum over everything behind this chunk
 #pragma unroll
   for (int k = 0; k < W; ++k) C[k] = T(0);
@@ -210,12 +215,12 @@ scan_bwd_right_kernel(const T* __restrict__ y, const T* __restrict__ g, T* __res
       const bool valid = i < L;
       const T* pg = g + row(valid ? i : 0);
 #pragma unroll
-      for (int k = 0; k < D; ++k) nu[j][k] = valid ? pg[k] : T(0);
+      for (int k = 0; k < D; ++k) nu[j][k] = pg[k];               // (raw: selected at the consumer)
       nu[j][D] = T(0);
       const bool has = valid && i > 0;                            // y_{i-1}
       const T* py = y + row(has ? i - 1 : 0);
 #pragma unroll
-      for (int k = 0; k < W; ++k) ny[j][k] = has ? py[k] : G::ident(k);
+      for (int k = 0; k < W; ++k) ny[j][k] = py[k];
     }
   };
   fetch((nch - 1) * CH);
@@ -223,9 +228,12 @@ scan_bwd_right_kernel(const T* __restrict__ y, const T* __restrict__ g, T* __res
     const int64_t c0 = c * CH;
     T yv[K][W], u[K][W];
 #pragma unroll
-    for (int j = 0; j < K; ++j)
+    for (int j = 0; j < K; ++j) {
+      const int64_t i = c0 + (int64_t)rl * K + j;
+      const bool valid = i < L, has = valid && i > 0;
 #pragma unroll
-      for (int k = 0; k < W; ++k) { yv[j][k] = ny[j][k]; u[j][k] = nu[j][k]; }
+      for (int k = 0; k < W; ++k) { yv[j][k] = has ? ny[j][k] : G::ident(k); u[j][k] = (valid && k < D) ? nu[j][k] : T(0); }
+    }
     if (c > 0) fetch(c0 - CH);
     // suffix sums over positions: inside the lane, then over the (reversed) lanes
 #pragma unroll
@@ -255,7 +263,7 @@ scan_bwd_right_kernel(const T* __restrict__ y, const T* __restrict__ g, T* __res
         T* p = gx + row(i);
 #pragma unroll
         for (int k = 0; k < D; ++k) p[k] = out[k];
-        p[D] = i == 0 ? g[row(0) + D] : T(0);
+        p[D] = i == 0 ? g0D : T(0);
       }
     }
   }
@@ -288,6 +296,7 @@ scan_bwd_left_kernel(const T* __restrict__ x, const T* __restrict__ g, T* __rest
   if (seq >= nseq) return;
   const int64_t o = seq / inner, in = seq % inner;
   auto row = [&](int64_t i) { return ((o * L + i) * inner + in) * W; };
+  const T g0D = g[row(0) + D];     // (element 0's padding component passes through: read once, not under a branch in the loop)
   T C[W];                 // gx of the later chunk's first element (zero behind the end of the sequence)
 #pragma unroll
   for (int k = 0; k < W; ++k) C[k] = T(0);
@@ -301,10 +310,10 @@ scan_bwd_left_kernel(const T* __restrict__ x, const T* __restrict__ g, T* __rest
       const T* pg = g + row(valid ? i : 0);
       const T* px = x + row(nxt ? i + 1 : 0);
 #pragma unroll
-      for (int k = 0; k < D; ++k) nc[j][k] = valid ? pg[k] : T(0);
+      for (int k = 0; k < D; ++k) nc[j][k] = pg[k];               // (raw: selected at the consumer)
       nc[j][D] = T(0);
 #pragma unroll
-      for (int k = 0; k < W; ++k) nM[j][k] = nxt ? px[k] : G::ident(k);
+      for (int k = 0; k < W; ++k) nM[j][k] = px[k];
     }
   };
   fetch((nch - 1) * CH);
@@ -313,9 +322,12 @@ scan_bwd_left_kernel(const T* __restrict__ x, const T* __restrict__ g, T* __rest
     // element i carries the map  s -> g_i + Adj(x_{i+1})^T s ; M[j], c[j] become the lane-local composites of [j .. K-1]
     T M[K][W], c[K][W];
 #pragma unroll
-    for (int j = 0; j < K; ++j)
+    for (int j = 0; j < K; ++j) {
+      const int64_t i = c0 + (int64_t)rl * K + j;
+      const bool valid = i < L, nxt = i + 1 < L;
 #pragma unroll
-      for (int k = 0; k < W; ++k) { M[j][k] = nM[j][k]; c[j][k] = nc[j][k]; }
+      for (int k = 0; k < W; ++k) { M[j][k] = nxt ? nM[j][k] : G::ident(k); c[j][k] = (valid && k < D) ? nc[j][k] : T(0); }
+    }
     if (ch > 0) fetch(c0 - CH);
 #pragma unroll
     for (int j = K - 2; j >= 0; --j) affine_after<T, G>(M[j], c[j], M[j + 1], c[j + 1]);
@@ -353,7 +365,7 @@ scan_bwd_left_kernel(const T* __restrict__ x, const T* __restrict__ g, T* __rest
         T* p = gx + row(i);
 #pragma unroll
         for (int k = 0; k < D; ++k) p[k] = out[k];
-        p[D] = i == 0 ? g[row(0) + D] : T(0);
+        p[D] = i == 0 ? g0D : T(0);
       }
     }
 #pragma unroll
@@ -421,25 +433,25 @@ imu_integrate_kernel(const T* __restrict__ dt, const T* __restrict__ gyro, const
     const int64_t f = c0 + lane;
     const bool ok = f < F;
     const int64_t row = b * F + (ok ? f : 0);
-    nh = ok ? dt[row] : T(0);
+    nh = dt[row];                                    // (raw loads from clamped rows; selected at the consumer)
 #pragma unroll
-    for (int k = 0; k < 3; ++k) { ng[k] = ok ? gyro[row * 3 + k] : T(0); na[k] = ok ? acc[row * 3 + k] : T(0); }
-    if (rot_known) {
+    for (int k = 0; k < 3; ++k) { ng[k] = gyro[row * 3 + k]; na[k] = acc[row * 3 + k]; }
+    const T* rkp = rot_known ? rot_known : init_rot;  // (a branch around these loads would end in an s_waitcnt at its join)
+    const int64_t rrow = rot_known ? row : b;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) nr[k] = ok ? rot_known[row * 4 + k] : (k == 3 ? T(1) : T(0));
-    }
+    for (int k = 0; k < 4; ++k) nr[k] = rkp[rrow * 4 + k];
   };
   fetch(0);
   for (int64_t c0 = 0; c0 < F; c0 += 64) {
     const int64_t f = c0 + lane;
     const bool valid = f < F;
     const int64_t row = b * F + (valid ? f : 0);
-    const T h = nh;
+    const T h = valid ? nh : T(0);
     T w[3], am[3], rkn[4];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) { w[k] = ng[k] * h; am[k] = na[k]; }
+    for (int k = 0; k < 3; ++k) { w[k] = (valid ? ng[k] : T(0)) * h; am[k] = valid ? na[k] : T(0); }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) rkn[k] = nr[k];
+    for (int k = 0; k < 4; ++k) rkn[k] = valid ? nr[k] : (k == 3 ? T(1) : T(0));
     if (c0 + 64 < F) fetch(c0 + 64);
     T dr[4];
     so3_exp<T>(w, dr);
@@ -533,26 +545,33 @@ imu_integrate_bwd_kernel(const T* __restrict__ dt, const T* __restrict__ gyro, c
   const int64_t nch = (F + 63) / 64;
   // software pipeline: the next (earlier) chunk's 24 scalars per step are in flight while this chunk's sums run
   T n_h, n_gy[3], n_am[3], n_Q[4], n_Qm[4], n_Rw[4], n_Gp[3], n_Gv[3], n_Gr[3], n_vel[3];
+  // An absent cotangent (NULL) reads a stream of the same shape that IS there and the consumer selects zero: a launch-uniform
+  // `if (g_pos)` around the load is a scalar branch whose join waits for vmcnt(0) -- twelve serialized round trips per chunk.
+  const bool has_gp = g_pos != nullptr, has_gv = g_vel != nullptr, has_gr = g_rot != nullptr, has_dt = o_dt != nullptr;
+  const T* s_gp = has_gp ? g_pos : gyro;
+  const T* s_gv = has_gv ? g_vel : gyro;
+  const T* s_gr = has_gr ? g_rot : rot_out;
+  const T* s_vel = has_dt ? vel_out : gyro;
   auto fetch = [&](int64_t c) {
     const int64_t f = c * 64 + rl;
     const bool valid = f < F;
     const int64_t row = b * F + (valid ? f : 0);
-    n_h = valid ? dt[row] : T(0);
+    n_h = dt[row];                                    // (raw loads from clamped rows; selected at the consumer)
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-      n_gy[k] = valid ? gyro[row * 3 + k] : T(0);
-      n_am[k] = valid ? acc[row * 3 + k] : T(0);
-      n_Gp[k] = (g_pos && valid) ? g_pos[row * 3 + k] : T(0);
-      n_Gv[k] = (g_vel && valid) ? g_vel[row * 3 + k] : T(0);
-      n_Gr[k] = (g_rot && valid) ? g_rot[row * 4 + k] : T(0);
-      n_vel[k] = (o_dt && valid) ? vel_out[row * 3 + k] : T(0);
+      n_gy[k] = gyro[row * 3 + k];
+      n_am[k] = acc[row * 3 + k];
+      n_Gp[k] = s_gp[row * 3 + k];
+      n_Gv[k] = s_gv[row * 3 + k];
+      n_Gr[k] = s_gr[row * 4 + k];
+      n_vel[k] = s_vel[row * 3 + k];
     }
     const T* pm = (valid && f > 0) ? rot_out + (row - 1) * 4 : init_rot + b * 4;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      n_Q[k] = valid ? rot_out[row * 4 + k] : (k == 3 ? T(1) : T(0));
-      n_Qm[k] = valid ? pm[k] : (k == 3 ? T(1) : T(0));
-      n_Rw[k] = KNOWN ? (valid ? rot_known[row * 4 + k] : (k == 3 ? T(1) : T(0))) : n_Q[k];
+      n_Q[k] = rot_out[row * 4 + k];
+      n_Qm[k] = pm[k];
+      if (KNOWN) n_Rw[k] = rot_known[row * 4 + k];
     }
   };
   fetch(nch - 1);
@@ -560,14 +579,19 @@ imu_integrate_bwd_kernel(const T* __restrict__ dt, const T* __restrict__ gyro, c
     const int64_t f = c * 64 + rl;
     const bool valid = f < F;
     const int64_t row = b * F + (valid ? f : 0);
-    const T h = n_h;
+    const T h = valid ? n_h : T(0);
     T gyv[3], w[3], am[3], Q[4], Qm[4], Rw[4], Gp[3], Gv[3], Gr[3], velv[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-      gyv[k] = n_gy[k]; w[k] = gyv[k] * h; am[k] = n_am[k]; Gp[k] = n_Gp[k]; Gv[k] = n_Gv[k]; Gr[k] = n_Gr[k]; velv[k] = n_vel[k];
+      gyv[k] = valid ? n_gy[k] : T(0); w[k] = gyv[k] * h; am[k] = valid ? n_am[k] : T(0);
+      Gp[k] = (valid && has_gp) ? n_Gp[k] : T(0); Gv[k] = (valid && has_gv) ? n_Gv[k] : T(0);
+      Gr[k] = (valid && has_gr) ? n_Gr[k] : T(0); velv[k] = (valid && has_dt) ? n_vel[k] : T(0);
     }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { Q[k] = n_Q[k]; Qm[k] = n_Qm[k]; Rw[k] = n_Rw[k]; }
+    for (int k = 0; k < 4; ++k) {
+      const T idk = k == 3 ? T(1) : T(0);
+      Q[k] = valid ? n_Q[k] : idk; Qm[k] = valid ? n_Qm[k] : idk; Rw[k] = KNOWN ? (valid ? n_Rw[k] : idk) : Q[k];
+    }
     if (c > 0) fetch(c - 1);
     T Sp[3], T2[3], Sv[3];
 #pragma unroll
@@ -661,12 +685,12 @@ imu_integrate_multi_kernel(const T* __restrict__ dt, const T* __restrict__ gyro,
       const int f = c0 + lane * K + j;
       const bool ok = f < F;
       const int row = ok ? f : 0;
-      nh[j] = ok ? dt[row] : T(0);
+      nh[j] = dt[row];                                // (raw loads from clamped rows; selected at the consumer)
 #pragma unroll
-      for (int k = 0; k < 3; ++k) { ng[j][k] = ok ? gyro[row * 3 + k] : T(0); na[j][k] = ok ? acc[row * 3 + k] : T(0); }
+      for (int k = 0; k < 3; ++k) { ng[j][k] = gyro[row * 3 + k]; na[j][k] = acc[row * 3 + k]; }
       if (KNOWN) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) nr[j][k] = ok ? rot_known[row * 4 + k] : (k == 3 ? T(1) : T(0));
+        for (int k = 0; k < 4; ++k) nr[j][k] = rot_known[row * 4 + k];
       }
     }
   };
@@ -676,13 +700,14 @@ imu_integrate_multi_kernel(const T* __restrict__ dt, const T* __restrict__ gyro,
     T h[K], am[K][3], rkn[KNOWN ? K : 1][4], dr[K][4];
 #pragma unroll
     for (int j = 0; j < K; ++j) {
-      h[j] = nh[j];
+      const bool ok = c0 + lane * K + j < F;
+      h[j] = ok ? nh[j] : T(0);
       T w[3];
 #pragma unroll
-      for (int k = 0; k < 3; ++k) { w[k] = ng[j][k] * h[j]; am[j][k] = na[j][k]; }
+      for (int k = 0; k < 3; ++k) { w[k] = (ok ? ng[j][k] : T(0)) * h[j]; am[j][k] = ok ? na[j][k] : T(0); }
       if (KNOWN) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) rkn[j][k] = nr[j][k];
+        for (int k = 0; k < 4; ++k) rkn[j][k] = ok ? nr[j][k] : (k == 3 ? T(1) : T(0));
       }
       so3_exp<T>(w, dr[j]);
     }
@@ -841,22 +866,22 @@ imu_cov_scan_kernel(const T* __restrict__ dt, const T* __restrict__ rk, const T*
     const int64_t jj = ch * 64 + (63 - lane);
     const bool ok = jj < F;
     const int64_t row = b * F + (ok ? jj : 0);
-    nh = ok ? dt[row] : T(0);
+    nh = dt[row];                                    // (raw loads from clamped rows; selected at the consumer)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { nq[i] = ok ? rk[row * 4 + i] : (i == 3 ? T(1) : T(0)); nqij[i] = ok ? rij[row * 4 + i] : (i == 3 ? T(1) : T(0)); }
+    for (int i = 0; i < 4; ++i) { nq[i] = rk[row * 4 + i]; nqij[i] = rij[row * 4 + i]; }
 #pragma unroll
-    for (int i = 0; i < 3; ++i) nav[i] = ok ? a[row * 3 + i] : T(0);
+    for (int i = 0; i < 3; ++i) nav[i] = a[row * 3 + i];
   };
   fetch(nchunks - 1);
   for (int64_t ch = nchunks - 1; ch >= 0; --ch) {
     const int64_t j = ch * 64 + (63 - lane);   // lanes walk the chunk backwards: a suffix over steps is a prefix over lanes
     const bool valid = j < F;
-    const T h = nh;
+    const T h = valid ? nh : T(0);
     T q[4], qij[4], av[3];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { q[i] = nq[i]; qij[i] = nqij[i]; }
+    for (int i = 0; i < 4; ++i) { const T idk = i == 3 ? T(1) : T(0); q[i] = valid ? nq[i] : idk; qij[i] = valid ? nqij[i] : idk; }
 #pragma unroll
-    for (int i = 0; i < 3; ++i) av[i] = nav[i];
+    for (int i = 0; i < 3; ++i) av[i] = valid ? nav[i] : T(0);
     if (ch > 0) fetch(ch - 1);
     // ---- S: suffix product of inverse increments, s_j = dr_j^-1 * s_{j+1}
     T sv[4] = {-q[0], -q[1], -q[2], q[3]};
@@ -1159,11 +1184,18 @@ imu_cov_seg_kernel(const T* __restrict__ dt, const T* __restrict__ gyro, const T
       const bool ok = j < F;
       const int64_t row = b * F + (ok ? j : 0);
       T ro[4], rwq[4], ac[3], gyv[3], qq[4];
-      const T hv = ok ? dt[row] : T(0);
+      // (unconditional loads from the clamped row, THEN the selects: `ok ? p[i] : d` is a branch around every load with a wait at
+      //  its join -- the LS steps' loads went out one after the other)
+      T hv = dt[row];
 #pragma unroll
-      for (int i = 0; i < 3; ++i) { gyv[i] = ok ? gyro[row * 3 + i] : T(0); ac[i] = ok ? accel[row * 3 + i] : T(0); }
+      for (int i = 0; i < 3; ++i) { gyv[i] = gyro[row * 3 + i]; ac[i] = accel[row * 3 + i]; }
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { ro[i] = ok ? rout[row * 4 + i] : (i == 3 ? T(1) : T(0)); rwq[i] = ok ? rw[row * 4 + i] : (i == 3 ? T(1) : T(0)); }
+      for (int i = 0; i < 4; ++i) { ro[i] = rout[row * 4 + i]; rwq[i] = rw[row * 4 + i]; }
+      hv = ok ? hv : T(0);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) { gyv[i] = ok ? gyv[i] : T(0); ac[i] = ok ? ac[i] : T(0); }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { const T idk = i == 3 ? T(1) : T(0); ro[i] = ok ? ro[i] : idk; rwq[i] = ok ? rwq[i] : idk; }
       const V3<T> gb = quat_rotate_inv(v3(rwq), rwq[3], v3<T>(g0, g1, g2));       // Rw^-1 g
       if (C) so3_mul<T>(cq, ro, qq);
       else {
