@@ -1051,26 +1051,39 @@ pcg2_spmv_kernel(const int* __restrict__ ptr, const int* __restrict__ other, con
   for (int64_t base = wave * NPW; base < N; base += nwaves * NPW) {
     const int64_t n = base + sub;
     const bool act = active_lane && n < N;
-    T acc = T(0), pi = T(0);
-    T uk[M];                                                      // PACK: see below
+    T acc = T(0), pi = T(0), zi = T(0);
+    T uk[M], bi[M];                                               // PACK: see below; bi: this lane's row of Binv (used after the loop)
 #pragma unroll
-    for (int k = 0; k < M; ++k) uk[k] = T(0);
+    for (int k = 0; k < M; ++k) { uk[k] = T(0); bi[k] = T(0); }
     if (act) {
       T pv[M];
 #pragma unroll
       for (int j = 0; j < M; ++j) pv[j] = p[n * M + j];
       pi = pv[i];
+      T dv[M];
 #pragma unroll
-      for (int j = 0; j < M; ++j) acc += D[(n * M + i) * M + j] * pv[j];
+      for (int j = 0; j < M; ++j) dv[j] = D[(n * M + i) * M + j];
+      // everything this node needs that does not depend on the neighbour list goes out HERE, in one batch: a load under its own
+      // `if (act)` further down is a branch whose join waits for vmcnt(0) -- the six elements of the Binv row after the loop were
+      // six memory round trips one after the other per group of nodes
+#pragma unroll
+      for (int j = 0; j < M; ++j) bi[j] = Binv[(n * M + i) * M + j];
+      zi = z[n * M + i];
       const int beg = ptr[n], end = ptr[n + 1];
+#pragma unroll
+      for (int j = 0; j < M; ++j) acc += dv[j] * pv[j];
       // The neighbour indices run one pair ahead of the gathers they address: index -> p[index] is a chain of two memory round
-      // trips per pair, and with ~4 pairs per node on 6 waves per SIMD that chain, not bandwidth, set the kernel's time.
-      int nx0 = beg < end ? other[beg] : 0, nx1 = beg + 1 < end ? other[beg + 1] : nx0;
+      // trips per pair, and with ~4 pairs per node on 6 waves per SIMD that chain, not bandwidth, set the kernel's time.  The index
+      // loads are UNCONDITIONAL from clamped positions (c is always a valid one): `c + 2 < end ? other[c + 2] : 0` compiled to a
+      // branch around the load with an s_waitcnt at its join, i.e. no prefetch at all.
+      int nx0 = 0, nx1 = 0;
+      if (beg < end) { nx0 = other[beg]; nx1 = other[beg + 1 < end ? beg + 1 : beg]; }
       for (int c = beg; c < end; c += 2) {
         const bool two = c + 1 < end;
         const int64_t o0 = nx0, o1 = nx1;
-        nx0 = c + 2 < end ? other[c + 2] : 0;
-        nx1 = c + 3 < end ? other[c + 3] : nx0;
+        const int c2 = c + 2 < end ? c + 2 : c, c3 = c + 3 < end ? c + 3 : c2;
+        nx0 = other[c2];
+        nx1 = other[c3];
         const T* p0 = p + o0 * M;
         const T* p1 = p + o1 * M;
         T s0 = T(0), s1 = T(0);
@@ -1139,11 +1152,11 @@ pcg2_spmv_kernel(const int* __restrict__ ptr, const int* __restrict__ other, con
 #pragma unroll
     for (int j = 0; j < M; ++j) {
       const T qj = __shfl(acc, sub * M + j, 64);
-      if (act) bq += Binv[(n * M + i) * M + j] * qj;
+      bq += bi[j] * qj;                                           // (bi = 0 on idle lanes)
     }
     if (act) {
       a_pq += acc * pi;
-      a_qz += acc * z[n * M + i];
+      a_qz += acc * zi;
       a_qmq += acc * bq;
     }
   }
