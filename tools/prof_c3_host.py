@@ -9,7 +9,7 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 torch.manual_seed(0)
 init = pp.randn_SE3(B, device="cuda"); inp = pp.randn_SE3(B, device="cuda")
 net = InvNet(init.clone())
-opt = pp.optim.LM(net, strategy=pp.optim.strategy.Constant(damping=1e-4), static=True)
+opt = pp.optim.LM(net, strategy=pp.optim.strategy.Constant(damping=1e-4), static=("static" in sys.argv))
 for _ in range(5):
     opt.step(inp)
 torch.cuda.synchronize()
