@@ -350,7 +350,8 @@ class IMUPreintegrator(nn.Module):
             nat = _native_node(self, dt, gyro, acc, rk, ins[3], ins[4], ins[5])
             orot, ovel, opos = nat if nat is not None else _ImuIntegrate.apply(self, dt, gyro, acc, rk, ins[3], ins[4], ins[5])
         else:
-            orot, ovel, opos, _ = self._launch_integrate(dt, gyro, acc, rot, ins[3], ins[4], ins[5], Rij0, aux)
+            # (r_in itself, not the fresh alias in `ins`: _bcast's cache recognises the caller's tensor OBJECT)
+            orot, ovel, opos, _ = self._launch_integrate(dt, gyro, acc, rot, r_in, ins[4], ins[5], Rij0, aux)
         rot_out = _lt._wrap(orot, r_in.ltype if isinstance(r_in, LieTensor) else _lt.SO3_type)
         return {'rot': rot_out, 'vel': ovel, 'pos': opos}, aux
 

@@ -23,13 +23,27 @@ _SCALE_SIG = [ctypes.c_void_p] * 4 + [ctypes.c_int64, ctypes.c_int, ctypes.c_int
                                       ctypes.c_void_p]
 
 
+def fused_code(corrector):
+    """(kind, p0, p1) if ``corrector`` is one the HIP kernels reproduce -- exactly FastTriggs or Triggs (no subclass) over a
+    built-in kernel -- else None.  The ONE eligibility rule of every fused route (the correctors' own forward, the per-edge
+    blocks of optim/posegraph.py and multigraph.py, the robust linearisation kernel of optim/fused.py).  Triggs over Scale is
+    excluded everywhere: rho' is a constant there and the reference's second autograd.grad raises (corrector.py:155-157), so
+    the autograd formulation below must be the one that runs (and raises)."""
+    from .kernel import Scale
+    if type(corrector) not in (FastTriggs, Triggs):
+        return None
+    if type(corrector) is Triggs and type(corrector.kernel) is Scale:
+        return None
+    return robust_code(corrector.kernel)
+
+
 def fused_scale_rows(kernel, R, J, inplace=False):
     """(s R, s J) with s_i = sqrt(rho'(|R_i|^2)) by one kernel, or None if this call cannot take the route.
     R [n, dr]; J any tensor whose leading dimension splits into n row blocks.  ``inplace``: J is overwritten (the caller owns it)."""
     code = robust_code(kernel)
     if code is None or _C._test_backend is not None or not (R.is_cuda and J.is_cuda) or R.dtype != J.dtype \
             or R.dtype not in (torch.float32, torch.float64) or R.dim() != 2 or R.shape[1] > 64 or R.shape[0] == 0 \
-            or J.numel() % R.shape[0] or (torch.is_grad_enabled() and (R.requires_grad or J.requires_grad)) \
+            or J.numel() == 0 or J.numel() % R.shape[0] or (torch.is_grad_enabled() and (R.requires_grad or J.requires_grad)) \
             or torch._C._are_functorch_transforms_active():
         return None
     n, dr = R.shape
@@ -88,7 +102,7 @@ class Triggs(nn.Module):
         # built-in kernels are concave (rho'' <= 0): the second-order mask M below is empty and Triggs is FastTriggs' scaling --
         # except Scale, whose rho' is a constant the reference cannot differentiate again (it raises; so does the route below)
         from .kernel import Scale
-        done = None if type(self.kernel) is Scale else fused_scale_rows(self.kernel, R, J, inplace)
+        done = None if type(self.kernel) is Scale else fused_scale_rows(self.kernel, R, J, inplace)      # (cf. fused_code)
         if done is not None:
             return done
         x, g1, g2 = _rho_derivatives(self.kernel, R.square().sum(-1, keepdim=True), second=True)

@@ -1119,12 +1119,12 @@ def _same_input(a, b):
 
 def _pgo_linearization(opt, prog, weight, P, trivial):
     from . import posegraph as _pg
-    from .corrector import FastTriggs, Triggs
+    from .corrector import fused_code
     from .kernel import robust_code
     from .optimizer import Trivial
     # a built-in robust kernel rides inside the linearisation kernel (csrc/robust.h): no corrector pass, no autograd graph
     c = opt.corrector[0]
-    robust = robust_code(c.kernel) if (not trivial and type(c) in (FastTriggs, Triggs) and opt.group is None) else None
+    robust = fused_code(c) if (not trivial and opt.group is None) else None
     r, J = prog.linearize(robust)
     lin = _pg.build_graph_linearization(opt, weight, r, J, prog.idx, P, 7, 6, corrector=Trivial() if robust is not None else None)
     lin.kind = "fused:pgo"

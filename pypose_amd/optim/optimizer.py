@@ -136,7 +136,8 @@ class RobustModel(nn.Module):
     def loss(self, input, target):
         residuals = self.residuals(self.model_forward(input), target)
         kernels = self.kernel if len(self.kernel) > 1 else [self.kernel[0]] * len(residuals)
-        return sum(k(r.square().sum(-1)).sum() for k, r in zip(kernels, residuals))
+        # (|r|^2 >= 0 by construction: built-in kernels skip the public call's sign check and its device round trip)
+        return sum(getattr(k, 'of_squared_norm', k)(r.square().sum(-1)).sum() for k, r in zip(kernels, residuals))
 
 
 # ---------------------------------------------------------------------------------------------
@@ -621,7 +622,10 @@ class LevenbergMarquardt(_Optimizer):
         from .pgograph import PgoGraphStep
         from .posegraph import PCG, PERSIST_NODES, FusedPCG
         d = self.__dict__
-        ok = (defer and lin.kind == "fused:pgo" and hasattr(lin, 'fast_loss') and getattr(lin, 'robust', None) is None
+        # the captured trial's tail evaluates the PLAIN loss sum |r|^2 (pplie_pgo_trial_tail, RK_NONE): only the trivial kernel /
+        # corrector configuration may be captured -- a robust `fast_loss` (fused.py) must not make a problem eligible
+        trivial = all(isinstance(c, Trivial) for c in self.corrector) and all(isinstance(k, Trivial) for k in self.model.kernel)
+        ok = (defer and trivial and lin.kind == "fused:pgo" and hasattr(lin, 'fast_loss') and getattr(lin, 'robust', None) is None
               and target is None and len(self.param_groups) == 1
               and isinstance(self.solver, PCG) and getattr(self.solver, 'fused', True) and lin.N <= PERSIST_NODES
               and FusedPCG.persist and FusedPCG.two_launch and getattr(self, 'graph_step', True)
@@ -641,7 +645,6 @@ class LevenbergMarquardt(_Optimizer):
         d['_pgo_streak'] = (prog, n)
         if n >= PgoGraphStep.MIN_STREAK:
             params = [p for p in pg['params'] if p.requires_grad]
-            trivial = all(isinstance(c, Trivial) for c in self.corrector) and all(isinstance(k, Trivial) for k in self.model.kernel)
             try:
                 d['_pgo_graph_step'] = PgoGraphStep(self, pg, prog, input, weight, params[0], trivial)
             except Exception as e:                       # capture is an optimisation: the ordinary path stays correct

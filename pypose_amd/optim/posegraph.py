@@ -1065,8 +1065,8 @@ def Trivial_type():
 def _fused_rows(corrector, r, J):
     """FastTriggs / Triggs with a built-in kernel: sqrt(rho') is one scalar per edge, so the blocks are scaled where they lie
     (pplie_robust_scale_rows, csrc/robust.hip); None -> the corrector's own formulation"""
-    from .corrector import FastTriggs, Triggs, fused_scale_rows
-    if type(corrector) not in (FastTriggs, Triggs) or not J.is_contiguous() or J.requires_grad:
+    from .corrector import fused_code, fused_scale_rows
+    if fused_code(corrector) is None or not J.is_contiguous() or J.requires_grad:
         return None
     return fused_scale_rows(corrector.kernel, r, J, inplace=True)
 

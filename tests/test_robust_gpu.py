@@ -134,3 +134,41 @@ def test_pose_graph_lm_robust_matches_the_reference_package():
         lo = float(oo.step((ed, rel)))
         assert abs(lr - lo) <= 1e-8 * abs(lr), (lr, lo)
     assert oo.linearization == "fused:pgo"
+
+
+@pytest.mark.parametrize("corr", ["none", "user", "subclass", "user_kernel"])
+def test_robust_kernel_with_foreign_corrector_is_never_captured(corr):
+    """a built-in robust kernel gives the fused pose-graph linearisation a `fast_loss` even when the
+    corrector is not FastTriggs / Triggs over a built-in kernel.  The captured trial (optim/pgograph.py) evaluates the PLAIN loss,
+    so such a problem must stay un-captured past PgoGraphStep.MIN_STREAK and reproduce the path that never considers capture."""
+    from pypose_amd.optim.pgograph import PgoGraphStep
+    from tests.optim_models import run_steps
+    torch.manual_seed(5)
+    N, E = 60, 150
+    gt = pp.randn_SE3(N, sigma=0.3, device=DEV).cumprod(dim=0)
+    idx = torch.cat([torch.stack([torch.arange(N - 1), torch.arange(1, N)], 1), torch.randint(0, N, (E - N + 1, 2))]).to(DEV)
+    idx = idx[idx[:, 0] != idx[:, 1]]
+    rel = gt[idx[:, 0]].Inv() * gt[idx[:, 1]] * pp.randn_SE3(idx.shape[0], sigma=0.05, device=DEV)
+    init = gt * pp.randn_SE3(N, sigma=0.05, device=DEV)
+
+    class UserCorrector(torch.nn.Module):
+        def forward(self, R, J):
+            return R * 0.5, J * 0.5
+
+    def corrector():
+        k = K.Huber(0.3)
+        return {"none": None, "user": UserCorrector(), "subclass": type("FT2", (C.FastTriggs,), {})(k),
+                "user_kernel": C.FastTriggs(unfused("Huber", (0.3,)))}[corr]
+
+    runs = {}
+    for consider in (True, False):
+        graph = PoseGraph(pp.SE3(init.tensor().clone()))
+        opt = pp.optim.LM(graph, solver=pp.optim.solver.PCG(tol=1e-6, maxiter=500), strategy=pp.optim.strategy.TrustRegion(radius=1e4),
+                          kernel=K.Huber(0.3), corrector=corrector(), min=1e-6)
+        opt.graph_step = consider
+        rec = run_steps(opt, ((idx, rel),), {}, PgoGraphStep.MIN_STREAK + 5)
+        assert opt.__dict__.get('_pgo_graph_step') is None, "a robust-loss problem was captured with the plain-loss trial tail"
+        runs[consider] = (rec, graph.nodes.detach().tensor().clone())
+    a, b = runs[True][0], runs[False][0]
+    assert a["loss"] == b["loss"] and a["damping"] == b["damping"] and a["reject"] == b["reject"], (a, b)
+    assert torch.equal(runs[True][1], runs[False][1])
