@@ -97,21 +97,49 @@ def _random_inputs(name, n, dtype, rng):
     return table[kind]()
 
 
+def mixed_row_err(out, ref, ins):
+    """|out - ref| per row over max(|ref|, 0.1 |g| |p|): the cotangent-times-operand scale is the natural magnitude of a
+    Jinvp / Jr gradient row; a row whose exact value happens to cancel to 1e-3 of that scale (rn / scale reaches 4e-4 in 100k
+    random rows) carries the rounding of the terms that cancelled and would fail any purely row-relative gate."""
+    d = np.linalg.norm(out.astype(np.float64) - ref, axis=-1)
+    scale = np.linalg.norm(ins[-1].astype(np.float64), axis=-1)
+    if len(ins) == 3:
+        scale = scale * np.linalg.norm(ins[1].astype(np.float64), axis=-1)
+    return d / np.maximum(np.linalg.norm(ref, axis=-1), 0.1 * scale)
+
+
 @pytest.mark.parametrize("name", ALL_OPS)
 def test_random_100k_fp32_vs_oracle_fp64(name):
     n = 100_003                       # not a multiple of the 512-row tile: ragged tail
+    if name in AUTOGRAD_OPS:
+        # Jinvp / Jr backward.  The oracle differentiates the reference's closed forms by central differences in fp64 with
+        # h = 1e-6: its OWN error is ~ eps64 / (theta^4 h) for the Q-term of se3 (coefficients that cancel to theta^4 and are
+        # divided by it), i.e. 1e-2 at theta = 2e-4, 2e-4 at 1e-3, 5e-6 at 1e-2 -- measured against 40-digit arithmetic by
+        # tools/sweep_jinvp_bwd.py and oracle/jinvp_mp.py.  (The round-4 tail of this test, > 10 rows in 100k above 1e-4 for
+        # some seeds, was exactly that: every such row had theta in [1e-3, 2e-3] and the kernel agreed with the reference's
+        # autograd to 2e-7 there.)  So: against THIS oracle only rows with theta >= 1e-2, every row (max, not a quantile),
+        # several seeds; the band below is tests/test_jinvp_small_angle.py against the 40-digit truth.
+        for k in range(3):
+            rng = np.random.default_rng(zlib.crc32(name.encode()) + k)
+            ins = _random_inputs(name, n, np.float32, rng)
+            keep = well_conditioned_rows(name, ins, theta_min=1e-2)
+            ins = [a[keep] for a in ins]
+            refs = lie_np.OPS[name](*[a.astype(np.float64) for a in ins])
+            outs = run_hip(name, ins)
+            for o, r in zip(outs, refs):
+                e = mixed_row_err(o, r, ins)
+                assert e.max() < 1e-5, (name, k, e.max(), int(np.argmax(e)))
+                assert np.median(e) < 2e-7, (name, np.median(e))
+        return
     rng = np.random.default_rng(zlib.crc32(name.encode()))       # (hash(str) is salted per process: the inputs must not be)
     ins = _random_inputs(name, n, np.float32, rng)
     refs = lie_np.OPS[name](*[a.astype(np.float64) for a in ins])
-    if name in AUTOGRAD_OPS:       # the oracle differentiates numerically: needs theta >> its step
-        keep = well_conditioned_rows(name, ins, theta_min=1e-3)
-        ins, refs = [a[keep] for a in ins], [r[keep] for r in refs]
     outs = run_hip(name, ins)
     # rows at the rotation-log singularity (|theta| ~ pi, 2pi) are ill-conditioned w.r.t. the
     # fp32 rounding of the INPUT; they are excluded by the 99.99% quantile, the bulk must be tight
     for o, r in zip(outs, refs):
         e, ok = row_rel_err(o, r)
-        assert np.quantile(e, 0.9999) < (1e-4 if name in AUTOGRAD_OPS else 1e-5), (name, np.quantile(e, 0.9999))
+        assert np.quantile(e, 0.9999) < 1e-5, (name, np.quantile(e, 0.9999))
         assert np.median(e) < 2e-7, (name, np.median(e))
 
 
