@@ -760,10 +760,9 @@ def ops_all_groups(dev, B=10_000_000, reps=10):
                 res[key][name] = [round(ms, 4), round(B * bpr / ms / 1e6 / HBM_PEAK_GBPS, 3)]
                 del o
             del x, X, Y, a, p3, table
-    fr = {k: v[1] for d in ("f32", "f64") for k, v in res[d].items()}
     res["min_frac_f32"] = min(v[1] for v in res["f32"].values())
     res["min_frac_f64"] = min(v[1] for v in res["f64"].values())
-    res["below_0.65"] = sorted(k + ("" if k in res["f32"] and res["f32"][k][1] < 0.65 else ":f64") for k, v in fr.items() if v < 0.65)
+    res["below_0.65"] = sorted([k for k, v in res["f32"].items() if v[1] < 0.65] + [k + ":f64" for k, v in res["f64"].items() if v[1] < 0.65])
     return res
 
 
