@@ -81,6 +81,11 @@ _SUFFIX = {torch.float32: "_f32", torch.float64: "_f64"}
 _test_backend = None
 
 
+def tune_library() -> HipLibrary:
+    """lib/libpplie_tune.so (build.build_tune): launch-shape variants for the measurement tools; never loaded by the product"""
+    return HipLibrary(_LIB_PATH.with_name("libpplie_tune.so"))
+
+
 def library() -> HipLibrary:
     return _lib
 

@@ -116,6 +116,32 @@ def build_torch_ext(force: bool = False, verbose: bool = True):
     return out
 
 
+TUNE_SRC = PKG.parent / "tools" / "micro" / "tuning_variants.hip"
+TUNE_LIB = "libpplie_tune.so"
+
+
+def build_tune(force: bool = False, verbose: bool = True):
+    """tools/micro/tuning_variants.hip -> lib/libpplie_tune.so: launch-shape variants of the row kernels for the A/B tools
+    (tools/tune_*.py, tools/pmc_probe.py).  Measurement scaffolding: NOT linked into libpplie.so (round 4 shipped it inside the
+    product binary), not declared in include/pplie.h, loaded only by those tools (``_C.tune_library()``)."""
+    if not TUNE_SRC.exists():
+        return None
+    OBJDIR.mkdir(exist_ok=True)
+    LIBDIR.mkdir(exist_ok=True)
+    out = LIBDIR / TUNE_LIB
+    stamp = OBJDIR / "tuning_variants.sha1"
+    dig = _digest(TUNE_SRC)
+    if not force and out.exists() and stamp.exists() and stamp.read_text() == dig:
+        return out
+    r = subprocess.run([HIPCC, *CFLAGS, "-shared", str(TUNE_SRC), "-o", str(out)], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc failed on {TUNE_SRC.name}:\n{r.stdout}\n{r.stderr}")
+    stamp.write_text(dig)
+    if verbose:
+        print(f"[pypose_amd.build] {out} ({out.stat().st_size >> 10} KiB)")
+    return out
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--force", action="store_true")
@@ -124,6 +150,7 @@ if __name__ == "__main__":
     try:
         build(force=a.force, jobs=a.j)
         build_torch_ext(force=a.force)
+        build_tune(force=a.force)
     except RuntimeError as e:
         print(e, file=sys.stderr)
         sys.exit(1)

@@ -53,4 +53,13 @@
   PPLIE_EXPORT(pplie_##g##_adjt_fwd, pplie::Op_##g##_adjt_fwd)                   \
   PPLIE_EXPORT(pplie_##g##_adjt_bwd, pplie::Op_##g##_adjt_bwd)                   \
   PPLIE_EXPORT(pplie_##g##_jinvp_fwd, pplie::Op_##g##_jinvp_fwd)                 \
-  PPLIE_EXPORT(pplie_##g##_jinvp_bwd, pplie::Op_##g##_jinvp_bwd)
+  PPLIE_EXPORT(pplie_##g##_jinvp_bwd, pplie::Op_##g##_jinvp_bwd)                 \
+  /* the Function backwards with a broadcast cotangent (rowmap.h GB): first node of op(x).sum().backward() */ \
+  PPLIE_EXPORT_GB(pplie_##g##_exp_bwd, pplie::Op_##g##_exp_bwd)                  \
+  PPLIE_EXPORT_GB(pplie_##g##_log_bwd, pplie::Op_##g##_log_bwd)                  \
+  PPLIE_EXPORT_GB(pplie_##g##_inv_bwd, pplie::Op_##g##_inv_bwd)                  \
+  PPLIE_EXPORT_GB(pplie_##g##_mul_bwd, pplie::Op_##g##_mul_bwd)                  \
+  PPLIE_EXPORT_GB(pplie_##g##_act_bwd, pplie::Op_##g##_act_bwd)                  \
+  PPLIE_EXPORT_GB(pplie_##g##_act4_bwd, pplie::Op_##g##_act4_bwd)                \
+  PPLIE_EXPORT_GB(pplie_##g##_adj_bwd, pplie::Op_##g##_adj_bwd)                  \
+  PPLIE_EXPORT_GB(pplie_##g##_adjt_bwd, pplie::Op_##g##_adjt_bwd)

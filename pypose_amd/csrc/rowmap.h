@@ -127,15 +127,28 @@ struct NoParam {};
 template <class A, class B> struct SameType { static constexpr bool v = false; };
 template <class A> struct SameType<A, A> { static constexpr bool v = true; };
 
-template <class T, class Op, int RPT, int BLOCK, bool VEC, bool ROLL = false, class Prm = NoParam>
+// GB ("cotangent broadcast"): the LAST input is ONE row shared by all n rows -- what autograd hands the first backward node
+// of `op(x).sum().backward()` (a stride-0 expansion of one scalar).  That row is read once per workgroup into registers; no slab,
+// no HBM traffic for it: materialising it instead costs W x 4 bytes written + read per row (15 % of the Exp-Log chain's traffic).
+template <class T, class Op, int RPT, int BLOCK, bool VEC, bool ROLL = false, class Prm = NoParam, bool GB = false>
 __global__ void __launch_bounds__(BLOCK)
 rowmap_lds_kernel(const T* i0, const T* i1, const T* i2, T* o0, T* o1, int64_t n, Prm prm = Prm()) {
   // (no __restrict__: an output may be the buffer of an input -- the optimizer's in-place retraction -- and every tile is
   //  in LDS before any of its rows is written back)
   constexpr int TILE = RPT * BLOCK;
-  constexpr int IW0 = Op::IW0, IW1 = Op::IW1, IW2 = Op::IW2, OW0 = Op::OW0, OW1 = Op::OW1;
+  constexpr int OW0 = Op::OW0, OW1 = Op::OW1;
+  constexpr int LASTIN = Op::IW2 > 0 ? 2 : (Op::IW1 > 0 ? 1 : 0);
+  // slab widths: the broadcast input has none
+  constexpr int IW0 = (GB && LASTIN == 0) ? 0 : Op::IW0, IW1 = (GB && LASTIN == 1) ? 0 : Op::IW1, IW2 = (GB && LASTIN == 2) ? 0 : Op::IW2;
+  constexpr int GW = LASTIN == 2 ? Op::IW2 : (LASTIN == 1 ? Op::IW1 : Op::IW0);
   constexpr int OFF_I1 = TILE * IW0, OFF_I2 = OFF_I1 + TILE * IW1, OFF_O0 = OFF_I2 + TILE * IW2,
                 OFF_O1 = OFF_O0 + TILE * OW0, TOTAL = OFF_O1 + TILE * OW1;
+  T gb[AtLeast1<GB ? GW : 0>::v];
+  if constexpr (GB) {
+    const T* gp = LASTIN == 2 ? i2 : (LASTIN == 1 ? i1 : i0);
+#pragma unroll
+    for (int k = 0; k < GW; ++k) gb[k] = gp[k];
+  }
   __shared__ __attribute__((aligned(16))) T lds[TOTAL];
   T* s_i0 = lds;
   T* s_i1 = lds + OFF_I1;
@@ -150,7 +163,7 @@ rowmap_lds_kernel(const T* i0, const T* i1, const T* i2, T* o0, T* o1, int64_t n
     const bool full = left >= TILE;
     const int rows = full ? TILE : (int)left;
 
-    slab_g2s<T, BLOCK, TILE * IW0, VEC>(i0 + row0 * IW0, s_i0, rows * IW0, full);
+    if constexpr (IW0 > 0) slab_g2s<T, BLOCK, TILE * IW0, VEC>(i0 + row0 * IW0, s_i0, rows * IW0, full);
     if constexpr (IW1 > 0) slab_g2s<T, BLOCK, TILE * IW1, VEC>(i1 + row0 * IW1, s_i1, rows * IW1, full);
     if constexpr (IW2 > 0) slab_g2s<T, BLOCK, TILE * IW2, VEC>(i2 + row0 * IW2, s_i2, rows * IW2, full);
     __syncthreads();
@@ -158,10 +171,15 @@ rowmap_lds_kernel(const T* i0, const T* i1, const T* i2, T* o0, T* o1, int64_t n
     auto do_row = [&](int r) {
       const int row = threadIdx.x + r * BLOCK;
       if (row < rows) {
-        T a[AtLeast1<IW0>::v], b[AtLeast1<IW1>::v], c[AtLeast1<IW2>::v], p[AtLeast1<OW0>::v], q[AtLeast1<OW1>::v];
-        row_ld<IW0>(s_i0 + row * IW0, a);
+        T a[AtLeast1<Op::IW0>::v], b[AtLeast1<Op::IW1>::v], c[AtLeast1<Op::IW2>::v], p[AtLeast1<OW0>::v], q[AtLeast1<OW1>::v];
+        if constexpr (IW0 > 0) row_ld<IW0>(s_i0 + row * IW0, a);
         if constexpr (IW1 > 0) row_ld<IW1>(s_i1 + row * IW1, b);
         if constexpr (IW2 > 0) row_ld<IW2>(s_i2 + row * IW2, c);
+        if constexpr (GB) {
+          T* dst = LASTIN == 2 ? c : (LASTIN == 1 ? b : a);
+#pragma unroll
+          for (int k = 0; k < GW; ++k) dst[k] = gb[k];
+        }
         if constexpr (SameType<Prm, NoParam>::v) Op::apply(a, b, c, p, q);
         else Op::apply(a, b, c, p, q, prm);
         row_st<OW0>(s_o0 + row * OW0, p);
@@ -220,7 +238,7 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 // the grid-stride loop only engages beyond 2^30 tiles.
 constexpr int kGridCap = 1 << 30;
 
-template <class T, class Op, int RPT = 2, int BLOCK = 256, bool ROLL = false, class Prm = NoParam>
+template <class T, class Op, int RPT = 2, int BLOCK = 256, bool ROLL = false, class Prm = NoParam, bool GB = false>
 int launch_rowmap(const void* i0, const void* i1, const void* i2, void* o0, void* o1, int64_t n, void* stream,
                   int grid_cap = kGridCap, Prm prm = Prm()) {
   if (n < 0) return PPLIE_EBADARG;
@@ -230,17 +248,18 @@ int launch_rowmap(const void* i0, const void* i1, const void* i2, void* o0, void
   int64_t ntiles = (n + TILE - 1) / TILE;
   int grid = (int)(ntiles < grid_cap ? ntiles : grid_cap);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  bool vec = aligned16(i0) && aligned16(o0) && (Op::IW1 == 0 || aligned16(i1)) && (Op::IW2 == 0 || aligned16(i2)) &&
-             (Op::OW1 == 0 || aligned16(o1));
+  constexpr int LASTIN = Op::IW2 > 0 ? 2 : (Op::IW1 > 0 ? 1 : 0);           // (GB: the broadcast row is read element by element)
+  bool vec = ((GB && LASTIN == 0) || aligned16(i0)) && aligned16(o0) && (Op::IW1 == 0 || (GB && LASTIN == 1) || aligned16(i1)) &&
+             (Op::IW2 == 0 || (GB && LASTIN == 2) || aligned16(i2)) && (Op::OW1 == 0 || aligned16(o1));
   const T* a = static_cast<const T*>(i0);
   const T* b = static_cast<const T*>(i1);
   const T* c = static_cast<const T*>(i2);
   T* p = static_cast<T*>(o0);
   T* q = static_cast<T*>(o1);
   if (vec)
-    hipLaunchKernelGGL((rowmap_lds_kernel<T, Op, RPT, BLOCK, true, ROLL, Prm>), dim3(grid), dim3(BLOCK), 0, st, a, b, c, p, q, n, prm);
+    hipLaunchKernelGGL((rowmap_lds_kernel<T, Op, RPT, BLOCK, true, ROLL, Prm, GB>), dim3(grid), dim3(BLOCK), 0, st, a, b, c, p, q, n, prm);
   else
-    hipLaunchKernelGGL((rowmap_lds_kernel<T, Op, RPT, BLOCK, false, ROLL, Prm>), dim3(grid), dim3(BLOCK), 0, st, a, b, c, p, q, n, prm);
+    hipLaunchKernelGGL((rowmap_lds_kernel<T, Op, RPT, BLOCK, false, ROLL, Prm, GB>), dim3(grid), dim3(BLOCK), 0, st, a, b, c, p, q, n, prm);
   return hipGetLastError() == hipSuccess ? PPLIE_OK : PPLIE_ELAUNCH;
 }
 
@@ -308,6 +327,18 @@ template <class Op> struct TileOf {
   extern "C" int SYM##_f64(const void* i0, const void* i1, const void* i2, void* o0, void* o1, int64_t n,        \
                            void* stream) {                                                                       \
     return pplie::launch_rowmap<double, OP<double>, 1>(i0, i1, i2, o0, o1, n, stream);                           \
+  }
+
+// the same op with its LAST input broadcast from one row (rowmap_lds_kernel GB): SYM_gb_f32 / SYM_gb_f64
+#define PPLIE_EXPORT_GB(SYM, OP)                                                                                 \
+  extern "C" int SYM##_gb_f32(const void* i0, const void* i1, const void* i2, void* o0, void* o1, int64_t n,     \
+                              void* stream) {                                                                    \
+    return pplie::launch_rowmap<float, OP<float>, pplie::TileOf<OP<float>>::rpt32, pplie::TileOf<OP<float>>::block32,  \
+                                pplie::TileOf<OP<float>>::roll32, pplie::NoParam, true>(i0, i1, i2, o0, o1, n, stream); \
+  }                                                                                                              \
+  extern "C" int SYM##_gb_f64(const void* i0, const void* i1, const void* i2, void* o0, void* o1, int64_t n,     \
+                              void* stream) {                                                                    \
+    return pplie::launch_rowmap<double, OP<double>, 1, 256, false, pplie::NoParam, true>(i0, i1, i2, o0, o1, n, stream); \
   }
 
 }  // namespace pplie

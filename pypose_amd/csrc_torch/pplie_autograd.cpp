@@ -62,7 +62,7 @@ bool plain(const at::Tensor& t, const at::Tensor& ref) {
 struct RowOp : public torch::autograd::Function<RowOp> {
   // saved: which tensors the backward kernel reads, in its argument order: k >= 0 = input k, -1 = the output
   static at::Tensor forward(AutogradContext* ctx, const at::Tensor& a, const c10::optional<at::Tensor>& b, int64_t fwd_fn, int64_t bwd_fn,
-                            int64_t out_w, std::vector<int64_t> saved, std::vector<int64_t> bwd_out_w, int64_t rule) {
+                            int64_t out_w, std::vector<int64_t> saved, std::vector<int64_t> bwd_out_w, int64_t rule, int64_t bwd_gb_fn) {
     std::vector<at::Tensor> ins{a};
     if (b.has_value()) ins.push_back(*b);
     at::Tensor out = launch(fwd_fn, ins, {out_w})[0];
@@ -70,6 +70,7 @@ struct RowOp : public torch::autograd::Function<RowOp> {
     for (int64_t k : saved) keep.push_back(k < 0 ? out : ins[(size_t)k]);
     ctx->save_for_backward(keep);
     ctx->saved_data["bwd_fn"] = bwd_fn;
+    ctx->saved_data["bwd_gb_fn"] = bwd_gb_fn;
     ctx->saved_data["bwd_out_w"] = bwd_out_w;
     ctx->saved_data["rule"] = rule;
     ctx->saved_data["nin"] = (int64_t)ins.size();
@@ -79,7 +80,7 @@ struct RowOp : public torch::autograd::Function<RowOp> {
   static variable_list backward(AutogradContext* ctx, variable_list grads) {
     variable_list saved = ctx->get_saved_variables();
     const int64_t nin = ctx->saved_data["nin"].toInt();
-    variable_list res(8);                                          // (one slot per forward argument; non-tensors stay undefined)
+    variable_list res(9);                                          // (one slot per forward argument; non-tensors stay undefined)
     at::Tensor g = grads[0];
     if (at::GradMode::is_enabled() || !g.has_storage()) {
       // create_graph=True: the backward has to be differentiable -- the Python rule of this operator (torch operations).  A
@@ -104,6 +105,41 @@ struct RowOp : public torch::autograd::Function<RowOp> {
     }
     std::vector<at::Tensor> ins(saved.begin(), saved.end());
     const at::Tensor& ref = ins[0];
+    // A cotangent that is ONE row seen through stride-0 leading dimensions (what sum().backward() hands its producer): the
+    // kernel's broadcast variant (pplie_<op>_bwd_gb, csrc/rowmap.h GB) reads that row once per workgroup -- materialising it
+    // costs W x 4 bytes written and read per row, 15 % of the traffic of x.Exp().Log().sum().backward() at 10 M rows.
+    const int64_t gb_fn = ctx->saved_data["bwd_gb_fn"].toInt();
+    bool bcast = gb_fn != 0 && g.defined() && g.is_cuda() && g.dim() >= 1 && g.scalar_type() == ref.scalar_type() &&
+                 g.device() == ref.device() && g.numel() > g.size(-1) && (g.size(-1) == 1 || g.stride(-1) == 1 || g.stride(-1) == 0);
+    for (int64_t d = 0; bcast && d + 1 < g.dim(); ++d) bcast = g.size(d) == 1 || g.stride(d) == 0;
+    if (bcast) {
+      std::vector<int64_t> zero(g.dim(), 0);
+      at::Tensor row = g.size(-1) > 1 && g.stride(-1) == 0 ? g.as_strided({g.size(-1)}, {0}).contiguous()     // (one scalar seen W times)
+                                                           : g.as_strided({g.size(-1)}, {1});
+      std::vector<at::Tensor> outs;
+      {
+        c10::hip::HIPGuardMasqueradingAsCUDA guard(ref.device());
+        const int64_t n = ref.size(-1) > 0 ? ref.numel() / ref.size(-1) : 0;
+        std::vector<int64_t> lead(ref.sizes().begin(), ref.sizes().end() - 1);
+        for (int64_t w : ctx->saved_data["bwd_out_w"].toIntVector()) {
+          std::vector<int64_t> shp = lead;
+          shp.push_back(w);
+          outs.push_back(at::empty(shp, ref.options()));
+        }
+        if (n > 0) {
+          const void* pi[3] = {nullptr, nullptr, nullptr};
+          void* po[2] = {nullptr, nullptr};
+          for (size_t k = 0; k < ins.size(); ++k) pi[k] = ins[k].data_ptr();
+          pi[ins.size()] = row.data_ptr();
+          for (size_t k = 0; k < outs.size(); ++k) po[k] = outs[k].data_ptr();
+          const int code = reinterpret_cast<rowfn_t>(gb_fn)(pi[0], pi[1], pi[2], po[0], po[1], n,
+                                                           (void*)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(ref.device().index()).stream());
+          TORCH_CHECK(code == 0, "pplie row operator (broadcast cotangent) failed with status ", code);
+        }
+      }
+      for (int64_t k = 0; k < nin && k < (int64_t)outs.size(); ++k) res[(size_t)k] = outs[(size_t)k];
+      return res;
+    }
     if (!plain(g, ref) || g.sizes().slice(0, g.dim() - 1) != ref.sizes().slice(0, ref.dim() - 1)) {
       std::vector<int64_t> shp(ref.sizes().begin(), ref.sizes().end() - 1);      // (an expanded / strided cotangent: e.g. out of sum())
       shp.push_back(g.size(-1));
@@ -117,10 +153,10 @@ struct RowOp : public torch::autograd::Function<RowOp> {
 };
 
 at::Tensor row_op(const at::Tensor& a, const c10::optional<at::Tensor>& b, int64_t fwd_fn, int64_t bwd_fn, int64_t out_w,
-                  std::vector<int64_t> saved, std::vector<int64_t> bwd_out_w, int64_t rule) {
+                  std::vector<int64_t> saved, std::vector<int64_t> bwd_out_w, int64_t rule, int64_t bwd_gb_fn) {
   TORCH_CHECK(plain(a, a) && (!b.has_value() || (plain(*b, a) && b->sizes().slice(0, b->dim() - 1) == a.sizes().slice(0, a.dim() - 1))),
               "pplie native row operator: contiguous device tensors of one dtype and one leading shape");
-  return RowOp::apply(a, b, fwd_fn, bwd_fn, out_w, saved, bwd_out_w, rule);
+  return RowOp::apply(a, b, fwd_fn, bwd_fn, out_w, saved, bwd_out_w, rule, bwd_gb_fn);
 }
 
 void set_rule(int64_t key, py::object fn) { py_rules()[key] = std::move(fn); }
@@ -248,7 +284,8 @@ at::Tensor scan_op(at::Tensor x, int64_t fwd_fn, int64_t bwd_fn, int64_t nseq, i
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.doc() = "native autograd nodes for the row operators of libpplie (pypose_amd/csrc_torch/pplie_autograd.cpp)";
-  m.def("row_op", &row_op, "forward of one row operator recorded as a native autograd node");
+  m.def("row_op", &row_op, "forward of one row operator recorded as a native autograd node", py::arg("a"), py::arg("b"), py::arg("fwd_fn"),
+        py::arg("bwd_fn"), py::arg("out_w"), py::arg("saved"), py::arg("bwd_out_w"), py::arg("rule"), py::arg("bwd_gb_fn") = 0);
   m.def("set_rule", &set_rule, "register the differentiable Python rule of an operator's backward (double backward)");
   m.def("scan_op", &scan_op, "pplie_scan_<group> in place, recorded as a native autograd node (backward: pplie_scan_<group>_bwd)");
   m.def("imu_integrate", &imu_integrate, "pplie_imu_integrate recorded as a native autograd node (backward: pplie_imu_integrate_bwd)");

@@ -316,7 +316,8 @@ def _make_fwd(clsname, g, kind, doc):
                     # the plain eager case: a native autograd node around the same two kernels (csrc_torch/pplie_autograd.cpp)
                     dt = ins[0].dtype
                     return nat.row_op(ins[0], ins[1] if len(ins) == 2 else None, _kernel_address(fwd_kernel, dt),
-                                      _kernel_address(bwd_kernel, dt), fout, saved_spec, list(bout), cls._native_rule(nat))
+                                      _kernel_address(bwd_kernel, dt), fout, saved_spec, list(bout), cls._native_rule(nat),
+                                      _kernel_address(bwd_kernel + "_gb", dt))       # (broadcast cotangent: rowmap.h GB)
                 # recorded, but no functorch transform: the engine's own apply, past Function.apply's per-call
                 # inspect.signature binding of forward()'s defaults (~15 us; there are none)
                 return super(torch.autograd.Function, cls).apply(*ins)

@@ -310,3 +310,54 @@ def test_kernels_follow_torchs_current_stream():
         l = [float(opt.step(inp)) for _ in range(3)]
     side.synchronize()
     assert opt.linearization == "fused:se3inv" and l[-1] < 1e-6 * l0
+
+
+GB_KINDS = ("exp_bwd", "log_bwd", "inv_bwd", "mul_bwd", "act_bwd", "act4_bwd", "adj_bwd", "adjt_bwd")
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("name", [f"{g}_{k}" for g in lie_np.GROUPS for k in GB_KINDS])
+def test_broadcast_cotangent_variant_equals_the_materialised_launch(name, dtype):
+    """pplie_<op>_bwd_gb (csrc/rowmap.h GB): the cotangent is ONE row shared by all rows, read once per workgroup; the same bits as
+    the ordinary entry on that row repeated (ragged tail, 1 row, more rows than one tile)"""
+    import ctypes
+    from pypose_amd import _C
+    rng = np.random.default_rng(zlib.crc32(name.encode()) + 17)
+    for n in (1, 700, 5003):
+        ins = _random_inputs(name, n, dtype, rng)
+        g0 = ins[-1][:1].copy()
+        full = [*ins[:-1], np.repeat(g0, n, axis=0)]
+        want = run_hip(name, full)
+        dev = _dev()
+        t_in = [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in ins[:-1]] + [torch.from_numpy(g0).to(dev)]
+        outs = [torch.empty((n, w), dtype=t_in[0].dtype, device=dev) for w in lie_np.op_signature(name)[1]]
+        fn = _C.library().symbol("pplie_" + name + "_gb" + ("_f32" if dtype == np.float32 else "_f64"))
+        pi = [t.data_ptr() for t in t_in] + [None] * (3 - len(t_in))
+        po = [t.data_ptr() for t in outs] + [None] * (2 - len(outs))
+        assert fn(*pi, *po, n, _C.stream_ptr(dev)) == 0
+        torch.cuda.synchronize()
+        for o, w in zip(outs, want):
+            assert np.array_equal(o.cpu().numpy(), w), (name, n)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_sum_backward_takes_the_broadcast_route_and_equals_the_materialised_one(dtype):
+    """x.Exp().Log().sum().backward(): autograd hands Log's node a stride-0 cotangent; the native node launches the _gb entry
+    (no [B, 6] buffer of ones) -- gradients bit-equal to the route with a materialised cotangent"""
+    import pypose_amd as pp
+    from pypose_amd.lietensor import operation as _op
+    assert _op._native() is not None, "native autograd nodes not built"
+    torch.manual_seed(3)
+    x = pp.randn_se3(4099, device=_dev(), dtype=dtype, requires_grad=True)
+    y = x.Exp().Log()
+    (g_mat,) = torch.autograd.grad(y, x, torch.ones_like(y), retain_graph=True)
+    y.sum().backward()
+    assert torch.equal(x.grad.tensor() if hasattr(x.grad, "tensor") else x.grad, g_mat.tensor() if hasattr(g_mat, "tensor") else g_mat)
+    # a cotangent broadcast along the batch only ([1, 6] row with distinct components)
+    x.grad = None
+    w = torch.arange(1.0, 7.0, device=_dev(), dtype=dtype)
+    y = x.Exp().Log()
+    (g_mat,) = torch.autograd.grad(y, x, w.expand(4099, 6).contiguous(), retain_graph=True)
+    (y.tensor() * w).sum().backward()
+    got = x.grad.tensor() if hasattr(x.grad, "tensor") else x.grad
+    assert torch.allclose(got, g_mat.tensor() if hasattr(g_mat, "tensor") else g_mat, rtol=0, atol=0)

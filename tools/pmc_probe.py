@@ -13,7 +13,8 @@ dev = torch.device("cuda:0")
 torch.manual_seed(0)
 x = pp.randn_se3(N, device=dev)
 lib = _C.library()
-fcopy = lib.symbol("pplie_var_copy", [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p])
+tune = _C.tune_library()
+fcopy = tune.symbol("pplie_var_copy", [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p])
 st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 src = torch.empty(N * 6, device=dev); dst = torch.empty_like(src)
 for _ in range(3):

@@ -5,7 +5,7 @@ import torch
 from pypose_amd import _C
 N = 10_000_000
 dev = torch.device("cuda:0")
-lib = _C.library()
+lib = _C.tune_library()
 SIG = [ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 5 + [ctypes.c_int64, ctypes.c_void_p]
 st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 ops = {"se3_exp_bwd": ((6, 7), (6,)), "se3_log_bwd": ((6, 6), (7,)), "se3_mul_fwd": ((7, 7), (7,)),

@@ -9,7 +9,7 @@ from pypose_amd import _C
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
 dev = torch.device("cuda:0")
-lib = _C.library()
+lib = _C.tune_library()
 VARSIG = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]
 fexp = lib.symbol("pplie_var_se3_exp_f32", VARSIG)
 flog = lib.symbol("pplie_var_se3_log_f32", VARSIG)
