@@ -317,6 +317,17 @@ template <class Op> struct TileOf {
   template <> struct TileOf<OP<float>> { static constexpr int rpt32 = RPT32; static constexpr int rpt64 = 1; \
                                          static constexpr int block32 = BLOCK32; static constexpr bool roll32 = ROLL32; };
 
+// fp64 shape of an op (its own trait: the fp32 specialisations above stay as they are).  Default 256 x 1 unrolled; ops measured
+// faster at another shape at 10 M rows (tools/tune_general.py --f64, profiles/r05) specialise it with PPLIE_TILE64.
+template <class Op> struct TileOf64 {
+  static constexpr int rpt = 1;
+  static constexpr int block = 256;
+  static constexpr bool roll = false;
+};
+#define PPLIE_TILE64(OP, RPT64, BLOCK64, ROLL64) \
+  template <> struct TileOf64<OP<double>> { static constexpr int rpt = RPT64; static constexpr int block = BLOCK64; \
+                                            static constexpr bool roll = ROLL64; };
+
 // C-ABI export of one op in both precisions (uniform signature, see include/pplie.h).
 #define PPLIE_EXPORT(SYM, OP)                                                                                    \
   extern "C" int SYM##_f32(const void* i0, const void* i1, const void* i2, void* o0, void* o1, int64_t n,        \
@@ -326,7 +337,8 @@ template <class Op> struct TileOf {
   }                                                                                                              \
   extern "C" int SYM##_f64(const void* i0, const void* i1, const void* i2, void* o0, void* o1, int64_t n,        \
                            void* stream) {                                                                       \
-    return pplie::launch_rowmap<double, OP<double>, 1>(i0, i1, i2, o0, o1, n, stream);                           \
+    return pplie::launch_rowmap<double, OP<double>, pplie::TileOf64<OP<double>>::rpt, pplie::TileOf64<OP<double>>::block, \
+                                pplie::TileOf64<OP<double>>::roll>(i0, i1, i2, o0, o1, n, stream);                   \
   }
 
 // the same op with its LAST input broadcast from one row (rowmap_lds_kernel GB): SYM_gb_f32 / SYM_gb_f64
@@ -338,7 +350,8 @@ template <class Op> struct TileOf {
   }                                                                                                              \
   extern "C" int SYM##_gb_f64(const void* i0, const void* i1, const void* i2, void* o0, void* o1, int64_t n,     \
                               void* stream) {                                                                    \
-    return pplie::launch_rowmap<double, OP<double>, 1, 256, false, pplie::NoParam, true>(i0, i1, i2, o0, o1, n, stream); \
+    return pplie::launch_rowmap<double, OP<double>, pplie::TileOf64<OP<double>>::rpt, pplie::TileOf64<OP<double>>::block, \
+                                pplie::TileOf64<OP<double>>::roll, pplie::NoParam, true>(i0, i1, i2, o0, o1, n, stream); \
   }
 
 }  // namespace pplie

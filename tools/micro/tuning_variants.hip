@@ -50,23 +50,28 @@ PPLIE_OP_1_1(Var_se3_exp_fwd, se3_exp, 6, 7)
 PPLIE_OP_1_1(Var_se3_log_fwd, se3_log, 7, 6)
 PPLIE_OP_2_1(Var_se3_act_fwd, se3_act, 7, 3, 3)
 PPLIE_OP_2_1(Var_se3_inv_bwd, se3_inv_bwd, 7, 7, 7)
-template <class Op>
+PPLIE_OP_1_1(Var_so3_exp_fwd, so3_exp, 3, 4)
+PPLIE_OP_1_1(Var_so3_log_fwd, so3_log, 4, 3)
+PPLIE_OP_1_1(Var_rxso3_exp_fwd, rxso3_exp, 4, 5)
+PPLIE_OP_1_1(Var_rxso3_log_fwd, rxso3_log, 5, 4)
+PPLIE_OP_2_1(Var_rxso3_mul_fwd, rxso3_mul, 5, 5, 5)
+template <class Op, class float_t = float>
 int var_general(int rpt, int block, const void* a, const void* b, const void* c, void* o, void* p, int64_t n, void* st) {
   // block: 256 / 128 = unrolled rows ; 1256 / 1128 = rolled rows (one row's registers at a time)
   if (block == 256) {
-    if (rpt == 1) return launch_rowmap<float, Op, 1, 256>(a, b, c, o, p, n, st);
-    if (rpt == 2) return launch_rowmap<float, Op, 2, 256>(a, b, c, o, p, n, st);
-    if (rpt == 4) return launch_rowmap<float, Op, 4, 256>(a, b, c, o, p, n, st);
+    if (rpt == 1) return launch_rowmap<float_t, Op, 1, 256>(a, b, c, o, p, n, st);
+    if (rpt == 2) return launch_rowmap<float_t, Op, 2, 256>(a, b, c, o, p, n, st);
+    if (rpt == 4) return launch_rowmap<float_t, Op, 4, 256>(a, b, c, o, p, n, st);
   } else if (block == 128) {
-    if (rpt == 1) return launch_rowmap<float, Op, 1, 128>(a, b, c, o, p, n, st);
-    if (rpt == 2) return launch_rowmap<float, Op, 2, 128>(a, b, c, o, p, n, st);
-    if (rpt == 4) return launch_rowmap<float, Op, 4, 128>(a, b, c, o, p, n, st);
+    if (rpt == 1) return launch_rowmap<float_t, Op, 1, 128>(a, b, c, o, p, n, st);
+    if (rpt == 2) return launch_rowmap<float_t, Op, 2, 128>(a, b, c, o, p, n, st);
+    if (rpt == 4) return launch_rowmap<float_t, Op, 4, 128>(a, b, c, o, p, n, st);
   } else if (block == 1256) {
-    if (rpt == 2) return launch_rowmap<float, Op, 2, 256, true>(a, b, c, o, p, n, st);
-    if (rpt == 4) return launch_rowmap<float, Op, 4, 256, true>(a, b, c, o, p, n, st);
+    if (rpt == 2) return launch_rowmap<float_t, Op, 2, 256, true>(a, b, c, o, p, n, st);
+    if (rpt == 4) return launch_rowmap<float_t, Op, 4, 256, true>(a, b, c, o, p, n, st);
   } else if (block == 1128) {
-    if (rpt == 2) return launch_rowmap<float, Op, 2, 128, true>(a, b, c, o, p, n, st);
-    if (rpt == 4) return launch_rowmap<float, Op, 4, 128, true>(a, b, c, o, p, n, st);
+    if (rpt == 2) return launch_rowmap<float_t, Op, 2, 128, true>(a, b, c, o, p, n, st);
+    if (rpt == 4) return launch_rowmap<float_t, Op, 4, 128, true>(a, b, c, o, p, n, st);
   }
   return PPLIE_EBADARG;
 }
@@ -76,6 +81,21 @@ int var_general(int rpt, int block, const void* a, const void* b, const void* c,
                                         void* p, int64_t n, void* st) {                                              \
     return pplie::var_general<pplie::Var_##NAME<float>>(rpt, block, a, b, c, o, p, n, st);                           \
   }
+#define PPLIE_VAR_GENERAL64(NAME)                                                                                    \
+  extern "C" int pplie_var_##NAME##_f64(int rpt, int block, const void* a, const void* b, const void* c, void* o,    \
+                                        void* p, int64_t n, void* st) {                                              \
+    return pplie::var_general<pplie::Var_##NAME<double>, double>(rpt, block, a, b, c, o, p, n, st);                  \
+  }
+PPLIE_VAR_GENERAL(so3_exp_fwd)
+PPLIE_VAR_GENERAL(rxso3_mul_fwd)
+PPLIE_VAR_GENERAL64(so3_exp_fwd)
+PPLIE_VAR_GENERAL64(so3_log_fwd)
+PPLIE_VAR_GENERAL64(se3_exp_fwd)
+PPLIE_VAR_GENERAL64(se3_log_fwd)
+PPLIE_VAR_GENERAL64(sim3_exp_fwd)
+PPLIE_VAR_GENERAL64(sim3_log_fwd)
+PPLIE_VAR_GENERAL64(rxso3_exp_fwd)
+PPLIE_VAR_GENERAL64(rxso3_log_fwd)
 PPLIE_VAR_GENERAL(se3_exp_bwd)
 PPLIE_VAR_GENERAL(se3_log_bwd)
 PPLIE_VAR_GENERAL(se3_mul_fwd)
