@@ -94,13 +94,18 @@ def pgo100k():
     return edges, rel, init, ref
 
 
-def _rounding_sensitivity(edges, rel, nodes):
-    """|L(round32(inputs)) - L(inputs)| / L with L evaluated by the reference's own ops in fp64: how far the loss of the problem
-    an fp32 run is GIVEN lies from the loss of the fp64 problem, before any arithmetic of ours"""
-    from oracle import ref_restate
-    L = lambda n, z: float(ref_restate.pgo_blocks(n, edges, z)[0].square().sum())
-    exact = L(nodes, rel)
-    return abs(L(nodes.float().double(), rel.float().double()) - exact) / exact
+def _pgo100k_fp32_reference(edges, rel, init):
+    """the reference's loop in fp32 with tight solves on this problem: tests/golden/pgo100k_fp32_ref.json (recorded by
+    tests/golden/make_pgo100k_golden.py, ~90 s of host time) if the problem generated here is the recorded one, else computed now"""
+    import json
+    import os
+    from tests.golden.make_pgo100k_golden import checksum, run
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pgo100k_fp32_ref.json")
+    if os.path.exists(path):
+        rec = json.load(open(path))
+        if np.allclose(rec["checksum"], checksum(edges, rel, init), rtol=1e-13, atol=0):
+            return rec
+    return run(edges, rel, init)
 
 
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
@@ -109,14 +114,14 @@ def test_pgo_100k_400k_tight_solves_equal_reference_restatement(pgo100k, dtype):
     tail -- with the linear solves run tight on both sides so that the solve error masks nothing.
     fp64 (PCG 1e-10 against the reference's CG 1e-10): per-step loss to 1e-8, damping / accept-reject equal, relative pose across
     every edge to 1e-6.
-    fp32 (PCG 1e-7 against the SAME fp64 reference run): north_star's "LM-step numerics within 1e-5 of reference" on the scale of
-    the loss each step started from, plus what rounding the INPUTS to fp32 does to the loss before any arithmetic of ours (the
-    measured, printed sensitivity: translations of ~100 units rounded at 6e-6 against residuals of 0.02), times 4."""
+    fp32 (PCG 1e-7): north_star's "LM-step numerics within 1e-5 of reference" literally -- per-step loss within 1e-5 of the
+    REFERENCE'S OWN fp32 run of the same loop on the same rounded problem (CG 1e-7), same decisions.  Against the fp64 run both
+    fp32 runs sit 1e-5 ... 7e-5 away (measured: ours 1.8e-5 / 6.6e-5 / 1.5e-5, the reference's 1.3e-5 / 7.3e-5 / 1.0e-5): that
+    distance is fp32 itself, asserted here only as "ours is no farther from fp64 than 1.5 x the reference's fp32 + 1e-5"."""
     edges, rel, init, ref = pgo100k
     graph = PoseGraph(pp.SE3(init.to(dtype).to(DEV)))
     tol = 1e-10 if dtype == torch.float64 else 1e-7
     opt = pp.optim.LM(graph, solver=pp.optim.solver.PCG(tol=tol, maxiter=4000), strategy=pp.optim.strategy.TrustRegion(radius=1e4))
-    l0 = float(graph(edges.to(DEV), pp.SE3(rel.to(dtype).to(DEV))).detach().double().square().sum())
     rec = run_steps(opt, ((edges.to(DEV), pp.SE3(rel.to(dtype).to(DEV))),), {}, 3)
     assert rec["kind"][-1] == "fused:pgo", rec["kind"]
     assert {w.sym for w in opt._pcg_workspaces.values()} == {"pack"}
@@ -130,12 +135,16 @@ def test_pgo_100k_400k_tight_solves_equal_reference_restatement(pgo100k, dtype):
         np.testing.assert_allclose(rec["loss"], ref["loss"], rtol=1e-8)
         assert err <= 1e-6, err
         return
-    sens = max(_rounding_sensitivity(edges, rel, init), _rounding_sensitivity(edges, rel, ref["final"]))
-    start = [l0] + list(ref["loss"][:-1])
-    over = [abs(a - b) / (1e-5 * s0 + 4 * sens * b) for a, b, s0 in zip(rec["loss"], ref["loss"], start)]
-    print(f"\nfp32 100k/400k: loss {rec['loss']} vs fp64 reference {ref['loss']}; relative {[abs(a - b) / b for a, b in zip(rec['loss'], ref['loss'])]}; "
-          f"input-rounding sensitivity of the loss {sens:.2e}; error over bound {over}; edge-relative pose error {err:.2e}")
-    assert max(over) <= 1.0, (over, sens)
+    ref32 = _pgo100k_fp32_reference(edges, rel, init)
+    d_ours = [abs(a - b) / b for a, b in zip(rec["loss"], ref["loss"])]
+    d_ref = [abs(a - b) / b for a, b in zip(ref32["loss"], ref["loss"])]
+    d_32 = [abs(a - b) / b for a, b in zip(rec["loss"], ref32["loss"])]
+    print(f"\nfp32 100k/400k losses: ours {rec['loss']}, reference fp32 {ref32['loss']}, reference fp64 {ref['loss']}; relative: ours vs "
+          f"reference fp32 {d_32}, ours vs fp64 {d_ours}, reference fp32 vs fp64 {d_ref}; edge-relative pose error vs fp64 {err:.2e}")
+    np.testing.assert_allclose(rec["loss"], ref32["loss"], rtol=1e-5)
+    assert rec["reject"] == ref32["reject"]
+    np.testing.assert_allclose(rec["damping"], ref32["damping"], rtol=1e-12)
+    assert all(a <= 1.5 * b + 1e-5 for a, b in zip(d_ours, d_ref)), (d_ours, d_ref)
     assert err <= 2e-4, err
 
 
