@@ -267,6 +267,23 @@ template <class T> __device__ __forceinline__ T slot_total(const T* base) {
   for (int k = 0; k < kSlots; ++k) s += base[k * kStride];
   return s;
 }
+// ---- coarse sums of the two-level preconditioner (block-Jacobi + the gauge modes Z = 1_N (x) I_M, see csrc/pcg_persist.hip "CZ"):
+//   cs: T[2 sets][kSlots][32]   one 128-byte (fp32) line per (set, slot); element q of a line:
+//       CS_E + i  = sum_n shift[n, i]  (= (Z^T A Z)_ii; set 0 only, written once per solve by pplie_pcg_prepare_coarse)
+//       CS_SQ + i = (Z^T q)_i          (K1)            CS_SR + i = (Z^T r)_i   (prepare / K2, into the NEXT iteration's set)
+// a workgroup adds all its entries of a kind with ONE wave instruction (lanes 0..M-1 on one line), a reader sums 32 lines.
+enum { CS_E = 0, CS_SQ = 8, CS_SR = 16, CS_LINE = 32 };
+template <class T> __device__ __forceinline__ T* cs_line(T* cs, int set) { return cs + ((size_t)set * kSlots + (blockIdx.x & (kSlots - 1))) * CS_LINE; }
+// totals of one set's 32 quantities into LDS `out[32]` (threads 0..31 of the workgroup; caller synchronises)
+template <class T> __device__ __forceinline__ void cs_totals(const T* cs, int set, T* out) {
+  if (threadIdx.x < CS_LINE) {
+    const T* base = cs + (size_t)set * kSlots * CS_LINE + threadIdx.x;
+    T v = T(0);
+#pragma unroll 8
+    for (int k = 0; k < kSlots; ++k) v += base[k * CS_LINE];
+    out[threadIdx.x] = v;
+  }
+}
 // K1 prologue (workgroup 0): clear the idle set for the accumulations of this and the next iteration
 template <class T> __device__ __forceinline__ void clear_idle_set(T* scal, int idle) {
   if (blockIdx.x == 0 && threadIdx.x < 3 * kSlots) squant(scal, idle, threadIdx.x / kSlots)[(threadIdx.x % kSlots) * kStride] = T(0);
@@ -816,7 +833,7 @@ template <class T, int M>
 __global__ void __launch_bounds__(256)
 pcg_prepare_kernel(const T* __restrict__ B, const T* __restrict__ g, T* __restrict__ D, T* __restrict__ Binv,
                    T* __restrict__ shift, T* __restrict__ x, T* __restrict__ r, T* __restrict__ z, T* __restrict__ p,
-                   T* scal, T s_host, T dmin, T dmax, int64_t N, const double* __restrict__ s_dev) {
+                   T* scal, T s_host, T dmin, T dmax, int64_t N, const double* __restrict__ s_dev, T* cs = nullptr) {
   // the compounded damping factor: a launch argument, or (s_dev) a device scalar -- a captured hipGraph of the whole LM trial
   // is replayed with the factor of the day written there
   // (system scope, one lane per workgroup: the scalar may sit in host-pinned memory that the host rewrites between replays of a
@@ -828,6 +845,9 @@ pcg_prepare_kernel(const T* __restrict__ B, const T* __restrict__ g, T* __restri
   }
   const T s = s_dev ? s_sh : s_host;
   T a_rho = T(0), a_bn = T(0);
+  T a_cs[2 * M];                           // coarse sums (cs != nullptr): E_i = sum_n shift[n, i], (Z^T r_0)_i = sum_n r[n, i]
+#pragma unroll
+  for (int i = 0; i < 2 * M; ++i) a_cs[i] = T(0);
   for (int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x; n < N; n += (int64_t)gridDim.x * 256) {
     T A[M * M], X[M * M], rv[M];
 #pragma unroll
@@ -840,6 +860,8 @@ pcg_prepare_kernel(const T* __restrict__ B, const T* __restrict__ g, T* __restri
       A[i * M + i] = c;
       rv[i] = -g[n * M + i];
       a_bn += rv[i] * rv[i];
+      a_cs[i] += c - d;
+      a_cs[M + i] += rv[i];
     }
     Op_spd_inverse_apply<T, M>(A, X);
 #pragma unroll
@@ -862,10 +884,17 @@ pcg_prepare_kernel(const T* __restrict__ B, const T* __restrict__ g, T* __restri
     slot_add(squant(scal, 0, Q_RHO), s1);
     slot_add(squant(scal, 0, Q_BN2), s2);
   }
+  if (cs) {                                // (launch-uniform) set 0 of the coarse sums: quantities CS_E + i and CS_SR + i
+#pragma unroll
+    for (int i = 0; i < 2 * M; ++i) {
+      const T t = block_sum(a_cs[i]);
+      if (threadIdx.x == 0) atomicAdd(cs_line(cs, 0) + (i < M ? CS_E + i : CS_SR + (i - M)), t);
+    }
+  }
 }
 template <class T>
 int pcg_prepare(const void* B, const void* g, void* D, void* Binv, void* shift, void* x, void* r, void* z, void* p, void* scal,
-                double s, double dmin, double dmax, int64_t N, int m, void* stream, const void* s_dev = nullptr) {
+                double s, double dmin, double dmax, int64_t N, int m, void* stream, const void* s_dev = nullptr, void* cs = nullptr) {
   if (N <= 0) return N == 0 ? PPLIE_OK : PPLIE_EBADARG;
   if (!B || !g || !D || !Binv || !shift || !x || !r || !z || !p || !scal) return PPLIE_EBADARG;
   int64_t nb = (N + 255) / 256;
@@ -873,7 +902,7 @@ int pcg_prepare(const void* B, const void* g, void* D, void* Binv, void* shift, 
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 #define LAUNCH(MM)                                                                                                      \
   hipLaunchKernelGGL((pcg_prepare_kernel<T, MM>), dim3(grid), dim3(256), 0, st, (const T*)B, (const T*)g, (T*)D, (T*)Binv, \
-                     (T*)shift, (T*)x, (T*)r, (T*)z, (T*)p, (T*)scal, (T)s, (T)dmin, (T)dmax, N, (const double*)s_dev);
+                     (T*)shift, (T*)x, (T*)r, (T*)z, (T*)p, (T*)scal, (T)s, (T)dmin, (T)dmax, N, (const double*)s_dev, (T*)cs);
   if (m == 6) { LAUNCH(6) } else if (m == 7) { LAUNCH(7) } else if (m == 3) { LAUNCH(3) } else return PPLIE_EBADARG;
 #undef LAUNCH
   return hipGetLastError() == hipSuccess ? PPLIE_OK : PPLIE_ELAUNCH;
@@ -941,6 +970,19 @@ extern "C" int pplie_pcg_prepare_f32(const void* B, const void* g, void* D, void
 extern "C" int pplie_pcg_prepare_f64(const void* B, const void* g, void* D, void* Binv, void* shift, void* x, void* r, void* z,
                                      void* p, void* scal, double s, double dmin, double dmax, int64_t N, int m, void* stream) {
   return pplie::pcg_prepare<double>(B, g, D, Binv, shift, x, r, z, p, scal, s, dmin, dmax, N, m, stream);
+}
+// the same two with the coarse sums of the two-level preconditioner accumulated into `cs` (zeroed by the caller)
+extern "C" int pplie_pcg_prepare_coarse_f32(const void* B, const void* g, void* D, void* Binv, void* shift, void* x, void* r, void* z,
+                                            void* p, void* scal, void* cs, double s, const void* s_dev, double dmin, double dmax,
+                                            int64_t N, int m, void* stream) {
+  if (!cs) return pplie::PPLIE_EBADARG;
+  return pplie::pcg_prepare<float>(B, g, D, Binv, shift, x, r, z, p, scal, s, dmin, dmax, N, m, stream, s_dev, cs);
+}
+extern "C" int pplie_pcg_prepare_coarse_f64(const void* B, const void* g, void* D, void* Binv, void* shift, void* x, void* r, void* z,
+                                            void* p, void* scal, void* cs, double s, const void* s_dev, double dmin, double dmax,
+                                            int64_t N, int m, void* stream) {
+  if (!cs) return pplie::PPLIE_EBADARG;
+  return pplie::pcg_prepare<double>(B, g, D, Binv, shift, x, r, z, p, scal, s, dmin, dmax, N, m, stream, s_dev, cs);
 }
 // The start of a solve inside a captured LM trial: clear the solve's control block (what a fill kernel did) and, in the same
 // launch, fetch the damping factor of the day from `s_src` -- host-pinned memory the host rewrites between replays of the captured
@@ -1012,15 +1054,51 @@ template <class T> __device__ __forceinline__ T* squant2(T* scal, int set, int q
 // captured chunks of iterations per read-back and the solve still ends in the iteration that converged.  it[0] then holds
 // the iteration count.  (it must be 4 ints, zeroed by the caller.)
 // PACK: HB is [nnz, M (M + 1) / 2]: symmetric blocks, upper triangle row by row (pplie_graph_assemble_csr_pack)
-template <class T, int M, bool SYM = false, bool STOP = false, bool PACK = false>
+// per-component sums over a 256-lane workgroup whose lane l holds component (l & 63) % M of node-group (l & 63) / M (the layout of
+// the two kernels below): dst[c] += sum of `v` over the lanes of component c -- lanes 0..M-1 issue ONE atomic instruction on one line
+template <class T, int M> __device__ __forceinline__ void comp_sums_add(T v, T* dst) {
+  __shared__ T pad[256];
+  constexpr int NPW = 64 / M;
+  __syncthreads();                                                  // (pad reuse across calls)
+  pad[threadIdx.x] = v;
+  __syncthreads();
+  if (threadIdx.x < M) {
+    T sum = T(0);
+#pragma unroll
+    for (int w = 0; w < 4; ++w)
+#pragma unroll
+      for (int s2 = 0; s2 < NPW; ++s2) sum += pad[w * 64 + s2 * M + threadIdx.x];
+    atomicAdd(dst + threadIdx.x, sum);
+  }
+}
+// p_0 = z_0 = Binv r_0 + Z (Z^T r_0 / E): the coarse part of the first search direction (after pplie_pcg_prepare_coarse, which left
+// p = Binv r_0 and the totals E, Z^T r_0 in set 0 of cs).  One launch per solve.
+template <class T, int M>
+__global__ void __launch_bounds__(256) pcg2_coarse_init_kernel(T* __restrict__ p, const T* cs, int64_t N) {
+  __shared__ T tot[CS_LINE];
+  cs_totals(cs, 0, tot);
+  __syncthreads();
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < N * M; e += (int64_t)gridDim.x * 256) {
+    const int i = (int)(e % M);
+    const T E = tot[CS_E + i];
+    p[e] += E > T(0) ? tot[CS_SR + i] / E : T(0);
+  }
+}
+// CZ: the two-level preconditioner (cs: the coarse sums, layout above): this kernel also reduces (Z^T q)_i per component
+template <class T, int M, bool SYM = false, bool STOP = false, bool PACK = false, bool CZ = false>
 __global__ void __launch_bounds__(256)
 pcg2_spmv_kernel(const int* __restrict__ ptr, const int* __restrict__ other, const T* __restrict__ HB, const T* __restrict__ D,
                  const T* __restrict__ Binv, const T* __restrict__ p, const T* __restrict__ z, T* __restrict__ q, T* scal,
-                 T* __restrict__ rr_hist, int* it, int cap, int64_t N, const int* __restrict__ blk = nullptr, T tol2 = T(0)) {
+                 T* __restrict__ rr_hist, int* it, int cap, int64_t N, const int* __restrict__ blk = nullptr, T tol2 = T(0),
+                 T* cs = nullptr) {
   constexpr int NPW = 64 / M;
   if (STOP && it[2] != 0) return;
   const int done = it[0];
   const int a = done & 1;
+  if (CZ && blockIdx.x == 0) {             // the idle set's Z^T q / Z^T r: accumulated by the step kernel of this iteration and the next K1
+    for (int e = threadIdx.x; e < kSlots * CS_LINE; e += 256)
+      if ((e & (CS_LINE - 1)) >= CS_SQ) cs[(size_t)(a ^ 1) * kSlots * CS_LINE + e] = T(0);
+  }
   if (blockIdx.x == 0) {
     // bookkeeping by the first workgroup: last iteration's |r|^2 into the history, then clear the idle set
     if (threadIdx.x == 0) {
@@ -1047,7 +1125,7 @@ pcg2_spmv_kernel(const int* __restrict__ ptr, const int* __restrict__ other, con
   const bool active_lane = sub < NPW;
   const int64_t wave = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * 256) >> 6;
-  T a_pq = T(0), a_qz = T(0), a_qmq = T(0);
+  T a_pq = T(0), a_qz = T(0), a_qmq = T(0), a_sq = T(0);
   for (int64_t base = wave * NPW; base < N; base += nwaves * NPW) {
     const int64_t n = base + sub;
     const bool act = active_lane && n < N;
@@ -1158,6 +1236,7 @@ pcg2_spmv_kernel(const int* __restrict__ ptr, const int* __restrict__ other, con
       a_pq += acc * pi;
       a_qz += acc * zi;
       a_qmq += acc * bq;
+      if (CZ) a_sq += acc;                                        // (this lane's component i is the same for all its nodes)
     }
   }
   T s1 = block_sum(a_pq);
@@ -1168,6 +1247,7 @@ pcg2_spmv_kernel(const int* __restrict__ ptr, const int* __restrict__ other, con
     slot_add(squant2(scal, a, Q2_QZ), s2);
     slot_add(squant2(scal, a, Q2_QMQ), s3);
   }
+  if constexpr (CZ) comp_sums_add<T, M>(active_lane ? a_sq : T(0), cs_line(cs, a) + CS_SQ);
 }
 
 // the sum of a quantity's kSlots slots, fetched ONCE per workgroup (wave 0: one slot per lane of each half... lanes 0-31) and
@@ -1193,10 +1273,10 @@ __device__ __forceinline__ void slot_totals_wg(const T* const (&base)[NQ], T (&o
 
 // M lanes per node (the spmv kernel's layout): lane i owns component i, the node's new residual goes round its lanes by
 // shuffles -- 10 loads per component instead of 21
-template <class T, int M, bool STOP = false>
+template <class T, int M, bool STOP = false, bool CZ = false>
 __global__ void __launch_bounds__(256)
 pcg2_step_kernel(T* __restrict__ x, T* r0, T* r1, T* __restrict__ p, const T* __restrict__ q, T* __restrict__ z,
-                 const T* __restrict__ Binv, T* scal, int* it, int64_t N) {
+                 const T* __restrict__ Binv, T* scal, int* it, int64_t N, T* cs = nullptr) {
   constexpr int NPW = 64 / M;
   if (STOP && it[2] != 0) return;
   const int done = it[1];
@@ -1206,14 +1286,33 @@ pcg2_step_kernel(T* __restrict__ x, T* r0, T* r1, T* __restrict__ p, const T* __
   const T* const bases[4] = {squant2(scal, a, Q2_RHO), squant2(scal, a, Q2_PQ), squant2(scal, a, Q2_QZ), squant2(scal, a, Q2_QMQ)};
   T tv[4];
   slot_totals_wg<T, 4>(bases, tv);
-  const T rho = tv[0], pq = tv[1], qz = tv[2], qmq = tv[3];
-  const T alpha = pq != T(0) ? rho / pq : T(0);                 // p.q = 0 only once r = 0: stay put, no NaN
-  T rho_rec = rho - T(2) * alpha * qz + alpha * alpha * qmq;
-  if (rho_rec < T(0)) rho_rec = T(0);
-  const T beta = rho != T(0) ? rho_rec / rho : T(0);
-  T a1 = T(0), a2 = T(0);
   const int lane = threadIdx.x & 63;
   const int sub = lane / M, i = lane % M;
+  T rho = tv[0];                                                // (CZ: the LOCAL part r.Binv r; the coarse part is added below)
+  const T pq = tv[1], qz = tv[2], qmq = tv[3];
+  __shared__ T c_cur[CZ ? CS_LINE : 1], c_e[CZ ? CS_LINE : 1];
+  if constexpr (CZ) {
+    cs_totals(cs, a, c_cur);                                     // Z^T q, Z^T r of this iteration
+    cs_totals(cs, 0, c_e);                                       // E (set 0; its other entries are not looked at)
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < M; ++k) { const T E = c_e[CS_E + k], sr = c_cur[CS_SR + k]; rho += E > T(0) ? sr * sr / E : T(0); }
+  }
+  const T alpha = pq != T(0) ? rho / pq : T(0);                 // p.q = 0 only once r = 0: stay put, no NaN
+  T rho_rec = tv[0] - T(2) * alpha * qz + alpha * alpha * qmq;
+  T cz = T(0);                                                   // this lane's component of Z (Z^T r' / E), Z^T r' = Z^T r - alpha Z^T q
+  if constexpr (CZ) {
+#pragma unroll
+    for (int k = 0; k < M; ++k) {
+      const T E = c_e[CS_E + k], sp = c_cur[CS_SR + k] - alpha * c_cur[CS_SQ + k];
+      rho_rec += E > T(0) ? sp * sp / E : T(0);
+    }
+    const T E = c_e[CS_E + i];
+    cz = E > T(0) ? (c_cur[CS_SR + i] - alpha * c_cur[CS_SQ + i]) / E : T(0);
+  }
+  if (rho_rec < T(0)) rho_rec = T(0);
+  const T beta = rho != T(0) ? rho_rec / rho : T(0);
+  T a1 = T(0), a2 = T(0), a_sr = T(0);
   const bool active_lane = sub < NPW;
   const int64_t wave = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * 256) >> 6;
@@ -1239,10 +1338,11 @@ pcg2_step_kernel(T* __restrict__ x, T* r0, T* r1, T* __restrict__ p, const T* __
     if (act) {
       x[e] = xe + alpha * pe;
       rout[e] = re;
-      z[e] = ze;
-      p[e] = ze + beta * pe;
+      z[e] = ze;                                                 // (the LOCAL part Binv r': what K1's q.z wants)
+      p[e] = (CZ ? ze + cz : ze) + beta * pe;
       a1 += re * ze;
       a2 += re * re;
+      if (CZ) a_sr += re;
     }
   }
   T s1 = block_sum(a1);
@@ -1252,21 +1352,27 @@ pcg2_step_kernel(T* __restrict__ x, T* r0, T* r1, T* __restrict__ p, const T* __
     slot_add(squant2(scal, a, Q2_RR), s2);
     if (blockIdx.x == 0) it[0] = done + 1;
   }
+  if constexpr (CZ) comp_sums_add<T, M>(active_lane ? a_sr : T(0), cs_line(cs, a ^ 1) + CS_SR);
 }
 
 template <class T>
 int pcg2_spmv(const void* ptr, const void* other, const void* HB, const void* D, const void* Binv, const void* p, const void* z,
               void* q, void* scal, void* rr_hist, void* it, int cap, int64_t N, int m, void* stream, const void* blk = nullptr,
-              bool stop = false, double tol2 = 0.0, bool pack = false) {
+              bool stop = false, double tol2 = 0.0, bool pack = false, void* cs = nullptr) {
   if (N <= 0) return N == 0 ? PPLIE_OK : PPLIE_EBADARG;
   if (!ptr || !other || !HB || !D || !Binv || !p || !z || !q || !scal || !rr_hist || !it) return PPLIE_EBADARG;
+  if (cs && !(pack && stop)) return PPLIE_EBADARG;                  // (the two-level variant exists for the packed, device-stopped iteration)
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 #define LAUNCH(MM)                                                                                                    \
   {                                                                                                                   \
     int64_t waves = (N + (64 / MM) - 1) / (64 / MM);                                                                  \
     int64_t blocks = (waves + 3) / 4;                                                                                 \
     int grid = (int)(blocks < 4096 ? blocks : 4096);                                                                  \
-    if (pack && stop)                                                                                                 \
+    if (cs)                                                                                                           \
+      hipLaunchKernelGGL((pcg2_spmv_kernel<T, MM, false, true, true, true>), dim3(grid), dim3(256), 0, st, (const int*)ptr, \
+                         (const int*)other, (const T*)HB, (const T*)D, (const T*)Binv, (const T*)p, (const T*)z, (T*)q, \
+                         (T*)scal, (T*)rr_hist, (int*)it, cap, N, (const int*)nullptr, (T)tol2, (T*)cs);                \
+    else if (pack && stop)                                                                                            \
       hipLaunchKernelGGL((pcg2_spmv_kernel<T, MM, false, true, true>), dim3(grid), dim3(256), 0, st, (const int*)ptr,   \
                          (const int*)other, (const T*)HB, (const T*)D, (const T*)Binv, (const T*)p, (const T*)z, (T*)q, \
                          (T*)scal, (T*)rr_hist, (int*)it, cap, N, (const int*)nullptr, (T)tol2);                        \
@@ -1293,15 +1399,19 @@ int pcg2_spmv(const void* ptr, const void* other, const void* HB, const void* D,
 }
 template <class T>
 int pcg2_step(void* x, void* r, void* r_alt, void* p, const void* q, void* z, const void* Binv, void* scal, void* it, int64_t N,
-              int m, void* stream, bool stop = false) {
+              int m, void* stream, bool stop = false, void* cs = nullptr) {
   if (N <= 0 || m <= 0 || m > 8) return PPLIE_EBADARG;
   if (!x || !r || !r_alt || r == r_alt || !p || !q || !z || !Binv || !scal || !it) return PPLIE_EBADARG;
+  if (cs && !stop) return PPLIE_EBADARG;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 #define LAUNCH(MM)                                                                                                     \
   {                                                                                                                    \
     const int64_t blocks = ((N + (64 / MM) - 1) / (64 / MM) + 3) / 4;                                                  \
     const int grid = (int)(blocks < 1024 ? blocks : 1024);                                                             \
-    if (stop)                                                                                                          \
+    if (cs)                                                                                                            \
+      hipLaunchKernelGGL((pcg2_step_kernel<T, MM, true, true>), dim3(grid), dim3(256), 0, st, (T*)x, (T*)r, (T*)r_alt, (T*)p, \
+                         (const T*)q, (T*)z, (const T*)Binv, (T*)scal, (int*)it, N, (T*)cs);                            \
+    else if (stop)                                                                                                     \
       hipLaunchKernelGGL((pcg2_step_kernel<T, MM, true>), dim3(grid), dim3(256), 0, st, (T*)x, (T*)r, (T*)r_alt, (T*)p, \
                          (const T*)q, (T*)z, (const T*)Binv, (T*)scal, (int*)it, N);                                   \
     else                                                                                                               \
@@ -1347,6 +1457,33 @@ extern "C" int pplie_pcg2_spmv_pack_f64(const void* ptr, const void* other, cons
                                         int64_t N, int m, double tol2, void* stream) {
   return pplie::pcg2_spmv<double>(ptr, other, HB, D, Binv, p, z, q, scal, rr_hist, it, cap, N, m, stream, nullptr, tol2 >= 0.0, tol2, true);
 }
+// ---- the packed, device-stopped iteration with the two-level preconditioner (block-Jacobi + gauge modes); cs: T[PPLIE_PCG2_CS_ELEMS]
+#define PPLIE_PCG2_COARSE(SFX, T)                                                                                                  \
+  extern "C" int pplie_pcg2_spmv_pack_coarse_##SFX(const void* ptr, const void* other, const void* HB, const void* D, const void* Binv, \
+                                                   const void* p, const void* z, void* q, void* scal, void* cs, void* rr_hist, void* it, \
+                                                   int cap, int64_t N, int m, double tol2, void* stream) {                          \
+    if (!cs) return pplie::PPLIE_EBADARG;                                                                                           \
+    return pplie::pcg2_spmv<T>(ptr, other, HB, D, Binv, p, z, q, scal, rr_hist, it, cap, N, m, stream, nullptr, true, tol2, true, cs); \
+  }                                                                                                                                \
+  extern "C" int pplie_pcg2_step_coarse_##SFX(void* x, void* r, void* r_alt, void* p, const void* q, void* z, const void* Binv,    \
+                                              void* scal, void* cs, void* it, int64_t N, int m, void* stream) {                    \
+    if (!cs) return pplie::PPLIE_EBADARG;                                                                                           \
+    return pplie::pcg2_step<T>(x, r, r_alt, p, q, z, Binv, scal, it, N, m, stream, true, cs);                                       \
+  }                                                                                                                                \
+  extern "C" int pplie_pcg2_coarse_init_##SFX(void* p, const void* cs, int64_t N, int m, void* stream) {                           \
+    if (!p || !cs || N <= 0) return pplie::PPLIE_EBADARG;                                                                           \
+    const int64_t nb = (N * m + 255) / 256;                                                                                        \
+    const int grid = (int)(nb < 1024 ? nb : 1024);                                                                                 \
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);                                                                        \
+    if (m == 6) hipLaunchKernelGGL((pplie::pcg2_coarse_init_kernel<T, 6>), dim3(grid), dim3(256), 0, st, (T*)p, (const T*)cs, N);   \
+    else if (m == 7) hipLaunchKernelGGL((pplie::pcg2_coarse_init_kernel<T, 7>), dim3(grid), dim3(256), 0, st, (T*)p, (const T*)cs, N); \
+    else if (m == 3) hipLaunchKernelGGL((pplie::pcg2_coarse_init_kernel<T, 3>), dim3(grid), dim3(256), 0, st, (T*)p, (const T*)cs, N); \
+    else return pplie::PPLIE_EBADARG;                                                                                              \
+    return hipGetLastError() == hipSuccess ? pplie::PPLIE_OK : pplie::PPLIE_ELAUNCH;                                                \
+  }
+PPLIE_PCG2_COARSE(f32, float)
+PPLIE_PCG2_COARSE(f64, double)
+
 extern "C" int pplie_pcg2_step_stop_f32(void* x, void* r, void* r_alt, void* p, const void* q, void* z, const void* Binv, void* scal,
                                         void* it, int64_t N, int m, void* stream) {
   return pplie::pcg2_step<float>(x, r, r_alt, p, q, z, Binv, scal, it, N, m, stream, true);

@@ -117,9 +117,9 @@ struct PersistPeers {
 
 // static LDS of the exchange, double-buffered by the iteration's parity so that one barrier separates "written" from "read"
 // and the next iteration's writes cannot overtake this one's reads
-template <class T> struct PersistShared {
-  T wave_part[2][kPersistQ][kPersistBlock / 64];   // per-wave partial sums
-  T total[2][kPersistQ];                           // the all-gathered sums
+template <class T, int NQMAX = kPersistQ> struct PersistShared {
+  T wave_part[2][NQMAX][kPersistBlock / 64];       // per-wave partial sums
+  T total[2][NQMAX];                               // the all-gathered sums
   int bad[2];                                      // a poll timed out / a lane saw a stale vector element for too long
 };
 
@@ -169,7 +169,7 @@ template <class T, int M> __device__ __forceinline__ T node_binv(const PersistLa
   return s;
 }
 // wave-level sums of NQ quantities into the exchange's LDS (every lane calls; then ONE __syncthreads, then publish_row)
-template <class T, int NQ> __device__ __forceinline__ void post_wave_sums(PersistShared<T>& sh, int par, T* v, bool act, bool stale) {
+template <class T, int NQ, class SH> __device__ __forceinline__ void post_wave_sums(SH& sh, int par, T* v, bool act, bool stale) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   // (DPP adds on the VALU: the 30 ds_bpermute of a shuffle tree queue behind the SpMV's reads on the one LDS pipe the 16 waves share)
 #pragma unroll
@@ -180,8 +180,9 @@ template <class T, int NQ> __device__ __forceinline__ void post_wave_sums(Persis
   }
   if (stale) sh.bad[par] = 1;
 }
-template <class T, int NQ> __device__ __forceinline__ void publish_row(PersistShared<T>& sh, int par, u64* part, unsigned tag) {
-  constexpr int NW = sizeof(T) / 4, RW = kPersistSlots * NW, WV = kPersistBlock / 64;
+template <class T, int NQ, class SH, int SLOTS = kPersistSlots>
+__device__ __forceinline__ void publish_row(SH& sh, int par, u64* part, unsigned tag) {
+  constexpr int NW = sizeof(T) / 4, RW = SLOTS * NW, WV = kPersistBlock / 64;
   if (threadIdx.x < NQ) {
     T sum = T(0);
 #pragma unroll
@@ -191,10 +192,11 @@ template <class T, int NQ> __device__ __forceinline__ void publish_row(PersistSh
 }
 // all-gather: wave q polls quantity q of every workgroup's row (all loads of a round in flight together) and adds them up in
 // row order -- the same order, hence the same bits, in every workgroup.  Then ONE __syncthreads; totals in sh.total[par].
-template <class T, int NQ> __device__ __forceinline__ void gather_rows(PersistShared<T>& sh, int par, const u64* part, unsigned tag) {
-  constexpr int NW = sizeof(T) / 4, RW = kPersistSlots * NW;
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  if (w < NQ) {
+template <class T, int NQ, class SH, int SLOTS = kPersistSlots>
+__device__ __forceinline__ void gather_rows(SH& sh, int par, const u64* part, unsigned tag) {
+  constexpr int NW = sizeof(T) / 4, RW = SLOTS * NW, WVS = kPersistBlock / 64;
+  const int lane = threadIdx.x & 63;
+  for (int w = threadIdx.x >> 6; w < NQ; w += WVS) {       // (more quantities than waves: a wave takes w, w + 16, ...)
     const u64* tab = part + (size_t)par * kPersistGridMax * RW;
     T sum = T(0);
     bool all = true;
@@ -422,14 +424,33 @@ pcg_persist_kernel(const int* __restrict__ ptr, const int* __restrict__ other, c
 //   incidence (optim/posegraph.py FusedPCG._ghost_map).
 constexpr int kGhostLayers = 3;
 
-template <class T, int M>
+// CZ ("coarse"): TWO-LEVEL preconditioner  M^-1 = blockdiag(A)^-1 + Z E^-1 Z^T  with Z = 1_N (x) I_M, the GAUGE modes of a pose
+// graph of relative-pose edges.  With left perturbations a global motion Exp(xi) is the SAME tangent xi at every node, and
+// J[e,0] = -J[e,1] makes J Z = 0 exactly: A Z = shift (.) Z (the damping / clamp part of the diagonal, pplie_pcg_prepare's `shift`)
+// and E = Z^T A Z = diag(sum_n shift[n, :]) is DIAGONAL.  Those M directions carry eigenvalues ~ damping (1e-5 of the rest of the
+// block-Jacobi-preconditioned spectrum, which starts at 0.06): they are what makes block-Jacobi PCG need 35 / 105 iterations in
+// the later LM steps of BASELINE's 10 k-pose graph where the rest of the spectrum needs ~20 (measured on the host in fp64:
+// 18 / 20 / 91 -> 18 / 20 / 26, and the solution's gauge component, 5e-3 of |x| with block-Jacobi at tol 1e-4, is exact).
+// Cost: 2 M more sums per exchange (Z^T q and Z^T r, per component) and one exchange before the first iteration (E and Z^T r_0).
+//   rho = r.Binv r + sum_i (Z^T r)_i^2 / E_i ;   z = Binv r + Z (Z^T r / E) ;  the recurrence value of rho_{k+1} (for beta only,
+//   as before) uses Z^T r' = Z^T r - alpha Z^T q.  Any E > 0 gives an SPD preconditioner: the stop test |r| <= tol |b| is unchanged.
+constexpr int kCoarseSlots = 24;          // row of the partial-sum table with the coarse sums (5 + 2 M <= 19 quantities)
+
+template <class T, int M, bool CZ = false>
 __global__ void __launch_bounds__(kPersistBlock)
 pcg_ghost_kernel(const int* __restrict__ ptr, const int* __restrict__ slot, const T* __restrict__ HB, const T* __restrict__ D,
                  const T* __restrict__ Binv, T* __restrict__ x, const T* __restrict__ r, const T* __restrict__ z,
                  const int* __restrict__ gptr, const int* __restrict__ gids, u64* part, u64* qtag /* [2][N * M tagged values] */,
-                 T* __restrict__ rr_hist, T* info, int* it_out, T tol2, int maxiter, int cap, int64_t N, int lds_bytes) {
+                 T* __restrict__ rr_hist, T* info, int* it_out, T tol2, int maxiter, int cap, int64_t N, int lds_bytes,
+                 const T* __restrict__ shift = nullptr) {
   extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
-  __shared__ PersistShared<T> sh;
+  constexpr int NQ = CZ ? kPersistQ + 2 * M : kPersistQ;
+  constexpr int SLOTS = CZ ? kCoarseSlots : kPersistSlots;
+  typedef PersistShared<T, NQ> SH;
+  __shared__ SH sh;
+  // CZ: per-component sums over a wave's nodes go through a 64-element pad per wave (M lanes add NPW values each: two LDS round
+  // trips) instead of M masked wave reductions per quantity
+  __shared__ T cz_pad[CZ ? kPersistBlock : 1];
   constexpr int NPW = 64 / M, WV = kPersistBlock / 64, NW = sizeof(T) / 4, POS = WV * NPW;      // POS: node positions per layer
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int sub = lane / M, i = lane % M;
@@ -485,11 +506,47 @@ pcg_ghost_kernel(const int* __restrict__ ptr, const int* __restrict__ slot, cons
     for (int e = threadIdx.x; e < c_cnt * M * M; e += kPersistBlock) hb_l[e] = src[e];
     for (int e = threadIdx.x; e < c_cnt; e += kPersistBlock) sl_l[e] = slot[c_lo + e];
   }
+  if (threadIdx.x == 0) { sh.bad[0] = 0; sh.bad[1] = 0; }
+  __shared__ T einv[CZ ? M : 1];                                      // 1 / E_i (LDS: uniform values, not M registers per lane)
+  // sh.wave_part[par][qbase + c][w] = sum over this wave's nodes of `val` at component c (lanes 0..M-1 store)
+  auto wave_comp_sums = [&](T val, int par_, int qbase) {
+    T* pad = cz_pad + (CZ ? w * 64 : 0);
+    pad[lane] = act ? val : T(0);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (lane < M) {
+      T sum = T(0);
+#pragma unroll
+      for (int s2 = 0; s2 < NPW; ++s2) sum += pad[s2 * M + lane];
+      sh.wave_part[par_][qbase + lane][w] = sum;
+    }
+    __builtin_amdgcn_wave_barrier();                                   // (the pad is rewritten by the next call)
+  };
+  if constexpr (CZ) {
+    // one exchange before the first iteration: E_i = sum_n shift[n, i] and (Z^T r_0)_i, per component (table 1, a tag no iteration
+    // uses; nobody reaches iteration 1's row of table 1 before everybody has left this gather: iteration 0's gather waits for all)
+    __syncthreads();
+    wave_comp_sums(act ? shift[n * M + i] : T(0), 1, 0);
+    wave_comp_sums(re, 1, M);
+    __syncthreads();
+    publish_row<T, 2 * M, SH, SLOTS>(sh, 1, part, 0x7fffffffu);
+    gather_rows<T, 2 * M, SH, SLOTS>(sh, 1, part, 0x7fffffffu);
+    __syncthreads();
+    if (threadIdx.x < M) {
+      const T e = sh.total[1][threadIdx.x];
+      einv[threadIdx.x] = e > T(0) ? T(1) / e : T(0);
+    }
+    __syncthreads();
+    const T c0 = sh.total[1][M + i] * einv[i];
+    pe += c0;                                                        // p_0 = z_0 = Binv r_0 + Z (Z^T r_0 / E)
+#pragma unroll
+    for (int l = 0; l < kGhostLayers; ++l) gp[l] += c0;
+  }
   if (act) p_l[pos * M + i] = pe;
 #pragma unroll
   for (int l = 0; l < kGhostLayers; ++l)
     if (gact[l]) p_l[(n_own + l * POS + pos) * M + i] = gp[l];
-  if (threadIdx.x == 0) { sh.bad[0] = 0; sh.bad[1] = 0; }
   __syncthreads();
   const int lbeg = act ? beg - c_lo : 0;
 
@@ -538,11 +595,15 @@ pcg_ghost_kernel(const int* __restrict__ ptr, const int* __restrict__ slot, cons
     T bq = T(0);
 #pragma unroll
     for (int j = 0; j < M; ++j) bq += br[j] * __shfl(acc, sub * M + j, 64);
-    T v[kPersistQ] = {acc * pe, acc * ze, acc * bq, re * ze, re * re};
+    T v[kPersistQ] = {acc * pe, acc * ze, acc * bq, re * ze, re * re};                       // (ze: the LOCAL part Binv r of z)
     post_wave_sums<T, kPersistQ>(sh, par, v, act, false);
+    if constexpr (CZ) {
+      wave_comp_sums(acc, par, kPersistQ);                                                   // Z^T q
+      wave_comp_sums(re, par, kPersistQ + M);                                                // Z^T r
+    }
     __syncthreads();                                                             // barrier 1
     PPLIE_TICK(1)
-    publish_row<T, kPersistQ>(sh, par, part, tag);
+    publish_row<T, NQ, SH, SLOTS>(sh, par, part, tag);
     // ---- the ghosts' q: issued now, needed after the all-gather
     T gq[kGhostLayers];
     bool gok[kGhostLayers];
@@ -551,7 +612,7 @@ pcg_ghost_kernel(const int* __restrict__ ptr, const int* __restrict__ slot, cons
       gok[l] = true;
       gq[l] = gact[l] ? get_value<T>(qtag + (size_t)par * NM + ((size_t)gnode[l] * M + i) * NW, tag, gok[l]) : T(0);
     }
-    gather_rows<T, kPersistQ>(sh, par, part, tag);
+    gather_rows<T, NQ, SH, SLOTS>(sh, par, part, tag);
     PPLIE_TICK(2)
     bool stale = false;
 #pragma unroll
@@ -566,7 +627,7 @@ pcg_ghost_kernel(const int* __restrict__ ptr, const int* __restrict__ slot, cons
     if (stale) sh.bad[par] = 1;
     __syncthreads();                                                             // barrier 2
     PPLIE_TICK(3)
-    const T pq = sh.total[par][0], qz = sh.total[par][1], qmq = sh.total[par][2], rho = sh.total[par][3];
+    const T pq = sh.total[par][0], qz = sh.total[par][1], qmq = sh.total[par][2], rho_loc = sh.total[par][3];
     rr = sh.total[par][4];
     if (sh.bad[par]) { flag = 3; break; }
     if (k == 0) bn2 = rr;
@@ -574,8 +635,22 @@ pcg_ghost_kernel(const int* __restrict__ ptr, const int* __restrict__ slot, cons
     if (!(rr == rr)) { flag = 2; break; }
     if (rr <= tol2 * bn2) { flag = 1; break; }
     if (k >= maxiter) break;
+    T rho = rho_loc;
+    if constexpr (CZ) {
+#pragma unroll
+      for (int q = 0; q < M; ++q) { const T sr = sh.total[par][kPersistQ + M + q]; rho += sr * sr * einv[q]; }
+    }
     const T alpha = pq != T(0) ? rho / pq : T(0);
-    T rho_next = rho - T(2) * alpha * qz + alpha * alpha * qmq;
+    T rho_next = rho_loc - T(2) * alpha * qz + alpha * alpha * qmq;
+    T cz = T(0);                                                       // this component's coarse part of the new z
+    if constexpr (CZ) {
+#pragma unroll
+      for (int q = 0; q < M; ++q) {
+        const T sp = sh.total[par][kPersistQ + M + q] - alpha * sh.total[par][kPersistQ + q];      // Z^T r' = Z^T r - alpha Z^T q
+        rho_next += sp * sp * einv[q];
+      }
+      cz = (sh.total[par][kPersistQ + M + i] - alpha * sh.total[par][kPersistQ + i]) * einv[i];
+    }
     if (rho_next < T(0)) rho_next = T(0);
     const T beta = rho != T(0) ? rho_next / rho : T(0);
     // ---- the same update for the owned element and for the ghosts (identical operands, order and contraction: identical bits)
@@ -586,7 +661,7 @@ pcg_ghost_kernel(const int* __restrict__ ptr, const int* __restrict__ slot, cons
 #pragma unroll
       for (int j = 0; j < M; ++j) zn += br[j] * __shfl(re, sub * M + j, 64);
       ze = zn;
-      pe = ze + beta * pe;
+      pe = (CZ ? ze + cz : ze) + beta * pe;
     }
     if (act) p_l[pos * M + i] = pe;
 #pragma unroll
@@ -595,7 +670,7 @@ pcg_ghost_kernel(const int* __restrict__ ptr, const int* __restrict__ slot, cons
       T zn = T(0);
 #pragma unroll
       for (int j = 0; j < M; ++j) zn += gbr[l][j] * __shfl(gr[l], sub * M + j, 64);
-      gp[l] = zn + beta * gp[l];
+      gp[l] = (CZ ? zn + cz : zn) + beta * gp[l];
       if (gact[l]) p_l[(n_own + l * POS + pos) * M + i] = gp[l];
     }
     __syncthreads();                                                             // barrier 3: every local p is in place
@@ -688,7 +763,7 @@ int pcg_persist_p2p(const void* ptr, const void* other, const void* HB, const vo
 
 // ghost-zone solve: PPLIE_ECAPACITY (nothing launched) when a workgroup's slice or ghost set does not fit -- the caller then uses
 // pplie_pcg_persist.  max_cnt / max_ghost: the largest incidence count and ghost count of any workgroup for THIS grid.
-template <class T, int M> static int ghost_capacity(int& lds_bytes) {
+template <class T, int M, bool CZ> static int ghost_capacity(int& lds_bytes) {
   static int cap[16] = {0}, lds[16] = {0};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 0;
@@ -696,12 +771,12 @@ template <class T, int M> static int ghost_capacity(int& lds_bytes) {
     int cus = 0, per = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
     lds[dev] = kPersistLds;
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&pcg_ghost_kernel<T, M>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&pcg_ghost_kernel<T, M, CZ>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             kPersistLds) != hipSuccess) {
       (void)hipGetLastError();
       lds[dev] = 48 * 1024;
     }
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, pcg_ghost_kernel<T, M>, kPersistBlock, lds[dev]) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, pcg_ghost_kernel<T, M, CZ>, kPersistBlock, lds[dev]) != hipSuccess) return 0;
     cap[dev] = cus * per > 0 ? cus * per : -1;
   }
   lds_bytes = lds[dev];
@@ -711,27 +786,29 @@ template <class T, int M> static int ghost_capacity(int& lds_bytes) {
 template <class T>
 int pcg_ghost(const void* ptr, const void* slot, const void* HB, const void* D, const void* Binv, void* x, const void* r, const void* z,
               const void* gptr, const void* gids, void* part, void* qtag, void* rr_hist, void* info, void* it, double tol, int maxiter,
-              int cap, int grid, int max_cnt, int max_ghost, int64_t N, int m, void* stream) {
+              int cap, int grid, int max_cnt, int max_ghost, int64_t N, int m, void* stream, const void* shift = nullptr) {
   if (N <= 0) return N == 0 ? PPLIE_OK : PPLIE_EBADARG;
   if (!ptr || !slot || !HB || !D || !Binv || !x || !r || !z || !gptr || !gids || !part || !qtag || !rr_hist || !info || !it) return PPLIE_EBADARG;
   if (grid < 1 || grid > kPersistGridMax || maxiter < 0 || max_cnt < 0 || max_ghost < 0) return PPLIE_EBADARG;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-#define LAUNCH(MM)                                                                                                             \
+#define LAUNCH(MM) { if (shift) LAUNCH2(MM, true) else LAUNCH2(MM, false) }
+#define LAUNCH2(MM, CZ)                                                                                                        \
   {                                                                                                                            \
     int lds_bytes = 0;                                                                                                         \
-    const int resident = ghost_capacity<T, MM>(lds_bytes);                                                                     \
+    const int resident = ghost_capacity<T, MM, CZ>(lds_bytes);                                                                 \
     constexpr int POS = (kPersistBlock / 64) * (64 / MM);                                                                      \
     const size_t need = (size_t)(1 + kGhostLayers) * POS * MM * sizeof(T) +                                                    \
                         (size_t)max_cnt * (MM * MM * sizeof(T) + MM * sizeof(T) + 4);                                          \
     if (resident < grid || need > (size_t)lds_bytes || max_ghost > kGhostLayers * POS || (N + grid - 1) / grid > POS)           \
       return PPLIE_ECAPACITY;             /* (the grid is part of the host's ghost map: it cannot be shrunk here) */             \
-    hipLaunchKernelGGL((pcg_ghost_kernel<T, MM>), dim3(grid), dim3(kPersistBlock), lds_bytes, st, (const int*)ptr, (const int*)slot, \
+    hipLaunchKernelGGL((pcg_ghost_kernel<T, MM, CZ>), dim3(grid), dim3(kPersistBlock), lds_bytes, st, (const int*)ptr, (const int*)slot, \
                        (const T*)HB, (const T*)D, (const T*)Binv, (T*)x, (const T*)r, (const T*)z, (const int*)gptr,             \
                        (const int*)gids, (unsigned long long*)part, (unsigned long long*)qtag, (T*)rr_hist, (T*)info, (int*)it,   \
-                       (T)(tol * tol), maxiter, cap, N, lds_bytes);                                                            \
+                       (T)(tol * tol), maxiter, cap, N, lds_bytes, (const T*)shift);                                           \
   }
   if (m == 6) LAUNCH(6) else if (m == 7) LAUNCH(7) else if (m == 3) LAUNCH(3) else return PPLIE_EBADARG;
 #undef LAUNCH
+#undef LAUNCH2
   return hipGetLastError() == hipSuccess ? PPLIE_OK : PPLIE_ELAUNCH;
 }
 }  // namespace pplie
@@ -769,6 +846,20 @@ PPLIE_P2P(f64, double)
   }
 PPLIE_GHOST(f32, float)
 PPLIE_GHOST(f64, double)
+// the same solve with the two-level (block-Jacobi + gauge modes) preconditioner: `shift` = pplie_pcg_prepare's output [N, m];
+// `part` must hold 2 x PPLIE_PCG_PERSIST_GRID x PPLIE_PCG_COARSE_SLOTS tagged values (zeroed by the caller like the narrow table)
+#define PPLIE_GHOST_CZ(SFX, T)                                                                                                    \
+  extern "C" int pplie_pcg_ghost_coarse_##SFX(const void* ptr, const void* slot, const void* HB, const void* D, const void* Binv,  \
+                                              const void* shift, void* x, const void* r, const void* z, const void* gptr,        \
+                                              const void* gids, void* part, void* qtag, void* rr_hist, void* info, void* it,      \
+                                              double tol, int maxiter, int cap, int grid, int max_cnt, int max_ghost, int64_t N,  \
+                                              int m, void* stream) {                                                             \
+    if (!shift) return pplie::PPLIE_EBADARG;                                                                                      \
+    return pplie::pcg_ghost<T>(ptr, slot, HB, D, Binv, x, r, z, gptr, gids, part, qtag, rr_hist, info, it, tol, maxiter, cap, grid,    \
+                               max_cnt, max_ghost, N, m, stream, shift);                                                            \
+  }
+PPLIE_GHOST_CZ(f32, float)
+PPLIE_GHOST_CZ(f64, double)
 
 // Peer access for the hand-off tables of the multi-GPU solve: the kernel of GPU `device` stores into (and polls) tables that
 // live in the memory of GPU `peer` (hipIpc-mapped by the caller).  Returns 0 when `device` can reach `peer`'s memory after the

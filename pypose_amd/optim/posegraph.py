@@ -53,6 +53,14 @@ _PERSIST_SIG = [ctypes.c_void_p] * 15 + [ctypes.c_double, ctypes.c_int, ctypes.c
 _GHOST_SIG = [ctypes.c_void_p] * 15 + [ctypes.c_double] + [ctypes.c_int] * 5 + [ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]
 _PERSIST_GRID_MAX = 256     # PPLIE_PCG_PERSIST_GRID
 _PERSIST_SLOTS = 8          # PPLIE_PCG_PERSIST_SLOTS
+_COARSE_SLOTS = 24          # PPLIE_PCG_COARSE_SLOTS: row of the partial-sum table of the two-level (gauge) variant
+_PCG2_CS_ELEMS = 2 * 32 * 32  # PPLIE_PCG2_CS_ELEMS: coarse sums of the two-launch iteration
+_GHOST_CZ_SIG = [ctypes.c_void_p] * 16 + [ctypes.c_double] + [ctypes.c_int] * 5 + [ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]
+_PREP_CZ_SIG = [ctypes.c_void_p] * 11 + [ctypes.c_double, ctypes.c_void_p, ctypes.c_double, ctypes.c_double, ctypes.c_int64, ctypes.c_int,
+                                         ctypes.c_void_p]
+_PCG2_SPMV_CZ_SIG = [ctypes.c_void_p] * 12 + [ctypes.c_int, ctypes.c_int64, ctypes.c_int, ctypes.c_double, ctypes.c_void_p]
+_PCG2_STEP_CZ_SIG = [ctypes.c_void_p] * 10 + [ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]
+_CZ_INIT_SIG = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]
 import os as _os
 # graphs up to this many nodes run the whole PCG solve in ONE persistent launch (csrc/pcg_persist.hip); larger ones need
 # the whole chip's bandwidth per iteration and keep the two-launch hipGraph iteration
@@ -194,9 +202,14 @@ class PCG(nn.Module):
     pose-graph normal equations (the name the reference exposes for its plugin solver,
     pypose/optim/solver.py:343-364).  Stops when ||r|| <= tol * ||b|| or after ``maxiter``."""
 
-    def __init__(self, maxiter=None, tol=1e-5, check_every=8):
+    def __init__(self, maxiter=None, tol=1e-5, check_every=8, gauge=True):
         super().__init__()
         self.maxiter, self.tol, self.check_every = maxiter, tol, check_every
+        # gauge: on relative-pose graphs (J[e, 0] = -J[e, 1]: a global motion is in J's null space) the block-Jacobi preconditioner
+        # is completed by the exact coarse correction over the m gauge directions, M^-1 = blockdiag(A)^-1 + Z E^-1 Z^T
+        # (csrc/pcg_persist.hip "CZ"): same stop test, same system, 17 / 35 / 105 -> ~18 / 20 / 26 iterations on the LM steps of a
+        # 10 k-pose graph.  gauge=False: the plain block-Jacobi iteration of the reference's plugin solver.
+        self.gauge = gauge
 
     def solve(self, matvec, b, precond, stall=None):
         """``stall`` (singular systems): keep the iterate of smallest residual and stop once the residual has
@@ -306,6 +319,7 @@ class FusedPCG:
     persist = True           # one persistent launch per solve on small graphs (csrc/pcg_persist.hip)
     ghost = True             # the ghost-zone form of the persistent solve (one grid-wide dependency per iteration)
     profile = False          # tools/time_pcg_iter.py: the persistent kernel leaves per-phase clock ticks in rr_hist[cap - 8:]
+    coarse = True            # two-level preconditioner (block-Jacobi + gauge modes) where the linearisation allows it (PCG(gauge=))
 
     def __init__(self, E, K, dr, m, N, dtype, device, has_w, check_every):
         z = lambda *s: torch.zeros(s, dtype=dtype, device=device)
@@ -321,13 +335,16 @@ class FusedPCG:
         # scal | part | it share ONE allocation: a solve clears them with a single fill instead of three
         esz = 4 if dtype == torch.float32 else 8
         nw = esz // 4
-        nb_scal, nb_part, nb_it = _PCG_SCAL_ELEMS * esz, 2 * _PERSIST_GRID_MAX * _PERSIST_SLOTS * nw * 8, 16
+        # (part is sized for the wider rows of the two-level variant; cs, its coarse sums of the two-launch iteration, rides behind scal)
+        nb_scal, nb_part, nb_it = (_PCG_SCAL_ELEMS + _PCG2_CS_ELEMS) * esz, 2 * _PERSIST_GRID_MAX * _COARSE_SLOTS * nw * 8, 16
         # the persistent solve's hand-off table of p (tagged 64-bit words, double-buffered) sits in the same allocation
         nb_ptag = 2 * N * m * nw * 8 if (N <= PERSIST_NODES and m in (3, 6, 7)) else 0
         self._ctl = torch.zeros(nb_scal + nb_part + nb_it + nb_ptag, dtype=torch.uint8, device=device)
         self.ptag = self._ctl[nb_scal + nb_part + nb_it:].view(torch.int64) if nb_ptag else None
         self.no_persist = nb_ptag == 0                              # (also set when the device cannot hold the solve resident)
-        self.scal = self._ctl[:nb_scal].view(dtype)
+        self.scal = self._ctl[:_PCG_SCAL_ELEMS * esz].view(dtype)
+        self.cs = self._ctl[_PCG_SCAL_ELEMS * esz:nb_scal].view(dtype)
+        self.cz = False                                            # this solve runs the two-level variant
         self.cap = 1 << 16
         self.rr_hist = z(self.cap)
         self.part = self._ctl[nb_scal:nb_scal + nb_part].view(torch.int64)   # persistent solve: tagged partial sums
@@ -391,6 +408,17 @@ class FusedPCG:
             # q = A p with p.q, q.z, q.Binv q ; then every vector update in one launch (csrc/graph.hip, pcg2)
             # (stop: convergence test on the device -- a launch after the converging iteration returns at once)
             stop = self.stop_tol2 is not None and self.sym in (False, 'pack')
+            if self.cz and stop and self.sym == 'pack':
+                code = lib.symbol("pplie_pcg2_spmv_pack_coarse" + self.sfx, _PCG2_SPMV_CZ_SIG)(
+                    self.ptr.data_ptr(), self.other.data_ptr(), self.HB.data_ptr(), self.D.data_ptr(), self.Binv.data_ptr(),
+                    self.p.data_ptr(), self.z.data_ptr(), self.q.data_ptr(), self.scal.data_ptr(), self.cs.data_ptr(),
+                    self.rr_hist.data_ptr(), self.it.data_ptr(), self.cap, self.N, self.m, self.stop_tol2, st)
+                _C.check(code, "pplie_pcg2_spmv_pack_coarse")
+                code = lib.symbol("pplie_pcg2_step_coarse" + self.sfx, _PCG2_STEP_CZ_SIG)(
+                    self.x.data_ptr(), self.r.data_ptr(), self.r2.data_ptr(), self.p.data_ptr(), self.q.data_ptr(),
+                    self.z.data_ptr(), self.Binv.data_ptr(), self.scal.data_ptr(), self.cs.data_ptr(), self.it.data_ptr(), self.N, self.m, st)
+                _C.check(code, "pplie_pcg2_step_coarse")
+                return
             if self.sym == 'pack':
                 code = lib.symbol("pplie_pcg2_spmv_pack" + self.sfx, _PCG2_SPMV_STOP_SIG)(
                     self.ptr.data_ptr(), self.other.data_ptr(), self.HB.data_ptr(), self.D.data_ptr(), self.Binv.data_ptr(),
@@ -470,7 +498,15 @@ class FusedPCG:
                 self.W.copy_(lin.W)
         s_dev = getattr(lin, 's_dev', None)
         if s_dev is None:
-            self._ctl.zero_()                                       # scal, part (sequence tags restart at 1), it
+            self._ctl.zero_()                                       # scal, cs, part (sequence tags restart at 1), it
+        # the two-level preconditioner: relative-pose linearisations (J[e,0] = -J[e,1]) on the single-GPU block paths that have it
+        # -- the ghost-zone persistent solve and the packed two-launch iteration with the device-side stop test
+        persistent = bsr and self._persistent(plain) and not self.sym
+        two = bsr and self.two_launch and not plain and group is None and self.sym == 'pack' and self.device_stop and not persistent
+        cz = bool(FusedPCG.coarse and getattr(self, 'want_gauge', True) and getattr(lin, 'antisym', False) and not plain and group is None
+                  and ((persistent and FusedPCG.ghost and not self.__dict__.get('_no_ghost')) or two))
+        if cz != self.cz:
+            self.cz, self.graph = cz, None                          # (the captured iterations differ)
         with _C._on_device(self.device):
             # one launch: D = clamped + damped block diagonal, Binv = D^-1, shift, x = 0, r = -g, z = Binv r, p = z, r.z, |g|^2
             if s_dev is not None:
@@ -483,6 +519,15 @@ class FusedPCG:
                     lin.B.data_ptr(), lin.g.data_ptr(), self.D.data_ptr(), self.Binv.data_ptr(), self.shift.data_ptr(),
                     self.x.data_ptr(), self.r.data_ptr(), self.z.data_ptr(), self.p.data_ptr(), self.scal.data_ptr(),
                     self.s_device.data_ptr(), float(dmin), float(dmax), self.N, self.m, _C.stream_ptr(self.device))
+            elif self.cz and two:
+                # (the persistent solve sums E and Z^T r_0 itself, in its first exchange; the two-launch iteration gets them here)
+                code = _C.library().symbol("pplie_pcg_prepare_coarse" + self.sfx, _PREP_CZ_SIG)(
+                    lin.B.data_ptr(), lin.g.data_ptr(), self.D.data_ptr(), self.Binv.data_ptr(), self.shift.data_ptr(),
+                    self.x.data_ptr(), self.r.data_ptr(), self.z.data_ptr(), self.p.data_ptr(), self.scal.data_ptr(), self.cs.data_ptr(),
+                    float(s), None, float(dmin), float(dmax), self.N, self.m, _C.stream_ptr(self.device))
+                _C.check(code, "pplie_pcg_prepare_coarse")
+                code = _C.library().symbol("pplie_pcg2_coarse_init" + self.sfx, _CZ_INIT_SIG)(
+                    self.p.data_ptr(), self.cs.data_ptr(), self.N, self.m, _C.stream_ptr(self.device))
             else:
                 code = _C.library().symbol("pplie_pcg_prepare" + self.sfx, _PREP_SIG)(
                     lin.B.data_ptr(), lin.g.data_ptr(), self.D.data_ptr(), self.Binv.data_ptr(), self.shift.data_ptr(),
@@ -510,11 +555,19 @@ class FusedPCG:
                     while hit[1]:
                         grid = hit[1][0]
                         slot, gptr, gids, max_cnt, max_ghost = self._ghost_map(lin, grid)
-                        code = _C.library().symbol("pplie_pcg_ghost" + self.sfx, _GHOST_SIG)(
-                            self.ptr.data_ptr(), slot.data_ptr(), self.HB.data_ptr(), self.D.data_ptr(), self.Binv.data_ptr(),
-                            self.x.data_ptr(), self.r.data_ptr(), self.z.data_ptr(), gptr.data_ptr(), gids.data_ptr(), self.part.data_ptr(),
-                            self.ptag.data_ptr(), self.rr_hist.data_ptr(), self.info.data_ptr(), self.it.data_ptr(), float(tol), int(maxit),
-                            -self.cap if FusedPCG.profile else self.cap, grid, max_cnt, max_ghost, self.N, self.m, _C.stream_ptr(self.device))
+                        if self.cz:
+                            code = _C.library().symbol("pplie_pcg_ghost_coarse" + self.sfx, _GHOST_CZ_SIG)(
+                                self.ptr.data_ptr(), slot.data_ptr(), self.HB.data_ptr(), self.D.data_ptr(), self.Binv.data_ptr(),
+                                self.shift.data_ptr(), self.x.data_ptr(), self.r.data_ptr(), self.z.data_ptr(), gptr.data_ptr(),
+                                gids.data_ptr(), self.part.data_ptr(), self.ptag.data_ptr(), self.rr_hist.data_ptr(), self.info.data_ptr(),
+                                self.it.data_ptr(), float(tol), int(maxit), -self.cap if FusedPCG.profile else self.cap, grid, max_cnt,
+                                max_ghost, self.N, self.m, _C.stream_ptr(self.device))
+                        else:
+                            code = _C.library().symbol("pplie_pcg_ghost" + self.sfx, _GHOST_SIG)(
+                                self.ptr.data_ptr(), slot.data_ptr(), self.HB.data_ptr(), self.D.data_ptr(), self.Binv.data_ptr(),
+                                self.x.data_ptr(), self.r.data_ptr(), self.z.data_ptr(), gptr.data_ptr(), gids.data_ptr(), self.part.data_ptr(),
+                                self.ptag.data_ptr(), self.rr_hist.data_ptr(), self.info.data_ptr(), self.it.data_ptr(), float(tol), int(maxit),
+                                -self.cap if FusedPCG.profile else self.cap, grid, max_cnt, max_ghost, self.N, self.m, _C.stream_ptr(self.device))
                         if code != _C.ECAPACITY:
                             break
                         hit[1].pop(0)
@@ -887,6 +940,7 @@ class GraphLinearization:
                 wsp = cache[key] = FusedPCG(*key)
             defer = getattr(self.opt, '_defer_solver_info', False)
             defer = False if plain else (defer if defer == 'inplace' else bool(defer))
+            wsp.want_gauge = bool(getattr(solver, 'gauge', True))
             Dn, its = wsp.solve(self, s, dmin, dmax, solver.tol, maxiter, self.group, plain=plain, defer=defer)
             if isinstance(its, _PendingInfo):
                 self.pending_info, self._pending_solver = its, solver
