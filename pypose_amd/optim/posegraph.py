@@ -319,7 +319,8 @@ class FusedPCG:
     persist = True           # one persistent launch per solve on small graphs (csrc/pcg_persist.hip)
     ghost = True             # the ghost-zone form of the persistent solve (one grid-wide dependency per iteration)
     profile = False          # tools/time_pcg_iter.py: the persistent kernel leaves per-phase clock ticks in rr_hist[cap - 8:]
-    coarse = True            # two-level preconditioner (block-Jacobi + gauge modes) where the linearisation allows it (PCG(gauge=))
+    # two-level preconditioner (block-Jacobi + gauge modes) where the linearisation allows it (PCG(gauge=)); PPLIE_PCG_GAUGE=0: off
+    coarse = _os.environ.get("PPLIE_PCG_GAUGE", "1") != "0"
 
     def __init__(self, E, K, dr, m, N, dtype, device, has_w, check_every):
         z = lambda *s: torch.zeros(s, dtype=dtype, device=device)
