@@ -1298,7 +1298,8 @@ pcg2_step_kernel(T* __restrict__ x, T* r0, T* r1, T* __restrict__ p, const T* __
 #pragma unroll
     for (int k = 0; k < M; ++k) { const T E = c_e[CS_E + k], sr = c_cur[CS_SR + k]; rho += E > T(0) ? sr * sr / E : T(0); }
   }
-  const T alpha = pq != T(0) ? rho / pq : T(0);                 // p.q = 0 only once r = 0: stay put, no NaN
+  constexpr T tiny = sizeof(T) == 4 ? T(1e-30) : T(1e-290);     // (denormal denominators: see pcg_tiny in csrc/pcg_persist.hip)
+  const T alpha = pq > tiny ? rho / pq : T(0);                  // p.q = 0 only once r = 0: stay put, no NaN
   T rho_rec = tv[0] - T(2) * alpha * qz + alpha * alpha * qmq;
   T cz = T(0);                                                   // this lane's component of Z (Z^T r' / E), Z^T r' = Z^T r - alpha Z^T q
   if constexpr (CZ) {
@@ -1311,7 +1312,7 @@ pcg2_step_kernel(T* __restrict__ x, T* r0, T* r1, T* __restrict__ p, const T* __
     cz = E > T(0) ? (c_cur[CS_SR + i] - alpha * c_cur[CS_SQ + i]) / E : T(0);
   }
   if (rho_rec < T(0)) rho_rec = T(0);
-  const T beta = rho != T(0) ? rho_rec / rho : T(0);
+  const T beta = rho > tiny ? rho_rec / rho : T(0);
   T a1 = T(0), a2 = T(0), a_sr = T(0);
   const bool active_lane = sub < NPW;
   const int64_t wave = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;

@@ -5,5 +5,8 @@ PPLIE_DEFINE_GROUP_OPS(sim3, 7, 8)
 namespace pplie {
 PPLIE_TILE_EX(Op_sim3_exp_bwd, 4, 128, false)
 PPLIE_TILE_EX(Op_sim3_log_bwd, 4, 128, false)
+// (round 5, fp64: profiles/r05/tune_general_f64.json)
+PPLIE_TILE64(Op_sim3_exp_fwd, 2, 128, false)       // 0.2977 -> 0.2198 ms
+PPLIE_TILE64(Op_sim3_log_fwd, 2, 256, false)       // 0.3114 -> 0.2606
 }
 PPLIE_EXPORT_GROUP(sim3)

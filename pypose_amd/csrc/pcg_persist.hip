@@ -36,6 +36,11 @@
 
 namespace pplie {
 
+// Denominators of alpha = rho / p.q and beta = rho' / rho below this are treated as zero (the step stays put): an iteration driven
+// far past convergence reaches the denormal range (fp32: ~130 iterations at the two-level preconditioner's rate of 0.5 per
+// iteration), where the fast reciprocal of a flushed denormal is inf and 0 * inf a NaN in every vector
+template <class T> __device__ __forceinline__ constexpr T pcg_tiny() { return sizeof(T) == 4 ? T(1e-30) : T(1e-290); }
+
 constexpr int kPersistGridMax = 256;      // = PPLIE_PCG_PERSIST_GRID: rows of the partial-sum tables
 constexpr int kPersistBlock = 1024;       // 16 waves per workgroup
 constexpr int kPersistQ = 5;              // quantities per exchange: p.q, q.z, q.Binv q, r.z, r.r
@@ -382,10 +387,10 @@ pcg_persist_kernel(const int* __restrict__ ptr, const int* __restrict__ other, c
       if (!(rr == rr)) { flag = 2; break; }
       if (rr <= tol2 * bn2) { flag = 1; break; }                     // (also |b| = 0: x = 0 is the answer)
       if (k >= maxiter) break;
-      const T alpha = pq != T(0) ? rho / pq : T(0);                 // p.q = 0 only once r = 0: stay put, no NaN
+      const T alpha = pq > pcg_tiny<T>() ? rho / pq : T(0);                 // p.q = 0 only once r = 0: stay put, no NaN
       T rho_next = rho - T(2) * alpha * qz + alpha * alpha * qmq;
       if (rho_next < T(0)) rho_next = T(0);
-      const T beta = rho != T(0) ? rho_next / rho : T(0);
+      const T beta = rho > pcg_tiny<T>() ? rho_next / rho : T(0);
       xe += alpha * pe;
       re -= alpha * acc;
       ze = node_binv<T, M>(L, re);
@@ -640,7 +645,7 @@ pcg_ghost_kernel(const int* __restrict__ ptr, const int* __restrict__ slot, cons
 #pragma unroll
       for (int q = 0; q < M; ++q) { const T sr = sh.total[par][kPersistQ + M + q]; rho += sr * sr * einv[q]; }
     }
-    const T alpha = pq != T(0) ? rho / pq : T(0);
+    const T alpha = pq > pcg_tiny<T>() ? rho / pq : T(0);
     T rho_next = rho_loc - T(2) * alpha * qz + alpha * alpha * qmq;
     T cz = T(0);                                                       // this component's coarse part of the new z
     if constexpr (CZ) {
@@ -652,7 +657,7 @@ pcg_ghost_kernel(const int* __restrict__ ptr, const int* __restrict__ slot, cons
       cz = (sh.total[par][kPersistQ + M + i] - alpha * sh.total[par][kPersistQ + i]) * einv[i];
     }
     if (rho_next < T(0)) rho_next = T(0);
-    const T beta = rho != T(0) ? rho_next / rho : T(0);
+    const T beta = rho > pcg_tiny<T>() ? rho_next / rho : T(0);
     // ---- the same update for the owned element and for the ghosts (identical operands, order and contraction: identical bits)
     xe += alpha * pe;
     re -= alpha * acc;
@@ -770,9 +775,10 @@ template <class T, int M, bool CZ> static int ghost_capacity(int& lds_bytes) {
   if (cap[dev] == 0) {
     int cus = 0, per = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-    lds[dev] = kPersistLds;
+    // (the two-level variant's static LDS -- wider exchange rows, the component-sum pads -- is 6.5 KB in fp32, 13 KB in fp64)
+    lds[dev] = (CZ && sizeof(T) == 8) ? kPersistLds - 8 * 1024 : kPersistLds;
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&pcg_ghost_kernel<T, M, CZ>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            kPersistLds) != hipSuccess) {
+                            lds[dev]) != hipSuccess) {
       (void)hipGetLastError();
       lds[dev] = 48 * 1024;
     }

@@ -641,7 +641,7 @@ def test_ghost_zone_solve_equals_the_two_dependency_kernel(dtype, tol, atol, mon
     # (fp64 blocks are twice the size: fewer nodes per workgroup so that the slice + ghost state still fit in LDS)
     edges, rel, init = _synthetic_graph(*((9000, 36000) if dtype == torch.float32 else (5000, 20000)), dtype)
     graph = PoseGraph(init.clone())
-    solver = pp.optim.solver.PCG(tol=1e-4, maxiter=250)
+    solver = pp.optim.solver.PCG(tol=1e-4, maxiter=250, gauge=False)      # (the two-dependency kernel has block-Jacobi only)
     opt = pp.optim.LM(graph, solver=solver, strategy=pp.optim.strategy.TrustRegion(radius=1e4))
     opt.step((edges, rel))
     prog = opt._structure_cache["program"][3]
@@ -650,6 +650,7 @@ def test_ghost_zone_solve_equals_the_two_dependency_kernel(dtype, tol, atol, mon
         lin.build_normal_equations(1e-6, 1e32)
         lin.damp(1e-4)
         wsp = next(iter(opt._pcg_workspaces.values()))
+        assert wsp.want_gauge is False
         res = {}
         for ghost in (True, False):
             monkeypatch.setattr(posegraph.FusedPCG, "ghost", ghost, raising=False)

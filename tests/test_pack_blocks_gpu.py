@@ -35,7 +35,9 @@ def _run(edges, rel, init, W, pack, monkeypatch, steps=2, tol=1e-8):      # (two
     monkeypatch.setattr(posegraph, "PERSIST_NODES", 64, raising=False)          # the two-launch iteration, as beyond 32 k nodes
     monkeypatch.setattr(posegraph.FusedPCG, "pack_blocks", pack, raising=False)
     graph = PoseGraph(pp.SE3(init.clone()))
-    opt = pp.optim.LM(graph, solver=pp.optim.solver.PCG(tol=tol, maxiter=2000), strategy=pp.optim.strategy.TrustRegion(radius=1e4))
+    # (gauge=False: the full-block iteration this is compared with has the block-Jacobi preconditioner only; the two-level one is
+    #  tests/test_pcg_gauge_gpu.py's subject)
+    opt = pp.optim.LM(graph, solver=pp.optim.solver.PCG(tol=tol, maxiter=2000, gauge=False), strategy=pp.optim.strategy.TrustRegion(radius=1e4))
     rec = run_steps(opt, ((edges, pp.SE3(rel)),), {"weight": W}, steps)
     modes = {w.sym for w in opt._pcg_workspaces.values()}
     return rec, graph.nodes.detach().tensor().clone(), modes, opt

@@ -19,7 +19,7 @@ DEV = "cuda:0"
 def _system(N, E, dtype):
     edges, rel, init = _synthetic_graph(N, E, dtype)
     graph = PoseGraph(init.clone())
-    solver = pp.optim.solver.PCG(tol=1e-4, maxiter=250)
+    solver = pp.optim.solver.PCG(tol=1e-4, maxiter=250, gauge=False)      # (the P2P kernel is the block-Jacobi iteration)
     opt = pp.optim.LM(graph, solver=solver, strategy=pp.optim.strategy.TrustRegion(radius=1e4))
     opt.step((edges, rel))
     prog = opt._structure_cache["program"][3]
