@@ -200,35 +200,48 @@ __device__ __forceinline__ void publish_row(SH& sh, int par, u64* part, unsigned
 template <class T, int NQ, class SH, int SLOTS = kPersistSlots>
 __device__ __forceinline__ void gather_rows(SH& sh, int par, const u64* part, unsigned tag) {
   constexpr int NW = sizeof(T) / 4, RW = SLOTS * NW, WVS = kPersistBlock / 64;
-  const int lane = threadIdx.x & 63;
-  for (int w = threadIdx.x >> 6; w < NQ; w += WVS) {       // (more quantities than waves: a wave takes w, w + 16, ...)
+  constexpr int PER = (NQ + WVS - 1) / WVS;                  // quantities per wave: w, w + 16, ... polled TOGETHER (one spin loop:
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;   //  a second quantity costs no second round of L2 latencies)
+  if (w < NQ) {
     const u64* tab = part + (size_t)par * kPersistGridMax * RW;
-    T sum = T(0);
+    T sum[PER];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) sum[u] = T(0);
     bool all = true;
     for (int base = 0; base < (int)gridDim.x; base += 256) {
-      T val[4];
-      bool done[4];
+      T val[PER][4];
+      bool done[PER][4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) { done[q] = base + lane + 64 * q >= (int)gridDim.x; val[q] = T(0); }
+      for (int u = 0; u < PER; ++u)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { done[u][q] = base + lane + 64 * q >= (int)gridDim.x || w + u * WVS >= NQ; val[u][q] = T(0); }
       for (long spin = 0; spin < (1L << 20); ++spin) {
         bool pending = false;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          if (!done[q]) {
-            bool ok = true;
-            const T t = get_value<T>(tab + (size_t)(base + lane + 64 * q) * RW + w * NW, tag, ok);
-            if (ok) { val[q] = t; done[q] = true; } else pending = true;
+        for (int u = 0; u < PER; ++u)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            if (!done[u][q]) {
+              bool ok = true;
+              const T t = get_value<T>(tab + (size_t)(base + lane + 64 * q) * RW + (w + u * WVS) * NW, tag, ok);
+              if (ok) { val[u][q] = t; done[u][q] = true; } else pending = true;
+            }
           }
-        }
         if (!pending) break;
         __builtin_amdgcn_s_sleep(1);
       }
 #pragma unroll
-      for (int q = 0; q < 4; ++q) { all = all && done[q]; sum += val[q]; }
+      for (int u = 0; u < PER; ++u)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { all = all && done[u][q]; sum[u] += val[u][q]; }
     }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
-    if (lane == 0) sh.total[par][w] = sum;
+    for (int u = 0; u < PER; ++u) {
+      T t = sum[u];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off, 64);
+      if (lane == 0 && w + u * WVS < NQ) sh.total[par][w + u * WVS] = t;
+    }
     if (!__all(all) && lane == 0) sh.bad[par] = 1;
   }
 }

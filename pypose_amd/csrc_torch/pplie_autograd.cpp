@@ -161,6 +161,45 @@ at::Tensor row_op(const at::Tensor& a, const c10::optional<at::Tensor>& b, int64
 
 void set_rule(int64_t key, py::object fn) { py_rules()[key] = std::move(fn); }
 
+// ---- prepared handles: everything one (operator, dtype) needs to be called, resolved ONCE -------------------------------------
+// BASELINE configs[0] (1024 rows) is four launches of a few microseconds each; what it costs is the host path to them.  Through
+// `row_op` above Python checked the operands (type, device, dtype, contiguity, widths: ~2 us), looked three kernel addresses up,
+// and marshalled nine arguments, two of them Python lists, per call.  A handle holds all of that; its call checks the operands in
+// C++ and either launches (no gradient wanted: the bare kernel; else the native autograd node) or returns None -- "not the plain
+// eager case" (host tensors, broadcasting, another dtype ...) -- and the caller takes the general Python path.
+struct RowHandle {
+  int64_t fwd_fn = 0, bwd_fn = 0, bwd_gb_fn = 0, out_w = 0, rule = 0;
+  int64_t in_w0 = 0, in_w1 = 0;                       // widths of the one or two operands (in_w1 = 0: unary)
+  std::vector<int64_t> saved, bwd_out_w;
+  at::ScalarType dtype = at::kFloat;
+
+  py::object call(const at::Tensor& a, const c10::optional<at::Tensor>& b) const {
+    const bool binary = in_w1 > 0;
+    if (binary != b.has_value()) return py::none();
+    // (a tensor without storage is a batched tensor of the legacy vmap -- torch.autograd.grad(is_grads_batched=True): Python peels it)
+    if (!a.defined() || !a.has_storage() || !a.is_cuda() || a.scalar_type() != dtype || a.dim() < 1 || a.size(-1) != in_w0 || !a.is_contiguous())
+      return py::none();
+    if (binary) {
+      const at::Tensor& bb = *b;
+      if (!bb.defined() || !bb.has_storage() || !bb.is_cuda() || bb.scalar_type() != dtype || bb.device() != a.device() || bb.dim() != a.dim() ||
+          bb.size(-1) != in_w1 || !bb.is_contiguous() || bb.sizes().slice(0, bb.dim() - 1) != a.sizes().slice(0, a.dim() - 1))
+        return py::none();
+    }
+    const bool record = at::GradMode::is_enabled() && (a.requires_grad() || (binary && b->requires_grad()));
+    if (!record) {
+      std::vector<at::Tensor> ins{a};
+      if (binary) ins.push_back(*b);
+      at::Tensor out;
+      {
+        py::gil_scoped_release nogil;
+        out = launch(fwd_fn, ins, {out_w})[0];
+      }
+      return py::cast(out);
+    }
+    return py::cast(RowOp::apply(a, b, fwd_fn, bwd_fn, out_w, saved, bwd_out_w, rule, bwd_gb_fn));
+  }
+};
+
 // ---- IMU pre-integration (module/imu_preintegrator.py): pplie_imu_integrate / pplie_imu_integrate_bwd as ONE native node ----------
 // Training through the pre-integrator is two kernels (64 + 108 us at 4096 x 1024); as a Python Function the pair cost ~190 us of
 // host time per step (the backward runs on the engine's device thread behind the GIL) -- more than the kernels.  Same contract as
@@ -286,6 +325,16 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.doc() = "native autograd nodes for the row operators of libpplie (pypose_amd/csrc_torch/pplie_autograd.cpp)";
   m.def("row_op", &row_op, "forward of one row operator recorded as a native autograd node", py::arg("a"), py::arg("b"), py::arg("fwd_fn"),
         py::arg("bwd_fn"), py::arg("out_w"), py::arg("saved"), py::arg("bwd_out_w"), py::arg("rule"), py::arg("bwd_gb_fn") = 0);
+  py::class_<RowHandle>(m, "RowHandle")
+      .def(py::init([](int64_t fwd_fn, int64_t bwd_fn, int64_t bwd_gb_fn, int64_t in_w0, int64_t in_w1, int64_t out_w,
+                       std::vector<int64_t> saved, std::vector<int64_t> bwd_out_w, int64_t rule, bool f64) {
+             RowHandle h;
+             h.fwd_fn = fwd_fn; h.bwd_fn = bwd_fn; h.bwd_gb_fn = bwd_gb_fn; h.in_w0 = in_w0; h.in_w1 = in_w1; h.out_w = out_w;
+             h.saved = std::move(saved); h.bwd_out_w = std::move(bwd_out_w); h.rule = rule; h.dtype = f64 ? at::kDouble : at::kFloat;
+             return h;
+           }))
+      .def("__call__", &RowHandle::call, py::arg("a"), py::arg("b") = py::none(),
+           "launch (bare kernel, or native autograd node when a gradient is being recorded); None if the operands are not the plain eager case");
   m.def("set_rule", &set_rule, "register the differentiable Python rule of an operator's backward (double backward)");
   m.def("scan_op", &scan_op, "pplie_scan_<group> in place, recorded as a native autograd node (backward: pplie_scan_<group>_bwd)");
   m.def("imu_integrate", &imu_integrate, "pplie_imu_integrate recorded as a native autograd node (backward: pplie_imu_integrate_bwd)");

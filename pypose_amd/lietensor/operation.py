@@ -308,6 +308,14 @@ def _make_fwd(clsname, g, kind, doc):
             # launch directly -- Function.apply costs ~40 us of Python per call (signature binding,
             # context set-up), which is the whole budget of a small kernel inside LM.step
             if not _transforms_active():
+                # the plain eager case through a PREPARED handle of the native extension (csrc_torch/pplie_autograd.cpp RowHandle):
+                # operand checks, the no-gradient launch and the native autograd node behind ONE call; None -> the paths below
+                if not _op_tracers and _C.row_op is _ROW_OP and len(ins) <= 2:
+                    h = cls._handle(ins[0].dtype)
+                    if h is not None and not _C.dry_tracing():
+                        out = h(*ins)
+                        if out is not None:
+                            return out
                 if not (torch.is_grad_enabled() and any(t.requires_grad for t in ins)):
                     return _launch(fwd_kernel, ins, fin, (fout,))[0]
                 nat = _native()
@@ -322,6 +330,27 @@ def _make_fwd(clsname, g, kind, doc):
                 # inspect.signature binding of forward()'s defaults (~15 us; there are none)
                 return super(torch.autograd.Function, cls).apply(*ins)
             return super().apply(*ins)
+
+        @classmethod
+        def _handle(cls, dtype):
+            """this operator's prepared handle for ``dtype`` (built on first use; None: no native extension / another dtype)"""
+            hs = cls.__dict__.get('_handles')
+            if hs is None:
+                hs = cls._handles = {}
+            if dtype in hs:
+                return hs[dtype]
+            h = None
+            nat = _native()
+            if nat is not None and hasattr(nat, "RowHandle") and dtype in (torch.float32, torch.float64) and len(fin) <= 2 \
+                    and _C._test_backend is None:
+                try:
+                    h = nat.RowHandle(_kernel_address(fwd_kernel, dtype), _kernel_address(bwd_kernel, dtype),
+                                      _kernel_address(bwd_kernel + "_gb", dtype), fin[0], fin[1] if len(fin) == 2 else 0, fout,
+                                      saved_spec, list(bout), cls._native_rule(nat), dtype == torch.float64)
+                except Exception:
+                    h = None
+            hs[dtype] = h
+            return h
 
         @classmethod
         def _native_rule(cls, nat):

@@ -143,6 +143,9 @@ class Scale(RobustKernel):
     def forward(self, input):
         return self.delta * input
 
+    def rho(self, x):
+        return self.delta * x
+
 
 class Tolerant(RobustKernel):
     """b log(1 + e^((x - a) / b)) - b log(1 + e^(-a / b)) with a > 0 > b (kernel.py:244-259)."""

@@ -137,7 +137,9 @@ class RobustModel(nn.Module):
         residuals = self.residuals(self.model_forward(input), target)
         kernels = self.kernel if len(self.kernel) > 1 else [self.kernel[0]] * len(residuals)
         # (|r|^2 >= 0 by construction: built-in kernels skip the public call's sign check and its device round trip)
-        return sum(getattr(k, 'of_squared_norm', k)(r.square().sum(-1)).sum() for k, r in zip(kernels, residuals))
+        from .kernel import RobustKernel        # (a user kernel that subclasses it and overrides forward keeps its forward)
+        entry = lambda k: k.of_squared_norm if isinstance(k, RobustKernel) and type(k).forward is RobustKernel.forward else k
+        return sum(entry(k)(r.square().sum(-1)).sum() for k, r in zip(kernels, residuals))
 
 
 # ---------------------------------------------------------------------------------------------

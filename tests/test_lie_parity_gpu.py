@@ -361,3 +361,37 @@ def test_sum_backward_takes_the_broadcast_route_and_equals_the_materialised_one(
     (y.tensor() * w).sum().backward()
     got = x.grad.tensor() if hasattr(x.grad, "tensor") else x.grad
     assert torch.allclose(got, g_mat.tensor() if hasattr(g_mat, "tensor") else g_mat, rtol=0, atol=0)
+
+
+def test_prepared_handles_carry_the_plain_eager_case():
+    """csrc_torch RowHandle: one call per op for contiguous device operands (bare kernel without grad, native node with), None --
+    and the general Python path -- for anything else; same bits either way"""
+    import pypose_amd as pp
+    from pypose_amd.lietensor import operation as _op
+    assert _op._native() is not None and hasattr(_op._native(), "RowHandle"), "native extension without RowHandle"
+    dev = _dev()
+    torch.manual_seed(11)
+    x = pp.randn_se3(1000, device=dev).tensor()
+    X = pp.randn_SE3(1000, device=dev).tensor()
+    h = _op.se3_Exp._handle(torch.float32)
+    assert h is not None and _op.SE3_Mul._handle(torch.float64) is not None
+    with torch.no_grad():
+        a = h(x)
+        assert a is not None and not a.requires_grad
+        b = _op._launch("se3_exp_fwd", (x,), (6,), (7,))[0]
+        assert torch.equal(a, b)
+        assert h(x.double()) is None and h(x.cpu()) is None and h(x[::2]) is None and h(x[:, :5]) is None
+        hm = _op.SE3_Mul._handle(torch.float32)
+        assert hm(X, X[:1]) is None and hm(X) is None                  # broadcasting / arity: the Python path
+        assert torch.equal(hm(X, a), _op._launch("se3_mul_fwd", (X, a), (7, 7), (7,))[0])
+    xr = x.clone().requires_grad_(True)
+    y = h(xr)
+    assert y.requires_grad and "RowOp" in type(y.grad_fn).__name__
+    (g,) = torch.autograd.grad(y, xr, torch.ones_like(y))
+    with torch.no_grad():
+        want = _op._launch("se3_exp_bwd", (x, torch.ones_like(y)), (6, 7), (6,))[0]
+    assert torch.equal(g, want)
+    # the public route lands on it: a LieTensor op under autograd is ONE native node
+    lt = pp.LieTensor(x.clone(), ltype=pp.se3_type).requires_grad_(True)
+    out = lt.Exp()
+    assert "RowOp" in type(out.tensor().grad_fn).__name__ or "Alias" in type(out.tensor().grad_fn).__name__
