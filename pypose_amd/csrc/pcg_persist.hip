@@ -198,23 +198,26 @@ __device__ __forceinline__ void publish_row(SH& sh, int par, u64* part, unsigned
 // all-gather: wave q polls quantity q of every workgroup's row (all loads of a round in flight together) and adds them up in
 // row order -- the same order, hence the same bits, in every workgroup.  Then ONE __syncthreads; totals in sh.total[par].
 template <class T, int NQ, class SH, int SLOTS = kPersistSlots>
-__device__ __forceinline__ void gather_rows(SH& sh, int par, const u64* part, unsigned tag) {
+__device__ __forceinline__ void gather_rows(SH& sh, int par, const u64* part, unsigned tag, int first = 0, int stride = 1, int count = -1,
+                                            int rows_per_table = kPersistGridMax) {
+  // rows first, first + stride, ... (count of them; default: one per workgroup of the grid) of table `par`
   constexpr int NW = sizeof(T) / 4, RW = SLOTS * NW, WVS = kPersistBlock / 64;
   constexpr int PER = (NQ + WVS - 1) / WVS;                  // quantities per wave: w, w + 16, ... polled TOGETHER (one spin loop:
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;   //  a second quantity costs no second round of L2 latencies)
+  if (count < 0) count = (int)gridDim.x;
   if (w < NQ) {
-    const u64* tab = part + (size_t)par * kPersistGridMax * RW;
+    const u64* tab = part + (size_t)par * rows_per_table * RW;
     T sum[PER];
 #pragma unroll
     for (int u = 0; u < PER; ++u) sum[u] = T(0);
     bool all = true;
-    for (int base = 0; base < (int)gridDim.x; base += 256) {
+    for (int base = 0; base < count; base += 256) {
       T val[PER][4];
       bool done[PER][4];
 #pragma unroll
       for (int u = 0; u < PER; ++u)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { done[u][q] = base + lane + 64 * q >= (int)gridDim.x || w + u * WVS >= NQ; val[u][q] = T(0); }
+        for (int q = 0; q < 4; ++q) { done[u][q] = base + lane + 64 * q >= count || w + u * WVS >= NQ; val[u][q] = T(0); }
       for (long spin = 0; spin < (1L << 20); ++spin) {
         bool pending = false;
 #pragma unroll
@@ -223,7 +226,7 @@ __device__ __forceinline__ void gather_rows(SH& sh, int par, const u64* part, un
           for (int q = 0; q < 4; ++q) {
             if (!done[u][q]) {
               bool ok = true;
-              const T t = get_value<T>(tab + (size_t)(base + lane + 64 * q) * RW + (w + u * WVS) * NW, tag, ok);
+              const T t = get_value<T>(tab + (size_t)(first + stride * (base + lane + 64 * q)) * RW + (w + u * WVS) * NW, tag, ok);
               if (ok) { val[u][q] = t; done[u][q] = true; } else pending = true;
             }
           }
@@ -244,6 +247,37 @@ __device__ __forceinline__ void gather_rows(SH& sh, int par, const u64* part, un
     }
     if (!__all(all) && lane == 0) sh.bad[par] = 1;
   }
+}
+
+// TWO-LEVEL all-gather (the wide exchange of the two-level preconditioner: 5 + 2 M quantities).  Every workgroup polling every
+// workgroup's row is grid x grid x NQ tagged loads per iteration -- all of them served by the memory side, the L2s of the eight
+// XCDs are not coherent with each other: measured 7.4 us per exchange with 17 quantities at 256 workgroups against 3.1 us with 5.
+// Here workgroup g < G (G = 8 groups) adds up the rows of the workgroups b = g (mod G) -- the ones the dispatcher places on its
+// own XCD -- and publishes ONE group row; everybody then polls the G group rows: (grid / G + G) x NQ loads per workgroup instead
+// of grid x NQ, two dependent hops instead of one.  Same bits everywhere: a group's sum has one order (its leader's), the final
+// sum runs over the groups in order.  Table rows: [0, kPersistGridMax) workgroups, then kHierGroups group rows.
+constexpr int kHierGroups = 8;
+constexpr int kHierRows = kPersistGridMax + kHierGroups;
+template <class T, int NQ, class SH, int SLOTS>
+__device__ __forceinline__ void exchange_two_level(SH& sh, int par, u64* part, unsigned tag) {
+  constexpr int NW = sizeof(T) / 4, RW = SLOTS * NW, WV = kPersistBlock / 64;
+  const int G = (int)gridDim.x < kHierGroups ? (int)gridDim.x : kHierGroups;
+  // (caller: post_wave_sums + __syncthreads done)  own row
+  if (threadIdx.x < NQ) {
+    T sum = T(0);
+#pragma unroll
+    for (int ww = 0; ww < WV; ++ww) sum += sh.wave_part[par][threadIdx.x][ww];
+    put_value<T>(part + ((size_t)par * kHierRows + blockIdx.x) * RW + threadIdx.x * NW, sum, tag);
+  }
+  if ((int)blockIdx.x < G) {                                   // leader of group blockIdx.x
+    const int members = ((int)gridDim.x - (int)blockIdx.x + G - 1) / G;
+    gather_rows<T, NQ, SH, SLOTS>(sh, par, part, tag, (int)blockIdx.x, G, members, kHierRows);
+    __syncthreads();
+    if (threadIdx.x < NQ)
+      put_value<T>(part + ((size_t)par * kHierRows + kPersistGridMax + blockIdx.x) * RW + threadIdx.x * NW, sh.total[par][threadIdx.x], tag);
+    __syncthreads();                                           // (sh.total is rewritten by the gather below)
+  }
+  gather_rows<T, NQ, SH, SLOTS>(sh, par, part, tag, kPersistGridMax, 1, G, kHierRows);
 }
 
 // (A PIPELINED recurrence -- Ghysels & Vanroose 2014: post the dot products before the matrix product, collect them after, so
@@ -548,8 +582,7 @@ pcg_ghost_kernel(const int* __restrict__ ptr, const int* __restrict__ slot, cons
     wave_comp_sums(act ? shift[n * M + i] : T(0), 1, 0);
     wave_comp_sums(re, 1, M);
     __syncthreads();
-    publish_row<T, 2 * M, SH, SLOTS>(sh, 1, part, 0x7fffffffu);
-    gather_rows<T, 2 * M, SH, SLOTS>(sh, 1, part, 0x7fffffffu);
+    exchange_two_level<T, 2 * M, SH, SLOTS>(sh, 1, part, 0x7fffffffu);
     __syncthreads();
     if (threadIdx.x < M) {
       const T e = sh.total[1][threadIdx.x];
@@ -621,7 +654,7 @@ pcg_ghost_kernel(const int* __restrict__ ptr, const int* __restrict__ slot, cons
     }
     __syncthreads();                                                             // barrier 1
     PPLIE_TICK(1)
-    publish_row<T, NQ, SH, SLOTS>(sh, par, part, tag);
+    if constexpr (!CZ) publish_row<T, NQ, SH, SLOTS>(sh, par, part, tag);
     // ---- the ghosts' q: issued now, needed after the all-gather
     T gq[kGhostLayers];
     bool gok[kGhostLayers];
@@ -630,7 +663,8 @@ pcg_ghost_kernel(const int* __restrict__ ptr, const int* __restrict__ slot, cons
       gok[l] = true;
       gq[l] = gact[l] ? get_value<T>(qtag + (size_t)par * NM + ((size_t)gnode[l] * M + i) * NW, tag, gok[l]) : T(0);
     }
-    gather_rows<T, NQ, SH, SLOTS>(sh, par, part, tag);
+    if constexpr (CZ) exchange_two_level<T, NQ, SH, SLOTS>(sh, par, part, tag);
+    else gather_rows<T, NQ, SH, SLOTS>(sh, par, part, tag);
     PPLIE_TICK(2)
     bool stale = false;
 #pragma unroll

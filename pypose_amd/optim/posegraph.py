@@ -337,7 +337,8 @@ class FusedPCG:
         esz = 4 if dtype == torch.float32 else 8
         nw = esz // 4
         # (part is sized for the wider rows of the two-level variant; cs, its coarse sums of the two-launch iteration, rides behind scal)
-        nb_scal, nb_part, nb_it = (_PCG_SCAL_ELEMS + _PCG2_CS_ELEMS) * esz, 2 * _PERSIST_GRID_MAX * _COARSE_SLOTS * nw * 8, 16
+        # (+ 8 group rows per table: the two-level exchange of the gauge variant, csrc/pcg_persist.hip kHierGroups)
+        nb_scal, nb_part, nb_it = (_PCG_SCAL_ELEMS + _PCG2_CS_ELEMS) * esz, 2 * (_PERSIST_GRID_MAX + 8) * _COARSE_SLOTS * nw * 8, 16
         # the persistent solve's hand-off table of p (tagged 64-bit words, double-buffered) sits in the same allocation
         nb_ptag = 2 * N * m * nw * 8 if (N <= PERSIST_NODES and m in (3, 6, 7)) else 0
         self._ctl = torch.zeros(nb_scal + nb_part + nb_it + nb_ptag, dtype=torch.uint8, device=device)
