@@ -10,6 +10,110 @@ def _update_width(p):
     return int(lt.manifold[0]) if lt is not None else (p.shape[-1] if p.dim() else 1)     # optimizer.py:44-49
 
 
+# ---- kernel route for the relative-pose residual ----------------------------------------------------------------------------
+# The reference's sparse pose-graph models (tests/optim/test_sparse_lm.py:11-13, examples/module/pgo) compute
+#     R = (relpose.Inv() @ node1.Inv() @ node2).Log().tensor()          node1 / node2: gathered rows of one tracked parameter
+# with the REFERENCE's autograd Functions; the graph they leave behind is  SE3_Log <- SE3_Mul(SE3_Mul(const, SE3_Inv(gather)), gather)
+# (plus alias / view / expand nodes).  When jacobian() finds exactly that, the per-edge 6 x 6 blocks come from ONE launch of
+# pplie_pgo_linearize (csrc/pgo_fused.hip: closed form, the kernel the fused pose-graph path uses) instead of six backward sweeps
+# through ~40 eager kernels each; the residual the kernel recomputes is compared with the traced one before its blocks are used.
+_PASS_THROUGH = {"AliasBackward0", "ViewBackward0", "ExpandBackward0", "ReshapeAliasBackward0", "UnsafeViewBackward0", "CloneBackward0"}
+route_taken = {"last": None}          # "kernel:pgo" / "autograd": what the latest jacobian() call did (tests)
+
+
+def _skip(fn):
+    while fn is not None and fn.name() in _PASS_THROUGH and len(fn.next_functions) == 1:
+        fn = fn.next_functions[0][0]
+    return fn
+
+
+def _same_node(a, b):
+    return a is not None and b is not None and (a is b or a == b)
+
+
+def _match_pgo(Rt, events, E, dr):
+    """(event of node1, event of node2, Z^-1 rows) if Rt's history is the relative-pose residual over two gathers, else None"""
+    if dr != 6 or len(events) != 2:
+        return None
+    try:
+        log = _skip(Rt.grad_fn)
+        if log is None or log.name() != "SE3_LogBackward":
+            return None
+        outer = _skip(log.next_functions[0][0])
+        if outer is None or outer.name() != "SE3_MulBackward" or len(outer.next_functions) != 2:
+            return None
+        inner, leaf2 = _skip(outer.next_functions[0][0]), _skip(outer.next_functions[1][0])
+        if inner is None or inner.name() != "SE3_MulBackward" or len(inner.next_functions) != 2 or inner.next_functions[0][0] is not None:
+            return None                                   # (the measurement must be a constant: no history on the left factor)
+        inv = _skip(inner.next_functions[1][0])
+        if inv is None or inv.name() != "SE3_InvBackward":
+            return None
+        leaf1 = _skip(inv.next_functions[0][0])
+        bases = [_skip(out.grad_fn) for _, _, out in events]
+        k1 = next((k for k, b in enumerate(bases) if _same_node(b, leaf1)), None)
+        k2 = next((k for k, b in enumerate(bases) if _same_node(b, leaf2)), None)
+        if k1 is None or k2 is None or k1 == k2:
+            return None
+        saved = inner.saved_tensors                        # SE3_Mul saves its left operand (operation.py:866-869): Z^-1
+        Zinv = torch.Tensor.as_subclass(saved[0], torch.Tensor).detach().reshape(-1, 7)
+        if Zinv.shape[0] != E or any(torch.Tensor.as_subclass(events[k][2], torch.Tensor).reshape(-1, 7).shape[0] != E for k in (k1, k2)):
+            return None                                    # (a broadcast operand: rows are not one-to-one)
+        return k1, k2, Zinv
+    except Exception:
+        return None
+
+
+def _pgo_blocks(events, k1, k2, Zinv, Rm):
+    """residual-checked blocks d r / d node1, d r / d node2 [E, 6, 6] from pplie_pgo_linearize, or None"""
+    import ctypes
+    from pypose_amd import _C
+    n1 = torch.Tensor.as_subclass(events[k1][2], torch.Tensor).detach().reshape(-1, 7)
+    n2 = torch.Tensor.as_subclass(events[k2][2], torch.Tensor).detach().reshape(-1, 7)
+    if not n1.is_cuda or n1.dtype not in (torch.float32, torch.float64) or _C._test_backend is not None:
+        return None
+    E = n1.shape[0]
+    nodes = torch.cat([n1, n2], 0).contiguous()
+    e = torch.arange(E, device=n1.device)
+    idx = torch.stack([e, e + E], -1).contiguous()
+    (Z,) = _C.row_op("se3_inv_fwd", [Zinv.contiguous()], (7,))
+    r = torch.empty((E, 6), dtype=n1.dtype, device=n1.device)
+    J = torch.empty((E, 2, 6, 6), dtype=n1.dtype, device=n1.device)
+    sig = [ctypes.c_void_p] * 5 + [ctypes.c_int64, ctypes.c_void_p]
+    fn = _C.library().symbol("pplie_pgo_linearize" + ("_f32" if n1.dtype == torch.float32 else "_f64"), sig)
+    with _C._on_device(n1.device):
+        _C.check(fn(nodes.data_ptr(), idx.data_ptr(), Z.data_ptr(), r.data_ptr(), J.data_ptr(), E, _C.stream_ptr(n1.device)),
+                 "pplie_pgo_linearize")
+    tol = 1e-4 if n1.dtype == torch.float32 else 1e-9
+    ref = Rm.detach()
+    if not bool((r - ref).abs().max() <= tol * ref.abs().max().clamp_min(1.0)):
+        return None                                        # not the function we took it for: the autograd sweeps decide
+    return J[:, 0], J[:, 1]
+
+
+def _kernel_pieces(Rt, Rm, events, pieces, E, dr, dev):
+    """fill `pieces` (row, column, value lists per parameter) from the kernel route; False if it does not apply"""
+    m = _match_pgo(Rt, events, E, dr)
+    if m is None:
+        return False
+    k1, k2, Zinv = m
+    blocks = _pgo_blocks(events, k1, k2, Zinv, Rm)
+    if blocks is None:
+        return False
+    if any(_update_width(events[k][0]) != 6 for k in (k1, k2)):
+        return False
+    e = torch.arange(E, device=dev)
+    for k, Jk in zip((k1, k2), blocks):
+        root, idx, out = events[k]
+        mw = 6
+        idx_k = e if idx is None else idx
+        keep = idx_k >= 0                                   # (rows of a fixed block concatenated in front: no column)
+        rr = (e.view(E, 1, 1) * dr + torch.arange(dr, device=dev).view(1, dr, 1)).expand(E, dr, mw)
+        cc = (idx_k.clamp_min(0).view(E, 1, 1) * mw + torch.arange(mw, device=dev).view(1, 1, mw)).expand(E, dr, mw)
+        r, c, v = pieces[id(root)]
+        r.append(rr[keep].reshape(-1)), c.append(cc[keep].reshape(-1)), v.append(Jk[keep].reshape(-1))
+    return True
+
+
 def jacobian(R, params):
     params = list(params)
     with torch.enable_grad():
@@ -27,7 +131,10 @@ def jacobian(R, params):
         ar = torch.arange(n, device=dev)
         r, c, v = pieces[id(R)]
         r.append(ar), c.append(ar), v.append(torch.ones(n, dtype=dt, device=dev))
+    elif events and Rt.requires_grad and _kernel_pieces(Rt, Rm, events, pieces, E, dr, dev):
+        route_taken["last"] = "kernel:pgo"
     elif events and Rt.requires_grad:
+        route_taken["last"] = "autograd"
         outs = [out for _, _, out in events]
         with torch.enable_grad():
             for k in range(dr):

@@ -142,3 +142,69 @@ def test_reference_ba_example_model_on_the_device():
             activate.deactivate()
         for g, w in zip(got, want):
             assert g == pytest.approx(w, rel=1e-6, abs=1e-15), (optim, got, want)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-10), (torch.float32, 2e-5)])
+def test_jacobian_of_the_relative_pose_residual_takes_the_kernel_route(dtype, tol, monkeypatch):
+    """bae.autograd.graph.jacobian on the reference's OWN (un-activated) ops: the history of
+    (rel.Inv() @ n1.Inv() @ n2).Log() is recognised and the blocks come from pplie_pgo_linearize -- equal to the six autograd
+    sweeps it replaces, fixed root rows (index -1) dropped alike"""
+    pp = load_reference()
+    import bae.autograd.graph as G
+    _, Chain, _ = models(pp)
+    torch.manual_seed(3)
+    N = 400
+    gt = pp.randn_SE3(N, sigma=0.5, dtype=dtype, device=DEV).cumprod(dim=0) if hasattr(pp.randn_SE3(1), "cumprod") else pp.randn_SE3(N, dtype=dtype, device=DEV)
+    e0 = torch.cat([torch.arange(N - 1), torch.randint(0, N, (300,))]).to(DEV)
+    e1 = torch.cat([torch.arange(1, N), torch.randint(0, N, (300,))]).to(DEV)
+    keep = e0 != e1
+    edges = torch.stack([e0[keep], e1[keep]], 1)
+    rel = gt[edges[:, 0]].Inv() @ gt[edges[:, 1]] @ pp.randn_SE3(edges.shape[0], sigma=0.05, dtype=dtype, device=DEV)
+    model = Chain(gt[:1], (gt[1:] @ pp.randn_SE3(N - 1, sigma=0.1, dtype=dtype, device=DEV))).to(DEV)
+    with torch.no_grad():
+        J_k = [j.to_dense() for j in G.jacobian(model(edges, rel), [model.nodes])]
+    assert G.route_taken["last"] == "kernel:pgo"
+    monkeypatch.setattr(G, "_match_pgo", lambda *a, **k: None)
+    with torch.no_grad():
+        J_a = [j.to_dense() for j in G.jacobian(model(edges, rel), [model.nodes])]
+    assert G.route_taken["last"] == "autograd"
+    for a, b in zip(J_k, J_a):
+        assert a.shape == b.shape
+        assert float((a - b).abs().max()) <= tol * float(b.abs().max())
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-9), (torch.float32, 2e-3)])
+def test_csr_pcg_and_diagonal_op_run_on_hip_kernels(dtype, tol):
+    """bae.utils.pysolvers.PCG / bae.sparse.py_ops.diagonal_op_ on a CSR normal-equation matrix: csrc/csr_pcg.hip against the torch
+    formulation of the same iteration (same iteration count +- 1, same solution), the diagonal rewritten in place"""
+    import functools
+    load_reference()
+    from bae.sparse.py_ops import diagonal_op_
+    from bae.utils import pysolvers
+    torch.manual_seed(5)
+    n, m = 6000, 9000
+    rows = torch.randint(0, m, (m * 6,))
+    cols = torch.randint(0, n, (m * 6,))
+    J = torch.sparse_coo_tensor(torch.stack([rows, cols]), torch.randn(m * 6, dtype=dtype), (m, n)).coalesce().to(DEV)
+    A = (J.mT.to_sparse_csr() @ J.to_sparse_csr())
+    A = (A.to_sparse_coo() + torch.sparse_coo_tensor(torch.stack([torch.arange(n)] * 2).to(DEV), torch.full((n,), 0.5, dtype=dtype, device=DEV),
+                                                   (n, n))).coalesce().to_sparse_csr()
+    A2 = torch.sparse_csr_tensor(A.crow_indices().clone(), A.col_indices().clone(), A.values().clone(), A.shape)
+    for op in (functools.partial(torch.clamp_, min=1.0, max=30.0), functools.partial(torch.mul, other=1.25)):
+        diagonal_op_(A, op)                                   # HIP
+        crow, col, val = A2.crow_indices(), A2.col_indices(), A2.values()
+        row = torch.repeat_interleave(torch.arange(n, device=DEV), crow[1:] - crow[:-1])
+        on = (row == col).nonzero().reshape(-1)
+        res = op(val[on])
+        val[on] = res if res is not None else val[on]        # the torch formulation
+        assert torch.equal(A.values(), A2.values())
+    b = torch.randn(n, 1, dtype=dtype, device=DEV)
+    hip = pysolvers.PCG(maxiter=2000, tol=1e-10 if dtype == torch.float64 else 1e-5)
+    x_h = hip(A, b)
+    assert hip.route == "hip"
+    ref = pysolvers.PCG(maxiter=2000, tol=hip.tol)
+    x_t = ref(A.to_dense(), b)                                # (dense input: the torch route)
+    assert ref.route == "torch"
+    assert abs(hip.iterations - ref.iterations) <= 2, (hip.iterations, ref.iterations)
+    assert float((x_h - x_t).abs().max()) <= tol * float(x_t.abs().max())
+    assert float((A.to_dense() @ x_h - b).norm() / b.norm()) <= 10 * hip.tol
