@@ -154,7 +154,7 @@ def test_jacobian_of_the_relative_pose_residual_takes_the_kernel_route(dtype, to
     _, Chain, _ = models(pp)
     torch.manual_seed(3)
     N = 400
-    gt = pp.randn_SE3(N, sigma=0.5, dtype=dtype, device=DEV).cumprod(dim=0) if hasattr(pp.randn_SE3(1), "cumprod") else pp.randn_SE3(N, dtype=dtype, device=DEV)
+    gt = pp.cumprod(pp.randn_SE3(N, sigma=0.5, dtype=dtype, device=DEV), dim=0, left=False)
     e0 = torch.cat([torch.arange(N - 1), torch.randint(0, N, (300,))]).to(DEV)
     e1 = torch.cat([torch.arange(1, N), torch.randint(0, N, (300,))]).to(DEV)
     keep = e0 != e1
