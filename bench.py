@@ -1017,7 +1017,7 @@ def _lift_second_half(out):
             "cpu_baseline_value": _r((pgo.get("cpu_baseline") or {}).get("value"), 3)}
     summ = {}
     for key in ("c1", "ops_10m", "lm_invnet", "lm_pgo", "lm_pgo_100k", "imu", "imu_train", "ba_reproj",
-                "lm_invnet_sharded", "imu_sharded", "lm_pgo_replicated", "lm_pgo_node_sharded"):
+                "lm_invnet_sharded", "imu_sharded", "lm_pgo_replicated", "lm_pgo_node_sharded", "lm_pgo_100k_one_gpu"):
         if key in out:
             summ[key] = _leg_summary(key, out[key])
     ops = out.get("ops_10m") if isinstance(out.get("ops_10m"), dict) else None
@@ -1287,6 +1287,25 @@ def main():
         # run across two physical GPUs in the builder's hands (ranks as processes on one GPU only).  A GPU memory fault there
         # would abort the job before the line is out, so the line goes out FIRST (with a note of what follows) and the leg's
         # result is written to stderr and to bench_p2p_leg.json beside this file afterwards.
+        # One-GPU equivalents, so that an N = 1 / N = 8 ratio falls out of this ONE line: the weak-scaling legs (problems / sequences
+        # per rank fixed) scale against value / ranks; configs[3] is ONE graph whatever N is (strong scaling): rank 0 runs the
+        # un-sharded single-GPU path on it while the other ranks wait at the barrier.
+        try:
+            one = pgo_lm_rate(dev, *((80, 200) if small else (100_000, 400_000)), reps=1 if small else 5, with_static=False) if rank == 0 else None
+        except Exception as e:
+            one = {"error": repr(e)}
+        dist.barrier()
+        if rank == 0:
+            out["lm_pgo_100k_one_gpu"] = {k: one.get(k) for k in ("value", "unit", "pcg_iterations", "losses", "error") if k in one}
+            for key in ("lm_invnet_sharded", "imu_sharded"):
+                if isinstance(out.get(key), dict) and "value" in out[key]:
+                    out[key]["one_gpu_equivalent"] = {"value": out[key]["value"] / world, "note": "weak scaling: per-rank work is fixed, "
+                                                      "the aggregate over ranks_seen ranks divided by their number"}
+            for key in ("lm_pgo_replicated", "lm_pgo_node_sharded"):
+                if isinstance(out.get(key), dict) and "value" in out[key] and one and one.get("value"):
+                    out[key]["one_gpu_equivalent"] = {"value": one["value"], "note": "strong scaling: the same 100k / 400k graph on rank 0 "
+                                                      "alone (single-GPU path, this run)"}
+                    out[key]["speedup_vs_one_gpu"] = out[key]["value"] / one["value"]
         post = os.environ.get("PPLIE_BENCH_P2P_LEG", "1") != "0"
         if rank == 0:
             out["lm_pgo_sharded"] = {"deferred": "runs after this line: LM(group=) default (node shards + in-kernel peer stores); "
@@ -1307,6 +1326,9 @@ def main():
             except Exception as e:
                 res = {"error": repr(e)}
             if rank == 0:
+                if isinstance(res, dict) and "value" in res and isinstance(out.get("lm_pgo_100k_one_gpu"), dict) and out["lm_pgo_100k_one_gpu"].get("value"):
+                    res["one_gpu_equivalent"] = {"value": out["lm_pgo_100k_one_gpu"]["value"], "note": "the same graph on rank 0 alone, this run"}
+                    res["speedup_vs_one_gpu"] = res["value"] / out["lm_pgo_100k_one_gpu"]["value"]
                 txt = json.dumps({"lm_pgo_sharded": res})
                 sys.stderr.write("PPLIE_BENCH_POSTLINE " + txt + "\n")
                 sys.stderr.flush()

@@ -44,6 +44,21 @@ def test_two_ranks_self_launched_dry_run():
     assert "error" not in leg and leg["ranks_seen"] == 2 and leg["effective"]["shard"] == "edges"      # (gloo group: no node shards)
 
 
+def test_eight_ranks_self_launched_dry_run():
+    """the command the driver runs on an 8-GPU node, on the CPU: every sharded leg with 8 ranks, each with `ranks_seen`, the
+    effective shard / exchange mode, microseconds per iteration and its one-GPU equivalent"""
+    out = _run(["--gpus", "8", "--steps", "2", "--warmup", "1", "--rows", "500", "--backend", "gloo", "--standin"], timeout=900)
+    assert out["n_gpus"] == 8 and out["ranks_seen"] == 8 and out["config"]["ranks"] == 8
+    for leg in ("lm_invnet_sharded", "imu_sharded", "lm_pgo_replicated", "lm_pgo_node_sharded"):
+        assert "error" not in out[leg], (leg, out[leg])
+        assert out[leg]["n_gpus"] == 8 and out[leg]["value"] > 0 and out[leg]["one_gpu_equivalent"]["value"] > 0
+    for leg in ("lm_pgo_replicated", "lm_pgo_node_sharded"):
+        assert out[leg]["ranks_seen"] == 8 and out[leg]["effective"]["shard"] in ("edges", "nodes") and out[leg]["speedup_vs_one_gpu"] > 0
+        assert out[leg]["us_per_pcg_iteration_incl_step_overheads"] > 0
+    assert out["lm_pgo_100k_one_gpu"]["value"] > 0
+    assert [k for k in out if k != "_stderr"][-1] == "summary" and "lm_pgo_node_sharded" in out["summary"]
+
+
 def test_single_process_dry_run_has_every_config():
     out = _run(["--gpus", "1", "--steps", "2", "--warmup", "1", "--rows", "1000", "--backend", "gloo", "--standin"])
     assert out["n_gpus"] == 1 and out["config"]["launch"] == "single process"
