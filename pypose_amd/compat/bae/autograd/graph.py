@@ -33,33 +33,42 @@ def _same_node(a, b):
 
 def _match_pgo(Rt, events, E, dr):
     """(event of node1, event of node2, Z^-1 rows) if Rt's history is the relative-pose residual over two gathers, else None"""
+    why = route_taken.__setitem__
     if dr != 6 or len(events) != 2:
+        why("why", f"dr {dr}, {len(events)} gathers")
         return None
     try:
         log = _skip(Rt.grad_fn)
         if log is None or log.name() != "SE3_LogBackward":
+            why("why", f"top node {None if log is None else log.name()}")
             return None
         outer = _skip(log.next_functions[0][0])
         if outer is None or outer.name() != "SE3_MulBackward" or len(outer.next_functions) != 2:
+            why("why", f"below Log: {None if outer is None else outer.name()}")
             return None
         inner, leaf2 = _skip(outer.next_functions[0][0]), _skip(outer.next_functions[1][0])
         if inner is None or inner.name() != "SE3_MulBackward" or len(inner.next_functions) != 2 or inner.next_functions[0][0] is not None:
+            why("why", f"left factor: {None if inner is None else inner.name()}")
             return None                                   # (the measurement must be a constant: no history on the left factor)
         inv = _skip(inner.next_functions[1][0])
         if inv is None or inv.name() != "SE3_InvBackward":
+            why("why", f"inner right factor: {None if inv is None else inv.name()}")
             return None
         leaf1 = _skip(inv.next_functions[0][0])
         bases = [_skip(out.grad_fn) for _, _, out in events]
         k1 = next((k for k, b in enumerate(bases) if _same_node(b, leaf1)), None)
         k2 = next((k for k, b in enumerate(bases) if _same_node(b, leaf2)), None)
         if k1 is None or k2 is None or k1 == k2:
+            why("why", f"leaves {leaf1 and leaf1.name()} / {leaf2 and leaf2.name()} vs gathers {[b and b.name() for b in bases]}")
             return None
         saved = inner.saved_tensors                        # SE3_Mul saves its left operand (operation.py:866-869): Z^-1
         Zinv = torch.Tensor.as_subclass(saved[0], torch.Tensor).detach().reshape(-1, 7)
         if Zinv.shape[0] != E or any(torch.Tensor.as_subclass(events[k][2], torch.Tensor).reshape(-1, 7).shape[0] != E for k in (k1, k2)):
+            why("why", "broadcast operand")
             return None                                    # (a broadcast operand: rows are not one-to-one)
         return k1, k2, Zinv
-    except Exception:
+    except Exception as ex:
+        why("why", "exception " + repr(ex))
         return None
 
 
@@ -70,6 +79,7 @@ def _pgo_blocks(events, k1, k2, Zinv, Rm):
     n1 = torch.Tensor.as_subclass(events[k1][2], torch.Tensor).detach().reshape(-1, 7)
     n2 = torch.Tensor.as_subclass(events[k2][2], torch.Tensor).detach().reshape(-1, 7)
     if not n1.is_cuda or n1.dtype not in (torch.float32, torch.float64) or _C._test_backend is not None:
+        route_taken["why"] = "not a HIP call"
         return None
     E = n1.shape[0]
     nodes = torch.cat([n1, n2], 0).contiguous()
@@ -86,6 +96,7 @@ def _pgo_blocks(events, k1, k2, Zinv, Rm):
     tol = 1e-4 if n1.dtype == torch.float32 else 1e-9
     ref = Rm.detach()
     if not bool((r - ref).abs().max() <= tol * ref.abs().max().clamp_min(1.0)):
+        route_taken["why"] = f"residual check: {float((r - ref).abs().max()):.3e}"
         return None                                        # not the function we took it for: the autograd sweeps decide
     return J[:, 0], J[:, 1]
 

