@@ -52,36 +52,31 @@ class StampedSE3(object):
             lifted = Sim3(torch.cat((data, torch.ones_like(data[..., :1])), dim=-1))
             self.poses = SE3((trans @ lifted).tensor()[..., :7])
 
-    def translation(self):
-        return self.poses.translation()
+    # -- the trajectory's view of its poses (API of ape_rpe.py:63-104): read accessors forward to the LieTensor, the three
+    #    "move" calls replace it in place.  One forwarding rule each instead of a method per name.
+    _FORWARDED = ("translation", "rotation")                  # poses.<name>()
+    _PROPERTIES = {"num_poses": lambda p: p.shape[0], "first_pose": lambda p: p[0], "dtype": lambda p: p.dtype,
+                   "device": lambda p: p.device}
 
-    def rotation(self):
-        return self.poses.rotation()
+    def __getattr__(self, name):
+        if name in StampedSE3._FORWARDED:
+            return getattr(self.__dict__["poses"], name)
+        prop = StampedSE3._PROPERTIES.get(name)
+        if prop is not None:
+            return prop(self.__dict__["poses"])
+        raise AttributeError(name)
+
+    def _replace(self, moved):
+        self.poses = moved
 
     def type(self, dtype=torch.float64):
-        self.poses = self.poses.to(dtype)
+        self._replace(self.poses.to(dtype))
 
     def cuda(self):
-        self.poses = self.poses.cuda()
+        self._replace(self.poses.cuda())
 
     def cpu(self):
-        self.poses = self.poses.cpu()
-
-    @property
-    def num_poses(self):
-        return self.poses.shape[0]
-
-    @property
-    def first_pose(self):
-        return self.poses[0]
-
-    @property
-    def dtype(self):
-        return self.poses.dtype
-
-    @property
-    def device(self):
-        return self.poses.device
+        self._replace(self.poses.cpu())
 
     @property
     def accumulated_distances(self):
