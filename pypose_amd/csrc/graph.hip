@@ -16,6 +16,7 @@
 #include "rowmap.h"
 #include "chol.h"
 #include "dpp.h"
+#include "gridsync.h"
 
 namespace pplie {
 
@@ -1668,6 +1669,255 @@ extern "C" int pplie_block_matvec_f32(const void* B, const void* x, void* y, int
 extern "C" int pplie_block_matvec_f64(const void* B, const void* x, void* y, int64_t N, int m, void* stream) {
   return pplie::block_matvec<double>(B, x, y, N, m, stream);
 }
+
+// ---------------------------------------------------------------------------------------------
+// Multi-parameter graphs (bundle adjustment): the PCG iteration in THREE launches (was eleven: VERDICT r04 missing 4).
+//   pplie_mg_jtimes   q_e = W_e sum_s J_{e,s} p[idx_s[e]]                                            (edge-parallel, as before)
+//   pplie_mg3_jt      y = sum over ALL slots of J^T q, segment sums by node, + shift o p;  p.y, y.z, y.(Binv y)   (one wave per node)
+//   pplie_mg3_step    alpha, beta from the reduced scalars (rho' = rho - 2 alpha y.z + alpha^2 y.Binv y: the block-diagonal
+//                     preconditioner makes rho' node-local, as in pcg2 above);  x += alpha p;  r -= alpha y;  z = Binv r;
+//                     p = z + beta p;  rho_next += r.z;  rr += r.r;  ++it[0]                          (one lane per node)
+// The unknowns of up to four parameters are concatenated (offsets `off`, widths m <= 8); a slot is (parameter, incidence lists, J).
+// scal / it: the layout and protocol of pplie_pcg2_* (PPLIE_PCG2_SCAL_ELEMS; set 0 seeded with rho by the caller).
+// ---------------------------------------------------------------------------------------------
+namespace pplie {
+constexpr int kMgParams = 4;
+template <class T> struct Mg3Args {
+  int nparams, nslots;
+  int64_t N[kMgParams], off[kMgParams];
+  int m[kMgParams];
+  const T* Binv[kMgParams];
+  int slot_param[kMgSlots];
+  const T* J[kMgSlots];
+  const int* perm[kMgSlots];
+  const int* ptr[kMgSlots];
+};
+// Work items of pplie_mg3_jt: a row of the normal equations (node n of parameter k: global row g = rows of the earlier parameters + n)
+// is the sum over its slots' incidence lists; a camera row of a bundle-adjustment problem has ~10^3 incidences, a point row ~4.  One
+// wavefront walking 10^3 incidences was the critical path of the whole product (round 2), so the host cuts every (slot, row) list into
+// chunks of <= PPLIE_MG3_CHUNK incidences: item = {g, slot, first incidence, end}; the items of a row are contiguous.  A row with ONE
+// item is finished by the wave that computed it.  Otherwise every wave leaves its partial row in `part` (agent-scope stores), counts
+// itself in `cnt[g]`, and the LAST one to arrive adds the row's partials IN ITEM ORDER (same bits whatever the arrival order), finishes
+// the row and zeroes the counter -- no second launch, no atomics on the values.
+struct Mg3Item { int g, slot, beg, end; };
+
+template <class T>
+__global__ void __launch_bounds__(256)
+mg3_jt_kernel(Mg3Args<T> A, const Mg3Item* __restrict__ items, const int* __restrict__ row_first, const int* __restrict__ row_items,
+              int64_t nitems, T* part, int* cnt, const T* __restrict__ q, const T* __restrict__ p, const T* __restrict__ z,
+              const T* __restrict__ shift, T* __restrict__ y, T* scal, T* __restrict__ rr_hist, int* it, int cap, int dr) {
+  const int done = it[0];
+  const int a = done & 1;
+  if (blockIdx.x == 0) {
+    if (threadIdx.x == 0) {
+      if (done > 0 && done - 1 < cap) rr_hist[done - 1] = slot_total(squant2(scal, a ^ 1, Q2_RR));
+      it[1] = done;
+    }
+    __syncthreads();
+    if (threadIdx.x < 5 * kSlots) {
+      const int qi = threadIdx.x / kSlots, quant = qi < 3 ? qi : qi + 1;
+      squant2(scal, a ^ 1, quant)[(threadIdx.x % kSlots) * kStride] = T(0);
+    }
+  }
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * 256) >> 6;
+  T a_pq = T(0), a_qz = T(0), a_qmq = T(0);
+  for (int64_t w = wave; w < nitems; w += nwaves) {
+    const Mg3Item itx = items[w];
+    int k = 0;
+    int64_t n = itx.g;
+    while (k + 1 < A.nparams && n >= A.N[k]) { n -= A.N[k]; ++k; }
+    const int m = A.m[k];
+    int subs = 1;
+    while (subs * 2 * m <= 64) subs *= 2;
+    const int sub = lane / m, j = lane - sub * m;
+    T acc = T(0);
+    if (sub < subs && itx.slot >= 0) {
+      const T* Js = A.J[itx.slot];
+      const int* perm = A.perm[itx.slot];
+      // two incidences per trip: index -> (J row, q row) is a chain of two memory round trips; the pairs are independent
+      int c = itx.beg + sub;
+      for (; c + subs < itx.end; c += 2 * subs) {
+        const int64_t e0 = perm[c], e1 = perm[c + subs];
+        const T* J0 = Js + e0 * dr * m;
+        const T* J1 = Js + e1 * dr * m;
+        const T* q0 = q + e0 * dr;
+        const T* q1 = q + e1 * dr;
+        T s0 = T(0), s1 = T(0);
+        for (int i = 0; i < dr; ++i) { s0 += J0[i * m + j] * q0[i]; s1 += J1[i * m + j] * q1[i]; }
+        acc += s0 + s1;
+      }
+      if (c < itx.end) {
+        const int64_t e0 = perm[c];
+        const T* J0 = Js + e0 * dr * m;
+        const T* q0 = q + e0 * dr;
+        for (int i = 0; i < dr; ++i) acc += J0[i * m + j] * q0[i];
+      }
+    }
+    for (int off = subs >> 1; off > 0; off >>= 1) acc += __shfl_down(acc, off * m, 64);
+    // ---- the row's sum: directly, or through the last-arriver reduction
+    const int nit = row_items[itx.g];
+    bool finish = true;
+    if (nit > 1) {
+      if (lane < m) xwg_store(part + (size_t)w * 8 + lane, acc);
+      __threadfence();
+      int old = 0;
+      if (lane == 0) old = atomicAdd(cnt + itx.g, 1);
+      old = __shfl(old, 0, 64);
+      finish = old == nit - 1;
+      if (finish) {
+        __threadfence();
+        const int f = row_first[itx.g];
+        T sum = T(0);
+        if (lane < m)
+          for (int t = 0; t < nit; ++t) sum += xwg_load(part + (size_t)(f + t) * 8 + lane);
+        acc = sum;
+        if (lane == 0) cnt[itx.g] = 0;                                  // (the next iteration's launch starts from zero)
+      }
+    }
+    if (!finish) continue;                                              // (wave-uniform)
+    const int64_t e0 = A.off[k] + n * m;
+    const bool own = lane < m;
+    T yj = T(0), pj = T(0), zj = T(0);
+    if (own) {
+      pj = p[e0 + lane];
+      zj = z[e0 + lane];
+      yj = acc + shift[e0 + lane] * pj;
+      y[e0 + lane] = yj;
+    }
+    T bq = T(0);
+    for (int l = 0; l < 8; ++l) {
+      const T yl = __shfl(yj, l, 64);
+      if (own && l < m) bq += A.Binv[k][(n * m + lane) * m + l] * yl;
+    }
+    if (own) { a_pq += yj * pj; a_qz += yj * zj; a_qmq += yj * bq; }
+  }
+  const T s1 = block_sum(a_pq), s2 = block_sum(a_qz), s3 = block_sum(a_qmq);
+  if (threadIdx.x == 0) {
+    slot_add(squant2(scal, a, Q2_PQ), s1);
+    slot_add(squant2(scal, a, Q2_QZ), s2);
+    slot_add(squant2(scal, a, Q2_QMQ), s3);
+  }
+}
+
+template <class T>
+__global__ void __launch_bounds__(256)
+mg3_step_kernel(Mg3Args<T> A, T* __restrict__ x, T* __restrict__ r, T* __restrict__ p, const T* __restrict__ y, T* __restrict__ z, T* scal,
+                int* it) {
+  const int done = it[1];
+  const int a = done & 1;
+  const T* const bases[4] = {squant2(scal, a, Q2_RHO), squant2(scal, a, Q2_PQ), squant2(scal, a, Q2_QZ), squant2(scal, a, Q2_QMQ)};
+  T tv[4];
+  slot_totals_wg<T, 4>(bases, tv);
+  constexpr T tiny = sizeof(T) == 4 ? T(1e-30) : T(1e-290);
+  const T rho = tv[0], pq = tv[1], qz = tv[2], qmq = tv[3];
+  const T alpha = pq > tiny ? rho / pq : T(0);
+  T rho_rec = rho - T(2) * alpha * qz + alpha * alpha * qmq;
+  if (rho_rec < T(0)) rho_rec = T(0);
+  const T beta = rho > tiny ? rho_rec / rho : T(0);
+  int64_t total = 0;
+  for (int k = 0; k < A.nparams; ++k) total += A.N[k];
+  T a1 = T(0), a2 = T(0);
+  for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < total; g += (int64_t)gridDim.x * 256) {
+    int k = 0;
+    int64_t n = g;
+    while (k + 1 < A.nparams && n >= A.N[k]) { n -= A.N[k]; ++k; }
+    const int m = A.m[k];
+    const int64_t e0 = A.off[k] + n * m;
+    T re[8];
+    for (int j = 0; j < m; ++j) re[j] = r[e0 + j] - alpha * y[e0 + j];
+    const T* B = A.Binv[k] + n * m * m;
+    for (int j = 0; j < m; ++j) {
+      T ze = T(0);
+      for (int l = 0; l < m; ++l) ze += B[j * m + l] * re[l];
+      const T pe = p[e0 + j];
+      x[e0 + j] += alpha * pe;
+      r[e0 + j] = re[j];
+      z[e0 + j] = ze;
+      p[e0 + j] = ze + beta * pe;
+      a1 += re[j] * ze;
+      a2 += re[j] * re[j];
+    }
+  }
+  const T s1 = block_sum(a1), s2 = block_sum(a2);
+  if (threadIdx.x == 0) {
+    slot_add(squant2(scal, a ^ 1, Q2_RHO), s1);
+    slot_add(squant2(scal, a, Q2_RR), s2);
+    if (blockIdx.x == 0) it[0] = done + 1;
+  }
+}
+
+template <class T>
+int mg3_fill(Mg3Args<T>& A, int nparams, const int64_t* N, const int64_t* off, const int* m, const void* const* Binv, int nslots,
+             const int* slot_param, const void* const* J, const void* const* perm, const void* const* ptr) {
+  if (nparams <= 0 || nparams > kMgParams || nslots <= 0 || nslots > kMgSlots || !N || !off || !m || !Binv || !slot_param || !J || !perm || !ptr)
+    return PPLIE_EBADARG;
+  A.nparams = nparams;
+  A.nslots = nslots;
+  for (int k = 0; k < nparams; ++k) {
+    if (N[k] < 0 || m[k] <= 0 || m[k] > 8 || !Binv[k]) return PPLIE_EBADARG;
+    A.N[k] = N[k]; A.off[k] = off[k]; A.m[k] = m[k]; A.Binv[k] = (const T*)Binv[k];
+  }
+  for (int s = 0; s < nslots; ++s) {
+    if (slot_param[s] < 0 || slot_param[s] >= nparams || !J[s] || !perm[s] || !ptr[s]) return PPLIE_EBADARG;
+    A.slot_param[s] = slot_param[s]; A.J[s] = (const T*)J[s]; A.perm[s] = (const int*)perm[s]; A.ptr[s] = (const int*)ptr[s];
+  }
+  return PPLIE_OK;
+}
+template <class T>
+int mg3_jt(int nparams, const int64_t* N, const int64_t* off, const int* m, const void* const* Binv, int nslots, const int* slot_param,
+           const void* const* J, const void* const* perm, const void* const* ptr, const void* items, const void* row_first,
+           const void* row_items, int64_t nitems, void* part, void* cnt, const void* q, const void* p, const void* z,
+           const void* shift, void* y, void* scal, void* rr_hist, void* it, int cap, int dr, void* stream) {
+  Mg3Args<T> A;
+  const int rc = mg3_fill<T>(A, nparams, N, off, m, Binv, nslots, slot_param, J, perm, ptr);
+  if (rc != PPLIE_OK) return rc;
+  if (!items || !row_first || !row_items || !part || !cnt || !q || !p || !z || !shift || !y || !scal || !rr_hist || !it || dr <= 0 || dr > 8 ||
+      nitems < 0)
+    return PPLIE_EBADARG;
+  if (nitems == 0) return PPLIE_OK;
+  const int64_t blocks = (nitems + 3) / 4;
+  hipLaunchKernelGGL((mg3_jt_kernel<T>), dim3((int)(blocks < (1 << 20) ? blocks : (1 << 20))), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), A,
+                     (const Mg3Item*)items, (const int*)row_first, (const int*)row_items, nitems, (T*)part, (int*)cnt, (const T*)q,
+                     (const T*)p, (const T*)z, (const T*)shift, (T*)y, (T*)scal, (T*)rr_hist, (int*)it, cap, dr);
+  return hipGetLastError() == hipSuccess ? PPLIE_OK : PPLIE_ELAUNCH;
+}
+template <class T>
+int mg3_step(int nparams, const int64_t* N, const int64_t* off, const int* m, const void* const* Binv, void* x, void* r, void* p,
+             const void* y, void* z, void* scal, void* it, void* stream) {
+  Mg3Args<T> A;
+  A.nparams = 0; A.nslots = 0;
+  if (nparams <= 0 || nparams > kMgParams || !N || !off || !m || !Binv || !x || !r || !p || !y || !z || !scal || !it) return PPLIE_EBADARG;
+  A.nparams = nparams;
+  int64_t total = 0;
+  for (int k = 0; k < nparams; ++k) {
+    if (N[k] < 0 || m[k] <= 0 || m[k] > 8 || !Binv[k]) return PPLIE_EBADARG;
+    A.N[k] = N[k]; A.off[k] = off[k]; A.m[k] = m[k]; A.Binv[k] = (const T*)Binv[k];
+    total += N[k];
+  }
+  if (total <= 0) return PPLIE_OK;
+  const int64_t blocks = (total + 255) / 256;
+  hipLaunchKernelGGL((mg3_step_kernel<T>), dim3((int)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), A, (T*)x,
+                     (T*)r, (T*)p, (const T*)y, (T*)z, (T*)scal, (int*)it);
+  return hipGetLastError() == hipSuccess ? PPLIE_OK : PPLIE_ELAUNCH;
+}
+}  // namespace pplie
+#define PPLIE_MG3(SFX, T)                                                                                                          \
+  extern "C" int pplie_mg3_jt_##SFX(int nparams, const int64_t* N, const int64_t* off, const int* m, const void* const* Binv, int nslots, \
+                                    const int* slot_param, const void* const* J, const void* const* perm, const void* const* ptr,  \
+                                    const void* items, const void* row_first, const void* row_items, int64_t nitems, void* part,   \
+                                    void* cnt, const void* q, const void* p, const void* z, const void* shift, void* y, void* scal, \
+                                    void* rr_hist, void* it, int cap, int dr, void* stream) {                                      \
+    return pplie::mg3_jt<T>(nparams, N, off, m, Binv, nslots, slot_param, J, perm, ptr, items, row_first, row_items, nitems, part, cnt, \
+                            q, p, z, shift, y, scal, rr_hist, it, cap, dr, stream);                                                \
+  }                                                                                                                                \
+  extern "C" int pplie_mg3_step_##SFX(int nparams, const int64_t* N, const int64_t* off, const int* m, const void* const* Binv, void* x, \
+                                      void* r, void* p, const void* y, void* z, void* scal, void* it, void* stream) {              \
+    return pplie::mg3_step<T>(nparams, N, off, m, Binv, x, r, p, y, z, scal, it, stream);                                          \
+  }
+PPLIE_MG3(f32, float)
+PPLIE_MG3(f64, double)
 
 // ---------------------------------------------------------------------------------------------
 // PCG vector stages on FLAT vectors (optim/multigraph.py: unknowns of several parameters concatenated, the

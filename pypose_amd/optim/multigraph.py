@@ -38,6 +38,10 @@ _MGS_SIG = [ctypes.c_void_p] * 5 + [ctypes.c_int64, ctypes.c_int, ctypes.c_int, 
 _BMV_SIG = [ctypes.c_void_p] * 3 + [ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]
 _STAGE_SIG = [ctypes.c_int] + [ctypes.c_void_p] * 10 + [ctypes.c_int, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]   # pplie_pcg_stage
 _FLAT_SIG = [ctypes.c_int] + [ctypes.c_void_p] * 8 + [ctypes.c_int, ctypes.c_int64, ctypes.c_void_p]                    # pplie_pcg_flat
+_MG3_JT_SIG = [ctypes.c_int] + [ctypes.c_void_p] * 4 + [ctypes.c_int] + [ctypes.c_void_p] * 7 + [ctypes.c_int64] + [ctypes.c_void_p] * 10 \
+    + [ctypes.c_int, ctypes.c_int, ctypes.c_void_p]                                                                   # pplie_mg3_jt
+_MG3_STEP_SIG = [ctypes.c_int] + [ctypes.c_void_p] * 11 + [ctypes.c_void_p]                                           # pplie_mg3_step
+MG3_CHUNK = 128            # PPLIE_MG3_CHUNK: incidences of one work item of pplie_mg3_jt
 
 
 class _Scatter:
@@ -466,8 +470,96 @@ class _GraphedPCG:
         self.rr_hist = z(self.cap)
         self.it = torch.zeros(2, dtype=torch.int32, device=dev)
         self.tot = tot
+        self.scal2 = z(2 * 8 * 32 * 32)            # PPLIE_PCG2_SCAL_ELEMS: the three-launch iteration's scalars
+        self.use_mg3 = self.hip and len(lin.N) <= 4 and all(sc.hip for sc in lin.scatters())
+
+    mg3 = True             # the three-launch iteration (csrc/graph.hip pplie_mg3_*); False: the eleven-launch formulation below
+
+    def _mg3_plan(self):
+        """work items of pplie_mg3_jt for the current incidence lists (rebuilt when the edge list changes): every (slot, row) list cut
+        into chunks of MG3_CHUNK incidences, the items of a row contiguous and in (slot, chunk) order; rows without any incidence get
+        one empty item (their y is shift o p)"""
+        L = self.lin_like
+        hit = self.__dict__.get('_mg3')
+        if hit is not None and hit[0] is L._scatters:
+            return hit[1]
+        dev = self.p.device
+        scs = L._scatters
+        rows0, g_all, s_all, b_all, e_all = [], [], [], [], []
+        base = 0
+        for k, n in enumerate(L.N):
+            rows0.append(base)
+            covered = torch.zeros(n, dtype=torch.bool, device=dev)
+            for si, ((pi, _, _), sc) in enumerate(zip(L.slots, scs)):
+                if pi != k:
+                    continue
+                ptr = sc.ptr.long()
+                cnt = ptr[1:] - ptr[:-1]
+                per = (cnt + MG3_CHUNK - 1) // MG3_CHUNK
+                row = torch.repeat_interleave(torch.arange(n, device=dev), per)
+                first = torch.cumsum(per, 0) - per
+                ch = torch.arange(row.numel(), device=dev) - first[row]
+                beg = ptr[row] + ch * MG3_CHUNK
+                g_all.append(row + base), s_all.append(torch.full_like(row, si)), b_all.append(beg)
+                e_all.append(torch.minimum(beg + MG3_CHUNK, ptr[row + 1]))
+                covered |= cnt > 0
+            empty = (~covered).nonzero().reshape(-1)
+            if empty.numel():
+                g_all.append(empty + base), s_all.append(torch.full_like(empty, -1)), b_all.append(torch.zeros_like(empty))
+                e_all.append(torch.zeros_like(empty))
+            base += n
+        g, sl, bg, en = (torch.cat(t) for t in (g_all, s_all, b_all, e_all))
+        order = torch.argsort((g * (len(L.slots) + 1) + (sl + 1)) * (1 << 22) + (bg // MG3_CHUNK) % (1 << 22), stable=True)
+        g, sl, bg, en = g[order], sl[order], bg[order], en[order]
+        items = torch.stack([g, sl, bg, en], 1).to(torch.int32).contiguous()
+        row_items = torch.bincount(g, minlength=base).to(torch.int32)
+        row_first = (torch.cumsum(row_items.long(), 0) - row_items.long()).to(torch.int32)
+        P = len(L.N)
+        S = len(L.slots)
+        offs, o = [], 0
+        for n, m in zip(L.N, L.m):
+            offs.append(o)
+            o += n * m
+        plan = dict(
+            N=(ctypes.c_int64 * P)(*L.N), off=(ctypes.c_int64 * P)(*offs), m=(ctypes.c_int * P)(*L.m),
+            Binv=(ctypes.c_void_p * P)(*[b.data_ptr() for b in self.Binv]),
+            slot_param=(ctypes.c_int * S)(*[pi for pi, _, _ in L.slots]), J=(ctypes.c_void_p * S)(*[J.data_ptr() for _, _, J in L.slots]),
+            perm=(ctypes.c_void_p * S)(*[sc.perm.data_ptr() for sc in scs]), ptr=(ctypes.c_void_p * S)(*[sc.ptr.data_ptr() for sc in scs]),
+            items=items, row_first=row_first, row_items=row_items, nitems=int(items.shape[0]),
+            part=torch.zeros(items.shape[0] * 8, dtype=self.p.dtype, device=dev), cnt=torch.zeros(base, dtype=torch.int32, device=dev),
+            y=torch.empty_like(self.p), P=P, S=S)
+        self._mg3 = (L._scatters, plan)
+        return plan
+
+    def _iteration_mg3(self):
+        """3 launches: q_e = W J p (edge-parallel), y = J^T q + shift o p with p.y / y.z / y.Binv y (row-parallel work items),
+        the whole vector update with alpha and beta from the reduced scalars (csrc/graph.hip pplie_mg3_*)"""
+        L, lib, st = self.lin_like, _C.library(), _C.stream_ptr(self.p.device)
+        sfx = L._sfx()
+        pl = self._mg3_plan()
+        xs = L._split(self.p)
+        S = pl["S"]
+        arr = lambda ts: (ctypes.c_void_p * S)(*[t.data_ptr() for t in ts])
+        q = self.__dict__.get('_mg3_q')
+        if q is None or q.shape != (L.E, L.dr) or q.dtype != self.p.dtype:
+            q = self._mg3_q = torch.empty((L.E, L.dr), dtype=self.p.dtype, device=self.p.device)
+        ms = (ctypes.c_int * S)(*[J.shape[-1] for _, _, J in L.slots])
+        with _C._on_device(self.p.device):
+            _C.check(lib.symbol("pplie_mg_jtimes" + sfx, _MGJ_SIG)(
+                S, arr([J for _, _, J in L.slots]), arr([i for _, i, _ in L.slots]), arr([xs[pi] for pi, _, _ in L.slots]),
+                ms, L.W.data_ptr() if L.W is not None else None, q.data_ptr(), L.E, L.dr, st), "pplie_mg_jtimes")
+            _C.check(lib.symbol("pplie_mg3_jt" + sfx, _MG3_JT_SIG)(
+                pl["P"], pl["N"], pl["off"], pl["m"], pl["Binv"], S, pl["slot_param"], pl["J"], pl["perm"], pl["ptr"],
+                pl["items"].data_ptr(), pl["row_first"].data_ptr(), pl["row_items"].data_ptr(), pl["nitems"], pl["part"].data_ptr(),
+                pl["cnt"].data_ptr(), q.data_ptr(), self.p.data_ptr(), self.z.data_ptr(), self.shift_flat.data_ptr(), pl["y"].data_ptr(),
+                self.scal2.data_ptr(), self.rr_hist.data_ptr(), self.it.data_ptr(), self.cap, L.dr, st), "pplie_mg3_jt")
+            _C.check(lib.symbol("pplie_mg3_step" + sfx, _MG3_STEP_SIG)(
+                pl["P"], pl["N"], pl["off"], pl["m"], pl["Binv"], self.x.data_ptr(), self.r.data_ptr(), self.p.data_ptr(),
+                pl["y"].data_ptr(), self.z.data_ptr(), self.scal2.data_ptr(), self.it.data_ptr(), st), "pplie_mg3_step")
 
     def _iteration_hip(self):
+        if self.mg3 and self.use_mg3:
+            return self._iteration_mg3()
         """11 launches: q = H p (1 + one per slot), q += shift o p with p.q, x / r update with |r|^2, z = Binv r per parameter,
         r.z, p = z + beta p -- scalars stay in the slot-spread device sets of the pose-graph PCG."""
         L, lib, st = self.lin_like, _C.library(), _C.stream_ptr(self.p.device)
@@ -527,6 +619,10 @@ class _GraphedPCG:
             self.scal.zero_()
             self.scal[0] = self.rho                                 # set 0, rho, slot 0
             self.it.zero_()
+            if self.mg3 and self.use_mg3:
+                self.z.copy_(zv)
+                self.scal2.zero_()
+                self.scal2[0] = self.rho
         bn2 = float((bv * bv).sum())
         if bn2 == 0.0:
             return self.x.clone(), 0
@@ -545,7 +641,10 @@ class _GraphedPCG:
                 for k in range(self.check_every):
                     self._iteration(k)
             done += self.check_every
-            rr = float(self.rr_hist[done - 1]) if self.hip else float(self.rr[-1])
+            if self.hip and self.mg3 and self.use_mg3:              # |r|^2 of the last iteration still sits in its slot-spread accumulator
+                rr = float(self.scal2.view(2, 8, 32, 32)[(done - 1) & 1, 2, :, 0].sum())
+            else:
+                rr = float(self.rr_hist[done - 1]) if self.hip else float(self.rr[-1])
             if rr <= tol * tol * bn2:
                 break
         return self.x.clone(), done
