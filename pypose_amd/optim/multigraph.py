@@ -473,7 +473,8 @@ class _GraphedPCG:
         self.scal2 = z(2 * 8 * 32 * 32)            # PPLIE_PCG2_SCAL_ELEMS: the three-launch iteration's scalars
         self.use_mg3 = self.hip and len(lin.N) <= 4 and all(sc.hip for sc in lin.scatters())
 
-    mg3 = True             # the three-launch iteration (csrc/graph.hip pplie_mg3_*); False: the eleven-launch formulation below
+    # the three-launch iteration (csrc/graph.hip pplie_mg3_*); False / PPLIE_MG3=0: the eleven-launch formulation below
+    mg3 = __import__("os").environ.get("PPLIE_MG3", "1") != "0"
 
     def _mg3_plan(self):
         """work items of pplie_mg3_jt for the current incidence lists (rebuilt when the edge list changes): every (slot, row) list cut
