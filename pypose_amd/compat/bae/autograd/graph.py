@@ -34,7 +34,7 @@ def _same_node(a, b):
 def _match_pgo(Rt, events, E, dr):
     """(event of node1, event of node2, Z^-1 rows) if Rt's history is the relative-pose residual over two gathers, else None"""
     why = route_taken.__setitem__
-    if dr != 6 or len(events) != 2:
+    if dr != 6 or len(events) < 2:
         why("why", f"dr {dr}, {len(events)} gathers")
         return None
     try:
@@ -56,8 +56,11 @@ def _match_pgo(Rt, events, E, dr):
             return None
         leaf1 = _skip(inv.next_functions[0][0])
         bases = [_skip(out.grad_fn) for _, _, out in events]
-        k1 = next((k for k, b in enumerate(bases) if _same_node(b, leaf1)), None)
-        k2 = next((k for k, b in enumerate(bases) if _same_node(b, leaf2)), None)
+        # (the tape also holds the gathers of earlier forward passes that nobody differentiated -- the loss evaluations of the
+        #  LM loop, optimizer.py:659, 670: the two gathers of THIS residual are found by their graph nodes, latest first)
+        order = range(len(bases) - 1, -1, -1)
+        k1 = next((k for k in order if _same_node(bases[k], leaf1)), None)
+        k2 = next((k for k in order if _same_node(bases[k], leaf2)), None)
         if k1 is None or k2 is None or k1 == k2:
             why("why", f"leaves {leaf1 and leaf1.name()} / {leaf2 and leaf2.name()} vs gathers {[b and b.name() for b in bases]}")
             return None

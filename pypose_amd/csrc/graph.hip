@@ -1760,18 +1760,46 @@ mg3_jt_kernel(Mg3Args<T> A, const Mg3Item* __restrict__ items, const int* __rest
     const int nit = row_items[itx.g];
     bool finish = true;
     if (nit > 1) {
-      if (lane < m) xwg_store(part + (size_t)w * 8 + lane, acc);
-      __threadfence();
+      // NO fences: an agent-scope release / acquire pair here is an L2 write-back + invalidate per wave (measured: 205 us for this
+      // kernel with two __threadfence() per chunk against ~15 us for the product itself).  A partial is a TAGGED word
+      // { iteration + 1 | value bits } written and read with single agent-scope accesses (csrc/pcg_persist.hip put_value / get_value):
+      // tag and payload cannot be seen apart, and the last arriver -- which knows that every other wave has ISSUED its stores before
+      // it counted itself -- re-reads a slot until this iteration's tag is there.  `part` is zeroed once per solve by the caller.
+      const unsigned tag = (unsigned)done + 1u;
+      constexpr int NW = sizeof(T) / 4;
+      unsigned long long* pw = reinterpret_cast<unsigned long long*>(part);
+      if (lane < m) {
+        unsigned wv[NW];
+        __builtin_memcpy(wv, &acc, sizeof(T));
+#pragma unroll
+        for (int u = 0; u < NW; ++u) xwg_store(pw + ((size_t)w * 8 + lane) * NW + u, ((unsigned long long)tag << 32) | (unsigned long long)wv[u]);
+      }
       int old = 0;
       if (lane == 0) old = atomicAdd(cnt + itx.g, 1);
       old = __shfl(old, 0, 64);
       finish = old == nit - 1;
       if (finish) {
-        __threadfence();
         const int f = row_first[itx.g];
         T sum = T(0);
-        if (lane < m)
-          for (int t = 0; t < nit; ++t) sum += xwg_load(part + (size_t)(f + t) * 8 + lane);
+        if (lane < m) {
+          for (int t = 0; t < nit; ++t) {
+            unsigned wv[NW];
+            for (long spin = 0; spin < (1L << 22); ++spin) {
+              bool ok = true;
+#pragma unroll
+              for (int u = 0; u < NW; ++u) {
+                const unsigned long long v = xwg_load(pw + ((size_t)(f + t) * 8 + lane) * NW + u);
+                ok = ok && (unsigned)(v >> 32) == tag;
+                wv[u] = (unsigned)v;
+              }
+              if (ok) break;
+              __builtin_amdgcn_s_sleep(1);
+            }
+            T val;
+            __builtin_memcpy(&val, wv, sizeof(T));
+            sum += val;
+          }
+        }
         acc = sum;
         if (lane == 0) cnt[itx.g] = 0;                                  // (the next iteration's launch starts from zero)
       }

@@ -527,7 +527,9 @@ class _GraphedPCG:
             slot_param=(ctypes.c_int * S)(*[pi for pi, _, _ in L.slots]), J=(ctypes.c_void_p * S)(*[J.data_ptr() for _, _, J in L.slots]),
             perm=(ctypes.c_void_p * S)(*[sc.perm.data_ptr() for sc in scs]), ptr=(ctypes.c_void_p * S)(*[sc.ptr.data_ptr() for sc in scs]),
             items=items, row_first=row_first, row_items=row_items, nitems=int(items.shape[0]),
-            part=torch.zeros(items.shape[0] * 8, dtype=self.p.dtype, device=dev), cnt=torch.zeros(base, dtype=torch.int32, device=dev),
+            # (tagged 64-bit words: 8 per item in fp32, 16 in fp64; zeroed per solve -- iteration numbers are the tags)
+            part=torch.zeros(items.shape[0] * 8 * (1 if self.p.dtype == torch.float32 else 2), dtype=torch.int64, device=dev),
+            cnt=torch.zeros(base, dtype=torch.int32, device=dev),
             y=torch.empty_like(self.p), P=P, S=S)
         self._mg3 = (L._scatters, plan)
         return plan
@@ -624,6 +626,9 @@ class _GraphedPCG:
                 self.z.copy_(zv)
                 self.scal2.zero_()
                 self.scal2[0] = self.rho
+                pl = self._mg3_plan()
+                pl["part"].zero_()                                  # (the partials' tags are iteration numbers of THIS solve)
+                pl["cnt"].zero_()
         bn2 = float((bv * bv).sum())
         if bn2 == 0.0:
             return self.x.clone(), 0
