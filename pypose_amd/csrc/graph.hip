@@ -1701,10 +1701,117 @@ template <class T> struct Mg3Args {
 // the row and zeroes the counter -- no second launch, no atomics on the values.
 struct Mg3Item { int g, slot, beg, end; };
 
+// One work item on a group of GS lanes (GS = 64: a wavefront; GS = 16: a quarter -- four SHORT items per wavefront: a point row of a
+// bundle-adjustment problem has ~4 incidences of 2 x 3 blocks, and a whole wave per row made the kernel a queue of 7 x 10^4 waves each
+// living for six dependent memory round trips).  `gl`: lane within the group; `active`: this group has an item.
+template <class T, int GS>
+__device__ __forceinline__ void mg3_item(const Mg3Args<T>& A, const Mg3Item itx, int64_t w, bool active, int gl, const int* __restrict__ row_first,
+                                         const int* __restrict__ row_items, T* part, int* cnt, const T* __restrict__ q,
+                                         const T* __restrict__ p, const T* __restrict__ z, const T* __restrict__ shift,
+                                         T* __restrict__ y, int done, int dr, T& a_pq, T& a_qz, T& a_qmq) {
+  int k = 0;
+  int64_t n = itx.g;
+  while (k + 1 < A.nparams && n >= A.N[k]) { n -= A.N[k]; ++k; }
+  const int m = A.m[k];
+  int subs = 1;
+  while (subs * 2 * m <= GS) subs *= 2;
+  const int sub = gl / m, j = gl - sub * m;
+  T acc = T(0);
+  if (active && sub < subs && itx.slot >= 0) {
+    const T* Js = A.J[itx.slot];
+    const int* perm = A.perm[itx.slot];
+    // two incidences per trip: index -> (J row, q row) is a chain of two memory round trips; the pairs are independent
+    int c = itx.beg + sub;
+    for (; c + subs < itx.end; c += 2 * subs) {
+      const int64_t e0 = perm[c], e1 = perm[c + subs];
+      const T* J0 = Js + e0 * dr * m;
+      const T* J1 = Js + e1 * dr * m;
+      const T* q0 = q + e0 * dr;
+      const T* q1 = q + e1 * dr;
+      T s0 = T(0), s1 = T(0);
+      for (int i = 0; i < dr; ++i) { s0 += J0[i * m + j] * q0[i]; s1 += J1[i * m + j] * q1[i]; }
+      acc += s0 + s1;
+    }
+    if (c < itx.end) {
+      const int64_t e0 = perm[c];
+      const T* J0 = Js + e0 * dr * m;
+      const T* q0 = q + e0 * dr;
+      for (int i = 0; i < dr; ++i) acc += J0[i * m + j] * q0[i];
+    }
+  }
+  for (int off = subs >> 1; off > 0; off >>= 1) acc += __shfl_down(acc, off * m, GS);
+  // ---- the row's sum: directly, or through the last-arriver reduction (whole-wave items only: short rows have one item)
+  bool finish = active;
+  if (GS == 64) {
+    const int nit = row_items[itx.g];
+    if (nit > 1) {
+      // NO fences: an agent-scope release / acquire pair here is an L2 write-back + invalidate per wave (measured: 205 us for this
+      // kernel with two __threadfence() per chunk against ~15 us for the product itself).  A partial is a TAGGED word
+      // { iteration + 1 | value bits } written and read with single agent-scope accesses (csrc/pcg_persist.hip put_value / get_value):
+      // tag and payload cannot be seen apart, and the last arriver -- which knows that every other wave has ISSUED its stores before
+      // it counted itself -- re-reads a slot until this iteration's tag is there.  `part` is zeroed once per solve by the caller.
+      const unsigned tag = (unsigned)done + 1u;
+      constexpr int NW = sizeof(T) / 4;
+      unsigned long long* pw = reinterpret_cast<unsigned long long*>(part);
+      if (gl < m) {
+        unsigned wv[NW];
+        __builtin_memcpy(wv, &acc, sizeof(T));
+#pragma unroll
+        for (int u = 0; u < NW; ++u) xwg_store(pw + ((size_t)w * 8 + gl) * NW + u, ((unsigned long long)tag << 32) | (unsigned long long)wv[u]);
+      }
+      int old = 0;
+      if (gl == 0) old = atomicAdd(cnt + itx.g, 1);
+      old = __shfl(old, 0, 64);
+      finish = old == nit - 1;
+      if (finish) {
+        const int f = row_first[itx.g];
+        T sum = T(0);
+        if (gl < m) {
+          for (int t = 0; t < nit; ++t) {
+            unsigned wv[NW];
+            for (long spin = 0; spin < (1L << 22); ++spin) {
+              bool ok = true;
+#pragma unroll
+              for (int u = 0; u < NW; ++u) {
+                const unsigned long long v = xwg_load(pw + ((size_t)(f + t) * 8 + gl) * NW + u);
+                ok = ok && (unsigned)(v >> 32) == tag;
+                wv[u] = (unsigned)v;
+              }
+              if (ok) break;
+              __builtin_amdgcn_s_sleep(1);
+            }
+            T val;
+            __builtin_memcpy(&val, wv, sizeof(T));
+            sum += val;
+          }
+        }
+        acc = sum;
+        if (gl == 0) cnt[itx.g] = 0;                                    // (the next iteration's launch starts from zero)
+      }
+    }
+  }
+  const int64_t e0 = A.off[k] + n * m;
+  const bool own = finish && gl < m;
+  T yj = T(0), pj = T(0), zj = T(0);
+  if (own) {
+    pj = p[e0 + gl];
+    zj = z[e0 + gl];
+    yj = acc + shift[e0 + gl] * pj;
+    y[e0 + gl] = yj;
+  }
+  T bq = T(0);
+  for (int l = 0; l < 8; ++l) {
+    const T yl = __shfl(yj, l, GS);
+    if (own && l < m) bq += A.Binv[k][(n * m + gl) * m + l] * yl;
+  }
+  if (own) { a_pq += yj * pj; a_qz += yj * zj; a_qmq += yj * bq; }
+}
+
+// items [0, nshort): rows that are ONE item of at most 16 incidences (in groups of four per wavefront), then the others (a wavefront each)
 template <class T>
 __global__ void __launch_bounds__(256)
 mg3_jt_kernel(Mg3Args<T> A, const Mg3Item* __restrict__ items, const int* __restrict__ row_first, const int* __restrict__ row_items,
-              int64_t nitems, T* part, int* cnt, const T* __restrict__ q, const T* __restrict__ p, const T* __restrict__ z,
+              int64_t nitems, int64_t nshort, T* part, int* cnt, const T* __restrict__ q, const T* __restrict__ p, const T* __restrict__ z,
               const T* __restrict__ shift, T* __restrict__ y, T* scal, T* __restrict__ rr_hist, int* it, int cap, int dr) {
   const int done = it[0];
   const int a = done & 1;
@@ -1722,104 +1829,19 @@ mg3_jt_kernel(Mg3Args<T> A, const Mg3Item* __restrict__ items, const int* __rest
   const int lane = threadIdx.x & 63;
   const int64_t wave = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * 256) >> 6;
+  const int64_t wshort = (nshort + 3) / 4;                            // waves of four short items
+  const int64_t wtotal = wshort + (nitems - nshort);
   T a_pq = T(0), a_qz = T(0), a_qmq = T(0);
-  for (int64_t w = wave; w < nitems; w += nwaves) {
-    const Mg3Item itx = items[w];
-    int k = 0;
-    int64_t n = itx.g;
-    while (k + 1 < A.nparams && n >= A.N[k]) { n -= A.N[k]; ++k; }
-    const int m = A.m[k];
-    int subs = 1;
-    while (subs * 2 * m <= 64) subs *= 2;
-    const int sub = lane / m, j = lane - sub * m;
-    T acc = T(0);
-    if (sub < subs && itx.slot >= 0) {
-      const T* Js = A.J[itx.slot];
-      const int* perm = A.perm[itx.slot];
-      // two incidences per trip: index -> (J row, q row) is a chain of two memory round trips; the pairs are independent
-      int c = itx.beg + sub;
-      for (; c + subs < itx.end; c += 2 * subs) {
-        const int64_t e0 = perm[c], e1 = perm[c + subs];
-        const T* J0 = Js + e0 * dr * m;
-        const T* J1 = Js + e1 * dr * m;
-        const T* q0 = q + e0 * dr;
-        const T* q1 = q + e1 * dr;
-        T s0 = T(0), s1 = T(0);
-        for (int i = 0; i < dr; ++i) { s0 += J0[i * m + j] * q0[i]; s1 += J1[i * m + j] * q1[i]; }
-        acc += s0 + s1;
-      }
-      if (c < itx.end) {
-        const int64_t e0 = perm[c];
-        const T* J0 = Js + e0 * dr * m;
-        const T* q0 = q + e0 * dr;
-        for (int i = 0; i < dr; ++i) acc += J0[i * m + j] * q0[i];
-      }
+  for (int64_t w = wave; w < wtotal; w += nwaves) {
+    if (w < wshort) {                                                   // (wave-uniform)
+      const int64_t idx = w * 4 + (lane >> 4);
+      const bool active = idx < nshort;
+      const Mg3Item itx = items[active ? idx : 0];
+      mg3_item<T, 16>(A, itx, idx, active, lane & 15, row_first, row_items, part, cnt, q, p, z, shift, y, done, dr, a_pq, a_qz, a_qmq);
+    } else {
+      const int64_t idx = nshort + (w - wshort);
+      mg3_item<T, 64>(A, items[idx], idx, true, lane, row_first, row_items, part, cnt, q, p, z, shift, y, done, dr, a_pq, a_qz, a_qmq);
     }
-    for (int off = subs >> 1; off > 0; off >>= 1) acc += __shfl_down(acc, off * m, 64);
-    // ---- the row's sum: directly, or through the last-arriver reduction
-    const int nit = row_items[itx.g];
-    bool finish = true;
-    if (nit > 1) {
-      // NO fences: an agent-scope release / acquire pair here is an L2 write-back + invalidate per wave (measured: 205 us for this
-      // kernel with two __threadfence() per chunk against ~15 us for the product itself).  A partial is a TAGGED word
-      // { iteration + 1 | value bits } written and read with single agent-scope accesses (csrc/pcg_persist.hip put_value / get_value):
-      // tag and payload cannot be seen apart, and the last arriver -- which knows that every other wave has ISSUED its stores before
-      // it counted itself -- re-reads a slot until this iteration's tag is there.  `part` is zeroed once per solve by the caller.
-      const unsigned tag = (unsigned)done + 1u;
-      constexpr int NW = sizeof(T) / 4;
-      unsigned long long* pw = reinterpret_cast<unsigned long long*>(part);
-      if (lane < m) {
-        unsigned wv[NW];
-        __builtin_memcpy(wv, &acc, sizeof(T));
-#pragma unroll
-        for (int u = 0; u < NW; ++u) xwg_store(pw + ((size_t)w * 8 + lane) * NW + u, ((unsigned long long)tag << 32) | (unsigned long long)wv[u]);
-      }
-      int old = 0;
-      if (lane == 0) old = atomicAdd(cnt + itx.g, 1);
-      old = __shfl(old, 0, 64);
-      finish = old == nit - 1;
-      if (finish) {
-        const int f = row_first[itx.g];
-        T sum = T(0);
-        if (lane < m) {
-          for (int t = 0; t < nit; ++t) {
-            unsigned wv[NW];
-            for (long spin = 0; spin < (1L << 22); ++spin) {
-              bool ok = true;
-#pragma unroll
-              for (int u = 0; u < NW; ++u) {
-                const unsigned long long v = xwg_load(pw + ((size_t)(f + t) * 8 + lane) * NW + u);
-                ok = ok && (unsigned)(v >> 32) == tag;
-                wv[u] = (unsigned)v;
-              }
-              if (ok) break;
-              __builtin_amdgcn_s_sleep(1);
-            }
-            T val;
-            __builtin_memcpy(&val, wv, sizeof(T));
-            sum += val;
-          }
-        }
-        acc = sum;
-        if (lane == 0) cnt[itx.g] = 0;                                  // (the next iteration's launch starts from zero)
-      }
-    }
-    if (!finish) continue;                                              // (wave-uniform)
-    const int64_t e0 = A.off[k] + n * m;
-    const bool own = lane < m;
-    T yj = T(0), pj = T(0), zj = T(0);
-    if (own) {
-      pj = p[e0 + lane];
-      zj = z[e0 + lane];
-      yj = acc + shift[e0 + lane] * pj;
-      y[e0 + lane] = yj;
-    }
-    T bq = T(0);
-    for (int l = 0; l < 8; ++l) {
-      const T yl = __shfl(yj, l, 64);
-      if (own && l < m) bq += A.Binv[k][(n * m + lane) * m + l] * yl;
-    }
-    if (own) { a_pq += yj * pj; a_qz += yj * zj; a_qmq += yj * bq; }
   }
   const T s1 = block_sum(a_pq), s2 = block_sum(a_qz), s3 = block_sum(a_qmq);
   if (threadIdx.x == 0) {
@@ -1896,18 +1918,18 @@ int mg3_fill(Mg3Args<T>& A, int nparams, const int64_t* N, const int64_t* off, c
 template <class T>
 int mg3_jt(int nparams, const int64_t* N, const int64_t* off, const int* m, const void* const* Binv, int nslots, const int* slot_param,
            const void* const* J, const void* const* perm, const void* const* ptr, const void* items, const void* row_first,
-           const void* row_items, int64_t nitems, void* part, void* cnt, const void* q, const void* p, const void* z,
+           const void* row_items, int64_t nitems, int64_t nshort, void* part, void* cnt, const void* q, const void* p, const void* z,
            const void* shift, void* y, void* scal, void* rr_hist, void* it, int cap, int dr, void* stream) {
   Mg3Args<T> A;
   const int rc = mg3_fill<T>(A, nparams, N, off, m, Binv, nslots, slot_param, J, perm, ptr);
   if (rc != PPLIE_OK) return rc;
   if (!items || !row_first || !row_items || !part || !cnt || !q || !p || !z || !shift || !y || !scal || !rr_hist || !it || dr <= 0 || dr > 8 ||
-      nitems < 0)
+      nitems < 0 || nshort < 0 || nshort > nitems)
     return PPLIE_EBADARG;
   if (nitems == 0) return PPLIE_OK;
-  const int64_t blocks = (nitems + 3) / 4;
+  const int64_t blocks = ((nshort + 3) / 4 + (nitems - nshort) + 3) / 4;
   hipLaunchKernelGGL((mg3_jt_kernel<T>), dim3((int)(blocks < (1 << 20) ? blocks : (1 << 20))), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), A,
-                     (const Mg3Item*)items, (const int*)row_first, (const int*)row_items, nitems, (T*)part, (int*)cnt, (const T*)q,
+                     (const Mg3Item*)items, (const int*)row_first, (const int*)row_items, nitems, nshort, (T*)part, (int*)cnt, (const T*)q,
                      (const T*)p, (const T*)z, (const T*)shift, (T*)y, (T*)scal, (T*)rr_hist, (int*)it, cap, dr);
   return hipGetLastError() == hipSuccess ? PPLIE_OK : PPLIE_ELAUNCH;
 }
@@ -1934,10 +1956,10 @@ int mg3_step(int nparams, const int64_t* N, const int64_t* off, const int* m, co
 #define PPLIE_MG3(SFX, T)                                                                                                          \
   extern "C" int pplie_mg3_jt_##SFX(int nparams, const int64_t* N, const int64_t* off, const int* m, const void* const* Binv, int nslots, \
                                     const int* slot_param, const void* const* J, const void* const* perm, const void* const* ptr,  \
-                                    const void* items, const void* row_first, const void* row_items, int64_t nitems, void* part,   \
-                                    void* cnt, const void* q, const void* p, const void* z, const void* shift, void* y, void* scal, \
-                                    void* rr_hist, void* it, int cap, int dr, void* stream) {                                      \
-    return pplie::mg3_jt<T>(nparams, N, off, m, Binv, nslots, slot_param, J, perm, ptr, items, row_first, row_items, nitems, part, cnt, \
+                                    const void* items, const void* row_first, const void* row_items, int64_t nitems,               \
+                                    int64_t nshort, void* part, void* cnt, const void* q, const void* p, const void* z,           \
+                                    const void* shift, void* y, void* scal, void* rr_hist, void* it, int cap, int dr, void* stream) { \
+    return pplie::mg3_jt<T>(nparams, N, off, m, Binv, nslots, slot_param, J, perm, ptr, items, row_first, row_items, nitems, nshort, part, cnt, \
                             q, p, z, shift, y, scal, rr_hist, it, cap, dr, stream);                                                \
   }                                                                                                                                \
   extern "C" int pplie_mg3_step_##SFX(int nparams, const int64_t* N, const int64_t* off, const int* m, const void* const* Binv, void* x, \
