@@ -1716,6 +1716,23 @@ __device__ __forceinline__ void mg3_item(const Mg3Args<T>& A, const Mg3Item itx,
   int subs = 1;
   while (subs * 2 * m <= GS) subs *= 2;
   const int sub = gl / m, j = gl - sub * m;
+  // what the row's finish needs and the incidence walk does not: issued HERE, so that these round trips overlap the walk's
+  // index -> (J, q) chain instead of following it (a wave of this kernel lives for its dependent loads, not for its arithmetic)
+  const int64_t e0 = A.off[k] + n * m;
+  const bool low = active && gl < m;
+  T pj = T(0), zj = T(0), shj = T(0), brow[8];
+#pragma unroll
+  for (int l = 0; l < 8; ++l) brow[l] = T(0);
+  if (low) {
+    pj = p[e0 + gl];
+    zj = z[e0 + gl];
+    shj = shift[e0 + gl];
+    const T* B = A.Binv[k] + (n * m + gl) * m;
+#pragma unroll
+    for (int l = 0; l < 8; ++l)
+      if (l < m) brow[l] = B[l];
+  }
+  const int nit = GS == 64 ? row_items[itx.g] : 1;
   T acc = T(0);
   if (active && sub < subs && itx.slot >= 0) {
     const T* Js = A.J[itx.slot];
@@ -1743,7 +1760,6 @@ __device__ __forceinline__ void mg3_item(const Mg3Args<T>& A, const Mg3Item itx,
   // ---- the row's sum: directly, or through the last-arriver reduction (whole-wave items only: short rows have one item)
   bool finish = active;
   if (GS == 64) {
-    const int nit = row_items[itx.g];
     if (nit > 1) {
       // NO fences: an agent-scope release / acquire pair here is an L2 write-back + invalidate per wave (measured: 205 us for this
       // kernel with two __threadfence() per chunk against ~15 us for the product itself).  A partial is a TAGGED word
@@ -1790,20 +1806,15 @@ __device__ __forceinline__ void mg3_item(const Mg3Args<T>& A, const Mg3Item itx,
       }
     }
   }
-  const int64_t e0 = A.off[k] + n * m;
   const bool own = finish && gl < m;
-  T yj = T(0), pj = T(0), zj = T(0);
+  T yj = T(0);
   if (own) {
-    pj = p[e0 + gl];
-    zj = z[e0 + gl];
-    yj = acc + shift[e0 + gl] * pj;
+    yj = acc + shj * pj;
     y[e0 + gl] = yj;
   }
   T bq = T(0);
-  for (int l = 0; l < 8; ++l) {
-    const T yl = __shfl(yj, l, GS);
-    if (own && l < m) bq += A.Binv[k][(n * m + gl) * m + l] * yl;
-  }
+#pragma unroll
+  for (int l = 0; l < 8; ++l) bq += brow[l] * __shfl(yj, l, GS);      // (brow = 0 beyond m and on lanes that do not own a component)
   if (own) { a_pq += yj * pj; a_qz += yj * zj; a_qmq += yj * bq; }
 }
 

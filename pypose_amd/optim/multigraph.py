@@ -41,7 +41,7 @@ _FLAT_SIG = [ctypes.c_int] + [ctypes.c_void_p] * 8 + [ctypes.c_int, ctypes.c_int
 _MG3_JT_SIG = [ctypes.c_int] + [ctypes.c_void_p] * 4 + [ctypes.c_int] + [ctypes.c_void_p] * 7 + [ctypes.c_int64] * 2 + [ctypes.c_void_p] * 10 \
     + [ctypes.c_int, ctypes.c_int, ctypes.c_void_p]                                                                   # pplie_mg3_jt
 _MG3_STEP_SIG = [ctypes.c_int] + [ctypes.c_void_p] * 11 + [ctypes.c_void_p]                                           # pplie_mg3_step
-MG3_CHUNK = 128            # PPLIE_MG3_CHUNK: incidences of one work item of pplie_mg3_jt
+MG3_CHUNK = int(__import__('os').environ.get('PPLIE_MG3_CHUNK', '128'))     # PPLIE_MG3_CHUNK: incidences of one work item of pplie_mg3_jt
 
 
 class _Scatter:
