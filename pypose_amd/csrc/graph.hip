@@ -1818,11 +1818,12 @@ __device__ __forceinline__ void mg3_item(const Mg3Args<T>& A, const Mg3Item itx,
   if (own) { a_pq += yj * pj; a_qz += yj * zj; a_qmq += yj * bq; }
 }
 
-// items [0, nshort): rows that are ONE item of at most 16 incidences (in groups of four per wavefront), then the others (a wavefront each)
+// items [0, ntiny): rows of width <= 4 that are ONE item of at most 8 incidences (eight per wavefront); [ntiny, nshort): rows that are
+// ONE item of at most 16 incidences (four per wavefront); then the others (a wavefront each)
 template <class T>
 __global__ void __launch_bounds__(256)
 mg3_jt_kernel(Mg3Args<T> A, const Mg3Item* __restrict__ items, const int* __restrict__ row_first, const int* __restrict__ row_items,
-              int64_t nitems, int64_t nshort, T* part, int* cnt, const T* __restrict__ q, const T* __restrict__ p, const T* __restrict__ z,
+              int64_t nitems, int64_t nshort, int64_t ntiny, T* part, int* cnt, const T* __restrict__ q, const T* __restrict__ p, const T* __restrict__ z,
               const T* __restrict__ shift, T* __restrict__ y, T* scal, T* __restrict__ rr_hist, int* it, int cap, int dr) {
   const int done = it[0];
   const int a = done & 1;
@@ -1840,12 +1841,18 @@ mg3_jt_kernel(Mg3Args<T> A, const Mg3Item* __restrict__ items, const int* __rest
   const int lane = threadIdx.x & 63;
   const int64_t wave = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * 256) >> 6;
-  const int64_t wshort = (nshort + 3) / 4;                            // waves of four short items
+  const int64_t wtiny = (ntiny + 7) / 8;                              // waves of eight tiny items
+  const int64_t wshort = wtiny + (nshort - ntiny + 3) / 4;            // ... then waves of four short items
   const int64_t wtotal = wshort + (nitems - nshort);
   T a_pq = T(0), a_qz = T(0), a_qmq = T(0);
   for (int64_t w = wave; w < wtotal; w += nwaves) {
-    if (w < wshort) {                                                   // (wave-uniform)
-      const int64_t idx = w * 4 + (lane >> 4);
+    if (w < wtiny) {                                                    // (wave-uniform)
+      const int64_t idx = w * 8 + (lane >> 3);
+      const bool active = idx < ntiny;
+      const Mg3Item itx = items[active ? idx : 0];
+      mg3_item<T, 8>(A, itx, idx, active, lane & 7, row_first, row_items, part, cnt, q, p, z, shift, y, done, dr, a_pq, a_qz, a_qmq);
+    } else if (w < wshort) {
+      const int64_t idx = ntiny + (w - wtiny) * 4 + (lane >> 4);
       const bool active = idx < nshort;
       const Mg3Item itx = items[active ? idx : 0];
       mg3_item<T, 16>(A, itx, idx, active, lane & 15, row_first, row_items, part, cnt, q, p, z, shift, y, done, dr, a_pq, a_qz, a_qmq);
@@ -1929,18 +1936,18 @@ int mg3_fill(Mg3Args<T>& A, int nparams, const int64_t* N, const int64_t* off, c
 template <class T>
 int mg3_jt(int nparams, const int64_t* N, const int64_t* off, const int* m, const void* const* Binv, int nslots, const int* slot_param,
            const void* const* J, const void* const* perm, const void* const* ptr, const void* items, const void* row_first,
-           const void* row_items, int64_t nitems, int64_t nshort, void* part, void* cnt, const void* q, const void* p, const void* z,
-           const void* shift, void* y, void* scal, void* rr_hist, void* it, int cap, int dr, void* stream) {
+           const void* row_items, int64_t nitems, int64_t nshort, int64_t ntiny, void* part, void* cnt, const void* q, const void* p,
+           const void* z, const void* shift, void* y, void* scal, void* rr_hist, void* it, int cap, int dr, void* stream) {
   Mg3Args<T> A;
   const int rc = mg3_fill<T>(A, nparams, N, off, m, Binv, nslots, slot_param, J, perm, ptr);
   if (rc != PPLIE_OK) return rc;
   if (!items || !row_first || !row_items || !part || !cnt || !q || !p || !z || !shift || !y || !scal || !rr_hist || !it || dr <= 0 || dr > 8 ||
-      nitems < 0 || nshort < 0 || nshort > nitems)
+      nitems < 0 || nshort < 0 || nshort > nitems || ntiny < 0 || ntiny > nshort)
     return PPLIE_EBADARG;
   if (nitems == 0) return PPLIE_OK;
-  const int64_t blocks = ((nshort + 3) / 4 + (nitems - nshort) + 3) / 4;
+  const int64_t blocks = ((ntiny + 7) / 8 + (nshort - ntiny + 3) / 4 + (nitems - nshort) + 3) / 4;
   hipLaunchKernelGGL((mg3_jt_kernel<T>), dim3((int)(blocks < (1 << 20) ? blocks : (1 << 20))), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), A,
-                     (const Mg3Item*)items, (const int*)row_first, (const int*)row_items, nitems, nshort, (T*)part, (int*)cnt, (const T*)q,
+                     (const Mg3Item*)items, (const int*)row_first, (const int*)row_items, nitems, nshort, ntiny, (T*)part, (int*)cnt, (const T*)q,
                      (const T*)p, (const T*)z, (const T*)shift, (T*)y, (T*)scal, (T*)rr_hist, (int*)it, cap, dr);
   return hipGetLastError() == hipSuccess ? PPLIE_OK : PPLIE_ELAUNCH;
 }
@@ -1968,9 +1975,10 @@ int mg3_step(int nparams, const int64_t* N, const int64_t* off, const int* m, co
   extern "C" int pplie_mg3_jt_##SFX(int nparams, const int64_t* N, const int64_t* off, const int* m, const void* const* Binv, int nslots, \
                                     const int* slot_param, const void* const* J, const void* const* perm, const void* const* ptr,  \
                                     const void* items, const void* row_first, const void* row_items, int64_t nitems,               \
-                                    int64_t nshort, void* part, void* cnt, const void* q, const void* p, const void* z,           \
-                                    const void* shift, void* y, void* scal, void* rr_hist, void* it, int cap, int dr, void* stream) { \
-    return pplie::mg3_jt<T>(nparams, N, off, m, Binv, nslots, slot_param, J, perm, ptr, items, row_first, row_items, nitems, nshort, part, cnt, \
+                                    int64_t nshort, int64_t ntiny, void* part, void* cnt, const void* q, const void* p,           \
+                                    const void* z, const void* shift, void* y, void* scal, void* rr_hist, void* it, int cap, int dr, \
+                                    void* stream) {                                                                                \
+    return pplie::mg3_jt<T>(nparams, N, off, m, Binv, nslots, slot_param, J, perm, ptr, items, row_first, row_items, nitems, nshort, ntiny, part, cnt, \
                             q, p, z, shift, y, scal, rr_hist, it, cap, dr, stream);                                                \
   }                                                                                                                                \
   extern "C" int pplie_mg3_step_##SFX(int nparams, const int64_t* N, const int64_t* off, const int* m, const void* const* Binv, void* x, \

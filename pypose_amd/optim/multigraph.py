@@ -38,7 +38,7 @@ _MGS_SIG = [ctypes.c_void_p] * 5 + [ctypes.c_int64, ctypes.c_int, ctypes.c_int, 
 _BMV_SIG = [ctypes.c_void_p] * 3 + [ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]
 _STAGE_SIG = [ctypes.c_int] + [ctypes.c_void_p] * 10 + [ctypes.c_int, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]   # pplie_pcg_stage
 _FLAT_SIG = [ctypes.c_int] + [ctypes.c_void_p] * 8 + [ctypes.c_int, ctypes.c_int64, ctypes.c_void_p]                    # pplie_pcg_flat
-_MG3_JT_SIG = [ctypes.c_int] + [ctypes.c_void_p] * 4 + [ctypes.c_int] + [ctypes.c_void_p] * 7 + [ctypes.c_int64] * 2 + [ctypes.c_void_p] * 10 \
+_MG3_JT_SIG = [ctypes.c_int] + [ctypes.c_void_p] * 4 + [ctypes.c_int] + [ctypes.c_void_p] * 7 + [ctypes.c_int64] * 3 + [ctypes.c_void_p] * 10 \
     + [ctypes.c_int, ctypes.c_int, ctypes.c_void_p]                                                                   # pplie_mg3_jt
 _MG3_STEP_SIG = [ctypes.c_int] + [ctypes.c_void_p] * 11 + [ctypes.c_void_p]                                           # pplie_mg3_step
 MG3_CHUNK = int(__import__('os').environ.get('PPLIE_MG3_CHUNK', '128'))     # PPLIE_MG3_CHUNK: incidences of one work item of pplie_mg3_jt
@@ -514,10 +514,14 @@ class _GraphedPCG:
         # (row, slot, chunk) so that a row's items are contiguous
         row_items = torch.bincount(g, minlength=base)
         short = (row_items[g] == 1) & (en - bg <= 16)
+        bounds = torch.tensor([0] + list(L.N), device=dev).cumsum(0)
+        width = torch.tensor(list(L.m), device=dev)[torch.searchsorted(bounds, g, right=True) - 1]
+        tiny = short & (en - bg <= 8) & (width <= 4)                   # eight of these share a wavefront
         key = (g * (len(L.slots) + 1) + (sl + 1)) * (1 << 22) + (bg // MG3_CHUNK) % (1 << 22)
-        order = torch.argsort(key + (~short).long() * (1 << 62), stable=True)
+        klass = torch.where(tiny, 0, torch.where(short, 1, 2))
+        order = torch.argsort(key + klass * (1 << 61), stable=True)
         g, sl, bg, en = g[order], sl[order], bg[order], en[order]
-        nshort = int(short.sum())
+        nshort, ntiny = int(short.sum()), int(tiny.sum())
         items = torch.stack([g, sl, bg, en], 1).to(torch.int32).contiguous()
         first = torch.full((base,), -1, dtype=torch.int64, device=dev)
         pos = torch.arange(g.numel(), device=dev)
@@ -535,7 +539,7 @@ class _GraphedPCG:
             Binv=(ctypes.c_void_p * P)(*[b.data_ptr() for b in self.Binv]),
             slot_param=(ctypes.c_int * S)(*[pi for pi, _, _ in L.slots]), J=(ctypes.c_void_p * S)(*[J.data_ptr() for _, _, J in L.slots]),
             perm=(ctypes.c_void_p * S)(*[sc.perm.data_ptr() for sc in scs]), ptr=(ctypes.c_void_p * S)(*[sc.ptr.data_ptr() for sc in scs]),
-            items=items, row_first=row_first, row_items=row_items, nitems=int(items.shape[0]), nshort=nshort,
+            items=items, row_first=row_first, row_items=row_items, nitems=int(items.shape[0]), nshort=nshort, ntiny=ntiny,
             # (tagged 64-bit words: 8 per item in fp32, 16 in fp64; zeroed per solve -- iteration numbers are the tags)
             part=torch.zeros(items.shape[0] * 8 * (1 if self.p.dtype == torch.float32 else 2), dtype=torch.int64, device=dev),
             cnt=torch.zeros(base, dtype=torch.int32, device=dev),
@@ -562,7 +566,7 @@ class _GraphedPCG:
                 ms, L.W.data_ptr() if L.W is not None else None, q.data_ptr(), L.E, L.dr, st), "pplie_mg_jtimes")
             _C.check(lib.symbol("pplie_mg3_jt" + sfx, _MG3_JT_SIG)(
                 pl["P"], pl["N"], pl["off"], pl["m"], pl["Binv"], S, pl["slot_param"], pl["J"], pl["perm"], pl["ptr"],
-                pl["items"].data_ptr(), pl["row_first"].data_ptr(), pl["row_items"].data_ptr(), pl["nitems"], pl["nshort"], pl["part"].data_ptr(),
+                pl["items"].data_ptr(), pl["row_first"].data_ptr(), pl["row_items"].data_ptr(), pl["nitems"], pl["nshort"], pl["ntiny"], pl["part"].data_ptr(),
                 pl["cnt"].data_ptr(), q.data_ptr(), self.p.data_ptr(), self.z.data_ptr(), self.shift_flat.data_ptr(), pl["y"].data_ptr(),
                 self.scal2.data_ptr(), self.rr_hist.data_ptr(), self.it.data_ptr(), self.cap, L.dr, st), "pplie_mg3_jt")
             _C.check(lib.symbol("pplie_mg3_step" + sfx, _MG3_STEP_SIG)(
