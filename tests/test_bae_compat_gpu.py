@@ -144,7 +144,7 @@ def test_reference_ba_example_model_on_the_device():
             assert g == pytest.approx(w, rel=1e-6, abs=1e-15), (optim, got, want)
 
 
-@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-10), (torch.float32, 2e-5)])
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-10), (torch.float32, 1e-4)])
 def test_jacobian_of_the_relative_pose_residual_takes_the_kernel_route(dtype, tol, monkeypatch):
     """bae.autograd.graph.jacobian on the reference's OWN (un-activated) ops: the history of
     (rel.Inv() @ n1.Inv() @ n2).Log() is recognised and the blocks come from pplie_pgo_linearize -- equal to the six autograd
