@@ -249,6 +249,71 @@ __device__ __forceinline__ void gather_rows(SH& sh, int par, const u64* part, un
   }
 }
 
+// PAIRS: two fp32 partial sums per 64-bit word, each carrying a 2-bit tag in the two LOWEST MANTISSA BITS (a relative perturbation of
+// 2.4e-7 of a dot product whose own summation error is larger).  Two bits are enough because the tables alternate with the
+// iteration's parity and every workgroup rewrites its row at every use of a table: what a reader can find in a slot is the value
+// of THIS use or of the PREVIOUS use of the same table, never an older one -- consecutive uses carry tags 1, 2, 3, 1, ... and 0 is
+// "never written" (the tables are zeroed per solve).  Halves the words of the wide exchange (17 quantities -> 9 words): measured
+// per-exchange cost is ~2.1 us + 0.19 us per polled word at 160 workgroups.
+__device__ __forceinline__ unsigned pair_tag(int use) { return (unsigned)(use % 3) + 1u; }
+__device__ __forceinline__ u64 pack_pair(float a, float b, unsigned t2) {
+  const unsigned ua = (__float_as_uint(a) & ~3u) | t2, ub = (__float_as_uint(b) & ~3u) | t2;
+  return ((u64)ub << 32) | (u64)ua;
+}
+__device__ __forceinline__ bool unpack_pair(u64 w, unsigned t2, float& a, float& b) {
+  const unsigned ua = (unsigned)w, ub = (unsigned)(w >> 32);
+  a = __uint_as_float(ua & ~3u);
+  b = __uint_as_float(ub & ~3u);
+  return (ua & 3u) == t2 && (ub & 3u) == t2;
+}
+// word j of a row = quantities (2 j, 2 j + 1); rows of SLOTS words (fp32: one word per slot)
+template <int NQ, class SH, int SLOTS>
+__device__ __forceinline__ void put_pairs(const float* vals_lds, u64* row, unsigned t2) {
+  constexpr int NP = (NQ + 1) / 2;
+  if (threadIdx.x < NP) {
+    const float a = vals_lds[2 * threadIdx.x], b = 2 * threadIdx.x + 1 < NQ ? vals_lds[2 * threadIdx.x + 1] : 0.f;
+    xwg_store(row + threadIdx.x, pack_pair(a, b, t2));
+  }
+}
+template <int NQ, class SH, int SLOTS>
+__device__ __forceinline__ void gather_pairs(SH& sh, int par, const u64* part, unsigned t2, int first, int stride, int count, int rows_per_table) {
+  constexpr int NP = (NQ + 1) / 2, RW = SLOTS, LD = 3;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (w < NP) {
+    const u64* tab = part + (size_t)par * rows_per_table * RW;
+    float s0 = 0.f, s1 = 0.f;
+    bool all = true;
+    for (int base = 0; base < count; base += 64 * LD) {            // (LD rows per lane and round: 192 cover the usual grids of 160 - 192)
+      float v0[LD], v1[LD];
+      bool done[LD];
+#pragma unroll
+      for (int q = 0; q < LD; ++q) { done[q] = base + lane + 64 * q >= count; v0[q] = 0.f; v1[q] = 0.f; }
+      for (long spin = 0; spin < (1L << 20); ++spin) {
+        bool pending = false;
+#pragma unroll
+        for (int q = 0; q < LD; ++q) {
+          if (!done[q]) {
+            float a, b;
+            if (unpack_pair(xwg_load(tab + (size_t)(first + stride * (base + lane + 64 * q)) * RW + w), t2, a, b)) { v0[q] = a; v1[q] = b; done[q] = true; }
+            else pending = true;
+          }
+        }
+        if (!pending) break;
+        __builtin_amdgcn_s_sleep(1);
+      }
+#pragma unroll
+      for (int q = 0; q < LD; ++q) { all = all && done[q]; s0 += v0[q]; s1 += v1[q]; }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { s0 += __shfl_xor(s0, off, 64); s1 += __shfl_xor(s1, off, 64); }
+    if (lane == 0) {
+      sh.total[par][2 * w] = s0;
+      if (2 * w + 1 < NQ) sh.total[par][2 * w + 1] = s1;
+    }
+    if (!__all(all) && lane == 0) sh.bad[par] = 1;
+  }
+}
+
 // TWO-LEVEL all-gather (the wide exchange of the two-level preconditioner: 5 + 2 M quantities).  Every workgroup polling every
 // workgroup's row is grid x grid x NQ tagged loads per iteration -- all of them served by the memory side, the L2s of the eight
 // XCDs are not coherent with each other: measured 7.4 us per exchange with 17 quantities at 256 workgroups against 3.1 us with 5.
@@ -260,9 +325,35 @@ constexpr int kHierGroups = 8;
 constexpr int kHierMinGrid = 224;        // grids from here on exchange in two levels
 constexpr int kHierRows = kPersistGridMax + kHierGroups;
 template <class T, int NQ, class SH, int SLOTS>
-__device__ __forceinline__ void exchange_two_level(SH& sh, int par, u64* part, unsigned tag) {
+__device__ __forceinline__ void exchange_two_level(SH& sh, int par, u64* part, unsigned tag, int use) {
   constexpr int NW = sizeof(T) / 4, RW = SLOTS * NW, WV = kPersistBlock / 64;
   const int G = (int)gridDim.x < kHierGroups ? (int)gridDim.x : kHierGroups;
+  if constexpr (sizeof(T) == 4) {
+    // fp32: packed pairs (see above); `use` = how many times this table has been used before in this solve
+    __shared__ float mine[NQ + 1];
+    const unsigned t2 = pair_tag(use);
+    if (threadIdx.x < NQ) {
+      float sum = 0.f;
+#pragma unroll
+      for (int ww = 0; ww < WV; ++ww) sum += sh.wave_part[par][threadIdx.x][ww];
+      mine[threadIdx.x] = sum;
+    }
+    __syncthreads();
+    put_pairs<NQ, SH, SLOTS>(mine, part + ((size_t)par * kHierRows + blockIdx.x) * RW, t2);
+    if ((int)gridDim.x < kHierMinGrid) {
+      gather_pairs<NQ, SH, SLOTS>(sh, par, part, t2, 0, 1, (int)gridDim.x, kHierRows);
+      return;
+    }
+    if ((int)blockIdx.x < G) {
+      const int members = ((int)gridDim.x - (int)blockIdx.x + G - 1) / G;
+      gather_pairs<NQ, SH, SLOTS>(sh, par, part, t2, (int)blockIdx.x, G, members, kHierRows);
+      __syncthreads();
+      put_pairs<NQ, SH, SLOTS>(&sh.total[par][0], part + ((size_t)par * kHierRows + kPersistGridMax + blockIdx.x) * RW, t2);
+      __syncthreads();
+    }
+    gather_pairs<NQ, SH, SLOTS>(sh, par, part, t2, kPersistGridMax, 1, G, kHierRows);
+    return;
+  }
   // (caller: post_wave_sums + __syncthreads done)  own row
   if (threadIdx.x < NQ) {
     T sum = T(0);
@@ -589,7 +680,7 @@ pcg_ghost_kernel(const int* __restrict__ ptr, const int* __restrict__ slot, cons
     wave_comp_sums(act ? shift[n * M + i] : T(0), 1, 0);
     wave_comp_sums(re, 1, M);
     __syncthreads();
-    exchange_two_level<T, 2 * M, SH, SLOTS>(sh, 1, part, 0x7fffffffu);
+    exchange_two_level<T, 2 * M, SH, SLOTS>(sh, 1, part, 0x7fffffffu, 0);         // (use 0 of table 1)
     __syncthreads();
     if (threadIdx.x < M) {
       const T e = sh.total[1][threadIdx.x];
@@ -670,7 +761,7 @@ pcg_ghost_kernel(const int* __restrict__ ptr, const int* __restrict__ slot, cons
       gok[l] = true;
       gq[l] = gact[l] ? get_value<T>(qtag + (size_t)par * NM + ((size_t)gnode[l] * M + i) * NW, tag, gok[l]) : T(0);
     }
-    if constexpr (CZ) exchange_two_level<T, NQ, SH, SLOTS>(sh, par, part, tag);
+    if constexpr (CZ) exchange_two_level<T, NQ, SH, SLOTS>(sh, par, part, tag, (k >> 1) + par);   // (table 1's use 0 was the set-up exchange)
     else gather_rows<T, NQ, SH, SLOTS>(sh, par, part, tag);
     PPLIE_TICK(2)
     bool stale = false;
