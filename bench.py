@@ -468,7 +468,9 @@ def pgo_lm_rate(dev, nodes=10_000, edges=40_000, steps=3, reps=5, with_static=Tr
                 "us_per_lm_step": dt * 1e6, "mean_pcg_iterations": its_mean,
                 "us_per_pcg_iteration_incl_step_overheads": dt * 1e6 / max(its_mean, 1.0),
                 "exchange_floor_us": [0.40, 0.57], "floor_source": "profiles/r03/pingpong.log (one tagged-word hand-off between two workgroups)",
-                "marginal_us_per_iteration": 5.6, "marginal_source": "profiles/r03/pcg_iter.json / profiles/r04 (tools/time_pcg_iter.py)",
+                "marginal_us_per_iteration": 8.0, "marginal_source": "profiles/r05/pcg_iter_gauge_pairs.json (tools/time_pcg_iter.py): the two-level "
+                "(block-Jacobi + gauge) iteration with its 17-quantity exchange; 5.6 for the plain block-Jacobi iteration, which needs "
+                "17 / 35 / 105 iterations on this instance where this one needs 17 / 19 / 25",
                 "hbm": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBPS,
                         "bytes_per_lm_step": lin_bytes + float(solve_bytes.get("fetch", 0.0) or 0.0) + float(solve_bytes.get("write", 0.0) or 0.0),
                         "note": "linearisation 388 B/edge + 168 B/node (SURVEY 8d C4) + the solve's COUNTED traffic per launch "

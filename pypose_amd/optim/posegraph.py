@@ -551,9 +551,11 @@ class FusedPCG:
                     # all-gather of the partial sums cheaper (5.6 us per iteration at 160-176 workgroups, 6.4 at 256, 10 k nodes):
                     # the smallest grid whose slices and ghost sets fit is kept for this workspace.
                     hit = self.__dict__.get('_ghost_grids')
-                    if hit is None or hit[0] != (PERSIST_GRID, GHOST_GRIDS) or hit[2] is not self._csr_obj:
-                        cands = sorted({min(g, self.N) for g in GHOST_GRIDS if g < PERSIST_GRID} | {min(PERSIST_GRID, self.N)})
-                        hit = self._ghost_grids = ((PERSIST_GRID, GHOST_GRIDS), cands, self._csr_obj)
+                    if hit is None or hit[0] != (PERSIST_GRID, GHOST_GRIDS, self.cz) or hit[2] is not self._csr_obj:
+                        # (the two-level variant's wide exchange goes in two levels from 224 workgroups on and is fastest there:
+                        #  8.0 us per iteration at 256 against 8.4 at 160, profiles/r05/pcg_iter_gauge_pairs.json -- largest grid first)
+                        cands = sorted({min(g, self.N) for g in GHOST_GRIDS if g < PERSIST_GRID} | {min(PERSIST_GRID, self.N)}, reverse=self.cz)
+                        hit = self._ghost_grids = ((PERSIST_GRID, GHOST_GRIDS, self.cz), cands, self._csr_obj)
                     while hit[1]:
                         grid = hit[1][0]
                         slot, gptr, gids, max_cnt, max_ghost = self._ghost_map(lin, grid)
