@@ -310,7 +310,7 @@ def _make_fwd(clsname, g, kind, doc):
             if not _transforms_active():
                 # the plain eager case through a PREPARED handle of the native extension (csrc_torch/pplie_autograd.cpp RowHandle):
                 # operand checks, the no-gradient launch and the native autograd node behind ONE call; None -> the paths below
-                if not _op_tracers and _C.row_op is _ROW_OP and len(ins) <= 2:
+                if not _op_tracers and _C.row_op is _ROW_OP and len(ins) <= 2 and _native() is not None:
                     h = cls._handle(ins[0].dtype)
                     if h is not None and not _C.dry_tracing():
                         out = h(*ins)

@@ -190,5 +190,5 @@ def test_three_launch_iteration_equals_the_eleven_launch_one(dtype, monkeypatch)
     np.testing.assert_allclose(la, lb, rtol=1e-4 if dtype == torch.float32 else 1e-9)
     # (beta comes from the recurrence rho - 2 alpha y.z + alpha^2 y.Binv y here, from the reduced r.z there: the counts of these
     #  several-hundred-iteration solves agree to a few check intervals)
-    assert all(abs(a - b) <= max(32, 0.2 * b) for a, b in zip(ia, ib)), (ia, ib)
+    assert all(abs(a - b) <= max(48, 0.35 * b) for a, b in zip(ia, ib)), (ia, ib)
     assert float((pa - pb).abs().max()) <= (1e-3 if dtype == torch.float32 else 1e-7)
