@@ -650,8 +650,10 @@ lap_blocks_kernel(const int* __restrict__ blk, const T* __restrict__ J, const T*
   const int lane = threadIdx.x & 63;
   const int sub = lane / M, i = lane % M;
   const int64_t wave = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
-  const int64_t c = wave * NPW + sub;
-  if (sub >= NPW || c >= nnz) return;
+  const int64_t c0 = wave * NPW;
+  const bool act = sub < NPW && c0 + sub < nnz;
+  const int64_t c = act ? c0 + sub : nnz - 1;                     // (idle lanes compute a clamped incidence and store nothing: the
+                                                                  //  wave exchanges through LDS below, so no lane leaves early)
   const int64_t bk = blk[c];
   const int64_t e = bk >> 1;
   const T* J1 = J + (e * 2 + 1) * (M * M);
@@ -678,14 +680,33 @@ lap_blocks_kernel(const int* __restrict__ blk, const T* __restrict__ J, const T*
 #pragma unroll
     for (int b = 0; b < M; ++b) srow[b] += v[l] * J1[l * M + b];
   }
-  gg[c * M + i] = (bk & 1) ? gi : -gi;                            // (side 0: J_c = -J_1)
+  if (act) gg[c * M + i] = (bk & 1) ? gi : -gi;                   // (side 0: J_c = -J_1)
   if constexpr (PACK) {
+    // The wave's NPW packed triangles are ONE contiguous run of HB (incidence order): the rows go through LDS and leave as
+    // lane-contiguous dwords (4 store instructions per wave for M = 6) instead of M masked stores per lane at an 84-byte pitch
+    __shared__ T stage[4][NPW * NP];
+    T* tile = stage[threadIdx.x >> 6];
+    if (sub < NPW) {
 #pragma unroll
-    for (int b = 0; b < M; ++b)
-      if (b >= i) HB[c * NP + (i * M - (i * (i - 1)) / 2 + (b - i))] = -srow[b];
+      for (int b = 0; b < M; ++b)
+        if (b >= i) tile[sub * NP + (i * M - (i * (i - 1)) / 2 + (b - i))] = -srow[b];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int64_t left = nnz - c0;
+    const int cnt = left <= 0 ? 0 : (int)(left < NPW ? left : NPW) * NP;
+    T* dst = HB + c0 * NP;
+#pragma unroll
+    for (int k = 0; k < (NPW * NP + 63) / 64; ++k) {
+      const int q = k * 64 + lane;
+      if (q < cnt) dst[q] = tile[q];
+    }
   } else {
+    if (act) {
 #pragma unroll
-    for (int b = 0; b < M; ++b) HB[(c * M + i) * M + b] = -srow[b];
+      for (int b = 0; b < M; ++b) HB[(c * M + i) * M + b] = -srow[b];
+    }
   }
 }
 
@@ -1284,11 +1305,31 @@ pcg2_step_kernel(T* __restrict__ x, T* r0, T* r1, T* __restrict__ p, const T* __
   const int a = done & 1;
   const T* __restrict__ rin = a ? r1 : r0;                       // residual of this iteration; the new one goes to the other
   T* __restrict__ rout = a ? r0 : r1;
+  const int lane = threadIdx.x & 63;
+  const int sub = lane / M, i = lane % M;
+  const bool active_lane = sub < NPW;
+  const int64_t wave = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * 256) >> 6;
+  // A trip's rows: raw loads from clamped positions (csrc/scan.hip's rule for a fetch) -- the FIRST trip's go out here, before the
+  // workgroup fetches the iteration's scalars (a dependent chain of slot loads, an LDS hand-off and a barrier that the vector loads
+  // used to wait behind), every later trip's one trip ahead.
+  struct Rows { T r, q, p, x, b[M]; };
+  auto fetch = [&](int64_t base, Rows& o) {
+    int64_t n = base + (active_lane ? sub : 0);
+    n = n < N ? n : N - 1;
+    const int64_t e = n * M + i;
+    o.r = rin[e];
+    o.q = q[e];
+    o.p = p[e];
+    o.x = x[e];
+#pragma unroll
+    for (int j = 0; j < M; ++j) o.b[j] = Binv[e * M + j];
+  };
+  Rows cur;
+  fetch(wave * NPW, cur);
   const T* const bases[4] = {squant2(scal, a, Q2_RHO), squant2(scal, a, Q2_PQ), squant2(scal, a, Q2_QZ), squant2(scal, a, Q2_QMQ)};
   T tv[4];
   slot_totals_wg<T, 4>(bases, tv);
-  const int lane = threadIdx.x & 63;
-  const int sub = lane / M, i = lane % M;
   T rho = tv[0];                                                // (CZ: the LOCAL part r.Binv r; the coarse part is added below)
   const T pq = tv[1], qz = tv[2], qmq = tv[3];
   __shared__ T c_cur[CZ ? CS_LINE : 1], c_e[CZ ? CS_LINE : 1];
@@ -1315,37 +1356,32 @@ pcg2_step_kernel(T* __restrict__ x, T* r0, T* r1, T* __restrict__ p, const T* __
   if (rho_rec < T(0)) rho_rec = T(0);
   const T beta = rho > tiny ? rho_rec / rho : T(0);
   T a1 = T(0), a2 = T(0), a_sr = T(0);
-  const bool active_lane = sub < NPW;
-  const int64_t wave = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
-  const int64_t nwaves = ((int64_t)gridDim.x * 256) >> 6;
   for (int64_t base = wave * NPW; base < N; base += nwaves * NPW) {
     const int64_t n = base + sub;
     const bool act = active_lane && n < N;
     const int64_t e = n * M + i;
-    T re = T(0), pe = T(0), xe = T(0);
-    T brow[M];
-    if (act) {
-      re = rin[e] - alpha * q[e];
-      pe = p[e];
-      xe = x[e];
-#pragma unroll
-      for (int j = 0; j < M; ++j) brow[j] = Binv[e * M + j];
+    Rows nxt;
+    {
+      const int64_t nb = base + nwaves * NPW;
+      fetch(nb < N ? nb : base, nxt);                            // (past the end: this trip's rows again, never used)
     }
+    const T re = cur.r - alpha * cur.q;
     T ze = T(0);
 #pragma unroll
     for (int j = 0; j < M; ++j) {
-      const T rj = __shfl(re, sub * M + j, 64);
-      if (act) ze += brow[j] * rj;
+      const T rj = __shfl(re, (sub * M + j) & 63, 64);
+      ze += cur.b[j] * rj;
     }
     if (act) {
-      x[e] = xe + alpha * pe;
+      x[e] = cur.x + alpha * cur.p;
       rout[e] = re;
       z[e] = ze;                                                 // (the LOCAL part Binv r': what K1's q.z wants)
-      p[e] = (CZ ? ze + cz : ze) + beta * pe;
+      p[e] = (CZ ? ze + cz : ze) + beta * cur.p;
       a1 += re * ze;
       a2 += re * re;
       if (CZ) a_sr += re;
     }
+    cur = nxt;
   }
   T s1 = block_sum(a1);
   T s2 = block_sum(a2);
@@ -1493,6 +1529,47 @@ extern "C" int pplie_pcg2_step_stop_f32(void* x, void* r, void* r_alt, void* p, 
 extern "C" int pplie_pcg2_step_stop_f64(void* x, void* r, void* r_alt, void* p, const void* q, void* z, const void* Binv, void* scal,
                                         void* it, int64_t N, int m, void* stream) {
   return pplie::pcg2_step<double>(x, r, r_alt, p, q, z, Binv, scal, it, N, m, stream, true);
+}
+// The end of a device-stopped solve that nobody on the host watches (a captured LM trial on a graph beyond the persistent solve,
+// optim/pgograph.py): the stop test of the LAST queued iteration -- the test of iteration k runs at the top of spmv launch k + 1,
+// which for the last one never comes -- and the solve's (iterations, |r|^2, |b|^2, flag) as four T, the record pplie_pgo_trial_tail
+// forwards to the host.  flag: 0 converged, 2 NaN, 4 the queued iterations did not reach the tolerance (the caller puts the
+// parameters back and takes the step on the watched path).  it[2] is updated, so iterations queued after this launch still stop.
+namespace pplie {
+template <class T>
+__global__ void __launch_bounds__(64) pcg2_report_kernel(const T* scal, T* __restrict__ rr_hist, int* it, int cap, T tol2, T* __restrict__ info) {
+  if (threadIdx.x != 0) return;
+  const int done = it[0];
+  int flag = it[2];
+  const T bn2 = slot_total(squant2(scal, 0, Q2_BN2));
+  T rr = T(0);
+  if (flag == 0 && done > 0) {
+    rr = slot_total(squant2(scal, (done & 1) ^ 1, Q2_RR));        // (the step kernel of iteration done - 1 left it there)
+    if (done - 1 < cap) rr_hist[done - 1] = rr;
+    if (!(rr == rr)) flag = 2;
+    else if (rr <= tol2 * bn2) flag = 1;
+    it[2] = flag;
+  } else if (done > 0 && done - 1 < cap) {
+    rr = rr_hist[done - 1];                                        // (the launch that raised the flag cleared the slots)
+  }
+  info[0] = (T)done;
+  info[1] = rr;
+  info[2] = bn2;
+  info[3] = flag == 1 ? T(0) : (flag == 2 ? T(2) : T(4));
+}
+template <class T>
+int pcg2_report(const void* scal, void* rr_hist, void* it, int cap, double tol2, void* info, void* stream) {
+  if (!scal || !rr_hist || !it || !info || cap <= 0 || !(tol2 >= 0.0)) return PPLIE_EBADARG;
+  hipLaunchKernelGGL((pcg2_report_kernel<T>), dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), (const T*)scal, (T*)rr_hist,
+                     (int*)it, cap, (T)tol2, (T*)info);
+  return hipGetLastError() == hipSuccess ? PPLIE_OK : PPLIE_ELAUNCH;
+}
+}  // namespace pplie
+extern "C" int pplie_pcg2_report_f32(const void* scal, void* rr_hist, void* it, int cap, double tol2, void* info, void* stream) {
+  return pplie::pcg2_report<float>(scal, rr_hist, it, cap, tol2, info, stream);
+}
+extern "C" int pplie_pcg2_report_f64(const void* scal, void* rr_hist, void* it, int cap, double tol2, void* info, void* stream) {
+  return pplie::pcg2_report<double>(scal, rr_hist, it, cap, tol2, info, stream);
 }
 // HB [E, M, M] per edge (pplie_graph_assemble_csr_sym), blk [nnz] = 2 edge + side of every incidence
 extern "C" int pplie_pcg2_spmv_sym_f32(const void* ptr, const void* other, const void* blk, const void* HB, const void* D,

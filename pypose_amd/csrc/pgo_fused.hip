@@ -144,7 +144,7 @@ constexpr int kPgoPartials = 1024;     // = PPLIE_PGO_PARTIALS in include/pplie.
 // four launches and no tensor ops --
 //   retract   nodes <- Exp(x_n) nodes_n   (lietensor.py:60-65, optimizer.py update_parameter); the old rows go to `backup` if given
 //   residual  per edge at the candidate: per-workgroup partials of |r|^2, the trial's loss (optimizer.py:672; pgo_residual_kernel)
-//   gain      JD_e = J_e0 x_i + J_e1 x_j: partials of sum JD.JD, sum JD.R  (strategy.py:144, :261; graph_gain_kernel, csrc/graph.hip)
+//   gain      JD_e = J_e0 x_i + J_e1 x_j = J_e1 (x_j - x_i): partials of sum JD.JD, sum JD.R  (strategy.py:144, :261; pgo_gain_antisym_kernel)
 //   pack      one wavefront: the partials summed in index order (double), the solve's (iterations, |r|^2, |b|^2, flag) appended,
 //             the loss stored into the caller's ring of loss scalars, and the 8 doubles {a, b, loss, its, rr, bn2, flag, seq}
 //             stored with SYSTEM scope -- `out` may be host-pinned memory the host polls for `seq`, the last word written.
@@ -207,6 +207,40 @@ pgo_trial_pack_kernel(const T* __restrict__ partial, int nparts, const T* __rest
   if (q == 0) __hip_atomic_store(out + 7, (double)seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// gain-ratio terms of the relative-pose program (strategy.py:144, :261): its two blocks per edge are opposite (J_e0 = -J_e1, see
+// pgo_linearize_kernel), so JD_e = J_e1 (x_j - x_i) and only the second block is read -- 144 instead of 288 bytes per edge.
+// M lanes per edge, lane i owns row i: the wave reads 10 consecutive blocks as one contiguous run (the generic graph_gain_kernel,
+// one lane per edge, walks 288-byte records per lane: 2.4 TB/s at 4e5 edges).  partial[2 w], partial[2 w + 1] per workgroup w.
+template <class T>
+__global__ void __launch_bounds__(256)
+pgo_gain_antisym_kernel(const T* __restrict__ J, const int64_t* __restrict__ idx, const T* __restrict__ x, const T* __restrict__ R,
+                        T* __restrict__ partial, int64_t E) {
+  constexpr int M = 6, NPW = 64 / M;
+  const int lane = threadIdx.x & 63;
+  const int sub = lane / M, i = lane - sub * M;
+  const int64_t wave = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * 256) >> 6;
+  T a1 = T(0), a2 = T(0);
+  for (int64_t base = wave * NPW; base < E; base += nwaves * NPW) {
+    const bool act = sub < NPW && base + sub < E;
+    const int64_t e = act ? base + sub : E - 1;                    // (clamped: every load below is unconditional)
+    const int64_t n0 = idx[e * 2], n1 = idx[e * 2 + 1];
+    const T dv = x[n1 * M + i] - x[n0 * M + i];
+    const T* Jr = J + ((e * 2 + 1) * M + i) * M;
+    T row[M];
+#pragma unroll
+    for (int j = 0; j < M; ++j) row[j] = Jr[j];
+    const T rv = R[e * M + i];
+    T jd = T(0);
+#pragma unroll
+    for (int j = 0; j < M; ++j) jd += row[j] * __shfl(dv, (sub * M + j) & 63, 64);
+    if (act) { a1 += jd * jd; a2 += jd * rv; }
+  }
+  T s1 = block_sum(a1);
+  T s2 = block_sum(a2);
+  if (threadIdx.x == 0) { partial[blockIdx.x * 2] = s1; partial[blockIdx.x * 2 + 1] = s2; }
+}
+
 template <class T>
 int pgo_trial_tail(void* nodes, void* backup, const void* idx, const void* Z, const void* J, const void* R, const void* x, const void* pcg_info,
                    void* partial, void* state, void* out, int64_t N, int64_t E, void* stream) {
@@ -221,9 +255,8 @@ int pgo_trial_tail(void* nodes, void* backup, const void* idx, const void* Z, co
   T* part = (T*)partial;
   hipLaunchKernelGGL((pgo_residual_kernel<T, BLOCK>), dim3(grid), dim3(BLOCK), 0, st, (const T*)nodes, (const int64_t*)idx,
                      (const T*)Z, (T*)nullptr, part, E, RobustParam<T>{RK_NONE, T(0), T(0)});
-  const int code = sizeof(T) == 4 ? pplie_graph_gain_terms_f32(J, idx, x, 6, R, part + kPgoPartials, E, 6, 6, 2, stream)
-                                  : pplie_graph_gain_terms_f64(J, idx, x, 6, R, part + kPgoPartials, E, 6, 6, 2, stream);
-  if (code != PPLIE_OK) return code;
+  hipLaunchKernelGGL((pgo_gain_antisym_kernel<T>), dim3(grid), dim3(256), 0, st, (const T*)J, (const int64_t*)idx, (const T*)x,
+                     (const T*)R, part + kPgoPartials, E);
   hipLaunchKernelGGL((pgo_trial_pack_kernel<T>), dim3(1), dim3(64), 0, st, (const T*)part, grid, (const T*)pcg_info,
                      (unsigned long long*)state, (double*)out);
   return hipGetLastError() == hipSuccess ? PPLIE_OK : PPLIE_ELAUNCH;

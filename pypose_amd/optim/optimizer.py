@@ -629,9 +629,20 @@ class LevenbergMarquardt(_Optimizer):
         trivial = all(isinstance(c, Trivial) for c in self.corrector) and all(isinstance(k, Trivial) for k in self.model.kernel)
         ok = (defer and trivial and lin.kind == "fused:pgo" and hasattr(lin, 'fast_loss') and getattr(lin, 'robust', None) is None
               and target is None and len(self.param_groups) == 1
-              and isinstance(self.solver, PCG) and getattr(self.solver, 'fused', True) and lin.N <= PERSIST_NODES
-              and FusedPCG.persist and FusedPCG.two_launch and getattr(self, 'graph_step', True)
+              and isinstance(self.solver, PCG) and getattr(self.solver, 'fused', True)
+              and FusedPCG.two_launch and getattr(self, 'graph_step', True)
               and not isinstance(weight, (tuple, list)))
+        # graphs beyond the persistent solve: the packed two-launch iteration with the device-side stop test can run unwatched
+        # (posegraph.FusedPCG.solve, defer='inplace'); the capture queues as many iterations as the longest watched solve of the
+        # streak needed, rounded up to a multiple of eight -- launches behind the converging iteration cost ~5 us each, so a capture
+        # sized far beyond what the solves take would give back what it saves in host latency
+        unwatched = None
+        if ok and not (lin.N <= PERSIST_NODES and FusedPCG.persist):
+            wsps = [w for w in (d.get('_pcg_workspaces') or {}).values() if w.N == lin.N and w.sym == 'pack' and w.iterations_seen > 0]
+            ok = (FusedPCG.capture_large and FusedPCG.device_stop and bool(getattr(lin, 'HB_pack', False)) and len(wsps) == 1)
+            if ok:
+                unwatched = max(16, -(-(wsps[0].iterations_seen + 1) // 8) * 8)
+                ok = unwatched <= min(FusedPCG.unwatched_max, self.solver.maxiter or FusedPCG.unwatched_max)
         cache = d.get('_structure_cache') or {}
         hit = cache.get("program")
         if not ok or hit is None or hit[2] != "pgo" or cache.get("fused") is not True:
@@ -648,6 +659,8 @@ class LevenbergMarquardt(_Optimizer):
         if n >= PgoGraphStep.MIN_STREAK:
             params = [p for p in pg['params'] if p.requires_grad]
             try:
+                if unwatched is not None:
+                    wsps[0].unwatched_iterations = unwatched
                 d['_pgo_graph_step'] = PgoGraphStep(self, pg, prog, input, weight, params[0], trivial)
             except Exception as e:                       # capture is an optimisation: the ordinary path stays correct
                 d['_pgo_graph_step'] = None

@@ -268,6 +268,17 @@ class PgoGraphStep:
             last_h = opt._host(opt.last)
         opt.linearization = lin.kind
         opt._last_replicated = False
+        if flag == 4.0:
+            # a graph beyond the persistent solve (posegraph.FusedPCG.solve, defer='inplace'): the iterations the capture queues did not
+            # reach the tolerance, and the trial's tail has moved the parameters by that unconverged step.  Put them back, drop this
+            # capture (the next one is sized by the watched solves that follow) and take the step on the ordinary path.
+            with torch.no_grad():
+                torch.Tensor.as_subclass(self.P, torch.Tensor).detach().copy_(self.backup)
+            _C.mark_written(self.P)
+            opt.__dict__.pop('_pgo_graph_step', None)
+            opt.__dict__['_pgo_streak'] = (None, 0)
+            opt.loss = opt.last
+            return opt._step_general(self.input, None, self.weight)
         if flag >= 2.0 or rr != rr:                # a failed solve returned a zero step: the parameters are where they were
             if flag == 3.0:                        # the persistent launch's workgroups were not all resident: drop the capture,
                 from .posegraph import SolveFailed, _check_persist_flag      # take this step on the two-launch iteration

@@ -61,6 +61,7 @@ _PREP_CZ_SIG = [ctypes.c_void_p] * 11 + [ctypes.c_double, ctypes.c_void_p, ctype
 _PCG2_SPMV_CZ_SIG = [ctypes.c_void_p] * 12 + [ctypes.c_int, ctypes.c_int64, ctypes.c_int, ctypes.c_double, ctypes.c_void_p]
 _PCG2_STEP_CZ_SIG = [ctypes.c_void_p] * 10 + [ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]
 _CZ_INIT_SIG = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]
+_PCG2_REPORT_SIG = [ctypes.c_void_p] * 3 + [ctypes.c_int, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p]
 import os as _os
 # graphs up to this many nodes run the whole PCG solve in ONE persistent launch (csrc/pcg_persist.hip); larger ones need
 # the whole chip's bandwidth per iteration and keep the two-launch hipGraph iteration
@@ -321,6 +322,10 @@ class FusedPCG:
     profile = False          # tools/time_pcg_iter.py: the persistent kernel leaves per-phase clock ticks in rr_hist[cap - 8:]
     # two-level preconditioner (block-Jacobi + gauge modes) where the linearisation allows it (PCG(gauge=)); PPLIE_PCG_GAUGE=0: off
     coarse = _os.environ.get("PPLIE_PCG_GAUGE", "1") != "0"
+    # the whole LM trial of a graph BEYOND the persistent solve as one hipGraph replay too (optim/pgograph.py): the two-launch iterations
+    # run unwatched, at most `unwatched_max` of them per capture (PPLIE_CAPTURE_LARGE=0: the watched chunks of eight only)
+    capture_large = _os.environ.get("PPLIE_CAPTURE_LARGE", "1") != "0"
+    unwatched_max = 48
 
     def __init__(self, E, K, dr, m, N, dtype, device, has_w, check_every):
         z = lambda *s: torch.zeros(s, dtype=dtype, device=device)
@@ -358,6 +363,8 @@ class FusedPCG:
         self.bsr = None                                            # which iteration the graph holds
         self.sym = False                                           # HB holds one block per edge
         self.stop_tol2 = None                                      # tol^2 when the captured iterations carry the device-side stop
+        self.iterations_seen = 0                                   # the longest watched two-launch solve so far (sizes a captured trial)
+        self.unwatched_iterations = 24                             # iterations a captured trial queues (PgoGraphStep sets it)
         self._csr_obj = None
 
     def _ghost_map(self, lin, grid):
@@ -517,10 +524,21 @@ class FusedPCG:
                 code = _C.library().symbol("pplie_pcg_begin", _BEGIN_SIG)(
                     self._ctl.data_ptr(), self._ctl.numel(), s_dev.data_ptr(), self.s_device.data_ptr(), _C.stream_ptr(self.device))
                 _C.check(code, "pplie_pcg_begin")
-                code = _C.library().symbol("pplie_pcg_prepare_dev" + self.sfx, _PREP_DEV_SIG)(
-                    lin.B.data_ptr(), lin.g.data_ptr(), self.D.data_ptr(), self.Binv.data_ptr(), self.shift.data_ptr(),
-                    self.x.data_ptr(), self.r.data_ptr(), self.z.data_ptr(), self.p.data_ptr(), self.scal.data_ptr(),
-                    self.s_device.data_ptr(), float(dmin), float(dmax), self.N, self.m, _C.stream_ptr(self.device))
+                if self.cz and two:
+                    # (a captured trial on a graph beyond the persistent solve: the two-launch iteration's coarse sums, the damping
+                    #  factor from the device scalar pplie_pcg_begin has just filled)
+                    code = _C.library().symbol("pplie_pcg_prepare_coarse" + self.sfx, _PREP_CZ_SIG)(
+                        lin.B.data_ptr(), lin.g.data_ptr(), self.D.data_ptr(), self.Binv.data_ptr(), self.shift.data_ptr(),
+                        self.x.data_ptr(), self.r.data_ptr(), self.z.data_ptr(), self.p.data_ptr(), self.scal.data_ptr(), self.cs.data_ptr(),
+                        1.0, self.s_device.data_ptr(), float(dmin), float(dmax), self.N, self.m, _C.stream_ptr(self.device))
+                    _C.check(code, "pplie_pcg_prepare_coarse")
+                    code = _C.library().symbol("pplie_pcg2_coarse_init" + self.sfx, _CZ_INIT_SIG)(
+                        self.p.data_ptr(), self.cs.data_ptr(), self.N, self.m, _C.stream_ptr(self.device))
+                else:
+                    code = _C.library().symbol("pplie_pcg_prepare_dev" + self.sfx, _PREP_DEV_SIG)(
+                        lin.B.data_ptr(), lin.g.data_ptr(), self.D.data_ptr(), self.Binv.data_ptr(), self.shift.data_ptr(),
+                        self.x.data_ptr(), self.r.data_ptr(), self.z.data_ptr(), self.p.data_ptr(), self.scal.data_ptr(),
+                        self.s_device.data_ptr(), float(dmin), float(dmax), self.N, self.m, _C.stream_ptr(self.device))
             elif self.cz and two:
                 # (the persistent solve sums E and Z^T r_0 itself, in its first exchange; the two-launch iteration gets them here)
                 code = _C.library().symbol("pplie_pcg_prepare_coarse" + self.sfx, _PREP_CZ_SIG)(
@@ -615,6 +633,19 @@ class FusedPCG:
                 tol2 = float(tol) * float(tol)
                 if self.stop_tol2 != tol2:
                     self.stop_tol2, self.graph = tol2, None        # (tol^2 is a launch argument of the captured chunk)
+                if defer == 'inplace':
+                    # Inside the capture of a whole LM trial (optim/pgograph.py): nobody reads the control word between the iterations
+                    # and the trial's tail.  `unwatched_iterations` launches of the pair are queued outright (those behind the converging
+                    # one return at once), then pplie_pcg2_report tests the last one and leaves (iterations, |r|^2, |b|^2, flag) where
+                    # the tail's pack kernel picks them up; flag 4 = not converged within what was queued: the host puts the parameters
+                    # back and takes that step on the watched path below.
+                    for _ in range(min(maxiter, self.unwatched_iterations)):
+                        self._iteration(None)
+                    code = _C.library().symbol("pplie_pcg2_report" + self.sfx, _PCG2_REPORT_SIG)(
+                        self.scal.data_ptr(), self.rr_hist.data_ptr(), self.it.data_ptr(), self.cap, tol2, self.info.data_ptr(),
+                        _C.stream_ptr(self.device))
+                    _C.check(code, "pplie_pcg2_report")
+                    return self.x, _PendingInfo(self.info)
                 # (a schedule guessed from the previous solve's count loses more in no-op launches than it saves; with the two-level
                 #  preconditioner a solve at the usual tolerances ends in 17 - 26 iterations: three chunks of eight, one read-back)
                 ahead = 3 if self.cz else 2
@@ -637,6 +668,7 @@ class FusedPCG:
                     its, _, flag, _ = self.it.tolist()
                     assert flag != 2, 'Linear solve produced NaN (matrix may not be positive-definite)'
                     if flag == 1:
+                        self.iterations_seen = max(self.iterations_seen, int(its))
                         return self.x.clone(), int(its)
                 return self.x.clone(), done
             if self.stop_tol2 is not None:

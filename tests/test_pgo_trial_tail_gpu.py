@@ -27,6 +27,7 @@ def test_trial_tail_equals_the_unfused_ops(dtype, tol, N, E):
     Z = pp.randn_SE3(E, dtype=dtype, device=DEV).tensor().contiguous()
     idx = torch.randint(0, N, (E, 2), device=DEV)
     J = torch.randn(E, 2, 6, 6, dtype=dtype, device=DEV)
+    J[:, 0] = -J[:, 1]          # the program's two blocks per edge are opposite (pplie_pgo_linearize); the tail reads J[:, 1] only
     R = torch.randn(E, 6, dtype=dtype, device=DEV)
     x = 0.01 * torch.randn(N, 6, dtype=dtype, device=DEV)
     info = torch.tensor([5.0, 1e-3, 1.0, 1.0], dtype=dtype, device=DEV)

@@ -1,0 +1,19 @@
+#!/bin/bash
+# Round 5, captured LM trial beyond the persistent solve + assembly / tail kernels: tests, the two pose-graph legs, the 100k timeline
+set -u
+cd "$(dirname "$0")/.."
+R=$PWD; O=gpurun_out/r05_${1:-h}; mkdir -p $O; export TMPDIR=/tmp
+timeout 1200 python -m pytest -q -m gpu --tb=short -p no:cacheprovider tests/test_pgo_capture_large_gpu.py tests/test_pack_blocks_gpu.py tests/test_pcg_gauge_gpu.py tests/test_optim_gpu.py tests/test_pgo_trial_tail_gpu.py tests/test_determinism_gpu.py tests/test_fullsize_parity_gpu.py 2>&1 | tail -25 | cut -c1-400
+timeout 600 python - <<'P'
+import sys, json, os, torch
+sys.path.insert(0, '.')
+import bench
+dev = torch.device("cuda:0")
+inst = bench._host_instances(False, False)
+r = bench.pgo_lm_rate(dev, 100_000, 400_000, reps=9, with_static=False, problem=inst.get("lm_pgo_100k"))
+print("100k", json.dumps({k: r.get(k) for k in ("value", "pcg_iterations", "losses")})[:600])
+r = bench.pgo_lm_rate(dev, 10_000, 40_000, reps=25, problem=inst.get("lm_pgo"))
+print("10k", json.dumps({k: r.get(k) for k in ("value", "pcg_iterations", "losses", "static_model_value")})[:600])
+P
+bash tools/gpu_timeline100k.sh 2>&1 | head -16 | cut -c1-220
+cp gpurun_out/tl/timeline_100k.txt $O/ 2>/dev/null
