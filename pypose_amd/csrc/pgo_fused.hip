@@ -12,6 +12,7 @@
 // 24 residual + 2 * 144 Jacobian written = 412 B; the autograd route makes 6 backward sweeps through five ops.
 #include "rowmap.h"
 #include "robust.h"
+#include "gridsync.h"
 
 extern "C" int pplie_graph_gain_terms_f32(const void* J, const void* idx, const void* d, int ld, const void* R, void* partial,
                                           int64_t E, int dr, int m, int k, void* stream);      // csrc/graph.hip
@@ -96,10 +97,17 @@ pgo_linearize_kernel(const T* __restrict__ nodes, const int64_t* __restrict__ id
 }
 
 // residuals only + per-workgroup partial sums of |r|^2 (the Trivial-kernel loss, optimizer.py:118-125)
-template <class T, int BLOCK>
+template <class T>
+__device__ __forceinline__ void pgo_trial_pack(const T* partial, int nparts, const T* pcg_info, unsigned long long* state, double* out,
+                                               bool coherent_loss);
+// PACKLAST (the trial tail's second launch): the workgroup that arrives last at the ticket state[4] also does what a fourth launch
+// did -- sums everybody's partials and reports (pgo_trial_pack).  The loss partials cross workgroups inside this launch: agent-scope
+// stores and loads (csrc/gridsync.h xwg_*), the ticket's increment a release.
+template <class T, int BLOCK, bool PACKLAST = false>
 __global__ void __launch_bounds__(BLOCK)
 pgo_residual_kernel(const T* __restrict__ nodes, const int64_t* __restrict__ idx, const T* __restrict__ Z,
-                    T* __restrict__ R /* or null */, T* __restrict__ partial /* [gridDim.x] */, int64_t E, RobustParam<T> rk) {
+                    T* __restrict__ R /* or null */, T* __restrict__ partial /* [gridDim.x] */, int64_t E, RobustParam<T> rk,
+                    const T* __restrict__ pcg_info = nullptr, unsigned long long* state = nullptr, double* out = nullptr) {
   __shared__ __attribute__((aligned(16))) T lds[BLOCK * 7];
   T acc = T(0);
   const int64_t ntiles = (E + BLOCK - 1) / BLOCK;
@@ -134,28 +142,41 @@ pgo_residual_kernel(const T* __restrict__ nodes, const int64_t* __restrict__ idx
     }
   }
   T s = block_sum(acc);
-  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+  if constexpr (!PACKLAST) {
+    if (threadIdx.x == 0) partial[blockIdx.x] = s;
+  } else {
+    __shared__ int last_sh;
+    if (threadIdx.x == 0) {
+      xwg_store(partial + blockIdx.x, s);
+      unsigned* ticket = reinterpret_cast<unsigned*>(state + 4);
+      const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      last_sh = t == gridDim.x - 1 ? 1 : 0;
+      if (last_sh) xwg_store(ticket, 0u);                          // (at rest again for the next execution)
+    }
+    __syncthreads();
+    if (last_sh && threadIdx.x < 64) pgo_trial_pack<T>(partial, (int)gridDim.x, pcg_info, state, out, true);
+  }
 }
 
 constexpr int kPgoPartials = 1024;     // = PPLIE_PGO_PARTIALS in include/pplie.h
 
 // ---------------------------------------------------------------------------------------------
 // The tail of one captured LM trial (optim/pgograph.py): everything between the linear solve and the host's decision,
-// four launches and no tensor ops --
+// TWO launches (four until round 5: at 10 k nodes each dependent launch costs ~4.5 us whatever it does) and no tensor ops --
+//   first     gain + retract side by side (pgo_tail_first_kernel);   second   residual, whose last workgroup packs --
 //   retract   nodes <- Exp(x_n) nodes_n   (lietensor.py:60-65, optimizer.py update_parameter); the old rows go to `backup` if given
 //   residual  per edge at the candidate: per-workgroup partials of |r|^2, the trial's loss (optimizer.py:672; pgo_residual_kernel)
 //   gain      JD_e = J_e0 x_i + J_e1 x_j = J_e1 (x_j - x_i): partials of sum JD.JD, sum JD.R  (strategy.py:144, :261; pgo_gain_antisym_kernel)
 //   pack      one wavefront: the partials summed in index order (double), the solve's (iterations, |r|^2, |b|^2, flag) appended,
 //             the loss stored into the caller's ring of loss scalars, and the 8 doubles {a, b, loss, its, rr, bn2, flag, seq}
 //             stored with SYSTEM scope -- `out` may be host-pinned memory the host polls for `seq`, the last word written.
-// `state` (device memory, four 64-bit words): {seq: incremented by every execution's last kernel, address of the loss ring (T*) or 0,
-// its length, retractions: incremented by every execution's FIRST kernel}.
+// `state` (device memory, EIGHT 64-bit words): {seq: incremented by every execution's last kernel, address of the loss ring (T*) or 0,
+// its length, retractions: incremented by every execution's FIRST kernel, arrival ticket of the second launch (zero at rest), 3 reserved}.
 // ---------------------------------------------------------------------------------------------
 template <class T>
-__global__ void __launch_bounds__(256)
-pgo_retract_kernel(T* __restrict__ nodes, const T* __restrict__ x, T* __restrict__ backup /* or null */, int64_t N,
-                   unsigned long long* state) {
-  const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void pgo_retract_rows(int64_t block, T* __restrict__ nodes, const T* __restrict__ x,
+                                                 T* __restrict__ backup /* or null */, int64_t N, unsigned long long* state) {
+  const int64_t n = block * 256 + threadIdx.x;
   if (n >= N) return;
   if (n == 0) state[3] += 1;             // "the parameters were moved": what an error path needs to know before it restores them
   T d[7], X[7], E[7], out[7];
@@ -175,15 +196,14 @@ pgo_retract_kernel(T* __restrict__ nodes, const T* __restrict__ x, T* __restrict
 }
 
 template <class T>
-__global__ void __launch_bounds__(64)
-pgo_trial_pack_kernel(const T* __restrict__ partial, int nparts, const T* __restrict__ pcg_info, unsigned long long* state,
-                      double* out) {
-  // every lane sums the partials i = q, q + 64, ... and a shuffle tree adds the lanes: a fixed order, the same bits every replay
+__device__ __forceinline__ void pgo_trial_pack(const T* partial, int nparts, const T* pcg_info, unsigned long long* state, double* out,
+                                               bool coherent_loss) {
+  // (one wavefront) every lane sums the partials i = q, q + 64, ... and a shuffle tree adds the lanes: a fixed order, the same bits every replay
   const int q = threadIdx.x;
   double loss = 0.0, a = 0.0, b = 0.0;
   for (int i = q; i < nparts; i += 64) {
-    loss += (double)partial[i];                                   // pgo_residual_kernel
-    a += (double)partial[kPgoPartials + 2 * i];                   // graph_gain_kernel: sum JD.JD
+    loss += (double)(coherent_loss ? xwg_load(partial + i) : partial[i]);     // pgo_residual_kernel (this launch's other workgroups)
+    a += (double)partial[kPgoPartials + 2 * i];                   // gain partials (an earlier launch): sum JD.JD
     b += (double)partial[kPgoPartials + 2 * i + 1];               //                    sum JD.R
   }
 #pragma unroll
@@ -212,14 +232,13 @@ pgo_trial_pack_kernel(const T* __restrict__ partial, int nparts, const T* __rest
 // M lanes per edge, lane i owns row i: the wave reads 10 consecutive blocks as one contiguous run (the generic graph_gain_kernel,
 // one lane per edge, walks 288-byte records per lane: 2.4 TB/s at 4e5 edges).  partial[2 w], partial[2 w + 1] per workgroup w.
 template <class T>
-__global__ void __launch_bounds__(256)
-pgo_gain_antisym_kernel(const T* __restrict__ J, const int64_t* __restrict__ idx, const T* __restrict__ x, const T* __restrict__ R,
-                        T* __restrict__ partial, int64_t E) {
+__device__ __forceinline__ void pgo_gain_antisym(int block, int nblocks, const T* __restrict__ J, const int64_t* __restrict__ idx,
+                                                 const T* __restrict__ x, const T* __restrict__ R, T* __restrict__ partial, int64_t E) {
   constexpr int M = 6, NPW = 64 / M;
   const int lane = threadIdx.x & 63;
   const int sub = lane / M, i = lane - sub * M;
-  const int64_t wave = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
-  const int64_t nwaves = ((int64_t)gridDim.x * 256) >> 6;
+  const int64_t wave = ((int64_t)block * 256 + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)nblocks * 256) >> 6;
   T a1 = T(0), a2 = T(0);
   for (int64_t base = wave * NPW; base < E; base += nwaves * NPW) {
     const bool act = sub < NPW && base + sub < E;
@@ -238,7 +257,17 @@ pgo_gain_antisym_kernel(const T* __restrict__ J, const int64_t* __restrict__ idx
   }
   T s1 = block_sum(a1);
   T s2 = block_sum(a2);
-  if (threadIdx.x == 0) { partial[blockIdx.x * 2] = s1; partial[blockIdx.x * 2 + 1] = s2; }
+  if (threadIdx.x == 0) { partial[block * 2] = s1; partial[block * 2 + 1] = s2; }
+}
+// The tail's FIRST launch: the two pieces of work that only read the solve's step x and nothing of each other -- the gain terms
+// (workgroups 0 .. gain_blocks - 1) and the retraction of the parameters (the rest, 256 nodes each)
+template <class T>
+__global__ void __launch_bounds__(256)
+pgo_tail_first_kernel(int gain_blocks, const T* __restrict__ J, const int64_t* __restrict__ idx, const T* __restrict__ x,
+                      const T* __restrict__ R, T* __restrict__ gain_partial, int64_t E, T* __restrict__ nodes,
+                      T* __restrict__ backup /* or null */, int64_t N, unsigned long long* state) {
+  if ((int)blockIdx.x < gain_blocks) pgo_gain_antisym<T>((int)blockIdx.x, gain_blocks, J, idx, x, R, gain_partial, E);
+  else pgo_retract_rows<T>((int64_t)blockIdx.x - gain_blocks, nodes, x, backup, N, state);
 }
 
 template <class T>
@@ -246,18 +275,18 @@ int pgo_trial_tail(void* nodes, void* backup, const void* idx, const void* Z, co
                    void* partial, void* state, void* out, int64_t N, int64_t E, void* stream) {
   if (N <= 0 || E <= 0) return PPLIE_EBADARG;
   if (!nodes || !idx || !Z || !J || !R || !x || !pcg_info || !partial || !state || !out || !aligned16(Z)) return PPLIE_EBADARG;
+  if (reinterpret_cast<uintptr_t>(state) & 7) return PPLIE_EBADARG;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL((pgo_retract_kernel<T>), dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, (T*)nodes, (const T*)x, (T*)backup, N,
-                     (unsigned long long*)state);
   constexpr int BLOCK = 256;
   const int64_t nt = (E + BLOCK - 1) / BLOCK;
-  const int grid = (int)(nt < kPgoPartials ? nt : kPgoPartials);             // (= the grid of both kernels below)
+  const int grid = (int)(nt < kPgoPartials ? nt : kPgoPartials);             // (= the number of partials of every kind)
   T* part = (T*)partial;
-  hipLaunchKernelGGL((pgo_residual_kernel<T, BLOCK>), dim3(grid), dim3(BLOCK), 0, st, (const T*)nodes, (const int64_t*)idx,
-                     (const T*)Z, (T*)nullptr, part, E, RobustParam<T>{RK_NONE, T(0), T(0)});
-  hipLaunchKernelGGL((pgo_gain_antisym_kernel<T>), dim3(grid), dim3(256), 0, st, (const T*)J, (const int64_t*)idx, (const T*)x,
-                     (const T*)R, part + kPgoPartials, E);
-  hipLaunchKernelGGL((pgo_trial_pack_kernel<T>), dim3(1), dim3(64), 0, st, (const T*)part, grid, (const T*)pcg_info,
+  const int64_t rb = (N + 255) / 256;
+  if (rb + grid >= (int64_t)1 << 31) return PPLIE_EBADARG;
+  hipLaunchKernelGGL((pgo_tail_first_kernel<T>), dim3((unsigned)(grid + rb)), dim3(256), 0, st, grid, (const T*)J, (const int64_t*)idx,
+                     (const T*)x, (const T*)R, part + kPgoPartials, E, (T*)nodes, (T*)backup, N, (unsigned long long*)state);
+  hipLaunchKernelGGL((pgo_residual_kernel<T, BLOCK, true>), dim3(grid), dim3(BLOCK), 0, st, (const T*)nodes, (const int64_t*)idx,
+                     (const T*)Z, (T*)nullptr, part, E, RobustParam<T>{RK_NONE, T(0), T(0)}, (const T*)pcg_info,
                      (unsigned long long*)state, (double*)out);
   return hipGetLastError() == hipSuccess ? PPLIE_OK : PPLIE_ELAUNCH;
 }

@@ -62,8 +62,9 @@ class TrialTail:
         self.out = torch.zeros(8, dtype=torch.float64).pin_memory()       # {a, b, loss, iterations, |r|^2, |b|^2, flag, seq}
         self.out_np = self.out.numpy()
         self.seq = 0
-        self.state = torch.zeros(4, dtype=torch.int64, device=dev)         # {seq (counts executions), loss ring address, its length,
-                                                                           #  retractions (counts moved parameters)}
+        self.state = torch.zeros(8, dtype=torch.int64, device=dev)         # {seq (counts executions), loss ring address, its length,
+                                                                           #  retractions (counts moved parameters), the second launch's
+                                                                           #  arrival ticket (zero at rest), three reserved}
         self.partial = torch.empty(3 * _PARTIALS, dtype=dtype, device=dev)
         self.no_info = torch.zeros(4, dtype=dtype, device=dev)             # (a solve that reported to the host already)
         self.new_ring()
@@ -128,6 +129,7 @@ class TrialTail:
         """after a failed launch / an exception: the host's execution count is read back from the device's (a read-back, so a
         synchronisation -- error paths only).  Returns how many executions the device counted beyond the host's mirror."""
         dev_seq, moved = (int(v) for v in self.state[[0, 3]].tolist())
+        self.state[4] = 0                            # (the tail's arrival ticket: at rest, whatever the failed call left)
         ahead = dev_seq - self.seq
         self.seq = dev_seq
         self.unfinished = moved - dev_seq            # retractions whose trial never reported (0 or 1)

@@ -33,7 +33,7 @@ def test_trial_tail_equals_the_unfused_ops(dtype, tol, N, E):
     info = torch.tensor([5.0, 1e-3, 1.0, 1.0], dtype=dtype, device=DEV)
     partial = torch.empty(3 * 1024, dtype=dtype, device=DEV)
     ring = torch.zeros(16, dtype=dtype, device=DEV)
-    state = torch.tensor([6, ring.data_ptr(), 16, 6], dtype=torch.int64, device=DEV)    # (six executions so far, six retractions)
+    state = torch.tensor([6, ring.data_ptr(), 16, 6, 0, 0, 0, 0], dtype=torch.int64, device=DEV)    # (six executions so far, six retractions; ticket at rest)
     out = torch.zeros(8, dtype=torch.float64).pin_memory()
     backup = torch.empty_like(nodes)
     want_nodes = (pp.se3(x).Exp() @ pp.SE3(nodes)).tensor()
@@ -50,6 +50,7 @@ def test_trial_tail_equals_the_unfused_ops(dtype, tol, N, E):
     torch.cuda.synchronize()
     got = out.tolist()
     assert got[7] == 7.0 and state.tolist()[0] == 7 and state.tolist()[3] == 7     # executions and retractions are counted
+    assert state.tolist()[4:] == [0, 0, 0, 0]                                       # the arrival ticket is back at rest
     assert got[3:7] == [5.0, pytest.approx(1e-3, rel=1e-6), 1.0, 1.0]
     assert got[0] == pytest.approx(want_a, rel=tol) and got[1] == pytest.approx(want_b, rel=tol, abs=tol * want_a)
     assert got[2] == pytest.approx(want_loss, rel=tol)
