@@ -855,7 +855,8 @@ template <class T, int M>
 __global__ void __launch_bounds__(256)
 pcg_prepare_kernel(const T* __restrict__ B, const T* __restrict__ g, T* __restrict__ D, T* __restrict__ Binv,
                    T* __restrict__ shift, T* __restrict__ x, T* __restrict__ r, T* __restrict__ z, T* __restrict__ p,
-                   T* scal, T s_host, T dmin, T dmax, int64_t N, const double* __restrict__ s_dev, T* cs = nullptr) {
+                   T* scal, T s_host, T dmin, T dmax, int64_t N, const double* __restrict__ s_dev, T* cs = nullptr,
+                   T* __restrict__ Dp = nullptr, T* __restrict__ Bp = nullptr) {
   // the compounded damping factor: a launch argument, or (s_dev) a device scalar -- a captured hipGraph of the whole LM trial
   // is replayed with the factor of the day written there
   // (system scope, one lane per workgroup: the scalar may sit in host-pinned memory that the host rewrites between replays of a
@@ -888,6 +889,17 @@ pcg_prepare_kernel(const T* __restrict__ B, const T* __restrict__ g, T* __restri
     Op_spd_inverse_apply<T, M>(A, X);
 #pragma unroll
     for (int i = 0; i < M * M; ++i) { D[n * M * M + i] = A[i]; Binv[n * M * M + i] = X[i]; }
+    if (Dp) {                              // (launch-uniform) the same two blocks as packed upper triangles, for the DPK iteration
+      constexpr int NPD = M * (M + 1) / 2;
+#pragma unroll
+      for (int r = 0; r < M; ++r)
+#pragma unroll
+        for (int c = r; c < M; ++c) {
+          const int e = r * M - (r * (r - 1)) / 2 + (c - r);
+          Dp[n * NPD + e] = A[r * M + c];
+          Bp[n * NPD + e] = X[r * M + c];
+        }
+    }
 #pragma unroll
     for (int i = 0; i < M; ++i) {
       T zi = T(0);
@@ -916,15 +928,17 @@ pcg_prepare_kernel(const T* __restrict__ B, const T* __restrict__ g, T* __restri
 }
 template <class T>
 int pcg_prepare(const void* B, const void* g, void* D, void* Binv, void* shift, void* x, void* r, void* z, void* p, void* scal,
-                double s, double dmin, double dmax, int64_t N, int m, void* stream, const void* s_dev = nullptr, void* cs = nullptr) {
+                double s, double dmin, double dmax, int64_t N, int m, void* stream, const void* s_dev = nullptr, void* cs = nullptr,
+                void* Dp = nullptr, void* Bp = nullptr) {
   if (N <= 0) return N == 0 ? PPLIE_OK : PPLIE_EBADARG;
-  if (!B || !g || !D || !Binv || !shift || !x || !r || !z || !p || !scal) return PPLIE_EBADARG;
+  if (!B || !g || !D || !Binv || !shift || !x || !r || !z || !p || !scal || (!Dp != !Bp)) return PPLIE_EBADARG;
   int64_t nb = (N + 255) / 256;
   int grid = (int)(nb < 2048 ? nb : 2048);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 #define LAUNCH(MM)                                                                                                      \
   hipLaunchKernelGGL((pcg_prepare_kernel<T, MM>), dim3(grid), dim3(256), 0, st, (const T*)B, (const T*)g, (T*)D, (T*)Binv, \
-                     (T*)shift, (T*)x, (T*)r, (T*)z, (T*)p, (T*)scal, (T)s, (T)dmin, (T)dmax, N, (const double*)s_dev, (T*)cs);
+                     (T*)shift, (T*)x, (T*)r, (T*)z, (T*)p, (T*)scal, (T)s, (T)dmin, (T)dmax, N, (const double*)s_dev, (T*)cs, \
+                     (T*)Dp, (T*)Bp);
   if (m == 6) { LAUNCH(6) } else if (m == 7) { LAUNCH(7) } else if (m == 3) { LAUNCH(3) } else return PPLIE_EBADARG;
 #undef LAUNCH
   return hipGetLastError() == hipSuccess ? PPLIE_OK : PPLIE_ELAUNCH;
@@ -1005,6 +1019,20 @@ extern "C" int pplie_pcg_prepare_coarse_f64(const void* B, const void* g, void* 
                                             int64_t N, int m, void* stream) {
   if (!cs) return pplie::PPLIE_EBADARG;
   return pplie::pcg_prepare<double>(B, g, D, Binv, shift, x, r, z, p, scal, s, dmin, dmax, N, m, stream, s_dev, cs);
+}
+// ... and with D and Binv ALSO written as packed upper triangles Dp, Bp [N + 1, m (m + 1) / 2] (one record of padding), which the
+// `_dp` forms of the two-launch iteration read instead of the full blocks (84 instead of 144 bytes per node, block and launch)
+extern "C" int pplie_pcg_prepare_coarse_dp_f32(const void* B, const void* g, void* D, void* Binv, void* Dp, void* Bp, void* shift, void* x,
+                                               void* r, void* z, void* p, void* scal, void* cs, double s, const void* s_dev, double dmin,
+                                               double dmax, int64_t N, int m, void* stream) {
+  if (!cs || !Dp || !Bp) return pplie::PPLIE_EBADARG;
+  return pplie::pcg_prepare<float>(B, g, D, Binv, shift, x, r, z, p, scal, s, dmin, dmax, N, m, stream, s_dev, cs, Dp, Bp);
+}
+extern "C" int pplie_pcg_prepare_coarse_dp_f64(const void* B, const void* g, void* D, void* Binv, void* Dp, void* Bp, void* shift, void* x,
+                                               void* r, void* z, void* p, void* scal, void* cs, double s, const void* s_dev, double dmin,
+                                               double dmax, int64_t N, int m, void* stream) {
+  if (!cs || !Dp || !Bp) return pplie::PPLIE_EBADARG;
+  return pplie::pcg_prepare<double>(B, g, D, Binv, shift, x, r, z, p, scal, s, dmin, dmax, N, m, stream, s_dev, cs, Dp, Bp);
 }
 // The start of a solve inside a captured LM trial: clear the solve's control block (what a fill kernel did) and, in the same
 // launch, fetch the damping factor of the day from `s_src` -- host-pinned memory the host rewrites between replays of the captured
@@ -1107,7 +1135,10 @@ __global__ void __launch_bounds__(256) pcg2_coarse_init_kernel(T* __restrict__ p
   }
 }
 // CZ: the two-level preconditioner (cs: the coarse sums, layout above): this kernel also reduces (Z^T q)_i per component
-template <class T, int M, bool SYM = false, bool STOP = false, bool PACK = false, bool CZ = false>
+// DPK (with PACK): D and Binv are PACKED too -- [N, M (M + 1) / 2] upper triangles (pplie_pcg_prepare_coarse's Dp / Bp): 84 instead
+// of 144 bytes per node and block; a lane handles its triangle row like an off-diagonal block's (own row from the upper part, what the
+// rows below are owed handed over by the node's lanes)
+template <class T, int M, bool SYM = false, bool STOP = false, bool PACK = false, bool CZ = false, bool DPK = false>
 __global__ void __launch_bounds__(256)
 pcg2_spmv_kernel(const int* __restrict__ ptr, const int* __restrict__ other, const T* __restrict__ HB, const T* __restrict__ D,
                  const T* __restrict__ Binv, const T* __restrict__ p, const T* __restrict__ z, T* __restrict__ q, T* scal,
@@ -1156,22 +1187,46 @@ pcg2_spmv_kernel(const int* __restrict__ ptr, const int* __restrict__ other, con
 #pragma unroll
     for (int k = 0; k < M; ++k) { uk[k] = T(0); bi[k] = T(0); }
     if (act) {
-      T pv[M];
+      constexpr int NPD = M * (M + 1) / 2;
+      const int tid = i * M - (i * (i - 1)) / 2;                    // where row i of an upper triangle starts
+      T pv[M], dv[M];
+      if constexpr (DPK) {
+        pi = p[n * M + i];
 #pragma unroll
-      for (int j = 0; j < M; ++j) pv[j] = p[n * M + j];
-      pi = pv[i];
-      T dv[M];
+        for (int k = 0; k < M; ++k) dv[k] = D[n * NPD + tid + k];   // (up to M - 1 elements past the row: masked below; Dp / Bp are padded)
 #pragma unroll
-      for (int j = 0; j < M; ++j) dv[j] = D[(n * M + i) * M + j];
-      // everything this node needs that does not depend on the neighbour list goes out HERE, in one batch: a load under its own
-      // `if (act)` further down is a branch whose join waits for vmcnt(0) -- the six elements of the Binv row after the loop were
-      // six memory round trips one after the other per group of nodes
+        for (int k = 0; k < M; ++k) bi[k] = Binv[n * NPD + tid + k];
+      } else {
 #pragma unroll
-      for (int j = 0; j < M; ++j) bi[j] = Binv[(n * M + i) * M + j];
+        for (int j = 0; j < M; ++j) pv[j] = p[n * M + j];
+        pi = pv[i];
+#pragma unroll
+        for (int j = 0; j < M; ++j) dv[j] = D[(n * M + i) * M + j];
+        // everything this node needs that does not depend on the neighbour list goes out HERE, in one batch: a load under its own
+        // `if (act)` further down is a branch whose join waits for vmcnt(0) -- the six elements of the Binv row after the loop were
+        // six memory round trips one after the other per group of nodes
+#pragma unroll
+        for (int j = 0; j < M; ++j) bi[j] = Binv[(n * M + i) * M + j];
+      }
       zi = z[n * M + i];
       const int beg = ptr[n], end = ptr[n + 1];
+      if constexpr (DPK) {
+        // D p of the node itself: the own p goes round the node's lanes by DPP shifts (as the neighbours' do below)
+        T ps[M];
+        ps[0] = pi;
 #pragma unroll
-      for (int j = 0; j < M; ++j) acc += dv[j] * pv[j];
+        for (int k = 1; k < M; ++k) ps[k] = dpp_mov<DPP_WAVE_SHL1, 0xf, 0xf>(T(0), ps[k - 1]);
+#pragma unroll
+        for (int k = 0; k < M; ++k) {
+          const bool in = k < M - i;
+          const T a0 = in ? dv[k] : T(0), b0 = in ? ps[k] : T(0);
+          acc += a0 * b0;
+          if (k > 0) uk[k] += a0 * pi;
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < M; ++j) acc += dv[j] * pv[j];
+      }
       // The neighbour indices run one pair ahead of the gathers they address: index -> p[index] is a chain of two memory round
       // trips per pair, and with ~4 pairs per node on 6 waves per SIMD that chain, not bandwidth, set the kernel's time.  The index
       // loads are UNCONDITIONAL from clamped positions (c is always a valid one): `c + 2 < end ? other[c + 2] : 0` compiled to a
@@ -1249,10 +1304,29 @@ pcg2_spmv_kernel(const int* __restrict__ ptr, const int* __restrict__ other, con
     }
     // (Binv q)_i needs the node's whole q: the M lanes of the node exchange their rows (all lanes take part)
     T bq = T(0);
+    if constexpr (DPK) {
+      T qs[M], vk[M];
+      qs[0] = acc;
 #pragma unroll
-    for (int j = 0; j < M; ++j) {
-      const T qj = __shfl(acc, sub * M + j, 64);
-      bq += bi[j] * qj;                                           // (bi = 0 on idle lanes)
+      for (int k = 1; k < M; ++k) qs[k] = dpp_mov<DPP_WAVE_SHL1, 0xf, 0xf>(T(0), qs[k - 1]);
+#pragma unroll
+      for (int k = 0; k < M; ++k) {
+        const bool in = k < M - i;
+        const T a0 = in ? bi[k] : T(0), b0 = in ? qs[k] : T(0);   // (bi = 0 on idle lanes)
+        bq += a0 * b0;
+        vk[k] = a0 * acc;
+      }
+#pragma unroll
+      for (int d = 1; d < M; ++d) {
+        const T t = __shfl_up(vk[d], d, 64);
+        if (i >= d) bq += t;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < M; ++j) {
+        const T qj = __shfl(acc, sub * M + j, 64);
+        bq += bi[j] * qj;                                           // (bi = 0 on idle lanes)
+      }
     }
     if (act) {
       a_pq += acc * pi;
@@ -1295,7 +1369,7 @@ __device__ __forceinline__ void slot_totals_wg(const T* const (&base)[NQ], T (&o
 
 // M lanes per node (the spmv kernel's layout): lane i owns component i, the node's new residual goes round its lanes by
 // shuffles -- 10 loads per component instead of 21
-template <class T, int M, bool STOP = false, bool CZ = false>
+template <class T, int M, bool STOP = false, bool CZ = false, bool DPK = false>      // DPK: Binv packed (see pcg2_spmv_kernel)
 __global__ void __launch_bounds__(256)
 pcg2_step_kernel(T* __restrict__ x, T* r0, T* r1, T* __restrict__ p, const T* __restrict__ q, T* __restrict__ z,
                  const T* __restrict__ Binv, T* scal, int* it, int64_t N, T* cs = nullptr) {
@@ -1322,8 +1396,15 @@ pcg2_step_kernel(T* __restrict__ x, T* r0, T* r1, T* __restrict__ p, const T* __
     o.q = q[e];
     o.p = p[e];
     o.x = x[e];
+    if constexpr (DPK) {
+      constexpr int NPD = M * (M + 1) / 2;
+      const T* row = Binv + n * NPD + (i * M - (i * (i - 1)) / 2);
 #pragma unroll
-    for (int j = 0; j < M; ++j) o.b[j] = Binv[e * M + j];
+      for (int k = 0; k < M; ++k) o.b[k] = row[k];               // (row i of the upper triangle; what lies beyond is masked below)
+    } else {
+#pragma unroll
+      for (int j = 0; j < M; ++j) o.b[j] = Binv[e * M + j];
+    }
   };
   Rows cur;
   fetch(wave * NPW, cur);
@@ -1367,10 +1448,29 @@ pcg2_step_kernel(T* __restrict__ x, T* r0, T* r1, T* __restrict__ p, const T* __
     }
     const T re = cur.r - alpha * cur.q;
     T ze = T(0);
+    if constexpr (DPK) {
+      T rs[M], vk[M];
+      rs[0] = re;
 #pragma unroll
-    for (int j = 0; j < M; ++j) {
-      const T rj = __shfl(re, (sub * M + j) & 63, 64);
-      ze += cur.b[j] * rj;
+      for (int k = 1; k < M; ++k) rs[k] = dpp_mov<DPP_WAVE_SHL1, 0xf, 0xf>(T(0), rs[k - 1]);
+#pragma unroll
+      for (int k = 0; k < M; ++k) {
+        const bool in = k < M - i && active_lane;
+        const T a0 = in ? cur.b[k] : T(0), b0 = in ? rs[k] : T(0);
+        ze += a0 * b0;
+        vk[k] = a0 * re;
+      }
+#pragma unroll
+      for (int d = 1; d < M; ++d) {
+        const T t = __shfl_up(vk[d], d, 64);
+        if (i >= d) ze += t;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < M; ++j) {
+        const T rj = __shfl(re, (sub * M + j) & 63, 64);
+        ze += cur.b[j] * rj;
+      }
     }
     if (act) {
       x[e] = cur.x + alpha * cur.p;
@@ -1396,17 +1496,21 @@ pcg2_step_kernel(T* __restrict__ x, T* r0, T* r1, T* __restrict__ p, const T* __
 template <class T>
 int pcg2_spmv(const void* ptr, const void* other, const void* HB, const void* D, const void* Binv, const void* p, const void* z,
               void* q, void* scal, void* rr_hist, void* it, int cap, int64_t N, int m, void* stream, const void* blk = nullptr,
-              bool stop = false, double tol2 = 0.0, bool pack = false, void* cs = nullptr) {
+              bool stop = false, double tol2 = 0.0, bool pack = false, void* cs = nullptr, bool dpk = false) {
   if (N <= 0) return N == 0 ? PPLIE_OK : PPLIE_EBADARG;
   if (!ptr || !other || !HB || !D || !Binv || !p || !z || !q || !scal || !rr_hist || !it) return PPLIE_EBADARG;
-  if (cs && !(pack && stop)) return PPLIE_EBADARG;                  // (the two-level variant exists for the packed, device-stopped iteration)
+  if ((cs && !(pack && stop)) || (dpk && !cs)) return PPLIE_EBADARG;  // (the two-level variant exists for the packed, device-stopped iteration)
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 #define LAUNCH(MM)                                                                                                    \
   {                                                                                                                   \
     int64_t waves = (N + (64 / MM) - 1) / (64 / MM);                                                                  \
     int64_t blocks = (waves + 3) / 4;                                                                                 \
     int grid = (int)(blocks < 4096 ? blocks : 4096);                                                                  \
-    if (cs)                                                                                                           \
+    if (cs && dpk)                                                                                                    \
+      hipLaunchKernelGGL((pcg2_spmv_kernel<T, MM, false, true, true, true, true>), dim3(grid), dim3(256), 0, st, (const int*)ptr, \
+                         (const int*)other, (const T*)HB, (const T*)D, (const T*)Binv, (const T*)p, (const T*)z, (T*)q, \
+                         (T*)scal, (T*)rr_hist, (int*)it, cap, N, (const int*)nullptr, (T)tol2, (T*)cs);                \
+    else if (cs)                                                                                                      \
       hipLaunchKernelGGL((pcg2_spmv_kernel<T, MM, false, true, true, true>), dim3(grid), dim3(256), 0, st, (const int*)ptr, \
                          (const int*)other, (const T*)HB, (const T*)D, (const T*)Binv, (const T*)p, (const T*)z, (T*)q, \
                          (T*)scal, (T*)rr_hist, (int*)it, cap, N, (const int*)nullptr, (T)tol2, (T*)cs);                \
@@ -1437,8 +1541,8 @@ int pcg2_spmv(const void* ptr, const void* other, const void* HB, const void* D,
 }
 template <class T>
 int pcg2_step(void* x, void* r, void* r_alt, void* p, const void* q, void* z, const void* Binv, void* scal, void* it, int64_t N,
-              int m, void* stream, bool stop = false, void* cs = nullptr) {
-  if (N <= 0 || m <= 0 || m > 8) return PPLIE_EBADARG;
+              int m, void* stream, bool stop = false, void* cs = nullptr, bool dpk = false) {
+  if (N <= 0 || m <= 0 || m > 8 || (dpk && !cs)) return PPLIE_EBADARG;
   if (!x || !r || !r_alt || r == r_alt || !p || !q || !z || !Binv || !scal || !it) return PPLIE_EBADARG;
   if (cs && !stop) return PPLIE_EBADARG;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -1446,7 +1550,10 @@ int pcg2_step(void* x, void* r, void* r_alt, void* p, const void* q, void* z, co
   {                                                                                                                    \
     const int64_t blocks = ((N + (64 / MM) - 1) / (64 / MM) + 3) / 4;                                                  \
     const int grid = (int)(blocks < 1024 ? blocks : 1024);                                                             \
-    if (cs)                                                                                                            \
+    if (cs && dpk)                                                                                                     \
+      hipLaunchKernelGGL((pcg2_step_kernel<T, MM, true, true, true>), dim3(grid), dim3(256), 0, st, (T*)x, (T*)r, (T*)r_alt, (T*)p, \
+                         (const T*)q, (T*)z, (const T*)Binv, (T*)scal, (int*)it, N, (T*)cs);                            \
+    else if (cs)                                                                                                       \
       hipLaunchKernelGGL((pcg2_step_kernel<T, MM, true, true>), dim3(grid), dim3(256), 0, st, (T*)x, (T*)r, (T*)r_alt, (T*)p, \
                          (const T*)q, (T*)z, (const T*)Binv, (T*)scal, (int*)it, N, (T*)cs);                            \
     else if (stop)                                                                                                     \
@@ -1521,6 +1628,21 @@ extern "C" int pplie_pcg2_spmv_pack_f64(const void* ptr, const void* other, cons
   }
 PPLIE_PCG2_COARSE(f32, float)
 PPLIE_PCG2_COARSE(f64, double)
+// the same pair reading PACKED diagonal blocks: D = Dp, Binv = Bp of pplie_pcg_prepare_coarse_dp
+#define PPLIE_PCG2_COARSE_DP(SFX, T)                                                                                                \
+  extern "C" int pplie_pcg2_spmv_pack_coarse_dp_##SFX(const void* ptr, const void* other, const void* HB, const void* Dp, const void* Bp, \
+                                                      const void* p, const void* z, void* q, void* scal, void* cs, void* rr_hist,     \
+                                                      void* it, int cap, int64_t N, int m, double tol2, void* stream) {               \
+    if (!cs) return pplie::PPLIE_EBADARG;                                                                                            \
+    return pplie::pcg2_spmv<T>(ptr, other, HB, Dp, Bp, p, z, q, scal, rr_hist, it, cap, N, m, stream, nullptr, true, tol2, true, cs, true); \
+  }                                                                                                                                 \
+  extern "C" int pplie_pcg2_step_coarse_dp_##SFX(void* x, void* r, void* r_alt, void* p, const void* q, void* z, const void* Bp,     \
+                                                 void* scal, void* cs, void* it, int64_t N, int m, void* stream) {                   \
+    if (!cs) return pplie::PPLIE_EBADARG;                                                                                            \
+    return pplie::pcg2_step<T>(x, r, r_alt, p, q, z, Bp, scal, it, N, m, stream, true, cs, true);                                    \
+  }
+PPLIE_PCG2_COARSE_DP(f32, float)
+PPLIE_PCG2_COARSE_DP(f64, double)
 
 extern "C" int pplie_pcg2_step_stop_f32(void* x, void* r, void* r_alt, void* p, const void* q, void* z, const void* Binv, void* scal,
                                         void* it, int64_t N, int m, void* stream) {

@@ -62,6 +62,8 @@ _PCG2_SPMV_CZ_SIG = [ctypes.c_void_p] * 12 + [ctypes.c_int, ctypes.c_int64, ctyp
 _PCG2_STEP_CZ_SIG = [ctypes.c_void_p] * 10 + [ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]
 _CZ_INIT_SIG = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]
 _PCG2_REPORT_SIG = [ctypes.c_void_p] * 3 + [ctypes.c_int, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p]
+_PREP_CZ_DP_SIG = [ctypes.c_void_p] * 13 + [ctypes.c_double, ctypes.c_void_p, ctypes.c_double, ctypes.c_double, ctypes.c_int64, ctypes.c_int,
+                                             ctypes.c_void_p]
 import os as _os
 # graphs up to this many nodes run the whole PCG solve in ONE persistent launch (csrc/pcg_persist.hip); larger ones need
 # the whole chip's bandwidth per iteration and keep the two-launch hipGraph iteration
@@ -325,6 +327,8 @@ class FusedPCG:
     # the whole LM trial of a graph BEYOND the persistent solve as one hipGraph replay too (optim/pgograph.py): the two-launch iterations
     # run unwatched, at most `unwatched_max` of them per capture (PPLIE_CAPTURE_LARGE=0: the watched chunks of eight only)
     capture_large = _os.environ.get("PPLIE_CAPTURE_LARGE", "1") != "0"
+    # the two-level two-launch iteration reads D and Binv as packed upper triangles too (pplie_*_dp; PPLIE_PACK_DIAG=0: full blocks)
+    pack_diag = _os.environ.get("PPLIE_PACK_DIAG", "1") != "0"
     unwatched_max = 48
 
     def __init__(self, E, K, dr, m, N, dtype, device, has_w, check_every):
@@ -364,6 +368,8 @@ class FusedPCG:
         self.sym = False                                           # HB holds one block per edge
         self.stop_tol2 = None                                      # tol^2 when the captured iterations carry the device-side stop
         self.iterations_seen = 0                                   # the longest watched two-launch solve so far (sizes a captured trial)
+        self.Dp = self.Bp = None                                   # packed upper triangles of D / Binv (the _dp iteration; allocated on first use)
+        self.dp = False                                            # this solve's iteration reads them
         self.unwatched_iterations = 24                             # iterations a captured trial queues (PgoGraphStep sets it)
         self._csr_obj = None
 
@@ -418,14 +424,16 @@ class FusedPCG:
             # (stop: convergence test on the device -- a launch after the converging iteration returns at once)
             stop = self.stop_tol2 is not None and self.sym in (False, 'pack')
             if self.cz and stop and self.sym == 'pack':
-                code = lib.symbol("pplie_pcg2_spmv_pack_coarse" + self.sfx, _PCG2_SPMV_CZ_SIG)(
-                    self.ptr.data_ptr(), self.other.data_ptr(), self.HB.data_ptr(), self.D.data_ptr(), self.Binv.data_ptr(),
+                dp = "_dp" if self.dp else ""
+                Dm, Bm = (self.Dp, self.Bp) if self.dp else (self.D, self.Binv)
+                code = lib.symbol("pplie_pcg2_spmv_pack_coarse" + dp + self.sfx, _PCG2_SPMV_CZ_SIG)(
+                    self.ptr.data_ptr(), self.other.data_ptr(), self.HB.data_ptr(), Dm.data_ptr(), Bm.data_ptr(),
                     self.p.data_ptr(), self.z.data_ptr(), self.q.data_ptr(), self.scal.data_ptr(), self.cs.data_ptr(),
                     self.rr_hist.data_ptr(), self.it.data_ptr(), self.cap, self.N, self.m, self.stop_tol2, st)
                 _C.check(code, "pplie_pcg2_spmv_pack_coarse")
-                code = lib.symbol("pplie_pcg2_step_coarse" + self.sfx, _PCG2_STEP_CZ_SIG)(
+                code = lib.symbol("pplie_pcg2_step_coarse" + dp + self.sfx, _PCG2_STEP_CZ_SIG)(
                     self.x.data_ptr(), self.r.data_ptr(), self.r2.data_ptr(), self.p.data_ptr(), self.q.data_ptr(),
-                    self.z.data_ptr(), self.Binv.data_ptr(), self.scal.data_ptr(), self.cs.data_ptr(), self.it.data_ptr(), self.N, self.m, st)
+                    self.z.data_ptr(), Bm.data_ptr(), self.scal.data_ptr(), self.cs.data_ptr(), self.it.data_ptr(), self.N, self.m, st)
                 _C.check(code, "pplie_pcg2_step_coarse")
                 return
             if self.sym == 'pack':
@@ -475,6 +483,19 @@ class FusedPCG:
                          self.it.data_ptr(), self.cap, self.N, self.m, st)
             _C.check(code, "pplie_pcg_stage")
 
+    def _prepare_coarse(self, lin, s, s_dev, dmin, dmax):
+        """pplie_pcg_prepare_coarse (+ the packed triangles of D / Binv when this solve's iteration reads those)"""
+        st = _C.stream_ptr(self.device)
+        if self.dp:
+            return _C.library().symbol("pplie_pcg_prepare_coarse_dp" + self.sfx, _PREP_CZ_DP_SIG)(
+                lin.B.data_ptr(), lin.g.data_ptr(), self.D.data_ptr(), self.Binv.data_ptr(), self.Dp.data_ptr(), self.Bp.data_ptr(),
+                self.shift.data_ptr(), self.x.data_ptr(), self.r.data_ptr(), self.z.data_ptr(), self.p.data_ptr(), self.scal.data_ptr(),
+                self.cs.data_ptr(), float(s), s_dev, float(dmin), float(dmax), self.N, self.m, st)
+        return _C.library().symbol("pplie_pcg_prepare_coarse" + self.sfx, _PREP_CZ_SIG)(
+            lin.B.data_ptr(), lin.g.data_ptr(), self.D.data_ptr(), self.Binv.data_ptr(), self.shift.data_ptr(),
+            self.x.data_ptr(), self.r.data_ptr(), self.z.data_ptr(), self.p.data_ptr(), self.scal.data_ptr(), self.cs.data_ptr(),
+            float(s), s_dev, float(dmin), float(dmax), self.N, self.m, st)
+
     def solve(self, lin, s, dmin, dmax, tol, maxiter, group, plain=False, defer=False):
         """Solve (H + damping) x = -g for the linearisation ``lin`` (raw block diagonal ``lin.B``, gradient ``lin.g``)
         with the LM clamp [dmin, dmax] and compounded damping factor ``s`` folded in by ``pplie_pcg_prepare``.
@@ -516,6 +537,12 @@ class FusedPCG:
                   and ((persistent and FusedPCG.ghost and not self.__dict__.get('_no_ghost')) or two))
         if cz != self.cz:
             self.cz, self.graph = cz, None                          # (the captured iterations differ)
+        dp = bool(cz and two and FusedPCG.pack_diag)
+        if dp and self.Dp is None:
+            npd = self.m * (self.m + 1) // 2
+            self.Dp, self.Bp = (torch.zeros((self.N + 1, npd), dtype=self.dtype, device=self.device)[:self.N] for _ in range(2))
+        if dp != self.dp:
+            self.dp, self.graph = dp, None
         with _C._on_device(self.device):
             # one launch: D = clamped + damped block diagonal, Binv = D^-1, shift, x = 0, r = -g, z = Binv r, p = z, r.z, |g|^2
             if s_dev is not None:
@@ -527,10 +554,7 @@ class FusedPCG:
                 if self.cz and two:
                     # (a captured trial on a graph beyond the persistent solve: the two-launch iteration's coarse sums, the damping
                     #  factor from the device scalar pplie_pcg_begin has just filled)
-                    code = _C.library().symbol("pplie_pcg_prepare_coarse" + self.sfx, _PREP_CZ_SIG)(
-                        lin.B.data_ptr(), lin.g.data_ptr(), self.D.data_ptr(), self.Binv.data_ptr(), self.shift.data_ptr(),
-                        self.x.data_ptr(), self.r.data_ptr(), self.z.data_ptr(), self.p.data_ptr(), self.scal.data_ptr(), self.cs.data_ptr(),
-                        1.0, self.s_device.data_ptr(), float(dmin), float(dmax), self.N, self.m, _C.stream_ptr(self.device))
+                    code = self._prepare_coarse(lin, 1.0, self.s_device.data_ptr(), dmin, dmax)
                     _C.check(code, "pplie_pcg_prepare_coarse")
                     code = _C.library().symbol("pplie_pcg2_coarse_init" + self.sfx, _CZ_INIT_SIG)(
                         self.p.data_ptr(), self.cs.data_ptr(), self.N, self.m, _C.stream_ptr(self.device))
@@ -541,10 +565,7 @@ class FusedPCG:
                         self.s_device.data_ptr(), float(dmin), float(dmax), self.N, self.m, _C.stream_ptr(self.device))
             elif self.cz and two:
                 # (the persistent solve sums E and Z^T r_0 itself, in its first exchange; the two-launch iteration gets them here)
-                code = _C.library().symbol("pplie_pcg_prepare_coarse" + self.sfx, _PREP_CZ_SIG)(
-                    lin.B.data_ptr(), lin.g.data_ptr(), self.D.data_ptr(), self.Binv.data_ptr(), self.shift.data_ptr(),
-                    self.x.data_ptr(), self.r.data_ptr(), self.z.data_ptr(), self.p.data_ptr(), self.scal.data_ptr(), self.cs.data_ptr(),
-                    float(s), None, float(dmin), float(dmax), self.N, self.m, _C.stream_ptr(self.device))
+                code = self._prepare_coarse(lin, float(s), None, dmin, dmax)
                 _C.check(code, "pplie_pcg_prepare_coarse")
                 code = _C.library().symbol("pplie_pcg2_coarse_init" + self.sfx, _CZ_INIT_SIG)(
                     self.p.data_ptr(), self.cs.data_ptr(), self.N, self.m, _C.stream_ptr(self.device))

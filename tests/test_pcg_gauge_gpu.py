@@ -84,3 +84,26 @@ def test_non_antisymmetric_linearisations_keep_block_jacobi():
     opt.step((edges, rel))
     assert opt.linearization == "graph"
     assert all(not w.cz for w in (opt.__dict__.get('_pcg_workspaces') or {}).values())
+
+
+@pytest.mark.parametrize("dtype,tol,eps", [(torch.float64, 1e-13, 1e-8), (torch.float32, 1e-5, 5e-4)])
+def test_packed_diagonal_blocks_give_the_same_solve(dtype, tol, eps, monkeypatch):
+    """The two-level two-launch iteration reading D / Binv as packed upper triangles (pplie_pcg_prepare_coarse_dp, pplie_pcg2_*_dp,
+    csrc/graph.hip DPK) against the same iteration on the full blocks: one damped system, the same step (Binv enters through its
+    upper triangle, i.e. exactly symmetrised -- a rounding-level change of the preconditioner), and the triangles themselves."""
+    edges, rel, init = _synthetic_graph(40_000, 160_000, dtype)
+    sol = {}
+    for dp in (True, False):
+        monkeypatch.setattr(posegraph.FusedPCG, "pack_diag", dp, raising=False)
+        graph = PoseGraph(pp.SE3(init.tensor().clone()))
+        opt = _lm(graph, True, tol, maxiter=20000)
+        opt.step((edges, rel))
+        wsp = [w for w in opt._pcg_workspaces.values()]
+        assert len(wsp) == 1 and wsp[0].cz and wsp[0].dp == dp and wsp[0].sym == 'pack'
+        sol[dp] = (graph.nodes.detach().tensor().clone(), opt.solver.iterations, wsp[0])
+    d = (pp.SE3(sol[True][0]).Inv() @ pp.SE3(sol[False][0])).Log().tensor().abs().max().item()
+    assert d <= eps, (d, sol[True][1], sol[False][1])
+    assert abs(sol[True][1] - sol[False][1]) <= max(2, sol[False][1] // 10), (sol[True][1], sol[False][1])
+    w = sol[True][2]
+    iu = torch.triu_indices(6, 6)
+    assert torch.equal(w.Dp, w.D[:, iu[0], iu[1]]) and torch.equal(w.Bp, w.Binv[:, iu[0], iu[1]])
