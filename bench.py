@@ -481,13 +481,16 @@ def pgo_lm_rate(dev, nodes=10_000, edges=40_000, steps=3, reps=5, with_static=Tr
     else:
         # two launches per iteration (pcg2_spmv_pack + pcg2_step), every iteration streams the packed blocks: SURVEY 8(d) C4's
         # 400 B/edge is the un-packed figure; the packed layout moves 84 B per incidence + 2 x 144 B per node + the vectors
-        it_bytes = 84.0 * 2 * edges + (144.0 * 2 + 24.0 * 6) * nodes + 4.0 * 2 * edges
+        from pypose_amd.optim.posegraph import FusedPCG as _F
+        diag = 84.0 if getattr(_F, "pack_diag", False) else 144.0     # D and Binv as packed upper triangles (round 5) or full blocks
+        it_bytes = 84.0 * 2 * edges + (diag * 2 + 24.0 * 6) * nodes + 4.0 * 2 * edges
         step_bytes = its_mean * it_bytes + 388.0 * edges + 168.0 * nodes
         roof = {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBPS, "achieved": step_bytes / dt / 1e9,
                 "frac": step_bytes / dt / 1e9 / HBM_PEAK_GBPS, "algorithmic_bytes_per_step": step_bytes,
                 "algorithmic_bytes_per_pcg_iteration": it_bytes, "mean_pcg_iterations": its_mean,
                 "us_per_pcg_iteration_incl_step_overheads": dt * 1e6 / max(its_mean, 1.0),
-                "per": "LM step (linearise + mean PCG iterations x packed blocks 84 B/incidence, D and Binv 144 B/node each, vectors)",
+                "per": f"LM step (linearise + mean PCG iterations x packed blocks 84 B/incidence, D and Binv {diag:.0f} B/node each, vectors)",
+                "captured_trial": bool(getattr(_F, "capture_large", False)),
                 "note": "the iteration is bound by the rate the memory system serves its gathers (profiles/r04/EXPERIMENTS.md: "
                         "waves 66 % parked on s_waitcnt, insensitive to occupancy and to trips per wave), counted fetch 1.5x algorithmic"}
     out = {"metric": f"LM iters/sec (PGO {nodes} poses / {edges} edges)", "value": 1.0 / dt, "unit": "LM steps/s", "nodes": nodes,
