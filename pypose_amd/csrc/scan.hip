@@ -1146,7 +1146,10 @@ __global__ void __launch_bounds__(WAVES * 64, 3)
 imu_cov_seg_kernel(const T* __restrict__ dt, const T* __restrict__ gyro, const T* __restrict__ accel, const T* __restrict__ rout,
                    const T* __restrict__ rw, const T* __restrict__ C, const T* __restrict__ init_cov, const T* __restrict__ gyro_cov,
                    int64_t gc_sb, int64_t gc_sf, const T* __restrict__ acc_cov, int64_t ac_sb, int64_t ac_sf, T g0, T g1, T g2,
-                   T* __restrict__ cov, int64_t B, int64_t F) {
+                   T* __restrict__ cov, int64_t B, int64_t F, int64_t in_mask = -1) {
+  // in_mask (tools/micro/imu_cov_chain.hip; the library passes -1): sequence b reads the INPUT streams of sequence b & in_mask --
+  // a wave-uniform AND on the row address, the same instructions and registers otherwise.  With a small mask the inputs of all B
+  // sequences are a few MB that stay cache-resident: what this kernel costs when its bytes are free.
   __shared__ T sd[WAVES * LS * 11 * 64];          // [wave][step of the segment][field][lane]
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int64_t b = (int64_t)blockIdx.x * WAVES + wv;
@@ -1182,7 +1185,7 @@ imu_cov_seg_kernel(const T* __restrict__ dt, const T* __restrict__ gyro, const T
     for (int s = 0; s < LS; ++s) {
       const int64_t j = j0 + s;
       const bool ok = j < F;
-      const int64_t row = b * F + (ok ? j : 0);
+      const int64_t row = (b & in_mask) * F + (ok ? j : 0);
       T ro[4], rwq[4], ac[3], gyv[3], qq[4];
       // (unconditional loads from the clamped row, THEN the selects: `ok ? p[i] : d` is a branch around every load with a wait at
       //  its join -- the LS steps' loads went out one after the other)
