@@ -159,7 +159,10 @@ class graph_capture:
     another.)"""
 
     def __init__(self, g):
-        self.ctx = torch.cuda.graph(g)
+        # thread_local: only THIS thread's calls are policed while the stream captures -- another thread's event query or
+        # allocation (the RCCL watchdog of a process that also holds a process group, a pinned-memory loader) must not
+        # invalidate a capture it has nothing to do with
+        self.ctx = torch.cuda.graph(g, capture_error_mode="thread_local")
 
     def __enter__(self):
         import gc
