@@ -654,6 +654,10 @@ class FusedPCG:
                 tol2 = float(tol) * float(tol)
                 if self.stop_tol2 != tol2:
                     self.stop_tol2, self.graph = tol2, None        # (tol^2 is a launch argument of the captured chunk)
+                if defer == 'inplace' and self.sym != 'pack':
+                    # (a small graph whose persistent solve did not fit this device ends up here with full blocks and a capture sized
+                    #  for nothing: no unwatched route -- the capture is abandoned once, as before there was one)
+                    raise RuntimeError("the two-launch iteration on full blocks does not run unwatched")
                 if defer == 'inplace':
                     # Inside the capture of a whole LM trial (optim/pgograph.py): nobody reads the control word between the iterations
                     # and the trial's tail.  `unwatched_iterations` launches of the pair are queued outright (those behind the converging
