@@ -641,8 +641,8 @@ class LevenbergMarquardt(_Optimizer):
             wsps = [w for w in (d.get('_pcg_workspaces') or {}).values() if w.N == lin.N and w.sym == 'pack' and w.iterations_seen > 0]
             ok = (FusedPCG.capture_large and FusedPCG.device_stop and bool(getattr(lin, 'HB_pack', False)) and len(wsps) == 1)
             if ok:
-                unwatched = max(16, -(-(wsps[0].iterations_seen + 1) // 8) * 8)
-                ok = unwatched <= min(FusedPCG.unwatched_max, self.solver.maxiter or FusedPCG.unwatched_max)
+                unwatched = FusedPCG.unwatched_for(wsps[0].iterations_seen, self.solver.maxiter)
+                ok = unwatched is not None
         cache = d.get('_structure_cache') or {}
         hit = cache.get("program")
         if not ok or hit is None or hit[2] != "pgo" or cache.get("fused") is not True:

@@ -331,6 +331,16 @@ class FusedPCG:
     pack_diag = _os.environ.get("PPLIE_PACK_DIAG", "1") != "0"
     unwatched_max = 48
 
+    @staticmethod
+    def unwatched_for(iterations_seen, maxiter=None):
+        """How many iterations a captured trial queues after watched solves that took up to ``iterations_seen``: the next multiple of
+        eight above it (at least 16), or None when that exceeds ``unwatched_max`` / the solver's ``maxiter`` -- every launch behind the
+        converging iteration costs ~4.6 us, so a capture sized far beyond the solves gives back what it saves in host latency."""
+        if iterations_seen <= 0:
+            return None
+        k = max(16, -(-(int(iterations_seen) + 1) // 8) * 8)
+        return k if k <= min(FusedPCG.unwatched_max, maxiter or FusedPCG.unwatched_max) else None
+
     def __init__(self, E, K, dr, m, N, dtype, device, has_w, check_every):
         z = lambda *s: torch.zeros(s, dtype=dtype, device=device)
         self.key = (E, K, dr, m, N, dtype, device, has_w, check_every)
