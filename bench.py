@@ -491,8 +491,15 @@ def pgo_lm_rate(dev, nodes=10_000, edges=40_000, steps=3, reps=5, with_static=Tr
                 "us_per_pcg_iteration_incl_step_overheads": dt * 1e6 / max(its_mean, 1.0),
                 "per": f"LM step (linearise + mean PCG iterations x packed blocks 84 B/incidence, D and Binv {diag:.0f} B/node each, vectors)",
                 "captured_trial": bool(getattr(_F, "capture_large", False)),
-                "note": "the iteration is bound by the rate the memory system serves its gathers (profiles/r04/EXPERIMENTS.md: "
-                        "waves 66 % parked on s_waitcnt, insensitive to occupancy and to trips per wave), counted fetch 1.5x algorithmic"}
+                "note": "the iteration is bound by the rate the memory system serves its gathers' REQUESTS (profiles/r04 and r05 "
+                        "EXPERIMENTS.md: waves 66 % parked on s_waitcnt, insensitive to occupancy, to trips per wave and -- within 2 us -- "
+                        "to whether the gathered rows hit the L2), counted fetch 1.4x algorithmic"}
+        det = traffic.get("detail", {})
+        sp, stp = det.get("pcg2_spmv") or {}, det.get("pcg2_step") or {}
+        if sp.get("fetch_r05") and stp.get("fetch_r05"):
+            roof["traffic_per_pcg_iteration"] = sp["fetch_r05"] + sp.get("write_r05", 0.0) + stp["fetch_r05"] + stp.get("write_r05", 0.0)
+            roof["traffic_source"] = f"profiles/pmc_traffic.json ({traffic.get('_stamp', 'unstamped')}): FETCH_SIZE x 2 + WRITE_SIZE of " \
+                                     "pcg2_spmv + pcg2_step, an earlier run of these kernels on this workload"
     out = {"metric": f"LM iters/sec (PGO {nodes} poses / {edges} edges)", "value": 1.0 / dt, "unit": "LM steps/s", "nodes": nodes,
            "edges": edges, "path": opt.linearization, "initial_loss": l0, "losses": losses, "pcg_iterations": its,
            "steps_per_repetition": steps, "repetitions_ms_per_step": [round(t * 1e3, 3) for t in times], "roofline": roof}
