@@ -159,10 +159,12 @@ pgo_residual_kernel(const T* __restrict__ nodes, const int64_t* __restrict__ idx
 }
 
 constexpr int kPgoPartials = 1024;     // = PPLIE_PGO_PARTIALS in include/pplie.h
+constexpr int kPackLastGrid = 256;     // residual grids up to this size let their last workgroup pack (pgo_trial_tail)
 
 // ---------------------------------------------------------------------------------------------
 // The tail of one captured LM trial (optim/pgograph.py): everything between the linear solve and the host's decision,
-// TWO launches (four until round 5: at 10 k nodes each dependent launch costs ~4.5 us whatever it does) and no tensor ops --
+// TWO launches (three when the residual grid exceeds kPackLastGrid; four until round 5: at 10 k nodes each dependent launch costs
+// ~4.5 us whatever it does) and no tensor ops --
 //   first     gain + retract side by side (pgo_tail_first_kernel);   second   residual, whose last workgroup packs --
 //   retract   nodes <- Exp(x_n) nodes_n   (lietensor.py:60-65, optimizer.py update_parameter); the old rows go to `backup` if given
 //   residual  per edge at the candidate: per-workgroup partials of |r|^2, the trial's loss (optimizer.py:672; pgo_residual_kernel)
@@ -227,6 +229,13 @@ __device__ __forceinline__ void pgo_trial_pack(const T* partial, int nparts, con
   if (q == 0) __hip_atomic_store(out + 7, (double)seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// the pack as a launch of its own (large grids: see pgo_trial_tail)
+template <class T>
+__global__ void __launch_bounds__(64)
+pgo_trial_pack_kernel(const T* __restrict__ partial, int nparts, const T* __restrict__ pcg_info, unsigned long long* state, double* out) {
+  pgo_trial_pack<T>(partial, nparts, pcg_info, state, out, false);
+}
+
 // gain-ratio terms of the relative-pose program (strategy.py:144, :261): its two blocks per edge are opposite (J_e0 = -J_e1, see
 // pgo_linearize_kernel), so JD_e = J_e1 (x_j - x_i) and only the second block is read -- 144 instead of 288 bytes per edge.
 // M lanes per edge, lane i owns row i: the wave reads 10 consecutive blocks as one contiguous run (the generic graph_gain_kernel,
@@ -285,9 +294,19 @@ int pgo_trial_tail(void* nodes, void* backup, const void* idx, const void* Z, co
   if (rb + grid >= (int64_t)1 << 31) return PPLIE_EBADARG;
   hipLaunchKernelGGL((pgo_tail_first_kernel<T>), dim3((unsigned)(grid + rb)), dim3(256), 0, st, grid, (const T*)J, (const int64_t*)idx,
                      (const T*)x, (const T*)R, part + kPgoPartials, E, (T*)nodes, (T*)backup, N, (unsigned long long*)state);
-  hipLaunchKernelGGL((pgo_residual_kernel<T, BLOCK, true>), dim3(grid), dim3(BLOCK), 0, st, (const T*)nodes, (const int64_t*)idx,
-                     (const T*)Z, (T*)nullptr, part, E, RobustParam<T>{RK_NONE, T(0), T(0)}, (const T*)pcg_info,
-                     (unsigned long long*)state, (double*)out);
+  // The last-arriving workgroup packs only while the arrivals are few: every workgroup's ticket is a release on ONE address -- 157
+  // of them (10 k nodes / 40 k edges) cost about what the pack's own launch did (residual + pack 8.8 -> 9.1 us, one launch less), 1024
+  // (4e5 edges) turned an 11.6 us residual kernel into 41.5 us (profiles/r05/lm_pgo_100k_kernel_stats.csv).
+  if (grid <= kPackLastGrid) {
+    hipLaunchKernelGGL((pgo_residual_kernel<T, BLOCK, true>), dim3(grid), dim3(BLOCK), 0, st, (const T*)nodes, (const int64_t*)idx,
+                       (const T*)Z, (T*)nullptr, part, E, RobustParam<T>{RK_NONE, T(0), T(0)}, (const T*)pcg_info,
+                       (unsigned long long*)state, (double*)out);
+  } else {
+    hipLaunchKernelGGL((pgo_residual_kernel<T, BLOCK>), dim3(grid), dim3(BLOCK), 0, st, (const T*)nodes, (const int64_t*)idx,
+                       (const T*)Z, (T*)nullptr, part, E, RobustParam<T>{RK_NONE, T(0), T(0)});
+    hipLaunchKernelGGL((pgo_trial_pack_kernel<T>), dim3(1), dim3(64), 0, st, (const T*)part, grid, (const T*)pcg_info,
+                       (unsigned long long*)state, (double*)out);
+  }
   return hipGetLastError() == hipSuccess ? PPLIE_OK : PPLIE_ELAUNCH;
 }
 
