@@ -705,12 +705,20 @@ pcg_ghost_kernel(const int* __restrict__ ptr, const int* __restrict__ slot, cons
   const bool prof = cap < 0;
   if (prof) cap = -cap;
   const bool clocked = prof && blockIdx.x == gridDim.x / 2 && threadIdx.x == 0;
-  unsigned long long tk[5] = {0, 0, 0, 0, 0}, t_prev = clocked ? wall_clock64() : 0;
+  // (the accumulators live in LDS, not in registers: five 64-bit counters and the previous reading were 12 VGPRs of EVERY lane for the
+  //  whole loop -- at this kernel's 128-VGPR cap they pushed twelve of the ghosts' Binv rows into scratch, reloaded one by one inside
+  //  every iteration: <float, 6, CZ> spilled 24 VGPRs with them and spills 2 without, profiles/r05/kernel_resources.txt.  32-bit
+  //  ticks: differences are taken modulo 2^32 (43 s).)
+  __shared__ unsigned tk[6];                                   // tk[5]: the previous reading
+  if (clocked) {
+    for (int q = 0; q < 5; ++q) tk[q] = 0u;
+    tk[5] = (unsigned)wall_clock64();
+  }
 #define PPLIE_TICK(slot)                                       \
   if (clocked) {                                               \
-    const unsigned long long t_now = wall_clock64();           \
-    tk[slot] += t_now - t_prev;                                \
-    t_prev = t_now;                                            \
+    const unsigned t_now = (unsigned)wall_clock64();           \
+    tk[slot] += t_now - tk[5];                                 \
+    tk[5] = t_now;                                             \
   }
   for (;; ++k) {
     const unsigned tag = (unsigned)k + 1u;
