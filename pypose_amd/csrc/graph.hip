@@ -1161,7 +1161,8 @@ pcg2_spmv_kernel(const int* __restrict__ ptr, const int* __restrict__ other, con
         if (STOP) {
           const T bn2 = slot_total(squant2(scal, 0, Q2_BN2));
           if (!(rr == rr)) it[2] = 2;
-          else if (rr <= tol2 * bn2) it[2] = 1;           // this launch's q is not applied: the step kernel sees the flag
+          else if (tol2 >= T(0) && rr <= tol2 * bn2) it[2] = 1;   // this launch's q is not applied: the step kernel sees the flag
+                                                                  // (tol2 < 0: no test -- the caller's rows are one rank's share of the system)
         }
       }
       it[1] = done;
@@ -1499,7 +1500,7 @@ int pcg2_spmv(const void* ptr, const void* other, const void* HB, const void* D,
               bool stop = false, double tol2 = 0.0, bool pack = false, void* cs = nullptr, bool dpk = false) {
   if (N <= 0) return N == 0 ? PPLIE_OK : PPLIE_EBADARG;
   if (!ptr || !other || !HB || !D || !Binv || !p || !z || !q || !scal || !rr_hist || !it) return PPLIE_EBADARG;
-  if ((cs && !(pack && stop)) || (dpk && !cs)) return PPLIE_EBADARG;  // (the two-level variant exists for the packed, device-stopped iteration)
+  if ((cs && !stop) || (dpk && !(cs && pack))) return PPLIE_EBADARG;  // (the two-level variant carries the device-side stop test; DPK goes with PACK)
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 #define LAUNCH(MM)                                                                                                    \
   {                                                                                                                   \
@@ -1510,8 +1511,12 @@ int pcg2_spmv(const void* ptr, const void* other, const void* HB, const void* D,
       hipLaunchKernelGGL((pcg2_spmv_kernel<T, MM, false, true, true, true, true>), dim3(grid), dim3(256), 0, st, (const int*)ptr, \
                          (const int*)other, (const T*)HB, (const T*)D, (const T*)Binv, (const T*)p, (const T*)z, (T*)q, \
                          (T*)scal, (T*)rr_hist, (int*)it, cap, N, (const int*)nullptr, (T)tol2, (T*)cs);                \
-    else if (cs)                                                                                                      \
+    else if (cs && pack)                                                                                              \
       hipLaunchKernelGGL((pcg2_spmv_kernel<T, MM, false, true, true, true>), dim3(grid), dim3(256), 0, st, (const int*)ptr, \
+                         (const int*)other, (const T*)HB, (const T*)D, (const T*)Binv, (const T*)p, (const T*)z, (T*)q, \
+                         (T*)scal, (T*)rr_hist, (int*)it, cap, N, (const int*)nullptr, (T)tol2, (T*)cs);                \
+    else if (cs)                                                                                                      \
+      hipLaunchKernelGGL((pcg2_spmv_kernel<T, MM, false, true, false, true>), dim3(grid), dim3(256), 0, st, (const int*)ptr, \
                          (const int*)other, (const T*)HB, (const T*)D, (const T*)Binv, (const T*)p, (const T*)z, (T*)q, \
                          (T*)scal, (T*)rr_hist, (int*)it, cap, N, (const int*)nullptr, (T)tol2, (T*)cs);                \
     else if (pack && stop)                                                                                            \
@@ -1628,6 +1633,19 @@ extern "C" int pplie_pcg2_spmv_pack_f64(const void* ptr, const void* other, cons
   }
 PPLIE_PCG2_COARSE(f32, float)
 PPLIE_PCG2_COARSE(f64, double)
+// the two-level iteration on FULL per-incidence blocks HB [nnz, m, m] (node-sharded solves, optim/nodeshard.py: every rank runs the
+// pair on the rows it owns and all-reduces the slot totals of scal and of cs between the two launches); tol2 < 0: the device-side
+// stop test never fires (the ranks' local |r|^2 mean nothing by themselves), a NaN still raises it[2] = 2.  Pairs with
+// pplie_pcg2_step_coarse.
+#define PPLIE_PCG2_COARSE_FULL(SFX, T)                                                                                             \
+  extern "C" int pplie_pcg2_spmv_coarse_##SFX(const void* ptr, const void* other, const void* HB, const void* D, const void* Binv,  \
+                                              const void* p, const void* z, void* q, void* scal, void* cs, void* rr_hist, void* it, \
+                                              int cap, int64_t N, int m, double tol2, void* stream) {                               \
+    if (!cs) return pplie::PPLIE_EBADARG;                                                                                           \
+    return pplie::pcg2_spmv<T>(ptr, other, HB, D, Binv, p, z, q, scal, rr_hist, it, cap, N, m, stream, nullptr, true, tol2, false, cs); \
+  }
+PPLIE_PCG2_COARSE_FULL(f32, float)
+PPLIE_PCG2_COARSE_FULL(f64, double)
 // the same pair reading PACKED diagonal blocks: D = Dp, Binv = Bp of pplie_pcg_prepare_coarse_dp
 #define PPLIE_PCG2_COARSE_DP(SFX, T)                                                                                                \
   extern "C" int pplie_pcg2_spmv_pack_coarse_dp_##SFX(const void* ptr, const void* other, const void* HB, const void* Dp, const void* Bp, \

@@ -45,6 +45,7 @@ constexpr int kPersistGridMax = 256;      // = PPLIE_PCG_PERSIST_GRID: rows of t
 constexpr int kPersistBlock = 1024;       // 16 waves per workgroup
 constexpr int kPersistQ = 5;              // quantities per exchange: p.q, q.z, q.Binv q, r.z, r.r
 constexpr int kPersistSlots = 8;          // table row = 8 quantity slots (PPLIE_PCG_PERSIST_SLOTS)
+constexpr int kCoarseSlots = 24;          // row of the partial-sum table with the coarse sums (5 + 2 M <= 19 quantities)
 
 // one value as NW tagged words.  SYS: the word crosses GPUs (peer-mapped memory over xGMI): system-scope accesses
 template <class T, bool SYS = false> __device__ __forceinline__ void put_value(u64* dst, T v, unsigned tag) {
@@ -249,6 +250,22 @@ __device__ __forceinline__ void gather_rows(SH& sh, int par, const u64* part, un
   }
 }
 
+// Profiling clock of the ghost-zone kernel (tools/time_pcg_iter.py, cap < 0): kTickSlots accumulators of 10 ns wall-clock ticks +
+// the previous reading, in LDS, touched by thread 0 of a clocked workgroup only (`clocked` is false on every production launch).
+constexpr int kTickSlots = 14;
+__device__ __forceinline__ unsigned* tick_store() {
+  __shared__ unsigned tk_[kTickSlots + 2];
+  return tk_;
+}
+__device__ __forceinline__ void tick(bool clocked, int slot) {
+  if (clocked) {
+    unsigned* tk = tick_store();
+    const unsigned t_now = (unsigned)wall_clock64();
+    tk[slot] += t_now - tk[kTickSlots];
+    tk[kTickSlots] = t_now;
+  }
+}
+
 // PAIRS: two fp32 partial sums per 64-bit word, each carrying a 2-bit tag in the two LOWEST MANTISSA BITS (a relative perturbation of
 // 2.4e-7 of a dot product whose own summation error is larger).  Two bits are enough because the tables alternate with the
 // iteration's parity and every workgroup rewrites its row at every use of a table: what a reader can find in a slot is the value
@@ -325,7 +342,7 @@ constexpr int kHierGroups = 8;
 constexpr int kHierMinGrid = 224;        // grids from here on exchange in two levels
 constexpr int kHierRows = kPersistGridMax + kHierGroups;
 template <class T, int NQ, class SH, int SLOTS>
-__device__ __forceinline__ void exchange_two_level(SH& sh, int par, u64* part, unsigned tag, int use) {
+__device__ __forceinline__ void exchange_two_level(SH& sh, int par, u64* part, unsigned tag, int use, bool clocked = false) {
   constexpr int NW = sizeof(T) / 4, RW = SLOTS * NW, WV = kPersistBlock / 64;
   const int G = (int)gridDim.x < kHierGroups ? (int)gridDim.x : kHierGroups;
   if constexpr (sizeof(T) == 4) {
@@ -340,8 +357,10 @@ __device__ __forceinline__ void exchange_two_level(SH& sh, int par, u64* part, u
     }
     __syncthreads();
     put_pairs<NQ, SH, SLOTS>(mine, part + ((size_t)par * kHierRows + blockIdx.x) * RW, t2);
+    tick(clocked, 5);
     if ((int)gridDim.x < kHierMinGrid) {
       gather_pairs<NQ, SH, SLOTS>(sh, par, part, t2, 0, 1, (int)gridDim.x, kHierRows);
+      tick(clocked, 7);
       return;
     }
     if ((int)blockIdx.x < G) {
@@ -350,8 +369,10 @@ __device__ __forceinline__ void exchange_two_level(SH& sh, int par, u64* part, u
       __syncthreads();
       put_pairs<NQ, SH, SLOTS>(&sh.total[par][0], part + ((size_t)par * kHierRows + kPersistGridMax + blockIdx.x) * RW, t2);
       __syncthreads();
+      tick(clocked, 6);
     }
     gather_pairs<NQ, SH, SLOTS>(sh, par, part, t2, kPersistGridMax, 1, G, kHierRows);
+    tick(clocked, 7);
     return;
   }
   // (caller: post_wave_sums + __syncthreads done)  own row
@@ -382,16 +403,26 @@ __device__ __forceinline__ void exchange_two_level(SH& sh, int par, u64* part, u
 // that the all-gather overlaps the neighbour exchange -- was built and measured in round 3: 10.5 us per iteration instead of
 // 12.2, but its recurrences for Binv r and A Binv r lose the residual in fp32: it stalls above 1e-4 already at condition
 // number 100, cf. profiles/r03/SUMMARY.md.  Not kept.)
-template <class T, int M, bool XG>
+// CZ (with XG): the two-level preconditioner of the ghost-zone kernel below (block-Jacobi + the gauge modes Z = 1_N (x) I_M; see the
+// comment there) on the node-sharded multi-GPU solve: 2 M more sums per exchange at both levels (workgroups of this rank, then the
+// ranks), one exchange before the first iteration for E = sum_n shift[n, :] and Z^T r_0.  Rows of kCoarseSlots values in `part` and
+// in the peers' `rpart` tables.
+template <class T, int M, bool XG, bool CZ = false>
 __global__ void __launch_bounds__(kPersistBlock)
 pcg_persist_kernel(const int* __restrict__ ptr, const int* __restrict__ other, const T* __restrict__ HB, const T* __restrict__ D,
                    const T* __restrict__ Binv, T* __restrict__ x, const T* __restrict__ r, const T* __restrict__ z,
-                   u64* part /* [2][kPersistGridMax][kPersistSlots values as tagged words] */,
+                   u64* part /* [2][kPersistGridMax][kPersistSlots (CZ: kCoarseSlots) values as tagged words] */,
                    u64* ptag /* [2][N * M values as tagged words] (XG: peers.ptag[rank], all nodes of the graph) */,
                    T* __restrict__ rr_hist, T* info /* [4] */, int* it_out, T tol2, int maxiter, int cap, int64_t N, int lds_bytes,
-                   PersistPeers peers) {
+                   PersistPeers peers, const T* __restrict__ shift = nullptr) {
+  static_assert(!CZ || XG, "the two-level variant of this kernel is the multi-GPU one (one GPU: pcg_ghost_kernel<T, M, true>)");
   extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
-  __shared__ PersistShared<T> sh;
+  constexpr int NQ = CZ ? kPersistQ + 2 * M : kPersistQ;
+  constexpr int SLOTS = CZ ? kCoarseSlots : kPersistSlots;
+  typedef PersistShared<T, NQ> SH;
+  __shared__ SH sh;
+  __shared__ T cz_pad[CZ ? kPersistBlock : 1];
+  __shared__ T einv[CZ ? M : 1];
   constexpr int CH = sizeof(T) == 4 ? 16 : 8;   // incidences per round of tagged loads
   constexpr int NPW = 64 / M;              // nodes per wave: M lanes per node
   constexpr int WV = kPersistBlock / 64;   // waves per workgroup
@@ -434,7 +465,7 @@ pcg_persist_kernel(const int* __restrict__ ptr, const int* __restrict__ other, c
       put_value<T>(ptag + at, v, tag);
     }
   };
-  hand_off(ze, 0, tag0 + 1u);
+  if constexpr (!CZ) hand_off(ze, 0, tag0 + 1u);
   L.maxdeg = L.deg;                        // largest degree among this wave's nodes
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
@@ -461,6 +492,67 @@ pcg_persist_kernel(const int* __restrict__ ptr, const int* __restrict__ other, c
   if (threadIdx.x == 0) { sh.bad[0] = 0; sh.bad[1] = 0; }
   __syncthreads();
   L.lbeg = act ? L.beg - c_lo : 0;
+  // sh.wave_part[par][qbase + c][w] = sum over this wave's nodes of `val` at component c (as in pcg_ghost_kernel)
+  auto wave_comp_sums = [&](T val, int par_, int qbase) {
+    T* pad = cz_pad + (CZ ? w * 64 : 0);
+    pad[lane] = act ? val : T(0);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (lane < M) {
+      T sum = T(0);
+#pragma unroll
+      for (int s2 = 0; s2 < NPW; ++s2) sum += pad[s2 * M + lane];
+      sh.wave_part[par_][qbase + lane][w] = sum;
+    }
+    __builtin_amdgcn_wave_barrier();
+  };
+  // second level of an exchange (XG): this rank's totals of QN quantities to every rank; everybody adds the `world` rows in rank order
+  auto rank_exchange = [&](int par_, unsigned tag_, int QN) {
+    constexpr int RW2 = SLOTS * NW;
+    const size_t tab = (size_t)par_ * kPersistMaxWorld * RW2;
+    if (blockIdx.x == 0 && (int)threadIdx.x < QN) {
+      for (int rk = 0; rk < peers.world; ++rk)
+        put_value<T, true>(peers.rpart[rk] + tab + (size_t)peers.rank * RW2 + threadIdx.x * NW, sh.total[par_][threadIdx.x], tag_);
+    }
+    __syncthreads();                                             // (everybody has read this rank's totals before they are replaced)
+    if ((int)threadIdx.x < QN) {
+      const u64* mine = peers.rpart[peers.rank] + tab + threadIdx.x * NW;
+      T sum = T(0);
+      bool all = true;
+      for (int rk = 0; rk < peers.world; ++rk) {
+        bool ok = false;
+        T v = T(0);
+        for (long spin = 0; spin < (1L << 20) && !ok; ++spin) {
+          ok = true;
+          v = get_value<T, true>(mine + (size_t)rk * RW2, tag_, ok);
+          if (!ok) __builtin_amdgcn_s_sleep(1);
+        }
+        all = all && ok;
+        sum += v;
+      }
+      sh.total[par_][threadIdx.x] = sum;
+      if (!all) sh.bad[par_] = 1;
+    }
+    __syncthreads();
+  };
+  if constexpr (CZ) {
+    // one exchange before the first iteration: E_i = sum_n shift[n, i] and (Z^T r_0)_i over ALL ranks' nodes (table 1, tag = the
+    // epoch's base, which no iteration uses: iteration k carries tag0 + k + 1; nobody reaches iteration 1's rows of table 1
+    // before everybody has left this exchange, because iteration 0's exchange waits for all)
+    wave_comp_sums(act ? shift[n * M + i] : T(0), 1, 0);
+    wave_comp_sums(re, 1, M);
+    __syncthreads();
+    publish_row<T, 2 * M, SH, SLOTS>(sh, 1, part, tag0);
+    gather_rows<T, 2 * M, SH, SLOTS>(sh, 1, part, tag0);
+    __syncthreads();
+    rank_exchange(1, tag0, 2 * M);
+    if (threadIdx.x < M) {
+      const T e = sh.total[1][threadIdx.x];
+      einv[threadIdx.x] = e > T(0) ? T(1) / e : T(0);
+    }
+    __syncthreads();
+  }
 
   T bn2 = T(0), rr = T(0);
   int k = 0, flag = 0;                     // flag: 1 converged, 2 NaN, 3 a workgroup never arrived, 0 iteration limit
@@ -478,6 +570,11 @@ pcg_persist_kernel(const int* __restrict__ ptr, const int* __restrict__ other, c
   }
   {
     T pe = ze;                             // p_0 = z_0 (published above as hand-off 0)
+    if constexpr (CZ) {
+      pe += sh.total[1][M + i] * einv[i];  // p_0 = z_0 = Binv r_0 + Z (Z^T r_0 / E)
+      __syncthreads();                     // (sh.total[1] is rewritten by iteration 1's exchange: far away, but bad[] is read below)
+      hand_off(pe, 0, tag0 + 1u);
+    }
     for (;; ++k) {
       const unsigned tag = tag0 + (unsigned)k + 1u;
       const int par = k & 1;
@@ -487,15 +584,21 @@ pcg_persist_kernel(const int* __restrict__ ptr, const int* __restrict__ other, c
       const T bq = node_binv<T, M>(L, acc);
       T v[kPersistQ] = {acc * pe, acc * ze, acc * bq, re * ze, re * re};
       post_wave_sums<T, kPersistQ>(sh, par, v, act, stale);
+      if constexpr (CZ) {
+        wave_comp_sums(acc, par, kPersistQ);                                       // Z^T q
+        wave_comp_sums(re, par, kPersistQ + M);                                    // Z^T r
+      }
       PPLIE_TICK(1)
       __syncthreads();                                                           // barrier 1
       PPLIE_TICK(2)
-      publish_row<T, kPersistQ>(sh, par, part, tag);
-      gather_rows<T, kPersistQ>(sh, par, part, tag);
+      publish_row<T, NQ, SH, SLOTS>(sh, par, part, tag);
+      gather_rows<T, NQ, SH, SLOTS>(sh, par, part, tag);
       PPLIE_TICK(3)
       __syncthreads();                                                           // barrier 2
       PPLIE_TICK(4)
-      if (XG) {
+      if constexpr (CZ) {
+        rank_exchange(par, tag, NQ);
+      } else if (XG) {
         // second level: this rank's totals to every rank; everybody adds the `world` rows in rank order
         constexpr int RW2 = kPersistSlots * NW;
         const size_t tab = (size_t)par * kPersistMaxWorld * RW2;
@@ -524,7 +627,7 @@ pcg_persist_kernel(const int* __restrict__ ptr, const int* __restrict__ other, c
         }
         __syncthreads();
       }
-      const T pq = sh.total[par][0], qz = sh.total[par][1], qmq = sh.total[par][2], rho = sh.total[par][3];
+      const T pq = sh.total[par][0], qz = sh.total[par][1], qmq = sh.total[par][2], rho_loc = sh.total[par][3];
       rr = sh.total[par][4];
       if (sh.bad[par]) { flag = 3; break; }
       if (k == 0) bn2 = rr;
@@ -532,14 +635,28 @@ pcg_persist_kernel(const int* __restrict__ ptr, const int* __restrict__ other, c
       if (!(rr == rr)) { flag = 2; break; }
       if (rr <= tol2 * bn2) { flag = 1; break; }                     // (also |b| = 0: x = 0 is the answer)
       if (k >= maxiter) break;
+      T rho = rho_loc;                                               // (CZ: rho_loc = r.Binv r, the coarse part is added here)
+      if constexpr (CZ) {
+#pragma unroll
+        for (int q = 0; q < M; ++q) { const T sr = sh.total[par][kPersistQ + M + q]; rho += sr * sr * einv[q]; }
+      }
       const T alpha = pq > pcg_tiny<T>() ? rho / pq : T(0);                 // p.q = 0 only once r = 0: stay put, no NaN
-      T rho_next = rho - T(2) * alpha * qz + alpha * alpha * qmq;
+      T rho_next = rho_loc - T(2) * alpha * qz + alpha * alpha * qmq;
+      T cz = T(0);                                                   // this component's coarse part of the new z
+      if constexpr (CZ) {
+#pragma unroll
+        for (int q = 0; q < M; ++q) {
+          const T sp = sh.total[par][kPersistQ + M + q] - alpha * sh.total[par][kPersistQ + q];    // Z^T r' = Z^T r - alpha Z^T q
+          rho_next += sp * sp * einv[q];
+        }
+        cz = (sh.total[par][kPersistQ + M + i] - alpha * sh.total[par][kPersistQ + i]) * einv[i];
+      }
       if (rho_next < T(0)) rho_next = T(0);
       const T beta = rho > pcg_tiny<T>() ? rho_next / rho : T(0);
       xe += alpha * pe;
       re -= alpha * acc;
       ze = node_binv<T, M>(L, re);
-      pe = ze + beta * pe;
+      pe = (CZ ? ze + cz : ze) + beta * pe;
       hand_off(pe, (k + 1) & 1, tag + 1u);
       PPLIE_TICK(5)
     }
@@ -584,7 +701,6 @@ constexpr int kGhostLayers = 3;
 // Cost: 2 M more sums per exchange (Z^T q and Z^T r, per component) and one exchange before the first iteration (E and Z^T r_0).
 //   rho = r.Binv r + sum_i (Z^T r)_i^2 / E_i ;   z = Binv r + Z (Z^T r / E) ;  the recurrence value of rho_{k+1} (for beta only,
 //   as before) uses Z^T r' = Z^T r - alpha Z^T q.  Any E > 0 gives an SPD preconditioner: the stop test |r| <= tol |b| is unchanged.
-constexpr int kCoarseSlots = 24;          // row of the partial-sum table with the coarse sums (5 + 2 M <= 19 quantities)
 
 template <class T, int M, bool CZ = false>
 __global__ void __launch_bounds__(kPersistBlock)
@@ -704,22 +820,18 @@ pcg_ghost_kernel(const int* __restrict__ ptr, const int* __restrict__ slot, cons
   // cap < 0 (tools/time_pcg_iter.py): thread 0 of the middle workgroup accumulates the wall-clock ticks (10 ns) of the phases
   const bool prof = cap < 0;
   if (prof) cap = -cap;
-  const bool clocked = prof && blockIdx.x == gridDim.x / 2 && threadIdx.x == 0;
+  // two clocked workgroups: the middle one (a plain member of the two-level exchange) and workgroup 0 (a group leader)
+  const bool clocked = prof && (blockIdx.x == gridDim.x / 2 || blockIdx.x == 0) && threadIdx.x == 0;
   // (the accumulators live in LDS, not in registers: five 64-bit counters and the previous reading were 12 VGPRs of EVERY lane for the
   //  whole loop -- at this kernel's 128-VGPR cap they pushed twelve of the ghosts' Binv rows into scratch, reloaded one by one inside
   //  every iteration: <float, 6, CZ> spilled 24 VGPRs with them and spills 2 without, profiles/r05/kernel_resources.txt.  32-bit
   //  ticks: differences are taken modulo 2^32 (43 s).)
-  __shared__ unsigned tk[6];                                   // tk[5]: the previous reading
   if (clocked) {
-    for (int q = 0; q < 5; ++q) tk[q] = 0u;
-    tk[5] = (unsigned)wall_clock64();
+    unsigned* tk = tick_store();
+    for (int q = 0; q < kTickSlots; ++q) tk[q] = 0u;
+    tk[kTickSlots] = (unsigned)wall_clock64();
   }
-#define PPLIE_TICK(slot)                                       \
-  if (clocked) {                                               \
-    const unsigned t_now = (unsigned)wall_clock64();           \
-    tk[slot] += t_now - tk[5];                                 \
-    tk[5] = t_now;                                             \
-  }
+#define PPLIE_TICK(slot) tick(clocked, slot);
   for (;; ++k) {
     const unsigned tag = (unsigned)k + 1u;
     const int par = k & 1;
@@ -769,7 +881,7 @@ pcg_ghost_kernel(const int* __restrict__ ptr, const int* __restrict__ slot, cons
       gok[l] = true;
       gq[l] = gact[l] ? get_value<T>(qtag + (size_t)par * NM + ((size_t)gnode[l] * M + i) * NW, tag, gok[l]) : T(0);
     }
-    if constexpr (CZ) exchange_two_level<T, NQ, SH, SLOTS>(sh, par, part, tag, (k >> 1) + par);   // (table 1's use 0 was the set-up exchange)
+    if constexpr (CZ) exchange_two_level<T, NQ, SH, SLOTS>(sh, par, part, tag, (k >> 1) + par, clocked);   // (table 1's use 0 was the set-up exchange)
     else gather_rows<T, NQ, SH, SLOTS>(sh, par, part, tag);
     PPLIE_TICK(2)
     bool stale = false;
@@ -835,8 +947,16 @@ pcg_ghost_kernel(const int* __restrict__ ptr, const int* __restrict__ slot, cons
     PPLIE_TICK(4)
   }
 #undef PPLIE_TICK
-  if (clocked)
-    for (int q = 0; q < 5; ++q) rr_hist[cap - 8 + q] = (T)tk[q];
+  if (clocked) {
+    // middle workgroup: the five phase slots at rr_hist[cap - 8 ..] (as before) and all kTickSlots at [cap - 48 ..]; workgroup 0
+    // (a group leader of the two-level exchange): all slots at [cap - 32 ..]
+    const unsigned* tk = tick_store();
+    const bool mid = blockIdx.x == gridDim.x / 2;
+    if (mid)
+      for (int q = 0; q < 5; ++q) rr_hist[cap - 8 + q] = (T)tk[q];
+    if (mid || gridDim.x / 2 != 0)
+      for (int q = 0; q < kTickSlots; ++q) rr_hist[cap - (mid ? 48 : 32) + q] = (T)tk[q];
+  }
   if (act) x[n * M + i] = flag >= 2 ? T(0) : xe;
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     info[0] = (T)k; info[1] = rr; info[2] = bn2; info[3] = (T)flag;
@@ -847,20 +967,21 @@ pcg_ghost_kernel(const int* __restrict__ ptr, const int* __restrict__ slot, cons
 // Dynamic LDS of a workgroup (the staged matrix slice); the most workgroups of this kernel the device holds at once
 // (they spin on each other: all must be resident)
 constexpr int kPersistLds = 152 * 1024;      // of the 160 KB a CU has (one 1024-lane workgroup per CU; ~1.5 KB are static)
-template <class T, int M, bool XG> static int persist_capacity(int& lds_bytes) {
+template <class T, int M, bool XG, bool CZ = false> static int persist_capacity(int& lds_bytes) {
   static int cap[16] = {0}, lds[16] = {0};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 0;
   if (cap[dev] == 0) {
     int cus = 0, per = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-    lds[dev] = kPersistLds;
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&pcg_persist_kernel<T, M, XG>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            kPersistLds) != hipSuccess) {
+    // (the two-level variant's static LDS -- wider exchange rows, the component-sum pad -- is 6.5 KB in fp32, 13 KB in fp64)
+    lds[dev] = CZ ? kPersistLds - (sizeof(T) == 8 ? 12 : 6) * 1024 : kPersistLds;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&pcg_persist_kernel<T, M, XG, CZ>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            lds[dev]) != hipSuccess) {
       (void)hipGetLastError();
       lds[dev] = 48 * 1024;                                      // (always available without the attribute)
     }
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, pcg_persist_kernel<T, M, XG>, kPersistBlock, lds[dev]) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, pcg_persist_kernel<T, M, XG, CZ>, kPersistBlock, lds[dev]) != hipSuccess) return 0;
     cap[dev] = cus * per > 0 ? cus * per : -1;
   }
   lds_bytes = lds[dev];
@@ -870,27 +991,27 @@ template <class T, int M, bool XG> static int persist_capacity(int& lds_bytes) {
 template <class T>
 int pcg_persist(const void* ptr, const void* other, const void* HB, const void* D, const void* Binv, void* x, const void* r, const void* z,
                 void* part, void* ptag, void* rr_hist, void* info, void* it, double tol, int maxiter, int cap, int grid, int64_t N, int m,
-                void* stream, const PersistPeers* peers) {
+                void* stream, const PersistPeers* peers, const void* shift = nullptr) {
   if (N <= 0) return N == 0 ? PPLIE_OK : PPLIE_EBADARG;
   if (!ptr || !other || !HB || !D || !Binv || !x || !r || !z || !part || !ptag || !rr_hist || !info || !it) return PPLIE_EBADARG;
-  if (grid < 1 || grid > kPersistGridMax || maxiter < 0 || maxiter > 65534) return PPLIE_EBADARG;
+  if (grid < 1 || grid > kPersistGridMax || maxiter < 0 || maxiter > 65534 || (shift && !peers)) return PPLIE_EBADARG;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   PersistPeers none = {};
-#define LAUNCH2(MM, XG)                                                                                                        \
+#define LAUNCH2(MM, XG, CZ)                                                                                                    \
   {                                                                                                                            \
     int lds_bytes = 0;                                                                                                         \
-    const int resident = persist_capacity<T, MM, XG>(lds_bytes);                                                               \
+    const int resident = persist_capacity<T, MM, XG, CZ>(lds_bytes);                                                           \
     if (resident <= 0 || (size_t)lds_bytes < (size_t)(kPersistBlock / 64) * (64 / MM) * MM * MM * sizeof(T)) return PPLIE_ECAPACITY; \
     if (grid > resident) grid = resident;                         /* fewer CUs than asked for: every workgroup must be resident */ \
     if (grid > N) grid = (int)N;                                                                                               \
     const int64_t per_wg = (kPersistBlock / 64) * (64 / MM);     /* one lane per (node, component): nodes one workgroup holds */ \
     if ((N + grid - 1) / grid > per_wg) return PPLIE_ECAPACITY;  /* too large for this device: use the two-launch iteration */  \
-    hipLaunchKernelGGL((pcg_persist_kernel<T, MM, XG>), dim3(grid), dim3(kPersistBlock), lds_bytes, st, (const int*)ptr,       \
+    hipLaunchKernelGGL((pcg_persist_kernel<T, MM, XG, CZ>), dim3(grid), dim3(kPersistBlock), lds_bytes, st, (const int*)ptr,   \
                        (const int*)other, (const T*)HB, (const T*)D, (const T*)Binv, (T*)x, (const T*)r, (const T*)z,            \
                        (unsigned long long*)part, (unsigned long long*)ptag, (T*)rr_hist, (T*)info, (int*)it, (T)(tol * tol),    \
-                       maxiter, cap, N, lds_bytes, XG ? *peers : none);                                                        \
+                       maxiter, cap, N, lds_bytes, XG ? *peers : none, (const T*)shift);                                       \
   }
-#define LAUNCH(MM) { if (peers) LAUNCH2(MM, true) else LAUNCH2(MM, false) }
+#define LAUNCH(MM) { if (peers && shift) LAUNCH2(MM, true, true) else if (peers) LAUNCH2(MM, true, false) else LAUNCH2(MM, false, false) }
   if (m == 6) LAUNCH(6) else if (m == 7) LAUNCH(7) else if (m == 3) LAUNCH(3) else return PPLIE_EBADARG;
 #undef LAUNCH
 #undef LAUNCH2
@@ -901,7 +1022,7 @@ template <class T>
 int pcg_persist_p2p(const void* ptr, const void* other, const void* HB, const void* D, const void* Binv, void* x, const void* r,
                     const void* z, void* part, const void* const* ptag_peers, const void* const* rpart_peers, void* rr_hist, void* info,
                     void* it, double tol, int maxiter, int cap, int grid, int64_t n_own, int64_t row0, int64_t n_global, int world,
-                    int rank, int epoch, int m, void* stream) {
+                    int rank, int epoch, int m, void* stream, const void* shift = nullptr) {
   if (world < 1 || world > kPersistMaxWorld || rank < 0 || rank >= world || !ptag_peers || !rpart_peers || row0 < 0 ||
       row0 + n_own > n_global)
     return PPLIE_EBADARG;
@@ -916,7 +1037,8 @@ int pcg_persist_p2p(const void* ptr, const void* other, const void* HB, const vo
     pe.ptag[k] = (u64*)ptag_peers[k];
     pe.rpart[k] = (u64*)rpart_peers[k];
   }
-  return pcg_persist<T>(ptr, other, HB, D, Binv, x, r, z, part, pe.ptag[rank], rr_hist, info, it, tol, maxiter, cap, grid, n_own, m, stream, &pe);
+  return pcg_persist<T>(ptr, other, HB, D, Binv, x, r, z, part, pe.ptag[rank], rr_hist, info, it, tol, maxiter, cap, grid, n_own, m, stream, &pe,
+                        shift);
 }
 
 // ghost-zone solve: PPLIE_ECAPACITY (nothing launched) when a workgroup's slice or ghost set does not fit -- the caller then uses
@@ -995,6 +1117,22 @@ extern "C" int pplie_pcg_persist_f64(const void* ptr, const void* other, const v
   }
 PPLIE_P2P(f32, float)
 PPLIE_P2P(f64, double)
+// the same solve with the two-level (block-Jacobi + gauge modes) preconditioner: `shift` = pplie_pcg_prepare's output for the owned
+// rows [n_own, m]; `part` must hold 2 x PPLIE_PCG_PERSIST_GRID x PPLIE_PCG_COARSE_SLOTS tagged values and every rank's `rpart` table
+// 2 x 8 x PPLIE_PCG_COARSE_SLOTS (rows of COARSE_SLOTS values instead of PERSIST_SLOTS)
+#define PPLIE_P2P_CZ(SFX, T)                                                                                                      \
+  extern "C" int pplie_pcg_persist_p2p_coarse_##SFX(const void* ptr, const void* other, const void* HB, const void* D,            \
+                                                    const void* Binv, const void* shift, void* x, const void* r, const void* z,   \
+                                                    void* part, const void* const* ptag_peers, const void* const* rpart_peers,   \
+                                                    void* rr_hist, void* info, void* it, double tol, int maxiter, int cap,        \
+                                                    int grid, int64_t n_own, int64_t row0, int64_t n_global, int world, int rank, \
+                                                    int epoch, int m, void* stream) {                                            \
+    if (!shift) return pplie::PPLIE_EBADARG;                                                                                      \
+    return pplie::pcg_persist_p2p<T>(ptr, other, HB, D, Binv, x, r, z, part, ptag_peers, rpart_peers, rr_hist, info, it, tol,     \
+                                     maxiter, cap, grid, n_own, row0, n_global, world, rank, epoch, m, stream, shift);           \
+  }
+PPLIE_P2P_CZ(f32, float)
+PPLIE_P2P_CZ(f64, double)
 #define PPLIE_GHOST(SFX, T)                                                                                                       \
   extern "C" int pplie_pcg_ghost_##SFX(const void* ptr, const void* slot, const void* HB, const void* D, const void* Binv, void* x,  \
                                        const void* r, const void* z, const void* gptr, const void* gids, void* part, void* qtag,     \

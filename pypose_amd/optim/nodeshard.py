@@ -32,7 +32,11 @@ from .. import _C
 _P2P_SIG = [ctypes.c_void_p] * 9 + [ctypes.POINTER(ctypes.c_void_p)] * 2 + [ctypes.c_void_p] * 3 + \
            [ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
             ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+_P2P_CZ_SIG = [ctypes.c_void_p] * 10 + [ctypes.POINTER(ctypes.c_void_p)] * 2 + [ctypes.c_void_p] * 3 + \
+              [ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
+               ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
 _P2P_CAP = 1 << 16
+_ROW_SLOTS = 24          # PPLIE_PCG_COARSE_SLOTS: the tables are sized for the wide rows of the two-level variant
 
 
 class P2PRank:
@@ -44,27 +48,34 @@ class P2PRank:
         nw = 1 if dtype == torch.float32 else 2
         z64 = lambda k: torch.zeros(k, dtype=torch.int64, device=device)
         self.ptag = z64(2 * n_global * m * nw)                         # zeroed once: tags carry the solve's epoch
-        self.rpart = z64(2 * 8 * 8 * nw)
-        self.part = z64(2 * 256 * 8 * nw)
+        self.rpart = z64(2 * 8 * _ROW_SLOTS * nw)
+        self.part = z64(2 * 256 * _ROW_SLOTS * nw)
         self.rr_hist = torch.zeros(_P2P_CAP, dtype=dtype, device=device)
         self.info = torch.zeros(4, dtype=dtype, device=device)
         self.it = torch.zeros(4, dtype=torch.int32, device=device)
 
 
 def persist_p2p_launch(rk, ptag_ptrs, rpart_ptrs, ptr, other, HB, D, Binv, x, r, z, tol, maxiter, grid, row0, n_global, world, rank,
-                       epoch, m):
+                       epoch, m, shift=None):
     """enqueue one rank's kernel on the current stream.  ``ptag_ptrs`` / ``rpart_ptrs``: the ``world`` table addresses as this
-    process sees them (its own allocation + the peers' mapped ones)."""
+    process sees them (its own allocation + the peers' mapped ones).  ``shift`` (the owned rows' damping shift): the two-level
+    (block-Jacobi + gauge) preconditioner, ``pplie_pcg_persist_p2p_coarse`` -- every rank must pass it or none."""
     n_own = D.shape[0]
     sfx = "_f32" if D.dtype == torch.float32 else "_f64"
     arr = ctypes.c_void_p * world
-    fn = _C.library().symbol("pplie_pcg_persist_p2p" + sfx, _P2P_SIG)
     rk.part.zero_()                                                  # (workgroup-level table: local, cleared per solve)
+    tail = (rk.part.data_ptr(), arr(*ptag_ptrs), arr(*rpart_ptrs), rk.rr_hist.data_ptr(), rk.info.data_ptr(),
+            rk.it.data_ptr(), float(tol), int(min(maxiter, 65534)), _P2P_CAP, int(grid), n_own, int(row0), int(n_global),
+            int(world), int(rank), int(epoch), int(m), _C.stream_ptr(D.device))
     with _C._on_device(D.device):
-        code = fn(ptr.data_ptr(), other.data_ptr(), HB.data_ptr(), D.data_ptr(), Binv.data_ptr(), x.data_ptr(), r.data_ptr(),
-                  z.data_ptr(), rk.part.data_ptr(), arr(*ptag_ptrs), arr(*rpart_ptrs), rk.rr_hist.data_ptr(), rk.info.data_ptr(),
-                  rk.it.data_ptr(), float(tol), int(min(maxiter, 65534)), _P2P_CAP, int(grid), n_own, int(row0), int(n_global),
-                  int(world), int(rank), int(epoch), int(m), _C.stream_ptr(D.device))
+        if shift is not None:
+            fn = _C.library().symbol("pplie_pcg_persist_p2p_coarse" + sfx, _P2P_CZ_SIG)
+            code = fn(ptr.data_ptr(), other.data_ptr(), HB.data_ptr(), D.data_ptr(), Binv.data_ptr(), shift.data_ptr(), x.data_ptr(),
+                      r.data_ptr(), z.data_ptr(), *tail)
+        else:
+            fn = _C.library().symbol("pplie_pcg_persist_p2p" + sfx, _P2P_SIG)
+            code = fn(ptr.data_ptr(), other.data_ptr(), HB.data_ptr(), D.data_ptr(), Binv.data_ptr(), x.data_ptr(), r.data_ptr(),
+                      z.data_ptr(), *tail)
     return code
 
 
@@ -190,6 +201,7 @@ class NodeShardedSystem:
     def __init__(self, lin, shard):
         self.lin, self.sh = lin, shard
         self.B = self.g = self.HB = None
+        self.gauge = False            # this solve's preconditioner carries the gauge correction (set by solve())
 
     def _hip(self):
         return self.lin._hip() and self.lin.m in (3, 6, 7)
@@ -258,45 +270,86 @@ class NodeShardedSystem:
         sfx = "_f32" if dt == torch.float32 else "_f64"
         lib, st = _C.library(), _C.stream_ptr(dev)
         z = lambda *shape: torch.zeros(shape, dtype=dt, device=dev)
+        gauge = self.gauge
         w = self.__dict__.get('_ws')
         if w is None or w['key'] != (n, chunk, sh.halo.numel(), dt):
             w = self._ws = dict(key=(n, chunk, sh.halo.numel(), dt), D=z(n, m, m), Binv=z(n, m, m), shift=z(n, m), x=z(n, m), r=z(n, m),
                                 r2=z(n, m), q=z(n, m), z=z(n, m), p=z(chunk + sh.halo.numel(), m), full=z(sh.world * chunk, m),
-                                scal=z(_pg._PCG_SCAL_ELEMS), rr_hist=z(1 << 16), it=torch.zeros(2, dtype=torch.int32, device=dev),
+                                scal=z(_pg._PCG_SCAL_ELEMS), cs=z(_pg._PCG2_CS_ELEMS), rr_hist=z(1 << 16),
+                                it=torch.zeros(4, dtype=torch.int32, device=dev),
                                 other=torch.where(sh.other >= n, sh.other + (chunk - n), sh.other).contiguous(),
-                                qsel=torch.tensor([0, 1, 4, 5], device=dev))
+                                qsel=torch.tensor([0, 1, 4, 5], device=dev), tot=z(8 + 16))
         w['scal'].zero_()
+        w['cs'].zero_()
         w['it'].zero_()
         w['p'].zero_()
         S = w['scal'].view(2, 8, 32, 32)
+        CS = w['cs'].view(2, 32, 32)                                   # [set][slot][E 0..7 | Z^T q 8..15 | Z^T r 16..23 | -] (csrc/graph.hip)
         with _C._on_device(dev):
-            _C.check(lib.symbol("pplie_pcg_prepare" + sfx, _pg._PREP_SIG)(
-                self.B.data_ptr(), self.g.data_ptr(), w['D'].data_ptr(), w['Binv'].data_ptr(), w['shift'].data_ptr(), w['x'].data_ptr(),
-                w['r'].data_ptr(), w['z'].data_ptr(), w['p'].data_ptr(), w['scal'].data_ptr(), float(s), float(dmin), float(dmax), n, m, st),
-                "pplie_pcg_prepare")
-            bn2 = S[0, 3, :, 0].sum().reshape(1)
-            dist.all_reduce(bn2, group=sh.group)
-            bn2 = float(bn2)
+            if gauge:
+                # two-level preconditioner: the rank's partial E and Z^T r_0 land in set 0 of cs; their totals over the ranks go back
+                # into slot 0 (the kernels sum the 32 slots of a set), then p_0 += Z (Z^T r_0 / E)
+                _C.check(lib.symbol("pplie_pcg_prepare_coarse" + sfx, _pg._PREP_CZ_SIG)(
+                    self.B.data_ptr(), self.g.data_ptr(), w['D'].data_ptr(), w['Binv'].data_ptr(), w['shift'].data_ptr(), w['x'].data_ptr(),
+                    w['r'].data_ptr(), w['z'].data_ptr(), w['p'].data_ptr(), w['scal'].data_ptr(), w['cs'].data_ptr(), float(s), None,
+                    float(dmin), float(dmax), n, m, st), "pplie_pcg_prepare_coarse")
+                head = torch.cat([S[0, 3, :, 0].sum().reshape(1), CS[0].sum(0)[:24]])
+                dist.all_reduce(head, group=sh.group)
+                bn2 = float(head[0])
+                CS[0].zero_()
+                CS[0, 0, :24] = head[1:]
+                _C.check(lib.symbol("pplie_pcg2_coarse_init" + sfx, _pg._CZ_INIT_SIG)(w['p'].data_ptr(), w['cs'].data_ptr(), n, m, st),
+                         "pplie_pcg2_coarse_init")
+            else:
+                _C.check(lib.symbol("pplie_pcg_prepare" + sfx, _pg._PREP_SIG)(
+                    self.B.data_ptr(), self.g.data_ptr(), w['D'].data_ptr(), w['Binv'].data_ptr(), w['shift'].data_ptr(), w['x'].data_ptr(),
+                    w['r'].data_ptr(), w['z'].data_ptr(), w['p'].data_ptr(), w['scal'].data_ptr(), float(s), float(dmin), float(dmax), n, m, st),
+                    "pplie_pcg_prepare")
+                bn2 = S[0, 3, :, 0].sum().reshape(1)
+                dist.all_reduce(bn2, group=sh.group)
+                bn2 = float(bn2)
             if bn2 == 0.0:
                 return sh.gather_rows(w['x']), 0
-            spmv = lib.symbol("pplie_pcg2_spmv" + sfx, _pg._PCG2_SPMV_SIG)
-            step = lib.symbol("pplie_pcg2_step" + sfx, _pg._PCG2_STEP_SIG)
+            if gauge:
+                spmv_cz = lib.symbol("pplie_pcg2_spmv_coarse" + sfx, _pg._PCG2_SPMV_CZ_SIG)
+                step_cz = lib.symbol("pplie_pcg2_step_coarse" + sfx, _pg._PCG2_STEP_CZ_SIG)
+            else:
+                spmv = lib.symbol("pplie_pcg2_spmv" + sfx, _pg._PCG2_SPMV_SIG)
+                step = lib.symbol("pplie_pcg2_step" + sfx, _pg._PCG2_STEP_SIG)
             done, thresh = 0, tol * tol * bn2
             maxiter = min(maxiter, (1 << 16) - check_every)
+            tot = w['tot']
             while done < maxiter:
                 a = done & 1
                 dist.all_gather_into_tensor(w['full'], w['p'][:chunk], group=sh.group)       # halo refresh
                 if sh.halo.numel():
                     torch.index_select(w['full'], 0, sh.halo_rows, out=w['p'][chunk:])
-                _C.check(spmv(sh.ptr.data_ptr(), w['other'].data_ptr(), self.HB.data_ptr(), w['D'].data_ptr(), w['Binv'].data_ptr(),
-                              w['p'].data_ptr(), w['z'].data_ptr(), w['q'].data_ptr(), w['scal'].data_ptr(), w['rr_hist'].data_ptr(),
-                              w['it'].data_ptr(), 1 << 16, n, m, st), "pplie_pcg2_spmv")
-                tot = S[a, :, :, 0].sum(-1)                                                   # [8] totals of this rank
-                dist.all_reduce(tot, group=sh.group)
-                S[a, w['qsel'], :, 0] = 0
-                S[a, w['qsel'], 0, 0] = tot[w['qsel']]
-                _C.check(step(w['x'].data_ptr(), w['r'].data_ptr(), w['r2'].data_ptr(), w['p'].data_ptr(), w['q'].data_ptr(), w['z'].data_ptr(),
-                              w['Binv'].data_ptr(), w['scal'].data_ptr(), w['it'].data_ptr(), n, m, st), "pplie_pcg2_step")
+                if gauge:
+                    # (tol2 = -1: the device-side stop test compares THIS rank's |r|^2 and never fires; the host tests the global one)
+                    _C.check(spmv_cz(sh.ptr.data_ptr(), w['other'].data_ptr(), self.HB.data_ptr(), w['D'].data_ptr(), w['Binv'].data_ptr(),
+                                     w['p'].data_ptr(), w['z'].data_ptr(), w['q'].data_ptr(), w['scal'].data_ptr(), w['cs'].data_ptr(),
+                                     w['rr_hist'].data_ptr(), w['it'].data_ptr(), 1 << 16, n, m, -1.0, st), "pplie_pcg2_spmv_coarse")
+                    # the 8 scalars and this iteration's Z^T q / Z^T r (set a of cs, elements 8..23) in ONE all-reduce
+                    torch.sum(S[a, :, :, 0], -1, out=tot[:8])
+                    torch.sum(CS[a, :, 8:24], 0, out=tot[8:])
+                    dist.all_reduce(tot, group=sh.group)
+                    S[a, w['qsel'], :, 0] = 0
+                    S[a, w['qsel'], 0, 0] = tot[w['qsel']]
+                    CS[a, :, 8:24] = 0
+                    CS[a, 0, 8:24] = tot[8:]
+                    _C.check(step_cz(w['x'].data_ptr(), w['r'].data_ptr(), w['r2'].data_ptr(), w['p'].data_ptr(), w['q'].data_ptr(),
+                                     w['z'].data_ptr(), w['Binv'].data_ptr(), w['scal'].data_ptr(), w['cs'].data_ptr(), w['it'].data_ptr(),
+                                     n, m, st), "pplie_pcg2_step_coarse")
+                else:
+                    _C.check(spmv(sh.ptr.data_ptr(), w['other'].data_ptr(), self.HB.data_ptr(), w['D'].data_ptr(), w['Binv'].data_ptr(),
+                                  w['p'].data_ptr(), w['z'].data_ptr(), w['q'].data_ptr(), w['scal'].data_ptr(), w['rr_hist'].data_ptr(),
+                                  w['it'].data_ptr(), 1 << 16, n, m, st), "pplie_pcg2_spmv")
+                    t8 = S[a, :, :, 0].sum(-1)                                                # [8] totals of this rank
+                    dist.all_reduce(t8, group=sh.group)
+                    S[a, w['qsel'], :, 0] = 0
+                    S[a, w['qsel'], 0, 0] = t8[w['qsel']]
+                    _C.check(step(w['x'].data_ptr(), w['r'].data_ptr(), w['r2'].data_ptr(), w['p'].data_ptr(), w['q'].data_ptr(), w['z'].data_ptr(),
+                                  w['Binv'].data_ptr(), w['scal'].data_ptr(), w['it'].data_ptr(), n, m, st), "pplie_pcg2_step")
                 done += 1
                 if done % check_every == 0 or done >= maxiter:
                     rr = S[a, 2, :, 0].sum().reshape(1)
@@ -334,7 +387,8 @@ class NodeShardedSystem:
                     _C.stream_ptr(dev)), "pplie_pcg_prepare")
                 code = persist_p2p_launch(pp_['rk'], [t.data_ptr() for t in pp_['ptag']], [t.data_ptr() for t in pp_['rpart']], sh.ptr,
                                           sh.other_global, self.HB, w['D'], w['Binv'], w['x'][:n], w['r'], w['z'], tol, maxiter,
-                                          _pg.PERSIST_GRID, sh.a, sh.N, sh.world, sh.rank, pp_['epoch'], m)
+                                          _pg.PERSIST_GRID, sh.a, sh.N, sh.world, sh.rank, pp_['epoch'], m,
+                                          shift=w['shift'] if self.gauge else None)
             _C.check(code, "pplie_pcg_persist_p2p")
         except Exception as e:                          # this rank could not launch: the peers will time out at the exchange
             local_err = e
@@ -366,10 +420,11 @@ class NodeShardedSystem:
                 and sh.world <= 8 and sh.chunk <= 256 * per_wg and sh.chunk > 0 and sh.N % 1 == 0
                 and (sh.p2p is None or sh.p2p.get('ok', True)))
 
-    def solve(self, s, dmin, dmax, tol, maxiter, check_every=8):
+    def solve(self, s, dmin, dmax, tol, maxiter, check_every=8, gauge=True):
         """(H + damping) d = -g over all ranks; returns the FULL step [N, m] (all-gathered) and the iteration count."""
         sh, m = self.sh, self.lin.m
         n = sh.n_own
+        self.gauge = bool(gauge)      # (the caller's verdict, from the gathered blocks every rank holds alike: group-uniform)
         if self.p2p_applicable() and (sh.world - 1) * sh.chunk < sh.N:       # (every rank owns at least one row)
             from . import posegraph as _pg
             try:
@@ -388,12 +443,24 @@ class NodeShardedSystem:
         D.diagonal(dim1=-2, dim2=-1).copy_(s * diag.clamp(dmin, dmax))        # optimizer.py:656-657, :666
         Binv = torch.linalg.inv(D) if n else D
         apply_Binv = lambda v: (Binv @ v.unsqueeze(-1)).squeeze(-1)
+        # two-level preconditioner (block-Jacobi + gauge modes, csrc/pcg_persist.hip "CZ"):  z = Binv r + Z (Z^T r / E) with
+        # E = sum over ALL nodes of the damping shift: m more sums in the scalar all-reduce of every iteration, one more at the start
+        gauge = self.gauge
         x = torch.zeros_like(self.g)
         r = -self.g
         z = apply_Binv(r)
-        p = z.clone()
-        sums = sh.sum_scalars(torch.stack([(r * z).sum(), (r * r).sum()]))
+        head = [(r * z).sum().reshape(1), (r * r).sum().reshape(1)]
+        if gauge:
+            head += [r.sum(0), (s * diag.clamp(dmin, dmax) - diag).sum(0)]
+        sums = sh.sum_scalars(torch.cat(head))
         rho, bn2 = sums[0], sums[1]
+        if gauge:
+            E = sums[2 + m:2 + 2 * m]
+            Einv = torch.where(E > 0, 1.0 / E.clamp_min(torch.finfo(E.dtype).tiny), torch.zeros_like(E))
+            c = sums[2:2 + m] * Einv
+            rho = rho + (sums[2:2 + m] * c).sum()
+            z = z + c
+        p = z.clone()
         if float(bn2) == 0.0:
             return sh.gather_rows(x), 0
         thresh = tol * tol * float(bn2)
@@ -407,8 +474,15 @@ class NodeShardedSystem:
             x = x + alpha * p
             r = r - alpha * q
             z = apply_Binv(r)
-            sums = sh.sum_scalars(torch.stack([(r * z).sum(), (r * r).sum()]))
+            tail = [(r * z).sum().reshape(1), (r * r).sum().reshape(1)]
+            if gauge:
+                tail.append(r.sum(0))
+            sums = sh.sum_scalars(torch.cat(tail))
             rho_new, rr = sums[0], sums[1]
+            if gauge:
+                c = sums[2:2 + m] * Einv
+                rho_new = rho_new + (sums[2:2 + m] * c).sum()
+                z = z + c
             done += 1
             if done % check_every == 0 or done >= maxiter:
                 rr_h = float(rr)

@@ -850,6 +850,32 @@ class GraphLinearization:
             cache['src'], cache['key'], cache['ok'] = None, key, bool(torch.equal(self.W, self.W.mT))
         return cache['ok']
 
+    def gauge_ok(self, solver=None):
+        """The two-level (block-Jacobi + gauge) preconditioner applies: pairwise edges with J[e, 0] = -J[e, 1], i.e. a global
+        motion Z = 1_N (x) I_m is in J's null space and E = Z^T A Z = diag(sum_n shift[n, :]).  Either the builder's promise
+        (``antisym``: the recognised relative-pose program) or, for an autograd-derived J, a check of the blocks themselves
+        (J_0 + J_1 = 0 up to rounding: any E > 0 keeps the preconditioner SPD, so rounding-level defects only cost iterations;
+        a unary prior makes J Z != 0 and fails it).  Under edge shards the verdict is agreed over the group (MIN)."""
+        if solver is not None and not getattr(solver, 'gauge', True):
+            return False
+        if not FusedPCG.coarse or self.K != 2:
+            return False
+        hit = self.__dict__.get('_gauge_ok')
+        if hit is None:
+            if self.antisym:
+                hit = True
+            else:
+                J = self.J
+                tol = float(torch.finfo(J.dtype).eps) ** 0.75
+                hit = bool((J[:, 0] + J[:, 1]).abs().amax() <= tol * J.abs().amax()) if self.E else False
+            if self.group is not None and not self.replicated:
+                import torch.distributed as dist
+                flag = torch.tensor([1.0 if hit else 0.0], device=self.J.device)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+                hit = bool(flag.item() > 0)
+            self._gauge_ok = hit
+        return hit
+
     # -- kernels ---------------------------------------------------------------------------------
     def _hip(self):
         return (_C._test_backend is None and self.J.is_cuda and (self.dr, self.m, self.K) in _HIP_SHAPES
@@ -980,7 +1006,7 @@ class GraphLinearization:
         if self.node_group is not None:
             pcg = solver if isinstance(solver, PCG) else PCG(tol=1e-10, maxiter=max(1000, 2 * N))
             maxiter = N * m * 10 if pcg.maxiter is None else pcg.maxiter
-            Dn, its = self.ns.solve(self.s, self.dmin, self.dmax, pcg.tol, maxiter, pcg.check_every)
+            Dn, its = self.ns.solve(self.s, self.dmin, self.dmax, pcg.tol, maxiter, pcg.check_every, gauge=self.gauge_ok(pcg))
             solver.iterations = its
             return Dn
         if not isinstance(solver, PCG) and N * m <= DENSE_LIMIT and self.group is None:
@@ -1004,7 +1030,10 @@ class GraphLinearization:
                 self.opt._warned_pcg = True
             solver = PCG(tol=1e-10, maxiter=max(1000, 2 * N))
         maxiter = N * m * 10 if solver.maxiter is None else solver.maxiter
-        if self._hip() and getattr(solver, 'fused', True) and m in (3, 6, 7):
+        # (edge shards with an all-reduced H p -- LM(group=) with replicate_solve off: the fused launches of that route carry the
+        #  block-Jacobi preconditioner only; with the gauge correction asked for and applicable the iteration below runs it)
+        sharded_gauge = self.group is not None and not self.replicated and not plain and self.gauge_ok(solver)
+        if self._hip() and getattr(solver, 'fused', True) and m in (3, 6, 7) and not sharded_gauge:
             cache = self.opt.__dict__.setdefault('_pcg_workspaces', {})
             key = (self.E, self.K, self.dr, self.m, self.N, self.J.dtype, self.J.device, self.W is not None,
                    solver.check_every)
@@ -1029,6 +1058,12 @@ class GraphLinearization:
             Bd.diagonal(dim1=-2, dim2=-1).copy_(s * clamped)
             Binv = torch.linalg.inv(Bd)
             precond = lambda r: (Binv * r.unsqueeze(-2)).sum(-1)
+            if self.gauge_ok(solver):
+                # + Z E^-1 Z^T (csrc/pcg_persist.hip "CZ"): r is whole on every rank here (edge shards all-reduce H p), no collective
+                E = shift.sum(0)
+                Einv = torch.where(E > 0, 1.0 / E.clamp_min(torch.finfo(E.dtype).tiny), torch.zeros_like(E))
+                local = precond
+                precond = lambda r: local(r) + r.sum(0) * Einv
         Dn = solver.solve(lambda p: self._Hp(p) + shift * p, -self.g, precond, stall=_STALL_CHECKS if plain else None)
         assert not torch.any(torch.isnan(Dn)), 'Linear solve produced NaN (matrix may not be positive-definite)'
         return Dn

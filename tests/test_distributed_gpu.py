@@ -85,6 +85,46 @@ def test_node_sharded_solve_on_rccl_equals_single_process(group, fused, exchange
     torch.testing.assert_close(a[2][0], model.nodes.detach(), rtol=0, atol=1e-7)
 
 
+@pytest.mark.parametrize("mode", ["replicated", "edges/allreduce", "nodes/rccl", "nodes/p2p"])
+def test_gauge_preconditioner_under_group_iteration_counts(group, mode):
+    """VERDICT r05 missing 2: PCG(gauge=True) keeps the two-level preconditioner under LM(group=...) -- replicated solve, node shards over
+    RCCL collectives (pplie_pcg2_spmv_coarse / pplie_pcg2_step_coarse + the all-reduced coarse sums) and over in-kernel peer stores
+    (pplie_pcg_persist_p2p_coarse): iteration counts within +-2 of the single-process solve and well below block-Jacobi's."""
+    from tests.test_optim_gpu import _synthetic_graph
+    edges, rel, init = _synthetic_graph(3000, 12000, torch.float32)
+    S = pp.optim.strategy.TrustRegion
+
+    def run(gauge, **kw):
+        graph = PoseGraph(init.clone())
+        replicate = kw.pop("replicate_solve", True)
+        opt = pp.optim.LM(graph, solver=pp.optim.solver.PCG(tol=1e-4, maxiter=400, check_every=1, gauge=gauge), strategy=S(radius=1e4), **kw)
+        opt.replicate_solve = replicate
+        kw["replicate_solve"] = replicate
+        its, losses = [], []
+        for _ in range(3):
+            losses.append(float(opt.step((edges, rel))))
+            its.append(int(opt.solver.iterations))
+        return its, losses, opt
+    ref_g, loss_g, _ = run(True)
+    ref_b, _, _ = run(False)
+    assert sum(ref_g) < sum(ref_b), (ref_g, ref_b)
+    kw = {"group": group}
+    if mode.startswith("nodes"):
+        kw.update(shard="nodes", exchange=mode.split("/")[1])
+    elif mode == "edges/allreduce":                      # edge shards, H p all-reduced in every iteration (replicate_solve off)
+        kw.update(replicate_solve=False)
+    its, losses, opt = run(True, **kw)
+    want = {"replicated": "replicated", "edges/allreduce": "edge-sharded"}.get(mode, "node-sharded solve")
+    assert opt._last_shard_mode.startswith(want), opt._last_shard_mode
+    if mode == "nodes/p2p":
+        assert opt._node_shards['shard'][1].p2p['ok']
+    assert all(abs(a - b) <= 2 for a, b in zip(its, ref_g)), (mode, its, ref_g, ref_b)
+    for x, y in zip(loss_g, losses):
+        assert abs(x - y) <= 2e-3 * abs(x)
+    its_b, _, _ = run(False, **kw)
+    assert all(abs(a - b) <= 2 for a, b in zip(its_b, ref_b)), (mode, its_b, ref_b)
+
+
 def test_p2p_failure_is_agreed_and_falls_back_to_rccl(group, monkeypatch):
     """a peer-exchange failure seen by ONE rank must move EVERY rank to the RCCL iteration, in the same
     solve.  A launch failure is injected into this rank's second p2p solve: the verdict all-reduce turns it into the group's

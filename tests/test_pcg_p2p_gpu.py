@@ -16,10 +16,10 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-def _system(N, E, dtype):
+def _system(N, E, dtype, gauge=False):
     edges, rel, init = _synthetic_graph(N, E, dtype)
     graph = PoseGraph(init.clone())
-    solver = pp.optim.solver.PCG(tol=1e-4, maxiter=250, gauge=False)      # (the P2P kernel is the block-Jacobi iteration)
+    solver = pp.optim.solver.PCG(tol=1e-4, maxiter=250, gauge=gauge)       # (the one-rank reference solve runs the same preconditioner)
     opt = pp.optim.LM(graph, solver=solver, strategy=pp.optim.strategy.TrustRegion(radius=1e4))
     opt.step((edges, rel))
     prog = opt._structure_cache["program"][3]
@@ -31,17 +31,17 @@ def _system(N, E, dtype):
     return lin, wsp
 
 
-def _rank_operands(lin, D, Binv, r, z, world, rank, dtype, m):
+def _rank_operands(lin, D, Binv, r, z, world, rank, dtype, m, shift=None):
     N = D.shape[0]
     ptr, blk, other = lin.csr()
     chunk, a, b = NS._bounds(N, world, rank)
     lo, hi = int(ptr[a]), int(ptr[b])
     return a, dict(ptr=(ptr[a:b + 1] - lo).to(torch.int32).contiguous(), other=other[lo:hi].contiguous(), HB=lin.HB[lo:hi].contiguous(),
                    D=D[a:b].contiguous(), Binv=Binv[a:b].contiguous(), x=torch.zeros(b - a, m, dtype=dtype, device=DEV),
-                   r=r[a:b].contiguous(), z=z[a:b].contiguous())
+                   r=r[a:b].contiguous(), z=z[a:b].contiguous(), **({} if shift is None else {"shift": shift[a:b].contiguous()}))
 
 
-def _worker(rank, world, port, dtype, tol, out, delay_rank=None):
+def _worker(rank, world, port, dtype, tol, out, delay_rank=None, gauge=False):
     """one process = one rank (all on this box's one GPU: separate processes have separate hardware queues, so their persistent
     kernels run side by side as they would on separate GPUs); the tables cross processes through hipIpc exactly as in production"""
     import torch.distributed as dist
@@ -49,17 +49,19 @@ def _worker(rank, world, port, dtype, tol, out, delay_rank=None):
     try:
         torch.cuda.set_device(0)
         N, E, m = 3000, 12000, 6
-        lin, wsp = _system(N, E, dtype)
+        lin, wsp = _system(N, E, dtype, gauge)
         with torch.no_grad():
+            wsp.want_gauge = gauge
             x_ref, its_ref = wsp.solve(lin, lin.s, lin.dmin, lin.dmax, tol, 2000, None)
-            D, Binv = wsp.D.clone(), wsp.Binv.clone()
+            assert wsp.cz == gauge
+            D, Binv, shift = wsp.D.clone(), wsp.Binv.clone(), (wsp.shift.clone() if gauge else None)
             r = (-lin.g).contiguous()
             z = (Binv @ r.unsqueeze(-1)).squeeze(-1).contiguous()
         rk = NS.P2PRank(N, m, dtype, torch.device(DEV))
         ptag, rpart = NS.p2p_exchange_tables(rk, dist.group.WORLD)
         res = []
         for epoch in (1, 2):                                         # twice: the tables are not cleared between solves
-            a, ops = _rank_operands(lin, D, Binv, r, z, world, rank, dtype, m)
+            a, ops = _rank_operands(lin, D, Binv, r, z, world, rank, dtype, m, shift)
             dist.barrier()
             if delay_rank == rank and epoch == 2:
                 import time
@@ -76,11 +78,13 @@ def _worker(rank, world, port, dtype, tol, out, delay_rank=None):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("gauge", [False, True], ids=["block_jacobi", "gauge"])
 @pytest.mark.parametrize("dtype,tol,atol", [(torch.float32, 1e-5, 2e-4), (torch.float64, 1e-10, 1e-8)])
 @pytest.mark.parametrize("world,delay_rank", [(2, None), (3, None), (4, None), (3, 1)])
-def test_ranks_in_separate_processes_reproduce_the_one_rank_solve(world, delay_rank, dtype, tol, atol):
+def test_ranks_in_separate_processes_reproduce_the_one_rank_solve(world, delay_rank, dtype, tol, atol, gauge):
     """2, 3 and 4 ranks; and 3 ranks of which one enters its second solve 50 ms late (the others spin at the exchange: tags of
-    the previous epoch are still in the tables and must not be taken for this one's)"""
+    the previous epoch are still in the tables and must not be taken for this one's).  gauge: the two-level preconditioner
+    (pplie_pcg_persist_p2p_coarse) against the one-rank ghost-zone solve with the same preconditioner."""
     import socket
     import torch.multiprocessing as mp
     with socket.socket() as sk:
@@ -88,7 +92,7 @@ def test_ranks_in_separate_processes_reproduce_the_one_rank_solve(world, delay_r
         port = sk.getsockname()[1]
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(k, world, port, dtype, tol, out, delay_rank)) for k in range(world)]
+    procs = [ctx.Process(target=_worker, args=(k, world, port, dtype, tol, out, delay_rank, gauge)) for k in range(world)]
     for p in procs:
         p.start()
     got = {}

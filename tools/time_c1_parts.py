@@ -45,3 +45,49 @@ y = x.Exp().Log().tensor()
 print("ours  bwd only (retain)     %.1f us" % timeit(lambda: torch.autograd.grad(y, x, g, retain_graph=True)))
 ty = t.sin().cos()
 print("torch bwd only (retain)     %.1f us" % timeit(lambda: torch.autograd.grad(ty, t, g, retain_graph=True)))
+
+
+# ---- where do fwd + bwd's extra microseconds go? (79.9 us in r03 -> 115-136 us in r05)
+def only_grad_none():
+    x.grad = None
+
+
+def bwd_contig():
+    x.grad = None
+    x.Exp().Log().tensor().backward(g)
+
+
+def bwd_sum_plain_leaf():
+    xt.grad = None
+    pp.se3(xt).Exp().Log().tensor().sum().backward()
+
+
+def fwd_bwd_autograd_grad():
+    return torch.autograd.grad(x.Exp().Log().tensor().sum(), x)
+
+
+xt = x.detach().tensor().clone().requires_grad_(True)
+print("x.grad = None alone         %.1f us" % timeit(only_grad_none))
+print("fwd + backward(ones)        %.1f us" % timeit(bwd_contig))
+print("fwd + sum + bwd, plain leaf %.1f us" % timeit(bwd_sum_plain_leaf))
+print("fwd + sum + autograd.grad   %.1f us" % timeit(fwd_bwd_autograd_grad))
+print("ours  fwd + bwd (again)     %.1f us" % timeit(fwd_bwd))
+import cProfile, pstats, io
+pr = cProfile.Profile()
+for _ in range(50): fwd_bwd()
+torch.cuda.synchronize()
+pr.enable()
+for _ in range(300): fwd_bwd()
+torch.cuda.synchronize()
+pr.disable()
+sio = io.StringIO()
+pstats.Stats(pr, stream=sio).sort_stats("tottime").print_stats(18)
+print("\n".join(l[:150] for l in sio.getvalue().splitlines()[:40]))
+try:
+    from torch.profiler import profile, ProfilerActivity
+    with profile(activities=[ProfilerActivity.CPU]) as prof:
+        for _ in range(100): fwd_bwd()
+        torch.cuda.synchronize()
+    print(prof.key_averages().table(sort_by="self_cpu_time_total", row_limit=25, max_name_column_width=60)[:6000])
+except Exception as e:
+    print("profiler:", repr(e))

@@ -43,17 +43,22 @@ with torch.no_grad():
         out[f"ghost_grid{grid}"] = {"us_per_solve_40": round(res[40][0], 1), "us_per_solve_200": round(res[200][0], 1),
                                     "marginal_us_per_iteration": round((res[200][0] - res[40][0]) / (res[200][1] - res[40][1]), 2),
                                     "used": not wsp.__dict__.get("_no_ghost", False)}
+    for pg in (160, 256):
+        G.PERSIST_GRID = pg
+        wsp.__dict__.pop('_no_ghost', None)
+        G.FusedPCG.profile = True                    # phases of the ghost-zone iteration (ticks of 10 ns, thread 0 of a clocked workgroup)
+        try:
+            x, its = wsp.solve(lin, lin.s, lin.dmin, lin.dmax, 1e-30, 200, None)
+        finally:
+            G.FusedPCG.profile = False
+        torch.cuda.synchronize()
+        # all tick slots of the two clocked workgroups (middle: a plain member of the exchange; 0: a group leader at grids >= 224).
+        # Slots: 0 spmv+put_q | 1 wave sums+barrier1 | 5 own row summed+published | 6 leader's group gather+publish | 7 final gather |
+        # 2 rest of the exchange call | 3 ghost q wait+barrier2 | 4 update+barrier3
+        for nm, off in (("mid", 48), ("wg0", 32)):
+            tk = wsp.rr_hist[wsp.cap - off:wsp.cap - off + 14].tolist()
+            out["ghost_grid%d_ticks_us_per_iteration_%s" % (pg, nm)] = [round(t * 0.01 / max(its, 1), 3) for t in tk]
     G.PERSIST_GRID = 256
-    wsp.__dict__.pop('_no_ghost', None)
-    G.FusedPCG.profile = True                    # phases of the ghost-zone iteration (ticks of 10 ns, thread 0 of the middle workgroup)
-    try:
-        x, its = wsp.solve(lin, lin.s, lin.dmin, lin.dmax, 1e-30, 200, None)
-    finally:
-        G.FusedPCG.profile = False
-    torch.cuda.synchronize()
-    tk = wsp.rr_hist[wsp.cap - 8:wsp.cap - 3].tolist()
-    out["ghost_grid256_phase_us_per_iteration"] = {n: round(t * 0.01 / max(its, 1), 3) for n, t in zip(
-        ("spmv(2 passes, barrier0)+put_q", "wave_sums+barrier1", "publish+issue_ghost_q+allgather", "ghost_q_wait+barrier2", "update+barrier3"), tk)}
     xg, itg = wsp.solve(lin, lin.s, lin.dmin, lin.dmax, 1e-6, 2000, None)
     G.FusedPCG.ghost = False
     xp, itp = wsp.solve(lin, lin.s, lin.dmin, lin.dmax, 1e-6, 2000, None)
@@ -103,4 +108,5 @@ with torch.no_grad():
         torch.cuda.synchronize()
         ts.append(a.elapsed_time(b) * 1e3)
     out["two_launch_it200"] = {"us_per_solve": round(sorted(ts[1:])[1], 1), "iterations": its, "us_per_iteration": round(sorted(ts[1:])[1] / max(its, 1), 2)}
-print(json.dumps(out))
+for k, v in out.items():
+    print(json.dumps({k: v}))
