@@ -783,6 +783,36 @@ int graph_assemble_lap(const void* ptr, const void* blk, const void* J, const vo
 }
 }  // namespace pplie
 
+// the second launch alone (the blocks and gradient shares came out of pplie_pgo_linearize_lap)
+namespace pplie {
+template <class T>
+int graph_lap_diag(const void* ptr, const void* HB, const void* gg, void* B, void* g, int64_t N, int m, int pack, void* stream) {
+  if (N <= 0) return N == 0 ? PPLIE_OK : PPLIE_EBADARG;
+  if (!ptr || !HB || !gg || !B || !g) return PPLIE_EBADARG;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+#define LAUNCH(MM, PK)                                                                                                        \
+  {                                                                                                                           \
+    constexpr int NPW = 64 / MM;                                                                                              \
+    const int64_t bb = ((N + NPW - 1) / NPW + 3) / 4;                                                                         \
+    hipLaunchKernelGGL((lap_diag_kernel<T, MM, PK>), dim3((unsigned)bb), dim3(256), 0, st, (const int*)ptr, (const T*)HB,      \
+                       (const T*)gg, (T*)B, (T*)g, N);                                                                        \
+  }
+#define BYM(MM) { if (pack) LAUNCH(MM, true) else LAUNCH(MM, false) }
+  if (m == 6) BYM(6) else if (m == 7) BYM(7) else if (m == 3) BYM(3) else return PPLIE_EBADARG;
+#undef BYM
+#undef LAUNCH
+  return hipGetLastError() == hipSuccess ? PPLIE_OK : PPLIE_ELAUNCH;
+}
+}  // namespace pplie
+extern "C" int pplie_graph_lap_diag_f32(const void* ptr, const void* HB, const void* gg, void* Bdiag, void* grad, int64_t N, int m, int pack,
+                                        void* stream) {
+  return pplie::graph_lap_diag<float>(ptr, HB, gg, Bdiag, grad, N, m, pack, stream);
+}
+extern "C" int pplie_graph_lap_diag_f64(const void* ptr, const void* HB, const void* gg, void* Bdiag, void* grad, int64_t N, int m, int pack,
+                                        void* stream) {
+  return pplie::graph_lap_diag<double>(ptr, HB, gg, Bdiag, grad, N, m, pack, stream);
+}
+
 extern "C" int pplie_graph_assemble_lap_f32(const void* ptr, const void* blk, const void* J, const void* W, const void* R, void* Bdiag,
                                             void* grad, void* HB, void* gg, int64_t N, int64_t nnz, int m, int pack, void* stream) {
   return pplie::graph_assemble_lap<float>(ptr, blk, J, W, R, Bdiag, grad, HB, gg, N, nnz, m, pack, stream);
@@ -851,6 +881,49 @@ extern "C" int pplie_segment_sum_f64(const void* vals, const void* perm, const v
 // ---------------------------------------------------------------------------------------------
 namespace pplie {
 enum { Q_BN2 = 3 };
+// one node of pplie_pcg_prepare: A = the raw diagonal block (overwritten by D), gv = the gradient row
+template <class T, int M>
+__device__ __forceinline__ void prepare_node(T* A, const T* gv, int64_t n, T s, T dmin, T dmax, T* __restrict__ D, T* __restrict__ Binv,
+                                             T* __restrict__ shift, T* __restrict__ x, T* __restrict__ r, T* __restrict__ z,
+                                             T* __restrict__ p, T* __restrict__ Dp, T* __restrict__ Bp, T& a_rho, T& a_bn, T* a_cs) {
+  T X[M * M], rv[M];
+#pragma unroll
+  for (int i = 0; i < M; ++i) {
+    const T d = A[i * M + i];
+    const T c = s * (d < dmin ? dmin : (d > dmax ? dmax : d));
+    shift[n * M + i] = c - d;
+    A[i * M + i] = c;
+    rv[i] = -gv[i];
+    a_bn += rv[i] * rv[i];
+    a_cs[i] += c - d;
+    a_cs[M + i] += rv[i];
+  }
+  Op_spd_inverse_apply<T, M>(A, X);
+#pragma unroll
+  for (int i = 0; i < M * M; ++i) { D[n * M * M + i] = A[i]; Binv[n * M * M + i] = X[i]; }
+  if (Dp) {                              // (launch-uniform) the same two blocks as packed upper triangles, for the DPK iteration
+    constexpr int NPD = M * (M + 1) / 2;
+#pragma unroll
+    for (int rr = 0; rr < M; ++rr)
+#pragma unroll
+      for (int c = rr; c < M; ++c) {
+        const int e = rr * M - (rr * (rr - 1)) / 2 + (c - rr);
+        Dp[n * NPD + e] = A[rr * M + c];
+        Bp[n * NPD + e] = X[rr * M + c];
+      }
+  }
+#pragma unroll
+  for (int i = 0; i < M; ++i) {
+    T zi = T(0);
+#pragma unroll
+    for (int j = 0; j < M; ++j) zi += X[i * M + j] * rv[j];
+    x[n * M + i] = T(0);
+    r[n * M + i] = rv[i];
+    z[n * M + i] = zi;
+    p[n * M + i] = zi;
+    a_rho += rv[i] * zi;
+  }
+}
 template <class T, int M>
 __global__ void __launch_bounds__(256)
 pcg_prepare_kernel(const T* __restrict__ B, const T* __restrict__ g, T* __restrict__ D, T* __restrict__ Binv,
@@ -872,45 +945,12 @@ pcg_prepare_kernel(const T* __restrict__ B, const T* __restrict__ g, T* __restri
 #pragma unroll
   for (int i = 0; i < 2 * M; ++i) a_cs[i] = T(0);
   for (int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x; n < N; n += (int64_t)gridDim.x * 256) {
-    T A[M * M], X[M * M], rv[M];
+    T A[M * M], gv[M];
 #pragma unroll
     for (int i = 0; i < M * M; ++i) A[i] = B[n * M * M + i];
 #pragma unroll
-    for (int i = 0; i < M; ++i) {
-      const T d = A[i * M + i];
-      const T c = s * (d < dmin ? dmin : (d > dmax ? dmax : d));
-      shift[n * M + i] = c - d;
-      A[i * M + i] = c;
-      rv[i] = -g[n * M + i];
-      a_bn += rv[i] * rv[i];
-      a_cs[i] += c - d;
-      a_cs[M + i] += rv[i];
-    }
-    Op_spd_inverse_apply<T, M>(A, X);
-#pragma unroll
-    for (int i = 0; i < M * M; ++i) { D[n * M * M + i] = A[i]; Binv[n * M * M + i] = X[i]; }
-    if (Dp) {                              // (launch-uniform) the same two blocks as packed upper triangles, for the DPK iteration
-      constexpr int NPD = M * (M + 1) / 2;
-#pragma unroll
-      for (int r = 0; r < M; ++r)
-#pragma unroll
-        for (int c = r; c < M; ++c) {
-          const int e = r * M - (r * (r - 1)) / 2 + (c - r);
-          Dp[n * NPD + e] = A[r * M + c];
-          Bp[n * NPD + e] = X[r * M + c];
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < M; ++i) {
-      T zi = T(0);
-#pragma unroll
-      for (int j = 0; j < M; ++j) zi += X[i * M + j] * rv[j];
-      x[n * M + i] = T(0);
-      r[n * M + i] = rv[i];
-      z[n * M + i] = zi;
-      p[n * M + i] = zi;
-      a_rho += rv[i] * zi;
-    }
+    for (int i = 0; i < M; ++i) gv[i] = g[n * M + i];
+    prepare_node<T, M>(A, gv, n, s, dmin, dmax, D, Binv, shift, x, r, z, p, Dp, Bp, a_rho, a_bn, a_cs);
   }
   T s1 = block_sum(a_rho);
   T s2 = block_sum(a_bn);

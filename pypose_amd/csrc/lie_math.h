@@ -858,9 +858,26 @@ template <class S> PP_HD void ws_coef(const V3<S>& phi, S sigma, S& A, S& B, S& 
     B = (S(T(0.5)) * s2 * scale + scale - S(T(1)) - s2 * scale) / (s2 * sigma);   // sic: reference :115
   } else {
     C = pp_expm1(sigma) / sigma;
-    S a = scale * pp_sin(th), b = scale * pp_cos(th), c = th2 + s2;
-    A = (a * sigma + (S(T(1)) - b) * th) / (th * c);
-    B = (C - ((b - S(T(1))) * sigma + a * th) / c) * (S(T(1)) / th2);
+    S c = th2 + s2;
+    if (sizeof(T) == 4 && pp_val(c) < T(1.0 / 64)) {
+      // fp32, sigma AND theta small: the closed forms below cancel -- a sigma and (1 - b) theta agree to a fraction c / 2 of
+      // themselves and 1 - b carries an absolute rounding error of one ulp of 1, so A is wrong by ~2e-7 / c (1 % at
+      // sigma = theta = 3e-3; 3 rows in 300 k random ones left the 1e-5 band of the fp64 oracle, profiles/r06).  There, the
+      // coefficients' own series  A = int_0^1 e^{u sigma} sin(u theta) / theta du = sum sigma^n (-theta^2)^m / (n! (2m+1)! (n+2m+2)),
+      // B = int_0^1 e^{u sigma} (1 - cos(u theta)) / theta^2 du = sum sigma^n (-theta^2)^m / (n! (2m+2)! (n+2m+3)),
+      // to total degree 6 (next term < 1e-10 at c = 1/64).  fp64 keeps the closed forms (their error there is 2e-16 / c).
+      const S g = sigma, t = th2;
+      A = S(T(1.0 / 2)) + g * (S(T(1.0 / 3)) + g * (S(T(1.0 / 8)) + g * (S(T(1.0 / 30)) + g * (S(T(1.0 / 144)) + g * (S(T(1.0 / 840)) + g * S(T(1.0 / 5760)))))))
+          - t * (S(T(1.0 / 24)) + g * (S(T(1.0 / 30)) + g * (S(T(1.0 / 72)) + g * (S(T(1.0 / 252)) + g * S(T(1.0 / 1152)))))
+                 - t * (S(T(1.0 / 720)) + g * (S(T(1.0 / 840)) + g * S(T(1.0 / 1920))) - t * S(T(1.0 / 40320))));
+      B = S(T(1.0 / 6)) + g * (S(T(1.0 / 8)) + g * (S(T(1.0 / 20)) + g * (S(T(1.0 / 72)) + g * (S(T(1.0 / 336)) + g * S(T(1.0 / 1920))))))
+          - t * (S(T(1.0 / 120)) + g * (S(T(1.0 / 144)) + g * (S(T(1.0 / 336)) + g * S(T(1.0 / 1152))))
+                 - t * (S(T(1.0 / 5040)) + g * S(T(1.0 / 5760))));
+    } else {
+      S a = scale * pp_sin(th), b = scale * pp_cos(th);
+      A = (a * sigma + (S(T(1)) - b) * th) / (th * c);
+      B = (C - ((b - S(T(1))) * sigma + a * th) / c) * (S(T(1)) / th2);
+    }
   }
 }
 // W v = A phi x v + B phi x (phi x v) + C v

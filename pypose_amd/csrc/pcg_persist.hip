@@ -203,6 +203,7 @@ __device__ __forceinline__ void gather_rows(SH& sh, int par, const u64* part, un
                                             int rows_per_table = kPersistGridMax) {
   // rows first, first + stride, ... (count of them; default: one per workgroup of the grid) of table `par`
   constexpr int NW = sizeof(T) / 4, RW = SLOTS * NW, WVS = kPersistBlock / 64;
+  constexpr int RPL = sizeof(T) == 8 && NQ > WVS ? 2 : 4;     // rows per lane and round (fewer where a value is two words and a wave polls two quantities: registers)
   constexpr int PER = (NQ + WVS - 1) / WVS;                  // quantities per wave: w, w + 16, ... polled TOGETHER (one spin loop:
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;   //  a second quantity costs no second round of L2 latencies)
   if (count < 0) count = (int)gridDim.x;
@@ -212,32 +213,49 @@ __device__ __forceinline__ void gather_rows(SH& sh, int par, const u64* part, un
 #pragma unroll
     for (int u = 0; u < PER; ++u) sum[u] = T(0);
     bool all = true;
-    for (int base = 0; base < count; base += 256) {
-      T val[PER][4];
-      bool done[PER][4];
+    for (int base = 0; base < count; base += 64 * RPL) {
+      // unconditional loads, tags tested after the whole round has been issued (see gather_pairs): one round trip per round
+      const u64* src[PER][RPL];
+      bool in[PER][RPL];
 #pragma unroll
       for (int u = 0; u < PER; ++u)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { done[u][q] = base + lane + 64 * q >= count || w + u * WVS >= NQ; val[u][q] = T(0); }
+        for (int q = 0; q < RPL; ++q) {
+          const int row = base + lane + 64 * q;
+          in[u][q] = row < count && w + u * WVS < NQ;
+          src[u][q] = tab + (size_t)(first + stride * (row < count ? row : 0)) * RW + (in[u][q] ? w + u * WVS : w) * NW;
+        }
+      u64 wv[PER][RPL][NW];
+      bool good = false;
       for (long spin = 0; spin < (1L << 20); ++spin) {
-        bool pending = false;
 #pragma unroll
         for (int u = 0; u < PER; ++u)
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            if (!done[u][q]) {
-              bool ok = true;
-              const T t = get_value<T>(tab + (size_t)(first + stride * (base + lane + 64 * q)) * RW + (w + u * WVS) * NW, tag, ok);
-              if (ok) { val[u][q] = t; done[u][q] = true; } else pending = true;
-            }
-          }
-        if (!pending) break;
+          for (int q = 0; q < RPL; ++q)
+#pragma unroll
+            for (int k = 0; k < NW; ++k) wv[u][q][k] = xwg_load(src[u][q] + k);
+        unsigned miss = 0u;
+#pragma unroll
+        for (int u = 0; u < PER; ++u)
+#pragma unroll
+          for (int q = 0; q < RPL; ++q)
+#pragma unroll
+            for (int k = 0; k < NW; ++k) miss |= in[u][q] ? ((unsigned)(wv[u][q][k] >> 32) ^ tag) : 0u;
+        if (miss == 0u) { good = true; break; }
         __builtin_amdgcn_s_sleep(1);
       }
+      all = all && good;
 #pragma unroll
       for (int u = 0; u < PER; ++u)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { all = all && done[u][q]; sum[u] += val[u][q]; }
+        for (int q = 0; q < RPL; ++q) {
+          unsigned lo[NW];
+#pragma unroll
+          for (int k = 0; k < NW; ++k) lo[k] = (unsigned)wv[u][q][k];
+          T t;
+          __builtin_memcpy(&t, lo, sizeof(T));
+          if (in[u][q] && good) sum[u] += t;
+        }
     }
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
@@ -301,25 +319,37 @@ __device__ __forceinline__ void gather_pairs(SH& sh, int par, const u64* part, u
     float s0 = 0.f, s1 = 0.f;
     bool all = true;
     for (int base = 0; base < count; base += 64 * LD) {            // (LD rows per lane and round: 192 cover the usual grids of 160 - 192)
-      float v0[LD], v1[LD];
-      bool done[LD];
+      // Every load of a poll round is UNCONDITIONAL (a row beyond `count` reads row `first` and is ignored) and the tags are looked
+      // at only after all LD loads have been issued: with a branch per row (`if (!done[q]) load`) the compiler waited for each load
+      // before issuing the next -- three dependent round trips to the memory side per round instead of one (round 6: the final
+      // gather of the 17-quantity exchange was 2.5 us of the 7.9 us iteration).  A round re-reads rows it has seen complete: their
+      // words cannot change before this workgroup has published its next row.
+      const u64* src[LD];
+      bool in[LD];
 #pragma unroll
-      for (int q = 0; q < LD; ++q) { done[q] = base + lane + 64 * q >= count; v0[q] = 0.f; v1[q] = 0.f; }
+      for (int q = 0; q < LD; ++q) {
+        const int row = base + lane + 64 * q;
+        in[q] = row < count;
+        src[q] = tab + (size_t)(first + stride * (in[q] ? row : 0)) * RW + w;
+      }
+      u64 wv[LD];
+      bool good = false;
       for (long spin = 0; spin < (1L << 20); ++spin) {
-        bool pending = false;
 #pragma unroll
-        for (int q = 0; q < LD; ++q) {
-          if (!done[q]) {
-            float a, b;
-            if (unpack_pair(xwg_load(tab + (size_t)(first + stride * (base + lane + 64 * q)) * RW + w), t2, a, b)) { v0[q] = a; v1[q] = b; done[q] = true; }
-            else pending = true;
-          }
-        }
-        if (!pending) break;
+        for (int q = 0; q < LD; ++q) wv[q] = xwg_load(src[q]);
+        unsigned miss = 0u;                                          // (bitwise, no short-circuit: a branch per row costs SALU mask work)
+#pragma unroll
+        for (int q = 0; q < LD; ++q) miss |= in[q] ? ((((unsigned)wv[q] ^ t2) | ((unsigned)(wv[q] >> 32) ^ t2)) & 3u) : 0u;
+        if (miss == 0u) { good = true; break; }
         __builtin_amdgcn_s_sleep(1);
       }
+      all = all && good;
 #pragma unroll
-      for (int q = 0; q < LD; ++q) { all = all && done[q]; s0 += v0[q]; s1 += v1[q]; }
+      for (int q = 0; q < LD; ++q) {
+        float a, b;
+        unpack_pair(wv[q], t2, a, b);
+        if (in[q] && good) { s0 += a; s1 += b; }
+      }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) { s0 += __shfl_xor(s0, off, 64); s1 += __shfl_xor(s1, off, 64); }
@@ -744,13 +774,14 @@ pcg_ghost_kernel(const int* __restrict__ ptr, const int* __restrict__ slot, cons
   }
   // ---- ghost elements: layer l holds ghost g_lo + l * POS + pos
   T gbr[kGhostLayers][M], gr[kGhostLayers], gp[kGhostLayers];
-  int gnode[kGhostLayers];
+  int gnode[kGhostLayers], goff[kGhostLayers];                     // goff: word offset of the ghost's element in a q table
   bool gact[kGhostLayers];
 #pragma unroll
   for (int l = 0; l < kGhostLayers; ++l) {
     const int gi = l * POS + pos;
     gact[l] = sub < NPW && gi < n_ghost;
     gnode[l] = gact[l] ? gids[g_lo + gi] : 0;
+    goff[l] = (gnode[l] * M + (sub < NPW ? i : 0)) * NW;
     gr[l] = T(0);
     gp[l] = T(0);
 #pragma unroll
@@ -873,26 +904,42 @@ pcg_ghost_kernel(const int* __restrict__ ptr, const int* __restrict__ slot, cons
     __syncthreads();                                                             // barrier 1
     PPLIE_TICK(1)
     if constexpr (!CZ) publish_row<T, NQ, SH, SLOTS>(sh, par, part, tag);
-    // ---- the ghosts' q: issued now, needed after the all-gather
-    T gq[kGhostLayers];
-    bool gok[kGhostLayers];
+    // ---- the ghosts' q: issued now, needed after the all-gather.  Raw tagged words, UNCONDITIONAL loads (an absent ghost reads
+    // node 0's word and is ignored), tags looked at after the exchange: nothing between here and the exchange's own loads waits
+    // for these (with `gact[l] ? get_value(..) : 0` every layer's load was followed by its own s_waitcnt).
+    u64 gw[kGhostLayers][NW];
+    const u64* qt = qtag + (size_t)par * NM;
 #pragma unroll
-    for (int l = 0; l < kGhostLayers; ++l) {
-      gok[l] = true;
-      gq[l] = gact[l] ? get_value<T>(qtag + (size_t)par * NM + ((size_t)gnode[l] * M + i) * NW, tag, gok[l]) : T(0);
-    }
+    for (int l = 0; l < kGhostLayers; ++l)
+#pragma unroll
+      for (int kk = 0; kk < NW; ++kk) gw[l][kk] = xwg_load(qt + goff[l] + kk);
     if constexpr (CZ) exchange_two_level<T, NQ, SH, SLOTS>(sh, par, part, tag, (k >> 1) + par, clocked);   // (table 1's use 0 was the set-up exchange)
     else gather_rows<T, NQ, SH, SLOTS>(sh, par, part, tag);
     PPLIE_TICK(2)
     bool stale = false;
+    for (long spin = 0;; ++spin) {
+      unsigned miss = 0u;
+#pragma unroll
+      for (int l = 0; l < kGhostLayers; ++l)
+#pragma unroll
+        for (int kk = 0; kk < NW; ++kk) miss |= gact[l] ? ((unsigned)(gw[l][kk] >> 32) ^ tag) : 0u;
+      if (miss == 0u) break;
+      if (spin >= (1L << 20)) { stale = true; break; }
+      __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+      for (int l = 0; l < kGhostLayers; ++l)
+#pragma unroll
+        for (int kk = 0; kk < NW; ++kk) gw[l][kk] = xwg_load(qt + goff[l] + kk);
+    }
+    T gq[kGhostLayers];
 #pragma unroll
     for (int l = 0; l < kGhostLayers; ++l) {
-      for (long spin = 0; gact[l] && !gok[l]; ++spin) {
-        if (spin >= (1L << 20)) { stale = true; break; }
-        __builtin_amdgcn_s_sleep(1);
-        gok[l] = true;
-        gq[l] = get_value<T>(qtag + (size_t)par * NM + ((size_t)gnode[l] * M + i) * NW, tag, gok[l]);
-      }
+      unsigned lo[NW];
+#pragma unroll
+      for (int kk = 0; kk < NW; ++kk) lo[kk] = (unsigned)gw[l][kk];
+      T v;
+      __builtin_memcpy(&v, lo, sizeof(T));
+      gq[l] = gact[l] && !stale ? v : T(0);
     }
     if (stale) sh.bad[par] = 1;
     __syncthreads();                                                             // barrier 2

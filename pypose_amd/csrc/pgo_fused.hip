@@ -31,11 +31,21 @@ template <class T> __device__ __forceinline__ void pgo_residual(const T* z, cons
   se3_log<T>(u, r);
 }
 
-template <class T, int BLOCK>
+// LAP != 0: the edge's share of the normal equations leaves the same kernel (round 6; was pplie_graph_assemble_lap's first launch,
+// csrc/graph.hip lap_blocks_kernel, which read the J blocks this kernel had just written back from memory -- 288 B per edge -- and
+// formed every S_e twice, once per incidence).  With J_e0 = -J_e1 = -Jm every block of H touched by edge e is +-S_e, S_e = Jm^T Jm
+// (symmetric; Jm = [[A, B], [0, A]] makes it 81 FMAs), and the gradient shares are -+Jm^T r_e: -S_e goes to BOTH incidence slots
+// inc[e, 0], inc[e, 1] of HB (incidence = position of (edge, side) in the node-sorted CSR list; LAP = 1: full [6, 6] blocks,
+// LAP = 2: packed upper triangles [21]), -+Jm^T r to the same slots of gg.  Same products in the same order as lap_blocks_kernel
+// (zeros of Jm's lower-left block skipped).  Per edge: 24 B (R) + 288 B (J) + 2 x (84 | 144) B + 2 x 24 B written, nothing re-read.
+template <class T, int BLOCK, int LAP = 0>
 __global__ void __launch_bounds__(BLOCK)
 pgo_linearize_kernel(const T* __restrict__ nodes, const int64_t* __restrict__ idx, const T* __restrict__ Z,
-                     T* __restrict__ R, T* __restrict__ J, int64_t E, RobustParam<T> rk) {
+                     T* __restrict__ R, T* __restrict__ J, int64_t E, RobustParam<T> rk, const int* __restrict__ inc = nullptr,
+                     T* __restrict__ HB = nullptr, T* __restrict__ gg = nullptr) {
   __shared__ __attribute__((aligned(16))) T lds[BLOCK * 72];
+  __shared__ int inc_s[LAP ? BLOCK * 2 : 1];
+  constexpr int SW = 27;                                          // staged per edge: 21 entries of S's upper triangle + 6 of Jm^T r
   const int64_t ntiles = (E + BLOCK - 1) / BLOCK;
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int64_t e0 = tile * BLOCK;
@@ -93,6 +103,49 @@ pgo_linearize_kernel(const T* __restrict__ nodes, const int64_t* __restrict__ id
     __syncthreads();
     slab_s2g<T, BLOCK, BLOCK * 72, true>(lds, J + e0 * 72, rows * 72, full);
     __syncthreads();
+    if constexpr (LAP != 0) {
+      if (t < rows) {
+        T* st = lds + t * SW;                                     // (stride 27 words: conflict-free)
+        int k = 0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+          for (int b = i; b < 6; ++b) {
+            T a = T(0);
+#pragma unroll
+            for (int l = 0; l < 6; ++l)
+              if (l < 3 || i >= 3) a += Jm[l * 6 + i] * Jm[l * 6 + b];     // (rows 3..5 of Jm are zero in columns 0..2)
+            st[k++] = a;
+          }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          T a = T(0);
+#pragma unroll
+          for (int l = 0; l < 6; ++l)
+            if (l < 3 || i >= 3) a += Jm[l * 6 + i] * r[l];
+          st[21 + i] = a;
+        }
+      }
+      for (int q = t; q < rows * 2; q += BLOCK) inc_s[q] = inc[e0 * 2 + q];
+      __syncthreads();
+      constexpr int RW = LAP == 2 ? 21 : 36;
+      for (int q = t; q < rows * 2 * RW; q += BLOCK) {            // consecutive lanes write consecutive words of an incidence's row
+        const int row = q / RW, k = q - row * RW;
+        int src = k;
+        if constexpr (LAP == 1) {
+          const int i = k / 6, b = k - i * 6;
+          const int lo = i < b ? i : b, hi = i < b ? b : i;
+          src = lo * 6 - (lo * (lo - 1)) / 2 + (hi - lo);
+        }
+        HB[(int64_t)inc_s[row] * RW + k] = -lds[(row >> 1) * SW + src];
+      }
+      for (int q = t; q < rows * 12; q += BLOCK) {
+        const int row = q / 6, k = q - row * 6;
+        const T v = lds[(row >> 1) * SW + 21 + k];
+        gg[(int64_t)inc_s[row] * 6 + k] = (row & 1) ? v : -v;     // (side 0: J_c = -Jm)
+      }
+      __syncthreads();
+    }
   }
 }
 
@@ -312,15 +365,26 @@ int pgo_trial_tail(void* nodes, void* backup, const void* idx, const void* Z, co
 
 template <class T>
 int pgo_linearize(const void* nodes, const void* idx, const void* Z, void* R, void* J, int64_t E, void* stream, int kind = 0,
-                  double p0 = 0, double p1 = 0) {
+                  double p0 = 0, double p1 = 0, const void* inc = nullptr, void* HB = nullptr, void* gg = nullptr, int pack = 0) {
   if (E < 0 || kind < 0 || kind > RK_TOLERANT) return PPLIE_EBADARG;
   if (E == 0) return PPLIE_OK;
   if (!nodes || !idx || !Z || !R || !J || !aligned16(Z) || !aligned16(R) || !aligned16(J)) return PPLIE_EBADARG;
+  if ((inc || HB || gg) && !(inc && HB && gg)) return PPLIE_EBADARG;
+  if (inc && E >= ((int64_t)1 << 30)) return PPLIE_EBADARG;      // (incidence slots are int32)
   constexpr int BLOCK = 64;
   int64_t nt = (E + BLOCK - 1) / BLOCK;
   int grid = (int)(nt < (1 << 20) ? nt : (1 << 20));
-  hipLaunchKernelGGL((pgo_linearize_kernel<T, BLOCK>), dim3(grid), dim3(BLOCK), 0, reinterpret_cast<hipStream_t>(stream),
-                     (const T*)nodes, (const int64_t*)idx, (const T*)Z, (T*)R, (T*)J, E, RobustParam<T>{kind, (T)p0, (T)p1});
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const RobustParam<T> rk{kind, (T)p0, (T)p1};
+  if (!inc)
+    hipLaunchKernelGGL((pgo_linearize_kernel<T, BLOCK>), dim3(grid), dim3(BLOCK), 0, st, (const T*)nodes, (const int64_t*)idx,
+                       (const T*)Z, (T*)R, (T*)J, E, rk);
+  else if (pack)
+    hipLaunchKernelGGL((pgo_linearize_kernel<T, BLOCK, 2>), dim3(grid), dim3(BLOCK), 0, st, (const T*)nodes, (const int64_t*)idx,
+                       (const T*)Z, (T*)R, (T*)J, E, rk, (const int*)inc, (T*)HB, (T*)gg);
+  else
+    hipLaunchKernelGGL((pgo_linearize_kernel<T, BLOCK, 1>), dim3(grid), dim3(BLOCK), 0, st, (const T*)nodes, (const int64_t*)idx,
+                       (const T*)Z, (T*)R, (T*)J, E, rk, (const int*)inc, (T*)HB, (T*)gg);
   return hipGetLastError() == hipSuccess ? PPLIE_OK : PPLIE_ELAUNCH;
 }
 template <class T>
@@ -358,6 +422,19 @@ extern "C" int pplie_pgo_residual_robust_f64(const void* nodes, const void* idx,
   return pplie::pgo_residual_launch<double>(nodes, idx, Z, R, partial, E, stream, kind, p0, p1);
 }
 
+// linearisation + the edges' shares of the normal equations in one launch (pgo_linearize_kernel LAP): inc [E, 2] int32 = the incidence
+// slot of (edge, side) in the node-sorted list of pplie_graph_assemble_lap (the inverse of its `blk`), HB [2 E, 36 | pack: 21] and
+// gg [2 E, 6] as that entry's first launch leaves them; pplie_graph_lap_diag then finishes the assembly
+extern "C" int pplie_pgo_linearize_lap_f32(const void* nodes, const void* idx, const void* Z, void* R, void* J, const void* inc, void* HB,
+                                           void* gg, int64_t E, int pack, int kind, double p0, double p1, void* stream) {
+  if (!inc) return pplie::PPLIE_EBADARG;
+  return pplie::pgo_linearize<float>(nodes, idx, Z, R, J, E, stream, kind, p0, p1, inc, HB, gg, pack);
+}
+extern "C" int pplie_pgo_linearize_lap_f64(const void* nodes, const void* idx, const void* Z, void* R, void* J, const void* inc, void* HB,
+                                           void* gg, int64_t E, int pack, int kind, double p0, double p1, void* stream) {
+  if (!inc) return pplie::PPLIE_EBADARG;
+  return pplie::pgo_linearize<double>(nodes, idx, Z, R, J, E, stream, kind, p0, p1, inc, HB, gg, pack);
+}
 extern "C" int pplie_pgo_linearize_f32(const void* nodes, const void* idx, const void* Z, void* R, void* J, int64_t E, void* stream) {
   return pplie::pgo_linearize<float>(nodes, idx, Z, R, J, E, stream);
 }

@@ -23,6 +23,7 @@ Programs:
 from __future__ import annotations
 
 import ctypes
+import os
 
 import torch
 
@@ -826,7 +827,11 @@ class LprLinearization:
         return dev.step()
 
 
+# the recognised pose-graph program's linearisation also assembles the edges' shares of the normal equations (pplie_pgo_linearize_lap);
+# PPLIE_FUSE_PGO_ASSEMBLY=0: the linearisation and pplie_graph_assemble_lap's two launches, as before round 6
+FUSE_PGO_ASSEMBLY = os.environ.get("PPLIE_FUSE_PGO_ASSEMBLY", "1") != "0"
 _PGO_SIG = [ctypes.c_void_p] * 5 + [ctypes.c_int64, ctypes.c_void_p]
+_PGO_LAP_SIG = [ctypes.c_void_p] * 8 + [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_void_p]
 _PGO_ROBUST_SIG = [ctypes.c_void_p] * 5 + [ctypes.c_int64, ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_void_p]
 _PGO_PARTIALS = 1024      # PPLIE_PGO_PARTIALS
 
@@ -908,13 +913,31 @@ class PgoProgram:
         return P is self.P and all(_unchanged(old, new, ver) and old.data_ptr() == ptr
                                    for (old, ptr, ver), new in zip(self.sources, (idx0, idx1, Z)))
 
-    def linearize(self, robust=None):
+    def outputs(self):
+        """uninitialised residuals [E, 6] and blocks [E, 2, 6, 6] for :meth:`linearize` / :meth:`linearize_lap` to fill"""
+        nodes = torch.Tensor.as_subclass(self.P, torch.Tensor).detach()
+        return (torch.empty((self.E, 6), dtype=nodes.dtype, device=nodes.device),
+                torch.empty((self.E, 2, 6, 6), dtype=nodes.dtype, device=nodes.device))
+
+    def linearize_lap(self, R, J, inc, HB, gg, pack, robust=None):
+        """:meth:`linearize` into ``R`` / ``J`` that ALSO leaves the edges' shares of the normal equations (``pplie_pgo_linearize_lap``):
+        -J_1^T J_1 at both incidence slots ``inc[e]`` of ``HB`` (full or packed blocks) and -+J_1^T r in ``gg`` -- what the first
+        launch of ``pplie_graph_assemble_lap`` computed from the J blocks it read back"""
+        nodes = torch.Tensor.as_subclass(self.P, torch.Tensor).detach()
+        assert nodes.is_contiguous() and inc.shape == (self.E, 2) and inc.dtype == torch.int32 and inc.is_contiguous()
+        kind, p0, p1 = (0, 0.0, 0.0) if robust is None else robust
+        with _C._on_device(nodes.device):
+            fn = _C.library().symbol("pplie_pgo_linearize_lap" + _blocks._suffix(nodes), _PGO_LAP_SIG)
+            code = fn(nodes.data_ptr(), self.idx.data_ptr(), self.Z.data_ptr(), R.data_ptr(), J.data_ptr(), inc.data_ptr(), HB.data_ptr(),
+                      gg.data_ptr(), self.E, 1 if pack else 0, kind, p0, p1, _C.stream_ptr(nodes.device))
+        _C.check(code, "pplie_pgo_linearize_lap")
+
+    def linearize(self, robust=None, out=None):
         """residuals [E, 6] and blocks [E, 2, 6, 6]; with ``robust`` = (kind, p0, p1) of a built-in kernel (optim/kernel.py
         robust_code) they come out already corrected -- sqrt(rho'(|r_e|^2)) applied to r_e and J_e in the kernel's registers"""
         nodes = torch.Tensor.as_subclass(self.P, torch.Tensor).detach()     # (plain: no __torch_function__ round trips below)
         assert nodes.is_contiguous()
-        R = torch.empty((self.E, 6), dtype=nodes.dtype, device=nodes.device)
-        J = torch.empty((self.E, 2, 6, 6), dtype=nodes.dtype, device=nodes.device)
+        R, J = self.outputs() if out is None else out
         with _C._on_device(nodes.device):
             if robust is None:
                 fn = _C.library().symbol("pplie_pgo_linearize" + _blocks._suffix(nodes), _PGO_SIG)
@@ -1125,12 +1148,27 @@ def _pgo_linearization(opt, prog, weight, P, trivial):
     # a built-in robust kernel rides inside the linearisation kernel (csrc/robust.h): no corrector pass, no autograd graph
     c = opt.corrector[0]
     robust = fused_code(c) if (not trivial and opt.group is None) else None
-    r, J = prog.linearize(robust)
+    # One launch for the linearisation AND the edges' shares of the normal equations where nothing stands between the two: no weight,
+    # no corrector pass left to run (Trivial, or a built-in kernel that rides in the linearisation), one GPU.  The outputs are then
+    # allocated first, the linearisation object built around them (it only holds them) and asked for its block plan.
+    fuse = (FUSE_PGO_ASSEMBLY and weight is None and opt.group is None and (robust is not None or isinstance(c, Trivial))
+            and _C._test_backend is None and P.is_cuda and prog.E * 2 < (1 << 31))
+    if fuse:
+        r, J = prog.outputs()
+    else:
+        r, J = prog.linearize(robust)
     lin = _pg.build_graph_linearization(opt, weight, r, J, prog.idx, P, 7, 6, corrector=Trivial() if robust is not None else None)
     lin.kind = "fused:pgo"
     lin.robust = robust
     # r = Log(Z^-1 n_i^-1 n_j): d r / d n_i = -d r / d n_j (csrc/pgo_fused.hip), and a corrector scales both blocks of an edge alike
     lin.antisym = True
+    if fuse:
+        plan = lin.plan_blocks() if (lin.R is r and lin.J is J and lin.W is None and lin.group is None and lin._hip()) else None
+        if plan is not None and lin.HB is not None:
+            prog.linearize_lap(r, J, lin.incidence_slots(), lin.HB, plan['gg'], lin.HB_pack, robust)
+            plan['blocks_done'] = True
+        else:
+            prog.linearize(robust, out=(r, J))
 
     def verify(ref, dmin, dmax, rtol=1e-3):
         """residuals and blocks against the autograd-derived pose-graph linearisation (whose edge ends are in

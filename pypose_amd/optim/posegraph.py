@@ -39,6 +39,7 @@ _SPMV_SIG = [ctypes.c_void_p] * 5 + [ctypes.c_int64, ctypes.c_int, ctypes.c_int,
 _ASM_SIG = [ctypes.c_void_p] * 7 + [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
 _ASMC_SIG = [ctypes.c_void_p] * 8 + [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
 _ASML_SIG = [ctypes.c_void_p] * 9 + [ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+_LAPD_SIG = [ctypes.c_void_p] * 5 + [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
 _PREP_SIG = [ctypes.c_void_p] * 10 + [ctypes.c_double] * 3 + [ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]
 _BEGIN_SIG = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
 _PREP_DEV_SIG = [ctypes.c_void_p] * 11 + [ctypes.c_double] * 2 + [ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]
@@ -881,6 +882,55 @@ class GraphLinearization:
         return (_C._test_backend is None and self.J.is_cuda and (self.dr, self.m, self.K) in _HIP_SHAPES
                 and self.J.dtype in (torch.float32, torch.float64))
 
+    def incidence_slots(self):
+        """inc [E, K] int32: the position of (edge, side) in the node-sorted incidence list of :meth:`csr` (the inverse permutation
+        of its ``blk``); cached with it"""
+        ptr, blk, _ = self.csr()
+        cache = self.opt.__dict__.setdefault('_graph_inc', {})
+        hit = cache.get('inc')
+        if hit is None or hit[0] is not blk:
+            inc = torch.empty_like(blk)
+            inc[blk.long()] = torch.arange(blk.numel(), dtype=blk.dtype, device=blk.device)
+            hit = cache['inc'] = (blk, inc.reshape(self.E, self.K).contiguous())
+        return hit[1]
+
+    def plan_blocks(self):
+        """The storage decisions of the single-GPU block assembly, taken before any launch (idempotent): the layout of the off-diagonal
+        blocks (``HB_pack`` / ``HB_sym``), the buffer ``HB`` they go to and -- returned -- the plan of the two-launch "Laplacian"
+        assembly when this linearisation takes it ({'gg': the gradient shares' scratch}), else None."""
+        plan = self.__dict__.get('_block_plan', False)
+        if plan is not False:
+            return plan
+        N, m, dt, dev = self.N, self.m, self.J.dtype, self.J.device
+        # off-diagonal blocks in incidence order feed the streaming node-parallel SpMV of the PCG; graphs too
+        # large for the persistent solve keep ONE block per edge (H_ji = H_ij^T for symmetric weights):
+        # half the bytes every SpMV streams
+        large = self.K == 2 and FusedPCG.two_launch and not (FusedPCG.persist and N <= PERSIST_NODES)
+        # J_0 = -J_1 and W symmetric: every off-diagonal block is -J_1^T W J_1, symmetric, the same for both incidences
+        self.HB_pack = (large and self.antisym and FusedPCG.pack_blocks and self.dr == self.m
+                        and self._weights_symmetric())
+        self.HB_sym = large and not self.HB_pack and FusedPCG.sym_blocks and self._weights_symmetric()
+        mode = 'pack' if self.HB_pack else self.HB_sym
+        self.HB = None
+        if self.K == 2:
+            shape = (self.E * 2, m * (m + 1) // 2) if self.HB_pack else (self.E * (1 if self.HB_sym else 2), m, m)
+            pad = 1 if self.HB_pack else 0      # (the packed SpMV reads up to m - 1 elements past a triangle's row)
+            # large graphs: assemble straight into the PCG workspace's block buffer (the captured iterations point
+            # at it) instead of into a fresh tensor that is then copied there -- 115 MB per LM step at 4e5 edges
+            for w in (self.opt.__dict__.get('_pcg_workspaces') or {}).values():
+                own = w.__dict__.get('_own_HB')
+                if own is not None and own.shape == shape and own.dtype == dt and own.device == dev and w.sym == mode:
+                    self.HB = own
+                    break
+            if self.HB is None:
+                self.HB = torch.empty((shape[0] + pad,) + tuple(shape[1:]), dtype=dt, device=dev)[:shape[0]]
+        plan = None
+        if (self.K == 2 and self.antisym and self.dr == self.m and not self.HB_sym and FusedPCG.lap_assembly
+                and self.m in (3, 6, 7) and self._weights_symmetric()):
+            plan = {'gg': torch.empty((self.E * 2, m), dtype=dt, device=dev)}
+        self._block_plan = plan
+        return plan
+
     def _assemble(self):
         N, m = self.N, self.m
         dt, dev = self.J.dtype, self.J.device
@@ -894,36 +944,19 @@ class GraphLinearization:
                     B = torch.empty((N, m, m), dtype=dt, device=dev)
                     g = torch.empty((N, m), dtype=dt, device=dev)
                     ptr, blk, _ = self.csr()
-                    # off-diagonal blocks in incidence order feed the streaming node-parallel SpMV of the PCG; graphs too
-                    # large for the persistent solve keep ONE block per edge (H_ji = H_ij^T for symmetric weights):
-                    # half the bytes every SpMV streams
-                    large = self.K == 2 and FusedPCG.two_launch and not (FusedPCG.persist and N <= PERSIST_NODES)
-                    # J_0 = -J_1 and W symmetric: every off-diagonal block is -J_1^T W J_1, symmetric, the same for both incidences
-                    self.HB_pack = (large and self.antisym and FusedPCG.pack_blocks and self.dr == self.m
-                                    and self._weights_symmetric())
-                    self.HB_sym = large and not self.HB_pack and FusedPCG.sym_blocks and self._weights_symmetric()
-                    mode = 'pack' if self.HB_pack else self.HB_sym
-                    self.HB = None
-                    if self.K == 2:
-                        shape = (self.E * 2, m * (m + 1) // 2) if self.HB_pack else (self.E * (1 if self.HB_sym else 2), m, m)
-                        pad = 1 if self.HB_pack else 0      # (the packed SpMV reads up to m - 1 elements past a triangle's row)
-                        # large graphs: assemble straight into the PCG workspace's block buffer (the captured iterations point
-                        # at it) instead of into a fresh tensor that is then copied there -- 115 MB per LM step at 4e5 edges
-                        for w in (self.opt.__dict__.get('_pcg_workspaces') or {}).values():
-                            own = w.__dict__.get('_own_HB')
-                            if own is not None and own.shape == shape and own.dtype == dt and own.device == dev and w.sym == mode:
-                                self.HB = own
-                                break
-                        if self.HB is None:
-                            self.HB = torch.empty((shape[0] + pad,) + tuple(shape[1:]), dtype=dt, device=dev)[:shape[0]]
-                    if (self.K == 2 and self.antisym and self.dr == self.m and not self.HB_sym and FusedPCG.lap_assembly
-                            and self.m in (3, 6, 7) and self._weights_symmetric()):
+                    lap = self.plan_blocks()
+                    if lap is not None:
                         # J_0 = -J_1: incidence-parallel blocks, then per-node sums (csrc/graph.hip, pplie_graph_assemble_lap)
-                        gg = torch.empty((self.E * 2, m), dtype=dt, device=dev)
-                        code = lib.symbol("pplie_graph_assemble_lap" + sfx, _ASML_SIG)(
-                            ptr.data_ptr(), blk.data_ptr(), self.J.data_ptr(), wptr, self.R.data_ptr(), B.data_ptr(), g.data_ptr(),
-                            self.HB.data_ptr(), gg.data_ptr(), N, self.E * 2, self.m, 1 if self.HB_pack else 0, st)
-                        _C.check(code, "pplie_graph_assemble_lap")
+                        if lap.get('blocks_done'):       # (the fused linearisation left HB and gg already: optim/fused.py)
+                            code = lib.symbol("pplie_graph_lap_diag" + sfx, _LAPD_SIG)(
+                                ptr.data_ptr(), self.HB.data_ptr(), lap['gg'].data_ptr(), B.data_ptr(), g.data_ptr(), N, self.m,
+                                1 if self.HB_pack else 0, st)
+                            _C.check(code, "pplie_graph_lap_diag")
+                        else:
+                            code = lib.symbol("pplie_graph_assemble_lap" + sfx, _ASML_SIG)(
+                                ptr.data_ptr(), blk.data_ptr(), self.J.data_ptr(), wptr, self.R.data_ptr(), B.data_ptr(), g.data_ptr(),
+                                self.HB.data_ptr(), lap['gg'].data_ptr(), N, self.E * 2, self.m, 1 if self.HB_pack else 0, st)
+                            _C.check(code, "pplie_graph_assemble_lap")
                     else:
                         code = lib.symbol("pplie_graph_assemble_csr" + ("_pack" if self.HB_pack else "_sym" if self.HB_sym else "") + sfx, _ASMC_SIG)(
                             ptr.data_ptr(), blk.data_ptr(), self.J.data_ptr(), wptr, self.R.data_ptr(), B.data_ptr(),

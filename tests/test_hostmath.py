@@ -47,3 +47,26 @@ def test_fp32_vs_reference_fp64(golden, name):
         assert o.dtype == np.float32 and np.isfinite(o).all()
         e, ok = row_rel_err(o[m], r[m])
         assert e.max() < (2e-5 if name in AUTOGRAD_OPS else 1e-5), (name, e.max(), int(np.argmax(e)))
+
+
+@pytest.mark.parametrize("name", ["sim3_exp_fwd", "sim3_log_fwd"])
+def test_sim3_small_sigma_and_theta_fp32(name):
+    """The reference's closed forms for rxso3_Ws's A, B (operation.py:117-122) cancel in fp32 when sigma AND theta are small
+    (a sigma against (1 - b) theta: A wrong by ~2e-7 / (theta^2 + sigma^2), i.e. 1e-5 of the translation at sigma = theta = 5e-3;
+    found by the max-over-rows gate of tests/test_lie_parity_gpu.py, 3 rows in 300 k).  lie_math.h's ws_coef uses the
+    coefficients' series there in fp32: every row within 1e-5 of the reference's formulas evaluated in fp64."""
+    rng = np.random.default_rng(11)
+    n = 20_000
+    d = rng.standard_normal((n, 3))
+    d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    theta = 10.0 ** rng.uniform(-5, -0.8, (n, 1))
+    sigma = 10.0 ** rng.uniform(-5, -0.8, (n, 1)) * rng.choice([-1.0, 1.0], (n, 1))
+    x = np.concatenate([rng.standard_normal((n, 3)), d * theta, sigma], -1).astype(np.float32)
+    if name == "sim3_exp_fwd":
+        ins = [x]
+    else:
+        ins = [lie_np.sim3_exp_fwd(x.astype(np.float64))[0].astype(np.float32)]
+    ref = lie_np.OPS[name](*[a.astype(np.float64) for a in ins])[0]
+    out = hostmath_op(name, ins)[0]
+    e, _ = row_rel_err(out, ref)
+    assert e.max() < 1e-5, (name, e.max(), ins[0][int(np.argmax(e))])

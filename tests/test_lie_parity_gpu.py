@@ -97,6 +97,23 @@ def _random_inputs(name, n, dtype, rng):
     return table[kind]()
 
 
+def rotation_angles(name, ins):
+    """rotation angle theta in [0, 2 pi] of every operand of op ``name`` that carries a rotation (group elements: from the
+    quaternion, 2 atan2(|v|, w); algebra elements: |phi|), in fp64 from the fp32 inputs"""
+    g, kind = name.split("_", 1)
+    qoff = {"so3": 0, "se3": 3, "sim3": 3, "rxso3": 0}[g]          # quaternion / phi offset in the group / algebra row
+    def of_group(X):
+        q = X[:, qoff:qoff + 4].astype(np.float64)
+        return 2.0 * np.arctan2(np.linalg.norm(q[:, :3], axis=-1), q[:, 3]) % (2.0 * np.pi)
+    def of_alg(x):
+        return np.linalg.norm(x[:, qoff:qoff + 3].astype(np.float64), axis=-1)
+    if kind in ("exp_fwd", "exp_bwd", "log_bwd", "jr_fwd", "jr_bwd"):
+        return [of_alg(ins[0])]
+    if kind == "mul_fwd":
+        return [of_group(ins[0]), of_group(ins[1])]
+    return [of_group(ins[0])]
+
+
 def mixed_row_err(out, ref, ins):
     """|out - ref| per row over max(|ref|, 0.1 |g| |p|): the cotangent-times-operand scale is the natural magnitude of a
     Jinvp / Jr gradient row; a row whose exact value happens to cancel to 1e-3 of that scale (rn / scale reaches 4e-4 in 100k
@@ -131,16 +148,27 @@ def test_random_100k_fp32_vs_oracle_fp64(name):
                 assert e.max() < 1e-5, (name, k, e.max(), int(np.argmax(e)))
                 assert np.median(e) < 2e-7, (name, np.median(e))
         return
-    rng = np.random.default_rng(zlib.crc32(name.encode()))       # (hash(str) is salted per process: the inputs must not be)
-    ins = _random_inputs(name, n, np.float32, rng)
-    refs = lie_np.OPS[name](*[a.astype(np.float64) for a in ins])
-    outs = run_hip(name, ins)
-    # rows at the rotation-log singularity (|theta| ~ pi, 2pi) are ill-conditioned w.r.t. the
-    # fp32 rounding of the INPUT; they are excluded by the 99.99% quantile, the bulk must be tight
-    for o, r in zip(outs, refs):
-        e, ok = row_rel_err(o, r)
-        assert np.quantile(e, 0.9999) < 1e-5, (name, np.quantile(e, 0.9999))
-        assert np.median(e) < 2e-7, (name, np.median(e))
+    # Every other op: EVERY row (max, not a quantile) of three seeds.  No rotation-angle mask is needed: the inputs' angles reach
+    # |theta| ~ 4 and tools/probe_parity_tail.py (profiles/r06/parity_tail.jsonl) found no row near pi / 2 pi outside the band.
+    # What it did find: (1) sim3 Exp / Log with sigma AND theta small -- the reference's closed forms cancel in fp32; ws_coef now
+    # sums the coefficients' series there (tests/test_hostmath.py::test_sim3_small_sigma_and_theta_fp32); (2) three rows of
+    # rxso3_adjt_bwd whose exact gradient cancels to < 1 % of |g| |a|: a bilinear backward's error is measured against
+    # max(|ref|, 0.01 |g| |operand|), the backward-stable scale, as for the autograd ops above (there with 0.1).
+    bilinear = name.endswith("_bwd") and len(lie_np.op_signature(name)[0]) == 3
+    for k in range(3):
+        rng = np.random.default_rng(zlib.crc32(name.encode()) + k)   # (hash(str) is salted per process: the inputs must not be)
+        ins = _random_inputs(name, n, np.float32, rng)
+        refs = lie_np.OPS[name](*[a.astype(np.float64) for a in ins])
+        outs = run_hip(name, ins)
+        for o, r in zip(outs, refs):
+            e, ok = row_rel_err(o, r)
+            assert ok.all()
+            if bilinear:
+                scale = np.linalg.norm(ins[1].astype(np.float64), axis=-1) * np.linalg.norm(ins[2].astype(np.float64), axis=-1)
+                rn = np.linalg.norm(r, axis=-1)
+                e = e * rn / np.maximum(rn, 0.01 * scale)
+            assert e.max() < 1e-5, (name, k, e.max(), int(np.argmax(e)), [a[int(np.argmax(e))] for a in ins])
+            assert np.median(e) < 2e-7, (name, np.median(e))
 
 
 @pytest.mark.parametrize("name", ["se3_exp_fwd", "se3_log_fwd", "se3_mul_fwd", "sim3_act_bwd", "so3_log_bwd"])
@@ -186,37 +214,50 @@ def test_bad_arguments_return_codes():
     assert fn(null, null, null, null, null, ctypes.c_int64(0), null) == 0
 
 
-def test_properties_at_full_size():
-    """BASELINE config[1] size (10M rows, fp32): size-independent invariants, checked on device."""
+@pytest.mark.parametrize("group", ["SE3", "SO3", "Sim3", "RxSO3"])
+def test_properties_at_full_size(group):
+    """BASELINE config[1] size (10M rows, fp32): size-independent invariants of every group, checked on device."""
     import pypose_amd as pp
     dev = _dev()
     n = 10_000_000
     torch.manual_seed(0)
-    x = pp.randn_se3(n, device=dev)
+    alg = group.lower()
+    qoff = {"SE3": 3, "SO3": 0, "Sim3": 3, "RxSO3": 0}[group]
+    x = getattr(pp, "randn_" + alg)(n, device=dev)
     X = x.Exp()
-    # |q| = 1
-    qn = X.tensor()[:, 3:].norm(dim=-1)
+    assert X.ltype == getattr(pp, group + "_type")
+    # |q| = 1 (and the scale of Sim3 / RxSO3 = exp(sigma) > 0)
+    qn = X.tensor()[:, qoff:qoff + 4].norm(dim=-1)
     assert (qn - 1).abs().max().item() < 1e-6
+    if group in ("Sim3", "RxSO3"):
+        sc, sg = X.tensor()[:, -1], x.tensor()[:, -1]
+        assert ((sc - sg.exp()).abs() / sg.exp()).max().item() < 1e-6
     # Log(Exp(x)) == x where |phi| < pi - 0.1 (the principal branch)
-    th = x.tensor()[:, 3:].norm(dim=-1)
+    th = x.tensor()[:, qoff:qoff + 3].norm(dim=-1)
     y = X.Log()
     sel = th < np.pi - 0.1
-    err = ((y.tensor() - x.tensor()).norm(dim=-1) / x.tensor().norm(dim=-1))[sel]
-    assert err.max().item() < 2e-5 and err.median().item() < 3e-7
+    # (relative to max(|x|, 1e-2): a group element stores exp(sigma) and cos(theta / 2) next to 1, so an algebra row of norm 4e-4 --
+    #  there is one among 10 M RxSO3 rows -- comes back with the absolute rounding of 1, 6e-8, whatever the kernel does)
+    err = torch.where(sel, (y.tensor() - x.tensor()).norm(dim=-1) / x.tensor().norm(dim=-1).clamp_min(1e-2), torch.zeros_like(th))
+    worst = int(err.argmax())
+    assert err.max().item() < 2e-5 and err[sel].median().item() < 3e-7, (err.max().item(), x.tensor()[worst].tolist(), y.tensor()[worst].tolist())
+    del y, err
     # X * X^-1 == identity ; (X^-1)^-1 == X
     I = (X * X.Inv()).tensor()
-    ident = torch.tensor([0, 0, 0, 0, 0, 0, 1.0], device=dev)
+    ident = pp.identity_like(X[:1]).tensor().reshape(-1).to(dev)
     assert (I - ident).abs().max().item() < 5e-5
-    assert (X.Inv().Inv().tensor() - X.tensor()).abs().max().item() < 5e-5
-    # Act is linear in p and Mul is compatible with Act: (X*Y).p == X.(Y.p)
-    Y = pp.SE3(X.tensor().flip(0))
+    assert ((X.Inv().Inv().tensor() - X.tensor()).abs().max() / (1 + X.tensor().abs().max())).item() < 5e-5
+    del I
+    # Mul is compatible with Act: (X*Y).p == X.(Y.p)
+    Y = getattr(pp, group)(X.tensor().flip(0))
     p = torch.randn(n, 3, device=dev)
     lhs, rhs = (X * Y).Act(p), X.Act(Y.Act(p))
     assert ((lhs - rhs).norm(dim=-1) / (1 + rhs.norm(dim=-1))).max().item() < 1e-5
+    del Y, p, lhs, rhs
     # Adj identity: Exp(Adj_X a) * X == X * Exp(a)
-    a = pp.randn_se3(n, sigma=0.2, device=dev)
+    a = getattr(pp, "randn_" + alg)(n, sigma=0.2, device=dev)
     d = ((X.Adj(a).Exp() * X).Inv() * (X * a.Exp())).Log().tensor().norm(dim=-1)
-    assert d.max().item() < 5e-4 and d.median().item() < 5e-6
+    assert d.max().item() < 5e-4 and d.median().item() < 5e-6, (d.max().item(), d.median().item())
 
 
 def test_c1_fwd_bwd_through_lietensor_api():

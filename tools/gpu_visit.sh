@@ -17,7 +17,7 @@ for part in "$@"; do
     prof)    (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof" -o headline -- python "$R/bench.py" --steps 50 --warmup 10 --no-cpu-baseline --no-secondary > "$O/rocprof.log" 2>&1)
              find "$O/prof" -name "*kernel_trace.csv" -delete; find "$O/prof" -name "*.db" -delete
              f=$(find "$O/prof" -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -6 "$f" | cut -c1-240 ;;
-    py:*)    timeout 900 python ${part#py:} 2>&1 | tail -40 | cut -c1-600 | tee -a "$O/py.log" ;;
+    py:*)    timeout 900 python ${part#py:} 2>&1 | tail -150 | cut -c1-900 | tee -a "$O/py.log" ;;
     sh:*)    timeout 1200 bash -c "${part#sh:}" 2>&1 | tail -60 | cut -c1-600 | tee -a "$O/sh.log" ;;
     *) echo "unknown part $part" ;;
   esac
