@@ -17,6 +17,8 @@ from pathlib import Path
 import torch
 
 _LIB_PATH = Path(__file__).resolve().parent / "lib" / "libpplie.so"
+if os.environ.get("PPLIE_LIBRARY_FILE"):       # measurement tools only: an alternative build of the same ABI, next to libpplie.so
+    _LIB_PATH = _LIB_PATH.with_name(os.environ["PPLIE_LIBRARY_FILE"])
 
 _ERRORS = {-1: "bad argument (negative row count or null pointer)", -2: "kernel launch failed (hipGetLastError)",
            -3: "the problem does not fit the device-resident variant (nothing launched)"}

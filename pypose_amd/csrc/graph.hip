@@ -985,6 +985,119 @@ int pcg_prepare(const void* B, const void* g, void* D, void* Binv, void* shift, 
 }
 
 // ---------------------------------------------------------------------------------------------
+// pplie_graph_lap_diag + pplie_pcg_prepare in ONE launch (round 6): the per-node sums of the "Laplacian" assembly feed the PCG
+// set-up through LDS.  Phase 1 is lap_diag_kernel's layout -- M lanes per node, lane i sums row i of the node's incidence blocks and
+// its component of the gradient shares -- and leaves the raw block + gradient in LDS (and in Bdiag / grad, which the LM strategies and
+// retries read).  Phase 2 is pcg_prepare_kernel's: one lane per node takes its block from LDS (stride 43 words: conflict-free) and
+// clamps, damps, inverts and writes D, Binv, shift, x, r, z, p and the solve's first sums.  One launch less in front of every solve
+// (5 -> 7 us at 10 k nodes where a launch costs that much; at 1e5 nodes 14 MB less written and read back).
+// ---------------------------------------------------------------------------------------------
+template <class T, int M, bool PACK>
+__global__ void __launch_bounds__(256)
+lap_diag_prepare_kernel(const int* __restrict__ ptr, const T* __restrict__ HB, const T* __restrict__ gg, T* __restrict__ Bdiag,
+                        T* __restrict__ grad, T* __restrict__ D, T* __restrict__ Binv, T* __restrict__ shift, T* __restrict__ x,
+                        T* __restrict__ r, T* __restrict__ z, T* __restrict__ p, T* scal, T s_host, T dmin, T dmax, int64_t N,
+                        const double* __restrict__ s_dev, T* cs, T* __restrict__ Dp, T* __restrict__ Bp) {
+  constexpr int NPW = 64 / M, NPB = NPW * 4, NP = M * (M + 1) / 2, LD = (M * M + M) | 1;
+  __shared__ T stage[NPB * LD];
+  __shared__ T s_sh;
+  if (s_dev && threadIdx.x == 0) s_sh = (T)__hip_atomic_load(s_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int sub = lane / M, i = lane % M;
+  const int local = w * NPW + sub;
+  const int64_t n = (int64_t)blockIdx.x * NPB + local;
+  if (sub < NPW && n < N) {
+    const int beg = ptr[n], end = ptr[n + 1];
+    T row[M], gi = T(0);
+#pragma unroll
+    for (int b = 0; b < M; ++b) row[b] = T(0);
+    T* st = stage + local * LD;
+    if constexpr (PACK) {
+      const int tii = i * M - (i * (i - 1)) / 2;
+      for (int c = beg; c < end; ++c) {
+        const T* h = HB + (int64_t)c * NP + tii;
+        T l[M];
+#pragma unroll
+        for (int k = 0; k < M; ++k) l[k] = h[k];
+#pragma unroll
+        for (int k = 0; k < M; ++k) row[k] -= (k < M - i) ? l[k] : T(0);
+        gi += gg[(int64_t)c * M + i];
+      }
+#pragma unroll
+      for (int k = 0; k < M; ++k)
+        if (k < M - i) {
+          Bdiag[(n * M + i) * M + i + k] = row[k];
+          Bdiag[(n * M + i + k) * M + i] = row[k];
+          st[i * M + i + k] = row[k];
+          st[(i + k) * M + i] = row[k];
+        }
+    } else {
+      for (int c = beg; c < end; ++c) {
+        const T* h = HB + ((int64_t)c * M + i) * M;
+#pragma unroll
+        for (int b = 0; b < M; ++b) row[b] -= h[b];
+        gi += gg[(int64_t)c * M + i];
+      }
+#pragma unroll
+      for (int b = 0; b < M; ++b) { Bdiag[(n * M + i) * M + b] = row[b]; st[i * M + b] = row[b]; }
+    }
+    grad[n * M + i] = gi;
+    st[M * M + i] = gi;
+  }
+  __syncthreads();
+  const T s = s_dev ? s_sh : s_host;
+  T a_rho = T(0), a_bn = T(0);
+  T a_cs[2 * M];
+#pragma unroll
+  for (int q = 0; q < 2 * M; ++q) a_cs[q] = T(0);
+  const int64_t n2 = (int64_t)blockIdx.x * NPB + threadIdx.x;
+  if ((int)threadIdx.x < NPB && n2 < N) {
+    T A[M * M], gv[M];
+    const T* st = stage + threadIdx.x * LD;
+#pragma unroll
+    for (int q = 0; q < M * M; ++q) A[q] = st[q];
+#pragma unroll
+    for (int q = 0; q < M; ++q) gv[q] = st[M * M + q];
+    prepare_node<T, M>(A, gv, n2, s, dmin, dmax, D, Binv, shift, x, r, z, p, Dp, Bp, a_rho, a_bn, a_cs);
+  }
+  T s1 = block_sum(a_rho);
+  T s2 = block_sum(a_bn);
+  if (threadIdx.x == 0) {
+    slot_add(squant(scal, 0, Q_RHO), s1);
+    slot_add(squant(scal, 0, Q_BN2), s2);
+  }
+  if (cs) {
+#pragma unroll
+    for (int q = 0; q < 2 * M; ++q) {
+      const T t = block_sum(a_cs[q]);
+      if (threadIdx.x == 0) atomicAdd(cs_line(cs, 0) + (q < M ? CS_E + q : CS_SR + (q - M)), t);
+    }
+  }
+}
+template <class T>
+int pcg_prepare_lap(const void* ptr, const void* HB, const void* gg, int pack, void* Bdiag, void* grad, void* D, void* Binv, void* Dp,
+                    void* Bp, void* shift, void* x, void* r, void* z, void* p, void* scal, void* cs, double s, const void* s_dev,
+                    double dmin, double dmax, int64_t N, int m, void* stream) {
+  if (N <= 0) return N == 0 ? PPLIE_OK : PPLIE_EBADARG;
+  if (!ptr || !HB || !gg || !Bdiag || !grad || !D || !Binv || !shift || !x || !r || !z || !p || !scal || (!Dp != !Bp)) return PPLIE_EBADARG;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+#define LAUNCH(MM, PK)                                                                                                         \
+  {                                                                                                                            \
+    constexpr int NPB = (64 / MM) * 4;                                                                                         \
+    const int64_t nb = (N + NPB - 1) / NPB;                                                                                    \
+    if (nb >= ((int64_t)1 << 31)) return PPLIE_EBADARG;                                                                        \
+    hipLaunchKernelGGL((lap_diag_prepare_kernel<T, MM, PK>), dim3((unsigned)nb), dim3(256), 0, st, (const int*)ptr, (const T*)HB, \
+                       (const T*)gg, (T*)Bdiag, (T*)grad, (T*)D, (T*)Binv, (T*)shift, (T*)x, (T*)r, (T*)z, (T*)p, (T*)scal, (T)s,  \
+                       (T)dmin, (T)dmax, N, (const double*)s_dev, (T*)cs, (T*)Dp, (T*)Bp);                                      \
+  }
+#define BYM(MM) { if (pack) LAUNCH(MM, true) else LAUNCH(MM, false) }
+  if (m == 6) BYM(6) else if (m == 7) BYM(7) else if (m == 3) BYM(3) else return PPLIE_EBADARG;
+#undef BYM
+#undef LAUNCH
+  return hipGetLastError() == hipSuccess ? PPLIE_OK : PPLIE_ELAUNCH;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Gain-ratio terms of the damping strategies (strategy.py:144, :261) without forming J D:
 //   JD_e = sum_k J[e,k] d[idx[e,k], :M] ;  partial[w] = { sum JD.JD, sum JD.R } per workgroup w (caller-zeroed
 //   [PPLIE_GAIN_PARTIALS, 2]).  d is the step with row stride `ld` (the zero-padded group width).
@@ -1108,6 +1221,19 @@ extern "C" int pplie_pcg_prepare_dev_f64(const void* B, const void* g, void* D, 
                                          void* stream) {
   if (!s_dev) return pplie::PPLIE_EBADARG;
   return pplie::pcg_prepare<double>(B, g, D, Binv, shift, x, r, z, p, scal, 1.0, dmin, dmax, N, m, stream, s_dev);
+}
+// pplie_graph_lap_diag + pplie_pcg_prepare(_dev | _coarse | _coarse_dp) in one launch: cs / Dp, Bp / s_dev may be NULL as there
+extern "C" int pplie_pcg_prepare_lap_f32(const void* ptr, const void* HB, const void* gg, int pack, void* Bdiag, void* grad, void* D,
+                                         void* Binv, void* Dp, void* Bp, void* shift, void* x, void* r, void* z, void* p, void* scal,
+                                         void* cs, double s, const void* s_dev, double dmin, double dmax, int64_t N, int m, void* stream) {
+  return pplie::pcg_prepare_lap<float>(ptr, HB, gg, pack, Bdiag, grad, D, Binv, Dp, Bp, shift, x, r, z, p, scal, cs, s, s_dev, dmin, dmax, N, m,
+                                       stream);
+}
+extern "C" int pplie_pcg_prepare_lap_f64(const void* ptr, const void* HB, const void* gg, int pack, void* Bdiag, void* grad, void* D,
+                                         void* Binv, void* Dp, void* Bp, void* shift, void* x, void* r, void* z, void* p, void* scal,
+                                         void* cs, double s, const void* s_dev, double dmin, double dmax, int64_t N, int m, void* stream) {
+  return pplie::pcg_prepare_lap<double>(ptr, HB, gg, pack, Bdiag, grad, D, Binv, Dp, Bp, shift, x, r, z, p, scal, cs, s, s_dev, dmin, dmax, N, m,
+                                        stream);
 }
 extern "C" int pplie_graph_gain_terms_f32(const void* J, const void* idx, const void* d, int ld, const void* R, void* partial,
                                           int64_t E, int dr, int m, int k, void* stream) {
@@ -2042,6 +2168,7 @@ __device__ __forceinline__ void mg3_item(const Mg3Args<T>& A, const Mg3Item itx,
         if (gl < m) {
           for (int t = 0; t < nit; ++t) {
             unsigned wv[NW];
+            bool got = false;
             for (long spin = 0; spin < (1L << 22); ++spin) {
               bool ok = true;
 #pragma unroll
@@ -2050,12 +2177,14 @@ __device__ __forceinline__ void mg3_item(const Mg3Args<T>& A, const Mg3Item itx,
                 ok = ok && (unsigned)(v >> 32) == tag;
                 wv[u] = (unsigned)v;
               }
-              if (ok) break;
+              if (ok) { got = true; break; }
               __builtin_amdgcn_s_sleep(1);
             }
             T val;
             __builtin_memcpy(&val, wv, sizeof(T));
-            sum += val;
+            // a partial that never arrived must not pass for a sum: NaN in this row of J^T q makes |r|^2 NaN, which the step kernel
+            // and the host's check of the solve report as a failed solve (the timeout used to fall through silently)
+            sum += got ? val : T(NAN);
           }
         }
         acc = sum;

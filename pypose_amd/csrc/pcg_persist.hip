@@ -203,7 +203,6 @@ __device__ __forceinline__ void gather_rows(SH& sh, int par, const u64* part, un
                                             int rows_per_table = kPersistGridMax) {
   // rows first, first + stride, ... (count of them; default: one per workgroup of the grid) of table `par`
   constexpr int NW = sizeof(T) / 4, RW = SLOTS * NW, WVS = kPersistBlock / 64;
-  constexpr int RPL = sizeof(T) == 8 && NQ > WVS ? 2 : 4;     // rows per lane and round (fewer where a value is two words and a wave polls two quantities: registers)
   constexpr int PER = (NQ + WVS - 1) / WVS;                  // quantities per wave: w, w + 16, ... polled TOGETHER (one spin loop:
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;   //  a second quantity costs no second round of L2 latencies)
   if (count < 0) count = (int)gridDim.x;
@@ -213,49 +212,32 @@ __device__ __forceinline__ void gather_rows(SH& sh, int par, const u64* part, un
 #pragma unroll
     for (int u = 0; u < PER; ++u) sum[u] = T(0);
     bool all = true;
-    for (int base = 0; base < count; base += 64 * RPL) {
-      // unconditional loads, tags tested after the whole round has been issued (see gather_pairs): one round trip per round
-      const u64* src[PER][RPL];
-      bool in[PER][RPL];
+    for (int base = 0; base < count; base += 256) {
+      T val[PER][4];
+      bool done[PER][4];
 #pragma unroll
       for (int u = 0; u < PER; ++u)
 #pragma unroll
-        for (int q = 0; q < RPL; ++q) {
-          const int row = base + lane + 64 * q;
-          in[u][q] = row < count && w + u * WVS < NQ;
-          src[u][q] = tab + (size_t)(first + stride * (row < count ? row : 0)) * RW + (in[u][q] ? w + u * WVS : w) * NW;
-        }
-      u64 wv[PER][RPL][NW];
-      bool good = false;
+        for (int q = 0; q < 4; ++q) { done[u][q] = base + lane + 64 * q >= count || w + u * WVS >= NQ; val[u][q] = T(0); }
       for (long spin = 0; spin < (1L << 20); ++spin) {
+        bool pending = false;
 #pragma unroll
         for (int u = 0; u < PER; ++u)
 #pragma unroll
-          for (int q = 0; q < RPL; ++q)
-#pragma unroll
-            for (int k = 0; k < NW; ++k) wv[u][q][k] = xwg_load(src[u][q] + k);
-        unsigned miss = 0u;
-#pragma unroll
-        for (int u = 0; u < PER; ++u)
-#pragma unroll
-          for (int q = 0; q < RPL; ++q)
-#pragma unroll
-            for (int k = 0; k < NW; ++k) miss |= in[u][q] ? ((unsigned)(wv[u][q][k] >> 32) ^ tag) : 0u;
-        if (miss == 0u) { good = true; break; }
+          for (int q = 0; q < 4; ++q) {
+            if (!done[u][q]) {
+              bool ok = true;
+              const T t = get_value<T>(tab + (size_t)(first + stride * (base + lane + 64 * q)) * RW + (w + u * WVS) * NW, tag, ok);
+              if (ok) { val[u][q] = t; done[u][q] = true; } else pending = true;
+            }
+          }
+        if (!pending) break;
         __builtin_amdgcn_s_sleep(1);
       }
-      all = all && good;
 #pragma unroll
       for (int u = 0; u < PER; ++u)
 #pragma unroll
-        for (int q = 0; q < RPL; ++q) {
-          unsigned lo[NW];
-#pragma unroll
-          for (int k = 0; k < NW; ++k) lo[k] = (unsigned)wv[u][q][k];
-          T t;
-          __builtin_memcpy(&t, lo, sizeof(T));
-          if (in[u][q] && good) sum[u] += t;
-        }
+        for (int q = 0; q < 4; ++q) { all = all && done[u][q]; sum[u] += val[u][q]; }
     }
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
@@ -272,7 +254,7 @@ __device__ __forceinline__ void gather_rows(SH& sh, int par, const u64* part, un
 // the previous reading, in LDS, touched by thread 0 of a clocked workgroup only (`clocked` is false on every production launch).
 constexpr int kTickSlots = 14;
 __device__ __forceinline__ unsigned* tick_store() {
-  __shared__ unsigned tk_[kTickSlots + 2];
+  __shared__ unsigned tk_[kTickSlots + 3];
   return tk_;
 }
 __device__ __forceinline__ void tick(bool clocked, int slot) {
@@ -310,6 +292,11 @@ __device__ __forceinline__ void put_pairs(const float* vals_lds, u64* row, unsig
     xwg_store(row + threadIdx.x, pack_pair(a, b, t2));
   }
 }
+// (Round 6, measured on the 10 k-pose LM step with four builds of this file side by side, tools/gpu_ab_lib.sh: the loop below waits
+//  for each row's load before issuing the next -- three dependent round trips per poll round -- and is still the FASTEST form.
+//  Issuing a round's loads together and re-reading every row until all are complete made the step 16 us slower (0.281 against
+//  0.265 ms); issuing only the first round together, 3 - 5 us slower.  The polls of 160 workgroups x 9 waves share the memory side
+//  with the stores they are waiting for: fewer, staggered polls win over fewer round trips.)
 template <int NQ, class SH, int SLOTS>
 __device__ __forceinline__ void gather_pairs(SH& sh, int par, const u64* part, unsigned t2, int first, int stride, int count, int rows_per_table) {
   constexpr int NP = (NQ + 1) / 2, RW = SLOTS, LD = 3;
@@ -319,37 +306,25 @@ __device__ __forceinline__ void gather_pairs(SH& sh, int par, const u64* part, u
     float s0 = 0.f, s1 = 0.f;
     bool all = true;
     for (int base = 0; base < count; base += 64 * LD) {            // (LD rows per lane and round: 192 cover the usual grids of 160 - 192)
-      // Every load of a poll round is UNCONDITIONAL (a row beyond `count` reads row `first` and is ignored) and the tags are looked
-      // at only after all LD loads have been issued: with a branch per row (`if (!done[q]) load`) the compiler waited for each load
-      // before issuing the next -- three dependent round trips to the memory side per round instead of one (round 6: the final
-      // gather of the 17-quantity exchange was 2.5 us of the 7.9 us iteration).  A round re-reads rows it has seen complete: their
-      // words cannot change before this workgroup has published its next row.
-      const u64* src[LD];
-      bool in[LD];
+      float v0[LD], v1[LD];
+      bool done[LD];
 #pragma unroll
-      for (int q = 0; q < LD; ++q) {
-        const int row = base + lane + 64 * q;
-        in[q] = row < count;
-        src[q] = tab + (size_t)(first + stride * (in[q] ? row : 0)) * RW + w;
-      }
-      u64 wv[LD];
-      bool good = false;
+      for (int q = 0; q < LD; ++q) { done[q] = base + lane + 64 * q >= count; v0[q] = 0.f; v1[q] = 0.f; }
       for (long spin = 0; spin < (1L << 20); ++spin) {
+        bool pending = false;
 #pragma unroll
-        for (int q = 0; q < LD; ++q) wv[q] = xwg_load(src[q]);
-        unsigned miss = 0u;                                          // (bitwise, no short-circuit: a branch per row costs SALU mask work)
-#pragma unroll
-        for (int q = 0; q < LD; ++q) miss |= in[q] ? ((((unsigned)wv[q] ^ t2) | ((unsigned)(wv[q] >> 32) ^ t2)) & 3u) : 0u;
-        if (miss == 0u) { good = true; break; }
+        for (int q = 0; q < LD; ++q) {
+          if (!done[q]) {
+            float a, b;
+            if (unpack_pair(xwg_load(tab + (size_t)(first + stride * (base + lane + 64 * q)) * RW + w), t2, a, b)) { v0[q] = a; v1[q] = b; done[q] = true; }
+            else pending = true;
+          }
+        }
+        if (!pending) break;
         __builtin_amdgcn_s_sleep(1);
       }
-      all = all && good;
 #pragma unroll
-      for (int q = 0; q < LD; ++q) {
-        float a, b;
-        unpack_pair(wv[q], t2, a, b);
-        if (in[q] && good) { s0 += a; s1 += b; }
-      }
+      for (int q = 0; q < LD; ++q) { all = all && done[q]; s0 += v0[q]; s1 += v1[q]; }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) { s0 += __shfl_xor(s0, off, 64); s1 += __shfl_xor(s1, off, 64); }
@@ -732,7 +707,7 @@ constexpr int kGhostLayers = 3;
 //   rho = r.Binv r + sum_i (Z^T r)_i^2 / E_i ;   z = Binv r + Z (Z^T r / E) ;  the recurrence value of rho_{k+1} (for beta only,
 //   as before) uses Z^T r' = Z^T r - alpha Z^T q.  Any E > 0 gives an SPD preconditioner: the stop test |r| <= tol |b| is unchanged.
 
-template <class T, int M, bool CZ = false>
+template <class T, int M, bool CZ = false, bool PROF = false>
 __global__ void __launch_bounds__(kPersistBlock)
 pcg_ghost_kernel(const int* __restrict__ ptr, const int* __restrict__ slot, const T* __restrict__ HB, const T* __restrict__ D,
                  const T* __restrict__ Binv, T* __restrict__ x, const T* __restrict__ r, const T* __restrict__ z,
@@ -740,6 +715,17 @@ pcg_ghost_kernel(const int* __restrict__ ptr, const int* __restrict__ slot, cons
                  T* __restrict__ rr_hist, T* info, int* it_out, T tol2, int maxiter, int cap, int64_t N, int lds_bytes,
                  const T* __restrict__ shift = nullptr) {
   extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
+  // cap < 0 (tools/time_pcg_iter.py): thread 0 of two workgroups -- the middle one (a plain member of the two-level exchange) and
+  // workgroup 0 (a group leader) -- accumulates the wall-clock ticks (10 ns) of the phases; the clock starts with the kernel
+  // (PROF: an instantiation of its own -- the production kernel carries none of this, not even the flag's SGPRs)
+  if (cap < 0) cap = -cap;
+  const bool clocked = PROF && (blockIdx.x == gridDim.x / 2 || blockIdx.x == 0) && threadIdx.x == 0;
+  if (clocked) {
+    unsigned* tk = tick_store();
+    for (int q = 0; q < kTickSlots; ++q) tk[q] = 0u;
+    tk[kTickSlots] = (unsigned)wall_clock64();
+    tk[kTickSlots + 1] = tk[kTickSlots];                         // (the kernel's start, kept)
+  }
   constexpr int NQ = CZ ? kPersistQ + 2 * M : kPersistQ;
   constexpr int SLOTS = CZ ? kCoarseSlots : kPersistSlots;
   typedef PersistShared<T, NQ> SH;
@@ -759,13 +745,16 @@ pcg_ghost_kernel(const int* __restrict__ ptr, const int* __restrict__ slot, cons
   const int g_lo = gptr[blockIdx.x], n_ghost = gptr[blockIdx.x + 1] - g_lo;
 
   // ---- owned element
-  T dr[M], br[M], xe = T(0), re = T(0), ze = T(0), pe = T(0);
+  // (the node's row of D is not kept in registers: the owned nodes' diagonal blocks are staged behind the off-diagonal slice as one
+  //  more "incidence" per node -- block D_n, far end the node itself -- so the diagonal term is formed by pass 1 of the SpMV with
+  //  all 16 waves and six VGPRs per lane are free: this kernel sits at its 128-VGPR cap)
+  T br[M], xe = T(0), re = T(0), ze = T(0), pe = T(0);
   int beg = 0, deg = 0;
 #pragma unroll
-  for (int j = 0; j < M; ++j) { dr[j] = T(0); br[j] = T(0); }
+  for (int j = 0; j < M; ++j) br[j] = T(0);
   if (act) {
 #pragma unroll
-    for (int j = 0; j < M; ++j) { dr[j] = D[(n * M + i) * M + j]; br[j] = Binv[(n * M + i) * M + j]; }
+    for (int j = 0; j < M; ++j) br[j] = Binv[(n * M + i) * M + j];
     re = r[n * M + i];
     ze = z[n * M + i];
     pe = ze;
@@ -774,14 +763,13 @@ pcg_ghost_kernel(const int* __restrict__ ptr, const int* __restrict__ slot, cons
   }
   // ---- ghost elements: layer l holds ghost g_lo + l * POS + pos
   T gbr[kGhostLayers][M], gr[kGhostLayers], gp[kGhostLayers];
-  int gnode[kGhostLayers], goff[kGhostLayers];                     // goff: word offset of the ghost's element in a q table
+  int gnode[kGhostLayers];
   bool gact[kGhostLayers];
 #pragma unroll
   for (int l = 0; l < kGhostLayers; ++l) {
     const int gi = l * POS + pos;
     gact[l] = sub < NPW && gi < n_ghost;
     gnode[l] = gact[l] ? gids[g_lo + gi] : 0;
-    goff[l] = (gnode[l] * M + (sub < NPW ? i : 0)) * NW;
     gr[l] = T(0);
     gp[l] = T(0);
 #pragma unroll
@@ -795,15 +783,20 @@ pcg_ghost_kernel(const int* __restrict__ ptr, const int* __restrict__ slot, cons
   constexpr size_t kPBytes = (size_t)(1 + kGhostLayers) * POS * M * sizeof(T);
   T* p_l = reinterpret_cast<T*>(dyn_lds);
   const int c_lo = ptr[n0], c_cnt = ptr[n1] - c_lo;
+  const int c_all = c_cnt + n_own;                                 // staged blocks: the slice's incidences, then the owned nodes' D
   T* hb_l = reinterpret_cast<T*>(dyn_lds + kPBytes);
-  T* yb = hb_l + (size_t)c_cnt * M * M;
-  int* sl_l = reinterpret_cast<int*>(yb + (size_t)c_cnt * M);
+  T* yb = hb_l + (size_t)c_all * M * M;
+  int* sl_l = reinterpret_cast<int*>(yb + (size_t)c_all * M);
   {                                                                // (host guarantees the slice fits: see pcg_ghost())
     const T* src = HB + (size_t)c_lo * M * M;
     for (int e = threadIdx.x; e < c_cnt * M * M; e += kPersistBlock) hb_l[e] = src[e];
+    const T* dsrc = D + (size_t)n0 * M * M;
+    for (int e = threadIdx.x; e < n_own * M * M; e += kPersistBlock) hb_l[(size_t)c_cnt * M * M + e] = dsrc[e];
     for (int e = threadIdx.x; e < c_cnt; e += kPersistBlock) sl_l[e] = slot[c_lo + e];
+    for (int e = threadIdx.x; e < n_own; e += kPersistBlock) sl_l[c_cnt + e] = e;
   }
   if (threadIdx.x == 0) { sh.bad[0] = 0; sh.bad[1] = 0; }
+  tick(clocked, 9);                                            // slot 9: registers loaded, block slice staged (issued)
   __shared__ T einv[CZ ? M : 1];                                      // 1 / E_i (LDS: uniform values, not M registers per lane)
   // sh.wave_part[par][qbase + c][w] = sum over this wave's nodes of `val` at component c (lanes 0..M-1 store)
   auto wave_comp_sums = [&](T val, int par_, int qbase) {
@@ -839,6 +832,7 @@ pcg_ghost_kernel(const int* __restrict__ ptr, const int* __restrict__ slot, cons
 #pragma unroll
     for (int l = 0; l < kGhostLayers; ++l) gp[l] += c0;
   }
+  tick(clocked, 10);                                           // slot 10: the set-up exchange (CZ)
   if (act) p_l[pos * M + i] = pe;
 #pragma unroll
   for (int l = 0; l < kGhostLayers; ++l)
@@ -849,30 +843,26 @@ pcg_ghost_kernel(const int* __restrict__ ptr, const int* __restrict__ slot, cons
   T bn2 = T(0), rr = T(0);
   int k = 0, flag = 0;
   // cap < 0 (tools/time_pcg_iter.py): thread 0 of the middle workgroup accumulates the wall-clock ticks (10 ns) of the phases
-  const bool prof = cap < 0;
-  if (prof) cap = -cap;
-  // two clocked workgroups: the middle one (a plain member of the two-level exchange) and workgroup 0 (a group leader)
-  const bool clocked = prof && (blockIdx.x == gridDim.x / 2 || blockIdx.x == 0) && threadIdx.x == 0;
+  tick(clocked, 8);                                            // slot 8: everything before the first iteration
   // (the accumulators live in LDS, not in registers: five 64-bit counters and the previous reading were 12 VGPRs of EVERY lane for the
   //  whole loop -- at this kernel's 128-VGPR cap they pushed twelve of the ghosts' Binv rows into scratch, reloaded one by one inside
   //  every iteration: <float, 6, CZ> spilled 24 VGPRs with them and spills 2 without, profiles/r05/kernel_resources.txt.  32-bit
   //  ticks: differences are taken modulo 2^32 (43 s).)
-  if (clocked) {
-    unsigned* tk = tick_store();
-    for (int q = 0; q < kTickSlots; ++q) tk[q] = 0u;
-    tk[kTickSlots] = (unsigned)wall_clock64();
-  }
 #define PPLIE_TICK(slot) tick(clocked, slot);
+  unsigned t_start = 0u;
+  if (clocked) t_start = tick_store()[kTickSlots + 1];
   for (;; ++k) {
     const unsigned tag = (unsigned)k + 1u;
     const int par = k & 1;
+    // (profiling runs: when each of the first 64 passes of the middle workgroup began, in 10 ns ticks since the kernel's start)
+    if (clocked && blockIdx.x != 0 && k < 64) rr_hist[cap - 128 + k] = (T)((unsigned)wall_clock64() - t_start);
     // ---- q = A p from LDS in two passes.  (1) INCIDENCE-parallel over all 16 waves: lane group g takes incidences g, g + POS, ...
     // and lane i of it forms component i of y_c = H_c p_far(c) (row i of the block, the neighbour's p: both contiguous);
     // (2) the node's lanes add the diagonal term and their node's y in incidence order.  (Was: the node's own 6 lanes walked its
     // incidences -- a chain of dependent LDS reads as long as the largest degree in the wave, on 4 of the 16 waves -- and a
     // transpose through LDS: 1.65 us of the 7.1 us iteration.)
     if (sub < NPW) {
-      for (int c = pos; c < c_cnt; c += POS) {
+      for (int c = pos; c < c_all; c += POS) {
         const T* h = hb_l + ((size_t)c * M + i) * M;
         const T* pp = p_l + (size_t)sl_l[c] * M;
         T y = T(0);
@@ -884,9 +874,7 @@ pcg_ghost_kernel(const int* __restrict__ ptr, const int* __restrict__ slot, cons
     __syncthreads();                                                             // barrier 0: every y is in place
     T acc = T(0);
     if (act) {
-      const T* pp = p_l + (size_t)pos * M;
-#pragma unroll
-      for (int j = 0; j < M; ++j) acc += dr[j] * pp[j];
+      acc = yb[(c_cnt + pos) * M + i];                                           // D_n p_n
 #pragma unroll 4
       for (int c = 0; c < deg; ++c) acc += yb[(lbeg + c) * M + i];
     }
@@ -909,10 +897,11 @@ pcg_ghost_kernel(const int* __restrict__ ptr, const int* __restrict__ slot, cons
     // for these (with `gact[l] ? get_value(..) : 0` every layer's load was followed by its own s_waitcnt).
     u64 gw[kGhostLayers][NW];
     const u64* qt = qtag + (size_t)par * NM;
+    const int i0 = sub < NPW ? i : 0;                            // (lanes beyond the last node of the wave read node 0's words)
 #pragma unroll
     for (int l = 0; l < kGhostLayers; ++l)
 #pragma unroll
-      for (int kk = 0; kk < NW; ++kk) gw[l][kk] = xwg_load(qt + goff[l] + kk);
+      for (int kk = 0; kk < NW; ++kk) gw[l][kk] = xwg_load(qt + (gnode[l] * M + i0) * NW + kk);
     if constexpr (CZ) exchange_two_level<T, NQ, SH, SLOTS>(sh, par, part, tag, (k >> 1) + par, clocked);   // (table 1's use 0 was the set-up exchange)
     else gather_rows<T, NQ, SH, SLOTS>(sh, par, part, tag);
     PPLIE_TICK(2)
@@ -929,7 +918,7 @@ pcg_ghost_kernel(const int* __restrict__ ptr, const int* __restrict__ slot, cons
 #pragma unroll
       for (int l = 0; l < kGhostLayers; ++l)
 #pragma unroll
-        for (int kk = 0; kk < NW; ++kk) gw[l][kk] = xwg_load(qt + goff[l] + kk);
+        for (int kk = 0; kk < NW; ++kk) gw[l][kk] = xwg_load(qt + (gnode[l] * M + i0) * NW + kk);
     }
     T gq[kGhostLayers];
 #pragma unroll
@@ -1125,10 +1114,19 @@ int pcg_ghost(const void* ptr, const void* slot, const void* HB, const void* D, 
     int lds_bytes = 0;                                                                                                         \
     const int resident = ghost_capacity<T, MM, CZ>(lds_bytes);                                                                 \
     constexpr int POS = (kPersistBlock / 64) * (64 / MM);                                                                      \
+    const size_t per = (size_t)((N + grid - 1) / grid);       /* (+ the owned nodes' diagonal blocks, staged behind the slice) */ \
     const size_t need = (size_t)(1 + kGhostLayers) * POS * MM * sizeof(T) +                                                    \
-                        (size_t)max_cnt * (MM * MM * sizeof(T) + MM * sizeof(T) + 4);                                          \
+                        ((size_t)max_cnt + per) * (MM * MM * sizeof(T) + MM * sizeof(T) + 4);                                  \
     if (resident < grid || need > (size_t)lds_bytes || max_ghost > kGhostLayers * POS || (N + grid - 1) / grid > POS)           \
       return PPLIE_ECAPACITY;             /* (the grid is part of the host's ghost map: it cannot be shrunk here) */             \
+    if (cap < 0 && MM == 6 && sizeof(T) == 4) {   /* (the profiling build exists for the metric's shape only: fp32, m = 6) */   \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&pcg_ghost_kernel<float, 6, CZ, true>),                            \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess) return PPLIE_ELAUNCH;      \
+      hipLaunchKernelGGL((pcg_ghost_kernel<float, 6, CZ, true>), dim3(grid), dim3(kPersistBlock), lds_bytes, st, (const int*)ptr, \
+                         (const int*)slot, (const float*)HB, (const float*)D, (const float*)Binv, (float*)x, (const float*)r,     \
+                         (const float*)z, (const int*)gptr, (const int*)gids, (unsigned long long*)part, (unsigned long long*)qtag, \
+                         (float*)rr_hist, (float*)info, (int*)it, (float)(tol * tol), maxiter, cap, N, lds_bytes, (const float*)shift); \
+    } else                                                                                                                     \
     hipLaunchKernelGGL((pcg_ghost_kernel<T, MM, CZ>), dim3(grid), dim3(kPersistBlock), lds_bytes, st, (const int*)ptr, (const int*)slot, \
                        (const T*)HB, (const T*)D, (const T*)Binv, (T*)x, (const T*)r, (const T*)z, (const int*)gptr,             \
                        (const int*)gids, (unsigned long long*)part, (unsigned long long*)qtag, (T*)rr_hist, (T*)info, (int*)it,   \

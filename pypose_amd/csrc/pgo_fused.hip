@@ -42,10 +42,22 @@ template <class T, int BLOCK, int LAP = 0>
 __global__ void __launch_bounds__(BLOCK)
 pgo_linearize_kernel(const T* __restrict__ nodes, const int64_t* __restrict__ idx, const T* __restrict__ Z,
                      T* __restrict__ R, T* __restrict__ J, int64_t E, RobustParam<T> rk, const int* __restrict__ inc = nullptr,
-                     T* __restrict__ HB = nullptr, T* __restrict__ gg = nullptr) {
+                     T* __restrict__ HB = nullptr, T* __restrict__ gg = nullptr, unsigned long long* __restrict__ ctl = nullptr,
+                     int64_t ctl_words = 0, const double* __restrict__ s_src = nullptr, double* __restrict__ s_dst = nullptr) {
   __shared__ __attribute__((aligned(16))) T lds[BLOCK * 72];
   __shared__ int inc_s[LAP ? BLOCK * 2 : 1];
   constexpr int SW = 27;                                          // staged per edge: 21 entries of S's upper triangle + 6 of Jm^T r
+  if constexpr (LAP != 0) {
+    // what pplie_pcg_begin did in a launch of its own, 5 us in front of every solve: clear the coming solve's control block and bring
+    // the damping factor of the day from host-pinned memory (system-scope load) into the device scalar its set-up launch reads
+    if (ctl) {
+      const bool fetch = s_src && blockIdx.x == 0 && threadIdx.x == 0;
+      double sv = 0.0;
+      if (fetch) sv = __hip_atomic_load(s_src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      for (int64_t k = (int64_t)blockIdx.x * BLOCK + threadIdx.x; k < ctl_words; k += (int64_t)gridDim.x * BLOCK) ctl[k] = 0ull;
+      if (fetch) *s_dst = sv;
+    }
+  }
   const int64_t ntiles = (E + BLOCK - 1) / BLOCK;
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int64_t e0 = tile * BLOCK;
@@ -202,7 +214,9 @@ pgo_residual_kernel(const T* __restrict__ nodes, const int64_t* __restrict__ idx
     if (threadIdx.x == 0) {
       xwg_store(partial + blockIdx.x, s);
       unsigned* ticket = reinterpret_cast<unsigned*>(state + 4);
-      const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      // (acquire as well: the last arriver's reads of the other workgroups' partials are ordered after their releases by the
+      //  memory model, not only by the control dependency on the ticket's value -- ADVICE r05; <= 256 arrivals, nothing measurable)
+      const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
       last_sh = t == gridDim.x - 1 ? 1 : 0;
       if (last_sh) xwg_store(ticket, 0u);                          // (at rest again for the next execution)
     }
@@ -365,12 +379,14 @@ int pgo_trial_tail(void* nodes, void* backup, const void* idx, const void* Z, co
 
 template <class T>
 int pgo_linearize(const void* nodes, const void* idx, const void* Z, void* R, void* J, int64_t E, void* stream, int kind = 0,
-                  double p0 = 0, double p1 = 0, const void* inc = nullptr, void* HB = nullptr, void* gg = nullptr, int pack = 0) {
+                  double p0 = 0, double p1 = 0, const void* inc = nullptr, void* HB = nullptr, void* gg = nullptr, int pack = 0,
+                  void* ctl = nullptr, int64_t ctl_bytes = 0, const void* s_src = nullptr, void* s_dst = nullptr) {
   if (E < 0 || kind < 0 || kind > RK_TOLERANT) return PPLIE_EBADARG;
   if (E == 0) return PPLIE_OK;
   if (!nodes || !idx || !Z || !R || !J || !aligned16(Z) || !aligned16(R) || !aligned16(J)) return PPLIE_EBADARG;
   if ((inc || HB || gg) && !(inc && HB && gg)) return PPLIE_EBADARG;
   if (inc && E >= ((int64_t)1 << 30)) return PPLIE_EBADARG;      // (incidence slots are int32)
+  if (ctl && (!inc || ctl_bytes < 0 || (ctl_bytes & 7) || (reinterpret_cast<uintptr_t>(ctl) & 7) || (s_src && !s_dst))) return PPLIE_EBADARG;
   constexpr int BLOCK = 64;
   int64_t nt = (E + BLOCK - 1) / BLOCK;
   int grid = (int)(nt < (1 << 20) ? nt : (1 << 20));
@@ -381,10 +397,12 @@ int pgo_linearize(const void* nodes, const void* idx, const void* Z, void* R, vo
                        (const T*)Z, (T*)R, (T*)J, E, rk);
   else if (pack)
     hipLaunchKernelGGL((pgo_linearize_kernel<T, BLOCK, 2>), dim3(grid), dim3(BLOCK), 0, st, (const T*)nodes, (const int64_t*)idx,
-                       (const T*)Z, (T*)R, (T*)J, E, rk, (const int*)inc, (T*)HB, (T*)gg);
+                       (const T*)Z, (T*)R, (T*)J, E, rk, (const int*)inc, (T*)HB, (T*)gg, (unsigned long long*)ctl, ctl_bytes / 8,
+                       (const double*)s_src, (double*)s_dst);
   else
     hipLaunchKernelGGL((pgo_linearize_kernel<T, BLOCK, 1>), dim3(grid), dim3(BLOCK), 0, st, (const T*)nodes, (const int64_t*)idx,
-                       (const T*)Z, (T*)R, (T*)J, E, rk, (const int*)inc, (T*)HB, (T*)gg);
+                       (const T*)Z, (T*)R, (T*)J, E, rk, (const int*)inc, (T*)HB, (T*)gg, (unsigned long long*)ctl, ctl_bytes / 8,
+                       (const double*)s_src, (double*)s_dst);
   return hipGetLastError() == hipSuccess ? PPLIE_OK : PPLIE_ELAUNCH;
 }
 template <class T>
@@ -424,16 +442,19 @@ extern "C" int pplie_pgo_residual_robust_f64(const void* nodes, const void* idx,
 
 // linearisation + the edges' shares of the normal equations in one launch (pgo_linearize_kernel LAP): inc [E, 2] int32 = the incidence
 // slot of (edge, side) in the node-sorted list of pplie_graph_assemble_lap (the inverse of its `blk`), HB [2 E, 36 | pack: 21] and
-// gg [2 E, 6] as that entry's first launch leaves them; pplie_graph_lap_diag then finishes the assembly
+// gg [2 E, 6] as that entry's first launch leaves them; pplie_graph_lap_diag then finishes the assembly.  ctl != NULL: the launch also
+// does pplie_pcg_begin's work for the solve that follows (clears ctl_bytes of its control block, s_src -> s_dst)
 extern "C" int pplie_pgo_linearize_lap_f32(const void* nodes, const void* idx, const void* Z, void* R, void* J, const void* inc, void* HB,
-                                           void* gg, int64_t E, int pack, int kind, double p0, double p1, void* stream) {
+                                           void* gg, int64_t E, int pack, int kind, double p0, double p1, void* ctl, int64_t ctl_bytes,
+                                           const void* s_src, void* s_dst, void* stream) {
   if (!inc) return pplie::PPLIE_EBADARG;
-  return pplie::pgo_linearize<float>(nodes, idx, Z, R, J, E, stream, kind, p0, p1, inc, HB, gg, pack);
+  return pplie::pgo_linearize<float>(nodes, idx, Z, R, J, E, stream, kind, p0, p1, inc, HB, gg, pack, ctl, ctl_bytes, s_src, s_dst);
 }
 extern "C" int pplie_pgo_linearize_lap_f64(const void* nodes, const void* idx, const void* Z, void* R, void* J, const void* inc, void* HB,
-                                           void* gg, int64_t E, int pack, int kind, double p0, double p1, void* stream) {
+                                           void* gg, int64_t E, int pack, int kind, double p0, double p1, void* ctl, int64_t ctl_bytes,
+                                           const void* s_src, void* s_dst, void* stream) {
   if (!inc) return pplie::PPLIE_EBADARG;
-  return pplie::pgo_linearize<double>(nodes, idx, Z, R, J, E, stream, kind, p0, p1, inc, HB, gg, pack);
+  return pplie::pgo_linearize<double>(nodes, idx, Z, R, J, E, stream, kind, p0, p1, inc, HB, gg, pack, ctl, ctl_bytes, s_src, s_dst);
 }
 extern "C" int pplie_pgo_linearize_f32(const void* nodes, const void* idx, const void* Z, void* R, void* J, int64_t E, void* stream) {
   return pplie::pgo_linearize<float>(nodes, idx, Z, R, J, E, stream);

@@ -310,7 +310,11 @@ def _make_fwd(clsname, g, kind, doc):
             if not _transforms_active():
                 # the plain eager case through a PREPARED handle of the native extension (csrc_torch/pplie_autograd.cpp RowHandle):
                 # operand checks, the no-gradient launch and the native autograd node behind ONE call; None -> the paths below
-                if not _op_tracers and _C.row_op is _ROW_OP and len(ins) <= 2 and _native() is not None:
+                # (the stand-in back end of the host tests is looked at on EVERY call, not when the handle is built, and tensor
+                #  subclasses other than Parameter keep the Python route, as on the paths below: ADVICE r05)
+                if not _op_tracers and _C.row_op is _ROW_OP and _C._test_backend is None and len(ins) <= 2 and _native() is not None \
+                        and (type(ins[0]) is torch.Tensor or type(ins[0]) is torch.nn.Parameter) \
+                        and (len(ins) == 1 or type(ins[1]) is torch.Tensor or type(ins[1]) is torch.nn.Parameter):
                     h = cls._handle(ins[0].dtype)
                     if h is not None and not _C.dry_tracing():
                         out = h(*ins)
@@ -341,8 +345,7 @@ def _make_fwd(clsname, g, kind, doc):
                 return hs[dtype]
             h = None
             nat = _native()
-            if nat is not None and hasattr(nat, "RowHandle") and dtype in (torch.float32, torch.float64) and len(fin) <= 2 \
-                    and _C._test_backend is None:
+            if nat is not None and hasattr(nat, "RowHandle") and dtype in (torch.float32, torch.float64) and len(fin) <= 2:
                 try:
                     h = nat.RowHandle(_kernel_address(fwd_kernel, dtype), _kernel_address(bwd_kernel, dtype),
                                       _kernel_address(bwd_kernel + "_gb", dtype), fin[0], fin[1] if len(fin) == 2 else 0, fout,

@@ -831,7 +831,8 @@ class LprLinearization:
 # PPLIE_FUSE_PGO_ASSEMBLY=0: the linearisation and pplie_graph_assemble_lap's two launches, as before round 6
 FUSE_PGO_ASSEMBLY = os.environ.get("PPLIE_FUSE_PGO_ASSEMBLY", "1") != "0"
 _PGO_SIG = [ctypes.c_void_p] * 5 + [ctypes.c_int64, ctypes.c_void_p]
-_PGO_LAP_SIG = [ctypes.c_void_p] * 8 + [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_void_p]
+_PGO_LAP_SIG = [ctypes.c_void_p] * 8 + [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_void_p, ctypes.c_int64,
+                ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
 _PGO_ROBUST_SIG = [ctypes.c_void_p] * 5 + [ctypes.c_int64, ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_void_p]
 _PGO_PARTIALS = 1024      # PPLIE_PGO_PARTIALS
 
@@ -919,17 +920,21 @@ class PgoProgram:
         return (torch.empty((self.E, 6), dtype=nodes.dtype, device=nodes.device),
                 torch.empty((self.E, 2, 6, 6), dtype=nodes.dtype, device=nodes.device))
 
-    def linearize_lap(self, R, J, inc, HB, gg, pack, robust=None):
+    def linearize_lap(self, R, J, inc, HB, gg, pack, robust=None, begin=None):
         """:meth:`linearize` into ``R`` / ``J`` that ALSO leaves the edges' shares of the normal equations (``pplie_pgo_linearize_lap``):
         -J_1^T J_1 at both incidence slots ``inc[e]`` of ``HB`` (full or packed blocks) and -+J_1^T r in ``gg`` -- what the first
         launch of ``pplie_graph_assemble_lap`` computed from the J blocks it read back"""
         nodes = torch.Tensor.as_subclass(self.P, torch.Tensor).detach()
         assert nodes.is_contiguous() and inc.shape == (self.E, 2) and inc.dtype == torch.int32 and inc.is_contiguous()
         kind, p0, p1 = (0, 0.0, 0.0) if robust is None else robust
+        # begin = (control block, host-pinned damping factor or None, device scalar): pplie_pcg_begin's work for the solve that follows
+        ctl, s_src, s_dst = (None, None, None) if begin is None else begin
         with _C._on_device(nodes.device):
             fn = _C.library().symbol("pplie_pgo_linearize_lap" + _blocks._suffix(nodes), _PGO_LAP_SIG)
             code = fn(nodes.data_ptr(), self.idx.data_ptr(), self.Z.data_ptr(), R.data_ptr(), J.data_ptr(), inc.data_ptr(), HB.data_ptr(),
-                      gg.data_ptr(), self.E, 1 if pack else 0, kind, p0, p1, _C.stream_ptr(nodes.device))
+                      gg.data_ptr(), self.E, 1 if pack else 0, kind, p0, p1, None if ctl is None else ctl.data_ptr(),
+                      0 if ctl is None else ctl.numel() * ctl.element_size(), None if s_src is None else s_src.data_ptr(),
+                      None if s_dst is None else s_dst.data_ptr(), _C.stream_ptr(nodes.device))
         _C.check(code, "pplie_pgo_linearize_lap")
 
     def linearize(self, robust=None, out=None):
@@ -1140,7 +1145,7 @@ def _same_input(a, b):
     return False
 
 
-def _pgo_linearization(opt, prog, weight, P, trivial):
+def _pgo_linearization(opt, prog, weight, P, trivial, s_dev=None):
     from . import posegraph as _pg
     from .corrector import fused_code
     from .kernel import robust_code
@@ -1165,8 +1170,21 @@ def _pgo_linearization(opt, prog, weight, P, trivial):
     if fuse:
         plan = lin.plan_blocks() if (lin.R is r and lin.J is J and lin.W is None and lin.group is None and lin._hip()) else None
         if plan is not None and lin.HB is not None:
-            prog.linearize_lap(r, J, lin.incidence_slots(), lin.HB, plan['gg'], lin.HB_pack, robust)
+            # the solve's workspace, if this optimizer has solved this system before: the launch then also clears its control block
+            # (and, in a captured trial, fetches the damping factor from `s_dev`) -- what pplie_pcg_begin / a fill did in front of
+            # every solve; the workspace is told through lin._begun
+            wsp, begin = None, None
+            solver = opt.solver
+            if isinstance(solver, _pg.PCG) and getattr(solver, 'fused', True) and _pg.FusedPCG.fuse_prepare:
+                wsp = (opt.__dict__.get('_pcg_workspaces') or {}).get(
+                    (lin.E, lin.K, lin.dr, lin.m, lin.N, lin.J.dtype, lin.J.device, False, solver.check_every))
+            if wsp is not None:
+                begin = (wsp._ctl, s_dev, wsp.s_device)
+            prog.linearize_lap(r, J, lin.incidence_slots(), lin.HB, plan['gg'], lin.HB_pack, robust, begin)
             plan['blocks_done'] = True
+            if wsp is not None:
+                # (valid only while nothing else has used the workspace in between: the workspace counts its solves)
+                lin._begun = (wsp, s_dev, wsp.__dict__.get('_solves', 0))
         else:
             prog.linearize(robust, out=(r, J))
 

@@ -638,7 +638,9 @@ class LevenbergMarquardt(_Optimizer):
         # sized far beyond what the solves take would give back what it saves in host latency
         unwatched = None
         if ok and not (lin.N <= PERSIST_NODES and FusedPCG.persist):
-            wsps = [w for w in (d.get('_pcg_workspaces') or {}).values() if w.N == lin.N and w.sym == 'pack' and w.iterations_seen > 0]
+            # (the dict also holds the multigraph route's workspaces, which have none of these attributes: ADVICE r05)
+            wsps = [w for w in (d.get('_pcg_workspaces') or {}).values()
+                    if isinstance(w, FusedPCG) and w.N == lin.N and w.sym == 'pack' and w.iterations_seen > 0]
             ok = (FusedPCG.capture_large and FusedPCG.device_stop and bool(getattr(lin, 'HB_pack', False)) and len(wsps) == 1)
             if ok:
                 unwatched = FusedPCG.unwatched_for(wsps[0].iterations_seen, self.solver.maxiter)

@@ -173,7 +173,7 @@ class PgoGraphStep:
         # (a replay launched speculatively -- before this step's run of the model has confirmed the program, see
         #  fused.checked_shortcut -- is undone by copying `backup` back: the retraction kernel, the only writer of the
         #  parameters in the trial, saves the rows it overwrites)
-        lin = _fused._pgo_linearization(opt, self.prog, self.weight, self.P, self.trivial)
+        lin = _fused._pgo_linearization(opt, self.prog, self.weight, self.P, self.trivial, s_dev=self.ctl)
         lin.build_normal_equations(*self.clamp)
         lin.s_dev = self.ctl                       # prepare reads the damping factor from here (pplie_pcg_prepare_dev)
         opt._defer_solver_info = 'inplace'

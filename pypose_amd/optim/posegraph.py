@@ -40,6 +40,8 @@ _ASM_SIG = [ctypes.c_void_p] * 7 + [ctypes.c_int64, ctypes.c_int, ctypes.c_int, 
 _ASMC_SIG = [ctypes.c_void_p] * 8 + [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
 _ASML_SIG = [ctypes.c_void_p] * 9 + [ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
 _LAPD_SIG = [ctypes.c_void_p] * 5 + [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+_PREP_LAP_SIG = ([ctypes.c_void_p] * 3 + [ctypes.c_int] + [ctypes.c_void_p] * 13 + [ctypes.c_double, ctypes.c_void_p, ctypes.c_double, ctypes.c_double,
+                                                                                          ctypes.c_int64, ctypes.c_int, ctypes.c_void_p])
 _PREP_SIG = [ctypes.c_void_p] * 10 + [ctypes.c_double] * 3 + [ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]
 _BEGIN_SIG = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
 _PREP_DEV_SIG = [ctypes.c_void_p] * 11 + [ctypes.c_double] * 2 + [ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]
@@ -323,6 +325,8 @@ class FusedPCG:
     persist = True           # one persistent launch per solve on small graphs (csrc/pcg_persist.hip)
     ghost = True             # the ghost-zone form of the persistent solve (one grid-wide dependency per iteration)
     profile = False          # tools/time_pcg_iter.py: the persistent kernel leaves per-phase clock ticks in rr_hist[cap - 8:]
+    # the "Laplacian" assembly's per-node sums inside the solve's set-up launch (pplie_pcg_prepare_lap); PPLIE_PCG_FUSE_PREPARE=0: off
+    fuse_prepare = _os.environ.get("PPLIE_PCG_FUSE_PREPARE", "1") != "0"
     # two-level preconditioner (block-Jacobi + gauge modes) where the linearisation allows it (PCG(gauge=)); PPLIE_PCG_GAUGE=0: off
     coarse = _os.environ.get("PPLIE_PCG_GAUGE", "1") != "0"
     # the whole LM trial of a graph BEYOND the persistent solve as one hipGraph replay too (optim/pgograph.py): the two-launch iterations
@@ -494,8 +498,26 @@ class FusedPCG:
                          self.it.data_ptr(), self.cap, self.N, self.m, st)
             _C.check(code, "pplie_pcg_stage")
 
+    def _prepare_lap(self, lin, s, s_dev, dmin, dmax, coarse):
+        """the set-up launch that also finishes the linearisation's assembly (its per-node sums are pending: pplie_pcg_prepare_lap);
+        None when there is nothing pending -- the caller then runs the plain set-up on lin.B / lin.g"""
+        pend = lin.__dict__.get('_diag_pending')
+        if pend is None:
+            return None
+        lin._diag_pending = None
+        ptr, gg = pend
+        dp = self.dp and coarse
+        return _C.library().symbol("pplie_pcg_prepare_lap" + self.sfx, _PREP_LAP_SIG)(
+            ptr.data_ptr(), lin.HB.data_ptr(), gg.data_ptr(), 1 if lin.HB_pack else 0, lin._B.data_ptr(), lin._g.data_ptr(),
+            self.D.data_ptr(), self.Binv.data_ptr(), self.Dp.data_ptr() if dp else None, self.Bp.data_ptr() if dp else None,
+            self.shift.data_ptr(), self.x.data_ptr(), self.r.data_ptr(), self.z.data_ptr(), self.p.data_ptr(), self.scal.data_ptr(),
+            self.cs.data_ptr() if coarse else None, float(s), s_dev, float(dmin), float(dmax), self.N, self.m, _C.stream_ptr(self.device))
+
     def _prepare_coarse(self, lin, s, s_dev, dmin, dmax):
         """pplie_pcg_prepare_coarse (+ the packed triangles of D / Binv when this solve's iteration reads those)"""
+        code = self._prepare_lap(lin, s, s_dev, dmin, dmax, True)
+        if code is not None:
+            return code
         st = _C.stream_ptr(self.device)
         if self.dp:
             return _C.library().symbol("pplie_pcg_prepare_coarse_dp" + self.sfx, _PREP_CZ_DP_SIG)(
@@ -538,7 +560,11 @@ class FusedPCG:
             if self.W is not None:
                 self.W.copy_(lin.W)
         s_dev = getattr(lin, 's_dev', None)
-        if s_dev is None:
+        # (the fused pose-graph linearisation may have cleared the control block / fetched the damping factor in its own launch already)
+        begun = lin.__dict__.pop('_begun', None)
+        begun = begun is not None and begun[0] is self and begun[1] is s_dev and begun[2] == self.__dict__.get('_solves', 0)
+        self._solves = self.__dict__.get('_solves', 0) + 1
+        if s_dev is None and not begun:
             self._ctl.zero_()                                       # scal, cs, part (sequence tags restart at 1), it
         # the two-level preconditioner: relative-pose linearisations (J[e,0] = -J[e,1]) on the single-GPU block paths that have it
         # -- the ghost-zone persistent solve and the packed two-launch iteration with the device-side stop test
@@ -559,9 +585,10 @@ class FusedPCG:
             if s_dev is not None:
                 # a captured trial: the damping factor of the day sits in a host-pinned scalar; the launch that clears the
                 # control block also brings it into device memory (pplie_pcg_begin)
-                code = _C.library().symbol("pplie_pcg_begin", _BEGIN_SIG)(
-                    self._ctl.data_ptr(), self._ctl.numel(), s_dev.data_ptr(), self.s_device.data_ptr(), _C.stream_ptr(self.device))
-                _C.check(code, "pplie_pcg_begin")
+                if not begun:
+                    code = _C.library().symbol("pplie_pcg_begin", _BEGIN_SIG)(
+                        self._ctl.data_ptr(), self._ctl.numel(), s_dev.data_ptr(), self.s_device.data_ptr(), _C.stream_ptr(self.device))
+                    _C.check(code, "pplie_pcg_begin")
                 if self.cz and two:
                     # (a captured trial on a graph beyond the persistent solve: the two-launch iteration's coarse sums, the damping
                     #  factor from the device scalar pplie_pcg_begin has just filled)
@@ -570,10 +597,12 @@ class FusedPCG:
                     code = _C.library().symbol("pplie_pcg2_coarse_init" + self.sfx, _CZ_INIT_SIG)(
                         self.p.data_ptr(), self.cs.data_ptr(), self.N, self.m, _C.stream_ptr(self.device))
                 else:
-                    code = _C.library().symbol("pplie_pcg_prepare_dev" + self.sfx, _PREP_DEV_SIG)(
-                        lin.B.data_ptr(), lin.g.data_ptr(), self.D.data_ptr(), self.Binv.data_ptr(), self.shift.data_ptr(),
-                        self.x.data_ptr(), self.r.data_ptr(), self.z.data_ptr(), self.p.data_ptr(), self.scal.data_ptr(),
-                        self.s_device.data_ptr(), float(dmin), float(dmax), self.N, self.m, _C.stream_ptr(self.device))
+                    code = self._prepare_lap(lin, 1.0, self.s_device.data_ptr(), dmin, dmax, False)
+                    if code is None:
+                        code = _C.library().symbol("pplie_pcg_prepare_dev" + self.sfx, _PREP_DEV_SIG)(
+                            lin.B.data_ptr(), lin.g.data_ptr(), self.D.data_ptr(), self.Binv.data_ptr(), self.shift.data_ptr(),
+                            self.x.data_ptr(), self.r.data_ptr(), self.z.data_ptr(), self.p.data_ptr(), self.scal.data_ptr(),
+                            self.s_device.data_ptr(), float(dmin), float(dmax), self.N, self.m, _C.stream_ptr(self.device))
             elif self.cz and two:
                 # (the persistent solve sums E and Z^T r_0 itself, in its first exchange; the two-launch iteration gets them here)
                 code = self._prepare_coarse(lin, float(s), None, dmin, dmax)
@@ -581,10 +610,12 @@ class FusedPCG:
                 code = _C.library().symbol("pplie_pcg2_coarse_init" + self.sfx, _CZ_INIT_SIG)(
                     self.p.data_ptr(), self.cs.data_ptr(), self.N, self.m, _C.stream_ptr(self.device))
             else:
-                code = _C.library().symbol("pplie_pcg_prepare" + self.sfx, _PREP_SIG)(
-                    lin.B.data_ptr(), lin.g.data_ptr(), self.D.data_ptr(), self.Binv.data_ptr(), self.shift.data_ptr(),
-                    self.x.data_ptr(), self.r.data_ptr(), self.z.data_ptr(), self.p.data_ptr(), self.scal.data_ptr(),
-                    float(s), float(dmin), float(dmax), self.N, self.m, _C.stream_ptr(self.device))
+                code = self._prepare_lap(lin, float(s), None, dmin, dmax, False)
+                if code is None:
+                    code = _C.library().symbol("pplie_pcg_prepare" + self.sfx, _PREP_SIG)(
+                        lin.B.data_ptr(), lin.g.data_ptr(), self.D.data_ptr(), self.Binv.data_ptr(), self.shift.data_ptr(),
+                        self.x.data_ptr(), self.r.data_ptr(), self.z.data_ptr(), self.p.data_ptr(), self.scal.data_ptr(),
+                        float(s), float(dmin), float(dmax), self.N, self.m, _C.stream_ptr(self.device))
             _C.check(code, "pplie_pcg_prepare")
             if plain:                                               # z = r, p = r, rho = r.r = |b|^2, Binv = I
                 self.Binv.copy_(torch.eye(self.m, dtype=self.Binv.dtype, device=self.Binv.device).expand_as(self.Binv))
@@ -706,6 +737,9 @@ class FusedPCG:
                     if flag == 1:
                         self.iterations_seen = max(self.iterations_seen, int(its))
                         return self.x.clone(), int(its)
+                # (ended at the iteration limit: a capture sized by a shorter solve would report "not converged" again and again --
+                #  the count is recorded so that unwatched_for() sizes the next capture beyond it or declines: ADVICE r05)
+                self.iterations_seen = max(self.iterations_seen, int(done))
                 return self.x.clone(), done
             if self.stop_tol2 is not None:
                 self.stop_tol2, self.graph = None, None
@@ -947,7 +981,11 @@ class GraphLinearization:
                     lap = self.plan_blocks()
                     if lap is not None:
                         # J_0 = -J_1: incidence-parallel blocks, then per-node sums (csrc/graph.hip, pplie_graph_assemble_lap)
-                        if lap.get('blocks_done'):       # (the fused linearisation left HB and gg already: optim/fused.py)
+                        if lap.get('blocks_done') and FusedPCG.fuse_prepare and not self.__dict__.get('_eager_diag'):
+                            # (the per-node sums ride in the solve's set-up launch, pplie_pcg_prepare_lap -- or run on the first
+                            #  read of B / g by anybody else: _materialize_diag)
+                            self._diag_pending = (ptr, lap['gg'])
+                        elif lap.get('blocks_done'):     # (the fused linearisation left HB and gg already: optim/fused.py)
                             code = lib.symbol("pplie_graph_lap_diag" + sfx, _LAPD_SIG)(
                                 ptr.data_ptr(), self.HB.data_ptr(), lap['gg'].data_ptr(), B.data_ptr(), g.data_ptr(), N, self.m,
                                 1 if self.HB_pack else 0, st)
@@ -1017,6 +1055,39 @@ class GraphLinearization:
         # the parameter components outside the tangent space (7th of SE3, ...) have a structurally
         # zero Jacobian column: the reference clamps their diagonal to ``min`` and solves d = 0.
         self.s = 1.0
+
+    # B (raw block diagonal [N, m, m]) and g (gradient [N, m]): attributes, except that the "Laplacian" assembly behind a fused
+    # linearisation leaves their per-node sums to the solve's set-up launch -- whoever reads them first otherwise runs the sums
+    @property
+    def B(self):
+        self._materialize_diag()
+        return self._B
+
+    @B.setter
+    def B(self, v):
+        self._B = v
+
+    @property
+    def g(self):
+        self._materialize_diag()
+        return self._g
+
+    @g.setter
+    def g(self, v):
+        self._g = v
+
+    def _materialize_diag(self):
+        pend = self.__dict__.get('_diag_pending')
+        if pend is None:
+            return
+        self._diag_pending = None
+        ptr, gg = pend
+        sfx = "_f32" if self.J.dtype == torch.float32 else "_f64"
+        with _C._on_device(self.J.device):
+            code = _C.library().symbol("pplie_graph_lap_diag" + sfx, _LAPD_SIG)(
+                ptr.data_ptr(), self.HB.data_ptr(), gg.data_ptr(), self._B.data_ptr(), self._g.data_ptr(), self.N, self.m,
+                1 if self.HB_pack else 0, _C.stream_ptr(self.J.device))
+        _C.check(code, "pplie_graph_lap_diag")
 
     @property
     def diag_raw(self):

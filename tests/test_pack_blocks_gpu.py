@@ -111,7 +111,13 @@ def test_two_launch_laplacian_assembly_equals_the_node_parallel_kernel(dtype, to
             lin.build_normal_equations(1e-6, 1e32)
         assert bool(lin.HB_pack) == pack
         out[lap] = (lin.HB.clone(), lin.B.clone(), lin.g.clone())
-    assert torch.equal(out[True][0], out[False][0])
+    if weighted:
+        assert torch.equal(out[True][0], out[False][0])
+    else:
+        # (round 6: without a weight the blocks of the lap route come out of the LINEARISATION kernel, pplie_pgo_linearize_lap --
+        #  the same products in the same order, contracted into FMAs differently: equal to a few ulp of a block's largest entry)
+        a, b = out[True][0].reshape(out[True][0].shape[0], -1), out[False][0].reshape(out[False][0].shape[0], -1)
+        assert float(((a - b).abs().amax(-1) / b.abs().amax(-1).clamp_min(1e-30)).max()) <= (2e-6 if dtype == torch.float32 else 1e-14)
     scale_B, scale_g = out[False][1].abs().max().item(), out[False][2].abs().max().item()
     assert (out[True][1] - out[False][1]).abs().max().item() <= tol * scale_B
     assert (out[True][2] - out[False][2]).abs().max().item() <= tol * scale_g

@@ -61,3 +61,52 @@ def test_fused_assembly_equals_linearize_then_assemble(N, E, dtype, robust, monk
             full[iu[0], iu[1]] = blk
             blk = full + full.triu(1).mT
         torch.testing.assert_close(blk, -S, rtol=1e-5 if dtype == torch.float32 else 1e-12, atol=1e-6 if dtype == torch.float32 else 1e-13)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("N,E", [(3000, 12_001), (40_000, 130_000)], ids=["persistent_solve", "two_launch_solve"])
+def test_set_up_launch_that_finishes_the_assembly(N, E, dtype, monkeypatch):
+    """pplie_pcg_prepare_lap (the per-node sums of the assembly inside the solve's set-up launch, the control block cleared by the
+    linearisation's launch) against the separate launches: the same damped blocks, inverses, right-hand side, and the same solve."""
+    from pypose_amd.optim import posegraph as G
+    edges, rel, init = _synthetic_graph(N, E, dtype)
+    graph = PoseGraph(init.clone())
+    solver = pp.optim.solver.PCG(tol=1e-6 if dtype == torch.float32 else 1e-10, maxiter=400)
+    opt = pp.optim.LM(graph, solver=solver, strategy=pp.optim.strategy.TrustRegion(radius=1e4))
+    opt.step((edges, rel))
+    graph.nodes.data.copy_(init.tensor())
+    prog = opt._structure_cache["program"][3]
+    wsp = next(iter(opt._pcg_workspaces.values()))
+    out = {}
+    for fuse in (True, False):
+        monkeypatch.setattr(F, "FUSE_PGO_ASSEMBLY", fuse)
+        monkeypatch.setattr(G.FusedPCG, "fuse_prepare", fuse)
+        with torch.no_grad():
+            lin = F._pgo_linearization(opt, prog, None, graph.nodes, True)
+            lin.build_normal_equations(1e-6, 1e32)
+            assert (lin.__dict__.get('_diag_pending') is not None) == fuse and (lin.__dict__.get('_begun') is not None) == fuse
+            lin.damp(1e-4)
+            x, its = wsp.solve(lin, lin.s, lin.dmin, lin.dmax, solver.tol, 400, None)
+            assert lin.__dict__.get('_diag_pending') is None and lin.__dict__.get('_begun') is None
+            # a second solve of the same linearisation (a retry after a rejected trial) takes the plain set-up on lin.B / lin.g
+            lin.damp(1e-4)
+            x2, _ = wsp.solve(lin, lin.s, lin.dmin, lin.dmax, solver.tol, 400, None)
+        out[fuse] = (lin.B.clone(), lin.g.clone(), wsp.D.clone(), wsp.Binv.clone(), x.clone(), x2.clone(), its)
+    torch.cuda.synchronize()
+    tol = 2e-6 if dtype == torch.float32 else 1e-13
+    for a, b, name in zip(out[True][:3], out[False][:3], ("B", "g", "D")):
+        a2, b2 = a.reshape(a.shape[0], -1), b.reshape(b.shape[0], -1)
+        err = ((a2 - b2).abs().amax(-1) / b2.abs().amax(-1).clamp_min(1e-30)).max()
+        assert float(err) <= tol, (name, float(err))
+    # (the inverses of blocks that differ in their last bits differ by the blocks' condition number times that: each is checked
+    #  against its own D)
+    eye = torch.eye(6, dtype=dtype, device=out[True][2].device)
+    if dtype == torch.float64:                # (fp32: blocks with entries from 1e-2 to 1e4 -- the residual says nothing there)
+        for fuse in (True, False):
+            res = (out[fuse][3] @ out[fuse][2] - eye).abs().amax((-1, -2)).max()
+            assert float(res) <= 1e-9, (fuse, float(res))
+    for k in (4, 5):
+        a, b = out[True][k], out[False][k]
+        assert float((a - b).abs().max()) <= (2e-3 if dtype == torch.float32 else 1e-8) * float(b.abs().max()), \
+            (k, float((a - b).abs().max()), float(b.abs().max()), out[True][6], out[False][6])
+    assert abs(out[True][6] - out[False][6]) <= 1

@@ -58,6 +58,24 @@ with torch.no_grad():
         for nm, off in (("mid", 48), ("wg0", 32)):
             tk = wsp.rr_hist[wsp.cap - off:wsp.cap - off + 14].tolist()
             out["ghost_grid%d_ticks_us_per_iteration_%s" % (pg, nm)] = [round(t * 0.01 / max(its, 1), 3) for t in tk]
+            # once per solve: slot 9 = registers + block slice staged, 10 = the set-up exchange, 8 = the rest before iteration 0
+            out["ghost_grid%d_prologue_us_%s" % (pg, nm)] = {"stage": round(tk[9] * 0.01, 2), "setup_exchange": round(tk[10] * 0.01, 2),
+                                                             "rest": round(tk[8] * 0.01, 2), "all_slots_sum": round(sum(tk) * 0.01, 1)}
+        starts = wsp.rr_hist[wsp.cap - 128:wsp.cap - 64].tolist()
+        out["ghost_grid%d_pass_start_us" % pg] = [round(t * 0.01, 1) for t in starts[:24]]
+        # what a solve costs beside its iterations: HIP events around solves of 1 .. 40 iterations (fill + set-up launch + the kernel)
+        res = {}
+        for iters in (1, 5, 10, 20, 40):
+            ts = []
+            for rep in range(6):
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                wsp.solve(lin, lin.s, lin.dmin, lin.dmax, 1e-30, iters, None)
+                b.record()
+                torch.cuda.synchronize()
+                ts.append(a.elapsed_time(b) * 1e3)
+            res[iters] = round(sorted(ts[1:])[len(ts[1:]) // 2], 1)
+        out["ghost_grid%d_us_per_solve_by_iterations" % pg] = res
     G.PERSIST_GRID = 256
     xg, itg = wsp.solve(lin, lin.s, lin.dmin, lin.dmax, 1e-6, 2000, None)
     G.FusedPCG.ghost = False
