@@ -284,12 +284,28 @@ __device__ __forceinline__ bool unpack_pair(u64 w, unsigned t2, float& a, float&
   return (ua & 3u) == t2 && (ub & 3u) == t2;
 }
 // word j of a row = quantities (2 j, 2 j + 1); rows of SLOTS words (fp32: one word per slot)
+// Table layout: ROW-major, word j of row b at tab[b * SLOTS + j] -- a row's words share one or two cache lines that ONE workgroup
+// writes.  (Round 6 experiment, PPLIE_PAIRS_ROW_MAJOR=0: WORD-major, tab[j * kPairRows + b], so that a gathering wave reads 512
+// contiguous bytes instead of 64 lines.  Measured on the 10 k-pose LM step: 0.306 ms against 0.263 -- the final gather went from
+// 2.8 to 4.1 us per iteration.  A line then carries words of 8 - 16 workgroups written at different times: the partial-line
+// write-throughs and the polls of that line collide.  One writer per line is what is fast; kept for the record.)
+#ifndef PPLIE_PAIRS_ROW_MAJOR
+#define PPLIE_PAIRS_ROW_MAJOR 1
+#endif
+constexpr int kPairRows = 256 + 8;       // = kHierRows (defined below): rows of one pair table
+// (also tried, round 6: a row pitch of 512 B / 1 KB / 4 KB instead of 192 B, to spread the rows over more memory channels -- no
+//  effect beyond the run-to-run noise of 1 %: the gather is not bound by where the rows live)
+template <int SLOTS> __device__ __forceinline__ constexpr int pair_pitch() { return SLOTS; }
+template <int SLOTS> __device__ __forceinline__ size_t pair_at(int row, int word) {
+  return PPLIE_PAIRS_ROW_MAJOR ? (size_t)row * pair_pitch<SLOTS>() + word : (size_t)word * kPairRows + row;
+}
 template <int NQ, class SH, int SLOTS>
-__device__ __forceinline__ void put_pairs(const float* vals_lds, u64* row, unsigned t2) {
+__device__ __forceinline__ void put_pairs(const float* vals_lds, u64* tab, int row, unsigned t2) {
   constexpr int NP = (NQ + 1) / 2;
+  static_assert(NP <= SLOTS, "a table holds SLOTS words per row in either layout");
   if (threadIdx.x < NP) {
     const float a = vals_lds[2 * threadIdx.x], b = 2 * threadIdx.x + 1 < NQ ? vals_lds[2 * threadIdx.x + 1] : 0.f;
-    xwg_store(row + threadIdx.x, pack_pair(a, b, t2));
+    xwg_store(tab + pair_at<SLOTS>(row, threadIdx.x), pack_pair(a, b, t2));
   }
 }
 // (Round 6, measured on the 10 k-pose LM step with four builds of this file side by side, tools/gpu_ab_lib.sh: the loop below waits
@@ -302,7 +318,7 @@ __device__ __forceinline__ void gather_pairs(SH& sh, int par, const u64* part, u
   constexpr int NP = (NQ + 1) / 2, RW = SLOTS, LD = 3;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   if (w < NP) {
-    const u64* tab = part + (size_t)par * rows_per_table * RW;
+    const u64* tab = part + (size_t)par * rows_per_table * pair_pitch<SLOTS>();
     float s0 = 0.f, s1 = 0.f;
     bool all = true;
     for (int base = 0; base < count; base += 64 * LD) {            // (LD rows per lane and round: 192 cover the usual grids of 160 - 192)
@@ -316,7 +332,7 @@ __device__ __forceinline__ void gather_pairs(SH& sh, int par, const u64* part, u
         for (int q = 0; q < LD; ++q) {
           if (!done[q]) {
             float a, b;
-            if (unpack_pair(xwg_load(tab + (size_t)(first + stride * (base + lane + 64 * q)) * RW + w), t2, a, b)) { v0[q] = a; v1[q] = b; done[q] = true; }
+            if (unpack_pair(xwg_load(tab + pair_at<SLOTS>(first + stride * (base + lane + 64 * q), w)), t2, a, b)) { v0[q] = a; v1[q] = b; done[q] = true; }
             else pending = true;
           }
         }
@@ -346,6 +362,7 @@ __device__ __forceinline__ void gather_pairs(SH& sh, int par, const u64* part, u
 constexpr int kHierGroups = 8;
 constexpr int kHierMinGrid = 224;        // grids from here on exchange in two levels
 constexpr int kHierRows = kPersistGridMax + kHierGroups;
+static_assert(kHierRows == kPairRows, "pair tables: kPairRows rows");
 template <class T, int NQ, class SH, int SLOTS>
 __device__ __forceinline__ void exchange_two_level(SH& sh, int par, u64* part, unsigned tag, int use, bool clocked = false) {
   constexpr int NW = sizeof(T) / 4, RW = SLOTS * NW, WV = kPersistBlock / 64;
@@ -361,7 +378,7 @@ __device__ __forceinline__ void exchange_two_level(SH& sh, int par, u64* part, u
       mine[threadIdx.x] = sum;
     }
     __syncthreads();
-    put_pairs<NQ, SH, SLOTS>(mine, part + ((size_t)par * kHierRows + blockIdx.x) * RW, t2);
+    put_pairs<NQ, SH, SLOTS>(mine, part + (size_t)par * kHierRows * pair_pitch<SLOTS>(), blockIdx.x, t2);
     tick(clocked, 5);
     if ((int)gridDim.x < kHierMinGrid) {
       gather_pairs<NQ, SH, SLOTS>(sh, par, part, t2, 0, 1, (int)gridDim.x, kHierRows);
@@ -372,7 +389,7 @@ __device__ __forceinline__ void exchange_two_level(SH& sh, int par, u64* part, u
       const int members = ((int)gridDim.x - (int)blockIdx.x + G - 1) / G;
       gather_pairs<NQ, SH, SLOTS>(sh, par, part, t2, (int)blockIdx.x, G, members, kHierRows);
       __syncthreads();
-      put_pairs<NQ, SH, SLOTS>(&sh.total[par][0], part + ((size_t)par * kHierRows + kPersistGridMax + blockIdx.x) * RW, t2);
+      put_pairs<NQ, SH, SLOTS>(&sh.total[par][0], part + (size_t)par * kHierRows * pair_pitch<SLOTS>(), kPersistGridMax + blockIdx.x, t2);
       __syncthreads();
       tick(clocked, 6);
     }

@@ -200,6 +200,25 @@ struct RowHandle {
   }
 };
 
+// ---- the device-resident LM step (optim/fused.py DeviceLM): pplie_lm_se3inv_step behind ONE call -----------------------------------
+// BASELINE configs[2] (LM on 10^6 independent SE3 problems) is two launches, ~32 us of GPU time per step; the host path to them was
+// ~17 us of Python per step -- the current-stream lookup, a device-guard context manager and a ctypes call marshalling twelve
+// arguments -- on top of the model's dry run (round 5: 40 us of host against 32 us of kernels, host-bound).  The handle keeps every
+// pointer that does not change between steps; a step passes which state buffer is current and where the loss goes.
+// `cfg_addr`: the address of the caller's pplie_lm_cfg (a ctypes.Structure it refills in place before a call).
+typedef int (*lmstep_t)(void*, const void*, void*, void*, void*, void*, void*, const void*, int64_t, void*, void*, void*);
+struct LmStepHandle {
+  int64_t fn = 0, p_ptr = 0, x_ptr = 0, save = 0, partials = 0, st0 = 0, st1 = 0, sync = 0, cfg_addr = 0, n = 0;
+  int device = 0;
+  int launch(int cur, int64_t loss_ptr, int64_t last_ptr) const {
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(c10::Device(c10::kCUDA, (c10::DeviceIndex)device));
+    void* stream = (void*)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA((c10::DeviceIndex)device).stream();
+    const int64_t st_in = cur ? st1 : st0, st_out = cur ? st0 : st1;
+    return reinterpret_cast<lmstep_t>(fn)((void*)p_ptr, (const void*)x_ptr, (void*)save, (void*)partials, (void*)st_in, (void*)st_out,
+                                          (void*)sync, (const void*)cfg_addr, n, (void*)loss_ptr, (void*)last_ptr, stream);
+  }
+};
+
 // ---- IMU pre-integration (module/imu_preintegrator.py): pplie_imu_integrate / pplie_imu_integrate_bwd as ONE native node ----------
 // Training through the pre-integrator is two kernels (64 + 108 us at 4096 x 1024); as a Python Function the pair cost ~190 us of
 // host time per step (the backward runs on the engine's device thread behind the GIL) -- more than the kernels.  Same contract as
@@ -335,6 +354,16 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
            }))
       .def("__call__", &RowHandle::call, py::arg("a"), py::arg("b") = py::none(),
            "launch (bare kernel, or native autograd node when a gradient is being recorded); None if the operands are not the plain eager case");
+  py::class_<LmStepHandle>(m, "LmStepHandle")
+      .def(py::init([](int64_t fn, int64_t p_ptr, int64_t x_ptr, int64_t save, int64_t partials, int64_t st0, int64_t st1, int64_t sync,
+                       int64_t cfg_addr, int64_t n, int device) {
+             LmStepHandle h;
+             h.fn = fn; h.p_ptr = p_ptr; h.x_ptr = x_ptr; h.save = save; h.partials = partials; h.st0 = st0; h.st1 = st1; h.sync = sync;
+             h.cfg_addr = cfg_addr; h.n = n; h.device = device;
+             return h;
+           }))
+      .def("launch", &LmStepHandle::launch, py::arg("cur"), py::arg("loss_ptr"), py::arg("last_ptr"),
+           "enqueue one device-resident LM step on the device's current stream; returns the C ABI's status");
   m.def("set_rule", &set_rule, "register the differentiable Python rule of an operator's backward (double backward)");
   m.def("scan_op", &scan_op, "pplie_scan_<group> in place, recorded as a native autograd node (backward: pplie_scan_<group>_bwd)");
   m.def("imu_integrate", &imu_integrate, "pplie_imu_integrate recorded as a native autograd node (backward: pplie_imu_integrate_bwd)");

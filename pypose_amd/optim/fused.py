@@ -57,10 +57,13 @@ class OpTracer:
 class _DryState:
     """What a dry trace keeps from one step to the next (per optimizer): the `meta` outputs by trace position (the same
     program produces the same shapes every step: no allocation), and the signature + match of the latest trace."""
-    __slots__ = ("pool", "wrapped", "sig", "match", "base", "touched")
+    __slots__ = ("pool", "wrapped", "sig", "match", "base", "touched", "toks")
 
     def __init__(self):
         self.pool, self.wrapped, self.sig, self.match, self.touched = {}, {}, None, None, False
+        # signature tokens of the pooled outputs by id() (the pool keeps them alive, so an id cannot be re-used while it is here):
+        # a token is four attribute reads and two tuples, ~1.3 us, and a step asks for the same ones every time
+        self.toks = {}
         # every dry output is a view into ONE storage-less `meta` buffer at its own offset: the offset identifies the
         # value across as_subclass / view re-wrappings (a storage_offset() read is ~0.1 us; a storage handle ~1 us)
         self.base = torch.empty((1 << 60,), dtype=torch.uint8, device="meta")
@@ -72,9 +75,14 @@ def _meta_id(t):
     return -1 - t.storage_offset() * t.element_size()
 
 
-def _tok(t):
+def _tok(t, toks=None):
     """what a trace signature records of an operand: a dry value's identity AND view (shape / stride / dtype: a model that
-    returns r[..., :3] of the same value one step and r the next must not look unchanged), or a real tensor's memory + layout"""
+    returns r[..., :3] of the same value one step and r the next must not look unchanged), or a real tensor's memory + layout.
+    ``toks``: the tracer state's cache of its pooled outputs' tokens (by object identity)"""
+    if toks is not None:
+        hit = toks.get(id(t))
+        if hit is not None:
+            return hit
     if t.device.type == "meta":
         return (_meta_id(t), t.shape, t.stride(), t.dtype)
     return (t.data_ptr(), t.shape, t.dtype, t.requires_grad, t.stride(), t.device.index)
@@ -109,6 +117,8 @@ class DryTracer(OpTracer):
         hit = self.state.pool.get(pos)
         if hit is not None and hit[0] == shape and hit[1] is dtype:
             return hit[2]
+        if hit is not None:
+            self.state.toks.pop(id(hit[2]), None)
         n = 1
         for v in shape:
             n *= v
@@ -116,6 +126,7 @@ class DryTracer(OpTracer):
         off = (pos + 1) << 44                                        # byte offset: one 16 TB window per trace position
         t = self.state.base[off:off + max(n, 1) * esz].view(dtype)[:n].view(shape)
         self.state.pool[pos] = (shape, dtype, t)
+        self.state.toks[id(t)] = _tok(t)
         return t
 
     def dry_launch(self, name, ins, in_widths, out_widths, lead):
@@ -128,7 +139,8 @@ class DryTracer(OpTracer):
         lead = tuple(lead)
         outs = tuple(self._out(lead + (w,), x0.dtype) for w in out_widths)
         self.events.append((name, tuple(ins), outs))
-        self.sig.append((name,) + tuple(_tok(t) for t in ins) + tuple(_tok(o) for o in outs))
+        toks = self.state.toks
+        self.sig.append((name,) + tuple(_tok(t, toks) for t in ins) + tuple(_tok(o, toks) for o in outs))
         return outs
 
     def dry_lie(self, fn, xs, out_ltype):
@@ -152,7 +164,8 @@ class DryTracer(OpTracer):
         out = self._out(tuple(lead) + (out_width,), x0.dtype)
         ins = tuple(ins)
         self.events.append((name, ins, (out,)))
-        self.sig.append((name,) + tuple(_tok(t) for t in ins) + (_tok(out),))
+        toks = self.state.toks
+        self.sig.append((name,) + tuple(_tok(t, toks) for t in ins) + (_tok(out, toks),))
         wrapped = self.state.wrapped.get(pos)
         if wrapped is None or wrapped._pl is not out or wrapped.ltype is not out_ltype:
             wrapped = _lt._wrap(out, out_ltype)
@@ -172,7 +185,7 @@ class DryTracer(OpTracer):
         if src is None or src.dim() != 2:
             return None
         out = self._out(tuple(index.shape) + (src.shape[-1],), src.dtype)
-        self.sig.append(("gather", id(source), _tok(index), _tok(out)))
+        self.sig.append(("gather", id(source), _tok(index), _tok(out, self.state.toks)))
         return out
 
 
@@ -426,6 +439,18 @@ class DeviceLM:
         self.ptrs = (self.save.data_ptr(), self.partials.data_ptr(), (sp, sp + 8 * _LM_STATE), self.sync.data_ptr())
         self.item = pt.element_size()
         self.k = _LOSS_BLOCK
+        # the launch behind ONE native call (csrc_torch/pplie_autograd.cpp LmStepHandle: stream lookup, device guard and the C entry
+        # with every fixed pointer bound); None: the ctypes route of _launch
+        self.native = None
+        nat = _op._native()
+        if nat is not None and hasattr(nat, "LmStepHandle") and type(self) is DeviceLM and _C._test_backend is None:
+            try:
+                self.native = nat.LmStepHandle(_C.library().address("pplie_lm_se3inv_step" + sfx), self.p_ptr, self.x_ptr,
+                                               self.save.data_ptr(), self.partials.data_ptr(), sp, sp + 8 * _LM_STATE,
+                                               self.sync.data_ptr(), ctypes.addressof(self.cfg), self.n,
+                                               self.device.index if self.device.index is not None else torch.cuda.current_device())
+            except Exception:
+                self.native = None
         self.pending = False          # device state newer than the host mirrors
         self.host_dirty = True        # host param group newer than the device state
         self.last_loss = None         # the loss tensor handed out by the previous step
@@ -519,17 +544,23 @@ class DeviceLM:
             pg = self._wrap_group()
         self._fill_cfg(pg)
         k, loss_ptr, last_ptr = self._slot()
-        save, partials, state, sync = self.ptrs
-        st_in, st_out = state[self.cur], state[1 - self.cur]
-        stream = _C.stream_ptr(self.device)
-        if opt.group is None:
-            with _C._on_device(self.device):
-                code = self._launch(save, partials, st_in, st_out, sync, loss_ptr, last_ptr, stream)
+        if self.native is not None and opt.group is None:
+            code = self.native.launch(self.cur, loss_ptr, last_ptr)
             if code:
-                _C.check(code, "pplie_lm_*_step")
+                _C.check(code, "pplie_lm_se3inv_step")
             self.cur = 1 - self.cur
         else:
-            self._sharded(st_in, st_out, loss_ptr, last_ptr, stream)
+            save, partials, state, sync = self.ptrs
+            st_in, st_out = state[self.cur], state[1 - self.cur]
+            stream = _C.stream_ptr(self.device)
+            if opt.group is None:
+                with _C._on_device(self.device):
+                    code = self._launch(save, partials, st_in, st_out, sync, loss_ptr, last_ptr, stream)
+                if code:
+                    _C.check(code, "pplie_lm_*_step")
+                self.cur = 1 - self.cur
+            else:
+                self._sharded(st_in, st_out, loss_ptr, last_ptr, stream)
         _C.mark_written(self.P)                              # P was rewritten through its raw pointer
         self.host_dirty, self.pending = False, True
         opt.loss = self.last_loss = self.loss_views[k]
@@ -1069,11 +1100,13 @@ def dry_program(opt, params, input, target):
         with torch.no_grad(), DryTracer(st) as tr, _pg.GatherRecorder(params) as rec:
             R = _outputs(opt, input)
         st.touched = tr.touched
-        plain = [r if type(r) is torch.Tensor else torch.Tensor.as_subclass(r, torch.Tensor) for r in R]
+        # (a wrapped dry result carries its pooled plain alias: no re-wrapping, and its signature token is cached)
+        plain = [r if type(r) is torch.Tensor else (r.__dict__.get("_pl") if r.__dict__.get("_pl") is not None
+                                                    else torch.Tensor.as_subclass(r, torch.Tensor)) for r in R]
         if any(r.device.type != "meta" for r in plain):
             return None
         tt = None if target is None else (_tok(torch.Tensor.as_subclass(target, torch.Tensor)) if isinstance(target, torch.Tensor) else id(target))
-        sig = (tuple(tr.sig), tuple(_tok(r) for r in plain), id(params[0]), tt)
+        sig = (tuple(tr.sig), tuple(_tok(r, st.toks) for r in plain), id(params[0]), tt)
         if st.sig == sig:
             return st.match
         m = _match(tr, rec, plain, params, target)
