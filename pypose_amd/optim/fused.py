@@ -410,6 +410,8 @@ class DeviceLM:
     per trial over all problems; the damping compounds over rejected retries; a rejected trial restarts from the
     linearisation point (the reference returns there by ``Exp(-d)``, i.e. up to rounding)."""
 
+    native = None        # (the prepared native launch of the se3inv program; subclasses with their own launch keep the ctypes route)
+
     def __init__(self, opt, P, X_src, input):
         self.opt, self.P, self.X_src = opt, P, X_src
         self.kind = _strategy_kind(opt.strategy)

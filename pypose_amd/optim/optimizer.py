@@ -283,7 +283,13 @@ def _linearize(opt, pg, input, target, weight, gauss_newton=False):
     # on a 10k-pose graph, 8 % of the run if paid every 64 steps) and the least exposed -- a recognised program is re-derived
     # from a (dry) run of the model every step anyway -- so it expires every _REVERIFY linearisations instead.
     uses = cache['_uses'] = cache.get('_uses', 0) + 1
-    if uses % _REPROBE == 0:
+    if getattr(opt, 'structure', None) == "strict":
+        # LM(structure="strict") / PPLIE_STRUCTURE=strict: NO positive verdict outlives the linearisation it was established for --
+        # every step probes the model's row dependence again (and re-verifies a fused program against the autograd linearisation):
+        # for models whose sparsity pattern depends on parameter VALUES at fixed shapes, at the price of the probe per step
+        for k in [k for k, v in cache.items() if v is True]:
+            cache[k] = None
+    elif uses % _REPROBE == 0:
         for k in [k for k, v in cache.items() if v is True and (k != "fused" or uses % _REVERIFY == 0)]:
             cache[k] = None
     # Under torch.inference_mode nothing can be recorded for backward sweeps: only the reference's own
@@ -382,9 +388,17 @@ class LevenbergMarquardt(_Optimizer):
 
     def __init__(self, model, solver=None, strategy=None, kernel=None, corrector=None,
                  weight=None, reject=16, min=1e-6, max=1e32, vectorize=True, sparse=False, *, group=None, static=False, shard=None,
-                 exchange=None):
+                 exchange=None, structure=None):
         assert min > 0, ValueError("min value has to be positive: {}".format(min))
         assert max > 0, ValueError("max value has to be positive: {}".format(max))
+        # structure="strict" (or PPLIE_STRUCTURE=strict): the block / graph structure of the model's Jacobian is probed at EVERY
+        # linearisation instead of being remembered per shape signature and re-probed every 64 (a model whose row dependence changes
+        # with its parameter values at fixed shapes would otherwise run up to 63 steps on a stale verdict); the device-resident /
+        # captured shortcuts of recognised programs are not taken.  None (default): cached verdicts.
+        import os as _os
+        structure = _os.environ.get("PPLIE_STRUCTURE") or None if structure is None else structure
+        assert structure in (None, "strict"), ValueError("structure has to be 'strict' or None: {}".format(structure))
+        self.structure = structure
         self.strategy = TrustRegion() if strategy is None else strategy
         defaults = {**{'min': min, 'max': max}, **self.strategy.defaults}
         super().__init__(model.parameters(), defaults=defaults)
@@ -511,6 +525,8 @@ class LevenbergMarquardt(_Optimizer):
     def step(self, input, target=None, weight=None):
         d = self.__dict__
         dev, gs = d.get('_device_lm'), d.get('_pgo_graph_step')
+        if d.get('structure') == "strict":
+            dev = gs = None                      # (every step goes through _linearize and its fresh probe)
         if (dev is not None or gs is not None) and not (self._optimizer_step_pre_hooks or self._optimizer_step_post_hooks
                                                         or _torch_opt._global_optimizer_pre_hooks or _torch_opt._global_optimizer_post_hooks):
             # A verified fused program with its loop state on the device: the whole step is one or two launches.  Nothing
