@@ -1141,8 +1141,10 @@ __device__ __forceinline__ void imu_cov_step(T* P, T h, const T* gy, const T* av
   P[22] += h;
 }
 
+// (fp64 gets the whole register file: under the three-workgroup budget of 168 VGPRs the LS = 2 build spilled 548 registers, 1.2 KB of
+//  scratch per lane -- the reference's tests run the module in fp64)
 template <class T, int WAVES, int LS, bool ISO>
-__global__ void __launch_bounds__(WAVES * 64, 3)
+__global__ void __launch_bounds__(WAVES * 64, sizeof(T) == 8 ? 1 : 3)
 imu_cov_seg_kernel(const T* __restrict__ dt, const T* __restrict__ gyro, const T* __restrict__ accel, const T* __restrict__ rout,
                    const T* __restrict__ rw, const T* __restrict__ C, const T* __restrict__ init_cov, const T* __restrict__ gyro_cov,
                    int64_t gc_sb, int64_t gc_sf, const T* __restrict__ acc_cov, int64_t ac_sb, int64_t ac_sf, T g0, T g1, T g2,
