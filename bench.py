@@ -468,7 +468,7 @@ def pgo_lm_rate(dev, nodes=10_000, edges=40_000, steps=3, reps=5, with_static=Tr
                 "us_per_lm_step": dt * 1e6, "mean_pcg_iterations": its_mean,
                 "us_per_pcg_iteration_incl_step_overheads": dt * 1e6 / max(its_mean, 1.0),
                 "exchange_floor_us": [0.40, 0.57], "floor_source": "profiles/r03/pingpong.log (one tagged-word hand-off between two workgroups)",
-                "marginal_us_per_iteration": 8.0, "marginal_source": "profiles/r05/pcg_iter_gauge_pairs.json (tools/time_pcg_iter.py): the two-level "
+                "marginal_us_per_iteration": 7.4, "marginal_source": "profiles/r06/pcg_iter.json (tools/time_pcg_iter.py; 8.0 in round 5): the two-level "
                 "(block-Jacobi + gauge) iteration with its 17-quantity exchange; 5.6 for the plain block-Jacobi iteration, which needs "
                 "17 / 35 / 105 iterations on this instance where this one needs 17 / 19 / 25",
                 "hbm": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBPS,
@@ -493,7 +493,8 @@ def pgo_lm_rate(dev, nodes=10_000, edges=40_000, steps=3, reps=5, with_static=Tr
                 "captured_trial": bool(getattr(_F, "capture_large", False)),
                 "note": "the iteration is bound by the rate the memory system serves its gathers' REQUESTS (profiles/r04 and r05 "
                         "EXPERIMENTS.md: waves 66 % parked on s_waitcnt, insensitive to occupancy, to trips per wave and -- within 2 us -- "
-                        "to whether the gathered rows hit the L2), counted fetch 1.4x algorithmic"}
+                        "to whether the gathered rows hit the L2); counted traffic 1.71x algorithmic (173.3 MB per iteration, "
+                        "profiles/pmc_traffic.json)"}
         det = traffic.get("detail", {})
         sp, stp = det.get("pcg2_spmv") or {}, det.get("pcg2_step") or {}
         if sp.get("fetch_r05") and stp.get("fetch_r05"):

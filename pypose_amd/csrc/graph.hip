@@ -1000,6 +1000,10 @@ lap_diag_prepare_kernel(const int* __restrict__ ptr, const T* __restrict__ HB, c
                         const double* __restrict__ s_dev, T* cs, T* __restrict__ Dp, T* __restrict__ Bp) {
   constexpr int NPW = 64 / M, NPB = NPW * 4, NP = M * (M + 1) / 2, LD = (M * M + M) | 1;
   __shared__ T stage[NPB * LD];
+  // phase 2's results leave through LDS as well: one lane per node writing 144-byte rows made every store instruction touch 40
+  // cache lines (51 us at 1e5 nodes, the same pattern as pplie_pcg_prepare's 23 us); staged, the workgroup's 40 nodes are ONE
+  // contiguous run of each output array
+  __shared__ T o_D[NPB * M * M], o_B[NPB * M * M], o_Dp[NPB * NP], o_Bp[NPB * NP], o_v[5][NPB * M];
   __shared__ T s_sh;
   if (s_dev && threadIdx.x == 0) s_sh = (T)__hip_atomic_load(s_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -1014,7 +1018,20 @@ lap_diag_prepare_kernel(const int* __restrict__ ptr, const T* __restrict__ HB, c
     T* st = stage + local * LD;
     if constexpr (PACK) {
       const int tii = i * M - (i * (i - 1)) / 2;
-      for (int c = beg; c < end; ++c) {
+      // two incidences per trip (the loads of both are in flight together; same order of additions)
+      int c = beg;
+      for (; c + 1 < end; c += 2) {
+        const T* h = HB + (int64_t)c * NP + tii;
+        T l0[M], l1[M];
+#pragma unroll
+        for (int k = 0; k < M; ++k) { l0[k] = h[k]; l1[k] = h[NP + k]; }
+        const T g0 = gg[(int64_t)c * M + i], g1 = gg[(int64_t)(c + 1) * M + i];
+#pragma unroll
+        for (int k = 0; k < M; ++k) { row[k] -= (k < M - i) ? l0[k] : T(0); row[k] -= (k < M - i) ? l1[k] : T(0); }
+        gi += g0;
+        gi += g1;
+      }
+      if (c < end) {
         const T* h = HB + (int64_t)c * NP + tii;
         T l[M];
 #pragma unroll
@@ -1032,7 +1049,19 @@ lap_diag_prepare_kernel(const int* __restrict__ ptr, const T* __restrict__ HB, c
           st[(i + k) * M + i] = row[k];
         }
     } else {
-      for (int c = beg; c < end; ++c) {
+      int c = beg;
+      for (; c + 1 < end; c += 2) {
+        const T* h = HB + ((int64_t)c * M + i) * M;
+        T l0[M], l1[M];
+#pragma unroll
+        for (int b = 0; b < M; ++b) { l0[b] = h[b]; l1[b] = h[M * M + b]; }
+        const T g0 = gg[(int64_t)c * M + i], g1 = gg[(int64_t)(c + 1) * M + i];
+#pragma unroll
+        for (int b = 0; b < M; ++b) { row[b] -= l0[b]; row[b] -= l1[b]; }
+        gi += g0;
+        gi += g1;
+      }
+      if (c < end) {
         const T* h = HB + ((int64_t)c * M + i) * M;
 #pragma unroll
         for (int b = 0; b < M; ++b) row[b] -= h[b];
@@ -1058,7 +1087,21 @@ lap_diag_prepare_kernel(const int* __restrict__ ptr, const T* __restrict__ HB, c
     for (int q = 0; q < M * M; ++q) A[q] = st[q];
 #pragma unroll
     for (int q = 0; q < M; ++q) gv[q] = st[M * M + q];
-    prepare_node<T, M>(A, gv, n2, s, dmin, dmax, D, Binv, shift, x, r, z, p, Dp, Bp, a_rho, a_bn, a_cs);
+    // (node index = the position in this workgroup: every output lands in its LDS stage)
+    prepare_node<T, M>(A, gv, (int64_t)threadIdx.x, s, dmin, dmax, o_D, o_B, o_v[0], o_v[1], o_v[2], o_v[3], o_v[4], Dp ? o_Dp : nullptr,
+                       Dp ? o_Bp : nullptr, a_rho, a_bn, a_cs);
+  }
+  __syncthreads();
+  {
+    const int64_t nb0 = (int64_t)blockIdx.x * NPB;
+    const int nn = (int)((N - nb0) < NPB ? (N - nb0) : NPB);           // nodes of this workgroup
+    for (int e = threadIdx.x; e < nn * M * M; e += 256) { D[nb0 * M * M + e] = o_D[e]; Binv[nb0 * M * M + e] = o_B[e]; }
+    if (Dp)
+      for (int e = threadIdx.x; e < nn * NP; e += 256) { Dp[nb0 * NP + e] = o_Dp[e]; Bp[nb0 * NP + e] = o_Bp[e]; }
+    for (int e = threadIdx.x; e < nn * M; e += 256) {
+      shift[nb0 * M + e] = o_v[0][e]; x[nb0 * M + e] = o_v[1][e]; r[nb0 * M + e] = o_v[2][e]; z[nb0 * M + e] = o_v[3][e];
+      p[nb0 * M + e] = o_v[4][e];
+    }
   }
   T s1 = block_sum(a_rho);
   T s2 = block_sum(a_bn);

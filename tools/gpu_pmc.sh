@@ -22,7 +22,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
         names = {"copy16": "copy16", "se3_exp_fwd": "se3_exp_fwd", "se3_log_fwd": "se3_log_fwd", "lm_se3inv_trial2": "lm_se3inv_trial2", "lm_se3inv_finish": "lm_se3inv_finish", "lm_se3inv_trial_kernel": "lm_se3inv_trial", "pcg_persist": "pcg_persist", "pcg_ghost": "pcg_ghost", "lm_lpr_trial": "lm_lpr_trial", "block_gram_mfma": "block_gram_mfma", "imu_cov_seg": "imu_cov_seg",
                  "pgo_linearize": "pgo_linearize", "graph_assemble_csr": "graph_assemble_csr", "graph_bsr_spmv": "graph_bsr_spmv",
                  "pcg_update": "pcg_update", "imu_integrate_multi": "imu_integrate_multi", "imu_integrate_kernel": "imu_integrate", "imu_cov_scan": "imu_cov_scan",
-                 "scan_bwd_left_kernel<float, pplie::MulSO3": "scan_bwd_left_so3", "scan_bwd_right_kernel<float, pplie::MulSO3": "scan_bwd_right_so3", "scan_bwd_left_kernel<float, pplie::MulSE3": "scan_bwd_left_se3", "scan_bwd_right_kernel<float, pplie::MulSE3": "scan_bwd_right_se3", "imu_integrate_bwd": "imu_integrate_bwd", "robust_scale_rows": "robust_scale_rows", "MulSO3": "scan_so3", "MulSE3": "scan_se3", "se3_bspline": "se3_bspline", "chspline": "chspline", "pcg2_spmv": "pcg2_spmv", "pcg2_step": "pcg2_step", "se3_reproj_lin": "se3_reproj_lin", "lap_blocks": "lap_blocks", "lap_diag": "lap_diag"}
+                 "scan_bwd_left_kernel<float, pplie::MulSO3": "scan_bwd_left_so3", "scan_bwd_right_kernel<float, pplie::MulSO3": "scan_bwd_right_so3", "scan_bwd_left_kernel<float, pplie::MulSE3": "scan_bwd_left_se3", "scan_bwd_right_kernel<float, pplie::MulSE3": "scan_bwd_right_se3", "imu_integrate_bwd": "imu_integrate_bwd", "robust_scale_rows": "robust_scale_rows", "MulSO3": "scan_so3", "MulSE3": "scan_se3", "se3_bspline": "se3_bspline", "chspline": "chspline", "pcg2_spmv": "pcg2_spmv", "pcg2_step": "pcg2_step", "se3_reproj_lin": "se3_reproj_lin", "lap_blocks": "lap_blocks", "lap_diag_prepare": "lap_diag_prepare", "lap_diag": "lap_diag", "pgo_tail_first": "pgo_tail_first", "pgo_residual": "pgo_residual"}
         for k, v in acc.items():
             short = next((s for n, s in names.items() if n in k), None)
             if short:
