@@ -915,7 +915,7 @@ def pgo_sharded_lm_rate(dev, rank, world, nodes=100_000, edges=400_000, steps=3,
     """BASELINE configs[3]: pose-graph LM, 100k SE3 nodes / 400k relative-pose edges, sharded over the ranks --
     `LM(group=...)`, SURVEY.md section 8(e).  Same generator, solver and strategy as `pgo_lm_rate`.  Collective: every rank
     calls this; rank 0's figures are reported.  Not part of `value`.  shard / exchange None = the library's own choice
-    (optim/posegraph.py resolve_shard_mode: node rows sharded with in-kernel peer stores for a graph of this size on GPUs)."""
+    (optim/posegraph.py resolve_shard_mode: node rows sharded over RCCL collectives for a graph of this size on GPUs; exchange="p2p": in-kernel peer stores)."""
     import torch
     import torch.distributed as dist
     import pypose_amd as pp
@@ -1369,10 +1369,10 @@ def main():
                 res = {"error": repr(e)}
             if rank == 0:
                 out[key] = res
-        # The library's DEFAULT for a graph of this size on several GPUs -- node rows sharded, p and the partial sums stored
-        # straight into the peers' tables from inside one persistent kernel per GPU (hipIpc-mapped memory over xGMI) -- has never
-        # run across two physical GPUs in the builder's hands (ranks as processes on one GPU only).  A GPU memory fault there
-        # would abort the job before the line is out, so the line goes out FIRST (with a note of what follows) and the leg's
+        # The OPT-IN exchange of the node-sharded solve -- p and the partial sums stored straight into the peers' tables from inside
+        # one persistent kernel per GPU (hipIpc-mapped memory over xGMI; LM(exchange="p2p"), the library's default until round 6) --
+        # has never run across two physical GPUs in the builder's hands (ranks as processes on one GPU only).  A GPU memory fault
+        # there would abort the job before the line is out, so the line goes out FIRST (with a note of what follows) and the leg's
         # result is written to stderr and to bench_p2p_leg.json beside this file afterwards.
         # One-GPU equivalents, so that an N = 1 / N = 8 ratio falls out of this ONE line: the weak-scaling legs (problems / sequences
         # per rank fixed) scale against value / ranks; configs[3] is ONE graph whatever N is (strong scaling): rank 0 runs the
@@ -1395,7 +1395,7 @@ def main():
                     out[key]["speedup_vs_one_gpu"] = out[key]["value"] / one["value"]
         post = os.environ.get("PPLIE_BENCH_P2P_LEG", "1") != "0"
         if rank == 0:
-            out["lm_pgo_sharded"] = {"deferred": "runs after this line: LM(group=) default (node shards + in-kernel peer stores); "
+            out["lm_pgo_sharded"] = {"deferred": "runs after this line: LM(group=, shard='nodes', exchange='p2p') (node shards + in-kernel peer stores, opt-in); "
                                                  "result on stderr as 'PPLIE_BENCH_POSTLINE {json}' and in bench_p2p_leg.json"} if post \
                 else {"skipped": "PPLIE_BENCH_P2P_LEG=0"}
         finished.set()
@@ -1409,7 +1409,8 @@ def main():
                 os._exit(0)
             threading.Thread(target=post_watchdog, daemon=True).start()
             try:
-                res = pgo_sharded_lm_rate(dev, rank, world, *((80, 200) if small else (100_000, 400_000)), reps=1 if small else 3)
+                res = pgo_sharded_lm_rate(dev, rank, world, *((80, 200) if small else (100_000, 400_000)), reps=1 if small else 3,
+                                          shard="nodes", exchange="p2p")
             except Exception as e:
                 res = {"error": repr(e)}
             if rank == 0:

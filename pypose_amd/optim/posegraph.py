@@ -1381,7 +1381,13 @@ def resolve_shard_mode(opt, group, n_nodes, pairwise):
     if shard is None:
         shard = "nodes" if (device_group and pairwise and dist.get_world_size(group) > 1 and n_nodes > PERSIST_NODES) else "edges"
     if exchange is None:
-        exchange = "p2p" if (shard == "nodes" and device_group) else "rccl"
+        # Node shards exchange over RCCL collectives by default (one all-gather + one all-reduce per PCG iteration): the route whose
+        # every collective is a stock RCCL call.  The in-kernel peer exchange ("p2p": hipIpc-mapped tables, system-scope stores over
+        # xGMI, no collective per iteration) is the faster design on paper but has only ever run with its ranks as processes on ONE
+        # GPU (no multi-GPU box was available to build it on): it is opt-in -- LM(exchange="p2p") or PPLIE_EXCHANGE=p2p -- until
+        # it has crossed a real link.  (Round 6; rounds 3-5 defaulted to it.)
+        env = _os.environ.get("PPLIE_EXCHANGE")
+        exchange = env if (env in ("rccl", "p2p") and shard == "nodes" and device_group) else "rccl"
     opt._shard_eff, opt._exchange_eff = shard, exchange
     return shard, exchange
 

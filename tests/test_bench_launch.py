@@ -52,11 +52,12 @@ def test_two_ranks_self_launched_dry_run():
     assert out["lm_pgo_replicated"]["losses"][-1] < out["lm_pgo_replicated"]["losses"][0]
     assert out["lm_pgo_node_sharded"]["mode"].startswith("node-sharded solve")
     assert out["lm_pgo_node_sharded"]["losses"] == pytest.approx(out["lm_pgo_replicated"]["losses"], rel=1e-4)
-    assert "deferred" in out["lm_pgo_sharded"]                     # the library-default leg runs after the line is out
+    assert "deferred" in out["lm_pgo_sharded"]                     # the opt-in peer-exchange leg runs after the line is out
     post = [l for l in out["_stderr"].splitlines() if l.startswith("PPLIE_BENCH_POSTLINE ")]
     assert len(post) == 1
     leg = json.loads(post[0].split(" ", 1)[1])["lm_pgo_sharded"]
-    assert "error" not in leg and leg["ranks_seen"] == 2 and leg["effective"]["shard"] == "edges"      # (gloo group: no node shards)
+    # (asked for explicitly: node shards; on a gloo group the peer exchange itself does not apply and the solve takes the collectives)
+    assert "error" not in leg and leg["ranks_seen"] == 2 and leg["effective"]["shard"] == "nodes"
 
 
 def test_eight_ranks_self_launched_dry_run():

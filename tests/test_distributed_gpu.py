@@ -157,13 +157,20 @@ def test_default_shard_mode_is_decided_from_group_uniform_facts(monkeypatch):
 
     class Opt:
         shard = exchange = None
-    for backend, world, n, want in (("nccl", 8, 100_000, ("nodes", "p2p")), ("nccl", 8, 10_000, ("edges", "rccl")),
+    monkeypatch.delenv("PPLIE_EXCHANGE", raising=False)
+    for backend, world, n, want in (("nccl", 8, 100_000, ("nodes", "rccl")), ("nccl", 8, 10_000, ("edges", "rccl")),
                                     ("nccl", 1, 100_000, ("edges", "rccl")), ("gloo", 8, 100_000, ("edges", "rccl"))):
         monkeypatch.setattr(dist, "get_backend", lambda g=None, b=backend: b)
         monkeypatch.setattr(dist, "get_world_size", lambda g=None, w=world: w)
         assert PG.resolve_shard_mode(Opt(), object(), n, True) == want, (backend, world, n)
     o = Opt(); o.shard, o.exchange = "nodes", "rccl"
     assert PG.resolve_shard_mode(o, object(), 50, True) == ("nodes", "rccl")
+    # the in-kernel peer exchange is opt-in: by argument or by environment (device groups only)
+    o = Opt(); o.shard, o.exchange = "nodes", "p2p"
+    assert PG.resolve_shard_mode(o, object(), 100_000, True) == ("nodes", "p2p")
+    monkeypatch.setenv("PPLIE_EXCHANGE", "p2p")
+    assert PG.resolve_shard_mode(Opt(), object(), 100_000, True) == ("nodes", "p2p")
+    monkeypatch.delenv("PPLIE_EXCHANGE")
     o = Opt(); o.shard = "nodes"
     monkeypatch.setattr(dist, "get_backend", lambda g=None: "gloo")
     assert PG.resolve_shard_mode(o, object(), 50, True) == ("nodes", "rccl")
