@@ -38,8 +38,10 @@ template <class T> __device__ __forceinline__ void pgo_residual(const T* z, cons
 // inc[e, 0], inc[e, 1] of HB (incidence = position of (edge, side) in the node-sorted CSR list; LAP = 1: full [6, 6] blocks,
 // LAP = 2: packed upper triangles [21]), -+Jm^T r to the same slots of gg.  Same products in the same order as lap_blocks_kernel
 // (zeros of Jm's lower-left block skipped).  Per edge: 24 B (R) + 288 B (J) + 2 x (84 | 144) B + 2 x 24 B written, nothing re-read.
-template <class T, int BLOCK, int LAP = 0>
-__global__ void __launch_bounds__(BLOCK)
+// THREADS: lanes of the workgroup (a multiple of BLOCK = the edges of a tile): lanes beyond BLOCK compute nothing and carry their share of
+// the copies between LDS and memory (the LAP builds run two waves: the tile's 4608 + 4608 words of J and HB leave in half the trips)
+template <class T, int BLOCK, int LAP = 0, int THREADS = BLOCK>
+__global__ void __launch_bounds__(THREADS)
 pgo_linearize_kernel(const T* __restrict__ nodes, const int64_t* __restrict__ idx, const T* __restrict__ Z,
                      T* __restrict__ R, T* __restrict__ J, int64_t E, RobustParam<T> rk, const int* __restrict__ inc = nullptr,
                      T* __restrict__ HB = nullptr, T* __restrict__ gg = nullptr, unsigned long long* __restrict__ ctl = nullptr,
@@ -54,7 +56,7 @@ pgo_linearize_kernel(const T* __restrict__ nodes, const int64_t* __restrict__ id
       const bool fetch = s_src && blockIdx.x == 0 && threadIdx.x == 0;
       double sv = 0.0;
       if (fetch) sv = __hip_atomic_load(s_src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      for (int64_t k = (int64_t)blockIdx.x * BLOCK + threadIdx.x; k < ctl_words; k += (int64_t)gridDim.x * BLOCK) ctl[k] = 0ull;
+      for (int64_t k = (int64_t)blockIdx.x * THREADS + threadIdx.x; k < ctl_words; k += (int64_t)gridDim.x * THREADS) ctl[k] = 0ull;
       if (fetch) *s_dst = sv;
     }
   }
@@ -64,7 +66,7 @@ pgo_linearize_kernel(const T* __restrict__ nodes, const int64_t* __restrict__ id
     const int64_t left = E - e0;
     const bool full = left >= BLOCK;
     const int rows = full ? BLOCK : (int)left;
-    slab_g2s<T, BLOCK, BLOCK * 7, true>(Z + e0 * 7, lds, rows * 7, full);
+    slab_g2s<T, THREADS, BLOCK * 7, true>(Z + e0 * 7, lds, rows * 7, full);
     __syncthreads();
     const int t = threadIdx.x;
     T r[6], Jm[36];
@@ -106,14 +108,14 @@ pgo_linearize_kernel(const T* __restrict__ nodes, const int64_t* __restrict__ id
     __syncthreads();                                              // every lane has read its Z row
     if (t < rows) row_st<6>(lds + t * 6, r);
     __syncthreads();
-    slab_s2g<T, BLOCK, BLOCK * 6, true>(lds, R + e0 * 6, rows * 6, full);
+    slab_s2g<T, THREADS, BLOCK * 6, true>(lds, R + e0 * 6, rows * 6, full);
     __syncthreads();
     if (t < rows) {
 #pragma unroll
       for (int k = 0; k < 36; ++k) { lds[t * 72 + k] = -Jm[k]; lds[t * 72 + 36 + k] = Jm[k]; }
     }
     __syncthreads();
-    slab_s2g<T, BLOCK, BLOCK * 72, true>(lds, J + e0 * 72, rows * 72, full);
+    slab_s2g<T, THREADS, BLOCK * 72, true>(lds, J + e0 * 72, rows * 72, full);
     __syncthreads();
     if constexpr (LAP != 0) {
       if (t < rows) {
@@ -138,10 +140,10 @@ pgo_linearize_kernel(const T* __restrict__ nodes, const int64_t* __restrict__ id
           st[21 + i] = a;
         }
       }
-      for (int q = t; q < rows * 2; q += BLOCK) inc_s[q] = inc[e0 * 2 + q];
+      for (int q = t; q < rows * 2; q += THREADS) inc_s[q] = inc[e0 * 2 + q];
       __syncthreads();
       constexpr int RW = LAP == 2 ? 21 : 36;
-      for (int q = t; q < rows * 2 * RW; q += BLOCK) {            // consecutive lanes write consecutive words of an incidence's row
+      for (int q = t; q < rows * 2 * RW; q += THREADS) {            // consecutive lanes write consecutive words of an incidence's row
         const int row = q / RW, k = q - row * RW;
         int src = k;
         if constexpr (LAP == 1) {
@@ -151,7 +153,7 @@ pgo_linearize_kernel(const T* __restrict__ nodes, const int64_t* __restrict__ id
         }
         HB[(int64_t)inc_s[row] * RW + k] = -lds[(row >> 1) * SW + src];
       }
-      for (int q = t; q < rows * 12; q += BLOCK) {
+      for (int q = t; q < rows * 12; q += THREADS) {
         const int row = q / 6, k = q - row * 6;
         const T v = lds[(row >> 1) * SW + 21 + k];
         gg[(int64_t)inc_s[row] * 6 + k] = (row & 1) ? v : -v;     // (side 0: J_c = -Jm)
@@ -396,11 +398,11 @@ int pgo_linearize(const void* nodes, const void* idx, const void* Z, void* R, vo
     hipLaunchKernelGGL((pgo_linearize_kernel<T, BLOCK>), dim3(grid), dim3(BLOCK), 0, st, (const T*)nodes, (const int64_t*)idx,
                        (const T*)Z, (T*)R, (T*)J, E, rk);
   else if (pack)
-    hipLaunchKernelGGL((pgo_linearize_kernel<T, BLOCK, 2>), dim3(grid), dim3(BLOCK), 0, st, (const T*)nodes, (const int64_t*)idx,
+    hipLaunchKernelGGL((pgo_linearize_kernel<T, BLOCK, 2, 2 * BLOCK>), dim3(grid), dim3(2 * BLOCK), 0, st, (const T*)nodes, (const int64_t*)idx,
                        (const T*)Z, (T*)R, (T*)J, E, rk, (const int*)inc, (T*)HB, (T*)gg, (unsigned long long*)ctl, ctl_bytes / 8,
                        (const double*)s_src, (double*)s_dst);
   else
-    hipLaunchKernelGGL((pgo_linearize_kernel<T, BLOCK, 1>), dim3(grid), dim3(BLOCK), 0, st, (const T*)nodes, (const int64_t*)idx,
+    hipLaunchKernelGGL((pgo_linearize_kernel<T, BLOCK, 1, 2 * BLOCK>), dim3(grid), dim3(2 * BLOCK), 0, st, (const T*)nodes, (const int64_t*)idx,
                        (const T*)Z, (T*)R, (T*)J, E, rk, (const int*)inc, (T*)HB, (T*)gg, (unsigned long long*)ctl, ctl_bytes / 8,
                        (const double*)s_src, (double*)s_dst);
   return hipGetLastError() == hipSuccess ? PPLIE_OK : PPLIE_ELAUNCH;
