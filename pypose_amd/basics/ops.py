@@ -1,8 +1,9 @@
 """``pm`` and the cumulative (scan) operators of the reference (pypose/basics/ops.py).
 
-``cumprod`` / ``cumprod_`` on SO3 / SE3 / Sim3 / RxSO3 LieTensors and on stacks of small square
-matrices run as a single-pass HIP scan kernel (``pplie_scan_*``: one wavefront per sequence,
-wave-level inclusive scan with the group product, O(L) work); every other ``ops`` callable falls
+``cumprod`` / ``cumprod_`` on SO3 / SE3 / Sim3 / RxSO3 LieTensors run as a single-pass HIP scan kernel
+(``pplie_scan_*``: one wavefront per sequence, wave-level inclusive scan with the group product, O(L) work),
+``cumprod_`` of a plain stack of small square matrices ``[..., L, d, d]`` along L as one walk per sequence
+(``pplie_scan_mat``; no gradient recorded); every other ``ops`` callable falls
 back to the reference's generic Hillis-Steele formulation built from torch index ops (the user's
 ``ops`` is an arbitrary Python callable, so it cannot be fused).
 """
@@ -40,7 +41,7 @@ def cummul_(input, dim, left=True):
 
 def cumprod_(input, dim, left=True):
     from .scan import try_scan_
-    done = try_scan_(input, dim, left)
+    done = try_scan_(input, dim, left, matmul=True)      # (plain [..., L, d, d] stacks: pplie_scan_mat)
     if done is not None:
         return done
     return cumops_(input, dim, (lambda a, b: b @ a) if left else (lambda a, b: a @ b))

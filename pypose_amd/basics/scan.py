@@ -124,10 +124,39 @@ def _native_scan(input, key, dim, left):
     return nat.scan_op(input, fns[0], fns[1], outer * inner, L, inner, bool(left), rule, dim)
 
 
-def try_scan_(input, dim, left):
-    """Scan ``input`` (a group LieTensor) in place along ``dim`` on the GPU; None if not applicable."""
+_MAT_SIG = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+_MAT_DIMS = (2, 3, 4, 6, 7, 9)
+
+
+def _try_mat_scan_(input, dim, left):
+    """``cumprod_`` of a plain tensor of square matrices ``[..., L, d, d]`` along the axis right in front of the matrices (the
+    reference's one use: the [B, F + 1, 9, 9] propagation matrices of the IMU covariance, module/imu_preintegrator.py:462) as ONE
+    launch of ``pplie_scan_mat`` instead of ceil(log2 L) rounds of index_select / bmm / index_copy_; None if not that case (another
+    axis, another matrix size, a gradient being recorded: the reference formulation in torch is differentiable)."""
+    if type(input) is not torch.Tensor or _C._test_backend is not None or not input.is_cuda or input.dim() < 3:
+        return None
+    d = input.shape[-1]
+    if input.shape[-2] != d or d not in _MAT_DIMS or dim % input.dim() != input.dim() - 3:
+        return None
+    if input.dtype not in (torch.float32, torch.float64) or not input.is_contiguous() or (torch.is_grad_enabled() and input.requires_grad):
+        return None
+    L = input.shape[-3]
+    nseq = input.numel() // (L * d * d) if L else 0
+    fn = _C.library().symbol("pplie_scan_mat" + ("_f32" if input.dtype == torch.float32 else "_f64"), _MAT_SIG)
+    with _C._on_device(input.device):
+        code = fn(input.data_ptr(), nseq, L, d, 1 if left else 0, _C.stream_ptr(input.device))
+    _C.check(code, "pplie_scan_mat")
+    _C.mark_written(input)
+    return input
+
+
+def try_scan_(input, dim, left, matmul=False):
+    """Scan ``input`` (a group LieTensor; with ``matmul`` -- cumprod_, whose operator is ``@`` -- also a plain stack of small square
+    matrices) in place along ``dim`` on the GPU; None if not applicable."""
     ltype = getattr(input, "ltype", None)
     key = _KEY.get(type(ltype).__name__) if ltype is not None else None
+    if key is None and ltype is None:
+        return _try_mat_scan_(input, dim, left) if matmul else None
     if key is None or _C._test_backend is not None or not input.is_cuda:
         return None
     if input.dtype not in (torch.float32, torch.float64) or not input.is_contiguous():

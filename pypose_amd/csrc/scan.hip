@@ -172,6 +172,71 @@ template <class T, class G> int scan_launch(void* data, int64_t nseq, int64_t L,
 }
 
 // ---------------------------------------------------------------------------------------------
+// Product scan of small square matrices [nseq, L, D, D] along L, in place (pypose/basics/ops.py:48-56 cumprod_ on plain tensors:
+// ops = b @ a / a @ b; the reference's use is the [B, F + 1, 9, 9] propagation matrices of the IMU covariance,
+// module/imu_preintegrator.py:462 -- SURVEY 8(b) `scan_mat9`).  The reference runs ceil(log2 L) rounds of index_select / bmm /
+// index_copy_ over the whole tensor (10 rounds x 3 passes at L = 1024); here a workgroup walks one sequence once: thread (i, j) keeps
+// entry (i, j) of the running product, the product of the previous step sits in LDS (double-buffered), the next matrix is in
+// flight while the current one is multiplied.  2 D^2 x sizeof(T) bytes per element moved -- the algorithmic minimum; the walk's
+// latency (one barrier per step) is hidden by the other sequences' workgroups on the CU.
+// ---------------------------------------------------------------------------------------------
+template <class T, int D, bool LEFT>
+__global__ void __launch_bounds__(128)
+scan_mat_kernel(T* __restrict__ data, int64_t nseq, int64_t L) {
+  __shared__ T P[2][D * D], A[2][D * D];
+  const int t = threadIdx.x, i = t / D, j = t % D;
+  const bool act = t < D * D;
+  for (int64_t seq = blockIdx.x; seq < nseq; seq += gridDim.x) {
+    T* base = data + seq * L * (D * D);
+    T nxt = act ? base[t] : T(0);                        // element t of matrix 0
+    if (act) P[0][t] = nxt;                              // out_0 = x_0
+    if (act && L > 1) nxt = base[(D * D) + t];
+    __syncthreads();
+    for (int64_t k = 1; k < L; ++k) {
+      const int cur = (int)(k & 1), prev = cur ^ 1;
+      if (act) A[cur][t] = nxt;
+      if (act && k + 1 < L) nxt = base[(k + 1) * (D * D) + t];          // (in flight during this step's product)
+      __syncthreads();
+      if (act) {
+        T acc = T(0);
+        // LEFT: out_k = x_k @ out_{k-1};  else out_k = out_{k-1} @ x_k
+#pragma unroll
+        for (int m = 0; m < D; ++m) acc += LEFT ? A[cur][i * D + m] * P[prev][m * D + j] : P[prev][i * D + m] * A[cur][m * D + j];
+        P[cur][t] = acc;
+        base[k * (D * D) + t] = acc;
+      }
+      // (one barrier per step: P[cur] / A[cur] are read by the next step, which writes P[prev] / A[prev] -- last read before
+      //  this step's barrier)
+    }
+    __syncthreads();
+  }
+}
+template <class T> int scan_mat_launch(void* data, int64_t nseq, int64_t L, int d, int left, void* stream) {
+  if (nseq < 0 || L < 0 || d < 1) return SC_EBADARG;
+  if (nseq == 0 || L == 0) return SC_OK;
+  if (!data) return SC_EBADARG;
+  const int64_t cap = 256 * 8;                            // eight workgroups per CU cover one another's barriers
+  const unsigned grid = (unsigned)(nseq < cap ? nseq : cap);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+#define PPLIE_SCAN_MAT(DD)                                                                                              \
+  {                                                                                                                     \
+    if (left) hipLaunchKernelGGL((scan_mat_kernel<T, DD, true>), dim3(grid), dim3(128), 0, st, static_cast<T*>(data), nseq, L);  \
+    else hipLaunchKernelGGL((scan_mat_kernel<T, DD, false>), dim3(grid), dim3(128), 0, st, static_cast<T*>(data), nseq, L);      \
+  }
+  switch (d) {
+    case 2: PPLIE_SCAN_MAT(2) break;
+    case 3: PPLIE_SCAN_MAT(3) break;
+    case 4: PPLIE_SCAN_MAT(4) break;
+    case 6: PPLIE_SCAN_MAT(6) break;
+    case 7: PPLIE_SCAN_MAT(7) break;
+    case 9: PPLIE_SCAN_MAT(9) break;
+    default: return SC_EBADARG;
+  }
+#undef PPLIE_SCAN_MAT
+  return hipGetLastError() == hipSuccess ? SC_OK : SC_ELAUNCH;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Backward of the product scan (the cotangent of  y = cumprod(x)  in the reference's gradient convention: gradients of
 // group elements are left-tangent vectors zero-padded to the embedding width, operation.py:846-852).  The reference gets
 // it by differentiating the log2(L) Hillis-Steele rounds (basics/ops.py:27-36: index_select / Mul / index_copy_ per round
@@ -1417,6 +1482,19 @@ int imu_cov_launch(const void* dt, const void* rk, const void* rij, const void* 
 }
 }  // namespace pplie
 
+// matrices [nseq, L, d, d] (d in {2, 3, 4, 6, 7, 9}); pplie_scan_mat9 = the reference's one use
+extern "C" int pplie_scan_mat_f32(void* data, int64_t nseq, int64_t L, int d, int left, void* stream) {
+  return pplie::scan_mat_launch<float>(data, nseq, L, d, left, stream);
+}
+extern "C" int pplie_scan_mat_f64(void* data, int64_t nseq, int64_t L, int d, int left, void* stream) {
+  return pplie::scan_mat_launch<double>(data, nseq, L, d, left, stream);
+}
+extern "C" int pplie_scan_mat9_f32(void* data, int64_t nseq, int64_t L, int left, void* stream) {
+  return pplie::scan_mat_launch<float>(data, nseq, L, 9, left, stream);
+}
+extern "C" int pplie_scan_mat9_f64(void* data, int64_t nseq, int64_t L, int left, void* stream) {
+  return pplie::scan_mat_launch<double>(data, nseq, L, 9, left, stream);
+}
 #define PPLIE_SCAN_EXPORT(g, G)                                                                                     \
   extern "C" int pplie_scan_##g##_f32(void* data, int64_t nseq, int64_t L, int64_t inner, int left, void* stream) { \
     return pplie::scan_launch<float, pplie::G<float>>(data, nseq, L, inner, left, stream);                          \

@@ -166,6 +166,8 @@ def test_default_shard_mode_is_decided_from_group_uniform_facts(monkeypatch):
     o = Opt(); o.shard, o.exchange = "nodes", "rccl"
     assert PG.resolve_shard_mode(o, object(), 50, True) == ("nodes", "rccl")
     # the in-kernel peer exchange is opt-in: by argument or by environment (device groups only)
+    monkeypatch.setattr(dist, "get_backend", lambda g=None: "nccl")
+    monkeypatch.setattr(dist, "get_world_size", lambda g=None: 8)
     o = Opt(); o.shard, o.exchange = "nodes", "p2p"
     assert PG.resolve_shard_mode(o, object(), 100_000, True) == ("nodes", "p2p")
     monkeypatch.setenv("PPLIE_EXCHANGE", "p2p")
