@@ -312,7 +312,9 @@ __device__ __forceinline__ void put_pairs(const float* vals_lds, u64* tab, int r
 //  for each row's load before issuing the next -- three dependent round trips per poll round -- and is still the FASTEST form.
 //  Issuing a round's loads together and re-reading every row until all are complete made the step 16 us slower (0.281 against
 //  0.265 ms); issuing only the first round together, 3 - 5 us slower.  The polls of 160 workgroups x 9 waves share the memory side
-//  with the stores they are waiting for: fewer, staggered polls win over fewer round trips.)
+//  with the stores they are waiting for: fewer, staggered polls win over fewer round trips.  A delay in front of the first poll
+//  (s_sleep 8 / 16 / 32 / 64 x 64 clocks): 0 / 0 / +0.5 / +2.4 us per iteration -- the last row is there ~0.6 us after the gather
+//  starts; the batched first round behind such a delay: still 3 - 6 % slower than the serial loop.)
 template <int NQ, class SH, int SLOTS>
 __device__ __forceinline__ void gather_pairs(SH& sh, int par, const u64* part, unsigned t2, int first, int stride, int count, int rows_per_table) {
   constexpr int NP = (NQ + 1) / 2, RW = SLOTS, LD = 3;
