@@ -9,6 +9,9 @@ namespace pplie {
 
 constexpr int kStepPartials = 4096;     // = PPLIE_LM_TRIAL_PARTIALS
 enum { ST_DAMPING = 0, ST_RADIUS, ST_DOWN, ST_SCALE, ST_LAST, ST_LOSS, ST_REJECTS, ST_DONE, ST_FAILED, ST_TRIALS, ST_QUALITY,
+       // StopOnPlateau evaluated on the device (scheduler.py:130-160; cfg.plateau_max_steps > 0): steps taken, consecutive steps that
+       // lowered the loss by less than `decreasing`, and the verdict -- once it is 1 every later launch of the step returns at once
+       ST_PL_STEPS, ST_PL_COUNT, ST_PL_STOP,
        ST_SIZE = 16 };                  // = PPLIE_LM_STATE
 enum { LM_CONSTANT = 0, LM_ADAPTIVE = 1, LM_TRUSTREGION = 2 };
 enum { LMF_HOST_STATE = 1, LMF_NO_LOSS = 2, LMF_OCC4 = 4 /* tuning: the trial kernel built for 4 waves / SIMD */ };
@@ -18,6 +21,10 @@ struct LmCfg {     // = pplie_lm_cfg in include/pplie.h
   double dmin, dmax;                                  // clamp of the diagonal of J^T J (LM(min=, max=))
   double host_damping, host_down;                     // param-group values, used when flags & LMF_HOST_STATE
   int strategy, reject, flags, grid_cap;               // grid_cap: workgroups of the trial kernel (0: 4096)
+  int plateau_patience, plateau_max_steps;             // StopOnPlateau(steps=, patience=) on the device; max_steps = 0: off
+  double plateau_decreasing;                           // StopOnPlateau(decreasing=)
+  unsigned long long plateau_flag;                     // address of a HOST-PINNED double (or 0): the step that stops the run stores its
+                                                       // step count there with system scope -- the host stops enqueuing without a sync
 };
 
 // ---- decision (optimizer.py:673-678 + strategy.py:143-151, 260-274) ---------------------------------------------------
@@ -72,10 +79,22 @@ __device__ __forceinline__ void lm_decide(const double* in, double* o, const LmC
   o[ST_FAILED] = failed ? 1.0 : 0.0;
   o[ST_TRIALS] = first ? 1.0 : in[ST_TRIALS] + 1.0;
   o[ST_QUALITY] = quality;
+  // the scheduler's rules on the step that has just ENDED (accepted, out of retries, or abandoned): scheduler.py:136-160 reads
+  // optimizer.last / .loss / .reject_count right after optimizer.step()
+  double pl_steps = in[ST_PL_STEPS], pl_count = in[ST_PL_COUNT], pl_stop = in[ST_PL_STOP];
+  if (cfg.plateau_max_steps > 0 && (done != 0.0 || failed)) {
+    pl_steps += 1.0;
+    pl_count = (last - loss) < cfg.plateau_decreasing ? pl_count + 1.0 : 0.0;
+    if (pl_steps >= (double)cfg.plateau_max_steps || pl_count >= (double)cfg.plateau_patience || rejects > 0.0) pl_stop = 1.0;
+  }
+  o[ST_PL_STEPS] = pl_steps; o[ST_PL_COUNT] = pl_count; o[ST_PL_STOP] = pl_stop;
 }
-template <class T> __device__ __forceinline__ void lm_store_state(const double* o, double* st, T* loss_out, T* last_out) {
+template <class T> __device__ __forceinline__ void lm_store_state(const double* o, double* st, T* loss_out, T* last_out,
+                                                                  unsigned long long plateau_flag = 0ull) {
 #pragma unroll
-  for (int i = 0; i <= ST_QUALITY; ++i) __hip_atomic_store(st + i, o[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (int i = 0; i <= ST_PL_STOP; ++i) __hip_atomic_store(st + i, o[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (plateau_flag && o[ST_PL_STOP] != 0.0)
+    __hip_atomic_store(reinterpret_cast<double*>(plateau_flag), o[ST_PL_STEPS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   if (loss_out) *loss_out = (T)o[ST_LOSS];
   if (last_out) *last_out = (T)o[ST_LAST];
 }

@@ -250,7 +250,7 @@ lm_lpr_finish_kernel(T* P, T* save, LprArgs ar, T* partials, int first_rows, con
       if (threadIdx.x == 0) {
         double in[ST_SIZE], o[ST_SIZE];
 #pragma unroll
-        for (int i = 0; i <= ST_QUALITY; ++i) in[i] = ld_state(st_out, i);
+        for (int i = 0; i <= ST_PL_STOP; ++i) in[i] = ld_state(st_out, i);
         lm_decide(in, o, cfg, false, v[0], v[1], v[2], v[3]);
         lm_store_state<T>(o, st_out, loss_out, last_out);
         __threadfence();

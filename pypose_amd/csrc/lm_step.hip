@@ -332,6 +332,7 @@ __device__ __forceinline__ void lm_trial_tiles(const T* Plin, const T* X, T* Pou
 template <class T, int BLOCK, bool FIRST, int WAVES>
 __global__ void __launch_bounds__(BLOCK, WAVES)
 lm_se3inv_trial2_kernel(T* P, const T* __restrict__ X, T* save, T* partials, const double* st, LmCfg cfg, int64_t n) {
+  if (FIRST && cfg.plateau_max_steps > 0 && st[ST_PL_STOP] != 0.0) return;      // the device-side StopOnPlateau has stopped the run
   PPLIE_LM_LDS(T, BLOCK, lds);
   double sc;
   if (FIRST) sc = 1.0 + ((cfg.flags & LMF_HOST_STATE) ? cfg.host_damping : st[ST_DAMPING]);
@@ -371,13 +372,23 @@ lm_se3inv_finish_kernel(T* P, const T* __restrict__ X, T* save, T* partials, int
                         unsigned* bar, LmCfg cfg, int64_t n, T* loss_out, T* last_out) {
   PPLIE_LM_LDS(T, BLOCK, lds);
   __shared__ double verdict[2];
+  if (cfg.plateau_max_steps > 0 && st_in[ST_PL_STOP] != 0.0) {
+    // stopped: the trial kernel did nothing; the state (and the loss scalars of this step's slot) pass through unchanged
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      double o[ST_SIZE];
+#pragma unroll
+      for (int i = 0; i <= ST_PL_STOP; ++i) o[i] = st_in[i];
+      lm_store_state<T>(o, st_out, loss_out, last_out);
+    }
+    return;
+  }
   {
     double v[4];
     lm_reduce_partials<T, BLOCK, true>(partials, first_rows, v);
     if (threadIdx.x == 0) {
       double o[ST_SIZE];
       lm_decide(st_in, o, cfg, true, v[0], v[1], v[2], v[3]);
-      if (blockIdx.x == 0) lm_store_state<T>(o, st_out, loss_out, last_out);
+      if (blockIdx.x == 0) lm_store_state<T>(o, st_out, loss_out, last_out, cfg.plateau_flag);
       verdict[0] = o[ST_DONE];
       verdict[1] = o[ST_FAILED];
     }
@@ -401,9 +412,9 @@ lm_se3inv_finish_kernel(T* P, const T* __restrict__ X, T* save, T* partials, int
       if (threadIdx.x == 0) {
         double in[ST_SIZE], o[ST_SIZE];
 #pragma unroll
-        for (int i = 0; i <= ST_QUALITY; ++i) in[i] = ld_state(st_out, i);
+        for (int i = 0; i <= ST_PL_STOP; ++i) in[i] = ld_state(st_out, i);
         lm_decide(in, o, cfg, false, v[0], v[1], v[2], v[3]);
-        lm_store_state<T>(o, st_out, loss_out, last_out);
+        lm_store_state<T>(o, st_out, loss_out, last_out, cfg.plateau_flag);
         __threadfence();
       }
     }

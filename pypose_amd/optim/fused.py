@@ -309,13 +309,15 @@ def _strategy_kind(strategy):
 class _LmCfg(ctypes.Structure):       # = pplie_lm_cfg (include/pplie.h)
     _fields_ = [(k, ctypes.c_double) for k in ("high", "low", "up", "factor", "smin", "smax", "sdown", "dmin", "dmax",
                                                "host_damping", "host_down")] + \
-               [(k, ctypes.c_int) for k in ("strategy", "reject", "flags", "grid_cap")]
+               [(k, ctypes.c_int) for k in ("strategy", "reject", "flags", "grid_cap", "plateau_patience", "plateau_max_steps")] + \
+               [("plateau_decreasing", ctypes.c_double), ("plateau_flag", ctypes.c_uint64)]
 
 
 _STEP_SIG = [ctypes.c_void_p] * 7 + [ctypes.POINTER(_LmCfg), ctypes.c_int64] + [ctypes.c_void_p] * 3
 _SUMS_SIG = [ctypes.c_void_p] * 5 + [ctypes.POINTER(_LmCfg), ctypes.c_int, ctypes.c_int64] + [ctypes.c_void_p] * 2
 _DECIDE_SIG = [ctypes.c_void_p] * 2 + [ctypes.POINTER(_LmCfg), ctypes.c_int] + [ctypes.c_void_p] * 4
 _ST_DAMPING, _ST_RADIUS, _ST_DOWN, _ST_SCALE, _ST_LAST, _ST_LOSS, _ST_REJECTS, _ST_DONE, _ST_FAILED, _ST_TRIALS = range(10)
+_ST_PL_STEPS, _ST_PL_COUNT, _ST_PL_STOP = 11, 12, 13        # device-side StopOnPlateau (csrc/lm_common.h)
 _LM_STATE = 16            # PPLIE_LM_STATE
 _LOSS_BLOCK = 1024        # loss / last scalars handed out as views of one allocation per 1024 steps
 _LAZY_KEYS = frozenset(("damping", "radius", "down"))
@@ -600,12 +602,38 @@ class DeviceLM:
                 break
             first = 0
 
-    # ---- host mirrors --------------------------------------------------------------------------------------------
+    # ---- StopOnPlateau on the device (optim/scheduler.py optimize()) -----------------------------------------------
+    def set_plateau(self, decreasing, patience, max_steps, steps, count):
+        """arm the device-side stop rules: from the next step on the finish kernel counts steps / plateau steps and raises the stop flag
+        (lm_common.h lm_decide); steps enqueued behind the stop return at once.  ``steps`` / ``count``: the scheduler's counters so far."""
+        if type(self) is not DeviceLM or self.opt.group is not None:
+            return False
+        self.cfg.plateau_decreasing, self.cfg.plateau_patience, self.cfg.plateau_max_steps = float(decreasing), int(patience), int(max_steps)
+        self.state[self.cur, _ST_PL_STEPS:_ST_PL_STOP + 1].copy_(torch.tensor([float(steps), float(count), 0.0], dtype=torch.float64))
+        # the stopping step announces itself in host-pinned memory (a system-scope store by the finish kernel): the host looks at it
+        # before enqueuing each further step -- no synchronisation, and at most the steps already in flight run as no-ops
+        flag = self.__dict__.get('_plateau_flag')
+        if flag is None:
+            flag = self._plateau_flag = torch.zeros(1, dtype=torch.float64).pin_memory()
+            self._plateau_flag_np = flag.numpy()
+        self._plateau_flag_np[0] = 0.0
+        self.cfg.plateau_flag = flag.data_ptr()
+        self.plateau = None
+        return True
+
+    def plateau_stopped(self):
+        return self._plateau_flag_np[0] != 0.0
+
+    def clear_plateau(self):
+        self.cfg.plateau_max_steps = 0
+        self.cfg.plateau_flag = 0
+
     def flush(self):
         if not self.pending:
             return
         self.pending = False
         st = self.state[self.cur].tolist()                    # the one read-back
+        self.plateau = (int(st[_ST_PL_STEPS]), int(st[_ST_PL_COUNT]), bool(st[_ST_PL_STOP]))
         opt = self.opt
         pg = opt.param_groups[0]
         dict.__setitem__(pg, 'damping', st[_ST_DAMPING])

@@ -74,5 +74,58 @@ class StopOnPlateau(_Scheduler):
 
     @torch.no_grad()
     def optimize(self, input, target=None, weight=None):
+        """``while continual(): step`` (scheduler.py:162-203).  With ``verbose=False`` and an optimizer whose step is the
+        device-resident one (optim/fused.py DeviceLM: loop state, accept / reject and the loss stay on the GPU) the stop rules are
+        evaluated ON THE DEVICE as well: the remaining steps are enqueued without reading a loss back between them, the step that
+        raises the stop flag is the last one that does anything (later launches return at once), and the counters come back in one
+        read at the end -- the host loop costs a synchronisation per step, more than the step's two kernels."""
         while self.continual():
+            if not self.verbose and self._optimize_on_device(input, target, weight):
+                continue
             self.step(self.optimizer.step(input, target, weight))
+
+    def _optimize_on_device(self, input, target, weight):
+        """Run the rest of the steps with the stop rules on the device; False (nothing done) when that route does not apply now."""
+        opt = self.optimizer
+        dev = opt.__dict__.get('_device_lm')
+        if dev is None or not hasattr(dev, 'set_plateau') or getattr(opt, 'structure', None) == "strict" or self.max_steps - self.steps <= 0:
+            return False
+        if not dev.set_plateau(self.decreasing, self.patience, self.max_steps, self.steps, self.patience_count):
+            return False
+        done = 0
+        try:
+            for _ in range(self.max_steps - self.steps):
+                if dev.plateau_stopped():                # (pinned memory, no synchronisation: the GPU is at most a few steps behind)
+                    break
+                before = dev.cur
+                opt.step(input, target, weight)
+                if opt.__dict__.get('_device_lm') is not dev or dev.cur == before:
+                    # this step did not take the device route (the program changed, a hook appeared ...): it ran on the general path
+                    # with the host's own bookkeeping -- account for it like the plain loop and leave the rest to that loop
+                    dev.clear_plateau()
+                    steps, count, stopped = self._read_back(dev, done, with_stop=True)
+                    self.steps, self.patience_count = steps, count
+                    if stopped:                      # (the device had stopped the run before this step)
+                        self._quit("Maximum patience steps reached" if count >= self.patience else "Maximum rejected steps reached")
+                    else:
+                        self.step(opt.loss)
+                    return True
+                done += 1
+        finally:
+            dev.clear_plateau()
+        steps, count, stopped = self._read_back(dev, done, with_stop=True)
+        self.steps, self.patience_count = steps, count
+        if self.steps >= self.max_steps:
+            self._quit("Maximum steps reached")
+        elif stopped:
+            self._quit("Maximum patience steps reached" if self.patience_count >= self.patience else "Maximum rejected steps reached")
+        return True
+
+    def _read_back(self, dev, enqueued, with_stop=False):
+        """the device's counters after ``enqueued`` steps of this call (one synchronising read)"""
+        if enqueued == 0:
+            return (self.steps, self.patience_count, False) if with_stop else (self.steps, self.patience_count)
+        dev.pending = True
+        dev.flush()
+        steps, count, stopped = dev.plateau
+        return (steps, count, stopped) if with_stop else (steps, count)

@@ -36,7 +36,48 @@ with torch.no_grad():
             return fn(w.ptr.data_ptr(), slot.data_ptr(), w.HB.data_ptr(), w.D.data_ptr(), w.Binv.data_ptr(), w.shift.data_ptr(), w.x.data_ptr(),
                       w.r.data_ptr(), w.z.data_ptr(), gptr.data_ptr(), gids.data_ptr(), w.part.data_ptr(), w.ptag.data_ptr(), w.rr_hist.data_ptr(),
                       w.info.data_ptr(), w.it.data_ptr(), 1e-30, iters, w.cap, grid, max_cnt, max_ghost, w.N, w.m, st)
+        # alternating with another (tiny) kernel: does the persistent kernel pay for following a different kernel?
         for iters in (0, 8):
+            for other in ("fill", "none"):
+                n = 40
+                ts = []
+                for rep in range(5):
+                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    a.record()
+                    for _ in range(n):
+                        if other == "fill":
+                            w.info.zero_()
+                        assert launch(iters) == 0
+                    b.record(); torch.cuda.synchronize()
+                    ts.append(a.elapsed_time(b) * 1e3 / n)
+                out[f"grid{grid}_{iters}it_after_{other}_us_per_launch"] = round(sorted(ts)[2], 2)
+        ts = []
+        for rep in range(5):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(40):
+                w.info.zero_()
+            b.record(); torch.cuda.synchronize()
+            ts.append(a.elapsed_time(b) * 1e3 / 40)
+        out[f"grid{grid}_fill_alone_us"] = round(sorted(ts)[2], 2)
+        # the same alternation as ONE captured hipGraph (kernel nodes chained by the stream's order): what does a graph edge cost?
+        for iters in (0, 8):
+            n = 40
+            g = torch.cuda.CUDAGraph()
+            st_keep = st
+            with _C.graph_capture(g):
+                st = _C.stream_ptr(w.device)                       # (the capture's stream)
+                for _ in range(n):
+                    w.info.zero_()
+                    assert launch(iters) == 0
+            st = st_keep
+            ts = []
+            for rep in range(5):
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record(); g.replay(); b.record(); torch.cuda.synchronize()
+                ts.append(a.elapsed_time(b) * 1e3 / n)
+            out[f"grid{grid}_{iters}it_after_fill_GRAPH_us_per_launch"] = round(sorted(ts)[2], 2)
+        for iters in ():
             for mode in ("eager", "graph"):
                 n = 40
                 if mode == "graph":
