@@ -445,3 +445,22 @@ def test_prepared_handles_carry_the_plain_eager_case():
         names.append(fn.name())
         fn = fn.next_functions[0][0] if fn.next_functions else None
     assert any("RowOp" in n for n in names), names
+
+
+@pytest.mark.parametrize("name", ["sim3_exp_fwd", "sim3_log_fwd"])
+def test_sim3_small_sigma_and_theta_fp32_on_device(name):
+    """the regime the every-row gate found (sigma AND theta small: the reference's closed forms for rxso3_Ws cancel in fp32;
+    lie_math.h ws_coef sums the coefficients' series there), sampled densely, through the C ABI: every row within 1e-5 of the
+    reference's formulas in fp64 (host twin: tests/test_hostmath.py::test_sim3_small_sigma_and_theta_fp32)"""
+    rng = np.random.default_rng(11)
+    n = 200_003
+    d = rng.standard_normal((n, 3))
+    d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    theta = 10.0 ** rng.uniform(-5, -0.8, (n, 1))
+    sigma = 10.0 ** rng.uniform(-5, -0.8, (n, 1)) * rng.choice([-1.0, 1.0], (n, 1))
+    x = np.concatenate([rng.standard_normal((n, 3)), d * theta, sigma], -1).astype(np.float32)
+    ins = [x] if name == "sim3_exp_fwd" else [lie_np.sim3_exp_fwd(x.astype(np.float64))[0].astype(np.float32)]
+    ref = lie_np.OPS[name](*[a.astype(np.float64) for a in ins])[0]
+    out = run_hip(name, ins)[0]
+    e, ok = row_rel_err(out, ref)
+    assert ok.all() and e.max() < 1e-5, (name, e.max(), ins[0][int(np.argmax(e))])
