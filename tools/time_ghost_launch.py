@@ -1,6 +1,6 @@
 """What does ONE launch of the persistent ghost-zone solve cost beside the work its workgroups clock themselves?
-The kernel alone, back to back (no fill, no set-up launch), for 0 and 8 iterations; HIP events over 40 launches; the same launches
-as a captured hipGraph.  (The tag tables are not cleared between launches: every poll finds complete rows of an earlier launch at
+The kernel alone, back to back, for 0 and 8 iterations, alone and alternating with a tiny fill kernel, eagerly and as ONE captured
+hipGraph; HIP events over 40 launches.  (The tag tables are not cleared between launches: every poll finds complete rows of an earlier launch at
 once -- a LOWER bound of the exchange, which is what isolates the launch cost.)"""
 import ctypes, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -77,24 +77,5 @@ with torch.no_grad():
                 a.record(); g.replay(); b.record(); torch.cuda.synchronize()
                 ts.append(a.elapsed_time(b) * 1e3 / n)
             out[f"grid{grid}_{iters}it_after_fill_GRAPH_us_per_launch"] = round(sorted(ts)[2], 2)
-        for iters in ():
-            for mode in ("eager", "graph"):
-                n = 40
-                if mode == "graph":
-                    g = torch.cuda.CUDAGraph()
-                    with _C.graph_capture(g):
-                        for _ in range(n):
-                            assert launch(iters) == 0
-                    run = g.replay
-                else:
-                    def run():
-                        for _ in range(n):
-                            assert launch(iters) == 0
-                ts = []
-                for rep in range(5):
-                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    a.record(); run(); b.record(); torch.cuda.synchronize()
-                    ts.append(a.elapsed_time(b) * 1e3 / n)
-                out[f"grid{grid}_{iters}it_{mode}_us_per_launch"] = round(sorted(ts)[2], 2)
 for k, v in out.items():
     print(json.dumps({k: v}))
