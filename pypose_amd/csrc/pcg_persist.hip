@@ -728,13 +728,27 @@ constexpr int kGhostLayers = 3;
 //   rho = r.Binv r + sum_i (Z^T r)_i^2 / E_i ;   z = Binv r + Z (Z^T r / E) ;  the recurrence value of rho_{k+1} (for beta only,
 //   as before) uses Z^T r' = Z^T r - alpha Z^T q.  Any E > 0 gives an SPD preconditioner: the stop test |r| <= tol |b| is unchanged.
 
+// The LM trial's tail in the solve's epilogue (round 6; SE3 pose graphs, M = 6; nodes == nullptr: none).  What the tail's first launch
+// did -- pgo_tail_first_kernel, 9.6 us at 10 k nodes and a launch boundary -- needs nothing the workgroups do not hold when the loop ends:
+//   gain terms   a = sum_e |J_e d|^2 = d^T H d  and  b = sum_e (J_e d).r_e = d^T g  (strategy.py:144, :261).  With A = H + diag(shift),
+//                the solve's right-hand side r_0 = -g and its final residual r = r_0 - A d:   a = d.(r_0 - r) - sum shift d^2,
+//                b = -d.r_0 -- node-local products of what every lane has in registers (d, r) or reads back once (r_0, shift),
+//                exact up to the rounding of the recurrence residual; one partial pair per workgroup in gain_partial[2 b .. 2 b + 1]
+//   retraction   nodes_n <- Exp(d_n) nodes_n, the old row to `backup` (lane 0 of each node's M lanes); state[3] counts it
+template <class T> struct GhostTail {
+  T* nodes;
+  T* backup;
+  T* gain_partial;
+  unsigned long long* state;
+  const T* shift;
+};
 template <class T, int M, bool CZ = false, bool PROF = false>
 __global__ void __launch_bounds__(kPersistBlock)
 pcg_ghost_kernel(const int* __restrict__ ptr, const int* __restrict__ slot, const T* __restrict__ HB, const T* __restrict__ D,
                  const T* __restrict__ Binv, T* __restrict__ x, const T* __restrict__ r, const T* __restrict__ z,
                  const int* __restrict__ gptr, const int* __restrict__ gids, u64* part, u64* qtag /* [2][N * M tagged values] */,
                  T* __restrict__ rr_hist, T* info, int* it_out, T tol2, int maxiter, int cap, int64_t N, int lds_bytes,
-                 const T* __restrict__ shift = nullptr) {
+                 const T* __restrict__ shift = nullptr, const GhostTail<T>* __restrict__ tail_p = nullptr) {
   extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
   // cap < 0 (tools/time_pcg_iter.py): thread 0 of two workgroups -- the middle one (a plain member of the two-level exchange) and
   // workgroup 0 (a group leader) -- accumulates the wall-clock ticks (10 ns) of the phases; the clock starts with the kernel
@@ -1014,10 +1028,54 @@ pcg_ghost_kernel(const int* __restrict__ ptr, const int* __restrict__ slot, cons
     if (mid || gridDim.x / 2 != 0)
       for (int q = 0; q < kTickSlots; ++q) rr_hist[cap - (mid ? 48 : 32) + q] = (T)tk[q];
   }
-  if (act) x[n * M + i] = flag >= 2 ? T(0) : xe;
+  const T xo = flag >= 2 ? T(0) : xe;
+  if (act) x[n * M + i] = xo;
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     info[0] = (T)k; info[1] = rr; info[2] = bn2; info[3] = (T)flag;
     it_out[0] = k;
+  }
+  if constexpr (M == 6) {
+    // (the five pointers sit in device memory and are read HERE: as kernel arguments they cost ten SGPRs for the whole loop -- at this
+    //  kernel's register cap that spilled two VGPRs)
+    if (tail_p) {                                                // (launch-uniform)
+      const GhostTail<T> tail = *tail_p;
+      T ta = T(0), tb = T(0);
+      if (act && flag < 2) {
+        const T r0e = r[n * M + i], she = tail.shift[n * M + i];
+        ta = xo * (r0e - re - she * xo);
+        tb = -xo * r0e;
+      }
+      ta = wave_total63<T>(ta);
+      tb = wave_total63<T>(tb);
+      __syncthreads();                                           // (every wave is out of the loop: the exchange's LDS is free)
+      if (lane == 63) { sh.wave_part[0][0][w] = ta; sh.wave_part[0][1][w] = tb; }
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        T sa = T(0), sb = T(0);
+#pragma unroll
+        for (int ww = 0; ww < WV; ++ww) { sa += sh.wave_part[0][0][ww]; sb += sh.wave_part[0][1][ww]; }
+        tail.gain_partial[2 * blockIdx.x] = sa;
+        tail.gain_partial[2 * blockIdx.x + 1] = sb;
+        if (blockIdx.x == 0) tail.state[3] += 1;                 // "the parameters were moved" (pgo_fused.hip pgo_retract_rows)
+      }
+      T d[7];
+#pragma unroll
+      for (int j = 0; j < 6; ++j) d[j] = __shfl(xo, (sub * M + j) & 63, 64);
+      d[6] = T(0);
+      if (act && i == 0) {
+        T X[7], Ex[7], out[7];
+#pragma unroll
+        for (int q = 0; q < 7; ++q) X[q] = tail.nodes[n * 7 + q];
+        if (tail.backup) {
+#pragma unroll
+          for (int q = 0; q < 7; ++q) tail.backup[n * 7 + q] = X[q];
+        }
+        se3_exp<T>(d, Ex);
+        se3_mul<T>(Ex, X, out);
+#pragma unroll
+        for (int q = 0; q < 7; ++q) tail.nodes[n * 7 + q] = out[q];
+      }
+    }
   }
 }
 
@@ -1124,10 +1182,13 @@ template <class T, int M, bool CZ> static int ghost_capacity(int& lds_bytes) {
 template <class T>
 int pcg_ghost(const void* ptr, const void* slot, const void* HB, const void* D, const void* Binv, void* x, const void* r, const void* z,
               const void* gptr, const void* gids, void* part, void* qtag, void* rr_hist, void* info, void* it, double tol, int maxiter,
-              int cap, int grid, int max_cnt, int max_ghost, int64_t N, int m, void* stream, const void* shift = nullptr) {
+              int cap, int grid, int max_cnt, int max_ghost, int64_t N, int m, void* stream, const void* shift = nullptr,
+              const GhostTail<T>* tail_in = nullptr) {
   if (N <= 0) return N == 0 ? PPLIE_OK : PPLIE_EBADARG;
   if (!ptr || !slot || !HB || !D || !Binv || !x || !r || !z || !gptr || !gids || !part || !qtag || !rr_hist || !info || !it) return PPLIE_EBADARG;
   if (grid < 1 || grid > kPersistGridMax || maxiter < 0 || max_cnt < 0 || max_ghost < 0) return PPLIE_EBADARG;
+  if (tail_in && m != 6) return PPLIE_EBADARG;                  // (tail_in: DEVICE memory, five pointers -- see pplie_pcg_ghost_tail)
+  const GhostTail<T>* tail = tail_in;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 #define LAUNCH(MM) { if (shift) LAUNCH2(MM, true) else LAUNCH2(MM, false) }
 #define LAUNCH2(MM, CZ)                                                                                                        \
@@ -1146,12 +1207,12 @@ int pcg_ghost(const void* ptr, const void* slot, const void* HB, const void* D, 
       hipLaunchKernelGGL((pcg_ghost_kernel<float, 6, CZ, true>), dim3(grid), dim3(kPersistBlock), lds_bytes, st, (const int*)ptr, \
                          (const int*)slot, (const float*)HB, (const float*)D, (const float*)Binv, (float*)x, (const float*)r,     \
                          (const float*)z, (const int*)gptr, (const int*)gids, (unsigned long long*)part, (unsigned long long*)qtag, \
-                         (float*)rr_hist, (float*)info, (int*)it, (float)(tol * tol), maxiter, cap, N, lds_bytes, (const float*)shift); \
+                           (float*)rr_hist, (float*)info, (int*)it, (float)(tol * tol), maxiter, cap, N, lds_bytes, (const float*)shift); \
     } else                                                                                                                     \
     hipLaunchKernelGGL((pcg_ghost_kernel<T, MM, CZ>), dim3(grid), dim3(kPersistBlock), lds_bytes, st, (const int*)ptr, (const int*)slot, \
                        (const T*)HB, (const T*)D, (const T*)Binv, (T*)x, (const T*)r, (const T*)z, (const int*)gptr,             \
                        (const int*)gids, (unsigned long long*)part, (unsigned long long*)qtag, (T*)rr_hist, (T*)info, (int*)it,   \
-                       (T)(tol * tol), maxiter, cap, N, lds_bytes, (const T*)shift);                                           \
+                       (T)(tol * tol), maxiter, cap, N, lds_bytes, (const T*)shift, tail);                                     \
   }
   if (m == 6) LAUNCH(6) else if (m == 7) LAUNCH(7) else if (m == 3) LAUNCH(3) else return PPLIE_EBADARG;
 #undef LAUNCH
@@ -1223,6 +1284,22 @@ PPLIE_GHOST(f64, double)
   }
 PPLIE_GHOST_CZ(f32, float)
 PPLIE_GHOST_CZ(f64, double)
+// the solve with the LM trial's tail in its epilogue (GhostTail above; m = 6): shift_cz = the two-level preconditioner's shift or NULL
+// (block-Jacobi); tail_args = FIVE pointers in DEVICE memory { nodes [N, 7], backup [N, 7] or 0, gain_partial [2 x grid] (the gain
+// partials of pplie_pgo_trial_tail's `partial`, i.e. partial + PPLIE_PGO_PARTIALS), state (that entry's state block), shift [N, 6]
+// (the damping shift of pplie_pcg_prepare) }
+#define PPLIE_GHOST_TAIL(SFX, T)                                                                                                  \
+  extern "C" int pplie_pcg_ghost_tail_##SFX(const void* ptr, const void* slot, const void* HB, const void* D, const void* Binv,    \
+                                            const void* shift_cz, void* x, const void* r, const void* z, const void* gptr,        \
+                                            const void* gids, void* part, void* qtag, void* rr_hist, void* info, void* it,        \
+                                            double tol, int maxiter, int cap, int grid, int max_cnt, int max_ghost, int64_t N,    \
+                                            int m, const void* tail_args, void* stream) {                                        \
+    if (!tail_args || (reinterpret_cast<uintptr_t>(tail_args) & 7)) return pplie::PPLIE_EBADARG;                                  \
+    return pplie::pcg_ghost<T>(ptr, slot, HB, D, Binv, x, r, z, gptr, gids, part, qtag, rr_hist, info, it, tol, maxiter, cap, grid,    \
+                               max_cnt, max_ghost, N, m, stream, shift_cz, reinterpret_cast<const pplie::GhostTail<T>*>(tail_args)); \
+  }
+PPLIE_GHOST_TAIL(f32, float)
+PPLIE_GHOST_TAIL(f64, double)
 
 // Peer access for the hand-off tables of the multi-GPU solve: the kernel of GPU `device` stores into (and polls) tables that
 // live in the memory of GPU `peer` (hipIpc-mapped by the caller).  Returns 0 when `device` can reach `peer`'s memory after the

@@ -166,7 +166,7 @@ pgo_linearize_kernel(const T* __restrict__ nodes, const int64_t* __restrict__ id
 // residuals only + per-workgroup partial sums of |r|^2 (the Trivial-kernel loss, optimizer.py:118-125)
 template <class T>
 __device__ __forceinline__ void pgo_trial_pack(const T* partial, int nparts, const T* pcg_info, unsigned long long* state, double* out,
-                                               bool coherent_loss);
+                                               bool coherent_loss, int ngain = -1);
 // PACKLAST (the trial tail's second launch): the workgroup that arrives last at the ticket state[4] also does what a fourth launch
 // did -- sums everybody's partials and reports (pgo_trial_pack).  The loss partials cross workgroups inside this launch: agent-scope
 // stores and loads (csrc/gridsync.h xwg_*), the ticket's increment a release.
@@ -174,7 +174,7 @@ template <class T, int BLOCK, bool PACKLAST = false>
 __global__ void __launch_bounds__(BLOCK)
 pgo_residual_kernel(const T* __restrict__ nodes, const int64_t* __restrict__ idx, const T* __restrict__ Z,
                     T* __restrict__ R /* or null */, T* __restrict__ partial /* [gridDim.x] */, int64_t E, RobustParam<T> rk,
-                    const T* __restrict__ pcg_info = nullptr, unsigned long long* state = nullptr, double* out = nullptr) {
+                    const T* __restrict__ pcg_info = nullptr, unsigned long long* state = nullptr, double* out = nullptr, int ngain = -1) {
   __shared__ __attribute__((aligned(16))) T lds[BLOCK * 7];
   T acc = T(0);
   const int64_t ntiles = (E + BLOCK - 1) / BLOCK;
@@ -223,7 +223,7 @@ pgo_residual_kernel(const T* __restrict__ nodes, const int64_t* __restrict__ idx
       if (last_sh) xwg_store(ticket, 0u);                          // (at rest again for the next execution)
     }
     __syncthreads();
-    if (last_sh && threadIdx.x < 64) pgo_trial_pack<T>(partial, (int)gridDim.x, pcg_info, state, out, true);
+    if (last_sh && threadIdx.x < 64) pgo_trial_pack<T>(partial, (int)gridDim.x, pcg_info, state, out, true, ngain);
   }
 }
 
@@ -268,12 +268,14 @@ __device__ __forceinline__ void pgo_retract_rows(int64_t block, T* __restrict__ 
 
 template <class T>
 __device__ __forceinline__ void pgo_trial_pack(const T* partial, int nparts, const T* pcg_info, unsigned long long* state, double* out,
-                                               bool coherent_loss) {
+                                               bool coherent_loss, int ngain) {
   // (one wavefront) every lane sums the partials i = q, q + 64, ... and a shuffle tree adds the lanes: a fixed order, the same bits every replay
+  // ngain: the number of gain-partial pairs when an earlier launch other than the tail's own wrote them (the solve's epilogue: one
+  // pair per workgroup of ITS grid); < 0: as many as loss partials
   const int q = threadIdx.x;
   double loss = 0.0, a = 0.0, b = 0.0;
-  for (int i = q; i < nparts; i += 64) {
-    loss += (double)(coherent_loss ? xwg_load(partial + i) : partial[i]);     // pgo_residual_kernel (this launch's other workgroups)
+  for (int i = q; i < nparts; i += 64) loss += (double)(coherent_loss ? xwg_load(partial + i) : partial[i]);   // pgo_residual_kernel
+  for (int i = q; i < (ngain < 0 ? nparts : ngain); i += 64) {
     a += (double)partial[kPgoPartials + 2 * i];                   // gain partials (an earlier launch): sum JD.JD
     b += (double)partial[kPgoPartials + 2 * i + 1];               //                    sum JD.R
   }
@@ -301,8 +303,9 @@ __device__ __forceinline__ void pgo_trial_pack(const T* partial, int nparts, con
 // the pack as a launch of its own (large grids: see pgo_trial_tail)
 template <class T>
 __global__ void __launch_bounds__(64)
-pgo_trial_pack_kernel(const T* __restrict__ partial, int nparts, const T* __restrict__ pcg_info, unsigned long long* state, double* out) {
-  pgo_trial_pack<T>(partial, nparts, pcg_info, state, out, false);
+pgo_trial_pack_kernel(const T* __restrict__ partial, int nparts, const T* __restrict__ pcg_info, unsigned long long* state, double* out,
+                      int ngain = -1) {
+  pgo_trial_pack<T>(partial, nparts, pcg_info, state, out, false, ngain);
 }
 
 // gain-ratio terms of the relative-pose program (strategy.py:144, :261): its two blocks per edge are opposite (J_e0 = -J_e1, see
@@ -375,6 +378,32 @@ int pgo_trial_tail(void* nodes, void* backup, const void* idx, const void* Z, co
                        (const T*)Z, (T*)nullptr, part, E, RobustParam<T>{RK_NONE, T(0), T(0)});
     hipLaunchKernelGGL((pgo_trial_pack_kernel<T>), dim3(1), dim3(64), 0, st, (const T*)part, grid, (const T*)pcg_info,
                        (unsigned long long*)state, (double*)out);
+  }
+  return hipGetLastError() == hipSuccess ? PPLIE_OK : PPLIE_ELAUNCH;
+}
+
+// what is left of the tail when the solve's epilogue has retracted the parameters and left the gain partials (csrc/pcg_persist.hip
+// GhostTail): the candidate loss and the report -- ONE launch (two beyond kPackLastGrid residual workgroups)
+template <class T>
+int pgo_trial_tail_after_solve(const void* nodes, const void* idx, const void* Z, const void* pcg_info, void* partial, void* state, void* out,
+                               int64_t E, int ngain, void* stream) {
+  if (E <= 0 || ngain < 1 || ngain > kPgoPartials) return PPLIE_EBADARG;
+  if (!nodes || !idx || !Z || !pcg_info || !partial || !state || !out || !aligned16(Z)) return PPLIE_EBADARG;
+  if (reinterpret_cast<uintptr_t>(state) & 7) return PPLIE_EBADARG;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  constexpr int BLOCK = 256;
+  const int64_t nt = (E + BLOCK - 1) / BLOCK;
+  const int grid = (int)(nt < kPgoPartials ? nt : kPgoPartials);
+  T* part = (T*)partial;
+  if (grid <= kPackLastGrid) {
+    hipLaunchKernelGGL((pgo_residual_kernel<T, BLOCK, true>), dim3(grid), dim3(BLOCK), 0, st, (const T*)nodes, (const int64_t*)idx,
+                       (const T*)Z, (T*)nullptr, part, E, RobustParam<T>{RK_NONE, T(0), T(0)}, (const T*)pcg_info,
+                       (unsigned long long*)state, (double*)out, ngain);
+  } else {
+    hipLaunchKernelGGL((pgo_residual_kernel<T, BLOCK>), dim3(grid), dim3(BLOCK), 0, st, (const T*)nodes, (const int64_t*)idx,
+                       (const T*)Z, (T*)nullptr, part, E, RobustParam<T>{RK_NONE, T(0), T(0)});
+    hipLaunchKernelGGL((pgo_trial_pack_kernel<T>), dim3(1), dim3(64), 0, st, (const T*)part, grid, (const T*)pcg_info,
+                       (unsigned long long*)state, (double*)out, ngain);
   }
   return hipGetLastError() == hipSuccess ? PPLIE_OK : PPLIE_ELAUNCH;
 }
@@ -469,6 +498,14 @@ extern "C" int pplie_pgo_residual_f32(const void* nodes, const void* idx, const 
 }
 extern "C" int pplie_pgo_residual_f64(const void* nodes, const void* idx, const void* Z, void* R, void* partial, int64_t E, void* stream) {
   return pplie::pgo_residual_launch<double>(nodes, idx, Z, R, partial, E, stream);
+}
+extern "C" int pplie_pgo_trial_tail_after_solve_f32(const void* nodes, const void* idx, const void* Z, const void* pcg_info, void* partial,
+                                                    void* state, void* out, int64_t E, int ngain, void* stream) {
+  return pplie::pgo_trial_tail_after_solve<float>(nodes, idx, Z, pcg_info, partial, state, out, E, ngain, stream);
+}
+extern "C" int pplie_pgo_trial_tail_after_solve_f64(const void* nodes, const void* idx, const void* Z, const void* pcg_info, void* partial,
+                                                    void* state, void* out, int64_t E, int ngain, void* stream) {
+  return pplie::pgo_trial_tail_after_solve<double>(nodes, idx, Z, pcg_info, partial, state, out, E, ngain, stream);
 }
 extern "C" int pplie_pgo_trial_tail_f32(void* nodes, void* backup, const void* idx, const void* Z, const void* J, const void* R, const void* x,
                                         const void* pcg_info, void* partial, void* state, void* out, int64_t N, int64_t E,

@@ -1272,23 +1272,38 @@ def _pgo_linearization(opt, prog, weight, P, trivial, s_dev=None):
     if trivial:
         lin.fast_loss = lambda: prog.loss(opt.group)
         if opt.group is None and lin._hip():
+            def tail_buffers():
+                from .pgograph import TrialTail
+                pt = torch.Tensor.as_subclass(P, torch.Tensor).detach()
+                tt = opt.__dict__.get('_trial_tail')
+                if tt is None or tt.dtype != pt.dtype or tt.dev != pt.device:
+                    tt = opt._trial_tail = TrialTail(pt.dtype, pt.device)
+                bk = tt.__dict__.get('_backup')
+                if bk is None or bk.shape != pt.shape or bk.dtype != pt.dtype or bk.device != pt.device:
+                    bk = tt._backup = torch.empty_like(pt)
+                return pt, tt, bk
+
+            def tail_setup():
+                """before the solve: a persistent solve may take the tail's first half (gain terms + retraction) into its epilogue
+                (optim/posegraph.py FusedPCG.solve, pplie_pcg_ghost_tail) -- the same arrangement as the captured trial's"""
+                pt, tt, bk = tail_buffers()
+                if pt.is_contiguous() and lin.idx.data_ptr() == prog.idx.data_ptr() and lin.J.shape == (prog.E, 2, 6, 6):
+                    lin._tail_in_solve = (pt, bk, tt.partial, tt.state)
+            lin.tail_setup = tail_setup
+
             def trial_tail():
                 """What the trial loop does between the solve and its decision (optimizer.py:669-673) as one C call and one wait on
                 pinned memory (optim/pgograph.py TrialTail): the parameters retracted by the step the solve just returned, then
                 (a, b, loss) as host floats and the loss as a device scalar; None if this trial cannot take the route."""
-                from .pgograph import TrialTail
                 Dn = lin.__dict__.pop('_last_Dn', None)
-                pt = torch.Tensor.as_subclass(P, torch.Tensor).detach()
+                pt, tt, bk = tail_buffers()
                 if Dn is None or Dn.shape != (lin.N, 6) or not pt.is_contiguous() or lin.idx.data_ptr() != prog.idx.data_ptr() \
                         or lin.J.shape != (prog.E, 2, 6, 6) or Dn.dtype != pt.dtype:
+                    if lin.__dict__.pop('_tail_done', None) is not None:
+                        raise RuntimeError("pypose_amd: the solve's epilogue moved the parameters of a trial whose tail cannot finish")
+                    lin.__dict__.pop('_tail_in_solve', None)
                     return None
-                tt = opt.__dict__.get('_trial_tail')
-                if tt is None or tt.dtype != pt.dtype or tt.dev != pt.device:
-                    tt = opt._trial_tail = TrialTail(pt.dtype, pt.device)
                 pend, lin.pending_info = lin.pending_info, None
-                bk = tt.__dict__.get('_backup')
-                if bk is None or bk.shape != pt.shape or bk.dtype != pt.dtype or bk.device != pt.device:
-                    bk = tt._backup = torch.empty_like(pt)
                 before = tt.seq
                 slot = tt.advance()
                 try:

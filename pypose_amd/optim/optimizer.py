@@ -600,6 +600,8 @@ class LevenbergMarquardt(_Optimizer):
             D = Dn = None
             try:
                 if use_tail:
+                    if hasattr(lin, 'tail_setup'):
+                        lin.tail_setup()
                     Dn = lin.solve_nodes(self.solver)          # (the padded step only if somebody needs it)
                 else:
                     D = lin.solve(self.solver)

@@ -33,6 +33,7 @@ from . import fused as _fused
 from . import strategy as _strategy
 
 _TAIL_SIG = [ctypes.c_void_p] * 11 + [ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p]
+_TAIL_AFTER_SIG = [ctypes.c_void_p] * 7 + [ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]
 _PARTIALS = 1024          # PPLIE_PGO_PARTIALS
 
 
@@ -62,6 +63,7 @@ class TrialTail:
         self.out = torch.zeros(8, dtype=torch.float64).pin_memory()       # {a, b, loss, iterations, |r|^2, |b|^2, flag, seq}
         self.out_np = self.out.numpy()
         self.seq = 0
+        self.after_solve = 0                                               # trials whose first half ran in the solve's epilogue
         self.state = torch.zeros(8, dtype=torch.int64, device=dev)         # {seq (counts executions), loss ring address, its length,
                                                                            #  retractions (counts moved parameters), the second launch's
                                                                            #  arrival ticket (zero at rest), three reserved}
@@ -77,9 +79,21 @@ class TrialTail:
         self.state[1:3].copy_(torch.tensor([self.ring.data_ptr(), self.RING], dtype=torch.int64))    # (once per RING trials)
 
     def enqueue(self, pt, backup, prog, lin, Dn, info):
-        """the four launches (nothing else: callable inside a stream capture)"""
+        """the tail's launches (nothing else: callable inside a stream capture)"""
         assert Dn.is_contiguous() and pt.is_contiguous() and lin.m == 6 and lin.K == 2 and lin.dr == 6 \
             and lin.idx.data_ptr() == prog.idx.data_ptr() and lin.E == prog.E and Dn.shape == (lin.N, 6)
+        ngain = lin.__dict__.pop('_tail_done', None)
+        lin.__dict__.pop('_tail_in_solve', None)
+        if ngain is not None:
+            # the solve's epilogue has moved the parameters and left the gain partials: the candidate loss and the report remain
+            fn_after = _C.library().symbol("pplie_pgo_trial_tail_after_solve" + ("_f32" if self.dtype == torch.float32 else "_f64"), _TAIL_AFTER_SIG)
+            with _C._on_device(pt.device):
+                code = fn_after(pt.data_ptr(), prog.idx.data_ptr(), prog.Z.data_ptr(), (self.no_info if info is None else info).data_ptr(),
+                                     self.partial.data_ptr(), self.state.data_ptr(), self.out.data_ptr(), lin.E, int(ngain),
+                                     _C.stream_ptr(pt.device))
+            _C.check(code, "pplie_pgo_trial_tail_after_solve")
+            self.after_solve += 1
+            return
         with _C._on_device(pt.device):
             code = self.fn(pt.data_ptr(), None if backup is None else backup.data_ptr(), prog.idx.data_ptr(), prog.Z.data_ptr(),
                            lin.J.data_ptr(), lin.R.data_ptr(), Dn.data_ptr(), (self.no_info if info is None else info).data_ptr(),
@@ -157,6 +171,10 @@ class PgoGraphStep:
         self.params = [p for p in pg['params'] if p.requires_grad]
         self.graph = None
         self.backup = torch.empty_like(pt)      # the parameters before the latest replay
+        # (the pointer table of the solve's epilogue tail is a host-to-device copy: made before the capture, not inside it)
+        for w in (opt.__dict__.get('_pcg_workspaces') or {}).values():
+            if getattr(w, 'm', None) == 6 and getattr(w, 'dtype', None) == pt.dtype and hasattr(w, '_tail_args'):
+                w._tail_args((pt, self.backup, self.tt.partial, self.tt.state))
         # capture on a side stream (torch.cuda.graph does that); the first replay-equivalent run happens during capture
         torch.cuda.synchronize(dev)
         saved = P.detach().clone()
@@ -176,6 +194,9 @@ class PgoGraphStep:
         lin = _fused._pgo_linearization(opt, self.prog, self.weight, self.P, self.trivial, s_dev=self.ctl)
         lin.build_normal_equations(*self.clamp)
         lin.s_dev = self.ctl                       # prepare reads the damping factor from here (pplie_pcg_prepare_dev)
+        # the persistent solve may take the tail's first half (gain terms + retraction) into its epilogue: it is told where the
+        # parameters, their backup and the tail's buffers are, and says so in lin._tail_done if it did
+        lin._tail_in_solve = (pt, self.backup, self.tt.partial, self.tt.state)
         opt._defer_solver_info = 'inplace'
         try:
             Dn = lin._pcg(opt.solver, lin.s, lin.dmin, lin.dmax, plain=False)       # [N, 6]: the solver workspace's x itself

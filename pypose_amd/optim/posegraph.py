@@ -59,6 +59,8 @@ _PERSIST_SLOTS = 8          # PPLIE_PCG_PERSIST_SLOTS
 _COARSE_SLOTS = 24          # PPLIE_PCG_COARSE_SLOTS: row of the partial-sum table of the two-level (gauge) variant
 _PCG2_CS_ELEMS = 2 * 32 * 32  # PPLIE_PCG2_CS_ELEMS: coarse sums of the two-launch iteration
 _GHOST_CZ_SIG = [ctypes.c_void_p] * 16 + [ctypes.c_double] + [ctypes.c_int] * 5 + [ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]
+_GHOST_TAIL_SIG = [ctypes.c_void_p] * 16 + [ctypes.c_double] + [ctypes.c_int] * 5 + [ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+_PGO_PARTIALS = 1024      # PPLIE_PGO_PARTIALS
 _PREP_CZ_SIG = [ctypes.c_void_p] * 11 + [ctypes.c_double, ctypes.c_void_p, ctypes.c_double, ctypes.c_double, ctypes.c_int64, ctypes.c_int,
                                          ctypes.c_void_p]
 _PCG2_SPMV_CZ_SIG = [ctypes.c_void_p] * 12 + [ctypes.c_int, ctypes.c_int64, ctypes.c_int, ctypes.c_double, ctypes.c_void_p]
@@ -327,6 +329,8 @@ class FusedPCG:
     profile = False          # tools/time_pcg_iter.py: the persistent kernel leaves per-phase clock ticks in rr_hist[cap - 8:]
     # the "Laplacian" assembly's per-node sums inside the solve's set-up launch (pplie_pcg_prepare_lap); PPLIE_PCG_FUSE_PREPARE=0: off
     fuse_prepare = _os.environ.get("PPLIE_PCG_FUSE_PREPARE", "1") != "0"
+    # the LM trial's gain terms and retraction in the persistent solve's epilogue (pplie_pcg_ghost_tail); PPLIE_PCG_TAIL_IN_SOLVE=0: off
+    tail_in_solve = _os.environ.get("PPLIE_PCG_TAIL_IN_SOLVE", "1") != "0"
     # two-level preconditioner (block-Jacobi + gauge modes) where the linearisation allows it (PCG(gauge=)); PPLIE_PCG_GAUGE=0: off
     coarse = _os.environ.get("PPLIE_PCG_GAUGE", "1") != "0"
     # the whole LM trial of a graph BEYOND the persistent solve as one hipGraph replay too (optim/pgograph.py): the two-launch iterations
@@ -498,6 +502,22 @@ class FusedPCG:
                          self.it.data_ptr(), self.cap, self.N, self.m, st)
             _C.check(code, "pplie_pcg_stage")
 
+    def _tail_args(self, tail):
+        """the five pointers of csrc/pcg_persist.hip GhostTail in device memory (nodes, backup, gain partials, state, shift); kept per
+        set of buffers: inside a captured graph the table must be the same memory at every replay"""
+        pt, backup, partial, state = tail
+        key = (pt.data_ptr(), 0 if backup is None else backup.data_ptr(), partial.data_ptr(), state.data_ptr(), self.shift.data_ptr())
+        tabs = self.__dict__.setdefault('_tail_tabs', {})          # (every table stays alive: a captured graph may hold its address)
+        tab = tabs.get(key)
+        if tab is None:
+            if torch.cuda.is_current_stream_capturing():           # (no host-to-device copy inside a capture: the two-launch tail runs)
+                return None
+            if len(tabs) >= 64:
+                raise RuntimeError("pypose_amd: more than 64 sets of trial buffers on one solve workspace")
+            gain = partial.data_ptr() + _PGO_PARTIALS * partial.element_size()       # (the tail's gain partials sit behind its loss partials)
+            tab = tabs[key] = torch.tensor([key[0], key[1], gain, key[3], key[4]], dtype=torch.int64).to(self.device)
+        return tab
+
     def _prepare_lap(self, lin, s, s_dev, dmin, dmax, coarse):
         """the set-up launch that also finishes the linearisation's assembly (its per-node sums are pending: pplie_pcg_prepare_lap);
         None when there is nothing pending -- the caller then runs the plain set-up on lin.B / lin.g"""
@@ -640,7 +660,23 @@ class FusedPCG:
                     while hit[1]:
                         grid = hit[1][0]
                         slot, gptr, gids, max_cnt, max_ghost = self._ghost_map(lin, grid)
-                        if self.cz:
+                        # (unweighted only: the gain terms are taken with the PLAIN J and R -- optimizer.py:670, strategy.py:128-140 -- and equal
+                        #  d.(H d), -d.r_0 of the solve only while H = J^T J)
+                        tail = lin.__dict__.get('_tail_in_solve') if self.m == 6 and not self.has_w and not FusedPCG.profile \
+                            and FusedPCG.tail_in_solve else None
+                        args = None if tail is None else self._tail_args(tail)
+                        if args is not None:
+                            # the LM trial's tail rides in the solve's epilogue (csrc/pcg_persist.hip GhostTail): gain terms + retraction
+                            # by the workgroups that hold d and r; the trial then has ONE launch left (optim/pgograph.py TrialTail)
+                            code = _C.library().symbol("pplie_pcg_ghost_tail" + self.sfx, _GHOST_TAIL_SIG)(
+                                self.ptr.data_ptr(), slot.data_ptr(), self.HB.data_ptr(), self.D.data_ptr(), self.Binv.data_ptr(),
+                                self.shift.data_ptr() if self.cz else None, self.x.data_ptr(), self.r.data_ptr(), self.z.data_ptr(),
+                                gptr.data_ptr(), gids.data_ptr(), self.part.data_ptr(), self.ptag.data_ptr(), self.rr_hist.data_ptr(),
+                                self.info.data_ptr(), self.it.data_ptr(), float(tol), int(maxit), self.cap, grid, max_cnt, max_ghost,
+                                self.N, self.m, args.data_ptr(), _C.stream_ptr(self.device))
+                            if code == 0:
+                                lin._tail_done = grid                # (gain partials: one pair per workgroup of THIS grid)
+                        elif self.cz:
                             code = _C.library().symbol("pplie_pcg_ghost_coarse" + self.sfx, _GHOST_CZ_SIG)(
                                 self.ptr.data_ptr(), slot.data_ptr(), self.HB.data_ptr(), self.D.data_ptr(), self.Binv.data_ptr(),
                                 self.shift.data_ptr(), self.x.data_ptr(), self.r.data_ptr(), self.z.data_ptr(), gptr.data_ptr(),
