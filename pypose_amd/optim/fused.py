@@ -1150,11 +1150,33 @@ def checked_shortcut(opt, dev, gs, input, target, weight):
     """``LM.step`` of the default (non-static) optimizer when a device-resident step exists: the model runs dry, and the
     shortcut is taken only if THIS step's program is the one it was built on."""
     pg = opt.param_groups[0]
-    with _no_tf():              # (attribute reads on a LieTensor parameter are __torch_function__ round trips: ~3 us each)
-        params = [p for p in dict.__getitem__(pg, 'params') if p.requires_grad]
     cache = opt.__dict__.get('_structure_cache') or {}
     if cache.get("fused") is not True or cache.get("dry") is False or torch.is_inference_mode_enabled():
         return None
+    if dev is None and gs is not None and getattr(opt, 'speculate', True):
+        # (round 6) the replay goes out before ANY of the step's checks but the two `quick` makes: what stands between the previous
+        # trial's verdict and this trial's first kernel is host time the GPU idles through (profiles/r06/EXPERIMENTS.md "host segments")
+        with _no_tf():
+            early = gs.quick(target)
+        if early:
+            gs.launch(pg)
+            w = opt.weight if weight is None else weight
+            m = None
+            if gs.usable(pg, input, target, w, checked=True):
+                with _no_tf():
+                    params = [p for p in dict.__getitem__(pg, 'params') if p.requires_grad]
+                m = dry_program(opt, params, input, target)
+                st = opt.__dict__.get('_dry_state')
+                if m and m[0] == "pgo" and gs.prog.matches(*m[1:]) and not (st is not None and st.touched):
+                    return gs.finish(pg)
+                if st is not None and st.touched:
+                    opt.speculate = False
+            gs.cancel()
+            if m:
+                opt._dry_hint = (input, m)
+            return None
+    with _no_tf():              # (attribute reads on a LieTensor parameter are __torch_function__ round trips: ~3 us each)
+        params = [p for p in dict.__getitem__(pg, 'params') if p.requires_grad]
     if dev is None and gs is not None and getattr(opt, 'speculate', True):
         # Pose graphs: a step is one hipGraph replay followed by a read-back the host has to wait for anyway (~0.5 ms).  The
         # replay is enqueued FIRST and the model's (dry) run -- this step's check that the program is still the one captured --

@@ -540,7 +540,14 @@ class LevenbergMarquardt(_Optimizer):
                         return out
                 if gs is not None:
                     pg = self.param_groups[0]
-                    if gs.usable(pg, input, target, self.weight if weight is None else weight):
+                    with _fused._no_tf():
+                        early = gs.quick(target)
+                    if early:                  # (replay first, the rest of the checks while the GPU works: fused.checked_shortcut)
+                        gs.launch(pg)
+                        if gs.usable(pg, input, target, self.weight if weight is None else weight):
+                            return gs.finish(pg)
+                        gs.cancel()
+                    elif gs.usable(pg, input, target, self.weight if weight is None else weight):
                         with torch.no_grad():
                             return gs.step(pg)
             else:

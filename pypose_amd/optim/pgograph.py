@@ -170,6 +170,8 @@ class PgoGraphStep:
         self.tt = TrialTail(pt.dtype, dev)
         self.params = [p for p in pg['params'] if p.requires_grad]
         self.graph = None
+        self.pt = pt                            # (keeps the captured storage alive whatever the caller does to the parameter)
+        self.keep = list((opt.__dict__.get('_pcg_workspaces') or {}).values())       # (and the solve's buffers)
         self.backup = torch.empty_like(pt)      # the parameters before the latest replay
         # (the pointer table of the solve's epilogue tail is a host-to-device copy: made before the capture, not inside it)
         for w in (opt.__dict__.get('_pcg_workspaces') or {}).values():
@@ -215,6 +217,15 @@ class PgoGraphStep:
         with _fused._no_tf():      # (attribute reads on a LieTensor parameter are __torch_function__ round trips: ~3 us each)
             return self._usable(pg, input, target, weight, checked)
 
+    def quick(self, target):
+        """the facts a SPECULATIVE replay needs (fused.checked_shortcut launches first and asks ``usable`` while the GPU works): the
+        captured kernels still write where the parameters are -- a replay into storage the caller has swapped out could not be undone
+        by copying ``backup`` back -- and this is not the step the ordinary path's periodic re-probe is due.  Everything else the
+        replay touches is kept alive by this object; anything else that turns out to have changed is undone by ``cancel``."""
+        cache = self.opt.__dict__.get('_structure_cache')
+        return (target is None and cache is not None and (cache.get('_uses', 0) + 1) % _optimizer_names()[1] != 0
+                and self.P.data_ptr() == self.ptr)
+
     def _usable(self, pg, input, target, weight, checked):
         opt, P = self.opt, self.P
         cache = opt.__dict__.get('_structure_cache')
@@ -253,7 +264,8 @@ class PgoGraphStep:
         opt = self.opt
         self._had_loss = hasattr(opt, 'loss')
         if not self._had_loss:                     # first step of a run: the loss at the starting point (optimizer.py:659)
-            opt.loss = self.lin.fast_loss()
+            with torch.no_grad():
+                opt.loss = self.lin.fast_loss()
         lin = self.lin
         lin.s = 1.0 + float(pg['damping'])         # (host mirror: a retry compounds from here)
         self.ctl_f[0] = lin.s
@@ -318,10 +330,11 @@ class PgoGraphStep:
         opt.solver.iterations = int(its)
         _strategy.update_from_terms(opt.strategy, pg, last_h, loss_h, a, b)
         if last_h < loss_h and opt.reject_count < opt.reject:        # rejected: back, then the ordinary trial loop
-            opt.update_parameter(params=pg['params'], step=-lin.nodes_to_step(self.Dn))
-            opt.loss, opt.reject_count, loss_h = opt.last, 1, last_h
-            J, R = lin.strategy_args()
-            loss_h = opt._trial_loop(pg, lin, J, R, None, None, last_h, loss_h, defer=False)
+            with torch.no_grad():
+                opt.update_parameter(params=pg['params'], step=-lin.nodes_to_step(self.Dn))
+                opt.loss, opt.reject_count, loss_h = opt.last, 1, last_h
+                J, R = lin.strategy_args()
+                loss_h = opt._trial_loop(pg, lin, J, R, None, None, last_h, loss_h, defer=False)
         else:
             opt.loss = self.tt.loss_views[self.slot]  # (a ring of device scalars: never overwritten while the view is alive)
         opt._host_loss = (opt.loss, loss_h)
