@@ -170,11 +170,15 @@ __device__ __forceinline__ void pgo_trial_pack(const T* partial, int nparts, con
 // PACKLAST (the trial tail's second launch): the workgroup that arrives last at the ticket state[4] also does what a fourth launch
 // did -- sums everybody's partials and reports (pgo_trial_pack).  The loss partials cross workgroups inside this launch: agent-scope
 // stores and loads (csrc/gridsync.h xwg_*), the ticket's increment a release.
-template <class T, int BLOCK, bool PACKLAST = false>
+// PACKLAST: 0 = partial sums only; 1 = the last workgroup to arrive packs the trial's report (pgo_trial_pack); 2 = the last workgroup
+// adds the partials (one wavefront, fixed order, in double) and stores the loss as ONE device scalar -- the model's loss in one launch
+// (pplie_pgo_loss; was: a zero fill, this kernel and a torch reduction, three launches in front of a run's first LM trial)
+template <class T, int BLOCK, int PACKLAST = 0>
 __global__ void __launch_bounds__(BLOCK)
 pgo_residual_kernel(const T* __restrict__ nodes, const int64_t* __restrict__ idx, const T* __restrict__ Z,
                     T* __restrict__ R /* or null */, T* __restrict__ partial /* [gridDim.x] */, int64_t E, RobustParam<T> rk,
-                    const T* __restrict__ pcg_info = nullptr, unsigned long long* state = nullptr, double* out = nullptr, int ngain = -1) {
+                    const T* __restrict__ pcg_info = nullptr, unsigned long long* state = nullptr, double* out = nullptr, int ngain = -1,
+                    T* __restrict__ loss_out = nullptr) {
   __shared__ __attribute__((aligned(16))) T lds[BLOCK * 7];
   T acc = T(0);
   const int64_t ntiles = (E + BLOCK - 1) / BLOCK;
@@ -209,7 +213,7 @@ pgo_residual_kernel(const T* __restrict__ nodes, const int64_t* __restrict__ idx
     }
   }
   T s = block_sum(acc);
-  if constexpr (!PACKLAST) {
+  if constexpr (PACKLAST == 0) {
     if (threadIdx.x == 0) partial[blockIdx.x] = s;
   } else {
     __shared__ int last_sh;
@@ -223,7 +227,17 @@ pgo_residual_kernel(const T* __restrict__ nodes, const int64_t* __restrict__ idx
       if (last_sh) xwg_store(ticket, 0u);                          // (at rest again for the next execution)
     }
     __syncthreads();
-    if (last_sh && threadIdx.x < 64) pgo_trial_pack<T>(partial, (int)gridDim.x, pcg_info, state, out, true, ngain);
+    if constexpr (PACKLAST == 1) {
+      if (last_sh && threadIdx.x < 64) pgo_trial_pack<T>(partial, (int)gridDim.x, pcg_info, state, out, true, ngain);
+    } else {
+      if (last_sh && threadIdx.x < 64) {
+        double tot = 0.0;
+        for (int q = threadIdx.x; q < (int)gridDim.x; q += 64) tot += (double)xwg_load(partial + q);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) tot += __shfl_down(tot, off, 64);
+        if (threadIdx.x == 0) loss_out[0] = (T)tot;
+      }
+    }
   }
 }
 
@@ -370,7 +384,7 @@ int pgo_trial_tail(void* nodes, void* backup, const void* idx, const void* Z, co
   // of them (10 k nodes / 40 k edges) cost about what the pack's own launch did (residual + pack 8.8 -> 9.1 us, one launch less), 1024
   // (4e5 edges) turned an 11.6 us residual kernel into 41.5 us (profiles/r05/lm_pgo_100k_kernel_stats.csv).
   if (grid <= kPackLastGrid) {
-    hipLaunchKernelGGL((pgo_residual_kernel<T, BLOCK, true>), dim3(grid), dim3(BLOCK), 0, st, (const T*)nodes, (const int64_t*)idx,
+    hipLaunchKernelGGL((pgo_residual_kernel<T, BLOCK, 1>), dim3(grid), dim3(BLOCK), 0, st, (const T*)nodes, (const int64_t*)idx,
                        (const T*)Z, (T*)nullptr, part, E, RobustParam<T>{RK_NONE, T(0), T(0)}, (const T*)pcg_info,
                        (unsigned long long*)state, (double*)out);
   } else {
@@ -396,7 +410,7 @@ int pgo_trial_tail_after_solve(const void* nodes, const void* idx, const void* Z
   const int grid = (int)(nt < kPgoPartials ? nt : kPgoPartials);
   T* part = (T*)partial;
   if (grid <= kPackLastGrid) {
-    hipLaunchKernelGGL((pgo_residual_kernel<T, BLOCK, true>), dim3(grid), dim3(BLOCK), 0, st, (const T*)nodes, (const int64_t*)idx,
+    hipLaunchKernelGGL((pgo_residual_kernel<T, BLOCK, 1>), dim3(grid), dim3(BLOCK), 0, st, (const T*)nodes, (const int64_t*)idx,
                        (const T*)Z, (T*)nullptr, part, E, RobustParam<T>{RK_NONE, T(0), T(0)}, (const T*)pcg_info,
                        (unsigned long long*)state, (double*)out, ngain);
   } else {
@@ -449,7 +463,33 @@ int pgo_residual_launch(const void* nodes, const void* idx, const void* Z, void*
                      (const T*)nodes, (const int64_t*)idx, (const T*)Z, (T*)R, (T*)partial, E, RobustParam<T>{kind, (T)p0, (T)p1});
   return hipGetLastError() == hipSuccess ? PPLIE_OK : PPLIE_ELAUNCH;
 }
+// the model's loss sum_e rho(|r_e|^2) as one device scalar in ONE launch; ws: [kPgoPartials] partials of T followed (8-byte aligned) by
+// eight 64-bit words of which word 4 is the arrival ticket (zero at rest) -- pplie_pgo_loss_ws_bytes() says how much
+template <class T>
+int pgo_loss(const void* nodes, const void* idx, const void* Z, void* ws, void* loss, int64_t E, void* stream, int kind, double p0, double p1) {
+  if (kind < 0 || kind > RK_TOLERANT || E < 0) return PPLIE_EBADARG;
+  if (!loss || (E > 0 && (!nodes || !idx || !Z || !ws || !aligned16(Z) || (reinterpret_cast<uintptr_t>(ws) & 7)))) return PPLIE_EBADARG;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (E == 0) return hipMemsetAsync(loss, 0, sizeof(T), st) == hipSuccess ? PPLIE_OK : PPLIE_ELAUNCH;
+  constexpr int BLOCK = 256;
+  int64_t nt = (E + BLOCK - 1) / BLOCK;
+  int grid = (int)(nt < kPgoPartials ? nt : kPgoPartials);
+  unsigned long long* state = reinterpret_cast<unsigned long long*>((char*)ws + sizeof(T) * kPgoPartials);
+  hipLaunchKernelGGL((pgo_residual_kernel<T, BLOCK, 2>), dim3(grid), dim3(BLOCK), 0, st, (const T*)nodes, (const int64_t*)idx, (const T*)Z,
+                     (T*)nullptr, (T*)ws, E, RobustParam<T>{kind, (T)p0, (T)p1}, (const T*)nullptr, state, (double*)nullptr, -1, (T*)loss);
+  return hipGetLastError() == hipSuccess ? PPLIE_OK : PPLIE_ELAUNCH;
+}
 }  // namespace pplie
+
+extern "C" int pplie_pgo_loss_ws_bytes(void) { return 8 * pplie::kPgoPartials + 64; }
+extern "C" int pplie_pgo_loss_f32(const void* nodes, const void* idx, const void* Z, void* ws, void* loss, int64_t E, int kind, double p0,
+                                  double p1, void* stream) {
+  return pplie::pgo_loss<float>(nodes, idx, Z, ws, loss, E, stream, kind, p0, p1);
+}
+extern "C" int pplie_pgo_loss_f64(const void* nodes, const void* idx, const void* Z, void* ws, void* loss, int64_t E, int kind, double p0,
+                                  double p1, void* stream) {
+  return pplie::pgo_loss<double>(nodes, idx, Z, ws, loss, E, stream, kind, p0, p1);
+}
 
 // the same two entries with a robust kernel (kind: PPLIE_ROBUST_* of include/pplie.h; p0 = delta, Tolerant: p0 = a, p1 = b):
 // the linearisation returns the CORRECTED residuals and blocks sqrt(rho'(|r|^2)) (r, J) of corrector.py:91-96, the residual

@@ -894,6 +894,7 @@ FUSE_PGO_ASSEMBLY = os.environ.get("PPLIE_FUSE_PGO_ASSEMBLY", "1") != "0"
 _PGO_SIG = [ctypes.c_void_p] * 5 + [ctypes.c_int64, ctypes.c_void_p]
 _PGO_LAP_SIG = [ctypes.c_void_p] * 8 + [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_void_p, ctypes.c_int64,
                 ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+_PGO_LOSS_SIG = [ctypes.c_void_p] * 5 + [ctypes.c_int64, ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_void_p]
 _PGO_ROBUST_SIG = [ctypes.c_void_p] * 5 + [ctypes.c_int64, ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_void_p]
 _PGO_PARTIALS = 1024      # PPLIE_PGO_PARTIALS
 
@@ -1019,18 +1020,20 @@ class PgoProgram:
     def loss(self, group=None, robust=None):
         """sum_e rho(|r_e|^2) at the current parameter values (optimizer.py:118-125; rho = identity without ``robust``)."""
         nodes = torch.Tensor.as_subclass(self.P, torch.Tensor).detach()     # (plain: no __torch_function__ round trips below)
-        part = torch.zeros(_PGO_PARTIALS, dtype=nodes.dtype, device=nodes.device)
+        # one launch (round 6; was a zero fill, the residual kernel and a torch reduction): the last workgroup adds the partial sums.
+        # The workspace (partials + arrival ticket) belongs to the stream the calls are ordered on
+        stream = _C.stream_ptr(nodes.device)
+        key = (nodes.dtype, nodes.device, stream.value)
+        ws = self.__dict__.setdefault('_loss_ws', {}).get(key)
+        if ws is None:
+            nbytes = _C.library().symbol("pplie_pgo_loss_ws_bytes", [])()
+            ws = self._loss_ws[key] = torch.zeros(nbytes // 8, dtype=torch.int64, device=nodes.device)
+        loss = torch.empty((), dtype=nodes.dtype, device=nodes.device)
+        kind, p0, p1 = (0, 0.0, 0.0) if robust is None else robust
         with _C._on_device(nodes.device):
-            if robust is None:
-                fn = _C.library().symbol("pplie_pgo_residual" + _blocks._suffix(nodes), _PGO_SIG)
-                code = fn(nodes.data_ptr(), self.idx.data_ptr(), self.Z.data_ptr(), None, part.data_ptr(), self.E,
-                          _C.stream_ptr(nodes.device))
-            else:
-                fn = _C.library().symbol("pplie_pgo_residual_robust" + _blocks._suffix(nodes), _PGO_ROBUST_SIG)
-                code = fn(nodes.data_ptr(), self.idx.data_ptr(), self.Z.data_ptr(), None, part.data_ptr(), self.E,
-                          robust[0], robust[1], robust[2], _C.stream_ptr(nodes.device))
-        _C.check(code, "pplie_pgo_residual")
-        loss = part.sum()
+            code = _C.library().symbol("pplie_pgo_loss" + _blocks._suffix(nodes), _PGO_LOSS_SIG)(
+                nodes.data_ptr(), self.idx.data_ptr(), self.Z.data_ptr(), ws.data_ptr(), loss.data_ptr(), self.E, kind, p0, p1, stream)
+        _C.check(code, "pplie_pgo_loss")
         if group is not None:
             import torch.distributed as dist
             dist.all_reduce(loss, group=group)

@@ -110,3 +110,29 @@ def test_set_up_launch_that_finishes_the_assembly(N, E, dtype, monkeypatch):
         assert float((a - b).abs().max()) <= (2e-3 if dtype == torch.float32 else 1e-8) * float(b.abs().max()), \
             (k, float((a - b).abs().max()), float(b.abs().max()), out[True][6], out[False][6])
     assert abs(out[True][6] - out[False][6]) <= 1
+
+
+@pytest.mark.parametrize("robust", [False, True], ids=["trivial", "huber"])
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-4), (torch.float64, 1e-12)], ids=["fp32", "fp64"])
+@pytest.mark.parametrize("N,E", [(40, 41), (3000, 12_001), (40_000, 300_000)])
+def test_one_launch_loss_equals_the_models_loss(N, E, dtype, tol, robust):
+    """pplie_pgo_loss (the residual kernel whose last workgroup adds the partial sums: one launch, one device scalar) against the
+    model's own loss, sum_e rho(|r_e|^2) of the forward's residuals in fp64 (optimizer.py:118-125); twice, for the ticket's rest state."""
+    edges, rel, init = _synthetic_graph(N, E, dtype)
+    graph = PoseGraph(init.clone())
+    kw = dict(kernel=pp.optim.kernel.Huber(delta=0.05)) if robust else {}
+    opt = pp.optim.LM(graph, solver=pp.optim.solver.PCG(tol=1e-4, maxiter=250), strategy=pp.optim.strategy.TrustRegion(radius=1e4), **kw)
+    opt.step((edges, rel))
+    assert opt.linearization == "fused:pgo"
+    prog = opt._structure_cache["program"][3]
+    from pypose_amd.optim.kernel import robust_code
+    code = robust_code(opt.model.kernel[0]) if robust else None
+    for _ in range(2):
+        with torch.no_grad():
+            x = graph(edges, rel).double().square().sum(-1)
+            ref = (pp.optim.kernel.Huber(delta=0.05)(x) if robust else x).sum()
+            got = prog.loss(None, code)
+        assert got.shape == () and got.dtype == dtype
+        assert abs(float(got) - float(ref)) <= tol * abs(float(ref)), (float(got), float(ref))
+        with torch.no_grad():
+            graph.nodes.data.copy_((pp.randn_SE3(N, sigma=1e-3, dtype=dtype, device=init.device) @ init).tensor())
