@@ -84,3 +84,35 @@ def test_epilogue_tail_leaves_a_failed_solves_parameters_alone(monkeypatch):
         pass
     after = graph.nodes.detach().tensor()
     assert torch.isfinite(after).all() and torch.equal(after, before)
+
+
+def test_speculative_replay_is_undone_when_the_steps_checks_fail():
+    """fused.checked_shortcut replays the captured trial BEFORE the step's checks (PgoGraphStep.quick: storage address and re-probe rhythm
+    only).  Whatever the checks then find -- other solver settings, a weight, the parameter's storage swapped -- the step must be the
+    ordinary path's step from the parameters as the caller left them: same losses and poses as an optimizer that never captured."""
+    N, E = 3000, 12_001
+    dtype = torch.float64
+    edges, rel, init = _synthetic_graph(N, E, dtype)
+    runs = {}
+    for captured in (True, False):
+        graph = PoseGraph(init.clone())
+        opt = pp.optim.LM(graph, solver=pp.optim.solver.PCG(tol=1e-8, maxiter=250), strategy=pp.optim.strategy.TrustRegion(radius=1e4))
+        opt.graph_step = captured
+        losses = [float(opt.step((edges, rel))) for _ in range(5)]
+        assert (opt.__dict__.get('_pgo_graph_step') is not None) == captured
+        opt.solver.tol = 1e-3                                    # (the capture holds the old tolerance)
+        with torch.no_grad():
+            graph.nodes.data.copy_(init.tensor())
+        del opt.loss
+        losses += [float(opt.step((edges, rel))) for _ in range(2)]
+        w = torch.eye(6, dtype=dtype, device=init.device).mul(2.0).expand(E, 6, 6).contiguous()
+        losses += [float(opt.step((edges, rel), weight=w)) for _ in range(2)]
+        with torch.no_grad():                                    # the parameter's storage is swapped: nothing may be replayed into the old one
+            graph.nodes.data = init.tensor().clone()
+        del opt.loss
+        losses += [float(opt.step((edges, rel))) for _ in range(4)]
+        runs[captured] = (losses, graph.nodes.detach().tensor().clone(), opt.solver.iterations)
+    a, b = runs[True], runs[False]
+    for x, y in zip(a[0], b[0]):
+        assert abs(x - y) <= 1e-9 * abs(y), (a[0], b[0])
+    assert float((a[1] - b[1]).abs().max()) <= 1e-9
