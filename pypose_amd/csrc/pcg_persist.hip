@@ -724,7 +724,8 @@ constexpr int kGhostLayers = 3;
 // block-Jacobi-preconditioned spectrum, which starts at 0.06): they are what makes block-Jacobi PCG need 35 / 105 iterations in
 // the later LM steps of BASELINE's 10 k-pose graph where the rest of the spectrum needs ~20 (measured on the host in fp64:
 // 18 / 20 / 91 -> 18 / 20 / 26, and the solution's gauge component, 5e-3 of |x| with block-Jacobi at tol 1e-4, is exact).
-// Cost: 2 M more sums per exchange (Z^T q and Z^T r, per component) and one exchange before the first iteration (E and Z^T r_0).
+// Cost: M more sums per exchange (Z^T q per component; Z^T r by its recurrence from the set-up exchange's Z^T r_0 -- pcg_persist_kernel
+// still sums both, 2 M) and one exchange before the first iteration (E and Z^T r_0).
 //   rho = r.Binv r + sum_i (Z^T r)_i^2 / E_i ;   z = Binv r + Z (Z^T r / E) ;  the recurrence value of rho_{k+1} (for beta only,
 //   as before) uses Z^T r' = Z^T r - alpha Z^T q.  Any E > 0 gives an SPD preconditioner: the stop test |r| <= tol |b| is unchanged.
 
@@ -761,10 +762,14 @@ pcg_ghost_kernel(const int* __restrict__ ptr, const int* __restrict__ slot, cons
     tk[kTickSlots] = (unsigned)wall_clock64();
     tk[kTickSlots + 1] = tk[kTickSlots];                         // (the kernel's start, kept)
   }
-  constexpr int NQ = CZ ? kPersistQ + 2 * M : kPersistQ;
+  // (round 6) the exchange carries Z^T q only: Z^T r follows the recurrence Z^T r' = Z^T r - alpha Z^T q that beta already used -- every
+  // workgroup applies it to the same gathered operands in the same order, so all hold the same bits -- from the set-up exchange's
+  // Z^T r_0.  Six sums, six wave-level reductions and three of nine 64-bit words per table row less per iteration (M = 6).
+  constexpr int NQ = CZ ? kPersistQ + M : kPersistQ;
   constexpr int SLOTS = CZ ? kCoarseSlots : kPersistSlots;
-  typedef PersistShared<T, NQ> SH;
+  typedef PersistShared<T, (CZ ? kPersistQ + 2 * M : kPersistQ)> SH;             // (the set-up exchange has 2 M quantities)
   __shared__ SH sh;
+  __shared__ T zr_sh[2][CZ ? M : 1];                                  // Z^T r of the iteration (parity k & 1)
   // CZ: per-component sums over a wave's nodes go through a 64-element pad per wave (M lanes add NPW values each: two LDS round
   // trips) instead of M masked wave reductions per quantity
   __shared__ T cz_pad[CZ ? kPersistBlock : 1];
@@ -860,6 +865,7 @@ pcg_ghost_kernel(const int* __restrict__ ptr, const int* __restrict__ slot, cons
     if (threadIdx.x < M) {
       const T e = sh.total[1][threadIdx.x];
       einv[threadIdx.x] = e > T(0) ? T(1) / e : T(0);
+      zr_sh[0][threadIdx.x] = sh.total[1][M + threadIdx.x];
     }
     __syncthreads();
     const T c0 = sh.total[1][M + i] * einv[i];
@@ -922,7 +928,6 @@ pcg_ghost_kernel(const int* __restrict__ ptr, const int* __restrict__ slot, cons
     post_wave_sums<T, kPersistQ>(sh, par, v, act, false);
     if constexpr (CZ) {
       wave_comp_sums(acc, par, kPersistQ);                                                   // Z^T q
-      wave_comp_sums(re, par, kPersistQ + M);                                                // Z^T r
     }
     __syncthreads();                                                             // barrier 1
     PPLIE_TICK(1)
@@ -979,7 +984,7 @@ pcg_ghost_kernel(const int* __restrict__ ptr, const int* __restrict__ slot, cons
     T rho = rho_loc;
     if constexpr (CZ) {
 #pragma unroll
-      for (int q = 0; q < M; ++q) { const T sr = sh.total[par][kPersistQ + M + q]; rho += sr * sr * einv[q]; }
+      for (int q = 0; q < M; ++q) { const T sr = zr_sh[par][q]; rho += sr * sr * einv[q]; }
     }
     const T alpha = pq > pcg_tiny<T>() ? rho / pq : T(0);
     T rho_next = rho_loc - T(2) * alpha * qz + alpha * alpha * qmq;
@@ -987,10 +992,12 @@ pcg_ghost_kernel(const int* __restrict__ ptr, const int* __restrict__ slot, cons
     if constexpr (CZ) {
 #pragma unroll
       for (int q = 0; q < M; ++q) {
-        const T sp = sh.total[par][kPersistQ + M + q] - alpha * sh.total[par][kPersistQ + q];      // Z^T r' = Z^T r - alpha Z^T q
+        const T sp = zr_sh[par][q] - alpha * sh.total[par][kPersistQ + q];      // Z^T r' = Z^T r - alpha Z^T q
         rho_next += sp * sp * einv[q];
       }
-      cz = (sh.total[par][kPersistQ + M + i] - alpha * sh.total[par][kPersistQ + i]) * einv[i];
+      const T zri = zr_sh[par][i] - alpha * sh.total[par][kPersistQ + i];
+      cz = zri * einv[i];
+      if (threadIdx.x < M) zr_sh[par ^ 1][i] = zri;                    // (read again behind barrier 3)
     }
     if (rho_next < T(0)) rho_next = T(0);
     const T beta = rho > pcg_tiny<T>() ? rho_next / rho : T(0);
