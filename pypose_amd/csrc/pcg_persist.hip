@@ -819,6 +819,19 @@ pcg_ghost_kernel(const int* __restrict__ ptr, const int* __restrict__ slot, cons
       gp[l] = z[(size_t)gnode[l] * M + i];                         // p_0 = z_0
     }
   }
+  // WAVE-UNIFORM activity (round 6): with 39 owned nodes of 160 positions only waves 0..3 of 16 hold owned elements, and the last ghost
+  // layer is usually empty -- but the iteration below is issue-bound (4 waves per SIMD share its VALU slots), and branch-free code
+  // runs the reductions, the 6-lane shuffles and the updates of all of them.  A wave without a single active lane in a layer skips
+  // that layer's work on a scalar branch; its partial sums stay the zeros written here.
+  const int ws = __builtin_amdgcn_readfirstlane(w);
+  const bool wact = ws * NPW < n_own;
+  bool wgl[kGhostLayers];
+#pragma unroll
+  for (int l = 0; l < kGhostLayers; ++l) wgl[l] = l * POS + ws * NPW < n_ghost;
+  if (!wact && lane < (int)(sizeof(sh.wave_part[0]) / sizeof(sh.wave_part[0][0]))) {
+    sh.wave_part[0][lane][w] = T(0);
+    sh.wave_part[1][lane][w] = T(0);
+  }
   // ---- LDS: [ p of the local nodes (owned, then ghost layers) | staged blocks, row-major | y = H_c p per incidence | local slots ]
   constexpr size_t kPBytes = (size_t)(1 + kGhostLayers) * POS * M * sizeof(T);
   T* p_l = reinterpret_cast<T*>(dyn_lds);
@@ -921,13 +934,15 @@ pcg_ghost_kernel(const int* __restrict__ ptr, const int* __restrict__ slot, cons
     }
     if (act) put_value<T>(qtag + (size_t)par * NM + (size_t)(n * M + i) * NW, acc, tag);      // q of the owned nodes, for their readers
     PPLIE_TICK(0)
-    T bq = T(0);
+    if (wact) {
+      T bq = T(0);
 #pragma unroll
-    for (int j = 0; j < M; ++j) bq += br[j] * __shfl(acc, sub * M + j, 64);
-    T v[kPersistQ] = {acc * pe, acc * ze, acc * bq, re * ze, re * re};                       // (ze: the LOCAL part Binv r of z)
-    post_wave_sums<T, kPersistQ>(sh, par, v, act, false);
-    if constexpr (CZ) {
-      wave_comp_sums(acc, par, kPersistQ);                                                   // Z^T q
+      for (int j = 0; j < M; ++j) bq += br[j] * __shfl(acc, sub * M + j, 64);
+      T v[kPersistQ] = {acc * pe, acc * ze, acc * bq, re * ze, re * re};                     // (ze: the LOCAL part Binv r of z)
+      post_wave_sums<T, kPersistQ>(sh, par, v, act, false);
+      if constexpr (CZ) {
+        wave_comp_sums(acc, par, kPersistQ);                                                 // Z^T q
+      }
     }
     __syncthreads();                                                             // barrier 1
     PPLIE_TICK(1)
@@ -941,7 +956,7 @@ pcg_ghost_kernel(const int* __restrict__ ptr, const int* __restrict__ slot, cons
 #pragma unroll
     for (int l = 0; l < kGhostLayers; ++l)
 #pragma unroll
-      for (int kk = 0; kk < NW; ++kk) gw[l][kk] = xwg_load(qt + (gnode[l] * M + i0) * NW + kk);
+      for (int kk = 0; kk < NW; ++kk) gw[l][kk] = wgl[l] ? xwg_load(qt + (gnode[l] * M + i0) * NW + kk) : 0ull;
     if constexpr (CZ) exchange_two_level<T, NQ, SH, SLOTS>(sh, par, part, tag, (k >> 1) + par, clocked);   // (table 1's use 0 was the set-up exchange)
     else gather_rows<T, NQ, SH, SLOTS>(sh, par, part, tag);
     PPLIE_TICK(2)
@@ -958,7 +973,8 @@ pcg_ghost_kernel(const int* __restrict__ ptr, const int* __restrict__ slot, cons
 #pragma unroll
       for (int l = 0; l < kGhostLayers; ++l)
 #pragma unroll
-        for (int kk = 0; kk < NW; ++kk) gw[l][kk] = xwg_load(qt + (gnode[l] * M + i0) * NW + kk);
+        for (int kk = 0; kk < NW; ++kk)
+          if (wgl[l]) gw[l][kk] = xwg_load(qt + (gnode[l] * M + i0) * NW + kk);
     }
     T gq[kGhostLayers];
 #pragma unroll
@@ -1002,24 +1018,26 @@ pcg_ghost_kernel(const int* __restrict__ ptr, const int* __restrict__ slot, cons
     if (rho_next < T(0)) rho_next = T(0);
     const T beta = rho > pcg_tiny<T>() ? rho_next / rho : T(0);
     // ---- the same update for the owned element and for the ghosts (identical operands, order and contraction: identical bits)
-    xe += alpha * pe;
-    re -= alpha * acc;
-    {
+    if (wact) {
+      xe += alpha * pe;
+      re -= alpha * acc;
       T zn = T(0);
 #pragma unroll
       for (int j = 0; j < M; ++j) zn += br[j] * __shfl(re, sub * M + j, 64);
       ze = zn;
       pe = (CZ ? ze + cz : ze) + beta * pe;
+      if (act) p_l[pos * M + i] = pe;
     }
-    if (act) p_l[pos * M + i] = pe;
 #pragma unroll
     for (int l = 0; l < kGhostLayers; ++l) {
-      gr[l] -= alpha * gq[l];
-      T zn = T(0);
+      if (wgl[l]) {
+        gr[l] -= alpha * gq[l];
+        T zn = T(0);
 #pragma unroll
-      for (int j = 0; j < M; ++j) zn += gbr[l][j] * __shfl(gr[l], sub * M + j, 64);
-      gp[l] = (CZ ? zn + cz : zn) + beta * gp[l];
-      if (gact[l]) p_l[(n_own + l * POS + pos) * M + i] = gp[l];
+        for (int j = 0; j < M; ++j) zn += gbr[l][j] * __shfl(gr[l], sub * M + j, 64);
+        gp[l] = (CZ ? zn + cz : zn) + beta * gp[l];
+        if (gact[l]) p_l[(n_own + l * POS + pos) * M + i] = gp[l];
+      }
     }
     __syncthreads();                                                             // barrier 3: every local p is in place
     PPLIE_TICK(4)
