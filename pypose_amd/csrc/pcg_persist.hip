@@ -842,9 +842,21 @@ pcg_ghost_kernel(const int* __restrict__ ptr, const int* __restrict__ slot, cons
   int* sl_l = reinterpret_cast<int*>(yb + (size_t)c_all * M);
   {                                                                // (host guarantees the slice fits: see pcg_ghost())
     const T* src = HB + (size_t)c_lo * M * M;
-    for (int e = threadIdx.x; e < c_cnt * M * M; e += kPersistBlock) hb_l[e] = src[e];
     const T* dsrc = D + (size_t)n0 * M * M;
-    for (int e = threadIdx.x; e < n_own * M * M; e += kPersistBlock) hb_l[(size_t)c_cnt * M * M + e] = dsrc[e];
+    constexpr int VE = 16 / sizeof(T);                             // elements of a 16-byte word
+    if constexpr ((M * M) % VE == 0) {
+      // (blocks are M * M * sizeof(T) = a multiple of 16 bytes from 16-byte aligned bases: a quarter of the copy's instructions)
+      typedef T V16 __attribute__((ext_vector_type(VE)));
+      const V16* s4 = reinterpret_cast<const V16*>(src);
+      V16* d4 = reinterpret_cast<V16*>(hb_l);
+      for (int e = threadIdx.x; e < c_cnt * (M * M / VE); e += kPersistBlock) d4[e] = s4[e];
+      const V16* sd4 = reinterpret_cast<const V16*>(dsrc);
+      V16* dd4 = reinterpret_cast<V16*>(hb_l + (size_t)c_cnt * M * M);
+      for (int e = threadIdx.x; e < n_own * (M * M / VE); e += kPersistBlock) dd4[e] = sd4[e];
+    } else {
+      for (int e = threadIdx.x; e < c_cnt * M * M; e += kPersistBlock) hb_l[e] = src[e];
+      for (int e = threadIdx.x; e < n_own * M * M; e += kPersistBlock) hb_l[(size_t)c_cnt * M * M + e] = dsrc[e];
+    }
     for (int e = threadIdx.x; e < c_cnt; e += kPersistBlock) sl_l[e] = slot[c_lo + e];
     for (int e = threadIdx.x; e < n_own; e += kPersistBlock) sl_l[c_cnt + e] = e;
   }
