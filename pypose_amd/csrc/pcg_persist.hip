@@ -354,6 +354,38 @@ __device__ __forceinline__ void gather_pairs(SH& sh, int par, const u64* part, u
   }
 }
 
+// The second level of the two-level exchange by ONE wavefront (round 6): lane (g, word) = (lane / 8, lane % 8) fetches one word of group
+// g's row -- G <= 8 rows of NP <= 8 words, one load instruction instead of one per word-wave -- and three shuffle steps add the groups
+// (a fixed tree: the same bits in every workgroup).  The wave then holds every total and can go on to the iteration's scalars without a
+// workgroup barrier in between (pcg_ghost_kernel: alpha, beta and the coarse part of z, which sixteen waves otherwise each work out).
+template <int NQ, class SH, int SLOTS>
+__device__ __forceinline__ void gather_groups_one_wave(SH& sh, int par, const u64* part, unsigned t2, int G, int rows_per_table) {
+  constexpr int NP = (NQ + 1) / 2;
+  static_assert(NP <= 8 && kPersistGridMax % 8 == 0, "lane = group * 8 + word");
+  const int lane = threadIdx.x & 63;
+  if ((threadIdx.x >> 6) == 0) {
+    const int g = lane >> 3, wq = lane & 7;
+    const u64* tab = part + (size_t)par * rows_per_table * pair_pitch<SLOTS>();
+    float a = 0.f, b = 0.f;
+    bool done = !(g < G && wq < NP);
+    for (long spin = 0; spin < (1L << 20); ++spin) {
+      if (!done) {
+        float x, y;
+        if (unpack_pair(xwg_load(tab + pair_at<SLOTS>(kPersistGridMax + g, wq)), t2, x, y)) { a = x; b = y; done = true; }
+      }
+      if (__all(done)) break;
+      __builtin_amdgcn_s_sleep(1);
+    }
+#pragma unroll
+    for (int off = 8; off < 64; off <<= 1) { a += __shfl_xor(a, off, 64); b += __shfl_xor(b, off, 64); }
+    if (lane < NP) {
+      sh.total[par][2 * lane] = a;
+      if (2 * lane + 1 < NQ) sh.total[par][2 * lane + 1] = b;
+    }
+    if (!__all(done) && lane == 0) sh.bad[par] = 1;
+  }
+}
+
 // TWO-LEVEL all-gather (the wide exchange of the two-level preconditioner: 5 + 2 M quantities).  Every workgroup polling every
 // workgroup's row is grid x grid x NQ tagged loads per iteration -- all of them served by the memory side, the L2s of the eight
 // XCDs are not coherent with each other: measured 7.4 us per exchange with 17 quantities at 256 workgroups against 3.1 us with 5.
@@ -365,7 +397,7 @@ constexpr int kHierGroups = 8;
 constexpr int kHierMinGrid = 224;        // grids from here on exchange in two levels
 constexpr int kHierRows = kPersistGridMax + kHierGroups;
 static_assert(kHierRows == kPairRows, "pair tables: kPairRows rows");
-template <class T, int NQ, class SH, int SLOTS>
+template <class T, int NQ, class SH, int SLOTS, bool ONEWAVE = false>
 __device__ __forceinline__ void exchange_two_level(SH& sh, int par, u64* part, unsigned tag, int use, bool clocked = false) {
   constexpr int NW = sizeof(T) / 4, RW = SLOTS * NW, WV = kPersistBlock / 64;
   const int G = (int)gridDim.x < kHierGroups ? (int)gridDim.x : kHierGroups;
@@ -397,7 +429,8 @@ __device__ __forceinline__ void exchange_two_level(SH& sh, int par, u64* part, u
       __syncthreads();
       tick(clocked, 6);
     }
-    gather_pairs<NQ, SH, SLOTS>(sh, par, part, t2, kPersistGridMax, 1, G, kHierRows);
+    if constexpr (ONEWAVE) gather_groups_one_wave<NQ, SH, SLOTS>(sh, par, part, t2, G, kHierRows);
+    else gather_pairs<NQ, SH, SLOTS>(sh, par, part, t2, kPersistGridMax, 1, G, kHierRows);
     tick(clocked, 7);
     return;
   }
@@ -770,6 +803,11 @@ pcg_ghost_kernel(const int* __restrict__ ptr, const int* __restrict__ slot, cons
   typedef PersistShared<T, (CZ ? kPersistQ + 2 * M : kPersistQ)> SH;             // (the set-up exchange has 2 M quantities)
   __shared__ SH sh;
   __shared__ T zr_sh[2][CZ ? M : 1];                                  // Z^T r of the iteration (parity k & 1)
+  // the iteration's scalars worked out ONCE, by the wave that gathers the second level of the exchange (fp32 two-level grids): what was
+  // ~27 LDS reads and ~70 VALU instructions in each of the 16 waves of an issue-bound iteration is three reads behind barrier 2
+  constexpr bool ONCE = CZ && sizeof(T) == 4;
+  __shared__ T ab_sh[2][2], czv_sh[2][CZ ? M : 1];
+  const bool hier = ONCE && (int)gridDim.x >= kHierMinGrid;
   // CZ: per-component sums over a wave's nodes go through a 64-element pad per wave (M lanes add NPW values each: two LDS round
   // trips) instead of M masked wave reductions per quantity
   __shared__ T cz_pad[CZ ? kPersistBlock : 1];
@@ -969,7 +1007,36 @@ pcg_ghost_kernel(const int* __restrict__ ptr, const int* __restrict__ slot, cons
     for (int l = 0; l < kGhostLayers; ++l)
 #pragma unroll
       for (int kk = 0; kk < NW; ++kk) gw[l][kk] = wgl[l] ? xwg_load(qt + (gnode[l] * M + i0) * NW + kk) : 0ull;
-    if constexpr (CZ) exchange_two_level<T, NQ, SH, SLOTS>(sh, par, part, tag, (k >> 1) + par, clocked);   // (table 1's use 0 was the set-up exchange)
+    if constexpr (CZ) {
+      exchange_two_level<T, NQ, SH, SLOTS, ONCE>(sh, par, part, tag, (k >> 1) + par, clocked);   // (table 1's use 0 was the set-up exchange)
+      if constexpr (ONCE) {
+        if (hier && w == 0) {
+          // (wave 0 has just stored the totals itself: a wave's LDS accesses execute in order, no barrier between the stores and these reads)
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          const T pq1 = sh.total[par][0], qz1 = sh.total[par][1], qmq1 = sh.total[par][2], rho_loc1 = sh.total[par][3];
+          T rho1 = rho_loc1;
+#pragma unroll
+          for (int q = 0; q < M; ++q) { const T sr = zr_sh[par][q]; rho1 += sr * sr * einv[q]; }
+          const T alpha1 = pq1 > pcg_tiny<T>() ? rho1 / pq1 : T(0);
+          T rho_next1 = rho_loc1 - T(2) * alpha1 * qz1 + alpha1 * alpha1 * qmq1;
+#pragma unroll
+          for (int q = 0; q < M; ++q) {
+            const T sp = zr_sh[par][q] - alpha1 * sh.total[par][kPersistQ + q];
+            rho_next1 += sp * sp * einv[q];
+          }
+          if (rho_next1 < T(0)) rho_next1 = T(0);
+          const T beta1 = rho1 > pcg_tiny<T>() ? rho_next1 / rho1 : T(0);
+          if (lane == 0) { ab_sh[par][0] = alpha1; ab_sh[par][1] = beta1; }
+          if (lane < M) {
+            const T zri = zr_sh[par][lane] - alpha1 * sh.total[par][kPersistQ + lane];
+            czv_sh[par][lane] = zri * einv[lane];
+            zr_sh[par ^ 1][lane] = zri;                            // (read behind barrier 3)
+          }
+        }
+      }
+    }
     else gather_rows<T, NQ, SH, SLOTS>(sh, par, part, tag);
     PPLIE_TICK(2)
     bool stale = false;
@@ -1001,7 +1068,6 @@ pcg_ghost_kernel(const int* __restrict__ ptr, const int* __restrict__ slot, cons
     if (stale) sh.bad[par] = 1;
     __syncthreads();                                                             // barrier 2
     PPLIE_TICK(3)
-    const T pq = sh.total[par][0], qz = sh.total[par][1], qmq = sh.total[par][2], rho_loc = sh.total[par][3];
     rr = sh.total[par][4];
     if (sh.bad[par]) { flag = 3; break; }
     if (k == 0) bn2 = rr;
@@ -1009,26 +1075,33 @@ pcg_ghost_kernel(const int* __restrict__ ptr, const int* __restrict__ slot, cons
     if (!(rr == rr)) { flag = 2; break; }
     if (rr <= tol2 * bn2) { flag = 1; break; }
     if (k >= maxiter) break;
-    T rho = rho_loc;
-    if constexpr (CZ) {
+    T alpha, beta, cz = T(0);                                          // cz: this component's coarse part of the new z
+    if (hier) {
+      alpha = ab_sh[par][0];
+      beta = ab_sh[par][1];
+      cz = czv_sh[par][CZ ? i : 0];
+    } else {
+      const T pq = sh.total[par][0], qz = sh.total[par][1], qmq = sh.total[par][2], rho_loc = sh.total[par][3];
+      T rho = rho_loc;
+      if constexpr (CZ) {
 #pragma unroll
-      for (int q = 0; q < M; ++q) { const T sr = zr_sh[par][q]; rho += sr * sr * einv[q]; }
-    }
-    const T alpha = pq > pcg_tiny<T>() ? rho / pq : T(0);
-    T rho_next = rho_loc - T(2) * alpha * qz + alpha * alpha * qmq;
-    T cz = T(0);                                                       // this component's coarse part of the new z
-    if constexpr (CZ) {
-#pragma unroll
-      for (int q = 0; q < M; ++q) {
-        const T sp = zr_sh[par][q] - alpha * sh.total[par][kPersistQ + q];      // Z^T r' = Z^T r - alpha Z^T q
-        rho_next += sp * sp * einv[q];
+        for (int q = 0; q < M; ++q) { const T sr = zr_sh[par][q]; rho += sr * sr * einv[q]; }
       }
-      const T zri = zr_sh[par][i] - alpha * sh.total[par][kPersistQ + i];
-      cz = zri * einv[i];
-      if (threadIdx.x < M) zr_sh[par ^ 1][i] = zri;                    // (read again behind barrier 3)
+      alpha = pq > pcg_tiny<T>() ? rho / pq : T(0);
+      T rho_next = rho_loc - T(2) * alpha * qz + alpha * alpha * qmq;
+      if constexpr (CZ) {
+#pragma unroll
+        for (int q = 0; q < M; ++q) {
+          const T sp = zr_sh[par][q] - alpha * sh.total[par][kPersistQ + q];      // Z^T r' = Z^T r - alpha Z^T q
+          rho_next += sp * sp * einv[q];
+        }
+        const T zri = zr_sh[par][i] - alpha * sh.total[par][kPersistQ + i];
+        cz = zri * einv[i];
+        if (threadIdx.x < M) zr_sh[par ^ 1][i] = zri;                    // (read again behind barrier 3)
+      }
+      if (rho_next < T(0)) rho_next = T(0);
+      beta = rho > pcg_tiny<T>() ? rho_next / rho : T(0);
     }
-    if (rho_next < T(0)) rho_next = T(0);
-    const T beta = rho > pcg_tiny<T>() ? rho_next / rho : T(0);
     // ---- the same update for the owned element and for the ghosts (identical operands, order and contraction: identical bits)
     if (wact) {
       xe += alpha * pe;
