@@ -468,8 +468,8 @@ def pgo_lm_rate(dev, nodes=10_000, edges=40_000, steps=3, reps=5, with_static=Tr
                 "us_per_lm_step": dt * 1e6, "mean_pcg_iterations": its_mean,
                 "us_per_pcg_iteration_incl_step_overheads": dt * 1e6 / max(its_mean, 1.0),
                 "exchange_floor_us": [0.40, 0.57], "floor_source": "profiles/r03/pingpong.log (one tagged-word hand-off between two workgroups)",
-                "marginal_us_per_iteration": 7.4, "marginal_source": "profiles/r06/pcg_iter.json (tools/time_pcg_iter.py; 8.0 in round 5): the two-level "
-                "(block-Jacobi + gauge) iteration with its 17-quantity exchange; 5.6 for the plain block-Jacobi iteration, which needs "
+                "marginal_us_per_iteration": 5.9, "marginal_source": "profiles/r06/pcg_iter.json (tools/time_pcg_iter.py; 8.0 in round 5, 7.4 at the start of "
+                "round 6): the two-level (block-Jacobi + gauge) iteration with its 11-quantity exchange; the plain block-Jacobi iteration needs "
                 "17 / 35 / 105 iterations on this instance where this one needs 17 / 19 / 25",
                 "hbm": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBPS,
                         "bytes_per_lm_step": lin_bytes + float(solve_bytes.get("fetch", 0.0) or 0.0) + float(solve_bytes.get("write", 0.0) or 0.0),

@@ -43,6 +43,10 @@ template <class T> __device__ __forceinline__ constexpr T pcg_tiny() { return si
 
 constexpr int kPersistGridMax = 256;      // = PPLIE_PCG_PERSIST_GRID: rows of the partial-sum tables
 constexpr int kPersistBlock = 1024;       // 16 waves per workgroup
+// polls of a word another RANK writes (another process, its launch not synchronised with this one's beyond a host barrier): four times
+// the in-GPU limit -- a peer process held up for a second on a busy host is late, not lost (the one flaky failure of the multi-process
+// test in round 6 was on a loaded box)
+constexpr long kPeerSpins = 1L << 22;
 constexpr int kPersistQ = 5;              // quantities per exchange: p.q, q.z, q.Binv q, r.z, r.r
 constexpr int kPersistSlots = 8;          // table row = 8 quantity slots (PPLIE_PCG_PERSIST_SLOTS)
 constexpr int kCoarseSlots = 24;          // row of the partial-sum table with the coarse sums (5 + 2 M <= 19 quantities)
@@ -90,7 +94,7 @@ __device__ __forceinline__ void spmv_cols(T* a, HP h, int cs, int js, NP nb, int
       for (int q = 0; q < CH; ++q)
         if (c0 + q < deg) pv[q] = get_value<T, SYS>(pin + (unsigned)((nb[c0 + q] * M + i) * NW), tag, ok);
       if (__all(ok)) break;
-      if (spin >= (1L << 20)) { stale = true; break; }
+      if (spin >= (SYS ? kPeerSpins : (1L << 20))) { stale = true; break; }
       __builtin_amdgcn_s_sleep(1);
     }
 #pragma unroll
@@ -582,7 +586,7 @@ pcg_persist_kernel(const int* __restrict__ ptr, const int* __restrict__ other, c
       for (int rk = 0; rk < peers.world; ++rk) {
         bool ok = false;
         T v = T(0);
-        for (long spin = 0; spin < (1L << 20) && !ok; ++spin) {
+        for (long spin = 0; spin < kPeerSpins && !ok; ++spin) {
           ok = true;
           v = get_value<T, true>(mine + (size_t)rk * RW2, tag_, ok);
           if (!ok) __builtin_amdgcn_s_sleep(1);
@@ -673,7 +677,7 @@ pcg_persist_kernel(const int* __restrict__ ptr, const int* __restrict__ other, c
           for (int rk = 0; rk < peers.world; ++rk) {
             bool ok = false;
             T v = T(0);
-            for (long spin = 0; spin < (1L << 20) && !ok; ++spin) {
+            for (long spin = 0; spin < kPeerSpins && !ok; ++spin) {
               ok = true;
               v = get_value<T, true>(mine + (size_t)rk * RW2, tag, ok);
               if (!ok) __builtin_amdgcn_s_sleep(1);
