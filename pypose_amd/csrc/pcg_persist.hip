@@ -825,6 +825,7 @@ pcg_ghost_kernel(const int* __restrict__ ptr, const int* __restrict__ slot, cons
   const bool act = sub < NPW && pos < n_own;
   const size_t NM = (size_t)N * M * NW;
   const int g_lo = gptr[blockIdx.x], n_ghost = gptr[blockIdx.x + 1] - g_lo;
+  const int c_lo = ptr[n0], c_cnt = ptr[n1] - c_lo;                // the slice's incidences
 
   // ---- owned element
   // (the node's row of D is not kept in registers: the owned nodes' diagonal blocks are staged behind the off-diagonal slice as one
@@ -847,6 +848,9 @@ pcg_ghost_kernel(const int* __restrict__ ptr, const int* __restrict__ slot, cons
   T gbr[kGhostLayers][M], gr[kGhostLayers], gp[kGhostLayers];
   int gnode[kGhostLayers];
   bool gact[kGhostLayers];
+  // (the set-up's loads in LEVELS of dependency, issued level by level: [gptr, ptr of the slice and of the node, the owned rows] ->
+  //  [the ghosts' ids, the block slice into LDS] -> [the ghosts' rows].  In program order -- owned, ghost ids, ghost rows, THEN the slice's
+  //  bounds and blocks -- four dependent memory latencies followed each other: 6.8 us before the set-up exchange, tools/time_pcg_iter.py)
 #pragma unroll
   for (int l = 0; l < kGhostLayers; ++l) {
     const int gi = l * POS + pos;
@@ -854,12 +858,6 @@ pcg_ghost_kernel(const int* __restrict__ ptr, const int* __restrict__ slot, cons
     gnode[l] = gact[l] ? gids[g_lo + gi] : 0;
     gr[l] = T(0);
     gp[l] = T(0);
-#pragma unroll
-    for (int j = 0; j < M; ++j) gbr[l][j] = gact[l] ? Binv[((size_t)gnode[l] * M + i) * M + j] : T(0);
-    if (gact[l]) {
-      gr[l] = r[(size_t)gnode[l] * M + i];
-      gp[l] = z[(size_t)gnode[l] * M + i];                         // p_0 = z_0
-    }
   }
   // WAVE-UNIFORM activity (round 6): with 39 owned nodes of 160 positions only waves 0..3 of 16 hold owned elements, and the last ghost
   // layer is usually empty -- but the iteration below is issue-bound (4 waves per SIMD share its VALU slots), and branch-free code
@@ -877,7 +875,6 @@ pcg_ghost_kernel(const int* __restrict__ ptr, const int* __restrict__ slot, cons
   // ---- LDS: [ p of the local nodes (owned, then ghost layers) | staged blocks, row-major | y = H_c p per incidence | local slots ]
   constexpr size_t kPBytes = (size_t)(1 + kGhostLayers) * POS * M * sizeof(T);
   T* p_l = reinterpret_cast<T*>(dyn_lds);
-  const int c_lo = ptr[n0], c_cnt = ptr[n1] - c_lo;
   const int c_all = c_cnt + n_own;                                 // staged blocks: the slice's incidences, then the owned nodes' D
   T* hb_l = reinterpret_cast<T*>(dyn_lds + kPBytes);
   T* yb = hb_l + (size_t)c_all * M * M;
@@ -901,6 +898,15 @@ pcg_ghost_kernel(const int* __restrict__ ptr, const int* __restrict__ slot, cons
     }
     for (int e = threadIdx.x; e < c_cnt; e += kPersistBlock) sl_l[e] = slot[c_lo + e];
     for (int e = threadIdx.x; e < n_own; e += kPersistBlock) sl_l[c_cnt + e] = e;
+  }
+#pragma unroll
+  for (int l = 0; l < kGhostLayers; ++l) {
+#pragma unroll
+    for (int j = 0; j < M; ++j) gbr[l][j] = gact[l] ? Binv[((size_t)gnode[l] * M + i) * M + j] : T(0);
+    if (gact[l]) {
+      gr[l] = r[(size_t)gnode[l] * M + i];
+      gp[l] = z[(size_t)gnode[l] * M + i];                         // p_0 = z_0
+    }
   }
   if (threadIdx.x == 0) { sh.bad[0] = 0; sh.bad[1] = 0; }
   tick(clocked, 9);                                            // slot 9: registers loaded, block slice staged (issued)
