@@ -32,7 +32,8 @@ for f in ("sq_imu", "sq_imu_train", "sq_lm_invnet", "sq_scan_bwd"):
         for pat, short in SHORT.items():
             if pat in name and (short not in sq or v.get("launches", 0) > sq[short].get("launches", 0)):
                 sq[short] = {k: (round(x, 1) if isinstance(x, float) else x) for k, x in v.items()}
-json.dump(sq, open(os.path.join(ROOT, "profiles", "pmc_sq.json"), "w"), indent=1)
+if len(sq) > 2:            # (a visit without SQ passes keeps the file of the last visit that had them -- its stamp says which)
+    json.dump(sq, open(os.path.join(ROOT, "profiles", "pmc_sq.json"), "w"), indent=1)
 
 raw = json.load(open(os.path.join(src, "pmc_raw.json")))
 tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")
